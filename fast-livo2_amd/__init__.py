@@ -1,0 +1,195 @@
+"""fast-livo2_amd — MI355X (gfx950) ESIKF measurement update of FAST-LIVO2 behind a C ABI.
+
+The product is `lib/liblivo2_hip.so` (sources in `csrc/`, ABI in `../include/livo2_hip.h`) plus the C++ host shim in
+`host/` that mirrors `VoxelMapManager::StateEstimation` / `VIOManager::computeJacobianAndUpdateEKF`.
+This Python package is a thin numpy/ctypes convenience layer over that ABI used by tests/, bench.py and smoke();
+import it with `importlib.import_module("fast-livo2_amd")` (the directory name is not a Python identifier).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
+
+
+class Livo2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"livo2 error {code}: {msg}")
+        self.code = code
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """One GPU + one HIP stream (livo2_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = abi.load_library()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self.lib.livo2_ctx_create(int(device), C.byref(h))
+        else:
+            rc = self.lib.livo2_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
+        if rc != abi.OK:
+            raise Livo2Error(rc, "livo2_ctx_create failed (no gfx950 device / HIP runtime?)")
+        self.h = h
+        self._keep = {}
+        self.n = 0
+        self.M = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.livo2_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != abi.OK:
+            raise Livo2Error(rc, self.lib.livo2_last_error(self.h).decode())
+
+    def synchronize(self):
+        self._chk(self.lib.livo2_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.livo2_ctx_stream(self.h)
+
+    def kernel_timing(self, enable):
+        self._chk(self.lib.livo2_ctx_kernel_timing(self.h, 1 if enable else 0))
+
+    def kernel_timing_read(self, which, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self.lib.livo2_ctx_kernel_timing_read(self.h, which, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    # ---- map -------------------------------------------------------------------------------------------------
+    def upload_map(self, fm):
+        """fm: object with the flat-map arrays (scenarios.FlatMap)."""
+        arrs = dict(
+            root_key=np.ascontiguousarray(fm.root_key, np.int64), root_node=np.ascontiguousarray(fm.root_node, np.int32),
+            root_center=_f64(fm.root_center), root_quarter=np.ascontiguousarray(fm.root_quarter, np.float32),
+            node_plane=np.ascontiguousarray(fm.node_plane, np.int32), node_child=np.ascontiguousarray(fm.node_child, np.int32),
+            plane_normal=_f64(fm.plane_normal), plane_center=_f64(fm.plane_center), plane_var=_f64(fm.plane_var),
+            plane_d=np.ascontiguousarray(fm.plane_d, np.float32), plane_radius=np.ascontiguousarray(fm.plane_radius, np.float32))
+        mv = MapView()
+        mv.n_roots, mv.n_nodes, mv.n_planes = len(arrs["root_node"]), len(arrs["node_plane"]), len(arrs["plane_d"])
+        mv.root_key = abi.as_ptr(arrs["root_key"], C.c_int64)
+        mv.root_node = abi.as_ptr(arrs["root_node"], C.c_int32)
+        mv.root_center = abi.as_ptr(arrs["root_center"], C.c_double)
+        mv.root_quarter = abi.as_ptr(arrs["root_quarter"], C.c_float)
+        mv.node_plane = abi.as_ptr(arrs["node_plane"], C.c_int32)
+        mv.node_child = abi.as_ptr(arrs["node_child"], C.c_int32)
+        mv.plane_normal = abi.as_ptr(arrs["plane_normal"], C.c_double)
+        mv.plane_center = abi.as_ptr(arrs["plane_center"], C.c_double)
+        mv.plane_var = abi.as_ptr(arrs["plane_var"], C.c_double)
+        mv.plane_d = abi.as_ptr(arrs["plane_d"], C.c_float)
+        mv.plane_radius = abi.as_ptr(arrs["plane_radius"], C.c_float)
+        self._chk(self.lib.livo2_map_upload(self.h, C.byref(mv)))
+
+    def update_planes(self, idx, normal, center, plane_var, d, radius):
+        idx = np.ascontiguousarray(idx, np.int32)
+        normal, center, plane_var = _f64(normal), _f64(center), _f64(plane_var)
+        d, radius = np.ascontiguousarray(d, np.float32), np.ascontiguousarray(radius, np.float32)
+        self._chk(self.lib.livo2_map_update_planes(self.h, abi.as_ptr(idx, C.c_int32), len(idx), abi.as_ptr(normal, C.c_double),
+                                                   abi.as_ptr(center, C.c_double), abi.as_ptr(plane_var, C.c_double), abi.as_ptr(d, C.c_float),
+                                                   abi.as_ptr(radius, C.c_float)))
+
+    # ---- LiDAR -----------------------------------------------------------------------------------------------
+    def set_scan(self, xyz, cfg):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        self.n = len(xyz)
+        self._chk(self.lib.livo2_lidar_set_scan(self.h, abi.as_ptr(xyz, C.c_float), self.n, C.byref(cfg)))
+
+    _POINT_FIELDS = {"match_plane": (np.int32, 1), "dis_to_plane": (np.float32, 1), "point_w": (np.float32, 3), "normal_plane": (np.int32, 1),
+                     "var": (np.float64, 9), "body_cov": (np.float64, 9), "r_inv": (np.float64, 1), "h_row": (np.float64, 6)}
+
+    def _points(self, want):
+        if not want:
+            return None, {}
+        pts, out = LidarPoints(), {}
+        for name in want:
+            dt, w = self._POINT_FIELDS[name]
+            arr = np.zeros((self.n, w) if w > 1 else (self.n,), dt)
+            out[name] = arr
+            ct = {np.int32: C.c_int32, np.float32: C.c_float, np.float64: C.c_double}[dt]
+            setattr(pts, name, abi.as_ptr(arr, ct))
+        return pts, out
+
+    def lidar_iterate(self, cur, prop, cfg, want=()):
+        sums = LidarSums()
+        pts, out = self._points(want)
+        self._chk(self.lib.livo2_lidar_iterate(self.h, C.byref(cur), C.byref(prop), C.byref(cfg), C.byref(sums), C.byref(pts) if pts else None))
+        return sums, out
+
+    def lidar_update(self, state_in, prop, cfg, want=()):
+        res = LidarResult()
+        pts, out = self._points(want)
+        self._chk(self.lib.livo2_lidar_update(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), C.byref(res), C.byref(pts) if pts else None))
+        return res, out
+
+    def lidar_update_async(self, state_in, prop, cfg):
+        self._chk(self.lib.livo2_lidar_update_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), None))
+
+    def lidar_update_fetch(self):
+        res = LidarResult()
+        self._chk(self.lib.livo2_lidar_update_fetch(self.h, C.byref(res), None))
+        return res
+
+    def lidar_iterations_async(self, state_in, prop, cfg, iters):
+        self._chk(self.lib.livo2_lidar_iterations_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
+
+    # ---- visual ----------------------------------------------------------------------------------------------
+    def set_frame(self, img, pos, warp_patch, search_levels, inv_expo_list):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        pos = _f64(pos).reshape(-1, 3)
+        M = len(pos)
+        warp_patch = np.ascontiguousarray(warp_patch, np.float32).reshape(M, -1, 64) if M else np.zeros((0, 1, 64), np.float32)
+        L = warp_patch.shape[1]
+        search_levels = np.ascontiguousarray(search_levels, np.int32)
+        inv_expo_list = _f64(inv_expo_list)
+        self.M, self.L = M, L
+        self._chk(self.lib.livo2_visual_set_frame(self.h, abi.as_ptr(img, C.c_uint8), w, h, w, abi.as_ptr(pos, C.c_double), abi.as_ptr(warp_patch, C.c_float),
+                                                  abi.as_ptr(search_levels, C.c_int32), abi.as_ptr(inv_expo_list, C.c_double), M, L))
+
+    def visual_iterate(self, level, cur, cfg, rows=False):
+        sums = VisualSums()
+        errors = np.zeros(self.M, np.float32)
+        z = np.zeros(self.M * 64, np.float64) if rows else None
+        H = np.zeros((self.M * 64, 7), np.float64) if rows else None
+        self._chk(self.lib.livo2_visual_iterate(self.h, int(level), C.byref(cur), C.byref(cfg), C.byref(sums), abi.as_ptr(errors, C.c_float),
+                                                abi.as_ptr(z, C.c_double) if rows else None, abi.as_ptr(H, C.c_double) if rows else None))
+        return sums, errors, z, H
+
+    def visual_update(self, state_in, prop, cfg):
+        res = VisualResult()
+        errors = np.zeros(self.M, np.float32)
+        self._chk(self.lib.livo2_visual_update(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), C.byref(res), abi.as_ptr(errors, C.c_float)))
+        return res, errors
+
+    def visual_update_async(self, state_in, prop, cfg):
+        self._chk(self.lib.livo2_visual_update_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg)))
+
+    def visual_update_fetch(self):
+        res = VisualResult()
+        self._chk(self.lib.livo2_visual_update_fetch(self.h, C.byref(res), None))
+        return res
+
+    def visual_iterations_async(self, level, state_in, prop, cfg, iters):
+        self._chk(self.lib.livo2_visual_iterations_async(self.h, int(level), C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
+
+    # ---- solve ---------------------------------------------------------------------------------------------
+    def esikf_solve(self, HtH, Htz, k, meas_cov_scale, sign, cur, prop):
+        HtH, Htz = _f64(HtH).reshape(k, k), _f64(Htz).reshape(k)
+        out, sol, G = State(), np.zeros(19), np.zeros((19, 19))
+        self._chk(self.lib.livo2_esikf_solve(self.h, abi.as_ptr(HtH, C.c_double), abi.as_ptr(Htz, C.c_double), k, float(meas_cov_scale), int(sign),
+                                             C.byref(cur), C.byref(prop), C.byref(out), abi.as_ptr(sol, C.c_double), abi.as_ptr(G, C.c_double)))
+        return out, sol, G

@@ -1,0 +1,171 @@
+"""ctypes binding of the C ABI declared in include/livo2_hip.h (liblivo2_hip.so).
+
+This module is plumbing only: it mirrors the C structs, loads the in-tree shared library and fails loudly when the
+HIP library is missing — there is no CPU fallback of any kind on the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+DIM_STATE = 19
+MAX_ITERS = 16
+MAX_LEVELS = 8
+MAX_LAYER = 4
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_MAP, ERR_NO_SCAN, ERR_NO_FRAME, ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblivo2_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "livo2_hip.h")
+
+
+class State(C.Structure):
+    """livo2_state == StatesGroup (reference include/common_lib.h:126-223)."""
+    _fields_ = [("rot", C.c_double * 9), ("pos", C.c_double * 3), ("inv_expo", C.c_double), ("vel", C.c_double * 3),
+                ("bg", C.c_double * 3), ("ba", C.c_double * 3), ("grav", C.c_double * 3), ("cov", C.c_double * 361)]
+
+    @staticmethod
+    def default():
+        """StatesGroup() (common_lib.h:128-140)."""
+        s = State()
+        s.rot[:] = np.eye(3).ravel().tolist()
+        s.inv_expo = 1.0
+        cov = np.eye(19) * 0.01
+        cov[6, 6] = 0.00001
+        cov[10:19, 10:19] = np.eye(9) * 0.00001
+        s.cov[:] = cov.ravel().tolist()
+        return s
+
+    def copy(self):
+        o = State()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(State))
+        return o
+
+    # numpy views -----------------------------------------------------------------------------------------------
+    @property
+    def R(self):
+        return np.ctypeslib.as_array(self.rot).reshape(3, 3)
+
+    @property
+    def t(self):
+        return np.ctypeslib.as_array(self.pos)
+
+    @property
+    def P(self):
+        return np.ctypeslib.as_array(self.cov).reshape(19, 19)
+
+    def vector(self):
+        """all 25 non-covariance scalars: rot(9) pos(3) inv_expo vel bg ba grav"""
+        return np.concatenate([np.array(self.rot), np.array(self.pos), [self.inv_expo], np.array(self.vel), np.array(self.bg),
+                               np.array(self.ba), np.array(self.grav)])
+
+
+class MapView(C.Structure):
+    _fields_ = [("n_roots", C.c_int32), ("n_nodes", C.c_int32), ("n_planes", C.c_int32),
+                ("root_key", C.POINTER(C.c_int64)), ("root_node", C.POINTER(C.c_int32)), ("root_center", C.POINTER(C.c_double)),
+                ("root_quarter", C.POINTER(C.c_float)), ("node_plane", C.POINTER(C.c_int32)), ("node_child", C.POINTER(C.c_int32)),
+                ("plane_normal", C.POINTER(C.c_double)), ("plane_center", C.POINTER(C.c_double)), ("plane_var", C.POINTER(C.c_double)),
+                ("plane_d", C.POINTER(C.c_float)), ("plane_radius", C.POINTER(C.c_float))]
+
+
+class LidarCfg(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("max_layer", C.c_int32), ("sigma_num", C.c_double), ("dept_err", C.c_double),
+                ("beam_err", C.c_double), ("voxel_size", C.c_double), ("deg2rad", C.c_double), ("extR", C.c_double * 9), ("extT", C.c_double * 3)]
+
+
+class LidarSums(C.Structure):
+    _fields_ = [("HtH", C.c_double * 36), ("Htz", C.c_double * 6), ("total_residual", C.c_double), ("n_eff", C.c_int32), ("pad", C.c_int32)]
+
+
+class LidarPoints(C.Structure):
+    _fields_ = [("match_plane", C.POINTER(C.c_int32)), ("dis_to_plane", C.POINTER(C.c_float)), ("point_w", C.POINTER(C.c_float)),
+                ("normal_plane", C.POINTER(C.c_int32)), ("var", C.POINTER(C.c_double)), ("body_cov", C.POINTER(C.c_double)),
+                ("r_inv", C.POINTER(C.c_double)), ("h_row", C.POINTER(C.c_double))]
+
+
+class LidarResult(C.Structure):
+    _fields_ = [("state", State), ("n_iters", C.c_int32), ("converged", C.c_int32), ("iter_sums", LidarSums * MAX_ITERS),
+                ("iter_solution", (C.c_double * DIM_STATE) * MAX_ITERS), ("position_last", C.c_double * 3)]
+
+
+class Cam(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5),
+                ("distortion", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("pad", C.c_int32)]
+
+
+class VisualCfg(C.Structure):
+    _fields_ = [("cam", Cam), ("Rcl", C.c_double * 9), ("Pcl", C.c_double * 3), ("extR", C.c_double * 9), ("extT", C.c_double * 3),
+                ("img_point_cov", C.c_double), ("patch_pyrimid_level", C.c_int32), ("max_iterations", C.c_int32),
+                ("exposure_estimate_en", C.c_int32), ("inverse_composition_en", C.c_int32)]
+
+
+class VisualSums(C.Structure):
+    _fields_ = [("HtH", C.c_double * 49), ("Htz", C.c_double * 7), ("err_sum", C.c_double), ("error", C.c_float), ("n_meas", C.c_int32)]
+
+
+class VisualStep(C.Structure):
+    _fields_ = [("level", C.c_int32), ("iteration", C.c_int32), ("accepted", C.c_int32), ("n_meas", C.c_int32), ("error", C.c_float),
+                ("pad", C.c_int32), ("HtH", C.c_double * 49), ("Htz", C.c_double * 7), ("solution", C.c_double * DIM_STATE)]
+
+
+class VisualResult(C.Structure):
+    _fields_ = [("state", State), ("G", C.c_double * 361), ("Rcw", C.c_double * 9), ("Pcw", C.c_double * 3), ("n_steps", C.c_int32),
+                ("pad", C.c_int32), ("steps", VisualStep * (MAX_LEVELS * MAX_ITERS))]
+
+
+# name -> (restype, argtypes); every symbol include/livo2_hip.h declares
+_P = C.POINTER
+_CTX = C.c_void_p
+SIGNATURES = {
+    "livo2_ctx_create": (C.c_int, [C.c_int, _P(_CTX)]),
+    "livo2_ctx_create_on_stream": (C.c_int, [C.c_int, C.c_void_p, _P(_CTX)]),
+    "livo2_ctx_destroy": (None, [_CTX]),
+    "livo2_last_error": (C.c_char_p, [_CTX]),
+    "livo2_ctx_stream": (C.c_void_p, [_CTX]),
+    "livo2_ctx_synchronize": (C.c_int, [_CTX]),
+    "livo2_version": (C.c_char_p, []),
+    "livo2_ctx_kernel_timing": (C.c_int, [_CTX, C.c_int]),
+    "livo2_ctx_kernel_timing_read": (C.c_int, [_CTX, C.c_int, _P(C.c_double), _P(C.c_int64), C.c_int]),
+    "livo2_map_upload": (C.c_int, [_CTX, _P(MapView)]),
+    "livo2_map_update_planes": (C.c_int, [_CTX, _P(C.c_int32), C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_float), _P(C.c_float)]),
+    "livo2_lidar_set_scan": (C.c_int, [_CTX, _P(C.c_float), C.c_int32, _P(LidarCfg)]),
+    "livo2_lidar_iterate": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarSums), _P(LidarPoints)]),
+    "livo2_lidar_update": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarResult), _P(LidarPoints)]),
+    "livo2_lidar_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarPoints)]),
+    "livo2_lidar_update_fetch": (C.c_int, [_CTX, _P(LidarResult), _P(LidarPoints)]),
+    "livo2_lidar_iterations_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), C.c_int32]),
+    "livo2_visual_set_frame": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32),
+                                         _P(C.c_double), C.c_int32, C.c_int32]),
+    "livo2_visual_iterate": (C.c_int, [_CTX, C.c_int32, _P(State), _P(VisualCfg), _P(VisualSums), _P(C.c_float), _P(C.c_double), _P(C.c_double)]),
+    "livo2_visual_update": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg), _P(VisualResult), _P(C.c_float)]),
+    "livo2_visual_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg)]),
+    "livo2_visual_update_fetch": (C.c_int, [_CTX, _P(VisualResult), _P(C.c_float)]),
+    "livo2_visual_iterations_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg), C.c_int32]),
+    "livo2_esikf_solve": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), C.c_int32, C.c_double, C.c_int32, _P(State), _P(State), _P(State),
+                                    _P(C.c_double), _P(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load liblivo2_hip.so (in-tree).  Raises if it has not been built — never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C fast-livo2_amd/csrc` (or __graft_entry__.build()); "
+                           "there is no CPU fallback for the ESIKF update path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def as_ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))

@@ -1,0 +1,626 @@
+// liblivo2_hip.so — C ABI implementation (include/livo2_hip.h) over the gfx950 kernels.
+// Host side of the boundary: context / stream ownership, VoxelMap snapshot packing (open-addressing hash + 256-B plane
+// records), scan and frame uploads, and the static launch sequences of the two ESIKF updates.  No CPU compute path exists
+// here: every entry point either drives the HIP kernels or fails.
+#include "lidar_kernels.hpp"
+#include "visual_kernels.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct HostIn { livo2_state cur, prop; DevHeader hdr; };      // pinned mirror of the head of DevCtl
+
+struct EvPair { hipEvent_t a, b; };
+
+struct TimingBin { std::vector<EvPair> used; double total_ms = 0; int64_t launches = 0; };
+
+} // namespace
+
+struct livo2_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  DevCtl *d_ctl = nullptr;
+  HostIn *h_in = nullptr;                   // pinned
+  void *h_out = nullptr;                    // pinned, sizeof(livo2_visual_result) (largest result)
+  // map
+  bool has_map = false;
+  DevMap map{};
+  HashSlot *d_hash = nullptr; RootAux *d_aux = nullptr; double *d_planes = nullptr; int32_t *d_node_plane = nullptr, *d_node_child = nullptr;
+  // scan
+  bool has_scan = false;
+  int n = 0, n_cap = 0;
+  float *d_xyz_aos = nullptr, *d_x = nullptr, *d_y = nullptr, *d_z = nullptr; double *d_cb = nullptr;
+  double *d_partials = nullptr; size_t partials_cap = 0;
+  int32_t *d_match = nullptr, *d_normal_plane = nullptr; float *d_dis = nullptr, *d_pw = nullptr; double *d_var = nullptr, *d_rinv = nullptr, *d_hrow = nullptr;
+  int out_cap = 0;
+  livo2_lidar_points want_l{};              // which per-point arrays the last enqueue produced
+  // frame
+  bool has_frame = false;
+  uint8_t *d_img = nullptr; size_t img_cap = 0; int width = 0, height = 0, stride = 0;
+  double *d_pos = nullptr, *d_invexpo = nullptr; float *d_warp = nullptr; int32_t *d_search = nullptr; int M = 0, L = 0, M_cap = 0; size_t warp_cap = 0;
+  float *d_errors = nullptr; double *d_zdbg = nullptr, *d_Hdbg = nullptr; int dbg_cap = 0;
+  // timing
+  bool timing = false;
+  TimingBin bins[3];
+  std::vector<EvPair> ev_pool;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                                        \
+  do {                                                                                                      \
+    hipError_t e_ = (call);                                                                                 \
+    if (e_ != hipSuccess) {                                                                                 \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                         \
+      return LIVO2_ERR_HIP;                                                                                 \
+    }                                                                                                       \
+  } while (0)
+
+int fail(livo2_ctx *ctx, int code, const char *msg) { if (ctx) ctx->err = msg; return code; }
+
+template <typename T> int ensure(livo2_ctx *ctx, T *&p, size_t &cap, size_t need) {
+  if (need <= cap && p) return LIVO2_OK;
+  if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; }
+  size_t newcap = std::max(need, cap + cap / 2);
+  HIPCHK(hipMalloc((void **)&p, newcap * sizeof(T)));
+  cap = newcap;
+  return LIVO2_OK;
+}
+
+struct Timed {                 // RAII-free helper: brackets one launch with an event pair when timing is on
+  livo2_ctx *ctx; int bin; EvPair ev{}; bool on = false;
+  Timed(livo2_ctx *c, int b) : ctx(c), bin(b) {
+    if (!c->timing) return;
+    if (c->bins[b].used.size() >= 8192) return;
+    if (c->ev_pool.empty()) { if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return; }
+    else { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    on = true;
+    hipError_t e = hipEventRecord(ev.a, c->stream); (void)e;
+  }
+  void done() { if (!on) return; hipError_t e = hipEventRecord(ev.b, ctx->stream); (void)e; ctx->bins[bin].used.push_back(ev); }
+};
+
+void pack_plane(double *rec, const double *normal, const double *center, const double *pv36, float d, float radius) {
+  for (int k = 0; k < 3; k++) { rec[k] = normal[k]; rec[3 + k] = center[k]; }
+  int q = 6;
+  for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) rec[q++] = 0.5 * (pv36[a * 6 + b] + pv36[b * 6 + a]);   // J S J^T only sees sym(S)
+  float dr[2] = {d, radius};
+  std::memcpy(&rec[27], dr, 8);
+  for (int k = 28; k < 32; k++) rec[k] = 0.0;
+}
+
+__global__ void k_scatter_planes(const double *__restrict__ recs, const int32_t *__restrict__ idx, int n, double *__restrict__ planes) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = t >> 5, k = t & 31;
+  if (p < n) planes[(size_t)idx[p] * PLANE_REC_DOUBLES + k] = recs[(size_t)p * PLANE_REC_DOUBLES + k];
+}
+
+__global__ void k_split_xyz(const float *__restrict__ aos, int n, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { x[i] = aos[(size_t)i * 3]; y[i] = aos[(size_t)i * 3 + 1]; z[i] = aos[(size_t)i * 3 + 2]; }
+}
+
+__global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restrict__ ctl, int k, double scale, int sign) {
+  __shared__ SolveLds s;
+  const int lane = threadIdx.x;
+  if (lane < k * k) s.hth[lane] = ctl->solve_hth[lane];
+  if (lane < k) s.htz[lane] = ctl->solve_htz[lane];
+  __syncthreads();
+  esikf_update_wave(ctl, s, k, scale, sign, lane);
+  if (lane < DS) ctl->solve_solution[lane] = s.sol[lane];
+}
+
+int lidar_grid(int n) { int chunks = (n + LIDAR_BLOCK - 1) / LIDAR_BLOCK; int per_xcd = (chunks + 7) / 8; return std::max(8, per_xcd * 8); }
+
+int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
+  if (!cfg) return fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL");
+  if (cfg->max_iterations < 1 || cfg->max_iterations > LIVO2_MAX_ITERS) return fail(ctx, LIVO2_ERR_INVALID, "max_iterations out of [1,LIVO2_MAX_ITERS]");
+  if (cfg->max_layer < 0 || cfg->max_layer > LIVO2_MAX_LAYER) return fail(ctx, LIVO2_ERR_INVALID, "max_layer out of [0,LIVO2_MAX_LAYER]");
+  if (!(cfg->voxel_size > 0)) return fail(ctx, LIVO2_ERR_INVALID, "voxel_size must be > 0");
+  return LIVO2_OK;
+}
+
+int upload_states(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *prop) {
+  // the pinned staging block is reused by every call: the previous H2D must have been consumed
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->h_in->cur = *cur; ctx->h_in->prop = *prop;
+  std::memset(&ctx->h_in->hdr, 0, sizeof(DevHeader));
+  ctx->h_in->hdr.last_error = FLT_MAX;
+  HIPCHK(hipMemcpyAsync(ctx->d_ctl, ctx->h_in, sizeof(HostIn), hipMemcpyHostToDevice, ctx->stream));
+  return LIVO2_OK;
+}
+
+int ensure_lidar_outputs(livo2_ctx *ctx, const livo2_lidar_points *want) {
+  ctx->want_l = livo2_lidar_points{};
+  if (!want) return LIVO2_OK;
+  ctx->want_l = *want;
+  if (ctx->out_cap < ctx->n) {
+    hipError_t e;
+    if (ctx->d_match) { e = hipFree(ctx->d_match); e = hipFree(ctx->d_normal_plane); e = hipFree(ctx->d_dis); e = hipFree(ctx->d_pw); e = hipFree(ctx->d_var); e = hipFree(ctx->d_rinv); e = hipFree(ctx->d_hrow); (void)e; }
+    size_t n = (size_t)ctx->n_cap;
+    HIPCHK(hipMalloc((void **)&ctx->d_match, n * 4)); HIPCHK(hipMalloc((void **)&ctx->d_normal_plane, n * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_dis, n * 4)); HIPCHK(hipMalloc((void **)&ctx->d_pw, n * 12));
+    HIPCHK(hipMalloc((void **)&ctx->d_var, n * 72)); HIPCHK(hipMalloc((void **)&ctx->d_rinv, n * 8)); HIPCHK(hipMalloc((void **)&ctx->d_hrow, n * 48));
+    ctx->out_cap = ctx->n_cap;
+  }
+  return LIVO2_OK;
+}
+
+LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
+  LidarKernelArgs a{};
+  a.x = ctx->d_x; a.y = ctx->d_y; a.z = ctx->d_z; a.cb = ctx->d_cb; a.n = ctx->n; a.max_layer = cfg->max_layer; a.map = ctx->map;
+  a.voxel_size = cfg->voxel_size; a.sigma_num = cfg->sigma_num;
+  std::memcpy(a.ER, cfg->extR, 72); std::memcpy(a.Et, cfg->extT, 24);
+  const livo2_lidar_points &w = ctx->want_l;
+  a.match_plane = w.match_plane ? ctx->d_match : nullptr; a.dis = w.dis_to_plane ? ctx->d_dis : nullptr; a.pw = w.point_w ? ctx->d_pw : nullptr;
+  a.normal_plane = w.normal_plane ? ctx->d_normal_plane : nullptr; a.var = w.var ? ctx->d_var : nullptr;
+  a.r_inv = w.r_inv ? ctx->d_rinv : nullptr; a.h_row = w.h_row ? ctx->d_hrow : nullptr;
+  return a;
+}
+
+int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
+  if (!p) return LIVO2_OK;
+  const livo2_lidar_points &w = ctx->want_l;
+  const size_t n = (size_t)ctx->n;
+  if ((p->match_plane && !w.match_plane) || (p->dis_to_plane && !w.dis_to_plane) || (p->point_w && !w.point_w) || (p->normal_plane && !w.normal_plane) ||
+      (p->var && !w.var) || (p->r_inv && !w.r_inv) || (p->h_row && !w.h_row))
+    return fail(ctx, LIVO2_ERR_INVALID, "per-point array requested at fetch was not selected at enqueue");
+  if (p->match_plane) HIPCHK(hipMemcpyAsync(p->match_plane, ctx->d_match, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->dis_to_plane) HIPCHK(hipMemcpyAsync(p->dis_to_plane, ctx->d_dis, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->point_w) HIPCHK(hipMemcpyAsync(p->point_w, ctx->d_pw, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->normal_plane) HIPCHK(hipMemcpyAsync(p->normal_plane, ctx->d_normal_plane, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->var) HIPCHK(hipMemcpyAsync(p->var, ctx->d_var, n * 72, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->r_inv) HIPCHK(hipMemcpyAsync(p->r_inv, ctx->d_rinv, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->h_row) HIPCHK(hipMemcpyAsync(p->h_row, ctx->d_hrow, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+  if (p->body_cov) {          // body_cov_list_: device keeps the symmetric 6; expand to 3x3 on the host
+    std::vector<double> cb(6 * n);
+    HIPCHK(hipMemcpyAsync(cb.data(), ctx->d_cb, 6 * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    for (size_t i = 0; i < n; i++) for (int e = 0; e < 9; e++) p->body_cov[i * 9 + e] = cb[(size_t)map9[e] * n + i];
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LIVO2_OK;
+}
+
+int check_visual_cfg(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
+  if (!cfg) return fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL");
+  if (cfg->inverse_composition_en) return fail(ctx, LIVO2_ERR_INVALID, "inverse_composition_en is not supported by this release");
+  if (cfg->max_iterations < 1 || cfg->max_iterations > LIVO2_MAX_ITERS) return fail(ctx, LIVO2_ERR_INVALID, "max_iterations out of range");
+  if (cfg->patch_pyrimid_level < 1 || cfg->patch_pyrimid_level > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level out of range");
+  if (cfg->patch_pyrimid_level > ctx->L) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level exceeds the uploaded warp_patch levels");
+  if (!(cfg->img_point_cov > 0)) return fail(ctx, LIVO2_ERR_INVALID, "img_point_cov must be > 0");
+  return LIVO2_OK;
+}
+
+void m3mul(const double *A, const double *B, double *C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j]; }
+
+// initializeVIO constants (reference src/vio.cpp:27-38, 57-65)
+VisualKernelArgs make_visual_args(livo2_ctx *ctx, const livo2_visual_cfg *cfg, int level) {
+  VisualKernelArgs a{};
+  a.img = ctx->d_img; a.width = ctx->width; a.height = ctx->height; a.stride = ctx->stride;
+  a.pos = ctx->d_pos; a.warp = ctx->d_warp; a.search_levels = ctx->d_search; a.inv_expo = ctx->d_invexpo;
+  a.M = ctx->M; a.L = ctx->L; a.level = level; a.exposure_en = cfg->exposure_estimate_en ? 1 : 0;
+  a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy; std::memcpy(a.d, cfg->cam.d, 40); a.distortion = cfg->cam.distortion;
+  double Rli[9], Pli[3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rli[i * 3 + j] = cfg->extR[j * 3 + i];                     // Rli = rot^T
+  for (int i = 0; i < 3; i++) Pli[i] = ((-Rli[i * 3]) * cfg->extT[0] + (-Rli[i * 3 + 1]) * cfg->extT[1]) + (-Rli[i * 3 + 2]) * cfg->extT[2];   // Pli = -rot^T * transl
+  m3mul(cfg->Rcl, Rli, a.Rci);                                                                                         // Rci = Rcl * Rli
+  for (int i = 0; i < 3; i++) a.Pci[i] = ((cfg->Rcl[i * 3] * Pli[0] + cfg->Rcl[i * 3 + 1] * Pli[1]) + cfg->Rcl[i * 3 + 2] * Pli[2]) + cfg->Pcl[i];
+  double Pic[3];
+  for (int i = 0; i < 3; i++) Pic[i] = ((-a.Rci[i]) * a.Pci[0] + (-a.Rci[3 + i]) * a.Pci[1]) + (-a.Rci[6 + i]) * a.Pci[2];   // Pic = -Rci^T * Pci
+  double tmp[9] = {0.0, -Pic[2], Pic[1], Pic[2], 0.0, -Pic[0], -Pic[1], Pic[0], 0.0}, nR[9];
+  for (int i = 0; i < 9; i++) nR[i] = -a.Rci[i];
+  m3mul(nR, tmp, a.Jdp_dR);                                                                                            // Jdp_dR = -Rci * skew(Pic)
+  return a;
+}
+
+int visual_grid(int M) { return std::max(1, (M + VIS_WAVES - 1) / VIS_WAVES); }
+
+} // namespace
+
+extern "C" {
+
+const char *livo2_version(void) { return "livo2_hip 0.1 (gfx950)"; }
+
+static int ctx_create_impl(int device, void *stream, bool external, livo2_ctx **out) {
+  if (!out) return LIVO2_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LIVO2_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LIVO2_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return LIVO2_ERR_NO_DEVICE;      // kernels are built for gfx950 only
+  if (hipSetDevice(device) != hipSuccess) return LIVO2_ERR_NO_DEVICE;
+  livo2_ctx *ctx = new livo2_ctx;
+  ctx->device = device;
+  if (external) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else { if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LIVO2_ERR_HIP; } ctx->own_stream = true; }
+  if (hipMalloc((void **)&ctx->d_ctl, sizeof(DevCtl)) != hipSuccess || hipHostMalloc((void **)&ctx->h_in, sizeof(HostIn)) != hipSuccess ||
+      hipHostMalloc(&ctx->h_out, sizeof(DevCtl)) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
+  if (hipMemsetAsync(ctx->d_ctl, 0, sizeof(DevCtl), ctx->stream) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
+  *out = ctx;
+  return LIVO2_OK;
+}
+int livo2_ctx_create(int device, livo2_ctx **out) { return ctx_create_impl(device, nullptr, false, out); }
+int livo2_ctx_create_on_stream(int device, void *hip_stream, livo2_ctx **out) { return ctx_create_impl(device, hip_stream, true, out); }
+
+void livo2_ctx_destroy(livo2_ctx *ctx) {
+  if (!ctx) return;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (ctx->stream) e = hipStreamSynchronize(ctx->stream);
+  void *dev[] = {ctx->d_ctl, ctx->d_hash, ctx->d_aux, ctx->d_planes, ctx->d_node_plane, ctx->d_node_child, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
+                 ctx->d_cb, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
+                 ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg};
+  for (void *p : dev) if (p) e = hipFree(p);
+  if (ctx->h_in) e = hipHostFree(ctx->h_in);
+  if (ctx->h_out) e = hipHostFree(ctx->h_out);
+  for (auto &b : ctx->bins) for (auto &ev : b.used) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
+  for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
+  if (ctx->own_stream && ctx->stream) e = hipStreamDestroy(ctx->stream);
+  (void)e;
+  delete ctx;
+}
+
+const char *livo2_last_error(const livo2_ctx *ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
+void *livo2_ctx_stream(livo2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; HIPCHK(hipStreamSynchronize(ctx->stream)); return LIVO2_OK; }
+
+int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable) { if (!ctx) return LIVO2_ERR_INVALID; ctx->timing = enable != 0; return LIVO2_OK; }
+int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset) {
+  if (!ctx || which < 0 || which > 2) return LIVO2_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  TimingBin &b = ctx->bins[which];
+  for (auto &ev : b.used) { float ms = 0; if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { b.total_ms += ms; b.launches++; } ctx->ev_pool.push_back(ev); }
+  b.used.clear();
+  if (total_ms) *total_ms = b.total_ms;
+  if (launches) *launches = b.launches;
+  if (reset) { b.total_ms = 0; b.launches = 0; }
+  return LIVO2_OK;
+}
+
+// ---- map ----------------------------------------------------------------------------------------------------------------
+int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!m || m->n_roots < 0 || m->n_nodes < 0 || m->n_planes < 0) return fail(ctx, LIVO2_ERR_INVALID, "bad map view");
+  if (m->n_roots > 0 && (!m->root_key || !m->root_node || !m->root_center || !m->root_quarter)) return fail(ctx, LIVO2_ERR_INVALID, "NULL root arrays");
+  if (m->n_nodes > 0 && (!m->node_plane || !m->node_child)) return fail(ctx, LIVO2_ERR_INVALID, "NULL node arrays");
+  if (m->n_planes > 0 && (!m->plane_normal || !m->plane_center || !m->plane_var || !m->plane_d || !m->plane_radius)) return fail(ctx, LIVO2_ERR_INVALID, "NULL plane arrays");
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int i = 0; i < m->n_nodes; i++) {
+    if (m->node_plane[i] < -1 || m->node_plane[i] >= m->n_planes) return fail(ctx, LIVO2_ERR_INVALID, "node_plane index out of range");
+    for (int k = 0; k < 8; k++) { int c = m->node_child[(size_t)i * 8 + k]; if (c < -1 || c >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "node_child index out of range"); }
+  }
+  uint32_t cap = 16;
+  while (cap < (uint32_t)m->n_roots * 2u) cap <<= 1;
+  std::vector<HashSlot> hash(cap, HashSlot{0, 0, 0, -1});
+  std::vector<RootAux> aux(cap);
+  std::memset(aux.data(), 0, aux.size() * sizeof(RootAux));
+  for (int r = 0; r < m->n_roots; r++) {
+    int64_t kx = m->root_key[(size_t)r * 3], ky = m->root_key[(size_t)r * 3 + 1], kz = m->root_key[(size_t)r * 3 + 2];
+    if (kx < INT32_MIN || kx > INT32_MAX || ky < INT32_MIN || ky > INT32_MAX || kz < INT32_MIN || kz > INT32_MAX) return fail(ctx, LIVO2_ERR_RANGE, "voxel key outside int32");
+    int node = m->root_node[r];
+    if (node < 0 || node >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "root_node index out of range");
+    uint32_t h = voxel_hash((int32_t)kx, (int32_t)ky, (int32_t)kz) & (cap - 1);
+    while (hash[h].val != -1) {
+      if (hash[h].kx == (int32_t)kx && hash[h].ky == (int32_t)ky && hash[h].kz == (int32_t)kz) return fail(ctx, LIVO2_ERR_INVALID, "duplicate voxel key");
+      h = (h + 1) & (cap - 1);
+    }
+    int pl = m->node_plane[node];
+    hash[h] = HashSlot{(int32_t)kx, (int32_t)ky, (int32_t)kz, pl >= 0 ? pl : -(node + 2)};
+    for (int k = 0; k < 3; k++) aux[h].center[k] = m->root_center[(size_t)r * 3 + k];
+    aux[h].quarter = m->root_quarter[r];
+  }
+  std::vector<double> recs((size_t)std::max(1, m->n_planes) * PLANE_REC_DOUBLES, 0.0);
+  for (int p = 0; p < m->n_planes; p++)
+    pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], m->plane_normal + (size_t)p * 3, m->plane_center + (size_t)p * 3, m->plane_var + (size_t)p * 36, m->plane_d[p], m->plane_radius[p]);
+
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipError_t e;
+  if (ctx->d_hash) { e = hipFree(ctx->d_hash); e = hipFree(ctx->d_aux); e = hipFree(ctx->d_planes); e = hipFree(ctx->d_node_plane); e = hipFree(ctx->d_node_child); (void)e; ctx->d_hash = nullptr; }
+  ctx->has_map = false;
+  const size_t nn = (size_t)std::max(1, m->n_nodes);
+  HIPCHK(hipMalloc((void **)&ctx->d_hash, cap * sizeof(HashSlot)));
+  HIPCHK(hipMalloc((void **)&ctx->d_aux, cap * sizeof(RootAux)));
+  HIPCHK(hipMalloc((void **)&ctx->d_planes, recs.size() * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_node_plane, nn * 4));
+  HIPCHK(hipMalloc((void **)&ctx->d_node_child, nn * 32));
+  HIPCHK(hipMemcpy(ctx->d_hash, hash.data(), cap * sizeof(HashSlot), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_aux, aux.data(), cap * sizeof(RootAux), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_planes, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
+  if (m->n_nodes > 0) {
+    HIPCHK(hipMemcpy(ctx->d_node_plane, m->node_plane, (size_t)m->n_nodes * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_node_child, m->node_child, (size_t)m->n_nodes * 32, hipMemcpyHostToDevice));
+  }
+  ctx->map.hash = ctx->d_hash; ctx->map.root_aux = ctx->d_aux; ctx->map.planes = ctx->d_planes; ctx->map.node_plane = ctx->d_node_plane;
+  ctx->map.node_child = ctx->d_node_child; ctx->map.hash_mask = cap - 1; ctx->map.n_planes = m->n_planes; ctx->map.n_nodes = m->n_nodes;
+  ctx->has_map = true;
+  return LIVO2_OK;
+}
+
+int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n, const double *normal, const double *center, const double *plane_var,
+                            const float *d, const float *radius) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->has_map) return fail(ctx, LIVO2_ERR_NO_MAP, "no map uploaded");
+  if (n < 0 || (n > 0 && (!plane_idx || !normal || !center || !plane_var || !d || !radius))) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (n == 0) return LIVO2_OK;
+  for (int i = 0; i < n; i++) if (plane_idx[i] < 0 || plane_idx[i] >= ctx->map.n_planes) return fail(ctx, LIVO2_ERR_INVALID, "plane index out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<double> recs((size_t)n * PLANE_REC_DOUBLES);
+  for (int p = 0; p < n; p++) pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], normal + (size_t)p * 3, center + (size_t)p * 3, plane_var + (size_t)p * 36, d[p], radius[p]);
+  double *d_recs = nullptr; int32_t *d_idx = nullptr;
+  HIPCHK(hipMalloc((void **)&d_recs, recs.size() * 8));
+  HIPCHK(hipMalloc((void **)&d_idx, (size_t)n * 4));
+  HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_idx, plane_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, n, ctx->d_planes);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx));
+  return LIVO2_OK;
+}
+
+// ---- LiDAR -----------------------------------------------------------------------------------------------------------------
+int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n < 0 || (n > 0 && !xyz)) return fail(ctx, LIVO2_ERR_INVALID, "bad scan");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n > ctx->n_cap) {
+    hipError_t e;
+    if (ctx->d_x) { e = hipFree(ctx->d_xyz_aos); e = hipFree(ctx->d_x); e = hipFree(ctx->d_y); e = hipFree(ctx->d_z); e = hipFree(ctx->d_cb); (void)e; }
+    int cap = std::max(n, 1024);
+    HIPCHK(hipMalloc((void **)&ctx->d_xyz_aos, (size_t)cap * 12)); HIPCHK(hipMalloc((void **)&ctx->d_x, (size_t)cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_y, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_z, (size_t)cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_cb, (size_t)cap * 48));
+    ctx->n_cap = cap;
+  }
+  ctx->n = n;
+  const int grid = lidar_grid(std::max(n, 1));
+  rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * 32, (size_t)64));
+  if (rc) return rc;
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_split_xyz, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, n, ctx->d_x, ctx->d_y, ctx->d_z);
+    const double deg2rad = cfg->deg2rad != 0.0 ? cfg->deg2rad : 0.017453293;
+    // d_cb is [6][n] with row pitch n (not n_cap): the residual kernel indexes cb[e*n + i]
+    hipLaunchKernelGGL(k_body_cov, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_x, ctx->d_y, ctx->d_z, n, (float)cfg->dept_err, (float)cfg->beam_err,
+                       deg2rad, ctx->d_cb);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));      // xyz is caller memory: do not return before the copy has consumed it
+  ctx->has_scan = true;
+  return LIVO2_OK;
+}
+
+static int lidar_ready(livo2_ctx *ctx, const livo2_state *a, const livo2_state *b, const livo2_lidar_cfg *cfg) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!a || !b) return fail(ctx, LIVO2_ERR_INVALID, "state is NULL");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  if (!ctx->has_map) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_map_upload has not been called");
+  if (!ctx->has_scan) return fail(ctx, LIVO2_ERR_NO_SCAN, "livo2_lidar_set_scan has not been called");
+  HIPCHK(hipSetDevice(ctx->device));
+  return LIVO2_OK;
+}
+
+int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *prop, const livo2_lidar_cfg *cfg, livo2_lidar_sums *sums,
+                        const livo2_lidar_points *points) {
+  int rc = lidar_ready(ctx, cur, prop, cfg); if (rc) return rc;
+  if (!sums) return fail(ctx, LIVO2_ERR_INVALID, "sums is NULL");
+  rc = ensure_lidar_outputs(ctx, points); if (rc) return rc;
+  rc = upload_states(ctx, cur, prop); if (rc) return rc;
+  if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
+  LidarKernelArgs a = make_lidar_args(ctx, cfg);
+  const int grid = lidar_grid(std::max(ctx->n, 1));
+  { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations); t.done(); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(sums, ctx->h_out, sizeof(livo2_lidar_sums));
+  return fetch_lidar_points(ctx, points);
+}
+
+static int lidar_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, int iters, int mode) {
+  int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
+  if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
+  LidarKernelArgs a = make_lidar_args(ctx, cfg);
+  const int grid = lidar_grid(std::max(ctx->n, 1));
+  for (int it = 0; it < iters; it++) {
+    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
+    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
+  }
+  hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);
+  HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+
+int livo2_lidar_update_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                             const livo2_lidar_points *want) {
+  int rc = lidar_ready(ctx, state_in, prop, cfg); if (rc) return rc;
+  rc = ensure_lidar_outputs(ctx, want); if (rc) return rc;
+  return lidar_enqueue(ctx, state_in, prop, cfg, cfg->max_iterations, 1);
+}
+
+int livo2_lidar_update_fetch(livo2_ctx *ctx, livo2_lidar_result *result, const livo2_lidar_points *points) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!result) return fail(ctx, LIVO2_ERR_INVALID, "result is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->lidar, sizeof(livo2_lidar_result), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(result, ctx->h_out, sizeof(livo2_lidar_result));
+  return fetch_lidar_points(ctx, points);
+}
+
+int livo2_lidar_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, livo2_lidar_result *result,
+                       const livo2_lidar_points *points) {
+  int rc = livo2_lidar_update_async(ctx, state_in, prop, cfg, points); if (rc) return rc;
+  return livo2_lidar_update_fetch(ctx, result, points);
+}
+
+int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, int32_t iters) {
+  int rc = lidar_ready(ctx, state_in, prop, cfg); if (rc) return rc;
+  if (iters < 1) return fail(ctx, LIVO2_ERR_INVALID, "iters must be >= 1");
+  rc = ensure_lidar_outputs(ctx, nullptr); if (rc) return rc;
+  return lidar_enqueue(ctx, state_in, prop, cfg, iters, 2);
+}
+
+// ---- visual ------------------------------------------------------------------------------------------------------------------
+int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const double *pos, const float *warp_patch,
+                           const int32_t *search_levels, const double *inv_expo_list, int32_t M, int32_t L) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!img || width <= 0 || height <= 0 || stride < width) return fail(ctx, LIVO2_ERR_INVALID, "bad image");
+  if (M < 0 || L < 1 || L > LIVO2_MAX_LEVELS || (M > 0 && (!pos || !warp_patch || !search_levels || !inv_expo_list))) return fail(ctx, LIVO2_ERR_INVALID, "bad sub-map arrays");
+  for (int i = 0; i < M; i++) if (search_levels[i] < 0 || search_levels[i] > 8) return fail(ctx, LIVO2_ERR_RANGE, "search_level out of [0,8]");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc = ensure(ctx, ctx->d_img, ctx->img_cap, (size_t)stride * height); if (rc) return rc;
+  if (M > ctx->M_cap) {
+    hipError_t e;
+    if (ctx->d_pos) { e = hipFree(ctx->d_pos); e = hipFree(ctx->d_invexpo); e = hipFree(ctx->d_search); e = hipFree(ctx->d_errors); (void)e; }
+    int cap = std::max(M, 512);
+    HIPCHK(hipMalloc((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_invexpo, (size_t)cap * 8));
+    HIPCHK(hipMalloc((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_errors, (size_t)cap * 4));
+    ctx->M_cap = cap;
+  }
+  rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)M * L * 64, (size_t)64)); if (rc) return rc;
+  const int grid = visual_grid(std::max(M, 1));
+  rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * VIS_PSTRIDE, (size_t)64)); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_img, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream));
+  if (M > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_pos, pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_warp, warp_patch, (size_t)M * L * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_search, search_levels, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_invexpo, inv_expo_list, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->width = width; ctx->height = height; ctx->stride = stride; ctx->M = M; ctx->L = L;
+  ctx->has_frame = true;
+  return LIVO2_OK;
+}
+
+static int visual_ready(livo2_ctx *ctx, const livo2_state *a, const livo2_state *b, const livo2_visual_cfg *cfg) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!a || !b) return fail(ctx, LIVO2_ERR_INVALID, "state is NULL");
+  if (!ctx->has_frame) return fail(ctx, LIVO2_ERR_NO_FRAME, "livo2_visual_set_frame has not been called");
+  int rc = check_visual_cfg(ctx, cfg); if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  return LIVO2_OK;
+}
+
+int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, const livo2_visual_cfg *cfg, livo2_visual_sums *sums, float *errors, double *z,
+                         double *H_sub) {
+  int rc = visual_ready(ctx, cur, cur, cfg); if (rc) return rc;
+  if (!sums) return fail(ctx, LIVO2_ERR_INVALID, "sums is NULL");
+  if (level < 0 || level >= cfg->patch_pyrimid_level) return fail(ctx, LIVO2_ERR_INVALID, "level out of range");
+  const int M = ctx->M;
+  if ((z || H_sub) && ctx->dbg_cap < M) {
+    hipError_t e; if (ctx->d_zdbg) { e = hipFree(ctx->d_zdbg); e = hipFree(ctx->d_Hdbg); (void)e; }
+    HIPCHK(hipMalloc((void **)&ctx->d_zdbg, (size_t)std::max(M, 1) * 64 * 8)); HIPCHK(hipMalloc((void **)&ctx->d_Hdbg, (size_t)std::max(M, 1) * 64 * 56));
+    ctx->dbg_cap = M;
+  }
+  rc = upload_states(ctx, cur, cur); if (rc) return rc;
+  VisualKernelArgs a = make_visual_args(ctx, cfg, level);
+  a.errors = ctx->d_errors; a.z = z ? ctx->d_zdbg : nullptr; a.H_sub = H_sub ? ctx->d_Hdbg : nullptr;
+  const int grid = visual_grid(std::max(M, 1));
+  if (z || H_sub) {
+    // a skipped (out-of-image) patch leaves its rows untouched: clear them first
+    if (z) HIPCHK(hipMemsetAsync(ctx->d_zdbg, 0, (size_t)std::max(M, 1) * 64 * 8, ctx->stream));
+    if (H_sub) HIPCHK(hipMemsetAsync(ctx->d_Hdbg, 0, (size_t)std::max(M, 1) * 64 * 56, ctx->stream));
+    Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<true>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
+  } else {
+    Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
+  }
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov); t.done(); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_v, sizeof(livo2_visual_sums), hipMemcpyDeviceToHost, ctx->stream));
+  if (errors && M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (z && M > 0) HIPCHK(hipMemcpyAsync(z, ctx->d_zdbg, (size_t)M * 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (H_sub && M > 0) HIPCHK(hipMemcpyAsync(H_sub, ctx->d_Hdbg, (size_t)M * 64 * 56, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(sums, ctx->h_out, sizeof(livo2_visual_sums));
+  return LIVO2_OK;
+}
+
+static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, int level_hi, int level_lo,
+                          int iters, int mode) {
+  int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
+  const int grid = visual_grid(std::max(ctx->M, 1));
+  VisualKernelArgs a{};
+  for (int level = level_hi; level >= level_lo; level--) {
+    a = make_visual_args(ctx, cfg, level);
+    a.errors = ctx->d_errors;
+    for (int it = 0; it < iters; it++) {
+      { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0); t.done(); }
+      { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
+    }
+  }
+  hipLaunchKernelGGL(k_visual_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, a, mode == 1 ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+
+int livo2_visual_update_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg) {
+  int rc = visual_ready(ctx, state_in, prop, cfg); if (rc) return rc;
+  if (ctx->M == 0) {            // total_points == 0: computeJacobianAndUpdateEKF returns immediately (vio.cpp:786)
+    rc = upload_states(ctx, state_in, prop); if (rc) return rc;
+    VisualKernelArgs a = make_visual_args(ctx, cfg, 0);
+    hipLaunchKernelGGL(k_visual_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, a, 0);
+    HIPCHK(hipGetLastError());
+    return LIVO2_OK;
+  }
+  return visual_enqueue(ctx, state_in, prop, cfg, cfg->patch_pyrimid_level - 1, 0, cfg->max_iterations, 1);
+}
+
+int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float *errors) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!result) return fail(ctx, LIVO2_ERR_INVALID, "result is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
+  if (errors && ctx->M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(result, ctx->h_out, sizeof(livo2_visual_result));
+  return LIVO2_OK;
+}
+
+int livo2_visual_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, livo2_visual_result *result,
+                        float *errors) {
+  int rc = livo2_visual_update_async(ctx, state_in, prop, cfg); if (rc) return rc;
+  return livo2_visual_update_fetch(ctx, result, errors);
+}
+
+int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg,
+                                  int32_t iters) {
+  int rc = visual_ready(ctx, state_in, prop, cfg); if (rc) return rc;
+  if (iters < 1 || level < 0 || level >= cfg->patch_pyrimid_level) return fail(ctx, LIVO2_ERR_INVALID, "bad iters/level");
+  if (ctx->M == 0) return fail(ctx, LIVO2_ERR_INVALID, "no patches");
+  return visual_enqueue(ctx, state_in, prop, cfg, level, level, iters, 2);
+}
+
+// ---- solve alone ----------------------------------------------------------------------------------------------------------------
+int livo2_esikf_solve(livo2_ctx *ctx, const double *HtH, const double *Htz, int32_t k, double meas_cov_scale, int32_t sign, const livo2_state *cur,
+                      const livo2_state *prop, livo2_state *out_state, double *solution, double *G) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!HtH || !Htz || !cur || !prop || k < 1 || k > 7 || !(meas_cov_scale > 0) || (sign != 1 && sign != -1)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = upload_states(ctx, cur, prop); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_ctl->solve_hth, HtH, (size_t)k * k * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_ctl->solve_htz, Htz, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_esikf_solve_only, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, k, meas_cov_scale, sign); t.done(); }
+  HIPCHK(hipGetLastError());
+  if (out_state) HIPCHK(hipMemcpyAsync(out_state, &ctx->d_ctl->cur, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
+  if (solution) HIPCHK(hipMemcpyAsync(solution, ctx->d_ctl->solve_solution, DS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (G) HIPCHK(hipMemcpyAsync(G, ctx->d_ctl->G, DS * DS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LIVO2_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,117 @@
+// Device-side data layout and small dense algebra shared by the gfx950 kernels of liblivo2_hip.so.
+//
+// Precision recipe: every quantity that the reference narrows to float32 or feeds into a
+// thresholded decision is evaluated with the reference's operand types and operation order; this translation unit is
+// compiled with -ffp-contract=off so the compiler never fuses those.  Where only tolerance-level agreement is
+// required (covariance propagation, quadratic forms, the 19x19 algebra) fused multiply-adds are requested explicitly
+// through fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/livo2_hip.h"
+
+#define LIVO2_WAVE 64
+#define DS LIVO2_DIM_STATE
+
+// ---- VoxelMap snapshot in HBM -------------------------------------------------------------------------------------
+// Plane record: 256 B, 256-B aligned => exactly two 128-B L2 lines, fetched by a lane as 16-B vector loads.
+//   [0..2] normal_  [3..5] center_  [6..26] sym(plane_var_) upper triangle row-major (21)  [27] {float d_, float radius_}
+//   [28..31] pad
+#define PLANE_REC_DOUBLES 32
+struct __attribute__((aligned(16))) HashSlot { int32_t kx, ky, kz, val; };   // val: >=0 plane idx (root is a plane) ; -1 empty ; <=-2 non-plane root node -(val+2)
+struct __attribute__((aligned(32))) RootAux { double center[3]; float quarter; float pad; };   // voxel_center_, quater_length_ (by hash slot)
+
+struct DevMap {
+  const HashSlot *hash;
+  const RootAux *root_aux;
+  const double *planes;        // [n_planes][32]
+  const int32_t *node_plane;   // [n_nodes]
+  const int32_t *node_child;   // [n_nodes][8]
+  uint32_t hash_mask;
+  int32_t n_planes, n_nodes;
+};
+
+__host__ __device__ inline uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
+  uint32_t h = (uint32_t)x * 73856093u ^ (uint32_t)y * 19349663u ^ (uint32_t)z * 83492791u;
+  h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+  return h;
+}
+
+// ---- control block (one per ctx, in HBM) ----------------------------------------------------------------------------
+struct DevHeader {             // reset by the host at the start of every update (one H2D copy together with cur/prop)
+  int32_t stop;                // LiDAR EKF_stop_flg / visual EKF_end of the running level
+  int32_t rematch_num;
+  int32_t pinv_valid;
+  float last_error;            // visual
+  int32_t n_steps;
+  int32_t pad[3];
+};
+struct DevCtl {
+  livo2_state cur;             // state_ / *state   (the iterate)
+  livo2_state prop;            // state_propagat
+  DevHeader hdr;
+  livo2_state old;             // visual old_state (vio.cpp:1523,1650,1679)
+  double Pinv[DS * DS];        // (P / meas_cov_scale)^-1, iteration invariant within one update
+  double G[DS * DS];
+  livo2_lidar_result lidar;
+  livo2_visual_result visual;
+  livo2_lidar_sums sums_l;     // result of a bare iterate call
+  livo2_visual_sums sums_v;
+  double solve_hth[49], solve_htz[7], solve_solution[DS];   // livo2_esikf_solve scratch
+};
+
+// ---- tiny 3x3 helpers (row-major) ------------------------------------------------------------------------------------
+__device__ __forceinline__ double dot3s(double a0, double a1, double a2, double b0, double b1, double b2) {
+  return (a0 * b0 + a1 * b1) + a2 * b2;     // strict left-to-right, one rounding per op
+}
+__device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_mul_Bt(const double *A, const double *B, double *C) {   // C = A * B^T
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[i * 3 + j] = (A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1]) + A[i * 3 + 2] * B[j * 3 + 2];
+}
+__device__ __forceinline__ void mat3_vec(const double *A, const double *v, double *o) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) o[i] = (A[i * 3] * v[0] + A[i * 3 + 1] * v[1]) + A[i * 3 + 2] * v[2];
+}
+__device__ __forceinline__ void mat3t_vec(const double *A, const double *v, double *o) {     // o = A^T v
+#pragma unroll
+  for (int i = 0; i < 3; i++) o[i] = (A[i] * v[0] + A[3 + i] * v[1]) + A[6 + i] * v[2];
+}
+
+// SO(3) Exp / Log  (reference include/utils/so3_math.h:44-66)
+__device__ inline void so3_exp(double v1, double v2, double v3, double *R) {
+  double nrm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+  if (nrm > 0.00001) {
+    double r0 = v1 / nrm, r1 = v2 / nrm, r2 = v3 / nrm;
+    double K[9] = {0.0, -r2, r1, r2, 0.0, -r0, -r1, r0, 0.0};
+    double KK[9];
+    mat3_mul(K, K, KK);
+    double s = sin(nrm), c1 = 1.0 - cos(nrm);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + s * K[i] + c1 * KK[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+}
+__device__ inline void so3_log(const double *R, double *o) {
+  double tr = (R[0] + R[4]) + R[8];
+  double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+  double K0 = R[7] - R[5], K1 = R[2] - R[6], K2 = R[3] - R[1];
+  if (fabs(theta) < 0.001) { o[0] = 0.5 * K0; o[1] = 0.5 * K1; o[2] = 0.5 * K2; }
+  else { double f = 0.5 * theta / sin(theta); o[0] = f * K0; o[1] = f * K1; o[2] = f * K2; }
+}
+
+// wave-64 all-reduce (sum) of a double through the LDS crossbar (ds_bpermute, no LDS storage)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}

@@ -1,0 +1,243 @@
+/*
+ * livo2_hip.h — C ABI of the MI355X (gfx950) ESIKF measurement-update library `liblivo2_hip.so`.
+ *
+ * This is the drop-in boundary for ONE hot path of hku-mars/FAST-LIVO2: the per-frame ESIKF measurement update
+ *   - LiDAR  : VoxelMapManager::StateEstimation(StatesGroup&)            (reference src/voxel_map.cpp:338-511,
+ *              called from LIVMapper::handleLIO, src/LIVMapper.cpp:370)
+ *   - visual : VIOManager::computeJacobianAndUpdateEKF(cv::Mat)           (reference src/vio.cpp:784-802,
+ *              called from VIOManager::processFrame, src/vio.cpp:1810)
+ * Plain pointers and sizes only; no C++/torch/Eigen types cross this boundary.  All matrices are ROW-MAJOR doubles.
+ * Every function returns LIVO2_OK (0) or a negative error code and never throws; `livo2_last_error(ctx)` gives text.
+ * One ctx = one GPU + one HIP stream; a ctx is not thread-safe; use one ctx per GPU / per host thread
+ * (reference threading: single caller thread, src/LIVMapper.cpp:534-552).
+ * The caller owns every host buffer for the duration of a call; the ctx owns device memory and pinned staging.
+ * There is NO CPU fallback: without a usable gfx950 device `livo2_ctx_create` fails with LIVO2_ERR_NO_DEVICE.
+ */
+#ifndef LIVO2_HIP_H
+#define LIVO2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIVO2_DIM_STATE 19      /* reference include/common_lib.h:30  (DIM_STATE) */
+#define LIVO2_MAX_ITERS 16      /* upper bound accepted for lio/vio max_iterations (reference default 5) */
+#define LIVO2_MAX_LEVELS 8      /* upper bound for vio/patch_pyrimid_level (reference default 4) */
+#define LIVO2_MAX_LAYER 4       /* upper bound for lio/max_layer (layer_init_num has 5 entries, voxel_map.cpp:46) */
+#define LIVO2_PATCH 8           /* vio/patch_size; the kernels are specialised for 8x8 (config/avia.yaml:33) */
+
+enum {
+  LIVO2_OK = 0,
+  LIVO2_ERR_INVALID = -1,       /* bad argument (NULL, size, range) */
+  LIVO2_ERR_NO_DEVICE = -2,     /* no gfx950 device / HIP runtime unusable */
+  LIVO2_ERR_HIP = -3,           /* a HIP call failed */
+  LIVO2_ERR_NO_MAP = -4,        /* LiDAR call before livo2_map_upload */
+  LIVO2_ERR_NO_SCAN = -5,       /* LiDAR call before livo2_lidar_set_scan */
+  LIVO2_ERR_NO_FRAME = -6,      /* visual call before livo2_visual_set_frame */
+  LIVO2_ERR_RANGE = -7          /* voxel key outside int32 / value outside supported range */
+};
+
+typedef struct livo2_ctx livo2_ctx;
+
+/* Mirror of StatesGroup (reference include/common_lib.h:126-223).  Error-state order:
+ * [0:3) rot, [3:6) pos, [6] inv_expo_time, [7:10) vel, [10:13) bias_g, [13:16) bias_a, [16:19) gravity. */
+typedef struct livo2_state {
+  double rot[9];                /* rot_end, row-major */
+  double pos[3];                /* pos_end */
+  double inv_expo;              /* inv_expo_time */
+  double vel[3];                /* vel_end */
+  double bg[3];                 /* bias_g */
+  double ba[3];                 /* bias_a */
+  double grav[3];               /* gravity */
+  double cov[LIVO2_DIM_STATE * LIVO2_DIM_STATE];
+} livo2_state;
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int livo2_ctx_create(int device, livo2_ctx **out);
+/* Same, but all work is enqueued on a caller-provided hipStream_t (e.g. torch's current stream) instead of a private one. */
+int livo2_ctx_create_on_stream(int device, void *hip_stream, livo2_ctx **out);
+void livo2_ctx_destroy(livo2_ctx *ctx);
+const char *livo2_last_error(const livo2_ctx *ctx);
+void *livo2_ctx_stream(livo2_ctx *ctx);                 /* the hipStream_t this ctx launches on */
+int livo2_ctx_synchronize(livo2_ctx *ctx);
+const char *livo2_version(void);
+
+/* Per-kernel timing with HIP events on the ctx stream (off by default; adds an event pair per launch).
+ * which: 0 = LiDAR residual kernel, 1 = visual residual kernel, 2 = ESIKF solve kernels. */
+int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
+int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
+
+/* ---- VoxelMap snapshot ("flat map") -------------------------------------------------------------------------- */
+/* Index-based mirror of `std::unordered_map<VOXEL_LOCATION, VoxelOctoTree*> voxel_map_` (reference include/voxel_map.h:194)
+ * restricted to what StateEstimation reads: per root the key, voxel_center_, quater_length_ (voxel_map.h:139,141); per octree
+ * node plane_ptr_->is_plane_ and leaves_[8] (voxel_map.h:135,138); per plane normal_, center_, plane_var_, d_, radius_
+ * (voxel_map.h:69-94). */
+typedef struct livo2_map_view {
+  int32_t n_roots, n_nodes, n_planes;
+  const int64_t *root_key;      /* [n_roots][3]  VOXEL_LOCATION x,y,z (must fit int32, else LIVO2_ERR_RANGE) */
+  const int32_t *root_node;     /* [n_roots]     node index of the root VoxelOctoTree */
+  const double *root_center;    /* [n_roots][3]  voxel_center_ */
+  const float *root_quarter;    /* [n_roots]     quater_length_ */
+  const int32_t *node_plane;    /* [n_nodes]     plane index if plane_ptr_->is_plane_, else -1 */
+  const int32_t *node_child;    /* [n_nodes][8]  leaves_[k] node index or -1 */
+  const double *plane_normal;   /* [n_planes][3] */
+  const double *plane_center;   /* [n_planes][3] */
+  const double *plane_var;      /* [n_planes][36] plane_var_ row-major 6x6 */
+  const float *plane_d;         /* [n_planes] */
+  const float *plane_radius;    /* [n_planes] */
+} livo2_map_view;
+
+int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *map);
+/* Refresh `n` plane records in place after UpdateVoxelMap touched them (VoxelPlane::is_update_, voxel_map.h:86). */
+int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n, const double *normal, const double *center,
+                            const double *plane_var, const float *d, const float *radius);
+
+/* ---- LiDAR point-to-plane update ------------------------------------------------------------------------------ */
+/* Knobs of VoxelMapConfig the path reads (reference include/voxel_map.h:35-52, src/voxel_map.cpp:36-53) + extrinsics
+ * extR_/extT_ (voxel_map.h:200-201).  deg2rad is PCL's DEG2RAD factor used by calcBodyCov (voxel_map.cpp:21); pass 0 for the
+ * PCL default 0.017453293. */
+typedef struct livo2_lidar_cfg {
+  int32_t max_iterations;       /* lio/max_iterations */
+  int32_t max_layer;            /* lio/max_layer */
+  double sigma_num;             /* lio/sigma_num */
+  double dept_err;              /* lio/dept_err  (narrowed to float like calcBodyCov's parameter) */
+  double beam_err;              /* lio/beam_err  (narrowed to float) */
+  double voxel_size;            /* lio/voxel_size */
+  double deg2rad;
+  double extR[9];               /* extrinsic_R (LiDAR -> IMU) */
+  double extT[3];               /* extrinsic_T */
+} livo2_lidar_cfg;
+
+/* Upload one down-sampled scan `feats_down_body_` (xyz float32, AoS [n][3]) and run the once-per-scan precompute
+ * (calcBodyCov per point, voxel_map.cpp:349-360).  The scan stays resident until the next set_scan. */
+int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg);
+
+/* Result of ONE residual+Jacobian+reduction pass (voxel_map.cpp:374-466 without the solve). */
+typedef struct livo2_lidar_sums {
+  double HtH[36];               /* Hsub_T_R_inv * Hsub, row-major 6x6 (voxel_map.cpp:466) */
+  double Htz[6];                /* Hsub_T_R_inv * meas_vec (voxel_map.cpp:464) */
+  double total_residual;        /* sum |dis_to_plane_| (voxel_map.cpp:399-402) */
+  int32_t n_eff;                /* effct_feat_num_ */
+  int32_t pad;
+} livo2_lidar_sums;
+
+/* Optional per-point outputs (any pointer may be NULL).  They describe the LAST executed iteration, i.e. what the
+ * reference leaves in pv_list_ / ptpl_list_ / body_cov_list_ when StateEstimation returns. */
+typedef struct livo2_lidar_points {
+  int32_t *match_plane;         /* [n]    plane index of the matched plane (-1: no residual)  -> ptpl_list_ membership */
+  float *dis_to_plane;          /* [n]    PointToPlane::dis_to_plane_ (signed, float32), 0 when unmatched */
+  float *point_w;               /* [n][3] pv.point_w (float32-rounded world point, voxel_map.cpp:524-526) */
+  int32_t *normal_plane;        /* [n]    plane whose normal_ pv.normal holds (persists across iterations), -1 = zero */
+  double *var;                  /* [n][9] pv.var (voxel_map.cpp:387) */
+  double *body_cov;             /* [n][9] body_cov_list_[i] */
+  double *r_inv;                /* [n]    R_inv(i) of matched points (debug / parity), 0 when unmatched */
+  double *h_row;                /* [n][6] Hsub.row(i) of matched points (debug / parity) */
+} livo2_lidar_points;
+
+/* One pass for the given current iterate `cur` and prior `prop` (state_propagat); no state update. */
+int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                        livo2_lidar_sums *sums, const livo2_lidar_points *points);
+
+typedef struct livo2_lidar_result {
+  livo2_state state;            /* posterior state_ (cov updated, voxel_map.cpp:489-490) */
+  int32_t n_iters;              /* iterations executed */
+  int32_t converged;            /* flg_EKF_converged of the last iteration */
+  livo2_lidar_sums iter_sums[LIVO2_MAX_ITERS];
+  double iter_solution[LIVO2_MAX_ITERS][LIVO2_DIM_STATE];
+  double position_last[3];      /* position_last_ (voxel_map.cpp:492) */
+} livo2_lidar_result;
+
+/* The whole StateEstimation loop (voxel_map.cpp:365-500) with every iteration, the 19x19 solves, boxplus/boxminus, the
+ * convergence / rematch logic and the final covariance update resident on the GPU (one result read-back at the end).
+ * state_in = state_ on entry (LIVMapper.cpp:257), prop = state_propagat. */
+int livo2_lidar_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                       livo2_lidar_result *result, const livo2_lidar_points *points);
+/* Asynchronous form for pipelined callers / benchmarks: enqueue only; results stay on the device until _fetch.
+ * `want` (may be NULL) only selects WHICH per-point arrays the kernels produce (non-NULL members); nothing is written
+ * through it.  _fetch synchronises the stream and copies the result and the selected per-point arrays out. */
+int livo2_lidar_update_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                             const livo2_lidar_points *want);
+int livo2_lidar_update_fetch(livo2_ctx *ctx, livo2_lidar_result *result, const livo2_lidar_points *points);
+/* Enqueue `iters` consecutive ESIKF iterations (residual kernel + solve kernel each) without convergence stopping and
+ * without host interaction; used by bench.py to time the per-iteration cost. */
+int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                                 int32_t iters);
+
+/* ---- visual photometric update ---------------------------------------------------------------------------------- */
+/* vk::AbstractCamera as used on the path: cam->fx()/fy()/cx()/cy()/width()/height() already scaled (vio.cpp:45-54) and
+ * cam->world2cam() (vio.cpp:1574; rpg_vikit pinhole + optional radtan d[0..4]; distortion=0 => pure pinhole). */
+typedef struct livo2_cam {
+  double fx, fy, cx, cy;
+  double d[5];
+  int32_t distortion;
+  int32_t width, height;
+  int32_t pad;
+} livo2_cam;
+
+typedef struct livo2_visual_cfg {
+  livo2_cam cam;
+  double Rcl[9], Pcl[3];        /* extrin_calib Rcl / Pcl (vio.cpp:33-37) */
+  double extR[9], extT[3];      /* extrinsic_R / extrinsic_T (vio.cpp:27-31) */
+  double img_point_cov;         /* vio/img_point_cov */
+  int32_t patch_pyrimid_level;  /* vio/patch_pyrimid_level (L) */
+  int32_t max_iterations;       /* vio/max_iterations */
+  int32_t exposure_estimate_en; /* vio/exposure_estimate_en */
+  int32_t inverse_composition_en; /* vio/inverse_composition_en — must be 0 in this release (forward compositional only) */
+} livo2_visual_cfg;
+
+/* Upload the current gray image (CV_8UC1, row stride `stride` bytes) and the visual sub-map arrays the update reads
+ * (SubSparseMap, reference include/vio.h:26-57): voxel_points[i]->pos_ ([M][3]), warp_patch ([M][L][64] float32, ragged
+ * vector<vector<float>> flattened), search_levels ([M]), inv_expo_list ([M]).  M = total_points. */
+int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const double *pos,
+                           const float *warp_patch, const int32_t *search_levels, const double *inv_expo_list, int32_t M, int32_t L);
+
+typedef struct livo2_visual_sums {
+  double HtH[49];               /* H_sub^T H_sub, row-major 7x7 (vio.cpp:1660); row/col 6 zero if !exposure_estimate_en */
+  double Htz[7];                /* H_sub^T z (vio.cpp:1662) */
+  double err_sum;               /* sum of patch errors before the division (double accumulation) */
+  float error;                  /* error / n_meas as float (vio.cpp:1636) */
+  int32_t n_meas;
+} livo2_visual_sums;
+
+/* One evaluation at pyramid `level` for iterate `cur` (vio.cpp:1538-1636 + 1657-1662); no state update.
+ * Optional outputs (NULL to skip): errors[M] = visual_submap->errors; z[M*64]; H_sub[M*64][7]. */
+int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, const livo2_visual_cfg *cfg, livo2_visual_sums *sums,
+                         float *errors, double *z, double *H_sub);
+
+typedef struct livo2_visual_step {
+  int32_t level, iteration, accepted, n_meas;
+  float error;
+  int32_t pad;
+  double HtH[49], Htz[7], solution[LIVO2_DIM_STATE];
+} livo2_visual_step;
+
+typedef struct livo2_visual_result {
+  livo2_state state;            /* posterior *state incl. cov -= G*cov (vio.cpp:800) */
+  double G[LIVO2_DIM_STATE * LIVO2_DIM_STATE];   /* last G */
+  double Rcw[9], Pcw[3];        /* new_frame_->T_f_w_ (vio.cpp:1690-1697) */
+  int32_t n_steps;
+  int32_t pad;
+  livo2_visual_step steps[LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS];
+} livo2_visual_result;
+
+/* The whole computeJacobianAndUpdateEKF (coarse-to-fine levels x iterations, accept/revert, solves, final covariance update)
+ * resident on the GPU.  errors[M] (optional) = visual_submap->errors after the last evaluation. */
+int livo2_visual_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg,
+                        livo2_visual_result *result, float *errors);
+int livo2_visual_update_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg);
+int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float *errors);
+int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_state *state_in, const livo2_state *prop,
+                                  const livo2_visual_cfg *cfg, int32_t iters);
+
+/* ---- ESIKF solve alone (voxel_map.cpp:468-474 with sign=+1,k=6,meas_cov_scale=1; vio.cpp:1661-1669 with sign=-1,k=7,
+ * meas_cov_scale=img_point_cov) — runs the same device kernel the update loops use. ------------------------------ */
+int livo2_esikf_solve(livo2_ctx *ctx, const double *HtH /*k*k*/, const double *Htz /*k*/, int32_t k, double meas_cov_scale, int32_t sign,
+                      const livo2_state *cur, const livo2_state *prop, livo2_state *out_state, double *solution /*19*/,
+                      double *G /*361*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIVO2_HIP_H */

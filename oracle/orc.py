@@ -1,0 +1,225 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of oracle/liboracle.so (the CPU restatement of the reference path, see orc_api.cpp).
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_IT = 16
+
+
+class StatePOD(C.Structure):
+    _fields_ = [("rot", C.c_double * 9), ("pos", C.c_double * 3), ("inv_expo", C.c_double), ("vel", C.c_double * 3), ("bg", C.c_double * 3),
+                ("ba", C.c_double * 3), ("grav", C.c_double * 3), ("cov", C.c_double * 361)]
+
+
+class LidarCfg(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("max_layer", C.c_int), ("sigma_num", C.c_double), ("dept_err", C.c_double), ("beam_err", C.c_double),
+                ("voxel_size", C.c_double), ("deg2rad", C.c_double), ("extR", C.c_double * 9), ("extT", C.c_double * 3), ("num_threads", C.c_int),
+                ("pad", C.c_int)]
+
+
+class VisualCfg(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5), ("distortion", C.c_int),
+                ("width", C.c_int), ("height", C.c_int), ("patch_pyrimid_level", C.c_int), ("max_iterations", C.c_int),
+                ("exposure_estimate_en", C.c_int), ("inverse_composition_en", C.c_int), ("num_threads", C.c_int), ("img_point_cov", C.c_double),
+                ("Rcl", C.c_double * 9), ("Pcl", C.c_double * 3), ("extR", C.c_double * 9), ("extT", C.c_double * 3)]
+
+
+class LidarIterTrace(C.Structure):
+    _fields_ = [("n_eff", C.c_int), ("total_residual", C.c_double), ("HtH", C.c_double * 36), ("Htz", C.c_double * 6), ("solution", C.c_double * 19),
+                ("converged", C.c_int), ("stopped", C.c_int)]
+
+
+class VisualIterTrace(C.Structure):
+    _fields_ = [("level", C.c_int), ("iteration", C.c_int), ("accepted", C.c_int), ("n_meas", C.c_int), ("error", C.c_float), ("HtH", C.c_double * 49),
+                ("Htz", C.c_double * 7), ("solution", C.c_double * 19)]
+
+
+def build(kind="golden", out_dir=None):
+    """Compile the oracle with the committed Makefile (g++ only).  kind: 'golden' | 'fast'."""
+    out_dir = out_dir or _HERE
+    subprocess.run(["make", "-C", _HERE, kind, f"OUT={out_dir}"], check=True, capture_output=True)
+    return os.path.join(out_dir, "liboracle.so" if kind == "golden" else "liboracle_fast.so")
+
+
+_libs = {}
+
+
+def load(path=None):
+    path = path or os.path.join(_HERE, "liboracle.so")
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        build("golden")
+    lib = C.CDLL(path)
+    assert lib.orc_sizeof_state() == C.sizeof(StatePOD)
+    assert lib.orc_sizeof_lidar_trace() == C.sizeof(LidarIterTrace), (lib.orc_sizeof_lidar_trace(), C.sizeof(LidarIterTrace))
+    assert lib.orc_sizeof_visual_trace() == C.sizeof(VisualIterTrace), (lib.orc_sizeof_visual_trace(), C.sizeof(VisualIterTrace))
+    lib.orc_map_create.restype = C.c_void_p
+    lib.orc_map_from_flat.restype = C.c_void_p
+    _libs[path] = lib
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def make_state(R, t, P, inv_expo=1.0, vel=None, bg=None, ba=None, grav=None, cls=StatePOD):
+    s = cls()
+    s.rot[:] = np.asarray(R, float).ravel().tolist()
+    s.pos[:] = np.asarray(t, float).tolist()
+    s.inv_expo = float(inv_expo)
+    for name, v in (("vel", vel), ("bg", bg), ("ba", ba), ("grav", grav)):
+        getattr(s, name)[:] = (np.zeros(3) if v is None else np.asarray(v, float)).tolist()
+    s.cov[:] = np.asarray(P, float).ravel().tolist()
+    return s
+
+
+def state_arrays(s):
+    return dict(R=np.array(s.rot).reshape(3, 3), t=np.array(s.pos), inv_expo=s.inv_expo, vel=np.array(s.vel), bg=np.array(s.bg), ba=np.array(s.ba),
+                grav=np.array(s.grav), P=np.array(s.cov).reshape(19, 19))
+
+
+class OracleMap:
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, C.c_void_p(handle)
+
+    @classmethod
+    def from_flat(cls, fm, lib=None):
+        lib = lib or load()
+        a = dict(keys=np.ascontiguousarray(fm.root_key, np.int64), rn=np.ascontiguousarray(fm.root_node, np.int32),
+                 rc=np.ascontiguousarray(fm.root_center, np.float64), rq=np.ascontiguousarray(fm.root_quarter, np.float32),
+                 npl=np.ascontiguousarray(fm.node_plane, np.int32), nch=np.ascontiguousarray(fm.node_child, np.int32),
+                 pn=np.ascontiguousarray(fm.plane_normal, np.float64), pc=np.ascontiguousarray(fm.plane_center, np.float64),
+                 pv=np.ascontiguousarray(fm.plane_var, np.float64), pd=np.ascontiguousarray(fm.plane_d, np.float32),
+                 pr=np.ascontiguousarray(fm.plane_radius, np.float32))
+        h = lib.orc_map_from_flat(C.c_double(fm.voxel_size), C.c_int(fm.max_layer), C.c_int(len(a["rn"])), _p(a["keys"], C.c_int64), _p(a["rn"], C.c_int32),
+                                  _p(a["rc"], C.c_double), _p(a["rq"], C.c_float), _p(a["npl"], C.c_int32), _p(a["nch"], C.c_int32), _p(a["pn"], C.c_double),
+                                  _p(a["pc"], C.c_double), _p(a["pv"], C.c_double), _p(a["pd"], C.c_float), _p(a["pr"], C.c_float))
+        return cls(lib, h)
+
+    @classmethod
+    def build(cls, pw, var, voxel_size, max_layer, layer_init_num, max_points_num, planer_threshold, lib=None):
+        """Restated BuildVoxelMap (reference src/voxel_map.cpp:532-591)."""
+        lib = lib or load()
+        lin = (C.c_int * 5)(*list(layer_init_num)[:5])
+        h = lib.orc_map_create(C.c_double(voxel_size), C.c_int(max_layer), lin, C.c_int(max_points_num), C.c_double(planer_threshold))
+        m = cls(lib, h)
+        pw = np.ascontiguousarray(pw, np.float64); var = np.ascontiguousarray(var, np.float64)
+        lib.orc_map_build(m.h, _p(pw, C.c_double), _p(var, C.c_double), C.c_int(len(pw)))
+        return m
+
+    def update(self, pw, var):
+        pw = np.ascontiguousarray(pw, np.float64); var = np.ascontiguousarray(var, np.float64)
+        self.lib.orc_map_update(self.h, _p(pw, C.c_double), _p(var, C.c_double), C.c_int(len(pw)))
+
+    def export(self, voxel_size, max_layer):
+        from scenarios.synth import FlatMap
+        nr, nn, npl = C.c_int(), C.c_int(), C.c_int()
+        self.lib.orc_map_counts(self.h, C.byref(nr), C.byref(nn), C.byref(npl))
+        R, N, P = nr.value, nn.value, npl.value
+        fm = FlatMap(voxel_size, max_layer, np.zeros((R, 3), np.int64), np.zeros(R, np.int32), np.zeros((R, 3)), np.zeros(R, np.float32),
+                     np.zeros(N, np.int32), np.zeros((N, 8), np.int32), np.zeros((P, 3)), np.zeros((P, 3)), np.zeros((P, 36)), np.zeros(P, np.float32),
+                     np.zeros(P, np.float32))
+        self.lib.orc_map_export(self.h, _p(fm.root_key, C.c_int64), _p(fm.root_node, C.c_int32), _p(fm.root_center, C.c_double), _p(fm.root_quarter, C.c_float),
+                                _p(fm.node_plane, C.c_int32), _p(fm.node_child, C.c_int32), _p(fm.plane_normal, C.c_double), _p(fm.plane_center, C.c_double),
+                                _p(fm.plane_var, C.c_double), _p(fm.plane_d, C.c_float), _p(fm.plane_radius, C.c_float))
+        return fm
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.orc_map_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def lidar_cfg(c, extR, extT, num_threads=1, deg2rad=0.017453293):
+    cfg = LidarCfg()
+    cfg.max_iterations, cfg.max_layer = int(c["max_iterations"]), int(c["max_layer"])
+    cfg.sigma_num, cfg.dept_err, cfg.beam_err, cfg.voxel_size, cfg.deg2rad = float(c["sigma_num"]), float(c["dept_err"]), float(c["beam_err"]), float(c["voxel_size"]), deg2rad
+    cfg.extR[:] = np.asarray(extR, float).ravel().tolist()
+    cfg.extT[:] = np.asarray(extT, float).tolist()
+    cfg.num_threads = num_threads
+    return cfg
+
+
+def _point_bufs(n):
+    return dict(match_plane=np.zeros(n, np.int32), dis=np.zeros(n, np.float32), pw=np.zeros((n, 3), np.float32), var=np.zeros((n, 9)),
+                body_cov=np.zeros((n, 9)), cross_mat=np.zeros((n, 9)), normal=np.zeros((n, 3)), Rinv=np.zeros(n), Hrow=np.zeros((n, 6)))
+
+
+def _point_args(b):
+    return [_p(b["match_plane"], C.c_int32), _p(b["dis"], C.c_float), _p(b["pw"], C.c_float), _p(b["var"], C.c_double), _p(b["body_cov"], C.c_double),
+            _p(b["cross_mat"], C.c_double), _p(b["normal"], C.c_double), _p(b["Rinv"], C.c_double), _p(b["Hrow"], C.c_double)]
+
+
+def lidar_iterate(omap, cfg, xyz, cur, prop):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = len(xyz)
+    HtH, Htz, neff, tr = np.zeros(36), np.zeros(6), C.c_int(), C.c_double()
+    b = _point_bufs(n)
+    omap.lib.orc_lidar_iterate(omap.h, C.byref(cfg), _p(xyz, C.c_float), C.c_int(n), C.byref(cur), C.byref(prop), _p(HtH, C.c_double), _p(Htz, C.c_double),
+                               C.byref(neff), C.byref(tr), *_point_args(b))
+    return dict(HtH=HtH.reshape(6, 6), Htz=Htz, n_eff=neff.value, total_residual=tr.value, **b)
+
+
+def lidar_state_estimation(omap, cfg, xyz, state_in, prop, want_points=True):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = len(xyz)
+    out = StatePOD()
+    trace = (LidarIterTrace * MAX_IT)()
+    nit, secs = C.c_int(), C.c_double()
+    b = _point_bufs(n if want_points else 0)
+    args = _point_args(b) if want_points else [None] * 9
+    omap.lib.orc_lidar_state_estimation(omap.h, C.byref(cfg), _p(xyz, C.c_float), C.c_int(n), C.byref(state_in), C.byref(prop), C.byref(out),
+                                        C.cast(trace, C.c_void_p), C.byref(nit), C.byref(secs), *args)
+    return dict(state=out, n_iters=nit.value, seconds=secs.value, trace=[trace[i] for i in range(nit.value)], **(b if want_points else {}))
+
+
+def visual_cfg(sc, num_threads=1, exposure=True, inverse=False, max_iterations=None):
+    cfg = VisualCfg()
+    cfg.fx, cfg.fy, cfg.cx, cfg.cy = sc.cam["fx"], sc.cam["fy"], sc.cam["cx"], sc.cam["cy"]
+    cfg.distortion, cfg.width, cfg.height = 0, sc.cam["width"], sc.cam["height"]
+    cfg.patch_pyrimid_level = int(sc.cfg["patch_pyrimid_level"])
+    cfg.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
+    cfg.exposure_estimate_en, cfg.inverse_composition_en, cfg.num_threads = int(exposure), int(inverse), num_threads
+    cfg.img_point_cov = float(sc.cfg["img_point_cov"])
+    cfg.Rcl[:] = sc.Rcl.ravel().tolist(); cfg.Pcl[:] = sc.Pcl.tolist(); cfg.extR[:] = sc.extR.ravel().tolist(); cfg.extT[:] = sc.extT.tolist()
+    return cfg
+
+
+def visual_iterate(cfg, sc, level, cur, lib=None):
+    lib = lib or load()
+    M = len(sc.pos)
+    img = np.ascontiguousarray(sc.img, np.uint8); pos = np.ascontiguousarray(sc.pos, np.float64); wp = np.ascontiguousarray(sc.warp_patch, np.float32)
+    sl = np.ascontiguousarray(sc.search_levels, np.int32); ie = np.ascontiguousarray(sc.inv_expo_list, np.float64)
+    z, H, err = np.zeros(M * 64), np.zeros((M * 64, 7)), np.zeros(M, np.float32)
+    HtH, Htz, e, nm = np.zeros(49), np.zeros(7), C.c_float(), C.c_int()
+    lib.orc_visual_iterate(C.byref(cfg), _p(img, C.c_uint8), _p(pos, C.c_double), _p(wp, C.c_float), _p(sl, C.c_int32), _p(ie, C.c_double), C.c_int(M),
+                           C.c_int(level), C.byref(cur), _p(z, C.c_double), _p(H, C.c_double), _p(err, C.c_float), _p(HtH, C.c_double), _p(Htz, C.c_double),
+                           C.byref(e), C.byref(nm))
+    return dict(z=z, H=H, errors=err, HtH=HtH.reshape(7, 7), Htz=Htz, error=e.value, n_meas=nm.value)
+
+
+def visual_update(cfg, sc, state_in, prop, lib=None):
+    lib = lib or load()
+    M = len(sc.pos)
+    img = np.ascontiguousarray(sc.img, np.uint8); pos = np.ascontiguousarray(sc.pos, np.float64); wp = np.ascontiguousarray(sc.warp_patch, np.float32)
+    sl = np.ascontiguousarray(sc.search_levels, np.int32); ie = np.ascontiguousarray(sc.inv_expo_list, np.float64)
+    out = StatePOD(); err = np.zeros(M, np.float32)
+    trace = (VisualIterTrace * (8 * MAX_IT))()
+    nt, secs = C.c_int(), C.c_double()
+    G, RP = np.zeros(361), np.zeros(12)
+    lib.orc_visual_update(C.byref(cfg), _p(img, C.c_uint8), _p(pos, C.c_double), _p(wp, C.c_float), _p(sl, C.c_int32), _p(ie, C.c_double), C.c_int(M),
+                          C.byref(state_in), C.byref(prop), C.byref(out), _p(err, C.c_float), C.cast(trace, C.c_void_p), C.byref(nt), C.byref(secs),
+                          _p(G, C.c_double), _p(RP, C.c_double), None, None, None, None, None, None)
+    return dict(state=out, errors=err, trace=[trace[i] for i in range(nt.value)], seconds=secs.value, G=G.reshape(19, 19), Rcw=RP[:9].reshape(3, 3), Pcw=RP[9:])

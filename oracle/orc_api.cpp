@@ -1,0 +1,308 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked into, imported by, or executed from the product path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+//
+// extern "C" surface over the restated reference path (orc_lidar.hpp / orc_visual.hpp / orc_voxel_map.hpp) so that the
+// Python test-suite can drive it through ctypes.  "Flat map" = the neutral array interchange format both the oracle and
+// the product's C-ABI (include/livo2_hip.h) can be fed from:
+//   roots : key int64[R][3], node int32[R], center f64[R][3], quarter f32[R]
+//   nodes : plane int32[Nn] (-1 when !is_plane_), child int32[Nn][8] (-1 when null)
+//   planes: normal f64[P][3], center f64[P][3], plane_var f64[P][36], d f32[P], radius f32[P]
+#include "orc_lidar.hpp"
+#include "orc_visual.hpp"
+#include <chrono>
+
+using namespace orc;
+
+namespace {
+struct MapHandle {
+  VoxelMap map;
+  std::unordered_map<const VoxelPlane *, int> plane_index;   // filled by export / from_flat
+  std::vector<VoxelOctoTree *> root_order;                   // export order of roots
+  std::vector<VOXEL_LOCATION> root_keys;
+};
+
+void count_nodes(const VoxelOctoTree *t, int &n_nodes, int &n_planes) {
+  n_nodes++;
+  if (t->plane_ptr_->is_plane_) n_planes++;
+  for (int i = 0; i < 8; i++) if (t->leaves_[i]) count_nodes(t->leaves_[i], n_nodes, n_planes);
+}
+
+struct Exporter {
+  MapHandle *h; int32_t *node_plane, *node_child; double *pn, *pc, *pv; float *pd, *pr; int n_nodes = 0, n_planes = 0;
+  int visit(const VoxelOctoTree *t) {
+    int me = n_nodes++;
+    if (t->plane_ptr_->is_plane_) {
+      const VoxelPlane *p = t->plane_ptr_;
+      int pi = n_planes++;
+      h->plane_index[p] = pi;
+      for (int k = 0; k < 3; k++) { pn[pi * 3 + k] = p->normal_[k]; pc[pi * 3 + k] = p->center_[k]; }
+      for (int k = 0; k < 36; k++) pv[(size_t)pi * 36 + k] = p->plane_var_.a[k];
+      pd[pi] = p->d_; pr[pi] = p->radius_;
+      node_plane[me] = pi;
+    } else node_plane[me] = -1;
+    for (int i = 0; i < 8; i++) node_child[(size_t)me * 8 + i] = -1;
+    for (int i = 0; i < 8; i++) if (t->leaves_[i]) { int c = visit(t->leaves_[i]); node_child[(size_t)me * 8 + i] = c; }
+    return me;
+  }
+};
+} // namespace
+
+extern "C" {
+
+struct orc_lidar_cfg {
+  int max_iterations; int max_layer;
+  double sigma_num, dept_err, beam_err, voxel_size, deg2rad;
+  double extR[9], extT[3];
+  int num_threads; int pad;
+};
+
+struct orc_visual_cfg {
+  double fx, fy, cx, cy, d[5];
+  int distortion, width, height, patch_pyrimid_level, max_iterations, exposure_estimate_en, inverse_composition_en, num_threads;
+  double img_point_cov;
+  double Rcl[9], Pcl[3], extR[9], extT[3];
+};
+
+int orc_sizeof_lidar_trace() { return (int)sizeof(LidarIterTrace); }
+int orc_sizeof_visual_trace() { return (int)sizeof(VisualIterTrace); }
+int orc_sizeof_state() { return (int)sizeof(StatePOD); }
+
+void *orc_map_create(double voxel_size, int max_layer, const int *layer_init_num5, int max_points_num, double planer_threshold) {
+  MapHandle *h = new MapHandle;
+  h->map.config_setting_.max_voxel_size_ = voxel_size;
+  h->map.config_setting_.max_layer_ = max_layer;
+  h->map.config_setting_.layer_init_num_.assign(layer_init_num5, layer_init_num5 + 5);
+  h->map.config_setting_.max_points_num_ = max_points_num;
+  h->map.config_setting_.planner_threshold_ = planer_threshold;
+  return h;
+}
+void orc_map_destroy(void *m) { delete (MapHandle *)m; }
+
+static void to_points(const double *pw, const double *var9, int n, std::vector<MapPoint> &pts) {
+  pts.resize(n);
+  for (int i = 0; i < n; i++) { for (int k = 0; k < 3; k++) pts[i].point_w[k] = pw[(size_t)i * 3 + k]; for (int k = 0; k < 9; k++) pts[i].var.a[k] = var9[(size_t)i * 9 + k]; }
+}
+void orc_map_build(void *m, const double *pw, const double *var9, int n) { std::vector<MapPoint> pts; to_points(pw, var9, n, pts); ((MapHandle *)m)->map.BuildVoxelMap(pts); }
+void orc_map_update(void *m, const double *pw, const double *var9, int n) { std::vector<MapPoint> pts; to_points(pw, var9, n, pts); ((MapHandle *)m)->map.UpdateVoxelMap(pts); }
+
+void orc_map_counts(void *m, int *n_roots, int *n_nodes, int *n_planes) {
+  MapHandle *h = (MapHandle *)m; int nn = 0, np = 0;
+  for (auto &kv : h->map.voxel_map_) count_nodes(kv.second, nn, np);
+  *n_roots = (int)h->map.voxel_map_.size(); *n_nodes = nn; *n_planes = np;
+}
+
+void orc_map_export(void *m, int64_t *keys, int32_t *root_node, double *root_center, float *root_quarter, int32_t *node_plane, int32_t *node_child,
+                    double *plane_normal, double *plane_center, double *plane_var, float *plane_d, float *plane_radius) {
+  MapHandle *h = (MapHandle *)m;
+  h->plane_index.clear(); h->root_order.clear(); h->root_keys.clear();
+  Exporter ex{h, node_plane, node_child, plane_normal, plane_center, plane_var, plane_d, plane_radius};
+  int r = 0;
+  for (auto &kv : h->map.voxel_map_) {
+    keys[r * 3 + 0] = kv.first.x; keys[r * 3 + 1] = kv.first.y; keys[r * 3 + 2] = kv.first.z;
+    for (int k = 0; k < 3; k++) root_center[r * 3 + k] = kv.second->voxel_center_[k];
+    root_quarter[r] = kv.second->quater_length_;
+    root_node[r] = ex.visit(kv.second);
+    h->root_order.push_back(kv.second); h->root_keys.push_back(kv.first);
+    r++;
+  }
+}
+
+static VoxelOctoTree *build_from_flat(MapHandle *h, int node, int layer, const int32_t *node_plane, const int32_t *node_child, const double *pn,
+                                      const double *pc, const double *pv, const float *pd, const float *pr) {
+  auto &cfg = h->map.config_setting_;
+  VoxelOctoTree *t = new VoxelOctoTree(cfg.max_layer_, layer, 5, cfg.max_points_num_, (float)cfg.planner_threshold_, &h->map.voxel_plane_id);
+  t->layer_init_num_ = cfg.layer_init_num_;
+  t->init_octo_ = true;
+  int pi = node_plane[node];
+  if (pi >= 0) {
+    VoxelPlane *p = t->plane_ptr_;
+    for (int k = 0; k < 3; k++) { p->normal_[k] = pn[pi * 3 + k]; p->center_[k] = pc[pi * 3 + k]; }
+    for (int k = 0; k < 36; k++) p->plane_var_.a[k] = pv[(size_t)pi * 36 + k];
+    p->d_ = pd[pi]; p->radius_ = pr[pi]; p->is_plane_ = true; p->is_init_ = true;
+    h->plane_index[p] = pi;
+  }
+  for (int i = 0; i < 8; i++) { int c = node_child[(size_t)node * 8 + i]; if (c >= 0) t->leaves_[i] = build_from_flat(h, c, layer + 1, node_plane, node_child, pn, pc, pv, pd, pr); }
+  return t;
+}
+
+void *orc_map_from_flat(double voxel_size, int max_layer, int n_roots, const int64_t *keys, const int32_t *root_node, const double *root_center,
+                        const float *root_quarter, const int32_t *node_plane, const int32_t *node_child, const double *plane_normal,
+                        const double *plane_center, const double *plane_var, const float *plane_d, const float *plane_radius) {
+  int lin[5] = {5, 5, 5, 5, 5};
+  MapHandle *h = (MapHandle *)orc_map_create(voxel_size, max_layer, lin, 50, 0.0025);
+  for (int r = 0; r < n_roots; r++) {
+    VoxelOctoTree *t = build_from_flat(h, root_node[r], 0, node_plane, node_child, plane_normal, plane_center, plane_var, plane_d, plane_radius);
+    for (int k = 0; k < 3; k++) t->voxel_center_[k] = root_center[r * 3 + k];
+    t->quater_length_ = root_quarter[r];
+    h->map.voxel_map_[VOXEL_LOCATION(keys[r * 3], keys[r * 3 + 1], keys[r * 3 + 2])] = t;
+  }
+  return h;
+}
+
+static void setup_manager(VoxelMapManager &mgr, MapHandle *h, const orc_lidar_cfg *cfg, const float *xyz, int n, const StatePOD *state_in) {
+  mgr.map_ = &h->map;
+  mgr.config_setting_ = h->map.config_setting_;
+  mgr.config_setting_.max_iterations_ = cfg->max_iterations; mgr.config_setting_.max_layer_ = cfg->max_layer;
+  mgr.config_setting_.sigma_num_ = cfg->sigma_num; mgr.config_setting_.dept_err_ = cfg->dept_err; mgr.config_setting_.beam_err_ = cfg->beam_err;
+  mgr.config_setting_.max_voxel_size_ = cfg->voxel_size;
+  mgr.deg2rad_ = cfg->deg2rad; mgr.num_threads_ = cfg->num_threads > 0 ? cfg->num_threads : 1;
+  std::memcpy(mgr.extR_.a, cfg->extR, 72); std::memcpy(mgr.extT_.a, cfg->extT, 24);
+  mgr.feats_down_body_.resize(n);
+  for (int i = 0; i < n; i++) { PointXYZINormal p; std::memset(&p, 0, sizeof(p)); p.x = xyz[(size_t)i * 3]; p.y = xyz[(size_t)i * 3 + 1]; p.z = xyz[(size_t)i * 3 + 2]; mgr.feats_down_body_[i] = p; }
+  mgr.feats_down_size_ = n;
+  mgr.state_.from_pod(*state_in);
+}
+
+static void dump_points(VoxelMapManager &mgr, MapHandle *h, int n, int32_t *match_plane, float *dis, float *pw, double *var, double *body_cov,
+                        double *cross_mat, double *normal, double *Rinv, double *Hrow) {
+  if (match_plane) for (int i = 0; i < n; i++) match_plane[i] = -1;
+  if (dis) for (int i = 0; i < n; i++) dis[i] = 0;
+  if (Rinv) for (int i = 0; i < n; i++) Rinv[i] = 0;
+  if (Hrow) for (size_t i = 0; i < (size_t)n * 6; i++) Hrow[i] = 0;
+  for (int i = 0; i < n; i++) {
+    const pointWithVar &pv = mgr.pv_list_[i];
+    if (pw) for (int k = 0; k < 3; k++) pw[(size_t)i * 3 + k] = (float)pv.point_w[k];
+    if (var) std::memcpy(var + (size_t)i * 9, pv.var.a, 72);
+    if (body_cov) std::memcpy(body_cov + (size_t)i * 9, mgr.body_cov_list_[i].a, 72);
+    if (cross_mat) std::memcpy(cross_mat + (size_t)i * 9, mgr.cross_mat_list_[i].a, 72);
+    if (normal) std::memcpy(normal + (size_t)i * 3, pv.normal.a, 24);
+  }
+  for (size_t j = 0; j < mgr.ptpl_list_.size(); j++) {
+    int i = mgr.ptpl_index_[j];
+    if (match_plane) { auto it = h->plane_index.find(mgr.ptpl_list_[j].plane_src_); match_plane[i] = (it == h->plane_index.end()) ? -2 : it->second; }
+    if (dis) dis[i] = mgr.ptpl_list_[j].dis_to_plane_;
+    if (Rinv && j < mgr.dump_Rinv_.size()) Rinv[i] = mgr.dump_Rinv_[j];
+    if (Hrow && (j + 1) * 6 <= mgr.dump_H_.size()) std::memcpy(Hrow + (size_t)i * 6, &mgr.dump_H_[j * 6], 48);
+  }
+}
+
+// One iteration of residual+Jacobian+reduction for a given current/prior state (no solve).
+int orc_lidar_iterate(void *m, const orc_lidar_cfg *cfg, const float *xyz, int n, const StatePOD *state_cur, const StatePOD *state_prop, double *HtH36,
+                      double *Htz6, int *n_eff, double *total_residual, int32_t *match_plane, float *dis, float *pw, double *var, double *body_cov,
+                      double *cross_mat, double *normal, double *Rinv, double *Hrow) {
+  MapHandle *h = (MapHandle *)m;
+  VoxelMapManager mgr; setup_manager(mgr, h, cfg, xyz, n, state_cur);
+  StatesGroup prop; prop.from_pod(*state_prop);
+  mgr.per_scan_precompute();
+  double tr;
+  mgr.iterate_residual_and_reduce(prop, HtH36, Htz6, tr);
+  *n_eff = mgr.effct_feat_num_; *total_residual = tr;
+  dump_points(mgr, h, n, match_plane, dis, pw, var, body_cov, cross_mat, normal, Rinv, Hrow);
+  return 0;
+}
+
+// Full StateEstimation (src/voxel_map.cpp:338-511).  `seconds` = wall time around StateEstimation only (the reference's "ICP" window,
+// src/LIVMapper.cpp:368-374).
+int orc_lidar_state_estimation(void *m, const orc_lidar_cfg *cfg, const float *xyz, int n, const StatePOD *state_in, const StatePOD *state_prop,
+                               StatePOD *state_out, void *trace /*LidarIterTrace[max_iterations]*/, int *n_iters, double *seconds, int32_t *match_plane,
+                               float *dis, float *pw, double *var, double *body_cov, double *cross_mat, double *normal, double *Rinv, double *Hrow) {
+  MapHandle *h = (MapHandle *)m;
+  VoxelMapManager mgr; setup_manager(mgr, h, cfg, xyz, n, state_in);
+  StatesGroup prop; prop.from_pod(*state_prop);
+  auto t0 = std::chrono::steady_clock::now();
+  mgr.StateEstimation(prop);
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  mgr.state_.to_pod(*state_out);
+  if (n_iters) *n_iters = (int)mgr.trace_.size();
+  if (trace) std::memcpy(trace, mgr.trace_.data(), mgr.trace_.size() * sizeof(LidarIterTrace));
+  dump_points(mgr, h, n, match_plane, dis, pw, var, body_cov, cross_mat, normal, Rinv, Hrow);
+  return 0;
+}
+
+static void setup_vio(VIOManager &vio, SubSparseMap &sm, std::vector<VisualPoint> &pts, const orc_visual_cfg *cfg, const double *pos, const float *warp_patch,
+                      const int32_t *search_levels, const double *inv_expo_list, int M, const uint8_t *ref_imgs, const int32_t *ref_img_idx,
+                      const double *ref_px, const double *ref_f, const double *ref_R, const double *ref_pos) {
+  vio.cam.fx = cfg->fx; vio.cam.fy = cfg->fy; vio.cam.cx = cfg->cx; vio.cam.cy = cfg->cy; std::memcpy(vio.cam.d, cfg->d, 40);
+  vio.cam.distortion = cfg->distortion; vio.cam.width = cfg->width; vio.cam.height = cfg->height;
+  M3 extR, Rcl; V3 extT, Pcl;
+  std::memcpy(extR.a, cfg->extR, 72); std::memcpy(extT.a, cfg->extT, 24); std::memcpy(Rcl.a, cfg->Rcl, 72); std::memcpy(Pcl.a, cfg->Pcl, 24);
+  vio.patch_size = 8; vio.patch_pyrimid_level = cfg->patch_pyrimid_level; vio.max_iterations = cfg->max_iterations;
+  vio.img_point_cov = cfg->img_point_cov; vio.exposure_estimate_en = cfg->exposure_estimate_en; vio.inverse_composition_en = cfg->inverse_composition_en;
+  vio.num_threads_ = cfg->num_threads > 0 ? cfg->num_threads : 1;
+  vio.setImuToLidarExtrinsic(extT, extR);       // LIVMapper.cpp:133
+  vio.setLidarToCameraExtrinsic(Rcl, Pcl);      // LIVMapper.cpp:134
+  vio.initializeVIO();
+  const int L = cfg->patch_pyrimid_level;
+  pts.resize(M);
+  sm.errors.assign(M, 0.f); sm.warp_patch.resize(M); sm.search_levels.resize(M); sm.voxel_points.resize(M); sm.inv_expo_list.resize(M);
+  for (int i = 0; i < M; i++) {
+    for (int k = 0; k < 3; k++) pts[i].pos_[k] = pos[(size_t)i * 3 + k];
+    sm.voxel_points[i] = &pts[i];
+    sm.warp_patch[i].assign(warp_patch + (size_t)i * L * 64, warp_patch + (size_t)(i + 1) * L * 64);
+    sm.search_levels[i] = search_levels[i];
+    sm.inv_expo_list[i] = inv_expo_list[i];
+  }
+  if (ref_imgs && ref_img_idx) {
+    sm.ref_patches.resize(M);
+    for (int i = 0; i < M; i++) {
+      RefPatch &rp = sm.ref_patches[i];
+      rp.img_ = ref_imgs + (size_t)ref_img_idx[i] * cfg->width * cfg->height;
+      rp.px_[0] = ref_px[i * 2]; rp.px_[1] = ref_px[i * 2 + 1];
+      for (int k = 0; k < 3; k++) { rp.f_[k] = ref_f[i * 3 + k]; rp.pos_ref[k] = ref_pos[i * 3 + k]; }
+      std::memcpy(rp.R_ref_w.a, ref_R + (size_t)i * 9, 72);
+    }
+  }
+  vio.visual_submap = &sm; vio.total_points = M;
+}
+
+// One forward-compositional evaluation at `level` for a given state: z, H_sub (H_DIM x 7), per-patch errors, 7x7 / 7x1 sums.
+int orc_visual_iterate(const orc_visual_cfg *cfg, const uint8_t *img, const double *pos, const float *warp_patch, const int32_t *search_levels,
+                       const double *inv_expo_list, int M, int level, const StatePOD *state_cur, double *z, double *H_sub, float *errors, double *HtH49,
+                       double *Htz7, float *error, int *n_meas) {
+  VIOManager vio; SubSparseMap sm; std::vector<VisualPoint> pts;
+  setup_vio(vio, sm, pts, cfg, pos, warp_patch, search_levels, inv_expo_list, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  StatesGroup st; st.from_pod(*state_cur); vio.state = &st; vio.state_propagat = &st;
+  const int H_DIM = M * 64;
+  std::vector<double> zz(H_DIM, 0.0), HH((size_t)H_DIM * 7, 0.0);
+  int nm = 0;
+  float e = vio.eval_forward(img, level, zz, HH, nm);
+  if (z) std::memcpy(z, zz.data(), zz.size() * 8);
+  if (H_sub) std::memcpy(H_sub, HH.data(), HH.size() * 8);
+  if (errors) std::memcpy(errors, sm.errors.data(), M * 4);
+  for (int a = 0; a < 7; a++) {
+    double s = 0.0; for (int r = 0; r < H_DIM; r++) s += HH[(size_t)r * 7 + a] * zz[r];
+    if (Htz7) Htz7[a] = s;
+    for (int b = 0; b < 7; b++) { double t = 0.0; for (int r = 0; r < H_DIM; r++) t += HH[(size_t)r * 7 + a] * HH[(size_t)r * 7 + b]; if (HtH49) HtH49[a * 7 + b] = t; }
+  }
+  *error = e; *n_meas = nm;
+  return 0;
+}
+
+// Full computeJacobianAndUpdateEKF (src/vio.cpp:784-802).  `seconds` = wall time around it (src/vio.cpp:1808-1812 window).
+int orc_visual_update(const orc_visual_cfg *cfg, const uint8_t *img, const double *pos, const float *warp_patch, const int32_t *search_levels,
+                      const double *inv_expo_list, int M, const StatePOD *state_in, const StatePOD *state_prop, StatePOD *state_out, float *errors,
+                      void *trace /*VisualIterTrace[L*max_it]*/, int *n_trace, double *seconds, double *G361, double *RcwPcw12, const uint8_t *ref_imgs,
+                      const int32_t *ref_img_idx, const double *ref_px, const double *ref_f, const double *ref_R, const double *ref_pos) {
+  VIOManager vio; SubSparseMap sm; std::vector<VisualPoint> pts;
+  setup_vio(vio, sm, pts, cfg, pos, warp_patch, search_levels, inv_expo_list, M, ref_imgs, ref_img_idx, ref_px, ref_f, ref_R, ref_pos);
+  StatesGroup st, prop; st.from_pod(*state_in); prop.from_pod(*state_prop); vio.state = &st; vio.state_propagat = &prop;
+  auto t0 = std::chrono::steady_clock::now();
+  vio.computeJacobianAndUpdateEKF(img);
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  st.to_pod(*state_out);
+  if (errors) std::memcpy(errors, sm.errors.data(), M * 4);
+  if (n_trace) *n_trace = (int)vio.trace_.size();
+  if (trace) std::memcpy(trace, vio.trace_.data(), vio.trace_.size() * sizeof(VisualIterTrace));
+  if (G361) std::memcpy(G361, vio.G.a, 361 * 8);
+  if (RcwPcw12) { std::memcpy(RcwPcw12, vio.Rcw.a, 72); std::memcpy(RcwPcw12 + 9, vio.Pcw.a, 24); }
+  return 0;
+}
+
+// calcBodyCov alone (src/voxel_map.cpp:15-34), for known-answer tests.
+void orc_calc_body_cov(const double *pb3, float range_inc, float degree_inc, double deg2rad, double *cov9, double *pb_out3) {
+  V3 pb = vec3(pb3[0], pb3[1], pb3[2]); M3 cov;
+  calcBodyCov(pb, range_inc, degree_inc, cov, deg2rad);
+  std::memcpy(cov9, cov.a, 72);
+  if (pb_out3) std::memcpy(pb_out3, pb.a, 24);
+}
+
+// State algebra (common_lib.h:182-206) and the 19x19 inverse, for known-answer tests.
+void orc_state_boxplus(const StatePOD *s, const double *d19, StatePOD *out) { StatesGroup g; g.from_pod(*s); VState d; std::memcpy(d.a, d19, 152); g += d; g.to_pod(*out); }
+void orc_state_boxminus(const StatePOD *a, const StatePOD *b, double *out19) { StatesGroup ga, gb; ga.from_pod(*a); gb.from_pod(*b); VState d = ga - gb; std::memcpy(out19, d.a, 152); }
+int orc_inverse19(const double *A361, double *inv361) { MState A, I; std::memcpy(A.a, A361, 361 * 8); bool ok = inverse_lu<19>(A, I); std::memcpy(inv361, I.a, 361 * 8); return ok ? 0 : -1; }
+void orc_so3_exp(const double *v3, double *R9) { M3 R = Exp(v3[0], v3[1], v3[2]); std::memcpy(R9, R.a, 72); }
+void orc_so3_log(const double *R9, double *v3) { M3 R; std::memcpy(R.a, R9, 72); V3 v = Log(R); std::memcpy(v3, v.a, 24); }
+
+} // extern "C"

@@ -1,0 +1,460 @@
+"""Seeded synthetic inputs for the ESIKF measurement-update path: piecewise-planar rooms, LiDAR scans with
+range/bearing noise, a VoxelMap snapshot built by a numpy restatement of BuildVoxelMap/init_plane, gray images and visual
+sub-maps.  Pure numpy/scipy — this package contains neither the oracle nor the product; both are fed from it.
+
+Flat map = index-based mirror of `unordered_map<VOXEL_LOCATION, VoxelOctoTree*>` (reference include/voxel_map.h:194), the
+interchange format of include/livo2_hip.h (`livo2_map_view`) and of oracle/orc_api.cpp.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# ---- configuration values of the reference's config/avia.yaml ---------------------------------------------------------
+AVIA = dict(
+    extrinsic_T=np.array([0.04165, 0.02326, -0.0284]), extrinsic_R=np.eye(3),
+    Rcl=np.array([[0.00610193, -0.999863, -0.0154172], [-0.00615449, 0.0153796, -0.999863], [0.999962, 0.00619598, -0.0060598]]),
+    Pcl=np.array([0.0194384, 0.104689, -0.0251952]),
+    lio=dict(max_iterations=5, dept_err=0.02, beam_err=0.05, min_eigen_value=0.0025, voxel_size=0.5, max_layer=2, max_points_num=50,
+             layer_init_num=[5, 5, 5, 5, 5], sigma_num=3.0),
+    vio=dict(max_iterations=5, img_point_cov=100.0, patch_size=8, patch_pyrimid_level=4, exposure_estimate_en=True),
+    # config/camera_pinhole.yaml values x scale 0.5 (vio.cpp:45-54), distortion dropped for the synthetic benchmark
+    cam=dict(fx=1293.56944 * 0.5, fy=1293.3155 * 0.5, cx=626.91359 * 0.5, cy=522.799224 * 0.5, width=640, height=512),
+    filter_size_surf=0.1, blind=0.8,
+)
+PCL_DEG2RAD = 0.017453293     # pcl/pcl_macros.h DEG2RAD factor
+
+
+@dataclass
+class FlatMap:
+    voxel_size: float
+    max_layer: int
+    root_key: np.ndarray      # int64 [R,3]
+    root_node: np.ndarray     # int32 [R]
+    root_center: np.ndarray   # f64 [R,3]
+    root_quarter: np.ndarray  # f32 [R]
+    node_plane: np.ndarray    # int32 [Nn]
+    node_child: np.ndarray    # int32 [Nn,8]
+    plane_normal: np.ndarray  # f64 [P,3]
+    plane_center: np.ndarray  # f64 [P,3]
+    plane_var: np.ndarray     # f64 [P,36]
+    plane_d: np.ndarray       # f32 [P]
+    plane_radius: np.ndarray  # f32 [P]
+
+    @property
+    def n_planes(self):
+        return len(self.plane_d)
+
+
+def rot_from_rpy(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def so3_exp(v):
+    v = np.asarray(v, float)
+    th = np.linalg.norm(v)
+    if th < 1e-12:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+# ---- scene ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class Scene:
+    """Axis-aligned rectangles in a scene frame, mapped to the world by T_ws = (R_ws, t_ws) so that no plane is aligned with
+    the voxel grid."""
+    faces: list = field(default_factory=list)     # (axis, coord, lo(2), hi(2)) with the two other axes in increasing order
+    R_ws: np.ndarray = field(default_factory=lambda: np.eye(3))
+    t_ws: np.ndarray = field(default_factory=lambda: np.zeros(3))
+
+
+def make_room(rng, size=(20.0, 20.0, 6.0), n_boxes=8):
+    sx, sy, sz = size
+    lo = np.array([-sx / 2 + 0.137, -sy / 2 + 0.211, -0.173])
+    hi = lo + np.array(size)
+    sc = Scene(R_ws=rot_from_rpy(0.03, -0.02, 0.31), t_ws=np.array([0.4, -0.3, 0.2]))
+
+    def add_box(blo, bhi):
+        for ax in range(3):
+            o = [a for a in range(3) if a != ax]
+            for c in (blo[ax], bhi[ax]):
+                sc.faces.append((ax, float(c), np.array([blo[o[0]], blo[o[1]]]), np.array([bhi[o[0]], bhi[o[1]]])))
+
+    add_box(lo, hi)
+    for _ in range(n_boxes):
+        w = rng.uniform(0.8, 0.15 * min(sx, sy), 3)
+        w[2] = rng.uniform(0.5, 0.5 * sz)
+        c = np.array([rng.uniform(lo[0] + 2, hi[0] - 2), rng.uniform(lo[1] + 2, hi[1] - 2), lo[2]])
+        if np.hypot(c[0], c[1]) < 3.0:       # keep the sensor's neighbourhood free
+            c[:2] += 3.0 * np.sign(c[:2] + 1e-9)
+        add_box(np.array([c[0] - w[0] / 2, c[1] - w[1] / 2, lo[2]]), np.array([c[0] + w[0] / 2, c[1] + w[1] / 2, lo[2] + w[2]]))
+    return sc
+
+
+def cast(scene, origin_w, dirs_w):
+    """First-hit distance of world rays against the scene (inf when nothing is hit)."""
+    o = scene.R_ws.T @ (origin_w - scene.t_ws)
+    d = dirs_w @ scene.R_ws            # rows: R_ws^T d
+    best = np.full(len(d), np.inf)
+    for ax, c, lo, hi in scene.faces:
+        oth = [a for a in range(3) if a != ax]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (c - o[ax]) / d[:, ax]
+        h0 = o[oth[0]] + t * d[:, oth[0]]
+        h1 = o[oth[1]] + t * d[:, oth[1]]
+        ok = (t > 1e-6) & (h0 >= lo[0]) & (h0 <= hi[0]) & (h1 >= lo[1]) & (h1 <= hi[1]) & (t < best)
+        best = np.where(ok, t, best)
+    return best
+
+
+def sample_dirs(rng, n, fov_h_deg=70.4, fov_v_deg=77.2, full_sphere=False):
+    """Unit directions in the LiDAR frame (+x forward).  Avia FoV by default."""
+    if full_sphere:
+        v = rng.normal(size=(n, 3))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    az = np.deg2rad(rng.uniform(-fov_h_deg / 2, fov_h_deg / 2, n))
+    el = np.deg2rad(rng.uniform(-fov_v_deg / 2, fov_v_deg / 2, n))
+    return np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
+
+
+def lidar_scan(rng, scene, R_wi, t_wi, extR, extT, n_rays, dept_err, beam_err_deg, blind=0.8, full_sphere=False, max_range=80.0):
+    """Noisy scan in the LiDAR body frame (float32 xyz), rays cast from the true pose."""
+    d_l = sample_dirs(rng, n_rays, full_sphere=full_sphere)
+    o_w = R_wi @ extT + t_wi
+    d_w = d_l @ (R_wi @ extR).T
+    r = cast(scene, o_w, d_w)
+    keep = np.isfinite(r) & (r > blind) & (r < max_range)
+    d_l, r = d_l[keep], r[keep]
+    r = r + rng.normal(0, dept_err, len(r))
+    # bearing noise: rotate by a small random vector orthogonal-ish to the ray
+    w = rng.normal(0, np.deg2rad(beam_err_deg), (len(r), 3))
+    d_n = d_l + np.cross(w, d_l)
+    d_n /= np.linalg.norm(d_n, axis=1, keepdims=True)
+    return (d_n * r[:, None]).astype(np.float32)
+
+
+def voxel_grid_downsample(xyz, leaf):
+    """Centroid voxel-grid filter in the spirit of pcl::VoxelGrid (reference src/LIVMapper.cpp:351-352): one centroid per occupied
+    leaf, output ordered by leaf index (z-major, then y, then x) like PCL's sorted-index pass."""
+    xyz = np.asarray(xyz, np.float32)
+    ijk = np.floor(xyz / np.float32(leaf)).astype(np.int64)
+    ijk -= ijk.min(0)
+    dims = ijk.max(0) + 1
+    idx = ijk[:, 0] + dims[0] * (ijk[:, 1] + dims[1] * ijk[:, 2])
+    order = np.argsort(idx, kind="stable")
+    idx_s = idx[order]
+    first = np.concatenate([[0], np.nonzero(np.diff(idx_s))[0] + 1])
+    counts = np.diff(np.concatenate([first, [len(idx_s)]]))
+    sums = np.add.reduceat(xyz[order].astype(np.float64), first, axis=0)
+    return (sums / counts[:, None]).astype(np.float32)
+
+
+# ---- numpy restatement of calcBodyCov (reference src/voxel_map.cpp:15-34), vectorised ----------------------------------
+def body_cov(p_l, dept_err, beam_err, deg2rad=PCL_DEG2RAD):
+    p = np.array(p_l, np.float64, copy=True)
+    p[p[:, 2] == 0, 2] = 0.001
+    rng_f = np.sqrt((p * p).sum(1)).astype(np.float32).astype(np.float64)
+    range_var = np.float64(np.float32(dept_err) * np.float32(dept_err))
+    dv = np.sin(np.float64(np.float32(beam_err)) * deg2rad) ** 2
+    d = p / np.linalg.norm(p, axis=1, keepdims=True)
+    b1 = np.stack([np.ones(len(p)), np.ones(len(p)), -(d[:, 0] + d[:, 1]) / d[:, 2]], 1)
+    b1 /= np.linalg.norm(b1, axis=1, keepdims=True)
+    b2 = np.cross(b1, d)
+    b2 /= np.linalg.norm(b2, axis=1, keepdims=True)
+    hat = np.zeros((len(p), 3, 3))
+    hat[:, 0, 1], hat[:, 0, 2], hat[:, 1, 0], hat[:, 1, 2], hat[:, 2, 0], hat[:, 2, 1] = -d[:, 2], d[:, 1], d[:, 2], -d[:, 0], -d[:, 1], d[:, 0]
+    N = np.stack([b1, b2], 2)
+    A = rng_f[:, None, None] * hat @ N
+    return range_var * d[:, :, None] * d[:, None, :] + dv * A @ A.transpose(0, 2, 1)
+
+
+def skew(v):
+    v = np.atleast_2d(v)
+    S = np.zeros((len(v), 3, 3))
+    S[:, 0, 1], S[:, 0, 2], S[:, 1, 0], S[:, 1, 2], S[:, 2, 0], S[:, 2, 1] = -v[:, 2], v[:, 1], v[:, 2], -v[:, 0], -v[:, 1], v[:, 0]
+    return S
+
+
+def world_points_and_var(xyz_l, R, t, extR, extT, P, dept_err, beam_err):
+    """World points and covariances as BuildVoxelMap forms them (reference src/voxel_map.cpp:542-555, LIVMapper.cpp:358)."""
+    pl = np.asarray(xyz_l, np.float64)
+    pw = (pl @ extR.T + extT) @ R.T + t
+    pw = pw.astype(np.float32).astype(np.float64)          # feats_down_world_ is a float32 cloud
+    cb = body_cov(pl, dept_err, beam_err)
+    RE = R @ extR
+    X = skew(pl)                                           # voxel_map.cpp:550 uses the LiDAR-frame point here
+    var = RE @ cb @ RE.T + X @ P[0:3, 0:3] @ X.transpose(0, 2, 1) + P[3:6, 3:6]
+    return pw, var
+
+
+# ---- numpy restatement of BuildVoxelMap / init_plane / cut_octo_tree (reference src/voxel_map.cpp:55-217, 532-591) --------
+def _fit_planes(pw, var, gid, G):
+    """Per-group plane fit: returns (is_plane-independent) centre, eigen-decomposition and plane covariance."""
+    cnt = np.bincount(gid, minlength=G).astype(np.float64)
+    ctr = np.stack([np.bincount(gid, pw[:, k], G) for k in range(3)], 1) / cnt[:, None]
+    outer = pw[:, :, None] * pw[:, None, :]
+    cov = np.stack([np.bincount(gid, outer[:, i, j], G) for i in range(3) for j in range(3)], 1).reshape(G, 3, 3) / cnt[:, None, None]
+    cov -= ctr[:, :, None] * ctr[:, None, :]
+    ev, evec = np.linalg.eigh(cov)                         # ascending: min = 0, mid = 1, max = 2
+    vmin = evec[:, :, 0]
+    n_pts = cnt[gid]
+    F = np.zeros((len(pw), 3, 3))
+    dp = pw - ctr[gid]
+    for m in (1, 2):
+        vm = evec[gid][:, :, m]
+        sym = vm[:, :, None] * vmin[gid][:, None, :] + vmin[gid][:, :, None] * vm[:, None, :]
+        denom = n_pts * (ev[gid, 0] - ev[gid, m])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            F[:, m, :] = np.einsum("ni,nij->nj", dp, sym) / denom[:, None]
+    J = np.zeros((len(pw), 6, 3))
+    J[:, 0:3, :] = evec[gid] @ F
+    J[:, 3, 0] = J[:, 4, 1] = J[:, 5, 2] = 1.0 / n_pts
+    JVJ = J @ var @ J.transpose(0, 2, 1)
+    pv = np.stack([np.bincount(gid, JVJ[:, i, j], G) for i in range(6) for j in range(6)], 1)
+    return cnt, ctr, ev, evec, pv
+
+
+def build_voxel_map(pw, var, voxel_size=0.5, max_layer=2, layer_init_num=(5, 5, 5, 5, 5), planer_threshold=0.0025):
+    pw = np.asarray(pw, np.float64)
+    vs_f = np.float64(np.float32(voxel_size))              # `float voxel_size` local (voxel_map.cpp:534)
+    loc = (pw / vs_f).astype(np.float32)
+    loc = np.where(loc < 0, (loc.astype(np.float64) - 1.0).astype(np.float32), loc)
+    key = loc.astype(np.int64)                             # truncation toward zero
+    ukey, gid = np.unique(key, axis=0, return_inverse=True)
+    gid = gid.reshape(-1)
+    R = len(ukey)
+    root_center = (0.5 + ukey.astype(np.float64)) * vs_f
+    root_quarter = np.full(R, np.float32(voxel_size) / np.float32(4), np.float32)
+
+    node_plane, node_child = [-1] * R, [[-1] * 8 for _ in range(R)]
+    planes = dict(normal=[], center=[], var=[], d=[], radius=[])
+    # active set: point index array, group id per point (0..G-1), per group node id / centre / quarter
+    act_pts = np.arange(len(pw))
+    act_gid = gid
+    act_node = np.arange(R)
+    act_ctr, act_q = root_center, root_quarter
+    for layer in range(max_layer + 1):
+        G = len(act_node)
+        if G == 0 or len(act_pts) == 0:
+            break
+        cnt = np.bincount(act_gid, minlength=G)
+        elig = cnt > layer_init_num[layer]
+        sel = elig[act_gid]
+        sub_pts, sub_gid_old = act_pts[sel], act_gid[sel]
+        remap = -np.ones(G, np.int64)
+        remap[elig] = np.arange(elig.sum())
+        sg = remap[sub_gid_old]
+        Ge = int(elig.sum())
+        if Ge == 0:
+            break
+        _, ctr, ev, evec, pvar = _fit_planes(pw[sub_pts], var[sub_pts], sg, Ge)
+        is_plane = ev[:, 0] < np.float64(np.float32(planer_threshold))
+        e_nodes = act_node[elig]
+        for g in np.nonzero(is_plane)[0]:
+            n = evec[g][:, 0]
+            node_plane[e_nodes[g]] = len(planes["d"])
+            planes["normal"].append(n)
+            planes["center"].append(ctr[g])
+            planes["var"].append(pvar[g])
+            planes["d"].append(np.float32(-(n[0] * ctr[g][0] + n[1] * ctr[g][1] + n[2] * ctr[g][2])))
+            planes["radius"].append(np.float32(np.sqrt(max(ev[g, 2], 0.0))))
+        if layer == max_layer:
+            break
+        # subdivide non-planar eligible groups (cut_octo_tree)
+        np_mask = ~is_plane
+        selp = np_mask[sg]
+        c_pts, c_g = sub_pts[selp], sg[selp]
+        if len(c_pts) == 0:
+            break
+        e_ctr, e_q = act_ctr[elig], act_q[elig]
+        bits = (pw[c_pts] > e_ctr[c_g]).astype(np.int64)
+        code = 4 * bits[:, 0] + 2 * bits[:, 1] + bits[:, 2]
+        pair = c_g * 8 + code
+        upair, new_gid = np.unique(pair, return_inverse=True)
+        new_gid = new_gid.reshape(-1)
+        par_g, par_code = upair // 8, upair % 8
+        new_nodes = np.arange(len(node_plane), len(node_plane) + len(upair))
+        node_plane.extend([-1] * len(upair))
+        node_child.extend([[-1] * 8 for _ in range(len(upair))])
+        for k in range(len(upair)):
+            node_child[e_nodes[par_g[k]]][par_code[k]] = int(new_nodes[k])
+        xyzb = np.stack([(par_code >> 2) & 1, (par_code >> 1) & 1, par_code & 1], 1)
+        q_par = e_q[par_g]
+        new_ctr = e_ctr[par_g] + ((2 * xyzb - 1).astype(np.float32) * q_par[:, None]).astype(np.float64)
+        new_q = (q_par / np.float32(2)).astype(np.float32)
+        act_pts, act_gid, act_node, act_ctr, act_q = c_pts, new_gid, new_nodes, new_ctr, new_q
+    P = len(planes["d"])
+    return FlatMap(
+        voxel_size=float(voxel_size), max_layer=int(max_layer), root_key=ukey.astype(np.int64), root_node=np.arange(R, dtype=np.int32),
+        root_center=root_center, root_quarter=root_quarter, node_plane=np.array(node_plane, np.int32),
+        node_child=np.array(node_child, np.int32).reshape(-1, 8),
+        plane_normal=np.array(planes["normal"], np.float64).reshape(P, 3), plane_center=np.array(planes["center"], np.float64).reshape(P, 3),
+        plane_var=np.array(planes["var"], np.float64).reshape(P, 36), plane_d=np.array(planes["d"], np.float32),
+        plane_radius=np.array(planes["radius"], np.float32))
+
+
+# ---- LiDAR scenario ------------------------------------------------------------------------------------------------------------
+@dataclass
+class LidarScenario:
+    fmap: FlatMap
+    xyz: np.ndarray            # float32 [N,3] down-sampled body-frame scan (feats_down_body_)
+    R_true: np.ndarray
+    t_true: np.ndarray
+    R_prior: np.ndarray
+    t_prior: np.ndarray
+    P: np.ndarray              # 19x19 prior covariance
+    extR: np.ndarray
+    extT: np.ndarray
+    cfg: dict
+
+
+def default_cov():
+    """StatesGroup() covariance (reference include/common_lib.h:137-139)."""
+    P = np.eye(19) * 0.01
+    P[6, 6] = 0.00001
+    P[10:19, 10:19] = np.eye(9) * 0.00001
+    return P
+
+
+def prior_cov(rng):
+    """A propagated-looking SPD prior: StatesGroup() diagonal scaled down + a small random symmetric coupling."""
+    P = default_cov() * 0.02
+    A = rng.normal(size=(19, 19)) * 1e-4
+    P = P + A @ A.T
+    return 0.5 * (P + P.T)
+
+
+def lidar_scenario(seed=1, n_points=10000, room=(20.0, 20.0, 6.0), n_boxes=8, full_sphere=False, map_rays_factor=12, downsample=None,
+                   rot_sigma_deg=0.5, pos_sigma=0.03, cfg=None):
+    """C1/C2-style scenario: map from a dense first sweep at the true pose, test scan with fresh noise, perturbed prior."""
+    rng = np.random.default_rng(seed)
+    c = dict(AVIA["lio"])
+    if cfg:
+        c.update(cfg)
+    extR, extT = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy()
+    scene = make_room(rng, room, n_boxes)
+    R_true = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
+    t_true = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    P0 = default_cov() * 1e-3
+    # map sweep (dense), in the world frame with the true pose
+    n_map = int(n_points * map_rays_factor)
+    chunks = []
+    for _ in range(max(1, n_map // 400000 + 1)):
+        chunks.append(lidar_scan(rng, scene, R_true, t_true, extR, extT, min(n_map, 400000), c["dept_err"], c["beam_err"], AVIA["blind"], full_sphere))
+    xyz_map = np.concatenate(chunks)[:n_map]
+    pw, var = world_points_and_var(xyz_map, R_true, t_true, extR, extT, P0, c["dept_err"], c["beam_err"])
+    fmap = build_voxel_map(pw, var, c["voxel_size"], c["max_layer"], c["layer_init_num"], c["min_eigen_value"])
+    # test scan
+    over = 1.6 if downsample else 1.25
+    xyz = lidar_scan(rng, scene, R_true, t_true, extR, extT, int(n_points * over) + 64, c["dept_err"], c["beam_err"], AVIA["blind"], full_sphere)
+    if downsample:
+        xyz = voxel_grid_downsample(xyz, downsample)
+    xyz = xyz[:n_points] if len(xyz) >= n_points else xyz
+    dth = rng.normal(0, np.deg2rad(rot_sigma_deg), 3)
+    dp = rng.normal(0, pos_sigma, 3)
+    R_prior = R_true @ so3_exp(dth)
+    t_prior = t_true + dp
+    return LidarScenario(fmap, np.ascontiguousarray(xyz, np.float32), R_true, t_true, R_prior, t_prior, prior_cov(rng), extR, extT, c)
+
+
+# ---- visual scenario -----------------------------------------------------------------------------------------------------------
+def make_image(rng, width=640, height=512, sigma=2.0):
+    from scipy.ndimage import gaussian_filter
+    img = gaussian_filter(rng.uniform(0, 1, (height, width)), sigma)
+    img += 0.5 * gaussian_filter(rng.uniform(0, 1, (height, width)), 4 * sigma)
+    img = (img - img.min()) / (img.max() - img.min())
+    return np.clip(np.round(img * 255.0), 0, 255).astype(np.uint8)
+
+
+def vio_constants(extR, extT, Rcl, Pcl):
+    """Rci, Pci of initializeVIO (reference src/vio.cpp:27-38, 57-58)."""
+    Rli = extR.T
+    Pli = -extR.T @ extT
+    return Rcl @ Rli, Rcl @ Pli + Pcl
+
+
+def sample_patch(img, pc, scale):
+    """The reference's bilinear 8x8 sample at stride `scale` around pixel pc (reference src/vio.cpp:1580-1620), float32 math."""
+    img = np.asarray(img)
+    f32 = np.float32
+    u_ref, v_ref = f32(pc[0]), f32(pc[1])
+    u_i = int(np.floor(f32(pc[0] / scale)) * f32(scale))
+    v_i = int(np.floor(f32(pc[1] / scale)) * f32(scale))
+    su = f32((u_ref - f32(u_i)) / f32(scale))
+    sv = f32((v_ref - f32(v_i)) / f32(scale))
+    w_tl = f32((1.0 - np.float64(su)) * (1.0 - np.float64(sv)))
+    w_tr = f32(np.float64(su) * (1.0 - np.float64(sv)))
+    w_bl = f32((1.0 - np.float64(su)) * np.float64(sv))
+    w_br = f32(su * sv)
+    xs = v_i + (np.arange(8) - 4) * scale
+    ys = u_i + (np.arange(8) - 4) * scale
+    a = img[np.ix_(xs, ys)].astype(f32)
+    b = img[np.ix_(xs, ys + scale)].astype(f32)
+    c = img[np.ix_(xs + scale, ys)].astype(f32)
+    d = img[np.ix_(xs + scale, ys + scale)].astype(f32)
+    return ((w_tl * a + w_tr * b) + w_bl * c) + w_br * d
+
+
+@dataclass
+class VisualScenario:
+    img: np.ndarray
+    pos: np.ndarray            # f64 [M,3] world positions (VisualPoint::pos_)
+    warp_patch: np.ndarray     # f32 [M,L,64]
+    search_levels: np.ndarray  # int32 [M]
+    inv_expo_list: np.ndarray  # f64 [M]
+    R_true: np.ndarray
+    t_true: np.ndarray
+    tau_true: float
+    R_prior: np.ndarray
+    t_prior: np.ndarray
+    tau_prior: float
+    P: np.ndarray
+    extR: np.ndarray
+    extT: np.ndarray
+    Rcl: np.ndarray
+    Pcl: np.ndarray
+    cam: dict
+    cfg: dict
+
+
+def visual_scenario(seed=3, n_patches=2000, L=4, rot_sigma_deg=0.05, pos_sigma=0.004, noise_sigma=1.0, R_true=None, t_true=None):
+    rng = np.random.default_rng(seed)
+    cam = dict(AVIA["cam"])
+    cfg = dict(AVIA["vio"])
+    cfg["patch_pyrimid_level"] = L
+    extR, extT, Rcl, Pcl = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy(), AVIA["Rcl"].copy(), AVIA["Pcl"].copy()
+    img = make_image(rng, cam["width"], cam["height"])
+    if R_true is None:
+        R_true = rot_from_rpy(0.02, -0.01, 0.7)
+    if t_true is None:
+        t_true = np.array([1.0, -0.5, 1.2])
+    tau_true = 1.0
+    Rci, Pci = vio_constants(extR, extT, Rcl, Pcl)
+    Rcw = Rci @ R_true.T
+    Pcw = -Rci @ R_true.T @ t_true + Pci
+    search = rng.choice([0, 1, 2], size=n_patches, p=[0.8, 0.15, 0.05]).astype(np.int32)
+    margin = 5 * (1 << (L - 1 + search)) + 24
+    margin = np.minimum(margin, min(cam["width"], cam["height"]) // 2 - 8)
+    u = rng.uniform(margin, cam["width"] - 1 - margin)
+    v = rng.uniform(margin, cam["height"] - 1 - margin)
+    depth = rng.uniform(2.0, 15.0, n_patches)
+    p_c = np.stack([(u - cam["cx"]) / cam["fx"] * depth, (v - cam["cy"]) / cam["fy"] * depth, depth], 1)
+    pos = (p_c - Pcw) @ Rcw                                   # Rcw^T (p_c - Pcw)
+    inv_ref = rng.uniform(0.9, 1.1, n_patches)
+    warp = np.zeros((n_patches, L, 64), np.float32)
+    for i in range(n_patches):
+        pf = Rcw @ pos[i] + Pcw
+        pc = np.array([cam["fx"] * pf[0] / pf[2] + cam["cx"], cam["fy"] * pf[1] / pf[2] + cam["cy"]])
+        for lvl in range(L):
+            cur = sample_patch(img, pc, 1 << (lvl + int(search[i]))).astype(np.float64)
+            warp[i, lvl] = (cur * (tau_true / inv_ref[i]) + rng.normal(0, noise_sigma, (8, 8))).astype(np.float32).ravel()
+    R_prior = R_true @ so3_exp(rng.normal(0, np.deg2rad(rot_sigma_deg), 3))
+    t_prior = t_true + rng.normal(0, pos_sigma, 3)
+    tau_prior = tau_true * (1.0 + rng.normal(0, 0.01))
+    return VisualScenario(img, pos, warp, search, inv_ref, R_true, t_true, tau_true, R_prior, t_prior, tau_prior, prior_cov(rng), extR, extT, Rcl, Pcl,
+                          cam, cfg)
