@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py — ESIKF measurement-update throughput on MI355X (driver contract: one JSON line from rank 0).
+
+Workload (BASELINE.json configs[1], "C2"): 100 000 synthetic LiDAR points, point-to-plane residual + Jacobian + H/b
+reduction + 19-dim solve.  One STEP = one complete ESIKF iteration over the whole scan (k_lidar_residual + k_lidar_solve),
+inputs (scan, body covariances, VoxelMap snapshot, states) resident in HBM.  metric = residual+Jacobian evaluations / s =
+points x steps / wall time (whole job, all ranks).  For --gpus N every rank runs the same-sized independent frame
+(frames shard embarrassingly; no data-path collective): scaling = "weak".
+
+Extra objects on the same line:
+  roofline      achieved = 276 B (SURVEY §8d algorithmic bytes per LiDAR point-iteration) x points / average
+                k_lidar_residual duration measured with HIP events on the launching stream; peak = 8 TB/s HBM3E.
+  cpu_baseline  the oracle ("port": restated reference CPU path, -O3 -march=native -fopenmp, 4 threads = the reference's
+                MP_PROC_NUM cap) timed on this host on the same scan: full StateEstimation calls, evals = points x iterations.
+  extra         visual path (C3: 2k patches) and full 5-iteration updates (C4-style), informational.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+LIDAR_BYTES_PER_EVAL = 276.0     # 12 (xyz f32) + 32 (hash probe) + 232 (plane record f64)        SURVEY.md §8(d)
+VISUAL_BYTES_PER_PATCH = 413.0   # 121 (u8 window) + 256 (ref patch f32) + 36 (pos, level, expo)  SURVEY.md §8(d)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_states(livo2, sc):
+    from oracle.orc import make_state          # plain struct filler (no oracle compute)
+    cur = make_state(sc.R_prior, sc.t_prior, sc.P, inv_expo=getattr(sc, "tau_prior", 1.0), cls=livo2.State)
+    prop = make_state(sc.R_prior, sc.t_prior, sc.P, inv_expo=getattr(sc, "tau_prior", 1.0), cls=livo2.State)
+    return cur, prop
+
+
+def cpu_baseline(sc, budget_s=20.0):
+    """Oracle (restated reference CPU path) timed on this host.  Bounded: at most `budget_s` seconds of StateEstimation calls."""
+    from oracle import orc
+    from tests import helpers as H
+    kind = "port"
+    try:
+        path = orc.build("fast", out_dir=tempfile.mkdtemp(prefix="orc_fast_"))     # -march=native: must be compiled on this host
+        flags = "-O3 -march=native -funroll-loops -fopenmp"
+    except Exception:
+        path = None
+        flags = "-O2 -ffp-contract=off -fopenmp (golden build; fast build failed)"
+    lib = orc.load(path)
+    om = orc.OracleMap.from_flat(sc.fmap, lib)
+    cur, prop = H.states(sc, orc.StatePOD)
+    out = {}
+    for threads in (4, 1):
+        cfg = orc.lidar_cfg(sc.cfg, sc.extR, sc.extT, num_threads=threads)
+        orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop, want_points=False)      # warm-up
+        secs, evals, runs = 0.0, 0, 0
+        while secs < budget_s * (0.7 if threads == 4 else 0.3) and runs < 40:
+            r = orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop, want_points=False)
+            secs += r["seconds"]; evals += len(sc.xyz) * r["n_iters"]; runs += 1
+        out[threads] = (evals / secs, runs)
+    return {"value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
+            "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
+            "value_1thread": out[1][0], "host_cores": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational visual / full-update legs")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the ESIKF path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    from scenarios import synth
+    from tests import helpers as H
+    livo2 = importlib.import_module("fast-livo2_amd")
+
+    # ---- workload: C2 ----------------------------------------------------------------------------------------------
+    sc = synth.lidar_scenario(seed=2 + rank, n_points=args.points, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12)
+    n = len(sc.xyz)
+    ctx = livo2.Context(local_rank)
+    cfg = H.lidar_cfg_product(sc)
+    ctx.upload_map(sc.fmap)
+    ctx.set_scan(sc.xyz, cfg)
+    cur, prop = make_states(livo2, sc)
+
+    def barrier():
+        ctx.synchronize(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.synchronize(); torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        ctx.lidar_iterations_async(cur, prop, cfg, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.lidar_iterations_async(cur, prop, cfg, args.steps)
+    ctx.synchronize(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = world * n * args.steps / elapsed
+
+    # ---- roofline leg: HIP-event duration of the dominant kernel over the same launch sequence ----------------------------
+    ctx.kernel_timing(True)
+    ctx.kernel_timing_read(0)
+    ctx.kernel_timing_read(2)
+    ctx.lidar_iterations_async(cur, prop, cfg, args.steps)
+    ms_res, n_res = ctx.kernel_timing_read(0)
+    ms_sol, n_sol = ctx.kernel_timing_read(2)
+    ctx.kernel_timing(False)
+    res_us = 1e3 * ms_res / max(n_res, 1)
+    sol_us = 1e3 * ms_sol / max(n_sol, 1)
+    achieved = LIDAR_BYTES_PER_EVAL * n / (res_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_lidar_residual", "kernel_us": res_us, "bytes_per_launch": LIDAR_BYTES_PER_EVAL * n, "solve_kernel_us": sol_us,
+                "traffic_note": "HBM PMC traffic: see profiles/ (FETCH_SIZE/WRITE_SIZE passes)"}
+
+    extra = {}
+    if rank == 0 and not args.no_extra:
+        # full StateEstimation (<=5 iterations with convergence logic), end-to-end incl. result read-back
+        reps = 20
+        ctx.lidar_update_async(cur, prop, cfg); r0 = ctx.lidar_update_fetch()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.lidar_update_async(cur, prop, cfg); r0 = ctx.lidar_update_fetch()
+        dt = (time.perf_counter() - t1) / reps
+        extra["lidar_full_update_ms"] = dt * 1e3
+        extra["lidar_full_update_iters"] = int(r0.n_iters)
+        extra["lidar_n_eff"] = int(r0.iter_sums[r0.n_iters - 1].n_eff)
+        # visual C3: 2k patches
+        vs = synth.visual_scenario(seed=3, n_patches=2000)
+        vcfg = H.visual_cfg_product(vs)
+        vcur, vprop = make_states(livo2, vs)
+        ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+        ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.warmup or 1); ctx.synchronize()
+        t1 = time.perf_counter()
+        ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.steps); ctx.synchronize()
+        dtv = time.perf_counter() - t1
+        extra["visual_evals_per_s"] = 64.0 * len(vs.pos) * args.steps / dtv
+        extra["visual_patches"] = len(vs.pos)
+        ctx.kernel_timing(True); ctx.kernel_timing_read(1)
+        ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.steps)
+        ms_v, n_v = ctx.kernel_timing_read(1)
+        ctx.kernel_timing(False)
+        v_us = 1e3 * ms_v / max(n_v, 1)
+        extra["visual_kernel_us"] = v_us
+        extra["visual_achieved_GBps"] = VISUAL_BYTES_PER_PATCH * len(vs.pos) / (v_us * 1e-6) / 1e9
+        reps = 20
+        ctx.visual_update_async(vcur, vprop, vcfg); ctx.visual_update_fetch()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.visual_update_async(vcur, vprop, vcfg); rv = ctx.visual_update_fetch()
+        extra["visual_full_update_ms"] = (time.perf_counter() - t1) / reps * 1e3
+        extra["visual_full_update_steps"] = int(rv.n_steps)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(sc)
+
+    if rank == 0:
+        line = {
+            "metric": "residual+Jacobian evals/sec (LiDAR+visual) per ESIKF iter", "value": value, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: 100k synthetic LiDAR points, point-to-plane residual+Jacobian+H/b+solve, 1 ESIKF iteration per step (BASELINE.json configs[1])",
+                       "points_per_gpu": n, "plane_records": int(sc.fmap.n_planes), "voxels": int(len(sc.fmap.root_node)), "parallelism": f"frames x{world} (no collective on the data path)"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
