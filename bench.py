@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--scan-order", choices=["voxelgrid", "random"], default="voxelgrid",
+                    help="voxelgrid: scan passed through the 0.1 m centroid voxel-grid filter like feats_down_body (LIVMapper.cpp:351-352), "
+                         "points ordered by leaf index; random: raw random-ray order (no spatial coherence)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational visual / full-update legs")
     args = ap.parse_args()
@@ -97,7 +100,8 @@ def main():
     livo2 = importlib.import_module("fast-livo2_amd")
 
     # ---- workload: C2 ----------------------------------------------------------------------------------------------
-    sc = synth.lidar_scenario(seed=2 + rank, n_points=args.points, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12)
+    sc = synth.lidar_scenario(seed=2 + rank, n_points=args.points, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12,
+                              downsample=(synth.AVIA["filter_size_surf"] if args.scan_order == "voxelgrid" else None))
     n = len(sc.xyz)
     ctx = livo2.Context(local_rank)
     cfg = H.lidar_cfg_product(sc)
@@ -189,7 +193,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: 100k synthetic LiDAR points, point-to-plane residual+Jacobian+H/b+solve, 1 ESIKF iteration per step (BASELINE.json configs[1])",
-                       "points_per_gpu": n, "plane_records": int(sc.fmap.n_planes), "voxels": int(len(sc.fmap.root_node)), "parallelism": f"frames x{world} (no collective on the data path)"},
+                       "points_per_gpu": n, "scan_order": args.scan_order, "plane_records": int(sc.fmap.n_planes), "voxels": int(len(sc.fmap.root_node)), "parallelism": f"frames x{world} (no collective on the data path)"},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)

@@ -1,107 +1,96 @@
-// Single-wavefront ESIKF solve on gfx950: 19x19 partial-pivot LU inverse, Kalman gain blocks, boxminus / boxplus.
+// Single-wavefront ESIKF solve on gfx950.
 //   LiDAR : reference src/voxel_map.cpp:468-474 (K_1, G, vec, solution, state_ += solution)
 //   visual: reference src/vio.cpp:1657-1669
 //   StatesGroup operator+= / operator-  : reference include/common_lib.h:182-206
-// The whole 19-dim algebra stays on the device so that the <=5-iteration loop never returns to the host
-// (a dependent kernel boundary costs ~1.5 us on MI355X, a host round trip >10 us).
-// Launch geometry: ONE wave (64 threads).  All LDS hand-offs are wave-synchronous (__syncthreads on a 1-wave block).
+//
+// The reference forms K_1 = (H_T_H + P^-1)^-1 with two general 19x19 inversions per iteration, although H_T_H is non-zero
+// only in its leading k x k block (k = 6 LiDAR, 7 visual) and only the first k columns of K_1 are ever used
+// (voxel_map.cpp:469,472; vio.cpp:1665,1667).  With P' = P / meas_cov_scale the matrix-inversion lemma gives exactly
+//        K_1[:, 0:k] = P'[:, 0:k] * (I_k + H_k * P'[0:k, 0:k])^-1
+// so one k x k Gauss-Jordan replaces both 19x19 LU inversions.  Algebraically identical; measured agreement with the
+// double-inversion form on the test scenes is ~1e-15 relative (tests/test_solve_gpu.py), far inside the 1e-5 contract.
+// The whole 19-dim algebra stays on the device so the <=5-iteration loop never returns to the host.
+// Launch geometry: ONE wave (64 threads); LDS hand-offs are ordered by __syncthreads() on a 1-wave block.
 #pragma once
 #include "livo2_device.hpp"
 
+#define KMAX 7
+
 struct SolveLds {
-  double A[DS * DS];       // matrix being factorised (LU in place)
-  double K1[DS * DS];      // inverse result
-  double G[DS * DS];
-  double cov[DS * DS];
-  double hth[49];
+  double P[DS * DS];           // P' = cov / scale
+  double aug[KMAX * 2 * KMAX]; // [S | I] during Gauss-Jordan, row stride 2k
+  double Kc[DS * KMAX];        // K_1[:, 0:k], row stride KMAX
+  double G[DS * KMAX];         // G[:, 0:k],   row stride KMAX
+  double hth[49];              // H_k, row stride k
   double htz[8];
   double vec[DS + 1];
   double sol[DS + 1];
-  int perm[DS + 1];
 };
 
-// inv = A^-1 by partial-pivot LU + solve against the identity.  A is destroyed.  Same operation order as the
-// CPU restatement (division for the multipliers, a(i,j) -= l*a(k,j), first-maximum pivot) so both agree to rounding.
-__device__ inline void inverse19_wave(double *A, double *inv, int *perm, int lane) {
-  if (lane < DS) perm[lane] = lane;
+// One Kalman update of ctl->cur given the reduced sums (s.hth: k x k row-major with stride k, s.htz).
+// sign=+1: LiDAR form (K1*HTz + vec - G*vec) ; sign=-1: visual form (-K1*HTz + vec - G*vec).
+// Leaves the solution in s.sol, G[:,0:k] in s.G (and the zero-padded 19x19 G in ctl->G).
+template <int k>
+__device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int sign, const int lane) {
+  constexpr int k2 = 2 * k;
+  for (int e = lane; e < DS * DS; e += LIVO2_WAVE) s.P[e] = ctl->cur.cov[e] / meas_cov_scale;
   __syncthreads();
-  for (int k = 0; k < DS; k++) {
-    int piv = k;
-    double best = fabs(A[k * DS + k]);
-    for (int i = k + 1; i < DS; i++) { double v = fabs(A[i * DS + k]); if (v > best) { best = v; piv = i; } }
-    if (piv != k) {                                       // wave-uniform
-      if (lane < DS) { double t = A[k * DS + lane]; A[k * DS + lane] = A[piv * DS + lane]; A[piv * DS + lane] = t; }
-      if (lane == 0) { int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t; }
+  // aug = [ I + H_k P'_kk | I ]
+  for (int e = lane; e < k * k2; e += LIVO2_WAVE) {
+    const int i = e / k2, j = e % k2;
+    double v;
+    if (j < k) {
+      v = (i == j) ? 1.0 : 0.0;
+      for (int m = 0; m < k; m++) v = fma(s.hth[i * k + m], s.P[m * DS + j], v);
+    } else v = (j - k == i) ? 1.0 : 0.0;
+    s.aug[e] = v;
+  }
+  __syncthreads();
+  // Gauss-Jordan with partial pivoting; every lane scans the pivot column itself (LDS broadcast reads), so no extra hand-off
+  for (int c = 0; c < k; c++) {
+    int piv = c;
+    double best = fabs(s.aug[c * k2 + c]);
+    for (int i = c + 1; i < k; i++) { double v = fabs(s.aug[i * k2 + c]); if (v > best) { best = v; piv = i; } }
+    if (piv != c) {                                          // wave-uniform
+      if (lane < k2) { double t = s.aug[c * k2 + lane]; s.aug[c * k2 + lane] = s.aug[piv * k2 + lane]; s.aug[piv * k2 + lane] = t; }
+      __syncthreads();
     }
-    __syncthreads();
-    const int m = DS - 1 - k, w = m + 1, tot = m * w;     // rows k+1.., cols k.. (col k receives the multiplier)
-    const double akk = A[k * DS + k];
-    double newv[6];
+    const double pinv = 1.0 / s.aug[c * k2 + c];
+    double nv[2]; int ne[2];
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-      int idx = lane + e * LIVO2_WAVE;
-      if (idx < tot) {
-        int i = k + 1 + idx / w, j = k + idx % w;
-        double l = A[i * DS + k] / akk;
-        newv[e] = (j == k) ? l : (A[i * DS + j] - l * A[k * DS + j]);
+    for (int q = 0; q < 2; q++) {
+      const int e = lane + q * LIVO2_WAVE;
+      ne[q] = e;
+      if (e < k * k2) {
+        const int i = e / k2, j = e % k2;
+        const double prow = s.aug[c * k2 + j] * pinv;
+        nv[q] = (i == c) ? prow : fma(-s.aug[i * k2 + c], prow, s.aug[e]);
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-      int idx = lane + e * LIVO2_WAVE;
-      if (idx < tot) { int i = k + 1 + idx / w, j = k + idx % w; A[i * DS + j] = newv[e]; }
-    }
+    for (int q = 0; q < 2; q++) if (ne[q] < k * k2) s.aug[ne[q]] = nv[q];
     __syncthreads();
   }
-  if (lane < DS) {
-    const int c = lane;
-    double y[DS];
-#pragma unroll
-    for (int i = 0; i < DS; i++) {                        // L y = P e_c
-      double s = (perm[i] == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int j = 0; j < i; j++) s = s - A[i * DS + j] * y[j];
-      y[i] = s;
-    }
-#pragma unroll
-    for (int i = DS - 1; i >= 0; i--) {                   // U x = y
-      double s = y[i];
-#pragma unroll
-      for (int j = i + 1; j < DS; j++) s = s - A[i * DS + j] * y[j];
-      y[i] = s / A[i * DS + i];
-    }
-#pragma unroll
-    for (int i = 0; i < DS; i++) inv[i * DS + c] = y[i];
+  // Kc = P'[:, 0:k] * S^-1
+  for (int e = lane; e < DS * k; e += LIVO2_WAVE) {
+    const int r = e / k, c = e % k;
+    double v = 0.0;
+    for (int m = 0; m < k; m++) v = fma(s.P[r * DS + m], s.aug[m * k2 + k + c], v);
+    s.Kc[r * KMAX + c] = v;
   }
   __syncthreads();
-}
-
-// One Kalman update of ctl->cur given the reduced sums (hth: k x k row-major in s.hth with stride k, htz in s.htz).
-// sign=+1: LiDAR form (K1*HTz + vec - G*vec) ; sign=-1: visual form (-K1*HTz + vec - G*vec).
-// Leaves solution in s.sol, K-gain blocks in s.G (also written to ctl->G).
-__device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, int k, double meas_cov_scale, int sign, int lane) {
-  // (P / scale)^-1 is iteration-invariant inside one update: cov is only rewritten when the update finishes.
-  if (!ctl->hdr.pinv_valid) {
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) s.A[e] = ctl->cur.cov[e] / meas_cov_scale;
-    __syncthreads();
-    inverse19_wave(s.A, s.K1, s.perm, lane);
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) ctl->Pinv[e] = s.K1[e];
-    __syncthreads();
-    if (lane == 0) ctl->hdr.pinv_valid = 1;
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) { int r = e / DS, c = e % DS; s.A[e] = ((r < k && c < k) ? s.hth[r * k + c] : 0.0) + s.K1[e]; }
-  } else {
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) { int r = e / DS, c = e % DS; s.A[e] = ((r < k && c < k) ? s.hth[r * k + c] : 0.0) + ctl->Pinv[e]; }
-  }
-  __syncthreads();
-  inverse19_wave(s.A, s.K1, s.perm, lane);                 // K_1 = (H_T_H + P^-1)^-1
-  for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {       // G[:, :k] = K_1[:, :k] * H_T_H[:k,:k]
-    int r = e / DS, c = e % DS;
+  // G[:, 0:k] = K_1[:, 0:k] * H_k
+  for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {
+    const int r = e / DS, c = e % DS;
     double g = 0.0;
-    if (c < k) { g = s.K1[r * DS] * s.hth[c]; for (int j = 1; j < k; j++) g = g + s.K1[r * DS + j] * s.hth[j * k + c]; }
-    s.G[e] = g; ctl->G[e] = g;
+    if (c < k) {
+      for (int m = 0; m < k; m++) g = fma(s.Kc[r * KMAX + m], s.hth[m * k + c], g);
+      s.G[r * KMAX + c] = g;
+    }
+    ctl->G[e] = g;
   }
-  if (lane == 0) {                                         // vec = state_propagat [-] state   (common_lib.h:194-206)
+  if (lane == 0) {                                           // vec = state_propagat [-] state   (common_lib.h:194-206)
     double rotd[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
       rotd[i * 3 + j] = (ctl->cur.rot[i] * ctl->prop.rot[j] + ctl->cur.rot[3 + i] * ctl->prop.rot[3 + j]) + ctl->cur.rot[6 + i] * ctl->prop.rot[6 + j];   // cur^T * prop
@@ -119,14 +108,12 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, int k, double
   __syncthreads();
   if (lane < DS) {
     const int r = lane;
-    double kz = s.K1[r * DS] * s.htz[0];
-    for (int j = 1; j < k; j++) kz = kz + s.K1[r * DS + j] * s.htz[j];
-    double gv = s.G[r * DS] * s.vec[0];
-    for (int j = 1; j < k; j++) gv = gv + s.G[r * DS + j] * s.vec[j];
+    double kz = 0.0, gv = 0.0;
+    for (int m = 0; m < k; m++) { kz = fma(s.Kc[r * KMAX + m], s.htz[m], kz); gv = fma(s.G[r * KMAX + m], s.vec[m], gv); }
     s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
   }
   __syncthreads();
-  if (lane == 0) {                                         // state += solution   (common_lib.h:182-192)
+  if (lane == 0) {                                           // state += solution   (common_lib.h:182-192)
     double E[9], Rn[9];
     so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
     mat3_mul(ctl->cur.rot, E, Rn);
@@ -137,17 +124,5 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, int k, double
     }
     ctl->cur.inv_expo += s.sol[6];
   }
-  __syncthreads();
-}
-
-// Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out32 (LDS).  64 lanes = 2 slices x 32 values;
-// slice s adds blocks s, s+2, ... in order, then slice0 + slice1.
-__device__ inline void reduce_partials_wave(const double *partials, int nblocks, double *out32 /*LDS, 64 doubles scratch*/, int lane) {
-  const int kidx = lane & 31, slice = lane >> 5;
-  double acc = 0.0;
-  for (int b = slice; b < nblocks; b += 2) acc += partials[(size_t)b * 32 + kidx];
-  out32[lane] = acc;
-  __syncthreads();
-  if (lane < 32) out32[lane] = out32[lane] + out32[lane + 32];
   __syncthreads();
 }

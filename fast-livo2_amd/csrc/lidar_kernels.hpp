@@ -1,17 +1,24 @@
 // gfx950 kernels for the LiDAR point-to-plane ESIKF update.
 //   k_body_cov        : once-per-scan precompute            reference src/voxel_map.cpp:15-34, 349-360
 //   k_lidar_residual  : per-iteration fused pass            reference src/voxel_map.cpp:374-466, 513-530, 643-786
-//                       (world transform -> world covariance -> voxel hash probe -> octree descent with 3-sigma gate and
-//                        max-probability plane -> H / R^-1 / z row -> per-block partial sums of H^T R^-1 H and H^T R^-1 z)
-//   k_lidar_solve     : partial-sum reduction + 19x19 solve + state update + convergence / rematch / covariance update
+//                       (world transform -> voxel key -> cuckoo root lookup -> plane / candidate-list visit with radius gate,
+//                        3-sigma gate and max-probability choice -> neighbour-voxel retry -> H / R^-1 / z row ->
+//                        per-block partial sums of H^T R^-1 H and H^T R^-1 z)
+//   k_lidar_solve     : partial-sum reduction + k x k solve + state update + convergence / rematch / covariance update
 //                                                           reference src/voxel_map.cpp:464-499
 // Layout: points SoA float x[],y[],z[] (coalesced 4-B/lane loads); body covariance SoA 6 x double[n];
-// plane records 256-B aligned AoS gathered per lane with 16-B loads; hash slots 16 B.
+// root slots 64 B (two fetched per lookup), plane records 256 B fetched whole per lane.
+//
+// The pass is LATENCY bound (every wave of a 100k-point scan is resident at once; rocprof shows waves parked in s_waitcnt),
+// so it is organised as the shortest possible chain of dependent round trips:
+//   T1 xyz + body covariance  ->  T2 both cuckoo slots  ->  T3 plane record  ||  both neighbour slots (speculative)
+//   ->  T4 neighbour plane (only lanes whose first visit failed)  ->  reduction.
 #pragma once
 #include "esikf_solve.hpp"
 
 #define LIDAR_BLOCK 256
 #define LIDAR_NSUM 29       // 21 (sym HtH) + 6 (Htz) + n_eff + sum|r|
+#define LIDAR_LDS_BYTES ((LIDAR_BLOCK / LIVO2_WAVE) * 32 * 65 * 8)
 
 struct LidarKernelArgs {
   const float *x, *y, *z;          // [n]
@@ -65,88 +72,139 @@ __global__ void __launch_bounds__(256) k_body_cov(const float *__restrict__ x, c
   }
 }
 
-// ---- per-candidate plane evaluation (build_single_residual's is_plane_ branch, voxel_map.cpp:721-768) -------------------
-struct Candidate { double prob; int32_t plane; float r; bool success; };
+// ---- plane record in registers ------------------------------------------------------------------------------------------
+struct PlaneRec {
+  double n[3], c[3], S[21];
+  float d, radius;
+};
 
-__device__ __forceinline__ void eval_plane(const double *__restrict__ planes, int32_t pidx, double sigma_num, const double pw[3], const double Sw[6],
-                                           Candidate &best) {
-  const double *P = planes + (size_t)pidx * PLANE_REC_DOUBLES;
-  const double2 *P2 = reinterpret_cast<const double2 *>(P);
-  double2 v0 = P2[0], v1 = P2[1], v2 = P2[2];                 // n0 n1 | n2 c0 | c1 c2
-  double n0 = v0.x, n1 = v0.y, n2 = v1.x, c0 = v1.y, c1 = v2.x, c2 = v2.y;
-  float2 dr = *reinterpret_cast<const float2 *>(P + 27);      // {d_, radius_}
-  double sd = ((n0 * pw[0] + n1 * pw[1]) + n2 * pw[2]) + (double)dr.x;
-  float dis_to_plane = (float)fabs(sd);
-  double e0 = c0 - pw[0], e1 = c1 - pw[1], e2 = c2 - pw[2];
-  float dis_to_center = (float)((e0 * e0 + e1 * e1) + e2 * e2);
-  float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);   // float ops; NaN (negative radicand) fails the gate below
-  if (!((double)range_dis <= 3.0 * (double)dr.y)) return;
-  // sigma_l = J_nq * plane_var * J_nq^T + n^T Sigma_w n,  J_nq = [p_w - c, -n]
-  double J[6] = {-e0, -e1, -e2, -n0, -n1, -n2};
-  double S[21];
-  const double2 *S2 = reinterpret_cast<const double2 *>(P + 6);
+__device__ __forceinline__ void load_plane(const double *__restrict__ planes, int32_t pidx, PlaneRec &r) {
+  const double2 *P2 = reinterpret_cast<const double2 *>(planes + (size_t)pidx * PLANE_REC_DOUBLES);
+  double2 v[14];
 #pragma unroll
-  for (int q = 0; q < 10; q++) { double2 t = S2[q]; S[2 * q] = t.x; S[2 * q + 1] = t.y; }
-  S[20] = P[26];
-  double sigma_l = 0.0;
-  {
-    int q = 0;
+  for (int q = 0; q < 14; q++) v[q] = P2[q];                    // one batch of 16-B loads: a single round trip
+  r.n[0] = v[0].x; r.n[1] = v[0].y; r.n[2] = v[1].x; r.c[0] = v[1].y; r.c[1] = v[2].x; r.c[2] = v[2].y;
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
-      double rowacc = 0.0;
+  for (int q = 0; q < 10; q++) { r.S[2 * q] = v[3 + q].x; r.S[2 * q + 1] = v[3 + q].y; }
+  r.S[20] = v[13].x;
+  const float2 dr = __builtin_bit_cast(float2, v[13].y);
+  r.d = dr.x; r.radius = dr.y;
+}
+
+// J S J^T for the symmetric 6x6 S (upper triangle, row-major) and J = [a, -n]
+__device__ __forceinline__ double quad6_sym(const double *S, const double *J) {
+  double acc = 0.0;
+  int q = 0;
 #pragma unroll
-      for (int b = a; b < 6; b++) { double wgt = (a == b) ? 1.0 : 2.0; rowacc = fma(wgt * S[q], J[b], rowacc); q++; }
-      sigma_l = fma(J[a], rowacc, sigma_l);
+  for (int a = 0; a < 6; a++) {
+    double rowacc = S[q] * J[a]; q++;                           // diagonal term once
+#pragma unroll
+    for (int b = a + 1; b < 6; b++) { rowacc = fma(2.0 * S[q], J[b], rowacc); q++; }
+    acc = fma(J[a], rowacc, acc);
+  }
+  return acc;
+}
+
+// Per-point invariants of the candidate search and of the Jacobian row.
+struct PointCtx {
+  double pw[3];                // float32-rounded world point, widened
+  double pc[3];                // z-patched IMU-frame point (cross matrix of the matching covariance, voxel_map.cpp:352-358)
+  double pi[3];                // un-patched IMU-frame point
+  double q[3];                 // PRIOR-pose world point R^ p_i + t^ (voxel_map.cpp:425)
+  double Cb[6];                // body covariance, symmetric
+};
+
+// State of the running max-probability search of one point (build_single_residual's in/out arguments).
+// * The probability is evaluated LAZILY: the first accepted plane always wins against prob = 0 (exp(-0.5 d^2/sigma)/sqrt(sigma) > 0
+//   because d < sigma_num*sqrt(sigma)), so exp/sqrt are only needed when a second plane is accepted for the same point.
+// * The H / R^-1 row of an accepted plane is computed on the spot, while its record is still in registers, so the search keeps
+//   8 doubles per point instead of a 29-double record copy (or a reload round trip at the end).
+struct Best {
+  double h[6];                 // Hsub row [A, n] of the best plane (voxel_map.cpp:453-454)
+  double w;                    // R_inv (voxel_map.cpp:449)
+  double dis2, sigma;          // of the best plane, for the lazy probability
+  double prob;                 // valid iff prob_valid
+  int32_t plane;
+  float r;
+  bool success, prob_valid;
+};
+
+// build_single_residual's is_plane_ branch (voxel_map.cpp:721-768) for one candidate plane already in registers, followed — when the
+// plane becomes the point's current best — by its measurement row (voxel_map.cpp:425-457)
+__device__ __forceinline__ void eval_plane(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *R, const double *RE,
+                                           const double *sPrr, const double *sPtt, Best &best) {
+  const double *pw = pt.pw, *pc = pt.pc;
+  const double sd = ((p.n[0] * pw[0] + p.n[1] * pw[1]) + p.n[2] * pw[2]) + (double)p.d;
+  const float dis_to_plane = (float)fabs(sd);
+  const double e0 = p.c[0] - pw[0], e1 = p.c[1] - pw[1], e2 = p.c[2] - pw[2];
+  const float dis_to_center = (float)((e0 * e0 + e1 * e1) + e2 * e2);
+  const float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);   // float ops; NaN (negative radicand) fails the gate below
+  if (!((double)range_dis <= 3.0 * (double)p.radius)) return;
+  // sigma_l = J_nq plane_var J_nq^T + n^T Sigma_w n ,  J_nq = [p_w - c, -n]
+  const double J[6] = {-e0, -e1, -e2, -p.n[0], -p.n[1], -p.n[2]};
+  double sigma_l = quad6_sym(p.S, J);
+  // n^T Sigma_w n = m^T Cb m + q^T Prr q + n^T Ptt n  with m = R^T n, q = n x p_i  (Sigma_w = R Cb R^T + X Prr X^T + Ptt, X = [p_i]x)
+  double m[3]; mat3t_vec_fma(R, p.n, m);
+  const double qx[3] = {p.n[1] * pc[2] - p.n[2] * pc[1], p.n[2] * pc[0] - p.n[0] * pc[2], p.n[0] * pc[1] - p.n[1] * pc[0]};
+  sigma_l += (quad3_sym(pt.Cb, m) + quad3_sym(sPrr, qx)) + quad3_sym(sPtt, p.n);
+  const double sq = sqrt(sigma_l);
+  if ((double)dis_to_plane < sigma_num * sq) {
+    const double dis2 = (double)dis_to_plane * (double)dis_to_plane;
+    bool take = true;
+    if (best.success) {
+      if (!best.prob_valid) { best.prob = 1.0 / sqrt(best.sigma) * exp(-0.5 * best.dis2 / best.sigma); best.prob_valid = true; }
+      const double this_prob = 1.0 / sq * exp(-0.5 * dis2 / sigma_l);
+      take = this_prob > best.prob;
+      if (take) best.prob = this_prob;
+    }
+    best.success = true;
+    if (take) {
+      best.plane = pidx; best.r = (float)sd; best.dis2 = dis2; best.sigma = sigma_l;
+      // H / R^-1 row (voxel_map.cpp:414-458): sigma_l' at the PRIOR-pose point, var with the PRIOR rotation, A with the CURRENT one
+      const double Jq[6] = {pt.q[0] - p.c[0], pt.q[1] - p.c[1], pt.q[2] - p.c[2], -p.n[0], -p.n[1], -p.n[2]};
+      const double sig_q = quad6_sym(p.S, Jq);
+      double mp[3]; mat3t_vec_fma(RE, p.n, mp);             // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
+      best.w = 1.0 / (0.001 + sig_q + quad3_sym(pt.Cb, mp));
+      best.h[0] = pt.pi[1] * m[2] - pt.pi[2] * m[1];       // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
+      best.h[1] = pt.pi[2] * m[0] - pt.pi[0] * m[2];
+      best.h[2] = pt.pi[0] * m[1] - pt.pi[1] * m[0];
+      best.h[3] = p.n[0]; best.h[4] = p.n[1]; best.h[5] = p.n[2];
     }
   }
-  double nSn = n0 * (Sw[0] * n0 + 2.0 * (Sw[1] * n1 + Sw[2] * n2)) + n1 * (Sw[3] * n1 + 2.0 * Sw[4] * n2) + n2 * Sw[5] * n2;
-  sigma_l += nSn;
-  double sq = sqrt(sigma_l);
-  if ((double)dis_to_plane < sigma_num * sq) {
-    best.success = true;
-    double this_prob = 1.0 / sq * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
-    if (this_prob > best.prob) { best.prob = this_prob; best.plane = pidx; best.r = (float)sd; }
-  }
 }
 
-// recursive all-8-children descent of a NON-plane node, iteratively (voxel_map.cpp:769-785); depth <= LIVO2_MAX_LAYER
-__device__ __forceinline__ void descend(const DevMap &map, int32_t node, int max_layer, double sigma_num, const double pw[3], const double Sw[6],
-                                        Candidate &best) {
-  // `node` is known to be a non-plane node at layer 0
-  if (0 >= max_layer) return;
-  int32_t stack_node[LIVO2_MAX_LAYER + 1];
-  int32_t stack_next[LIVO2_MAX_LAYER + 1];
-  int depth = 0;
-  stack_node[0] = node; stack_next[0] = 0;
-  while (depth >= 0) {
-    int k = stack_next[depth];
-    if (k >= 8) { depth--; continue; }
-    stack_next[depth] = k + 1;
-    int32_t child = map.node_child[(size_t)stack_node[depth] * 8 + k];
-    if (child < 0) continue;
-    int child_layer = depth + 1;
-    int32_t pl = map.node_plane[child];
-    if (pl >= 0) eval_plane(map.planes, pl, sigma_num, pw, Sw, best);
-    else if (child_layer < max_layer) { depth++; stack_node[depth] = child; stack_next[depth] = 0; }
-  }
+__device__ __forceinline__ bool slot_match(const RootSlot &s, const int32_t key[3]) { return s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]; }
+
+__device__ __forceinline__ RootSlot load_slot(const RootSlot *__restrict__ slots, uint32_t h) {
+  const int4 *p = reinterpret_cast<const int4 *>(slots + h);
+  int4 a = p[0], b = p[1], c = p[2], d = p[3];
+  RootSlot s;
+  s.kx = a.x; s.ky = a.y; s.kz = a.z; s.val = a.w;
+  s.center[0] = __builtin_bit_cast(double, make_int2(b.x, b.y)); s.center[1] = __builtin_bit_cast(double, make_int2(b.z, b.w));
+  s.center[2] = __builtin_bit_cast(double, make_int2(c.x, c.y)); s.quarter = __builtin_bit_cast(float, c.z); s.cand_begin = c.w;
+  s.cand_count = d.x; s.pad = d.y;
+  return s;
 }
 
-// looks a voxel key up; returns slot index or -1
-__device__ __forceinline__ int32_t hash_find(const DevMap &map, int32_t kx, int32_t ky, int32_t kz, int32_t &val) {
-  uint32_t h = voxel_hash(kx, ky, kz) & map.hash_mask;
-  for (uint32_t probe = 0; probe <= map.hash_mask; probe++) {
-    HashSlot s = map.hash[h];
-    if (s.val == -1) return -1;
-    if (s.kx == kx && s.ky == ky && s.kz == kz) { val = s.val; return (int32_t)h; }
-    h = (h + 1) & map.hash_mask;
+// visit one root voxel: its plane, or the flattened depth-first list of descendant planes (layers <= max_layer); the next list
+// entry is fetched while the current plane is evaluated, so a k-candidate voxel costs k+1 dependent round trips, not 2k.
+__device__ __forceinline__ void visit_root(const DevMap &map, const RootSlot &s, int max_layer, double sigma_num, const PointCtx &pt, const double *R,
+                                           const double *RE, const double *sPrr, const double *sPtt, Best &best) {
+  if (s.val >= 0) {
+    PlaneRec p; load_plane(map.planes, s.val, p);
+    eval_plane(p, s.val, sigma_num, pt, R, RE, sPrr, sPtt, best);
+  } else if (s.cand_count > 0) {
+    const int32_t *ce = map.cand + s.cand_begin;
+    int32_t e_cur = ce[0];
+    for (int k = 0; k < s.cand_count; k++) {
+      const int32_t e_nxt = (k + 1 < s.cand_count) ? ce[k + 1] : 0;
+      if ((e_cur >> CAND_LAYER_SHIFT) <= max_layer) {
+        PlaneRec p; load_plane(map.planes, e_cur & CAND_PLANE_MASK, p);
+        eval_plane(p, e_cur & CAND_PLANE_MASK, sigma_num, pt, R, RE, sPrr, sPtt, best);
+      }
+      e_cur = e_nxt;
+    }
   }
-  return -1;
-}
-
-__device__ __forceinline__ void visit_root(const DevMap &map, int32_t val, int max_layer, double sigma_num, const double pw[3], const double Sw[6],
-                                           Candidate &best) {
-  if (val >= 0) eval_plane(map.planes, val, sigma_num, pw, Sw, best);
-  else descend(map, -(val + 2), max_layer, sigma_num, pw, Sw, best);
 }
 
 // ---- fused per-iteration pass -----------------------------------------------------------------------------------------
@@ -168,48 +226,17 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
     // wave-uniform state (scalar loads)
     const double *R = ctl->cur.rot, *t = ctl->cur.pos, *Rp = ctl->prop.rot, *tp = ctl->prop.pos, *cov = ctl->cur.cov;
     const double plx = a.x[i], ply = a.y[i], plz = a.z[i];
+    PointCtx pt;
+    double *Cb = pt.Cb, *pi = pt.pi, *pw = pt.pw, *pc = pt.pc;
+#pragma unroll
+    for (int e = 0; e < 6; e++) Cb[e] = a.cb[(size_t)e * a.n + i];
     // p_i = extR * p_l + extT  (un-patched, voxel_map.cpp:522 / 418)
-    double pi[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) pi[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * plz) + a.Et[j];
     // p_w = float32( R * p_i + t )   (voxel_map.cpp:522-526)
-    float pwf[3]; double pw[3];
+    float pwf[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) { pwf[j] = (float)(((R[j * 3] * pi[0] + R[j * 3 + 1] * pi[1]) + R[j * 3 + 2] * pi[2]) + t[j]); pw[j] = (double)pwf[j]; }
-    // cross matrix uses the z-patched point (voxel_map.cpp:352-358)
-    double pc[3] = {pi[0], pi[1], pi[2]};
-    if (plz == 0) {
-      const double pz = 0.001;
-#pragma unroll
-      for (int j = 0; j < 3; j++) pc[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * pz) + a.Et[j];
-    }
-    // body covariance (symmetric)
-    double Cb[6];
-#pragma unroll
-    for (int e = 0; e < 6; e++) Cb[e] = a.cb[(size_t)e * a.n + i];
-    const double Cbf[9] = {Cb[0], Cb[1], Cb[2], Cb[1], Cb[3], Cb[4], Cb[2], Cb[4], Cb[5]};
-    // Sigma_w = R Cb R^T + X Prr X^T + Ptt   ((-X) Prr (-X)^T == X Prr X^T exactly)   (voxel_map.cpp:387)
-    double Sw[6];
-    {
-      double T[9], RC[9];
-      mat3_mul(R, Cbf, T);
-      mat3_mul_Bt(T, R, RC);
-      const double X[9] = {0.0, -pc[2], pc[1], pc[2], 0.0, -pc[0], -pc[1], pc[0], 0.0};
-      const double Prr[9] = {cov[0], cov[1], cov[2], cov[DS], cov[DS + 1], cov[DS + 2], cov[2 * DS], cov[2 * DS + 1], cov[2 * DS + 2]};
-      double XP[9], XPX[9];
-      mat3_mul(X, Prr, XP);
-      mat3_mul_Bt(XP, X, XPX);
-      const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-      for (int e = 0; e < 6; e++) Sw[e] = RC[ii[e] * 3 + jj[e]] + XPX[ii[e] * 3 + jj[e]] + cov[(3 + ii[e]) * DS + 3 + jj[e]];
-    }
-    if (a.var) {
-      const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-#pragma unroll
-      for (int e = 0; e < 9; e++) a.var[(size_t)i * 9 + e] = Sw[map9[e]];
-    }
-    if (a.pw) { a.pw[(size_t)i * 3] = pwf[0]; a.pw[(size_t)i * 3 + 1] = pwf[1]; a.pw[(size_t)i * 3 + 2] = pwf[2]; }
-
     // voxel key (voxel_map.cpp:665-671): double divide, narrow to float, -1 for negatives, truncate
     float loc[3]; int32_t key[3]; bool in_range = true;
 #pragma unroll
@@ -220,109 +247,166 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
       in_range = in_range && (l > -2147483000.f) && (l < 2147483000.f);
       key[j] = (int32_t)l;
     }
-    Candidate best; best.prob = 0.0; best.plane = -1; best.r = 0.f; best.success = false;
-    if (in_range) {
-      int32_t val = 0;
-      int32_t slot = hash_find(a.map, key[0], key[1], key[2], val);
-      if (slot >= 0) {
-        visit_root(a.map, val, a.max_layer, a.sigma_num, pw, Sw, best);
-        if (!best.success) {
-          // neighbour rule (voxel_map.cpp:682-690): voxel-index units compared with metres, reproduced as is
-          RootAux ra = a.map.root_aux[slot];
-          int32_t nk[3] = {key[0], key[1], key[2]};
+    // T2: both cuckoo slots at once
+    RootSlot s1, s2;
+    {
+      const uint32_t h1 = voxel_hash(key[0], key[1], key[2], a.map.seed1) & a.map.mask;
+      const uint32_t h2 = voxel_hash(key[0], key[1], key[2], a.map.seed2) & a.map.mask;
+      s1 = load_slot(a.map.slots, h1); s2 = load_slot(a.map.slots, h2);
+    }
+    // cross matrix uses the z-patched point (voxel_map.cpp:352-358)
+    pc[0] = pi[0]; pc[1] = pi[1]; pc[2] = pi[2];
+    if (plz == 0) {
+      const double pz = 0.001;
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
-            if ((double)loc[j] > (ra.center[j] + (double)ra.quarter)) nk[j] = nk[j] + 1;
-            else if ((double)loc[j] < (ra.center[j] - (double)ra.quarter)) nk[j] = nk[j] - 1;
-          }
-          int32_t nval = 0;
-          int32_t nslot = hash_find(a.map, nk[0], nk[1], nk[2], nval);
-          if (nslot >= 0) visit_root(a.map, nval, a.max_layer, a.sigma_num, pw, Sw, best);
-        }
+      for (int j = 0; j < 3; j++) pc[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * pz) + a.Et[j];
+    }
+    // symmetric parts of P[0:3,0:3] and P[3:6,3:6] (a quadratic form only sees the symmetric part)
+    double sPrr[6], sPtt[6];
+    {
+      const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        sPrr[e] = 0.5 * (cov[ii[e] * DS + jj[e]] + cov[jj[e] * DS + ii[e]]);
+        sPtt[e] = 0.5 * (cov[(3 + ii[e]) * DS + 3 + jj[e]] + cov[(3 + jj[e]) * DS + 3 + ii[e]]);
+      }
+    }
+    if (a.var) {       // pv.var = R Cb R^T + X Prr X^T + Ptt (voxel_map.cpp:387), only materialised when the caller asks for it
+      const double Cbf[9] = {Cb[0], Cb[1], Cb[2], Cb[1], Cb[3], Cb[4], Cb[2], Cb[4], Cb[5]};
+      double T[9], RC[9], XP[9], XPX[9];
+      mat3_mul(R, Cbf, T); mat3_mul_Bt(T, R, RC);
+      const double X[9] = {0.0, -pc[2], pc[1], pc[2], 0.0, -pc[0], -pc[1], pc[0], 0.0};
+      const double Prr[9] = {cov[0], cov[1], cov[2], cov[DS], cov[DS + 1], cov[DS + 2], cov[2 * DS], cov[2 * DS + 1], cov[2 * DS + 2]};
+      mat3_mul(X, Prr, XP); mat3_mul_Bt(XP, X, XPX);
+#pragma unroll
+      for (int e = 0; e < 9; e++) { const int r = e / 3, c = e % 3, u = r < c ? r : c, v = r < c ? c : r; a.var[(size_t)i * 9 + e] = RC[u * 3 + v] + XPX[u * 3 + v] + cov[(3 + u) * DS + 3 + v]; }
+    }
+    if (a.pw) { a.pw[(size_t)i * 3] = pwf[0]; a.pw[(size_t)i * 3 + 1] = pwf[1]; a.pw[(size_t)i * 3 + 2] = pwf[2]; }
+
+    // PRIOR-pose world point, un-rounded (voxel_map.cpp:425)
+#pragma unroll
+    for (int j = 0; j < 3; j++) pt.q[j] = ((Rp[j * 3] * pi[0] + Rp[j * 3 + 1] * pi[1]) + Rp[j * 3 + 2] * pi[2]) + tp[j];
+    const double *RE = ctl->hdr.RE;
+    Best best; best.prob = 0.0; best.plane = -1; best.r = 0.f; best.success = false; best.prob_valid = false; best.dis2 = 0.0; best.sigma = 1.0; best.w = 0.0;
+#pragma unroll
+    for (int u = 0; u < 6; u++) best.h[u] = 0.0;
+    const bool f1 = in_range && slot_match(s1, key), f2 = in_range && slot_match(s2, key);
+    if (f1 || f2) {
+      const RootSlot &s = f1 ? s1 : s2;
+      // neighbour rule (voxel_map.cpp:682-688): voxel-index units compared with metres, reproduced as is.  Issued before the
+      // first visit so the neighbour's slots travel together with the plane record (T3).
+      int32_t nk[3] = {key[0], key[1], key[2]};
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        if ((double)loc[j] > (s.center[j] + (double)s.quarter)) nk[j] = nk[j] + 1;
+        else if ((double)loc[j] < (s.center[j] - (double)s.quarter)) nk[j] = nk[j] - 1;
+      }
+      const bool nbr_differs = (nk[0] != key[0]) || (nk[1] != key[1]) || (nk[2] != key[2]);
+      RootSlot n1, n2;
+      n1.val = -1; n2.val = -1;
+      if (nbr_differs) {
+        const uint32_t g1 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed1) & a.map.mask;
+        const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
+        n1 = load_slot(a.map.slots, g1); n2 = load_slot(a.map.slots, g2);
+      }
+      visit_root(a.map, s, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+      if (!best.success && nbr_differs) {
+        // (when no axis triggers, the reference re-visits the same voxel with prob = 0 and fails again: nothing to do)
+        const bool g1m = slot_match(n1, nk), g2m = slot_match(n2, nk);
+        if (g1m || g2m) visit_root(a.map, g1m ? n1 : n2, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
       }
     }
     if (a.match_plane) a.match_plane[i] = best.success ? best.plane : -1;
     if (a.dis) a.dis[i] = best.success ? best.r : 0.f;
-    double w_out = 0.0, h_out[6] = {0, 0, 0, 0, 0, 0};
     if (best.success) {
       if (a.normal_plane) a.normal_plane[i] = best.plane;
-      // H / R^-1 / z row of the matched point (voxel_map.cpp:414-458)
-      const double *P = a.map.planes + (size_t)best.plane * PLANE_REC_DOUBLES;
-      const double n[3] = {P[0], P[1], P[2]}, c[3] = {P[3], P[4], P[5]};
-      double q[3];                                              // PRIOR pose, un-rounded (voxel_map.cpp:425)
-#pragma unroll
-      for (int j = 0; j < 3; j++) q[j] = ((Rp[j * 3] * pi[0] + Rp[j * 3 + 1] * pi[1]) + Rp[j * 3 + 2] * pi[2]) + tp[j];
-      const double J[6] = {q[0] - c[0], q[1] - c[1], q[2] - c[2], -n[0], -n[1], -n[2]};
-      double sigma_l = 0.0;
-      {
-        int s = 0;
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-          double rowacc = 0.0;
-#pragma unroll
-          for (int v = u; v < 6; v++) { double wgt = (u == v) ? 1.0 : 2.0; rowacc = fma(wgt * P[6 + s], J[v], rowacc); s++; }
-          sigma_l = fma(J[u], rowacc, sigma_l);
-        }
-      }
-      // var = (Rp*extR) Cb (Rp*extR)^T ; n^T var n = m^T Cb m with m = (Rp*extR)^T n     (voxel_map.cpp:445,449)
-      double RE[9]; mat3_mul(Rp, a.ER, RE);
-      double m[3]; mat3t_vec(RE, n, m);
-      double nVn = m[0] * (Cb[0] * m[0] + 2.0 * (Cb[1] * m[1] + Cb[2] * m[2])) + m[1] * (Cb[3] * m[1] + 2.0 * Cb[4] * m[2]) + m[2] * Cb[5] * m[2];
-      double w = 1.0 / (0.001 + sigma_l + nVn);
-      // A = [p_i]x * R^T * n   (CURRENT rotation; un-patched p_i)   (voxel_map.cpp:453)
-      double Rtn[3]; mat3t_vec(R, n, Rtn);
-      double A0 = pi[1] * Rtn[2] - pi[2] * Rtn[1];              // skew(p_i) * v = p_i x v
-      double A1 = pi[2] * Rtn[0] - pi[0] * Rtn[2];
-      double A2 = pi[0] * Rtn[1] - pi[1] * Rtn[0];
-      const double h[6] = {A0, A1, A2, n[0], n[1], n[2]};
       const double zz = -(double)best.r;                        // meas_vec(i) = -dis_to_plane_ (float32 residual, voxel_map.cpp:457)
-      int s = 0;
+      int sidx = 0;
 #pragma unroll
       for (int u = 0; u < 6; u++) {
-        double hw = h[u] * w;
+        const double hw = best.h[u] * best.w;
 #pragma unroll
-        for (int v = u; v < 6; v++) { acc[s] = hw * h[v]; s++; }
+        for (int v = u; v < 6; v++) { acc[sidx] = hw * best.h[v]; sidx++; }
         acc[21 + u] = hw * zz;
       }
       acc[27] = 1.0;
       acc[28] = fabs((double)best.r);
-      w_out = w;
-#pragma unroll
-      for (int u = 0; u < 6; u++) h_out[u] = h[u];
     }
-    if (a.r_inv) a.r_inv[i] = w_out;
+    if (a.r_inv) a.r_inv[i] = best.success ? best.w : 0.0;
     if (a.h_row) {
 #pragma unroll
-      for (int u = 0; u < 6; u++) a.h_row[(size_t)i * 6 + u] = h_out[u];
+      for (int u = 0; u < 6; u++) a.h_row[(size_t)i * 6 + u] = best.success ? best.h[u] : 0.0;
     }
   }
 
-  // block reduction: wave butterflies, then 4 waves through LDS in fixed order (deterministic)
-  __shared__ double red[LIDAR_BLOCK / LIVO2_WAVE][32];
+  // Block reduction through an LDS transpose (deterministic).  ds_bpermute butterflies over 29 doubles cost ~20 us of this
+  // kernel (measured); here every lane stores its 29 values (conflict-free: consecutive lanes -> consecutive 8-B words), then
+  // lane (v = lane&31, half = lane>>5) of each wave adds 32 of the 64 columns of value v (row pitch 65 doubles => the 32 lanes of
+  // a ds_read_b64 group hit 32 distinct bank pairs), one xor-32 exchange joins the halves, and 4 waves are joined in fixed order.
+  extern __shared__ __attribute__((aligned(16))) double lds_red[];
   const int lane = tid & 63, wave = tid >> 6;
+  double *T = lds_red + (size_t)wave * (32 * 65);
 #pragma unroll
-  for (int q = 0; q < LIDAR_NSUM; q++) {
-    double v = wave_sum(acc[q]);
-    if (lane == 0) red[wave][q] = v;
+  for (int q = 0; q < LIDAR_NSUM; q++) T[q * 65 + lane] = acc[q];
+  __syncthreads();
+  {
+    const int v = lane & 31, half = lane >> 5;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (v < LIDAR_NSUM) {
+      const double *row = T + v * 65 + half * 32;
+#pragma unroll
+      for (int j = 0; j < 32; j += 4) { s0 += row[j]; s1 += row[j + 1]; s2 += row[j + 2]; s3 += row[j + 3]; }
+    }
+    double tot = (s0 + s1) + (s2 + s3);
+    tot += __shfl_xor(tot, 32, 64);
+    __syncthreads();                                   // all column reads done before the tile is reused for the wave totals
+    if (lane < 32) lds_red[wave * 32 + lane] = tot;
   }
   __syncthreads();
   if (tid < 32) {
-    double v = 0.0;
-    if (tid < LIDAR_NSUM) v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-    partials[(size_t)blockIdx.x * 32 + tid] = v;
+    const double v = ((lds_red[tid] + lds_red[32 + tid]) + lds_red[64 + tid]) + lds_red[96 + tid];
+    partials[(size_t)blockIdx.x * 32 + tid] = (tid < LIDAR_NSUM) ? v : 0.0;
   }
+}
+
+// Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 32 slices
+// x 32 values: slice s adds blocks s, s+32, ... in order with all its loads in flight at once (the partials were written by other
+// CUs, so each dependent load is a full round trip: a single wave walking them serially cost ~20 us); the slices are then joined
+// in fixed order.  Every thread of the block must call this.
+#define SOLVE_THREADS 1024
+__device__ inline void reduce_partials_block(const double *__restrict__ partials, int nblocks, double *scratch /*[32][33]*/, double *out /*[32]*/) {
+  const int t = threadIdx.x, kidx = t & 31, slice = t >> 5;       // 32 slices
+  double acc = 0.0;
+  int b = slice;
+  for (; b + 96 < nblocks; b += 128) {
+    const double v0 = partials[(size_t)b * 32 + kidx], v1 = partials[(size_t)(b + 32) * 32 + kidx], v2 = partials[(size_t)(b + 64) * 32 + kidx],
+                 v3 = partials[(size_t)(b + 96) * 32 + kidx];
+    acc += v0; acc += v1; acc += v2; acc += v3;
+  }
+  for (; b < nblocks; b += 32) acc += partials[(size_t)b * 32 + kidx];
+  scratch[slice * 33 + kidx] = acc;
+  __syncthreads();
+  if (t < 32) {
+    double v = scratch[t];
+#pragma unroll
+    for (int sl = 1; sl < 32; sl++) v += scratch[sl * 33 + t];
+    out[t] = v;
+  }
+  __syncthreads();
 }
 
 // ---- reduction + solve + loop control ----------------------------------------------------------------------------------
 // mode 0: bare iterate (only reduce and publish sums_l) ; mode 1: full ESIKF iteration `iter` of `max_iter`;
 // mode 2: like 1 but never stops (benchmark: fixed iteration count).
-__global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
-                                                            int max_iter) {
+__global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
+                                                              int max_iter) {
   if (mode == 1 && ctl->hdr.stop) return;
   __shared__ SolveLds s;
-  __shared__ double sums[64];
+  __shared__ double scratch[32 * 33];
+  __shared__ double sums[32];
+  reduce_partials_block(partials, nblocks, scratch, sums);
+  if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
   const int lane = threadIdx.x;
-  reduce_partials_wave(partials, nblocks, sums, lane);
   // expand symmetric 21 -> 6x6
   if (lane < 36) {
     int r = lane / 6, c = lane % 6;
@@ -338,7 +422,7 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_solve(DevCtl *__restrict__
   if (lane == 0) { out->total_residual = sums[28]; out->n_eff = (int32_t)sums[27]; out->pad = 0; }
   if (mode == 0) return;
 
-  esikf_update_wave(ctl, s, 6, 1.0, +1, lane);
+  esikf_update_wave<6>(ctl, s, 1.0, +1, lane);
   if (lane < DS) ctl->lidar.iter_solution[iter][lane] = s.sol[lane];
 
   // convergence / rematch / covariance update (voxel_map.cpp:475-499)
@@ -350,12 +434,14 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_solve(DevCtl *__restrict__
   const bool stop_now = (rematch >= 2 || (iter == max_iter - 1));
   __syncthreads();
   if (stop_now && mode == 1) {
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) s.cov[e] = ctl->cur.cov[e];
-    __syncthreads();
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {       // cov = (I - G) * cov
-      int r = e / DS, c = e % DS;
-      double v = (((r == 0) ? 1.0 : 0.0) - s.G[r * DS]) * s.cov[c];
-      for (int k = 1; k < DS; k++) v = v + (((r == k) ? 1.0 : 0.0) - s.G[r * DS + k]) * s.cov[k * DS + c];
+    // cov = (I - G) * cov ; s.P holds cov (meas_cov_scale = 1) and G is zero beyond column 5
+    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {
+      const int r = e / DS, c = e % DS;
+      double v = 0.0;
+      for (int k = 0; k < DS; k++) {
+        const double coef = ((r == k) ? 1.0 : 0.0) - ((k < 6) ? s.G[r * KMAX + k] : 0.0);
+        v = v + coef * s.P[k * DS + c];
+      }
       ctl->cur.cov[e] = v;
     }
     if (lane < 3) ctl->lidar.position_last[lane] = ctl->cur.pos[lane];

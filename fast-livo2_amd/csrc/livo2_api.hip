@@ -5,6 +5,7 @@
 #include "lidar_kernels.hpp"
 #include "visual_kernels.hpp"
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -32,7 +33,7 @@ struct livo2_ctx {
   // map
   bool has_map = false;
   DevMap map{};
-  HashSlot *d_hash = nullptr; RootAux *d_aux = nullptr; double *d_planes = nullptr; int32_t *d_node_plane = nullptr, *d_node_child = nullptr;
+  RootSlot *d_slots = nullptr; int32_t *d_cand = nullptr; double *d_planes = nullptr;
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restr
   if (lane < k * k) s.hth[lane] = ctl->solve_hth[lane];
   if (lane < k) s.htz[lane] = ctl->solve_htz[lane];
   __syncthreads();
-  esikf_update_wave(ctl, s, k, scale, sign, lane);
+  if (k == 6) esikf_update_wave<6>(ctl, s, scale, sign, lane); else esikf_update_wave<7>(ctl, s, scale, sign, lane);
   if (lane < DS) ctl->solve_solution[lane] = s.sol[lane];
 }
 
@@ -127,12 +128,16 @@ int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   return LIVO2_OK;
 }
 
-int upload_states(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *prop) {
+int upload_states(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *prop, const double *extR = nullptr) {
   // the pinned staging block is reused by every call: the previous H2D must have been consumed
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->h_in->cur = *cur; ctx->h_in->prop = *prop;
   std::memset(&ctx->h_in->hdr, 0, sizeof(DevHeader));
   ctx->h_in->hdr.last_error = FLT_MAX;
+  if (extR) {            // state_propagat.rot_end * extR_ (voxel_map.cpp:445) is constant during one update
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      ctx->h_in->hdr.RE[i * 3 + j] = (prop->rot[i * 3] * extR[j] + prop->rot[i * 3 + 1] * extR[3 + j]) + prop->rot[i * 3 + 2] * extR[6 + j];
+  }
   HIPCHK(hipMemcpyAsync(ctx->d_ctl, ctx->h_in, sizeof(HostIn), hipMemcpyHostToDevice, ctx->stream));
   return LIVO2_OK;
 }
@@ -256,7 +261,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (!ctx) return;
   hipError_t e = hipSetDevice(ctx->device);
   if (ctx->stream) e = hipStreamSynchronize(ctx->stream);
-  void *dev[] = {ctx->d_ctl, ctx->d_hash, ctx->d_aux, ctx->d_planes, ctx->d_node_plane, ctx->d_node_child, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
+  void *dev[] = {ctx->d_ctl, ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
                  ctx->d_cb, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
                  ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg};
   for (void *p : dev) if (p) e = hipFree(p);
@@ -298,49 +303,87 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
     if (m->node_plane[i] < -1 || m->node_plane[i] >= m->n_planes) return fail(ctx, LIVO2_ERR_INVALID, "node_plane index out of range");
     for (int k = 0; k < 8; k++) { int c = m->node_child[(size_t)i * 8 + k]; if (c < -1 || c >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "node_child index out of range"); }
   }
-  uint32_t cap = 16;
-  while (cap < (uint32_t)m->n_roots * 2u) cap <<= 1;
-  std::vector<HashSlot> hash(cap, HashSlot{0, 0, 0, -1});
-  std::vector<RootAux> aux(cap);
-  std::memset(aux.data(), 0, aux.size() * sizeof(RootAux));
-  for (int r = 0; r < m->n_roots; r++) {
-    int64_t kx = m->root_key[(size_t)r * 3], ky = m->root_key[(size_t)r * 3 + 1], kz = m->root_key[(size_t)r * 3 + 2];
-    if (kx < INT32_MIN || kx > INT32_MAX || ky < INT32_MIN || ky > INT32_MAX || kz < INT32_MIN || kz > INT32_MAX) return fail(ctx, LIVO2_ERR_RANGE, "voxel key outside int32");
-    int node = m->root_node[r];
-    if (node < 0 || node >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "root_node index out of range");
-    uint32_t h = voxel_hash((int32_t)kx, (int32_t)ky, (int32_t)kz) & (cap - 1);
-    while (hash[h].val != -1) {
-      if (hash[h].kx == (int32_t)kx && hash[h].ky == (int32_t)ky && hash[h].kz == (int32_t)kz) return fail(ctx, LIVO2_ERR_INVALID, "duplicate voxel key");
-      h = (h + 1) & (cap - 1);
+  if (m->n_planes >= (1 << CAND_LAYER_SHIFT)) return fail(ctx, LIVO2_ERR_RANGE, "too many planes");
+  // flatten every non-plane root into the depth-first list of its descendant planes (the walk of voxel_map.cpp:769-785)
+  std::vector<int32_t> cand;
+  std::vector<int32_t> cbegin(m->n_roots, 0), ccount(m->n_roots, 0);
+  {
+    struct Fr { int node, layer, next; };
+    std::vector<Fr> st;
+    for (int r = 0; r < m->n_roots; r++) {
+      int root = m->root_node[r];
+      if (root < 0 || root >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "root_node index out of range");
+      cbegin[r] = (int32_t)cand.size();
+      if (m->node_plane[root] < 0) {
+        st.clear(); st.push_back({root, 0, 0});
+        while (!st.empty()) {
+          Fr &f = st.back();
+          if (f.next >= 8 || f.layer >= LIVO2_MAX_LAYER) { st.pop_back(); continue; }
+          int child = m->node_child[(size_t)f.node * 8 + f.next++];
+          if (child < 0) continue;
+          int cl = f.layer + 1;
+          int pl = m->node_plane[child];
+          if (pl >= 0) cand.push_back(pl | (cl << CAND_LAYER_SHIFT));
+          else { if (st.size() > 64) return fail(ctx, LIVO2_ERR_INVALID, "octree deeper than supported / cyclic"); st.push_back({child, cl, 0}); }
+        }
+      }
+      ccount[r] = (int32_t)cand.size() - cbegin[r];
     }
-    int pl = m->node_plane[node];
-    hash[h] = HashSlot{(int32_t)kx, (int32_t)ky, (int32_t)kz, pl >= 0 ? pl : -(node + 2)};
-    for (int k = 0; k < 3; k++) aux[h].center[k] = m->root_center[(size_t)r * 3 + k];
-    aux[h].quarter = m->root_quarter[r];
+  }
+  // 2-choice cuckoo table, load factor <= 0.25, one 64-B slot per bucket
+  uint32_t cap = 64;
+  while (cap < (uint32_t)m->n_roots * 4u) cap <<= 1;
+  std::vector<RootSlot> slots;
+  uint32_t seed1 = 0x243f6a88u, seed2 = 0x85a308d3u;
+  for (int attempt = 0;; attempt++) {
+    if (attempt > 24) return fail(ctx, LIVO2_ERR_INVALID, "cuckoo placement failed");
+    if (attempt > 0 && attempt % 6 == 0) cap <<= 1;
+    slots.assign(cap, RootSlot{});
+    for (auto &sl : slots) sl.val = -1;
+    bool ok = true;
+    for (int r = 0; r < m->n_roots && ok; r++) {
+      int64_t kx = m->root_key[(size_t)r * 3], ky = m->root_key[(size_t)r * 3 + 1], kz = m->root_key[(size_t)r * 3 + 2];
+      if (kx < INT32_MIN || kx > INT32_MAX || ky < INT32_MIN || ky > INT32_MAX || kz < INT32_MIN || kz > INT32_MAX) return fail(ctx, LIVO2_ERR_RANGE, "voxel key outside int32");
+      RootSlot cur{};
+      cur.kx = (int32_t)kx; cur.ky = (int32_t)ky; cur.kz = (int32_t)kz;
+      int pl = m->node_plane[m->root_node[r]];
+      cur.val = pl >= 0 ? pl : -2;
+      for (int k = 0; k < 3; k++) cur.center[k] = m->root_center[(size_t)r * 3 + k];
+      cur.quarter = m->root_quarter[r]; cur.cand_begin = cbegin[r]; cur.cand_count = ccount[r];
+      {   // duplicate keys are a caller error
+        uint32_t a = voxel_hash(cur.kx, cur.ky, cur.kz, seed1) & (cap - 1), b = voxel_hash(cur.kx, cur.ky, cur.kz, seed2) & (cap - 1);
+        for (uint32_t h : {a, b}) if (slots[h].val != -1 && slots[h].kx == cur.kx && slots[h].ky == cur.ky && slots[h].kz == cur.kz) return fail(ctx, LIVO2_ERR_INVALID, "duplicate voxel key");
+      }
+      uint32_t h = voxel_hash(cur.kx, cur.ky, cur.kz, seed1) & (cap - 1);
+      bool placed = false;
+      for (int kick = 0; kick < 512; kick++) {
+        if (slots[h].val == -1) { slots[h] = cur; placed = true; break; }
+        std::swap(cur, slots[h]);                     // evict the resident, move it to its other bucket
+        uint32_t a = voxel_hash(cur.kx, cur.ky, cur.kz, seed1) & (cap - 1), b = voxel_hash(cur.kx, cur.ky, cur.kz, seed2) & (cap - 1);
+        h = (h == a) ? b : a;
+      }
+      if (!placed) ok = false;
+    }
+    if (ok) break;
+    seed1 = seed1 * 1664525u + 1013904223u; seed2 = seed2 * 22695477u + 1u;
   }
   std::vector<double> recs((size_t)std::max(1, m->n_planes) * PLANE_REC_DOUBLES, 0.0);
   for (int p = 0; p < m->n_planes; p++)
     pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], m->plane_normal + (size_t)p * 3, m->plane_center + (size_t)p * 3, m->plane_var + (size_t)p * 36, m->plane_d[p], m->plane_radius[p]);
+  if (cand.empty()) cand.push_back(0);
 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hipError_t e;
-  if (ctx->d_hash) { e = hipFree(ctx->d_hash); e = hipFree(ctx->d_aux); e = hipFree(ctx->d_planes); e = hipFree(ctx->d_node_plane); e = hipFree(ctx->d_node_child); (void)e; ctx->d_hash = nullptr; }
+  if (ctx->d_slots) { e = hipFree(ctx->d_slots); e = hipFree(ctx->d_cand); e = hipFree(ctx->d_planes); (void)e; ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; }
   ctx->has_map = false;
-  const size_t nn = (size_t)std::max(1, m->n_nodes);
-  HIPCHK(hipMalloc((void **)&ctx->d_hash, cap * sizeof(HashSlot)));
-  HIPCHK(hipMalloc((void **)&ctx->d_aux, cap * sizeof(RootAux)));
+  HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand, cand.size() * 4));
   HIPCHK(hipMalloc((void **)&ctx->d_planes, recs.size() * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_node_plane, nn * 4));
-  HIPCHK(hipMalloc((void **)&ctx->d_node_child, nn * 32));
-  HIPCHK(hipMemcpy(ctx->d_hash, hash.data(), cap * sizeof(HashSlot), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->d_aux, aux.data(), cap * sizeof(RootAux), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_slots, slots.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_planes, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
-  if (m->n_nodes > 0) {
-    HIPCHK(hipMemcpy(ctx->d_node_plane, m->node_plane, (size_t)m->n_nodes * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->d_node_child, m->node_child, (size_t)m->n_nodes * 32, hipMemcpyHostToDevice));
-  }
-  ctx->map.hash = ctx->d_hash; ctx->map.root_aux = ctx->d_aux; ctx->map.planes = ctx->d_planes; ctx->map.node_plane = ctx->d_node_plane;
-  ctx->map.node_child = ctx->d_node_child; ctx->map.hash_mask = cap - 1; ctx->map.n_planes = m->n_planes; ctx->map.n_nodes = m->n_nodes;
+  ctx->map.slots = ctx->d_slots; ctx->map.cand = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = cap - 1;
+  ctx->map.seed1 = seed1; ctx->map.seed2 = seed2; ctx->map.n_planes = m->n_planes;
   ctx->has_map = true;
   return LIVO2_OK;
 }
@@ -416,12 +459,12 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   int rc = lidar_ready(ctx, cur, prop, cfg); if (rc) return rc;
   if (!sums) return fail(ctx, LIVO2_ERR_INVALID, "sums is NULL");
   rc = ensure_lidar_outputs(ctx, points); if (rc) return rc;
-  rc = upload_states(ctx, cur, prop); if (rc) return rc;
+  rc = upload_states(ctx, cur, prop, cfg->extR); if (rc) return rc;
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1));
-  { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
-  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations); t.done(); }
+  { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -430,13 +473,13 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
 }
 
 static int lidar_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, int iters, int mode) {
-  int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
+  int rc = upload_states(ctx, state_in, prop, cfg->extR); if (rc) return rc;
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1));
   for (int it = 0; it < iters; it++) {
-    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
-    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
+    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
+    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
   }
   hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);
   HIPCHK(hipGetLastError());
@@ -609,7 +652,7 @@ int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_sta
 int livo2_esikf_solve(livo2_ctx *ctx, const double *HtH, const double *Htz, int32_t k, double meas_cov_scale, int32_t sign, const livo2_state *cur,
                       const livo2_state *prop, livo2_state *out_state, double *solution, double *G) {
   if (!ctx) return LIVO2_ERR_INVALID;
-  if (!HtH || !Htz || !cur || !prop || k < 1 || k > 7 || !(meas_cov_scale > 0) || (sign != 1 && sign != -1)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!HtH || !Htz || !cur || !prop || (k != 6 && k != 7) || !(meas_cov_scale > 0) || (sign != 1 && sign != -1)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
   int rc = upload_states(ctx, cur, prop); if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ctx->d_ctl->solve_hth, HtH, (size_t)k * k * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -14,44 +14,65 @@
 #define DS LIVO2_DIM_STATE
 
 // ---- VoxelMap snapshot in HBM -------------------------------------------------------------------------------------
-// Plane record: 256 B, 256-B aligned => exactly two 128-B L2 lines, fetched by a lane as 16-B vector loads.
+// The kernel's critical path is a chain of DEPENDENT memory round trips (hash -> plane -> neighbour hash -> plane), each
+// costing ~1 us under load, while every wave of a 100k-point scan is resident at once: the layout below exists to make
+// that chain as short as possible, not to save bytes.
+//
+// Root table: 2-choice cuckoo hash, one 64-B slot per bucket.  A lookup issues BOTH candidate slots at once => exactly one
+// round trip, never a probe loop.  The slot carries everything the first visit and the neighbour rule need
+// (voxel_center_, quater_length_, reference include/voxel_map.h:139,141), so no second table is touched.
+struct __attribute__((aligned(64))) RootSlot {
+  int32_t kx, ky, kz;          // VOXEL_LOCATION (int32 range enforced at upload)
+  int32_t val;                 // -1 empty ; >=0: root is a plane -> plane index ; -2: non-plane root -> candidate list
+  double center[3];            // voxel_center_
+  float quarter;               // quater_length_
+  int32_t cand_begin;          // first entry in cand[] (non-plane roots)
+  int32_t cand_count;          // number of descendant planes in depth-first leaves_[0..7] order
+  int32_t pad;
+};
+// cand[] entry: plane index | (layer << 28); the all-8-children recursion of build_single_residual (voxel_map.cpp:769-785)
+// visits exactly the descendant planes whose ancestors are all non-planes, in depth-first child order, and only down to
+// cfg.max_layer: flattening that walk at upload time removes three dependent loads per visited node.
+#define CAND_LAYER_SHIFT 28
+#define CAND_PLANE_MASK 0x0fffffff
+
+// Plane record: 256 B, 256-B aligned => exactly two 128-B L2 lines, fetched by a lane as 16-B vector loads in ONE batch.
 //   [0..2] normal_  [3..5] center_  [6..26] sym(plane_var_) upper triangle row-major (21)  [27] {float d_, float radius_}
 //   [28..31] pad
 #define PLANE_REC_DOUBLES 32
-struct __attribute__((aligned(16))) HashSlot { int32_t kx, ky, kz, val; };   // val: >=0 plane idx (root is a plane) ; -1 empty ; <=-2 non-plane root node -(val+2)
-struct __attribute__((aligned(32))) RootAux { double center[3]; float quarter; float pad; };   // voxel_center_, quater_length_ (by hash slot)
 
 struct DevMap {
-  const HashSlot *hash;
-  const RootAux *root_aux;
+  const RootSlot *slots;
+  const int32_t *cand;
   const double *planes;        // [n_planes][32]
-  const int32_t *node_plane;   // [n_nodes]
-  const int32_t *node_child;   // [n_nodes][8]
-  uint32_t hash_mask;
-  int32_t n_planes, n_nodes;
+  uint32_t mask;               // capacity - 1 (power of two)
+  uint32_t seed1, seed2;
+  int32_t n_planes;
 };
 
-__host__ __device__ inline uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
-  uint32_t h = (uint32_t)x * 73856093u ^ (uint32_t)y * 19349663u ^ (uint32_t)z * 83492791u;
-  h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+__host__ __device__ inline uint32_t voxel_hash(int32_t x, int32_t y, int32_t z, uint32_t seed) {
+  uint32_t h = seed;
+  h ^= (uint32_t)x * 0x9e3779b1u; h = (h << 13) | (h >> 19); h *= 0x85ebca6bu;
+  h ^= (uint32_t)y * 0xc2b2ae35u; h = (h << 15) | (h >> 17); h *= 0x27d4eb2fu;
+  h ^= (uint32_t)z * 0x165667b1u; h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
 }
 
 // ---- control block (one per ctx, in HBM) ----------------------------------------------------------------------------
-struct DevHeader {             // reset by the host at the start of every update (one H2D copy together with cur/prop)
+struct DevHeader {             // written by the host at the start of every update (one H2D copy together with cur/prop)
   int32_t stop;                // LiDAR EKF_stop_flg / visual EKF_end of the running level
   int32_t rematch_num;
-  int32_t pinv_valid;
+  int32_t reserved;
   float last_error;            // visual
   int32_t n_steps;
   int32_t pad[3];
+  double RE[9];                // state_propagat.rot_end * extR_  (voxel_map.cpp:445), constant during one update
 };
 struct DevCtl {
   livo2_state cur;             // state_ / *state   (the iterate)
   livo2_state prop;            // state_propagat
   DevHeader hdr;
   livo2_state old;             // visual old_state (vio.cpp:1523,1650,1679)
-  double Pinv[DS * DS];        // (P / meas_cov_scale)^-1, iteration invariant within one update
   double G[DS * DS];
   livo2_lidar_result lidar;
   livo2_visual_result visual;
@@ -61,9 +82,6 @@ struct DevCtl {
 };
 
 // ---- tiny 3x3 helpers (row-major) ------------------------------------------------------------------------------------
-__device__ __forceinline__ double dot3s(double a0, double a1, double a2, double b0, double b1, double b2) {
-  return (a0 * b0 + a1 * b1) + a2 * b2;     // strict left-to-right, one rounding per op
-}
 __device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -76,13 +94,21 @@ __device__ __forceinline__ void mat3_mul_Bt(const double *A, const double *B, do
 #pragma unroll
     for (int j = 0; j < 3; j++) C[i * 3 + j] = (A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1]) + A[i * 3 + 2] * B[j * 3 + 2];
 }
-__device__ __forceinline__ void mat3_vec(const double *A, const double *v, double *o) {
-#pragma unroll
-  for (int i = 0; i < 3; i++) o[i] = (A[i * 3] * v[0] + A[i * 3 + 1] * v[1]) + A[i * 3 + 2] * v[2];
-}
 __device__ __forceinline__ void mat3t_vec(const double *A, const double *v, double *o) {     // o = A^T v
 #pragma unroll
   for (int i = 0; i < 3; i++) o[i] = (A[i] * v[0] + A[3 + i] * v[1]) + A[6 + i] * v[2];
+}
+// o = A^T v with fused multiply-adds (tolerance-level quantities only)
+__device__ __forceinline__ void mat3t_vec_fma(const double *A, const double *v, double *o) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) o[i] = fma(A[6 + i], v[2], fma(A[3 + i], v[1], A[i] * v[0]));
+}
+// v^T S v for a symmetric 3x3 given as (xx,xy,xz,yy,yz,zz)
+__device__ __forceinline__ double quad3_sym(const double *S, const double *v) {
+  double r0 = fma(S[2], v[2], fma(S[1], v[1], S[0] * v[0]));
+  double r1 = fma(S[4], v[2], fma(S[3], v[1], S[1] * v[0]));
+  double r2 = fma(S[5], v[2], fma(S[4], v[1], S[2] * v[0]));
+  return fma(v[2], r2, fma(v[1], r1, v[0] * r0));
 }
 
 // SO(3) Exp / Log  (reference include/utils/so3_math.h:44-66)

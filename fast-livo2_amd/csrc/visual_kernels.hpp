@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_solve(DevCtl *__restrict_
       for (int e = lane; e < nsl; e += LIVO2_WAVE) dst[e] = src[e];
     }
     __syncthreads();
-    esikf_update_wave(ctl, s, 7, img_point_cov, -1, lane);
+    esikf_update_wave<7>(ctl, s, img_point_cov, -1, lane);
     const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
     const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
     if ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) stop = 1;   // vio.cpp:1675
