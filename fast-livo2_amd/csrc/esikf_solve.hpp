@@ -30,11 +30,35 @@ struct SolveLds {
 // One Kalman update of ctl->cur given the reduced sums (s.hth: k x k row-major with stride k, s.htz).
 // sign=+1: LiDAR form (K1*HTz + vec - G*vec) ; sign=-1: visual form (-K1*HTz + vec - G*vec).
 // Leaves the solution in s.sol, G[:,0:k] in s.G (and the zero-padded 19x19 G in ctl->G).
+// Part 1 (independent of the measurement sums, so it can overlap the partial-sum loads): P' = cov / scale and
+// vec = state_propagat [-] state (common_lib.h:194-206) into LDS.  Call from wave 0 only; no barrier inside.
+__device__ inline void esikf_prefetch_wave(const DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int lane) {
+  double c[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; c[q] = (e < DS * DS) ? ctl->cur.cov[e] : 0.0; }
+  if (lane == 0) {
+    double rotd[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      rotd[i * 3 + j] = (ctl->cur.rot[i] * ctl->prop.rot[j] + ctl->cur.rot[3 + i] * ctl->prop.rot[3 + j]) + ctl->cur.rot[6 + i] * ctl->prop.rot[6 + j];   // cur^T * prop
+    double l[3]; so3_log(rotd, l);
+    for (int i = 0; i < 3; i++) {
+      s.vec[i] = l[i];
+      s.vec[3 + i] = ctl->prop.pos[i] - ctl->cur.pos[i];
+      s.vec[7 + i] = ctl->prop.vel[i] - ctl->cur.vel[i];
+      s.vec[10 + i] = ctl->prop.bg[i] - ctl->cur.bg[i];
+      s.vec[13 + i] = ctl->prop.ba[i] - ctl->cur.ba[i];
+      s.vec[16 + i] = ctl->prop.grav[i] - ctl->cur.grav[i];
+    }
+    s.vec[6] = ctl->prop.inv_expo - ctl->cur.inv_expo;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; if (e < DS * DS) s.P[e] = c[q] / meas_cov_scale; }
+}
+
+// Part 2: needs s.P / s.vec (esikf_prefetch_wave + a barrier) and the sums in s.hth / s.htz.
 template <int k>
-__device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int sign, const int lane) {
+__device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sign, const int lane) {
   constexpr int k2 = 2 * k;
-  for (int e = lane; e < DS * DS; e += LIVO2_WAVE) s.P[e] = ctl->cur.cov[e] / meas_cov_scale;
-  __syncthreads();
   // aug = [ I + H_k P'_kk | I ]
   for (int e = lane; e < k * k2; e += LIVO2_WAVE) {
     const int i = e / k2, j = e % k2;
@@ -89,21 +113,6 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const double 
       s.G[r * KMAX + c] = g;
     }
     ctl->G[e] = g;
-  }
-  if (lane == 0) {                                           // vec = state_propagat [-] state   (common_lib.h:194-206)
-    double rotd[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
-      rotd[i * 3 + j] = (ctl->cur.rot[i] * ctl->prop.rot[j] + ctl->cur.rot[3 + i] * ctl->prop.rot[3 + j]) + ctl->cur.rot[6 + i] * ctl->prop.rot[6 + j];   // cur^T * prop
-    double l[3]; so3_log(rotd, l);
-    for (int i = 0; i < 3; i++) {
-      s.vec[i] = l[i];
-      s.vec[3 + i] = ctl->prop.pos[i] - ctl->cur.pos[i];
-      s.vec[7 + i] = ctl->prop.vel[i] - ctl->cur.vel[i];
-      s.vec[10 + i] = ctl->prop.bg[i] - ctl->cur.bg[i];
-      s.vec[13 + i] = ctl->prop.ba[i] - ctl->cur.ba[i];
-      s.vec[16 + i] = ctl->prop.grav[i] - ctl->cur.grav[i];
-    }
-    s.vec[6] = ctl->prop.inv_expo - ctl->cur.inv_expo;
   }
   __syncthreads();
   if (lane < DS) {

@@ -23,6 +23,7 @@
 struct LidarKernelArgs {
   const float *x, *y, *z;          // [n]
   const double *cb;                // [6][n] body covariance, symmetric (xx,xy,xz,yy,yz,zz)
+  const int32_t *perm;             // [n] original index of the point stored at position i (scan is Morton-sorted at upload)
   int32_t n;
   int32_t max_layer;
   DevMap map;
@@ -30,7 +31,52 @@ struct LidarKernelArgs {
   double ER[9], Et[3];
   // optional per-point outputs (device pointers or null)
   int32_t *match_plane; float *dis; float *pw; int32_t *normal_plane; double *var; double *r_inv; double *h_row;
+#ifdef LIVO2_PHASE_PROF
+  unsigned long long *prof;        // [waves][8] s_memtime stamps (profiling build only)
+#endif
 };
+
+#ifdef LIVO2_PHASE_PROF
+// drain every outstanding memory op, then stamp: phase k of this wave ends here
+#define PHASE(k)                                                                                                   \
+  do {                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);           \
+    if (a.prof && (threadIdx.x & 63) == 0) a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  } while (0)
+#else
+#define PHASE(k) do { } while (0)
+#endif
+
+// ---- once per scan: spatial ordering --------------------------------------------------------------------------------------
+// The residual pass gathers one 256-B plane record per point; with points in arbitrary order every lane of a wave touches
+// different L2 lines (measured: 12 of 24 us).  Points are therefore re-ordered once per scan along a 30-bit Morton curve of their
+// body-frame cell (cell = voxel_size): a rigid transform keeps neighbours neighbours, so a wave's lanes share planes and each
+// XCD (consecutive chunks, see k_lidar_residual) keeps one spatial slab in its private L2.  Only the summation order changes.
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+  v &= 0x3ffu; v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void __launch_bounds__(256) k_morton_keys(const float *__restrict__ aos, int n, float inv_cell, uint32_t *__restrict__ keys, int32_t *__restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float f = floorf(aos[(size_t)i * 3 + j] * inv_cell) + 512.f;
+    f = fminf(fmaxf(f, 0.f), 1023.f);                          // NaN -> 0
+    c[j] = (uint32_t)f;
+  }
+  keys[i] = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+  idx[i] = i;
+}
+__global__ void __launch_bounds__(256) k_gather_xyz(const float *__restrict__ aos, const int32_t *__restrict__ perm, int n, float *__restrict__ x,
+                                                    float *__restrict__ y, float *__restrict__ z) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = perm[i];
+  x[i] = aos[(size_t)o * 3]; y[i] = aos[(size_t)o * 3 + 1]; z[i] = aos[(size_t)o * 3 + 2];
+}
 
 // ---- once per scan: calcBodyCov -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_body_cov(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, int n,
@@ -129,27 +175,33 @@ struct Best {
   bool success, prob_valid;
 };
 
-// build_single_residual's is_plane_ branch (voxel_map.cpp:721-768) for one candidate plane already in registers, followed — when the
-// plane becomes the point's current best — by its measurement row (voxel_map.cpp:425-457)
-__device__ __forceinline__ void eval_plane(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *R, const double *RE,
-                                           const double *sPrr, const double *sPtt, Best &best) {
-  const double *pw = pt.pw, *pc = pt.pc;
-  const double sd = ((p.n[0] * pw[0] + p.n[1] * pw[1]) + p.n[2] * pw[2]) + (double)p.d;
-  const float dis_to_plane = (float)fabs(sd);
-  const double e0 = p.c[0] - pw[0], e1 = p.c[1] - pw[1], e2 = p.c[2] - pw[2];
-  const float dis_to_center = (float)((e0 * e0 + e1 * e1) + e2 * e2);
-  const float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);   // float ops; NaN (negative radicand) fails the gate below
-  if (!((double)range_dis <= 3.0 * (double)p.radius)) return;
+// Radius gate of build_single_residual (voxel_map.cpp:724-730): needs only normal_, center_, d_, radius_ of the plane.
+// All three float32 quantities use the reference's operand types and operation order (Q5).
+struct GateOut { double sd; double e[3]; float dis_to_plane; };
+__device__ __forceinline__ bool radius_gate(const double *n, const double *c, float d, float radius, const double *pw, GateOut &g) {
+  g.sd = ((n[0] * pw[0] + n[1] * pw[1]) + n[2] * pw[2]) + (double)d;
+  g.dis_to_plane = (float)fabs(g.sd);
+  g.e[0] = c[0] - pw[0]; g.e[1] = c[1] - pw[1]; g.e[2] = c[2] - pw[2];
+  const float dis_to_center = (float)((g.e[0] * g.e[0] + g.e[1] * g.e[1]) + g.e[2] * g.e[2]);
+  const float range_dis = sqrtf(dis_to_center - g.dis_to_plane * g.dis_to_plane);   // float ops; NaN (negative radicand) fails the gate
+  return (double)range_dis <= 3.0 * (double)radius;
+}
+
+// 3-sigma gate, max-probability choice (voxel_map.cpp:732-755) and — when the plane becomes the point's current best — its
+// measurement row (voxel_map.cpp:425-457), for a plane that passed the radius gate.
+__device__ __forceinline__ void sigma_gate_and_row(const double *n, const double *c, const double *S, const GateOut &g, int32_t pidx, double sigma_num,
+                                                   const PointCtx &pt, const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best) {
+  const double *pc = pt.pc;
   // sigma_l = J_nq plane_var J_nq^T + n^T Sigma_w n ,  J_nq = [p_w - c, -n]
-  const double J[6] = {-e0, -e1, -e2, -p.n[0], -p.n[1], -p.n[2]};
-  double sigma_l = quad6_sym(p.S, J);
+  const double J[6] = {-g.e[0], -g.e[1], -g.e[2], -n[0], -n[1], -n[2]};
+  double sigma_l = quad6_sym(S, J);
   // n^T Sigma_w n = m^T Cb m + q^T Prr q + n^T Ptt n  with m = R^T n, q = n x p_i  (Sigma_w = R Cb R^T + X Prr X^T + Ptt, X = [p_i]x)
-  double m[3]; mat3t_vec_fma(R, p.n, m);
-  const double qx[3] = {p.n[1] * pc[2] - p.n[2] * pc[1], p.n[2] * pc[0] - p.n[0] * pc[2], p.n[0] * pc[1] - p.n[1] * pc[0]};
-  sigma_l += (quad3_sym(pt.Cb, m) + quad3_sym(sPrr, qx)) + quad3_sym(sPtt, p.n);
+  double m[3]; mat3t_vec_fma(R, n, m);
+  const double qx[3] = {n[1] * pc[2] - n[2] * pc[1], n[2] * pc[0] - n[0] * pc[2], n[0] * pc[1] - n[1] * pc[0]};
+  sigma_l += (quad3_sym(pt.Cb, m) + quad3_sym(sPrr, qx)) + quad3_sym(sPtt, n);
   const double sq = sqrt(sigma_l);
-  if ((double)dis_to_plane < sigma_num * sq) {
-    const double dis2 = (double)dis_to_plane * (double)dis_to_plane;
+  if ((double)g.dis_to_plane < sigma_num * sq) {
+    const double dis2 = (double)g.dis_to_plane * (double)g.dis_to_plane;
     bool take = true;
     if (best.success) {
       if (!best.prob_valid) { best.prob = 1.0 / sqrt(best.sigma) * exp(-0.5 * best.dis2 / best.sigma); best.prob_valid = true; }
@@ -159,18 +211,29 @@ __device__ __forceinline__ void eval_plane(const PlaneRec &p, int32_t pidx, doub
     }
     best.success = true;
     if (take) {
-      best.plane = pidx; best.r = (float)sd; best.dis2 = dis2; best.sigma = sigma_l;
+      best.plane = pidx; best.r = (float)g.sd; best.dis2 = dis2; best.sigma = sigma_l;
       // H / R^-1 row (voxel_map.cpp:414-458): sigma_l' at the PRIOR-pose point, var with the PRIOR rotation, A with the CURRENT one
-      const double Jq[6] = {pt.q[0] - p.c[0], pt.q[1] - p.c[1], pt.q[2] - p.c[2], -p.n[0], -p.n[1], -p.n[2]};
-      const double sig_q = quad6_sym(p.S, Jq);
-      double mp[3]; mat3t_vec_fma(RE, p.n, mp);             // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
+      const double Jq[6] = {pt.q[0] - c[0], pt.q[1] - c[1], pt.q[2] - c[2], -n[0], -n[1], -n[2]};
+      const double sig_q = quad6_sym(S, Jq);
+      double mp[3]; mat3t_vec_fma(RE, n, mp);               // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
       best.w = 1.0 / (0.001 + sig_q + quad3_sym(pt.Cb, mp));
       best.h[0] = pt.pi[1] * m[2] - pt.pi[2] * m[1];       // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
       best.h[1] = pt.pi[2] * m[0] - pt.pi[0] * m[2];
       best.h[2] = pt.pi[0] * m[1] - pt.pi[1] * m[0];
-      best.h[3] = p.n[0]; best.h[4] = p.n[1]; best.h[5] = p.n[2];
+      best.h[3] = n[0]; best.h[4] = n[1]; best.h[5] = n[2];
     }
   }
+}
+
+// covariance part of a plane record (21 doubles at offset 6) in one batch of 16-B loads
+__device__ __forceinline__ void load_plane_S(const double *__restrict__ planes, int32_t pidx, double *S) {
+  const double2 *P2 = reinterpret_cast<const double2 *>(planes + (size_t)pidx * PLANE_REC_DOUBLES + 6);
+  double2 v[11];
+#pragma unroll
+  for (int q = 0; q < 11; q++) v[q] = P2[q];
+#pragma unroll
+  for (int q = 0; q < 10; q++) { S[2 * q] = v[q].x; S[2 * q + 1] = v[q].y; }
+  S[20] = v[10].x;
 }
 
 __device__ __forceinline__ bool slot_match(const RootSlot &s, const int32_t key[3]) { return s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]; }
@@ -186,25 +249,133 @@ __device__ __forceinline__ RootSlot load_slot(const RootSlot *__restrict__ slots
   return s;
 }
 
-// visit one root voxel: its plane, or the flattened depth-first list of descendant planes (layers <= max_layer); the next list
-// entry is fetched while the current plane is evaluated, so a k-candidate voxel costs k+1 dependent round trips, not 2k.
-__device__ __forceinline__ void visit_root(const DevMap &map, const RootSlot &s, int max_layer, double sigma_num, const PointCtx &pt, const double *R,
-                                           const double *RE, const double *sPrr, const double *sPtt, Best &best) {
-  if (s.val >= 0) {
-    PlaneRec p; load_plane(map.planes, s.val, p);
-    eval_plane(p, s.val, sigma_num, pt, R, RE, sPrr, sPtt, best);
-  } else if (s.cand_count > 0) {
-    const int32_t *ce = map.cand + s.cand_begin;
-    int32_t e_cur = ce[0];
-    for (int k = 0; k < s.cand_count; k++) {
-      const int32_t e_nxt = (k + 1 < s.cand_count) ? ce[k + 1] : 0;
-      if ((e_cur >> CAND_LAYER_SHIFT) <= max_layer) {
-        PlaneRec p; load_plane(map.planes, e_cur & CAND_PLANE_MASK, p);
-        eval_plane(p, e_cur & CAND_PLANE_MASK, sigma_num, pt, R, RE, sPrr, sPtt, best);
-      }
-      e_cur = e_nxt;
-    }
+// Visit one root voxel (build_single_residual from layer 0).
+//  * plane root: the whole 256-B record in one batch, radius gate, 3-sigma gate.
+//  * non-plane root: the depth-first list of descendant planes (layers <= max_layer) was flattened at upload into contiguous 64-B
+//    GATE records {normal_, center_, d_, radius_, plane index|layer}; four of them travel per round trip, the radius gate runs on
+//    all four, and the 168-B covariance part is fetched only for the planes that pass it.  A k-candidate voxel thus costs
+//    ceil(k/4) + (#planes passing the radius gate) round trips instead of the 2k of walking the octree node by node — the tail of
+//    this kernel (it ends with its slowest wave).  Candidates are still evaluated in depth-first order, so ties keep the first.
+struct RootRef { int32_t val, cand_begin, cand_count; };   // what a visit needs from a RootSlot
+
+__device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *R, const double *RE,
+                                                 const double *sPrr, const double *sPtt, Best &best) {
+  GateOut g;
+  if (radius_gate(p.n, p.c, p.d, p.radius, pt.pw, g)) sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pt, R, RE, sPrr, sPtt, best);
+}
+
+// ---- block-cooperative visit of non-plane roots ----------------------------------------------------------------------------
+// A non-plane root owns a flattened depth-first list of descendant planes.  Walking it inside the owning lane serialises up to 73
+// plane evaluations while the other lanes idle, and the kernel ends with its slowest wave (measured tail: 14 us against a 2.6 us
+// median; the Morton order concentrates cluttered voxels in the same wave).  Instead every (point, candidate) pair of the BLOCK
+// becomes one work item: owners publish their point context and their pair range in LDS, each of the 256 threads evaluates one
+// pair per round (whole 256-B record copy from the candidate-ordered array: one round trip -> radius gate -> 3-sigma gate ->
+// probability and measurement row), and the owner folds the results of its pairs IN LIST ORDER with the reference's strict '>'
+// (ties keep the first), which reproduces the serial recursion of build_single_residual exactly.
+struct __attribute__((aligned(16))) CoopLds {
+  double ctx[LIDAR_BLOCK][18];       // owner context: pw pc pi q (3 each) Cb (6)
+  double res[LIDAR_BLOCK][10];       // pair result: prob, w, h[6], {float r, int32 plane}, accepted flag
+  int32_t pair_owner[LIDAR_BLOCK];
+  int32_t pair_cand[LIDAR_BLOCK];
+  int32_t wave_tot[8];
+};
+static_assert(sizeof(CoopLds) <= LIDAR_LDS_BYTES, "CoopLds must fit in the block's reduction tiles");
+
+// must be called by every thread of the block (cnt = 0 for threads without a pending candidate list)
+__device__ __forceinline__ int coop_visit(CoopLds &L, const DevMap &map, int cnt, int cand_begin, int max_layer, double sigma_num, const PointCtx &pt,
+                                          const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!__syncthreads_or(cnt > 0)) return 0;                  // block-uniform
+  if (cnt > 0) {
+    double *c = L.ctx[tid];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { c[k] = pt.pw[k]; c[3 + k] = pt.pc[k]; c[6 + k] = pt.pi[k]; c[9 + k] = pt.q[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) c[12 + k] = pt.Cb[k];
   }
+  int incl = cnt;                                            // inclusive prefix sum of the pair counts: wave scan + wave totals
+#pragma unroll
+  for (int off = 1; off < LIVO2_WAVE; off <<= 1) { const int t = __shfl_up(incl, off, LIVO2_WAVE); if (lane >= off) incl += t; }
+  if (lane == LIVO2_WAVE - 1) L.wave_tot[wave] = incl;
+  __syncthreads();
+  int woff = 0, W = 0;
+#pragma unroll
+  for (int w = 0; w < LIDAR_BLOCK / LIVO2_WAVE; w++) { const int t = L.wave_tot[w]; if (w < wave) woff += t; W += t; }
+  const int excl = woff + incl - cnt;
+  for (int base = 0; base < W; base += LIDAR_BLOCK) {
+    // owners publish the pairs that fall into this round
+    const int k_lo = max(0, base - excl), k_hi = min(cnt, base + LIDAR_BLOCK - excl);
+    for (int k = k_lo; k < k_hi; k++) { const int j = excl + k - base; L.pair_owner[j] = tid; L.pair_cand[j] = cand_begin + k; }
+    __syncthreads();
+    double r_prob = 0.0, r_w = 0.0, r_h[6] = {0, 0, 0, 0, 0, 0}, r_meta = 0.0, r_flag = 0.0;
+    if (base + tid < W) {
+      const int owner = L.pair_owner[tid];
+      PlaneRec p; int2 meta;
+      {
+        const double2 *P2 = reinterpret_cast<const double2 *>(map.cand_rec + (size_t)L.pair_cand[tid] * PLANE_REC_DOUBLES);
+        double2 v[15];
+#pragma unroll
+        for (int q = 0; q < 15; q++) v[q] = P2[q];
+        p.n[0] = v[0].x; p.n[1] = v[0].y; p.n[2] = v[1].x; p.c[0] = v[1].y; p.c[1] = v[2].x; p.c[2] = v[2].y;
+#pragma unroll
+        for (int q = 0; q < 10; q++) { p.S[2 * q] = v[3 + q].x; p.S[2 * q + 1] = v[3 + q].y; }
+        p.S[20] = v[13].x;
+        const float2 dr = __builtin_bit_cast(float2, v[13].y);
+        p.d = dr.x; p.radius = dr.y;
+        meta = __builtin_bit_cast(int2, v[14].x);
+      }
+      if ((meta.x >> CAND_LAYER_SHIFT) <= max_layer) {
+        const double *oc = L.ctx[owner];
+        PointCtx pp;
+#pragma unroll
+        for (int k = 0; k < 3; k++) pp.pw[k] = oc[k];
+        GateOut g;
+        if (radius_gate(p.n, p.c, p.d, p.radius, pp.pw, g)) {
+          const int32_t pidx = meta.x & CAND_PLANE_MASK;
+#pragma unroll
+          for (int k = 0; k < 3; k++) { pp.pc[k] = oc[3 + k]; pp.pi[k] = oc[6 + k]; pp.q[k] = oc[9 + k]; }
+#pragma unroll
+          for (int k = 0; k < 6; k++) pp.Cb[k] = oc[12 + k];
+          Best tb; tb.success = false; tb.prob_valid = false; tb.prob = 0.0; tb.dis2 = 0.0; tb.sigma = 1.0; tb.w = 0.0; tb.plane = -1; tb.r = 0.f;
+#pragma unroll
+          for (int u = 0; u < 6; u++) tb.h[u] = 0.0;
+          sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pp, R, RE, sPrr, sPtt, tb);
+          if (tb.success) {
+            r_flag = 1.0;
+            r_prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
+            r_w = tb.w;
+#pragma unroll
+            for (int u = 0; u < 6; u++) r_h[u] = tb.h[u];
+            r_meta = __builtin_bit_cast(double, make_int2(__builtin_bit_cast(int, tb.r), tb.plane));
+          }
+        }
+      }
+    }
+    {
+      double *o = L.res[tid];
+      o[0] = r_prob; o[1] = r_w;
+#pragma unroll
+      for (int u = 0; u < 6; u++) o[2 + u] = r_h[u];
+      o[8] = r_meta; o[9] = r_flag;
+    }
+    __syncthreads();
+    // owners fold their pairs of this round, in list order
+    for (int k = k_lo; k < k_hi; k++) {
+      const double *o = L.res[excl + k - base];
+      if (o[9] != 0.0) {
+        best.success = true;
+        if (o[0] > best.prob) {
+          best.prob = o[0]; best.prob_valid = true; best.w = o[1];
+#pragma unroll
+          for (int u = 0; u < 6; u++) best.h[u] = o[2 + u];
+          const int2 m2 = __builtin_bit_cast(int2, o[8]);
+          best.r = __builtin_bit_cast(float, m2.x); best.plane = m2.y;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return W;
 }
 
 // ---- fused per-iteration pass -----------------------------------------------------------------------------------------
@@ -213,113 +384,141 @@ __device__ __forceinline__ void visit_root(const DevMap &map, const RootSlot &s,
 __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop) {
   if (check_stop && ctl->hdr.stop) return;
+  extern __shared__ __attribute__((aligned(16))) double lds_red[];
   const int per_xcd = gridDim.x >> 3;                            // host launches a multiple of 8 blocks
   const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); // chunk index; chunks past the scan are empty
-  const int tid = threadIdx.x;
-  const int i = vb * LIDAR_BLOCK + tid;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = vb * LIDAR_BLOCK + tid;            // position in the sorted scan
+  const bool valid = i < a.n;
+  const int ic = valid ? i : 0;                    // clamped index: invalid lanes compute on point 0 and contribute nothing
+  CoopLds &coop = *reinterpret_cast<CoopLds *>(lds_red);       // aliases the block's reduction tiles (used strictly before them)
 
+  PHASE(0);
+  // wave-uniform state (scalar loads)
+  const double *R = ctl->cur.rot, *t = ctl->cur.pos, *Rp = ctl->prop.rot, *tp = ctl->prop.pos, *cov = ctl->cur.cov;
+  const double *RE = ctl->hdr.RE;
+  const double plx = a.x[ic], ply = a.y[ic], plz = a.z[ic];
+  const int o = a.perm[ic];                                     // per-point outputs go back to the caller's order
+  PointCtx pt;
+  double *Cb = pt.Cb, *pi = pt.pi, *pw = pt.pw, *pc = pt.pc;
+#pragma unroll
+  for (int e = 0; e < 6; e++) Cb[e] = a.cb[(size_t)e * a.n + ic];
+  // p_i = extR * p_l + extT  (un-patched, voxel_map.cpp:522 / 418)
+#pragma unroll
+  for (int j = 0; j < 3; j++) pi[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * plz) + a.Et[j];
+  // p_w = float32( R * p_i + t )   (voxel_map.cpp:522-526)
+  float pwf[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { pwf[j] = (float)(((R[j * 3] * pi[0] + R[j * 3 + 1] * pi[1]) + R[j * 3 + 2] * pi[2]) + t[j]); pw[j] = (double)pwf[j]; }
+  // voxel key (voxel_map.cpp:665-671): double divide, narrow to float, -1 for negatives, truncate
+  float loc[3]; int32_t key[3]; bool in_range = valid;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float l = (float)(pw[j] / a.voxel_size);
+    if (l < 0) l = (float)((double)l - 1.0);
+    loc[j] = l;
+    in_range = in_range && (l > -2147483000.f) && (l < 2147483000.f);
+    key[j] = in_range ? (int32_t)l : 0;
+  }
+  PHASE(1);
+  // T2: both cuckoo slots at once
+  RootSlot s1, s2;
+  {
+    const uint32_t h1 = voxel_hash(key[0], key[1], key[2], a.map.seed1) & a.map.mask;
+    const uint32_t h2 = voxel_hash(key[0], key[1], key[2], a.map.seed2) & a.map.mask;
+    s1 = load_slot(a.map.slots, h1); s2 = load_slot(a.map.slots, h2);
+  }
+  // cross matrix uses the z-patched point (voxel_map.cpp:352-358)
+  pc[0] = pi[0]; pc[1] = pi[1]; pc[2] = pi[2];
+  if (plz == 0) {
+    const double pz = 0.001;
+#pragma unroll
+    for (int j = 0; j < 3; j++) pc[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * pz) + a.Et[j];
+  }
+  // symmetric parts of P[0:3,0:3] and P[3:6,3:6] (a quadratic form only sees the symmetric part)
+  double sPrr[6], sPtt[6];
+  {
+    const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+      sPrr[e] = 0.5 * (cov[ii[e] * DS + jj[e]] + cov[jj[e] * DS + ii[e]]);
+      sPtt[e] = 0.5 * (cov[(3 + ii[e]) * DS + 3 + jj[e]] + cov[(3 + jj[e]) * DS + 3 + ii[e]]);
+    }
+  }
+  if (a.var && valid) {       // pv.var = R Cb R^T + X Prr X^T + Ptt (voxel_map.cpp:387), only materialised when the caller asks for it
+    const double Cbf[9] = {Cb[0], Cb[1], Cb[2], Cb[1], Cb[3], Cb[4], Cb[2], Cb[4], Cb[5]};
+    double T[9], RC[9], XP[9], XPX[9];
+    mat3_mul(R, Cbf, T); mat3_mul_Bt(T, R, RC);
+    const double X[9] = {0.0, -pc[2], pc[1], pc[2], 0.0, -pc[0], -pc[1], pc[0], 0.0};
+    const double Prr[9] = {cov[0], cov[1], cov[2], cov[DS], cov[DS + 1], cov[DS + 2], cov[2 * DS], cov[2 * DS + 1], cov[2 * DS + 2]};
+    mat3_mul(X, Prr, XP); mat3_mul_Bt(XP, X, XPX);
+#pragma unroll
+    for (int e = 0; e < 9; e++) { const int r = e / 3, c = e % 3, u = r < c ? r : c, v = r < c ? c : r; a.var[(size_t)o * 9 + e] = RC[u * 3 + v] + XPX[u * 3 + v] + cov[(3 + u) * DS + 3 + v]; }
+  }
+  if (a.pw && valid) { a.pw[(size_t)o * 3] = pwf[0]; a.pw[(size_t)o * 3 + 1] = pwf[1]; a.pw[(size_t)o * 3 + 2] = pwf[2]; }
+  // PRIOR-pose world point, un-rounded (voxel_map.cpp:425)
+#pragma unroll
+  for (int j = 0; j < 3; j++) pt.q[j] = ((Rp[j * 3] * pi[0] + Rp[j * 3 + 1] * pi[1]) + Rp[j * 3 + 2] * pi[2]) + tp[j];
+  PHASE(2);
+  Best best; best.prob = 0.0; best.plane = -1; best.r = 0.f; best.success = false; best.prob_valid = false; best.dis2 = 0.0; best.sigma = 1.0; best.w = 0.0;
+#pragma unroll
+  for (int u = 0; u < 6; u++) best.h[u] = 0.0;
+  const bool f1 = in_range && slot_match(s1, key), f2 = in_range && slot_match(s2, key);
+  const bool found = f1 || f2;
+  RootRef s = {-1, 0, 0}, nb = {-1, 0, 0};
+  {
+    const RootSlot &sl = f1 ? s1 : s2;
+    if (found) s = {sl.val, sl.cand_begin, sl.cand_count};
+    // neighbour rule (voxel_map.cpp:682-688): voxel-index units compared with metres, reproduced as is.  Its two slots are
+    // requested before the first visit so they travel together with the plane record (T3).
+    int32_t nk[3] = {key[0], key[1], key[2]};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if ((double)loc[j] > (sl.center[j] + (double)sl.quarter)) nk[j] = nk[j] + 1;
+      else if ((double)loc[j] < (sl.center[j] - (double)sl.quarter)) nk[j] = nk[j] - 1;
+    }
+    // (when no axis triggers, the reference re-visits the same voxel with prob = 0 and fails again: nothing to do)
+    const bool nbr = found && ((nk[0] != key[0]) || (nk[1] != key[1]) || (nk[2] != key[2]));
+    PlaneRec p0;
+    RootSlot n1, n2;
+    n1.val = -1; n2.val = -1;
+    if (nbr) {
+      const uint32_t g1 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed1) & a.map.mask;
+      const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
+      n1 = load_slot(a.map.slots, g1); n2 = load_slot(a.map.slots, g2);
+    }
+    if (s.val >= 0) load_plane(a.map.planes, s.val, p0);         // issued right behind the neighbour slots: same round trip
+    // the neighbour slots return first (in order); keep only the three words a later visit needs
+    if (nbr) {
+      if (slot_match(n1, nk)) nb = {n1.val, n1.cand_begin, n1.cand_count};
+      else if (slot_match(n2, nk)) nb = {n2.val, n2.cand_begin, n2.cand_count};
+    }
+    if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+  }
+  const int W1 = coop_visit(coop, a.map, (s.val == -2) ? s.cand_count : 0, s.cand_begin, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+#ifdef LIVO2_PHASE_PROF
+  if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)W1;
+#else
+  (void)W1;
+#endif
+  PHASE(3);
+  {
+    const bool retry = found && !best.success && nb.val != -1;
+    if (retry && nb.val >= 0) {
+      PlaneRec p1; load_plane(a.map.planes, nb.val, p1);
+      visit_plane_root(p1, nb.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+    }
+    coop_visit(coop, a.map, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+  }
+  PHASE(4);
   double acc[LIDAR_NSUM];
 #pragma unroll
   for (int q = 0; q < LIDAR_NSUM; q++) acc[q] = 0.0;
-
-  if (i < a.n) {
-    // wave-uniform state (scalar loads)
-    const double *R = ctl->cur.rot, *t = ctl->cur.pos, *Rp = ctl->prop.rot, *tp = ctl->prop.pos, *cov = ctl->cur.cov;
-    const double plx = a.x[i], ply = a.y[i], plz = a.z[i];
-    PointCtx pt;
-    double *Cb = pt.Cb, *pi = pt.pi, *pw = pt.pw, *pc = pt.pc;
-#pragma unroll
-    for (int e = 0; e < 6; e++) Cb[e] = a.cb[(size_t)e * a.n + i];
-    // p_i = extR * p_l + extT  (un-patched, voxel_map.cpp:522 / 418)
-#pragma unroll
-    for (int j = 0; j < 3; j++) pi[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * plz) + a.Et[j];
-    // p_w = float32( R * p_i + t )   (voxel_map.cpp:522-526)
-    float pwf[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) { pwf[j] = (float)(((R[j * 3] * pi[0] + R[j * 3 + 1] * pi[1]) + R[j * 3 + 2] * pi[2]) + t[j]); pw[j] = (double)pwf[j]; }
-    // voxel key (voxel_map.cpp:665-671): double divide, narrow to float, -1 for negatives, truncate
-    float loc[3]; int32_t key[3]; bool in_range = true;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      float l = (float)(pw[j] / a.voxel_size);
-      if (l < 0) l = (float)((double)l - 1.0);
-      loc[j] = l;
-      in_range = in_range && (l > -2147483000.f) && (l < 2147483000.f);
-      key[j] = (int32_t)l;
-    }
-    // T2: both cuckoo slots at once
-    RootSlot s1, s2;
-    {
-      const uint32_t h1 = voxel_hash(key[0], key[1], key[2], a.map.seed1) & a.map.mask;
-      const uint32_t h2 = voxel_hash(key[0], key[1], key[2], a.map.seed2) & a.map.mask;
-      s1 = load_slot(a.map.slots, h1); s2 = load_slot(a.map.slots, h2);
-    }
-    // cross matrix uses the z-patched point (voxel_map.cpp:352-358)
-    pc[0] = pi[0]; pc[1] = pi[1]; pc[2] = pi[2];
-    if (plz == 0) {
-      const double pz = 0.001;
-#pragma unroll
-      for (int j = 0; j < 3; j++) pc[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * pz) + a.Et[j];
-    }
-    // symmetric parts of P[0:3,0:3] and P[3:6,3:6] (a quadratic form only sees the symmetric part)
-    double sPrr[6], sPtt[6];
-    {
-      const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-      for (int e = 0; e < 6; e++) {
-        sPrr[e] = 0.5 * (cov[ii[e] * DS + jj[e]] + cov[jj[e] * DS + ii[e]]);
-        sPtt[e] = 0.5 * (cov[(3 + ii[e]) * DS + 3 + jj[e]] + cov[(3 + jj[e]) * DS + 3 + ii[e]]);
-      }
-    }
-    if (a.var) {       // pv.var = R Cb R^T + X Prr X^T + Ptt (voxel_map.cpp:387), only materialised when the caller asks for it
-      const double Cbf[9] = {Cb[0], Cb[1], Cb[2], Cb[1], Cb[3], Cb[4], Cb[2], Cb[4], Cb[5]};
-      double T[9], RC[9], XP[9], XPX[9];
-      mat3_mul(R, Cbf, T); mat3_mul_Bt(T, R, RC);
-      const double X[9] = {0.0, -pc[2], pc[1], pc[2], 0.0, -pc[0], -pc[1], pc[0], 0.0};
-      const double Prr[9] = {cov[0], cov[1], cov[2], cov[DS], cov[DS + 1], cov[DS + 2], cov[2 * DS], cov[2 * DS + 1], cov[2 * DS + 2]};
-      mat3_mul(X, Prr, XP); mat3_mul_Bt(XP, X, XPX);
-#pragma unroll
-      for (int e = 0; e < 9; e++) { const int r = e / 3, c = e % 3, u = r < c ? r : c, v = r < c ? c : r; a.var[(size_t)i * 9 + e] = RC[u * 3 + v] + XPX[u * 3 + v] + cov[(3 + u) * DS + 3 + v]; }
-    }
-    if (a.pw) { a.pw[(size_t)i * 3] = pwf[0]; a.pw[(size_t)i * 3 + 1] = pwf[1]; a.pw[(size_t)i * 3 + 2] = pwf[2]; }
-
-    // PRIOR-pose world point, un-rounded (voxel_map.cpp:425)
-#pragma unroll
-    for (int j = 0; j < 3; j++) pt.q[j] = ((Rp[j * 3] * pi[0] + Rp[j * 3 + 1] * pi[1]) + Rp[j * 3 + 2] * pi[2]) + tp[j];
-    const double *RE = ctl->hdr.RE;
-    Best best; best.prob = 0.0; best.plane = -1; best.r = 0.f; best.success = false; best.prob_valid = false; best.dis2 = 0.0; best.sigma = 1.0; best.w = 0.0;
-#pragma unroll
-    for (int u = 0; u < 6; u++) best.h[u] = 0.0;
-    const bool f1 = in_range && slot_match(s1, key), f2 = in_range && slot_match(s2, key);
-    if (f1 || f2) {
-      const RootSlot &s = f1 ? s1 : s2;
-      // neighbour rule (voxel_map.cpp:682-688): voxel-index units compared with metres, reproduced as is.  Issued before the
-      // first visit so the neighbour's slots travel together with the plane record (T3).
-      int32_t nk[3] = {key[0], key[1], key[2]};
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        if ((double)loc[j] > (s.center[j] + (double)s.quarter)) nk[j] = nk[j] + 1;
-        else if ((double)loc[j] < (s.center[j] - (double)s.quarter)) nk[j] = nk[j] - 1;
-      }
-      const bool nbr_differs = (nk[0] != key[0]) || (nk[1] != key[1]) || (nk[2] != key[2]);
-      RootSlot n1, n2;
-      n1.val = -1; n2.val = -1;
-      if (nbr_differs) {
-        const uint32_t g1 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed1) & a.map.mask;
-        const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
-        n1 = load_slot(a.map.slots, g1); n2 = load_slot(a.map.slots, g2);
-      }
-      visit_root(a.map, s, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
-      if (!best.success && nbr_differs) {
-        // (when no axis triggers, the reference re-visits the same voxel with prob = 0 and fails again: nothing to do)
-        const bool g1m = slot_match(n1, nk), g2m = slot_match(n2, nk);
-        if (g1m || g2m) visit_root(a.map, g1m ? n1 : n2, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
-      }
-    }
-    if (a.match_plane) a.match_plane[i] = best.success ? best.plane : -1;
-    if (a.dis) a.dis[i] = best.success ? best.r : 0.f;
+  if (valid) {
+    if (a.match_plane) a.match_plane[o] = best.success ? best.plane : -1;
+    if (a.dis) a.dis[o] = best.success ? best.r : 0.f;
     if (best.success) {
-      if (a.normal_plane) a.normal_plane[i] = best.plane;
+      if (a.normal_plane) a.normal_plane[o] = best.plane;
       const double zz = -(double)best.r;                        // meas_vec(i) = -dis_to_plane_ (float32 residual, voxel_map.cpp:457)
       int sidx = 0;
 #pragma unroll
@@ -332,19 +531,19 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
       acc[27] = 1.0;
       acc[28] = fabs((double)best.r);
     }
-    if (a.r_inv) a.r_inv[i] = best.success ? best.w : 0.0;
+    if (a.r_inv) a.r_inv[o] = best.success ? best.w : 0.0;
     if (a.h_row) {
 #pragma unroll
-      for (int u = 0; u < 6; u++) a.h_row[(size_t)i * 6 + u] = best.success ? best.h[u] : 0.0;
+      for (int u = 0; u < 6; u++) a.h_row[(size_t)o * 6 + u] = best.success ? best.h[u] : 0.0;
     }
   }
 
+  PHASE(5);
   // Block reduction through an LDS transpose (deterministic).  ds_bpermute butterflies over 29 doubles cost ~20 us of this
   // kernel (measured); here every lane stores its 29 values (conflict-free: consecutive lanes -> consecutive 8-B words), then
   // lane (v = lane&31, half = lane>>5) of each wave adds 32 of the 64 columns of value v (row pitch 65 doubles => the 32 lanes of
   // a ds_read_b64 group hit 32 distinct bank pairs), one xor-32 exchange joins the halves, and 4 waves are joined in fixed order.
-  extern __shared__ __attribute__((aligned(16))) double lds_red[];
-  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();                                     // the cooperative-visit tiles alias the reduction tiles
   double *T = lds_red + (size_t)wave * (32 * 65);
 #pragma unroll
   for (int q = 0; q < LIDAR_NSUM; q++) T[q * 65 + lane] = acc[q];
@@ -367,30 +566,31 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
     const double v = ((lds_red[tid] + lds_red[32 + tid]) + lds_red[64 + tid]) + lds_red[96 + tid];
     partials[(size_t)blockIdx.x * 32 + tid] = (tid < LIDAR_NSUM) ? v : 0.0;
   }
+  PHASE(6);
 }
 
 // Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 32 slices
-// x 32 values: slice s adds blocks s, s+32, ... in order with all its loads in flight at once (the partials were written by other
-// CUs, so each dependent load is a full round trip: a single wave walking them serially cost ~20 us); the slices are then joined
-// in fixed order.  Every thread of the block must call this.
+// x 32 values: slice s adds blocks s, s+32, ... in order.  The rows were written by other CUs, so every dependent load is a full
+// ~1.5-us round trip (a single wave walking them serially cost ~20 us): each thread therefore issues ALL its loads (up to 16,
+// i.e. 512 rows = 131k points; beyond that a loop) before the first add.  The slices are then joined in fixed order.
+// Every thread of the block must call this.
 #define SOLVE_THREADS 1024
 __device__ inline void reduce_partials_block(const double *__restrict__ partials, int nblocks, double *scratch /*[32][33]*/, double *out /*[32]*/) {
   const int t = threadIdx.x, kidx = t & 31, slice = t >> 5;       // 32 slices
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) { const int b = slice + 32 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
   double acc = 0.0;
-  int b = slice;
-  for (; b + 96 < nblocks; b += 128) {
-    const double v0 = partials[(size_t)b * 32 + kidx], v1 = partials[(size_t)(b + 32) * 32 + kidx], v2 = partials[(size_t)(b + 64) * 32 + kidx],
-                 v3 = partials[(size_t)(b + 96) * 32 + kidx];
-    acc += v0; acc += v1; acc += v2; acc += v3;
-  }
-  for (; b < nblocks; b += 32) acc += partials[(size_t)b * 32 + kidx];
+#pragma unroll
+  for (int u = 0; u < 16; u++) acc += v[u];
+  for (int b = slice + 512; b < nblocks; b += 32) acc += partials[(size_t)b * 32 + kidx];
   scratch[slice * 33 + kidx] = acc;
   __syncthreads();
   if (t < 32) {
-    double v = scratch[t];
+    double r = scratch[t];
 #pragma unroll
-    for (int sl = 1; sl < 32; sl++) v += scratch[sl * 33 + t];
-    out[t] = v;
+    for (int sl = 1; sl < 32; sl++) r += scratch[sl * 33 + t];
+    out[t] = r;
   }
   __syncthreads();
 }
@@ -404,6 +604,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
   __shared__ SolveLds s;
   __shared__ double scratch[32 * 33];
   __shared__ double sums[32];
+  if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, 1.0, threadIdx.x);   // travels with the partial rows
   reduce_partials_block(partials, nblocks, scratch, sums);
   if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
   const int lane = threadIdx.x;
@@ -422,7 +623,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
   if (lane == 0) { out->total_residual = sums[28]; out->n_eff = (int32_t)sums[27]; out->pad = 0; }
   if (mode == 0) return;
 
-  esikf_update_wave<6>(ctl, s, 1.0, +1, lane);
+  esikf_update_wave<6>(ctl, s, +1, lane);
   if (lane < DS) ctl->lidar.iter_solution[iter][lane] = s.sol[lane];
 
   // convergence / rematch / covariance update (voxel_map.cpp:475-499)

@@ -2,6 +2,8 @@
 // Host side of the boundary: context / stream ownership, VoxelMap snapshot packing (open-addressing hash + 256-B plane
 // records), scan and frame uploads, and the static launch sequences of the two ESIKF updates.  No CPU compute path exists
 // here: every entry point either drives the HIP kernels or fails.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "lidar_kernels.hpp"
 #include "visual_kernels.hpp"
 #include <algorithm>
@@ -33,11 +35,13 @@ struct livo2_ctx {
   // map
   bool has_map = false;
   DevMap map{};
-  RootSlot *d_slots = nullptr; int32_t *d_cand = nullptr; double *d_planes = nullptr;
+  RootSlot *d_slots = nullptr; double *d_cand = nullptr; double *d_planes = nullptr;
+  std::vector<int32_t> plane_cand_pos;      // host: position of each plane in the candidate-gate array, or -1
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
   float *d_xyz_aos = nullptr, *d_x = nullptr, *d_y = nullptr, *d_z = nullptr; double *d_cb = nullptr;
+  uint32_t *d_keys = nullptr, *d_keys2 = nullptr; int32_t *d_idx = nullptr, *d_perm = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_partials = nullptr; size_t partials_cap = 0;
   int32_t *d_match = nullptr, *d_normal_plane = nullptr; float *d_dis = nullptr, *d_pw = nullptr; double *d_var = nullptr, *d_rinv = nullptr, *d_hrow = nullptr;
   int out_cap = 0;
@@ -47,6 +51,9 @@ struct livo2_ctx {
   uint8_t *d_img = nullptr; size_t img_cap = 0; int width = 0, height = 0, stride = 0;
   double *d_pos = nullptr, *d_invexpo = nullptr; float *d_warp = nullptr; int32_t *d_search = nullptr; int M = 0, L = 0, M_cap = 0; size_t warp_cap = 0;
   float *d_errors = nullptr; double *d_zdbg = nullptr, *d_Hdbg = nullptr; int dbg_cap = 0;
+#ifdef LIVO2_PHASE_PROF
+  unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
+#endif
   // timing
   bool timing = false;
   TimingBin bins[3];
@@ -97,15 +104,15 @@ void pack_plane(double *rec, const double *normal, const double *center, const d
   for (int k = 28; k < 32; k++) rec[k] = 0.0;
 }
 
-__global__ void k_scatter_planes(const double *__restrict__ recs, const int32_t *__restrict__ idx, int n, double *__restrict__ planes) {
+__global__ void k_scatter_planes(const double *__restrict__ recs, const int32_t *__restrict__ idx, const int32_t *__restrict__ gate_pos, int n,
+                                 double *__restrict__ planes, double *__restrict__ gates) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int p = t >> 5, k = t & 31;
-  if (p < n) planes[(size_t)idx[p] * PLANE_REC_DOUBLES + k] = recs[(size_t)p * PLANE_REC_DOUBLES + k];
-}
-
-__global__ void k_split_xyz(const float *__restrict__ aos, int n, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { x[i] = aos[(size_t)i * 3]; y[i] = aos[(size_t)i * 3 + 1]; z[i] = aos[(size_t)i * 3 + 2]; }
+  if (p >= n) return;
+  const double v = recs[(size_t)p * PLANE_REC_DOUBLES + k];
+  planes[(size_t)idx[p] * PLANE_REC_DOUBLES + k] = v;
+  const int gp = gate_pos[p];                      // the plane's copy inside a candidate list (meta word [7] is left untouched)
+  if (gp >= 0 && k < 28) gates[(size_t)gp * PLANE_REC_DOUBLES + k] = v;
 }
 
 __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restrict__ ctl, int k, double scale, int sign) {
@@ -114,7 +121,9 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restr
   if (lane < k * k) s.hth[lane] = ctl->solve_hth[lane];
   if (lane < k) s.htz[lane] = ctl->solve_htz[lane];
   __syncthreads();
-  if (k == 6) esikf_update_wave<6>(ctl, s, scale, sign, lane); else esikf_update_wave<7>(ctl, s, scale, sign, lane);
+  esikf_prefetch_wave(ctl, s, scale, lane);
+  __syncthreads();
+  if (k == 6) esikf_update_wave<6>(ctl, s, sign, lane); else esikf_update_wave<7>(ctl, s, sign, lane);
   if (lane < DS) ctl->solve_solution[lane] = s.sol[lane];
 }
 
@@ -160,9 +169,17 @@ int ensure_lidar_outputs(livo2_ctx *ctx, const livo2_lidar_points *want) {
 
 LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   LidarKernelArgs a{};
-  a.x = ctx->d_x; a.y = ctx->d_y; a.z = ctx->d_z; a.cb = ctx->d_cb; a.n = ctx->n; a.max_layer = cfg->max_layer; a.map = ctx->map;
+  a.x = ctx->d_x; a.y = ctx->d_y; a.z = ctx->d_z; a.cb = ctx->d_cb; a.perm = ctx->d_perm; a.n = ctx->n; a.max_layer = cfg->max_layer; a.map = ctx->map;
   a.voxel_size = cfg->voxel_size; a.sigma_num = cfg->sigma_num;
   std::memcpy(a.ER, cfg->extR, 72); std::memcpy(a.Et, cfg->extT, 24);
+#ifdef LIVO2_PHASE_PROF
+  {
+    size_t waves = (size_t)lidar_grid(std::max(ctx->n, 1)) * 4;
+    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64); (void)e; ctx->prof_waves = waves; }
+    hipError_t e = hipMemsetAsync(ctx->d_prof, 0, waves * 64, ctx->stream); (void)e;
+    a.prof = ctx->d_prof;
+  }
+#endif
   const livo2_lidar_points &w = ctx->want_l;
   a.match_plane = w.match_plane ? ctx->d_match : nullptr; a.dis = w.dis_to_plane ? ctx->d_dis : nullptr; a.pw = w.point_w ? ctx->d_pw : nullptr;
   a.normal_plane = w.normal_plane ? ctx->d_normal_plane : nullptr; a.var = w.var ? ctx->d_var : nullptr;
@@ -184,12 +201,14 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   if (p->var) HIPCHK(hipMemcpyAsync(p->var, ctx->d_var, n * 72, hipMemcpyDeviceToHost, ctx->stream));
   if (p->r_inv) HIPCHK(hipMemcpyAsync(p->r_inv, ctx->d_rinv, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (p->h_row) HIPCHK(hipMemcpyAsync(p->h_row, ctx->d_hrow, n * 48, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->body_cov) {          // body_cov_list_: device keeps the symmetric 6; expand to 3x3 on the host
+  if (p->body_cov) {          // body_cov_list_: the device keeps the symmetric 6 in sorted order; expand to 3x3 in caller order
     std::vector<double> cb(6 * n);
+    std::vector<int32_t> perm(n);
     HIPCHK(hipMemcpyAsync(cb.data(), ctx->d_cb, 6 * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(perm.data(), ctx->d_perm, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-    for (size_t i = 0; i < n; i++) for (int e = 0; e < 9; e++) p->body_cov[i * 9 + e] = cb[(size_t)map9[e] * n + i];
+    for (size_t j = 0; j < n; j++) for (int e = 0; e < 9; e++) p->body_cov[(size_t)perm[j] * 9 + e] = cb[(size_t)map9[e] * n + j];
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LIVO2_OK;
@@ -262,7 +281,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   hipError_t e = hipSetDevice(ctx->device);
   if (ctx->stream) e = hipStreamSynchronize(ctx->stream);
   void *dev[] = {ctx->d_ctl, ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
-                 ctx->d_cb, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
+                 ctx->d_cb, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, ctx->d_sort_tmp, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
                  ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
@@ -370,19 +389,30 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   std::vector<double> recs((size_t)std::max(1, m->n_planes) * PLANE_REC_DOUBLES, 0.0);
   for (int p = 0; p < m->n_planes; p++)
     pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], m->plane_normal + (size_t)p * 3, m->plane_center + (size_t)p * 3, m->plane_var + (size_t)p * 36, m->plane_d[p], m->plane_radius[p]);
-  if (cand.empty()) cand.push_back(0);
+  // candidate lists hold whole record copies (one round trip per evaluated pair); remember where each plane sits for
+  // livo2_map_update_planes
+  ctx->plane_cand_pos.assign((size_t)std::max(1, m->n_planes), -1);
+  std::vector<double> gates((size_t)std::max<size_t>(1, cand.size()) * PLANE_REC_DOUBLES, 0.0);
+  for (size_t k = 0; k < cand.size(); k++) {
+    const int pl = cand[k] & CAND_PLANE_MASK;
+    double *g = &gates[k * PLANE_REC_DOUBLES];
+    std::memcpy(g, &recs[(size_t)pl * PLANE_REC_DOUBLES], 28 * sizeof(double));
+    int32_t meta[2] = {cand[k], 0};
+    std::memcpy(&g[28], meta, 8);
+    ctx->plane_cand_pos[pl] = (int32_t)k;
+  }
 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hipError_t e;
   if (ctx->d_slots) { e = hipFree(ctx->d_slots); e = hipFree(ctx->d_cand); e = hipFree(ctx->d_planes); (void)e; ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; }
   ctx->has_map = false;
   HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand, cand.size() * 4));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand, gates.size() * 8));
   HIPCHK(hipMalloc((void **)&ctx->d_planes, recs.size() * 8));
   HIPCHK(hipMemcpy(ctx->d_slots, slots.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_cand, gates.data(), gates.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_planes, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
-  ctx->map.slots = ctx->d_slots; ctx->map.cand = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = cap - 1;
+  ctx->map.slots = ctx->d_slots; ctx->map.cand_rec = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = cap - 1;
   ctx->map.seed1 = seed1; ctx->map.seed2 = seed2; ctx->map.n_planes = m->n_planes;
   ctx->has_map = true;
   return LIVO2_OK;
@@ -398,15 +428,19 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   HIPCHK(hipSetDevice(ctx->device));
   std::vector<double> recs((size_t)n * PLANE_REC_DOUBLES);
   for (int p = 0; p < n; p++) pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], normal + (size_t)p * 3, center + (size_t)p * 3, plane_var + (size_t)p * 36, d[p], radius[p]);
-  double *d_recs = nullptr; int32_t *d_idx = nullptr;
+  std::vector<int32_t> gpos(n);
+  for (int p = 0; p < n; p++) gpos[p] = ctx->plane_cand_pos[plane_idx[p]];
+  double *d_recs = nullptr; int32_t *d_idx = nullptr, *d_gpos = nullptr;
   HIPCHK(hipMalloc((void **)&d_recs, recs.size() * 8));
   HIPCHK(hipMalloc((void **)&d_idx, (size_t)n * 4));
+  HIPCHK(hipMalloc((void **)&d_gpos, (size_t)n * 4));
   HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_idx, plane_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, n, ctx->d_planes);
+  HIPCHK(hipMemcpyAsync(d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, d_gpos, n, ctx->d_planes, ctx->d_cand);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx));
+  HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_gpos));
   return LIVO2_OK;
 }
 
@@ -419,11 +453,13 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (n > ctx->n_cap) {
     hipError_t e;
-    if (ctx->d_x) { e = hipFree(ctx->d_xyz_aos); e = hipFree(ctx->d_x); e = hipFree(ctx->d_y); e = hipFree(ctx->d_z); e = hipFree(ctx->d_cb); (void)e; }
+    if (ctx->d_x) { e = hipFree(ctx->d_xyz_aos); e = hipFree(ctx->d_x); e = hipFree(ctx->d_y); e = hipFree(ctx->d_z); e = hipFree(ctx->d_cb); e = hipFree(ctx->d_keys); e = hipFree(ctx->d_keys2); e = hipFree(ctx->d_idx); e = hipFree(ctx->d_perm); (void)e; }
     int cap = std::max(n, 1024);
     HIPCHK(hipMalloc((void **)&ctx->d_xyz_aos, (size_t)cap * 12)); HIPCHK(hipMalloc((void **)&ctx->d_x, (size_t)cap * 4));
     HIPCHK(hipMalloc((void **)&ctx->d_y, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_z, (size_t)cap * 4));
     HIPCHK(hipMalloc((void **)&ctx->d_cb, (size_t)cap * 48));
+    HIPCHK(hipMalloc((void **)&ctx->d_keys, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_keys2, (size_t)cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_idx, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_perm, (size_t)cap * 4));
     ctx->n_cap = cap;
   }
   ctx->n = n;
@@ -432,7 +468,20 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
   if (rc) return rc;
   if (n > 0) {
     HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_split_xyz, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, n, ctx->d_x, ctx->d_y, ctx->d_z);
+    // Morton order of the body-frame cells (cell = voxel_size), then gather into SoA
+    hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, n, (float)(1.0 / cfg->voxel_size), ctx->d_keys, ctx->d_idx);
+    size_t need = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 30, ctx->stream));
+    if (need > ctx->sort_tmp_bytes) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (ctx->d_sort_tmp) HIPCHK(hipFree(ctx->d_sort_tmp));
+      ctx->d_sort_tmp = nullptr;
+      HIPCHK(hipMalloc(&ctx->d_sort_tmp, need + need / 2 + 256));
+      ctx->sort_tmp_bytes = need + need / 2 + 256;
+    }
+    size_t tmp_bytes = ctx->sort_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 30, ctx->stream));
+    hipLaunchKernelGGL(k_gather_xyz, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, ctx->d_perm, n, ctx->d_x, ctx->d_y, ctx->d_z);
     const double deg2rad = cfg->deg2rad != 0.0 ? cfg->deg2rad : 0.017453293;
     // d_cb is [6][n] with row pitch n (not n_cap): the residual kernel indexes cb[e*n + i]
     hipLaunchKernelGGL(k_body_cov, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_x, ctx->d_y, ctx->d_z, n, (float)cfg->dept_err, (float)cfg->beam_err,
@@ -582,7 +631,7 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   } else {
     Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
   }
-  { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov); t.done(); }
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_v, sizeof(livo2_visual_sums), hipMemcpyDeviceToHost, ctx->stream));
   if (errors && M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -603,7 +652,7 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
     a.errors = ctx->d_errors;
     for (int it = 0; it < iters; it++) {
       { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0); t.done(); }
-      { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
+      { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
     }
   }
   hipLaunchKernelGGL(k_visual_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, a, mode == 1 ? 1 : 0);
@@ -647,6 +696,18 @@ int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_sta
   if (ctx->M == 0) return fail(ctx, LIVO2_ERR_INVALID, "no patches");
   return visual_enqueue(ctx, state_in, prop, cfg, level, level, iters, 2);
 }
+
+#ifdef LIVO2_PHASE_PROF
+// profiling build only: copy the per-wave phase stamps of the LAST residual launch to host memory
+int livo2_debug_phase_prof(livo2_ctx *ctx, unsigned long long *out, size_t max_waves, size_t *n_waves) {
+  if (!ctx || !ctx->d_prof) return LIVO2_ERR_INVALID;
+  size_t w = std::min(max_waves, ctx->prof_waves);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, ctx->d_prof, w * 64, hipMemcpyDeviceToHost));
+  if (n_waves) *n_waves = w;
+  return LIVO2_OK;
+}
+#endif
 
 // ---- solve alone ----------------------------------------------------------------------------------------------------------------
 int livo2_esikf_solve(livo2_ctx *ctx, const double *HtH, const double *Htz, int32_t k, double meas_cov_scale, int32_t sign, const livo2_state *cur,

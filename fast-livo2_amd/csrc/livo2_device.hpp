@@ -30,7 +30,7 @@ struct __attribute__((aligned(64))) RootSlot {
   int32_t cand_count;          // number of descendant planes in depth-first leaves_[0..7] order
   int32_t pad;
 };
-// cand[] entry: plane index | (layer << 28); the all-8-children recursion of build_single_residual (voxel_map.cpp:769-785)
+// candidate entry meta: plane index | (layer << 28); the all-8-children recursion of build_single_residual (voxel_map.cpp:769-785)
 // visits exactly the descendant planes whose ancestors are all non-planes, in depth-first child order, and only down to
 // cfg.max_layer: flattening that walk at upload time removes three dependent loads per visited node.
 #define CAND_LAYER_SHIFT 28
@@ -43,7 +43,7 @@ struct __attribute__((aligned(64))) RootSlot {
 
 struct DevMap {
   const RootSlot *slots;
-  const int32_t *cand;
+  const double *cand_rec;      // [n_cand][32]: COPY of the plane record in candidate (depth-first) order, [28] = {int32 plane|layer<<28, 0}
   const double *planes;        // [n_planes][32]
   uint32_t mask;               // capacity - 1 (power of two)
   uint32_t seed1, seed2;

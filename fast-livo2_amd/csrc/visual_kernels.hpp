@@ -178,18 +178,35 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual(VisualKernelArgs 
 }
 
 // mode 0: bare evaluation -> ctl->sums_v ; mode 1: full ESIKF step (accept / revert / solve) ; mode 2: benchmark (always accept, never stop)
-__global__ void __launch_bounds__(LIVO2_WAVE) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
+#define VIS_SOLVE_THREADS 1000        // 25 slices x 40 values
+__global__ void __launch_bounds__(1024) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
                                                              int iter, double img_point_cov) {
   if (mode == 1 && iter > 0 && ctl->hdr.stop) return;
   __shared__ SolveLds s;
   __shared__ double sums[64];
-  const int lane = threadIdx.x;
+  __shared__ double scratch[25 * 41];
   {
+    // partial rows come from other CUs: every thread issues all its loads before the first add (slice s = rows s, s+25, ...)
+    const int t = threadIdx.x, kidx = t % VIS_PSTRIDE, slice = t / VIS_PSTRIDE;     // 25 slices
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int b = slice + 25 * u; v[u] = (b < nblocks) ? partials[(size_t)b * VIS_PSTRIDE + kidx] : 0.0; }
     double acc = 0.0;
-    if (lane < VIS_PSTRIDE) for (int b = 0; b < nblocks; b++) acc += partials[(size_t)b * VIS_PSTRIDE + lane];
-    sums[lane] = acc;
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += v[u];
+    for (int b = slice + 400; b < nblocks; b += 25) acc += partials[(size_t)b * VIS_PSTRIDE + kidx];
+    scratch[slice * 41 + kidx] = acc;
+    __syncthreads();
+    if (t < VIS_PSTRIDE) {
+      double r = scratch[t];
+#pragma unroll
+      for (int sl = 1; sl < 25; sl++) r += scratch[sl * 41 + t];
+      sums[t] = r;
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
+  const int lane = threadIdx.x;
   if (lane < 49) {
     int r = lane / 7, c = lane % 7;
     int u = r < c ? r : c, v = r < c ? c : r;
@@ -225,7 +242,9 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_solve(DevCtl *__restrict_
       for (int e = lane; e < nsl; e += LIVO2_WAVE) dst[e] = src[e];
     }
     __syncthreads();
-    esikf_update_wave<7>(ctl, s, img_point_cov, -1, lane);
+    esikf_prefetch_wave(ctl, s, img_point_cov, lane);
+    __syncthreads();
+    esikf_update_wave<7>(ctl, s, -1, lane);
     const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
     const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
     if ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) stop = 1;   // vio.cpp:1675

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Per-phase latency breakdown of k_lidar_residual from the profiling build (make -C fast-livo2_amd/csrc prof).
+Loads liblivo2_hip_prof.so in place of the product library, runs a few ESIKF iterations on the C2 scenario and prints, per phase,
+the mean / p50 / p95 / max wave time in microseconds (s_memtime ticks at 100 MHz on gfx950 -> 10 ns per tick)."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def main():
+    order = sys.argv[1] if len(sys.argv) > 1 else "voxelgrid"
+    livo2 = importlib.import_module("fast-livo2_amd")
+    livo2.abi.LIB_PATH = os.path.join(ROOT, "fast-livo2_amd", "lib", "liblivo2_hip_prof.so")
+    from scenarios import synth
+    from tests import helpers as H
+    import bench
+    sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12,
+                              downsample=(0.1 if order == "voxelgrid" else None))
+    ctx = livo2.Context(0)
+    cfg = H.lidar_cfg_product(sc)
+    ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
+    cur, prop = bench.make_states(livo2, sc)
+    ctx.lidar_iterations_async(cur, prop, cfg, 10); ctx.synchronize()
+    ctx.lidar_iterations_async(cur, prop, cfg, 5); ctx.synchronize()
+    fn = ctx.lib.livo2_debug_phase_prof
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+    W = 1 << 16
+    buf = np.zeros((W, 8), np.uint64)
+    nw = C.c_size_t()
+    assert fn(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), W, C.byref(nw)) == 0
+    st = buf[:nw.value].astype(np.int64)
+    st = st[st[:, 0] > 0]
+    # stamps are per-XCD counters: normalise each XCD (block b runs on XCD b % 8) to its own first wave
+    xcd = (np.arange(len(buf[:nw.value])) // 4 % 8)[buf[:nw.value, 0] > 0]
+    for x in range(8):
+        m = xcd == x
+        if m.any():
+            st[m, :7] -= st[m, 0].min()
+    names = ["launch skew (first wave start -> this wave start)", "T1 xyz+cov+state, transform, key", "T2 cuckoo slots (+ sym P)", "T3 first visit (plane / candidates)",
+             "T4 neighbour visit", "accumulate + outputs", "LDS reduction + partial store"]
+    tick_us = 0.01
+    t0 = st[:, 0].min()
+    rows = [("0 " + names[0], (st[:, 0] - t0) * tick_us)]
+    for k in range(1, 7):
+        ok = st[:, k] > 0
+        d = np.where(ok, st[:, k] - st[:, k - 1], 0)
+        # phases 3/4 are skipped by waves whose lanes never reach them: carry the previous stamp forward
+        if not ok.all():
+            st[:, k] = np.where(ok, st[:, k], st[:, k - 1])
+        rows.append((f"{k} " + names[k], d * tick_us))
+    print(f"scan order {order}: {len(st)} waves, kernel span {(st[:, 6].max() - t0) * tick_us:.2f} us")
+    for n, d in rows:
+        print(f"{n:55s} mean {d.mean():6.2f}  p50 {np.percentile(d, 50):6.2f}  p95 {np.percentile(d, 95):6.2f}  max {d.max():6.2f} us")
+    W = st[:, 7]
+    d3 = (st[:, 3] - st[:, 2]) * tick_us
+    for lo, hi in ((0, 0), (1, 8), (9, 32), (33, 64), (65, 10**9)):
+        m = (W >= lo) & (W <= hi)
+        if m.any():
+            print(f"  waves with {lo}..{hi} candidate pairs: {m.sum():5d}  T3 mean {d3[m].mean():7.2f} p95 {np.percentile(d3[m], 95):7.2f} max {d3[m].max():7.2f}")
+    slow = np.argsort(-d3)[:8]
+    print('  slowest T3 waves (index, W, T3):', [(int(k), int(W[k]), round(float(d3[k]), 1)) for k in slow])
+    end = (st[:, 6] - t0) * tick_us
+    print(f"wave end time: mean {end.mean():.2f} p50 {np.percentile(end, 50):.2f} p95 {np.percentile(end, 95):.2f} max {end.max():.2f} us")
+
+
+if __name__ == "__main__":
+    main()
