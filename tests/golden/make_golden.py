@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz: small frozen inputs + the oracle's outputs for them.
+
+The reference (ROS1/PCL/Eigen/OpenCV/Sophus/vikit) cannot be built or imported here and ships no golden vectors for this path
+(SURVEY.md §4, §8c), so these fixtures freeze the ORACLE's answers (golden build: -O2 -ffp-contract=off) on frozen inputs: they pin
+the oracle against regressions and give the GPU tests reference values that do not depend on regenerating the scenario.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import orc  # noqa: E402
+from scenarios import synth  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+FM_FIELDS = ["root_key", "root_node", "root_center", "root_quarter", "node_plane", "node_child", "plane_normal", "plane_center", "plane_var", "plane_d", "plane_radius"]
+
+
+def lidar():
+    sc = synth.lidar_scenario(seed=21, n_points=600, downsample=0.1, map_rays_factor=10)
+    om = orc.OracleMap.from_flat(sc.fmap)
+    cfg = orc.lidar_cfg(sc.cfg, sc.extR, sc.extT)
+    cur, prop = H.states(sc, orc.StatePOD)
+    it = orc.lidar_iterate(om, cfg, sc.xyz, cur, prop)
+    full = orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop)
+    so = orc.state_arrays(full["state"])
+    np.savez_compressed(
+        os.path.join(OUT, "lidar_small.npz"), xyz=sc.xyz, R_prior=sc.R_prior, t_prior=sc.t_prior, P=sc.P, extR=sc.extR, extT=sc.extT,
+        cfg_keys=np.array(sorted(k for k in sc.cfg if k != "layer_init_num")), cfg_vals=np.array([float(sc.cfg[k]) for k in sorted(sc.cfg) if k != "layer_init_num"]),
+        voxel_size=sc.fmap.voxel_size, max_layer=sc.fmap.max_layer, **{f: getattr(sc.fmap, f) for f in FM_FIELDS},
+        it_HtH=it["HtH"], it_Htz=it["Htz"], it_n_eff=it["n_eff"], it_match=it["match_plane"], it_dis=it["dis"], it_pw=it["pw"], it_Rinv=it["Rinv"], it_Hrow=it["Hrow"],
+        n_iters=full["n_iters"], tr_HtH=np.array([np.array(t.HtH) for t in full["trace"]]), tr_Htz=np.array([np.array(t.Htz) for t in full["trace"]]),
+        tr_sol=np.array([np.array(t.solution) for t in full["trace"]]), tr_neff=np.array([t.n_eff for t in full["trace"]]),
+        out_R=so["R"], out_t=so["t"], out_P=so["P"], out_match=full["match_plane"], out_dis=full["dis"])
+
+
+def visual():
+    vs = synth.visual_scenario(seed=22, n_patches=48)
+    cfg = orc.visual_cfg(vs)
+    cur, prop = H.states(vs, orc.StatePOD)
+    it = orc.visual_iterate(cfg, vs, 1, cur)
+    full = orc.visual_update(cfg, vs, cur, prop)
+    so = orc.state_arrays(full["state"])
+    np.savez_compressed(
+        os.path.join(OUT, "visual_small.npz"), img=vs.img, pos=vs.pos, warp_patch=vs.warp_patch, search_levels=vs.search_levels, inv_expo_list=vs.inv_expo_list,
+        R_prior=vs.R_prior, t_prior=vs.t_prior, tau_prior=vs.tau_prior, P=vs.P, extR=vs.extR, extT=vs.extT, Rcl=vs.Rcl, Pcl=vs.Pcl,
+        cam=np.array([vs.cam[k] for k in ("fx", "fy", "cx", "cy", "width", "height")], float), img_point_cov=vs.cfg["img_point_cov"], L=vs.cfg["patch_pyrimid_level"],
+        max_iterations=vs.cfg["max_iterations"], it_level=1, it_z=it["z"], it_H=it["H"], it_HtH=it["HtH"], it_Htz=it["Htz"], it_errors=it["errors"], it_error=it["error"],
+        steps=np.array([(t.level, t.iteration, t.accepted, t.n_meas) for t in full["trace"]]), step_error=np.array([t.error for t in full["trace"]]),
+        step_sol=np.array([np.array(t.solution) for t in full["trace"]]), out_R=so["R"], out_t=so["t"], out_P=so["P"], out_tau=so["inv_expo"], out_G=full["G"],
+        out_errors=full["errors"])
+
+
+if __name__ == "__main__":
+    lidar()
+    visual()
+    for f in ("lidar_small.npz", "visual_small.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -1,0 +1,197 @@
+"""GPU parity on edge cases: hand-crafted maps (quirks Q3/Q4/Q7), deep candidate lists, ragged / empty inputs, z == 0 points,
+in-place plane refresh, golden fixtures, error codes, determinism."""
+import numpy as np
+import pytest
+
+from scenarios import synth
+from tests import golden_io
+from tests import handmaps as HM
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+WANT = ("match_plane", "dis_to_plane", "point_w", "r_inv", "h_row", "normal_plane", "var", "body_cov")
+
+
+def _both(ctx, livo2, orc, sc):
+    om = orc.OracleMap.from_flat(sc.fmap)
+    ocur, oprop = H.states(sc, orc.StatePOD)
+    pcur, pprop = H.states(sc, livo2.State)
+    ref = orc.lidar_iterate(om, orc.lidar_cfg(sc.cfg, sc.extR, sc.extT), sc.xyz, ocur, oprop)
+    pcfg = H.lidar_cfg_product(sc)
+    ctx.upload_map(sc.fmap)
+    ctx.set_scan(sc.xyz, pcfg)
+    sums, pts = ctx.lidar_iterate(pcur, pprop, pcfg, want=WANT)
+    return ref, sums, pts
+
+
+def _check(ref, sums, pts, tol=1e-11):
+    assert np.array_equal(pts["point_w"], ref["pw"])
+    assert np.array_equal(pts["match_plane"], ref["match_plane"])
+    assert np.array_equal(pts["dis_to_plane"], ref["dis"])
+    assert sums.n_eff == ref["n_eff"]
+    if ref["n_eff"]:
+        assert H.relerr(np.array(sums.HtH).reshape(6, 6), ref["HtH"]) < tol
+        assert H.relerr(np.array(sums.Htz), ref["Htz"]) < 1e-9
+        m = ref["match_plane"] >= 0
+        assert H.relerr(pts["r_inv"][m], ref["Rinv"][m]) < 1e-12 and H.relerr(pts["h_row"][m], ref["Hrow"][m]) < 1e-13
+    else:
+        assert not np.any(np.array(sums.HtH)) and not np.any(np.array(sums.Htz))
+
+
+def test_hand_maps_quirks(ctx, livo2, orc):
+    b = HM.MapBuilder()
+    b.add_root([0, 0, -2], HM.plane_record([0, 0, 1], [0.25, 0.25, -0.5], radius=5.0))
+    b.add_root([0, 0, -1], HM.plane_record([0, 0, 1], [0.25, 0.25, -0.2], radius=5.0))
+    b.add_root([0, 0, 1], HM.plane_record([0, 0, 1], [0.25, 0.25, 0.7], radius=5.0))
+    far = HM.plane_record([0, 0, 1], [0.12, 0.12, 0.1004], radius=1.0, var_scale=1e-8)
+    near = HM.plane_record([0, 0, 1], [0.37, 0.37, 0.1001], radius=1.0, var_scale=1e-8)
+    b.add_root([0, 0, 0], None, children={0: far, 6: near})
+    b.add_root([2, 0, 0], HM.plane_record([0, 0, 1], [1.05, 0.25, 0.1], radius=0.01))
+    b.add_root([4, 0, 0], None)
+    b.add_root([5, 1, 1], HM.plane_record([0, 0, 1], [2.2, 0.3, 0.2], radius=2.0))
+    b.add_root([4, 0, 1], HM.plane_record([0, 0, 1], [2.2, 0.3, 0.2], radius=2.0))
+    pts = [[0.25, 0.25, -0.5], [0.25, 0.25, -0.2], [0.25, 0.25, 0.7], [0.25, 0.25, 0.1], [1.25, 0.25, 0.1], [2.15, 0.25, 0.2], [10, 10, 10], [0.3, 0.3, 0.0]]
+    sc = HM.HandScene(b.build(), pts)
+    ref, sums, out = _both(ctx, livo2, orc, sc)
+    assert list(ref["match_plane"][:7]) == [0, 1, 2, 4, -1, 6, -1]       # hand-derived (see tests/test_oracle_cpu.py)
+    _check(ref, sums, out)
+    # max_layer = 0: children never visited
+    sc0 = HM.HandScene(b.build(), pts, max_layer=0)
+    ref0, sums0, out0 = _both(ctx, livo2, orc, sc0)
+    assert ref0["match_plane"][3] == -1
+    _check(ref0, sums0, out0)
+
+
+def test_deep_candidate_lists(ctx, livo2, orc):
+    """cluttered scene: non-plane roots with up to ~30 descendant planes -> exercises the block-cooperative candidate evaluation"""
+    sc = synth.lidar_scenario(seed=31, n_points=20000, room=(12.0, 12.0, 4.0), n_boxes=60, downsample=0.05, map_rays_factor=20, cfg=dict(min_eigen_value=0.0004))
+    ref, sums, out = _both(ctx, livo2, orc, sc)
+    assert (ref["match_plane"] >= 0).sum() > 10000
+    _check(ref, sums, out)
+    assert H.relerr(out["var"], ref["var"]) < 1e-13 and H.relerr(out["body_cov"], ref["body_cov"]) < 1e-13
+    # full loop on the same scene, incl. pv.normal persistence
+    om = orc.OracleMap.from_flat(sc.fmap)
+    ocur, oprop = H.states(sc, orc.StatePOD)
+    pcur, pprop = H.states(sc, livo2.State)
+    full = orc.lidar_state_estimation(om, orc.lidar_cfg(sc.cfg, sc.extR, sc.extT), sc.xyz, ocur, oprop)
+    res, pts = ctx.lidar_update(pcur, pprop, H.lidar_cfg_product(sc), want=("match_plane", "normal_plane"))
+    assert res.n_iters == full["n_iters"]
+    assert np.array_equal(pts["match_plane"], full["match_plane"])
+    has_n = np.linalg.norm(full["normal"], axis=1) > 0
+    assert np.array_equal(has_n, pts["normal_plane"] >= 0)
+    assert np.array_equal(sc.fmap.plane_normal[pts["normal_plane"][has_n]], full["normal"][has_n])
+    d = H.state_diff(res.state, full["state"])
+    assert d["R"] < 1e-10 and d["t"] < 1e-9 and d["P"] < 1e-8, d
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 257, 1000])
+def test_ragged_sizes(ctx, livo2, orc, n):
+    sc = synth.lidar_scenario(seed=8, n_points=1000, downsample=0.1)
+    sc.xyz = np.ascontiguousarray(sc.xyz[:n])
+    if n >= 2:
+        sc.xyz[1, 2] = 0.0                       # z == 0: the 0.001 patch of voxel_map.cpp:352 (cross matrix / body covariance only)
+    ref, sums, out = _both(ctx, livo2, orc, sc)
+    _check(ref, sums, out)
+    if n:
+        assert H.relerr(out["body_cov"], ref["body_cov"]) < 1e-13
+    # the full loop must also agree (n = 0: H = 0, the solution is the prior difference)
+    om = orc.OracleMap.from_flat(sc.fmap)
+    ocur, oprop = H.states(sc, orc.StatePOD)
+    pcur, pprop = H.states(sc, livo2.State)
+    full = orc.lidar_state_estimation(om, orc.lidar_cfg(sc.cfg, sc.extR, sc.extT), sc.xyz, ocur, oprop, want_points=False)
+    res, _ = ctx.lidar_update(pcur, pprop, H.lidar_cfg_product(sc))
+    assert res.n_iters == full["n_iters"]
+    d = H.state_diff(res.state, full["state"])
+    assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-7, d
+
+
+def test_update_planes_in_place(ctx, livo2, orc):
+    sc = synth.lidar_scenario(seed=12, n_points=3000, downsample=0.1)
+    fm = sc.fmap
+    rng = np.random.default_rng(0)
+    idx = rng.choice(fm.n_planes, size=min(200, fm.n_planes), replace=False).astype(np.int32)
+    ctx.upload_map(fm)
+    # perturb those planes (as UpdateVoxelMap -> init_plane would), refresh them in place, compare with a full re-upload semantics
+    fm.plane_center[idx] += rng.normal(0, 0.002, (len(idx), 3))
+    fm.plane_var[idx] *= 1.5
+    fm.plane_d[idx] = -np.einsum("ij,ij->i", fm.plane_normal[idx], fm.plane_center[idx]).astype(np.float32)
+    fm.plane_radius[idx] *= np.float32(0.9)
+    ctx.update_planes(idx, fm.plane_normal[idx], fm.plane_center[idx], fm.plane_var[idx], fm.plane_d[idx], fm.plane_radius[idx])
+    om = orc.OracleMap.from_flat(fm)
+    ocur, oprop = H.states(sc, orc.StatePOD)
+    pcur, pprop = H.states(sc, livo2.State)
+    ref = orc.lidar_iterate(om, orc.lidar_cfg(sc.cfg, sc.extR, sc.extT), sc.xyz, ocur, oprop)
+    pcfg = H.lidar_cfg_product(sc)
+    ctx.set_scan(sc.xyz, pcfg)
+    sums, pts = ctx.lidar_iterate(pcur, pprop, pcfg, want=WANT)
+    _check(ref, sums, pts)
+
+
+def test_golden_fixtures(ctx, livo2):
+    sc, g = golden_io.lidar_small()
+    pcur, pprop = H.states(sc, livo2.State)
+    pcfg = H.lidar_cfg_product(sc)
+    ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, pcfg)
+    sums, pts = ctx.lidar_iterate(pcur, pprop, pcfg, want=("match_plane", "dis_to_plane", "point_w"))
+    assert np.array_equal(pts["match_plane"], g["it_match"]) and np.array_equal(pts["dis_to_plane"], g["it_dis"]) and np.array_equal(pts["point_w"], g["it_pw"])
+    assert H.relerr(np.array(sums.HtH).reshape(6, 6), g["it_HtH"]) < 1e-11
+    res, _ = ctx.lidar_update(pcur, pprop, pcfg)
+    assert res.n_iters == int(g["n_iters"])
+    assert np.allclose(res.state.R, g["out_R"], atol=1e-10) and np.allclose(res.state.t, g["out_t"], atol=1e-9) and H.relerr(res.state.P, g["out_P"]) < 1e-8
+    vs, g = golden_io.visual_small()
+    vcur, vprop = H.states(vs, livo2.State)
+    vcfg = H.visual_cfg_product(vs)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    sums, errors, z, Hs = ctx.visual_iterate(int(g["it_level"]), vcur, vcfg, rows=True)
+    assert np.array_equal(z, g["it_z"]) and H.relerr(Hs, g["it_H"]) < 1e-14 and H.relerr(np.array(sums.HtH).reshape(7, 7), g["it_HtH"]) < 1e-11
+    res, _ = ctx.visual_update(vcur, vprop, vcfg)
+    steps = np.array([(s.level, s.iteration, s.accepted, s.n_meas) for s in res.steps[:res.n_steps]])
+    assert np.array_equal(steps, g["steps"])
+    assert np.allclose(res.state.R, g["out_R"], atol=1e-10) and np.allclose(res.state.t, g["out_t"], atol=1e-9) and abs(res.state.inv_expo - float(g["out_tau"])) < 1e-9
+
+
+def test_visual_edges(ctx, livo2, orc):
+    vs = synth.visual_scenario(seed=14, n_patches=20)
+    vcfg = H.visual_cfg_product(vs)
+    vcur, vprop = H.states(vs, livo2.State)
+    # M == 0: computeJacobianAndUpdateEKF returns immediately (vio.cpp:786): state unchanged
+    ctx.set_frame(vs.img, vs.pos[:0], vs.warp_patch[:0], vs.search_levels[:0], vs.inv_expo_list[:0])
+    res, _ = ctx.visual_update(vcur, vprop, vcfg)
+    assert res.n_steps == 0 and np.array_equal(res.state.R, vcur.R) and np.array_equal(res.state.P, vcur.P)
+    # a patch whose window leaves the image is skipped by the HIP path (the reference would read out of bounds)
+    Rci, Pci = synth.vio_constants(vs.extR, vs.extT, vs.Rcl, vs.Pcl)
+    Rcw = Rci @ vs.R_prior.T; Pcw = -Rci @ vs.R_prior.T @ vs.t_prior + Pci
+    p_c = np.array([(3.0 - vs.cam["cx"]) / vs.cam["fx"] * 5.0, (3.0 - vs.cam["cy"]) / vs.cam["fy"] * 5.0, 5.0])     # projects to pixel (3,3)
+    pos = np.vstack([vs.pos, (p_c - Pcw) @ Rcw])
+    warp = np.concatenate([vs.warp_patch, vs.warp_patch[:1]]); sl = np.append(vs.search_levels, 0).astype(np.int32); ie = np.append(vs.inv_expo_list, 1.0)
+    ctx.set_frame(vs.img, pos, warp, sl, ie)
+    sums, errors, _, _ = ctx.visual_iterate(0, vcur, vcfg)
+    assert sums.n_meas == 64 * len(vs.pos) and errors[-1] == 0
+    ref = orc.visual_iterate(orc.visual_cfg(vs), vs, 0, H.states(vs, orc.StatePOD)[0])
+    assert H.relerr(np.array(sums.HtH).reshape(7, 7), ref["HtH"]) < 1e-11
+
+
+def test_error_codes_and_determinism(livo2):
+    c = livo2.Context(0)
+    sc = synth.lidar_scenario(seed=8, n_points=800, downsample=0.1)
+    cfg = H.lidar_cfg_product(sc)
+    cur, prop = H.states(sc, livo2.State)
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.lidar_update(cur, prop, cfg)
+    assert e.value.code == livo2.abi.ERR_NO_MAP
+    c.upload_map(sc.fmap)
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.lidar_update(cur, prop, cfg)
+    assert e.value.code == livo2.abi.ERR_NO_SCAN
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.visual_update(cur, prop, H.visual_cfg_product(synth.visual_scenario(seed=1, n_patches=2)))
+    assert e.value.code == livo2.abi.ERR_NO_FRAME
+    bad = H.lidar_cfg_product(sc); bad.max_iterations = 0
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.set_scan(sc.xyz, bad)
+    assert e.value.code == livo2.abi.ERR_INVALID
+    c.set_scan(sc.xyz, cfg)
+    a, _ = c.lidar_update(cur, prop, cfg)
+    b, _ = c.lidar_update(cur, prop, cfg)
+    assert bytes(a.state) == bytes(b.state) and bytes(a.iter_sums) == bytes(b.iter_sums)      # bit-reproducible run to run
+    c.close()
