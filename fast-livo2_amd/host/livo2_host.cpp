@@ -1,0 +1,149 @@
+// See livo2_host.hpp.  Pure data movement between the reference-shaped containers and the C ABI.
+#include "livo2_host.hpp"
+
+#include <cmath>
+
+namespace livo2 {
+
+namespace {
+struct Flat {
+  std::vector<int64_t> root_key; std::vector<int32_t> root_node; std::vector<double> root_center; std::vector<float> root_quarter;
+  std::vector<int32_t> node_plane, node_child;
+  std::vector<double> plane_normal, plane_center, plane_var; std::vector<float> plane_d, plane_radius;
+};
+
+int32_t flatten_node(const VoxelOctoTree *t, int layer, Flat &f, std::unordered_map<const VoxelPlane *, int32_t> &pidx, std::vector<const VoxelPlane *> &by_index,
+                     std::vector<int> &plane_layer) {
+  const int32_t me = (int32_t)f.node_plane.size();
+  f.node_plane.push_back(-1);
+  f.node_child.insert(f.node_child.end(), 8, -1);
+  const VoxelPlane *p = t->plane_ptr_;
+  if (p && p->is_plane_) {
+    const int32_t pi = (int32_t)f.plane_d.size();
+    pidx[p] = pi; by_index.push_back(p); plane_layer.push_back(layer);
+    f.plane_normal.insert(f.plane_normal.end(), p->normal_.begin(), p->normal_.end());
+    f.plane_center.insert(f.plane_center.end(), p->center_.begin(), p->center_.end());
+    f.plane_var.insert(f.plane_var.end(), p->plane_var_.begin(), p->plane_var_.end());
+    f.plane_d.push_back(p->d_); f.plane_radius.push_back(p->radius_);
+    f.node_plane[me] = pi;
+  }
+  for (int k = 0; k < 8; k++)
+    if (t->leaves_[k]) { const int32_t c = flatten_node(t->leaves_[k], layer + 1, f, pidx, by_index, plane_layer); f.node_child[(size_t)me * 8 + k] = c; }
+  return me;
+}
+} // namespace
+
+void VoxelMapManager::FlattenAndUpload() {
+  Flat f;
+  plane_index_.clear(); plane_by_index_.clear(); plane_layer_.clear();
+  for (const auto &kv : voxel_map_) {
+    f.root_key.push_back(kv.first.x); f.root_key.push_back(kv.first.y); f.root_key.push_back(kv.first.z);
+    for (int k = 0; k < 3; k++) f.root_center.push_back(kv.second->voxel_center_[k]);
+    f.root_quarter.push_back(kv.second->quater_length_);
+    f.root_node.push_back(flatten_node(kv.second, 0, f, plane_index_, plane_by_index_, plane_layer_));
+  }
+  livo2_map_view mv{};
+  mv.n_roots = (int32_t)f.root_node.size(); mv.n_nodes = (int32_t)f.node_plane.size(); mv.n_planes = (int32_t)f.plane_d.size();
+  mv.root_key = f.root_key.data(); mv.root_node = f.root_node.data(); mv.root_center = f.root_center.data(); mv.root_quarter = f.root_quarter.data();
+  mv.node_plane = f.node_plane.data(); mv.node_child = f.node_child.data();
+  mv.plane_normal = f.plane_normal.data(); mv.plane_center = f.plane_center.data(); mv.plane_var = f.plane_var.data();
+  mv.plane_d = f.plane_d.data(); mv.plane_radius = f.plane_radius.data();
+  dev_.check(livo2_map_upload(dev_.ctx(), &mv));
+  map_dirty_ = false;
+}
+
+void VoxelMapManager::RefreshPlanes(const std::vector<const VoxelPlane *> &planes) {
+  if (map_dirty_) return;                   // a full upload is pending anyway
+  std::vector<int32_t> idx; std::vector<double> n, c, pv; std::vector<float> d, r;
+  for (const VoxelPlane *p : planes) {
+    auto it = plane_index_.find(p);
+    if (it == plane_index_.end() || !p->is_plane_) { map_dirty_ = true; return; }   // structural change: re-flatten
+    idx.push_back(it->second);
+    n.insert(n.end(), p->normal_.begin(), p->normal_.end()); c.insert(c.end(), p->center_.begin(), p->center_.end());
+    pv.insert(pv.end(), p->plane_var_.begin(), p->plane_var_.end()); d.push_back(p->d_); r.push_back(p->radius_);
+  }
+  dev_.check(livo2_map_update_planes(dev_.ctx(), idx.data(), (int32_t)idx.size(), n.data(), c.data(), pv.data(), d.data(), r.data()));
+}
+
+void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
+  if (map_dirty_) FlattenAndUpload();
+  const int n = (int)feats_down_body_.size();
+  feats_down_size_ = n;
+  livo2_lidar_cfg cfg{};
+  cfg.max_iterations = config_setting_.max_iterations_; cfg.max_layer = config_setting_.max_layer_; cfg.sigma_num = config_setting_.sigma_num_;
+  cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
+  std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
+  static_assert(sizeof(PointXYZ) == 12, "xyz AoS");
+  dev_.check(livo2_lidar_set_scan(dev_.ctx(), n ? &feats_down_body_[0].x : nullptr, n, &cfg));
+
+  std::vector<int32_t> match(n), normal_plane(n);
+  std::vector<float> dis(n), pw((size_t)n * 3);
+  std::vector<double> var((size_t)n * 9), bcov((size_t)n * 9);
+  livo2_lidar_points pts{};
+  pts.match_plane = match.data(); pts.dis_to_plane = dis.data(); pts.point_w = pw.data(); pts.normal_plane = normal_plane.data();
+  pts.var = var.data(); pts.body_cov = bcov.data();
+  livo2_state s_in, s_prop;
+  state_.to_abi(s_in); state_propagat.to_abi(s_prop);
+  livo2_lidar_result res;
+  dev_.check(livo2_lidar_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, &pts));
+  state_.from_abi(res.state);
+  std::memcpy(position_last_.data(), res.position_last, 24);
+
+  // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811)
+  pv_list_.assign(n, pointWithVar());
+  cross_mat_list_.resize(n); body_cov_list_.resize(n);
+  ptpl_list_.clear();
+  for (int i = 0; i < n; i++) {
+    pointWithVar &pv = pv_list_[i];
+    const PointXYZ &p = feats_down_body_[i];
+    pv.point_b = {p.x, p.y, p.z};
+    pv.point_w = {pw[(size_t)i * 3], pw[(size_t)i * 3 + 1], pw[(size_t)i * 3 + 2]};
+    std::memcpy(pv.var.data(), &var[(size_t)i * 9], 72);
+    std::memcpy(pv.body_var.data(), &bcov[(size_t)i * 9], 72);
+    body_cov_list_[i] = pv.body_var;
+    double pz = (p.z == 0) ? 0.001 : (double)p.z;                                   // reference src/voxel_map.cpp:352-358
+    double q[3];
+    for (int j = 0; j < 3; j++) q[j] = extR_[j * 3] * p.x + extR_[j * 3 + 1] * p.y + extR_[j * 3 + 2] * pz + extT_[j];
+    cross_mat_list_[i] = {0.0, -q[2], q[1], q[2], 0.0, -q[0], -q[1], q[0], 0.0};
+    if (normal_plane[i] >= 0) pv.normal = plane_by_index_[normal_plane[i]]->normal_;
+    if (match[i] >= 0) {
+      const VoxelPlane *pl = plane_by_index_[match[i]];
+      PointToPlane pp;
+      pp.point_b_ = pv.point_b; pp.point_w_ = pv.point_w; pp.normal_ = pl->normal_; pp.center_ = pl->center_; pp.plane_var_ = pl->plane_var_;
+      pp.body_cov_ = pv.body_var; pp.layer_ = plane_layer_[match[i]]; pp.d_ = pl->d_; pp.is_valid_ = true; pp.dis_to_plane_ = dis[i];
+      ptpl_list_.push_back(pp);
+    }
+  }
+  effct_feat_num_ = (int)ptpl_list_.size();
+}
+
+void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
+  if (total_points == 0) return;            // reference src/vio.cpp:786
+  const int M = total_points, L = patch_pyrimid_level;
+  std::vector<double> pos((size_t)M * 3);
+  std::vector<float> warp((size_t)M * L * 64);
+  for (int i = 0; i < M; i++) {
+    std::memcpy(&pos[(size_t)i * 3], visual_submap->voxel_points[i]->pos_.data(), 24);
+    std::memcpy(&warp[(size_t)i * L * 64], visual_submap->warp_patch[i].data(), (size_t)L * 64 * sizeof(float));   // ragged vector<vector<float>> -> [M][L][64]
+  }
+  dev_.check(livo2_visual_set_frame(dev_.ctx(), img.data, img.cols, img.rows, img.step, pos.data(), warp.data(), visual_submap->search_levels.data(),
+                                    visual_submap->inv_expo_list.data(), M, L));
+  livo2_visual_cfg cfg{};
+  cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = 0; cfg.cam.width = width; cfg.cam.height = height;
+  std::memcpy(cfg.Rcl, Rcl.data(), 72); std::memcpy(cfg.Pcl, Pcl.data(), 24); std::memcpy(cfg.extR, extR.data(), 72); std::memcpy(cfg.extT, extT.data(), 24);
+  cfg.img_point_cov = img_point_cov; cfg.patch_pyrimid_level = L; cfg.max_iterations = max_iterations;
+  cfg.exposure_estimate_en = exposure_estimate_en; cfg.inverse_composition_en = inverse_composition_en;
+  livo2_state s_in, s_prop;
+  state->to_abi(s_in); state_propagat->to_abi(s_prop);
+  static livo2_visual_result res;
+  visual_submap->errors.resize(M);
+  dev_.check(livo2_visual_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, visual_submap->errors.data()));
+  state->from_abi(res.state);
+  std::memcpy(G.data(), res.G, sizeof(res.G));
+  std::memcpy(Rcw.data(), res.Rcw, 72); std::memcpy(Pcw.data(), res.Pcw, 24);     // new_frame_->T_f_w_ = SE3(Rcw, Pcw)
+  H_T_H.fill(0.0);
+  for (int k = res.n_steps - 1; k >= 0; k--)
+    if (res.steps[k].accepted) { for (int r = 0; r < 7; r++) for (int c = 0; c < 7; c++) H_T_H[r * LIVO2_DIM_STATE + c] = res.steps[k].HtH[r * 7 + c]; break; }
+}
+
+} // namespace livo2

@@ -1,0 +1,179 @@
+// C++ host shim: the reference's operator surface for the ESIKF measurement update, implemented on top of the C ABI
+// (include/livo2_hip.h).  Class / member names mirror the reference so that call sites read the same:
+//   VoxelMapManager::StateEstimation(StatesGroup&)            reference include/voxel_map.h:229, src/voxel_map.cpp:338-511
+//   VIOManager::computeJacobianAndUpdateEKF(img)              reference include/vio.h:153,     src/vio.cpp:784-802
+//   StatesGroup, pointWithVar, PointToPlane, VoxelPlane, VOXEL_LOCATION, VoxelOctoTree, VoxelMapConfig, SubSparseMap, VisualPoint
+// Eigen / PCL / OpenCV are not available in this image, so vectors and matrices are plain row-major arrays (V3D = double[3],
+// M3D = double[9]); INTEGRATION.md shows the same shim against the reference's Eigen types.
+// No arithmetic of the update happens here: the shim only flattens the pointer-based VoxelMap into the index-based snapshot the
+// ABI takes, moves data across, and scatters the results back into the members the rest of LIVMapper reads.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/livo2_hip.h"
+
+namespace livo2 {
+
+typedef std::array<double, 3> V3D;
+typedef std::array<double, 9> M3D;          // row-major
+
+struct StatesGroup {                        // reference include/common_lib.h:126-223
+  M3D rot_end{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  V3D pos_end{}, vel_end{}, bias_g{}, bias_a{}, gravity{};
+  double inv_expo_time = 1.0;
+  std::array<double, LIVO2_DIM_STATE * LIVO2_DIM_STATE> cov{};
+  StatesGroup() {
+    for (int i = 0; i < LIVO2_DIM_STATE; i++) cov[i * LIVO2_DIM_STATE + i] = 0.01;
+    cov[6 * LIVO2_DIM_STATE + 6] = 0.00001;
+    for (int i = 10; i < 19; i++) cov[i * LIVO2_DIM_STATE + i] = 0.00001;
+  }
+  void to_abi(livo2_state &s) const {
+    std::memcpy(s.rot, rot_end.data(), 72); std::memcpy(s.pos, pos_end.data(), 24); s.inv_expo = inv_expo_time;
+    std::memcpy(s.vel, vel_end.data(), 24); std::memcpy(s.bg, bias_g.data(), 24); std::memcpy(s.ba, bias_a.data(), 24);
+    std::memcpy(s.grav, gravity.data(), 24); std::memcpy(s.cov, cov.data(), sizeof(s.cov));
+  }
+  void from_abi(const livo2_state &s) {
+    std::memcpy(rot_end.data(), s.rot, 72); std::memcpy(pos_end.data(), s.pos, 24); inv_expo_time = s.inv_expo;
+    std::memcpy(vel_end.data(), s.vel, 24); std::memcpy(bias_g.data(), s.bg, 24); std::memcpy(bias_a.data(), s.ba, 24);
+    std::memcpy(gravity.data(), s.grav, 24); std::memcpy(cov.data(), s.cov, sizeof(s.cov));
+  }
+};
+
+struct PointXYZ { float x, y, z; };         // the fields of pcl::PointXYZINormal the path reads
+
+struct pointWithVar {                       // reference include/common_lib.h:102-123
+  V3D point_b{}, point_i{}, point_w{}, normal{};
+  M3D var_nostate{}, body_var{}, var{}, point_crossmat{};
+};
+
+struct PointToPlane {                       // reference include/voxel_map.h:54-67
+  V3D point_b_{}, point_w_{}, normal_{}, center_{};
+  std::array<double, 36> plane_var_{};
+  M3D body_cov_{};
+  int layer_ = 0;
+  double d_ = 0, eigen_value_ = 0;
+  bool is_valid_ = false;
+  float dis_to_plane_ = 0;
+};
+
+struct VoxelPlane {                         // reference include/voxel_map.h:69-94 (fields the update reads)
+  V3D center_{}, normal_{};
+  std::array<double, 36> plane_var_{};
+  float radius_ = 0, d_ = 0;
+  bool is_plane_ = false, is_update_ = false;
+};
+
+struct VOXEL_LOCATION {                     // reference include/voxel_map.h:96-104
+  int64_t x, y, z;
+  VOXEL_LOCATION(int64_t vx = 0, int64_t vy = 0, int64_t vz = 0) : x(vx), y(vy), z(vz) {}
+  bool operator==(const VOXEL_LOCATION &o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct VoxelLocationHash {                  // reference include/voxel_map.h:109-117
+  size_t operator()(const VOXEL_LOCATION &s) const {
+    return (size_t)(((((s.z) * 116101) % 10000000000LL + (s.y)) * 116101) % 10000000000LL + (s.x));
+  }
+};
+
+struct VoxelOctoTree {                      // reference include/voxel_map.h:129-183 (fields the update reads)
+  VoxelPlane *plane_ptr_ = new VoxelPlane;
+  int layer_ = 0;
+  VoxelOctoTree *leaves_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double voxel_center_[3] = {0, 0, 0};
+  float quater_length_ = 0;
+  ~VoxelOctoTree() { for (auto *l : leaves_) delete l; delete plane_ptr_; }
+};
+
+struct VoxelMapConfig {                     // reference include/voxel_map.h:35-52
+  double max_voxel_size_ = 0.5;
+  int max_layer_ = 2, max_iterations_ = 5;
+  double beam_err_ = 0.05, dept_err_ = 0.02, sigma_num_ = 3;
+};
+
+class Device {                              // one GPU + stream, shared by the two managers of a LIVMapper
+public:
+  explicit Device(int device = 0) { if (livo2_ctx_create(device, &ctx_) != LIVO2_OK) throw std::runtime_error("livo2_ctx_create failed: no gfx950 device"); }
+  ~Device() { livo2_ctx_destroy(ctx_); }
+  Device(const Device &) = delete;
+  Device &operator=(const Device &) = delete;
+  livo2_ctx *ctx() const { return ctx_; }
+  void check(int rc) const { if (rc != LIVO2_OK) throw std::runtime_error(std::string("livo2: ") + livo2_last_error(ctx_)); }
+private:
+  livo2_ctx *ctx_ = nullptr;
+};
+
+class VoxelMapManager {                     // reference include/voxel_map.h:187-256
+public:
+  VoxelMapConfig config_setting_;
+  std::unordered_map<VOXEL_LOCATION, VoxelOctoTree *, VoxelLocationHash> voxel_map_;
+  std::vector<PointXYZ> feats_down_body_;
+  int feats_down_size_ = 0, effct_feat_num_ = 0;
+  M3D extR_{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  V3D extT_{};
+  StatesGroup state_;
+  V3D position_last_{};
+  std::vector<M3D> cross_mat_list_, body_cov_list_;
+  std::vector<pointWithVar> pv_list_;
+  std::vector<PointToPlane> ptpl_list_;
+
+  explicit VoxelMapManager(Device &dev) : dev_(dev) {}
+  ~VoxelMapManager() { for (auto &kv : voxel_map_) delete kv.second; }
+
+  // Call after BuildVoxelMap / UpdateVoxelMap changed the tree structure (new voxels / nodes).  Plane-only refreshes can go
+  // through RefreshPlanes instead.
+  void MarkMapDirty() { map_dirty_ = true; }
+  // VoxelPlane::is_update_ planes (reference include/voxel_map.h:86): refresh their records in place.
+  void RefreshPlanes(const std::vector<const VoxelPlane *> &planes);
+
+  void StateEstimation(StatesGroup &state_propagat);   // reference src/voxel_map.cpp:338-511
+
+private:
+  void FlattenAndUpload();
+  Device &dev_;
+  bool map_dirty_ = true;
+  std::unordered_map<const VoxelPlane *, int32_t> plane_index_;
+  std::vector<const VoxelPlane *> plane_by_index_;
+  std::vector<int> plane_layer_;
+};
+
+// ---- visual ---------------------------------------------------------------------------------------------------------------
+struct VisualPoint { V3D pos_{}; };         // reference include/visual_point.h:23-46 (pos_ only)
+
+struct SubSparseMap {                       // reference include/vio.h:26-57
+  std::vector<float> errors;
+  std::vector<std::vector<float>> warp_patch;
+  std::vector<int> search_levels;
+  std::vector<VisualPoint *> voxel_points;
+  std::vector<double> inv_expo_list;
+};
+
+struct GrayImage { const uint8_t *data = nullptr; int cols = 0, rows = 0, step = 0; };   // cv::Mat CV_8UC1 view
+
+class VIOManager {                          // reference include/vio.h:89-186 (members the update reads / writes)
+public:
+  StatesGroup *state = nullptr, *state_propagat = nullptr;
+  M3D Rcl{{1, 0, 0, 0, 1, 0, 0, 0, 1}}, extR{{1, 0, 0, 0, 1, 0, 0, 0, 1}}, Rcw{};
+  V3D Pcl{}, extT{}, Pcw{};
+  double fx = 0, fy = 0, cx = 0, cy = 0;
+  int width = 0, height = 0;
+  int patch_pyrimid_level = 4, patch_size = 8, max_iterations = 5, total_points = 0;
+  double img_point_cov = 100;
+  bool exposure_estimate_en = true, inverse_composition_en = false;
+  SubSparseMap *visual_submap = nullptr;
+  std::array<double, LIVO2_DIM_STATE * LIVO2_DIM_STATE> G{}, H_T_H{};
+
+  explicit VIOManager(Device &dev) : dev_(dev) {}
+  void setImuToLidarExtrinsic(const V3D &transl, const M3D &rot) { extT = transl; extR = rot; }      // reference src/vio.cpp:27-31
+  void setLidarToCameraExtrinsic(const M3D &R, const V3D &P) { Rcl = R; Pcl = P; }                     // reference src/vio.cpp:33-37
+  void computeJacobianAndUpdateEKF(const GrayImage &img);                                              // reference src/vio.cpp:784-802
+
+private:
+  Device &dev_;
+};
+
+} // namespace livo2

@@ -1,0 +1,119 @@
+// Drives the C++ host shim exactly the way LIVMapper drives the reference managers (src/LIVMapper.cpp:357-372, src/vio.cpp:1806-1810):
+// fills a VoxelMapManager (pointer-based voxel_map_, feats_down_body_, state_) / a VIOManager (visual_submap, *state) from a dump
+// directory written by tests/test_host_shim_gpu.py, calls StateEstimation / computeJacobianAndUpdateEKF, and writes what the rest
+// of the pipeline would read back.  Usage: shim_demo <dir>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "livo2_host.hpp"
+
+using namespace livo2;
+
+template <typename T> static std::vector<T> rd(const std::string &dir, const char *name) {
+  std::ifstream f(dir + "/" + name + ".bin", std::ios::binary | std::ios::ate);
+  if (!f) return {};
+  size_t bytes = (size_t)f.tellg(); f.seekg(0);
+  std::vector<T> v(bytes / sizeof(T));
+  f.read((char *)v.data(), bytes);
+  return v;
+}
+template <typename T> static void wr(const std::string &dir, const char *name, const T *p, size_t n) {
+  std::ofstream f(dir + "/" + name + ".bin", std::ios::binary);
+  f.write((const char *)p, n * sizeof(T));
+}
+static StatesGroup state_from(const std::vector<double> &v) {       // 25 scalars + 361
+  StatesGroup s; livo2_state a;
+  std::memcpy(&a, v.data(), sizeof(a)); s.from_abi(a); return s;
+}
+static std::vector<double> state_to(const StatesGroup &s) { livo2_state a; s.to_abi(a); std::vector<double> v(sizeof(a) / 8); std::memcpy(v.data(), &a, sizeof(a)); return v; }
+
+static VoxelOctoTree *build(int node, int layer, const std::vector<int32_t> &node_plane, const std::vector<int32_t> &node_child, const std::vector<double> &pn,
+                            const std::vector<double> &pc, const std::vector<double> &pv, const std::vector<float> &pd, const std::vector<float> &pr) {
+  VoxelOctoTree *t = new VoxelOctoTree; t->layer_ = layer;
+  int pi = node_plane[node];
+  if (pi >= 0) {
+    VoxelPlane *p = t->plane_ptr_;
+    for (int k = 0; k < 3; k++) { p->normal_[k] = pn[pi * 3 + k]; p->center_[k] = pc[pi * 3 + k]; }
+    for (int k = 0; k < 36; k++) p->plane_var_[k] = pv[(size_t)pi * 36 + k];
+    p->d_ = pd[pi]; p->radius_ = pr[pi]; p->is_plane_ = true;
+  }
+  for (int k = 0; k < 8; k++) { int c = node_child[(size_t)node * 8 + k]; if (c >= 0) t->leaves_[k] = build(c, layer + 1, node_plane, node_child, pn, pc, pv, pd, pr); }
+  return t;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: shim_demo <dir>\n"); return 2; }
+  const std::string dir = argv[1];
+  try {
+    Device dev(0);
+    // ---- LiDAR ------------------------------------------------------------------------------------------------------------
+    auto keys = rd<int64_t>(dir, "root_key");
+    if (!keys.empty()) {
+      auto root_node = rd<int32_t>(dir, "root_node"); auto rc = rd<double>(dir, "root_center"); auto rq = rd<float>(dir, "root_quarter");
+      auto node_plane = rd<int32_t>(dir, "node_plane"), node_child = rd<int32_t>(dir, "node_child");
+      auto pn = rd<double>(dir, "plane_normal"), pc = rd<double>(dir, "plane_center"), pv = rd<double>(dir, "plane_var");
+      auto pd = rd<float>(dir, "plane_d"), pr = rd<float>(dir, "plane_radius");
+      auto xyz = rd<float>(dir, "xyz"); auto cfgv = rd<double>(dir, "lidar_cfg");     // max_it, max_layer, sigma, dept, beam, voxel, extR9, extT3
+      VoxelMapManager vm(dev);
+      for (size_t r = 0; r < root_node.size(); r++) {
+        VoxelOctoTree *t = build(root_node[r], 0, node_plane, node_child, pn, pc, pv, pd, pr);
+        for (int k = 0; k < 3; k++) t->voxel_center_[k] = rc[r * 3 + k];
+        t->quater_length_ = rq[r];
+        vm.voxel_map_[VOXEL_LOCATION(keys[r * 3], keys[r * 3 + 1], keys[r * 3 + 2])] = t;
+      }
+      vm.config_setting_.max_iterations_ = (int)cfgv[0]; vm.config_setting_.max_layer_ = (int)cfgv[1]; vm.config_setting_.sigma_num_ = cfgv[2];
+      vm.config_setting_.dept_err_ = cfgv[3]; vm.config_setting_.beam_err_ = cfgv[4]; vm.config_setting_.max_voxel_size_ = cfgv[5];
+      for (int k = 0; k < 9; k++) vm.extR_[k] = cfgv[6 + k];
+      for (int k = 0; k < 3; k++) vm.extT_[k] = cfgv[15 + k];
+      vm.feats_down_body_.resize(xyz.size() / 3);
+      std::memcpy(vm.feats_down_body_.data(), xyz.data(), xyz.size() * 4);
+      vm.state_ = state_from(rd<double>(dir, "state_in"));
+      StatesGroup prop = state_from(rd<double>(dir, "state_prop"));
+      vm.StateEstimation(prop);                                        // <- the reference call site (src/LIVMapper.cpp:370)
+      auto so = state_to(vm.state_);
+      wr(dir, "out_state", so.data(), so.size());
+      std::vector<double> normals, pvvar; std::vector<float> dis; std::vector<double> ptw;
+      for (auto &pvx : vm.pv_list_) { normals.insert(normals.end(), pvx.normal.begin(), pvx.normal.end()); pvvar.insert(pvvar.end(), pvx.var.begin(), pvx.var.end()); }
+      for (auto &pp : vm.ptpl_list_) { dis.push_back(pp.dis_to_plane_); ptw.insert(ptw.end(), pp.point_w_.begin(), pp.point_w_.end()); }
+      wr(dir, "out_pv_normal", normals.data(), normals.size()); wr(dir, "out_pv_var", pvvar.data(), pvvar.size());
+      wr(dir, "out_ptpl_dis", dis.data(), dis.size()); wr(dir, "out_ptpl_pw", ptw.data(), ptw.size());
+      int32_t eff = vm.effct_feat_num_; wr(dir, "out_effct", &eff, 1);
+      std::printf("lidar: effct_feat_num_=%d\n", vm.effct_feat_num_);
+    }
+    // ---- visual -----------------------------------------------------------------------------------------------------------
+    auto img = rd<uint8_t>(dir, "img");
+    if (!img.empty()) {
+      auto cam = rd<double>(dir, "vis_cfg");   // fx fy cx cy w h img_point_cov L max_it exposure Rcl9 Pcl3 extR9 extT3
+      auto pos = rd<double>(dir, "vis_pos"); auto warp = rd<float>(dir, "vis_warp"); auto sl = rd<int32_t>(dir, "vis_search"); auto ie = rd<double>(dir, "vis_invexpo");
+      VIOManager vio(dev);
+      vio.fx = cam[0]; vio.fy = cam[1]; vio.cx = cam[2]; vio.cy = cam[3]; vio.width = (int)cam[4]; vio.height = (int)cam[5];
+      vio.img_point_cov = cam[6]; vio.patch_pyrimid_level = (int)cam[7]; vio.max_iterations = (int)cam[8]; vio.exposure_estimate_en = cam[9] != 0;
+      M3D Rcl, extR; V3D Pcl, extT;
+      for (int k = 0; k < 9; k++) { Rcl[k] = cam[10 + k]; extR[k] = cam[22 + k]; }
+      for (int k = 0; k < 3; k++) { Pcl[k] = cam[19 + k]; extT[k] = cam[31 + k]; }
+      vio.setImuToLidarExtrinsic(extT, extR); vio.setLidarToCameraExtrinsic(Rcl, Pcl);
+      const int M = (int)sl.size(), L = vio.patch_pyrimid_level;
+      std::vector<VisualPoint> pts(M);
+      SubSparseMap sm;
+      for (int i = 0; i < M; i++) {
+        for (int k = 0; k < 3; k++) pts[i].pos_[k] = pos[(size_t)i * 3 + k];
+        sm.voxel_points.push_back(&pts[i]);
+        sm.warp_patch.emplace_back(warp.begin() + (size_t)i * L * 64, warp.begin() + (size_t)(i + 1) * L * 64);
+        sm.search_levels.push_back(sl[i]); sm.inv_expo_list.push_back(ie[i]);
+      }
+      vio.visual_submap = &sm; vio.total_points = M;
+      StatesGroup st = state_from(rd<double>(dir, "vis_state_in")), prop = state_from(rd<double>(dir, "vis_state_prop"));
+      vio.state = &st; vio.state_propagat = &prop;
+      GrayImage g{img.data(), vio.width, vio.height, vio.width};
+      vio.computeJacobianAndUpdateEKF(g);                              // <- the reference call site (src/vio.cpp:1810)
+      auto so = state_to(st);
+      wr(dir, "vis_out_state", so.data(), so.size());
+      wr(dir, "vis_out_errors", sm.errors.data(), sm.errors.size());
+      wr(dir, "vis_out_G", vio.G.data(), vio.G.size());
+      std::printf("visual: M=%d\n", M);
+    }
+  } catch (const std::exception &e) { std::fprintf(stderr, "shim_demo: %s\n", e.what()); return 1; }
+  return 0;
+}
