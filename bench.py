@@ -124,11 +124,27 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    value = world * n * args.steps / elapsed
+    frames = importlib.import_module("fast-livo2_amd.frames")
+    elapsed = frames.max_over_ranks(elapsed, dist, device="cuda")
+    n_all = int(frames.gather_results(np.array([[float(n)]]), world, dist, device="cuda").sum()) if dist is not None else n
+    value = n_all * args.steps / elapsed
+
+    # ---- frames/s leg (BASELINE "frames/sec at 1/2/4/8 GPU"): every rank replays F whole frames = scan upload (H2D, Morton sort, body
+    # covariance) + full StateEstimation loop on the GPU + result read-back; frames shard round-robin, results are gathered ----
+    F_per_rank = 16
+    ctx.set_scan(sc.xyz, cfg); ctx.lidar_update_async(cur, prop, cfg); ctx.lidar_update_fetch()
+    barrier()
+    tf0 = time.perf_counter()
+    local = []
+    for _ in range(F_per_rank):
+        ctx.set_scan(sc.xyz, cfg)
+        ctx.lidar_update_async(cur, prop, cfg)
+        rf = ctx.lidar_update_fetch()
+        local.append(np.concatenate([np.array(rf.state.pos), [rf.n_iters, rf.iter_sums[rf.n_iters - 1].n_eff]]))
+    ctx.synchronize()
+    tframes = frames.max_over_ranks(time.perf_counter() - tf0, dist, device="cuda")
+    gathered = frames.gather_results(np.array(local), F_per_rank * world, dist, device="cuda")
+    frames_per_s = len(gathered) / tframes
 
     # ---- roofline leg: HIP-event duration of the dominant kernel over the same launch sequence ----------------------------
     ctx.kernel_timing(True)
@@ -145,7 +161,8 @@ def main():
                 "kernel": "k_lidar_residual", "kernel_us": res_us, "bytes_per_launch": LIDAR_BYTES_PER_EVAL * n, "solve_kernel_us": sol_us,
                 "traffic_note": "HBM PMC traffic: see profiles/ (FETCH_SIZE/WRITE_SIZE passes)"}
 
-    extra = {}
+    extra = {"frames_per_s": frames_per_s, "frame_points": n, "frames": int(F_per_rank * world),
+             "frame_def": "set_scan (H2D + Morton sort + body cov) + full StateEstimation loop + result read-back"}
     if rank == 0 and not args.no_extra:
         # full StateEstimation (<=5 iterations with convergence logic), end-to-end incl. result read-back
         reps = 20

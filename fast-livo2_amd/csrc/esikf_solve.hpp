@@ -25,113 +25,119 @@ struct SolveLds {
   double htz[8];
   double vec[DS + 1];
   double sol[DS + 1];
+  double cur[25], prop[25];     // the 25 non-covariance scalars of state_ / state_propagat (rot 9, pos 3, inv_expo, vel, bg, ba, grav)
 };
 
 // One Kalman update of ctl->cur given the reduced sums (s.hth: k x k row-major with stride k, s.htz).
 // sign=+1: LiDAR form (K1*HTz + vec - G*vec) ; sign=-1: visual form (-K1*HTz + vec - G*vec).
 // Leaves the solution in s.sol, G[:,0:k] in s.G (and the zero-padded 19x19 G in ctl->G).
-// Part 1 (independent of the measurement sums, so it can overlap the partial-sum loads): P' = cov / scale and
-// vec = state_propagat [-] state (common_lib.h:194-206) into LDS.  Call from wave 0 only; no barrier inside.
-__device__ inline void esikf_prefetch_wave(const DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int lane) {
-  double c[6];
+// Part 1 (independent of the measurement sums, so it overlaps the partial-sum loads): P' = cov / scale and the 25 pose / bias scalars
+// of both states into LDS.  Every later step of the solve reads LDS only: a global load issued late costs a full ~1.5-us round trip
+// on the single wave that is the critical path of the whole iteration.  Call from wave 0 only; no barrier inside.
+__device__ inline void esikf_prefetch_wave(const DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int lane, double *c /*[6] raw covariance words of this lane*/) {
 #pragma unroll
   for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; c[q] = (e < DS * DS) ? ctl->cur.cov[e] : 0.0; }
-  if (lane == 0) {
-    double rotd[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
-      rotd[i * 3 + j] = (ctl->cur.rot[i] * ctl->prop.rot[j] + ctl->cur.rot[3 + i] * ctl->prop.rot[3 + j]) + ctl->cur.rot[6 + i] * ctl->prop.rot[6 + j];   // cur^T * prop
-    double l[3]; so3_log(rotd, l);
-    for (int i = 0; i < 3; i++) {
-      s.vec[i] = l[i];
-      s.vec[3 + i] = ctl->prop.pos[i] - ctl->cur.pos[i];
-      s.vec[7 + i] = ctl->prop.vel[i] - ctl->cur.vel[i];
-      s.vec[10 + i] = ctl->prop.bg[i] - ctl->cur.bg[i];
-      s.vec[13 + i] = ctl->prop.ba[i] - ctl->cur.ba[i];
-      s.vec[16 + i] = ctl->prop.grav[i] - ctl->cur.grav[i];
-    }
-    s.vec[6] = ctl->prop.inv_expo - ctl->cur.inv_expo;
-  }
+  const double *cs = reinterpret_cast<const double *>(&ctl->cur), *ps = reinterpret_cast<const double *>(&ctl->prop);
+  double sv = 0.0;
+  if (lane < 25) sv = cs[lane]; else if (lane < 50) sv = ps[lane - 25];
 #pragma unroll
   for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; if (e < DS * DS) s.P[e] = c[q] / meas_cov_scale; }
+  if (lane < 25) s.cur[lane] = sv; else if (lane < 50) s.prop[lane - 25] = sv;
 }
 
-// Part 2: needs s.P / s.vec (esikf_prefetch_wave + a barrier) and the sums in s.hth / s.htz.
+// rotation part of vec = state_propagat [-] state: Log(cur^T prop) (common_lib.h:196-197) -> s.vec[0..2].  ~1.5 us of dependent f64
+// transcendental code on one lane, so the solve kernels run it on a second wave while the partial rows are in flight.
+__device__ inline void esikf_log_lane(const DevCtl *ctl, SolveLds &s) {
+  double rc[9], rp[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { rc[i] = ctl->cur.rot[i]; rp[i] = ctl->prop.rot[i]; }
+  double rotd[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) rotd[i * 3 + j] = (rc[i] * rp[j] + rc[3 + i] * rp[3 + j]) + rc[6 + i] * rp[6 + j];   // cur^T * prop
+  double l[3]; so3_log(rotd, l);
+  s.vec[0] = l[0]; s.vec[1] = l[1]; s.vec[2] = l[2];
+}
+
+// Part 2: needs s.P / s.cur / s.prop (esikf_prefetch_wave), s.vec[0..2] (esikf_log_lane), the sums in s.hth / s.htz, and a barrier.
+//   S = I + H_k P'_kk is built once in LDS; then lane r (r < 19) solves  S^T x = P'[r, 0:k]^T  by LU with partial pivoting ENTIRELY IN
+//   REGISTERS (the matrix is the same in every lane, so pivoting is wave-uniform and row swaps are scalar branches), which gives
+//   x = K_1[r, 0:k]; G[r, :], the Kalman solution entry and the state update follow without further LDS round trips.
+//   (The LDS Gauss-Jordan this replaces cost 2.5 us of barriers and dependent LDS latency on the critical wave.)
 template <int k>
 __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sign, const int lane) {
-  constexpr int k2 = 2 * k;
-  // aug = [ I + H_k P'_kk | I ]
-  for (int e = lane; e < k * k2; e += LIVO2_WAVE) {
-    const int i = e / k2, j = e % k2;
-    double v;
-    if (j < k) {
-      v = (i == j) ? 1.0 : 0.0;
-      for (int m = 0; m < k; m++) v = fma(s.hth[i * k + m], s.P[m * DS + j], v);
-    } else v = (j - k == i) ? 1.0 : 0.0;
-    s.aug[e] = v;
+  if (lane < k * k) {                                        // S = I + H_k P'_kk, row-major stride k
+    const int i = lane / k, j = lane % k;
+    double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < k; m++) v = fma(s.hth[i * k + m], s.P[m * DS + j], v);
+    s.aug[lane] = v;
   }
+  if (lane >= 9 && lane < 25) s.vec[lane - 6] = s.prop[lane] - s.cur[lane];     // pos, inv_expo, vel, bg, ba, grav parts of vec
   __syncthreads();
-  // Gauss-Jordan with partial pivoting; every lane scans the pivot column itself (LDS broadcast reads), so no extra hand-off
+  const int r = lane < DS ? lane : DS - 1;
+  double A[k][k], b[k];
+#pragma unroll
+  for (int i = 0; i < k; i++) {
+#pragma unroll
+    for (int j = 0; j < k; j++) A[i][j] = s.aug[j * k + i];  // A = S^T
+    b[i] = s.P[r * DS + i];
+  }
+#pragma unroll
   for (int c = 0; c < k; c++) {
-    int piv = c;
-    double best = fabs(s.aug[c * k2 + c]);
-    for (int i = c + 1; i < k; i++) { double v = fabs(s.aug[i * k2 + c]); if (v > best) { best = v; piv = i; } }
-    if (piv != c) {                                          // wave-uniform
-      if (lane < k2) { double t = s.aug[c * k2 + lane]; s.aug[c * k2 + lane] = s.aug[piv * k2 + lane]; s.aug[piv * k2 + lane] = t; }
-      __syncthreads();
-    }
-    const double pinv = 1.0 / s.aug[c * k2 + c];
-    double nv[2]; int ne[2];
+    int piv = c; double best = fabs(A[c][c]);
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int e = lane + q * LIVO2_WAVE;
-      ne[q] = e;
-      if (e < k * k2) {
-        const int i = e / k2, j = e % k2;
-        const double prow = s.aug[c * k2 + j] * pinv;
-        nv[q] = (i == c) ? prow : fma(-s.aug[i * k2 + c], prow, s.aug[e]);
+    for (int i = c + 1; i < k; i++) { const double v = fabs(A[i][c]); if (v > best) { best = v; piv = i; } }
+    piv = __builtin_amdgcn_readfirstlane(piv);
+#pragma unroll
+    for (int i = c + 1; i < k; i++)
+      if (piv == i) {                                        // wave-uniform
+#pragma unroll
+        for (int j = c; j < k; j++) { const double t = A[c][j]; A[c][j] = A[i][j]; A[i][j] = t; }
+        const double t = b[c]; b[c] = b[i]; b[i] = t;
       }
-    }
-    __syncthreads();
+    const double inv = 1.0 / A[c][c];
 #pragma unroll
-    for (int q = 0; q < 2; q++) if (ne[q] < k * k2) s.aug[ne[q]] = nv[q];
-    __syncthreads();
-  }
-  // Kc = P'[:, 0:k] * S^-1
-  for (int e = lane; e < DS * k; e += LIVO2_WAVE) {
-    const int r = e / k, c = e % k;
-    double v = 0.0;
-    for (int m = 0; m < k; m++) v = fma(s.P[r * DS + m], s.aug[m * k2 + k + c], v);
-    s.Kc[r * KMAX + c] = v;
-  }
-  __syncthreads();
-  // G[:, 0:k] = K_1[:, 0:k] * H_k
-  for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {
-    const int r = e / DS, c = e % DS;
-    double g = 0.0;
-    if (c < k) {
-      for (int m = 0; m < k; m++) g = fma(s.Kc[r * KMAX + m], s.hth[m * k + c], g);
-      s.G[r * KMAX + c] = g;
+    for (int i = c + 1; i < k; i++) {
+      const double l = A[i][c] * inv;
+#pragma unroll
+      for (int j = c + 1; j < k; j++) A[i][j] = fma(-l, A[c][j], A[i][j]);
+      b[i] = fma(-l, b[c], b[i]);
     }
-    ctl->G[e] = g;
   }
-  __syncthreads();
+  double x[k];                                               // back substitution: x = K_1[r, 0:k]
+#pragma unroll
+  for (int i = k - 1; i >= 0; i--) {
+    double t = b[i];
+#pragma unroll
+    for (int j = i + 1; j < k; j++) t = fma(-A[i][j], x[j], t);
+    x[i] = t / A[i][i];
+  }
+  double g[KMAX], kz = 0.0, gv = 0.0;                        // G[r, 0:k] = K_1[r, 0:k] H_k
+#pragma unroll
+  for (int c = 0; c < k; c++) {
+    double t = 0.0;
+#pragma unroll
+    for (int m = 0; m < k; m++) t = fma(x[m], s.hth[m * k + c], t);
+    g[c] = t;
+    kz = fma(x[c], s.htz[c], kz);
+    gv = fma(t, s.vec[c], gv);
+  }
   if (lane < DS) {
-    const int r = lane;
-    double kz = 0.0, gv = 0.0;
-    for (int m = 0; m < k; m++) { kz = fma(s.Kc[r * KMAX + m], s.htz[m], kz); gv = fma(s.G[r * KMAX + m], s.vec[m], gv); }
+#pragma unroll
+    for (int c = 0; c < KMAX; c++) { const double t = (c < k) ? g[c] : 0.0; s.G[r * KMAX + c] = t; ctl->G[r * DS + c] = t; }   // columns >= KMAX of ctl->G stay zero
     s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
   }
   __syncthreads();
-  if (lane == 0) {                                           // state += solution   (common_lib.h:182-192)
+  // state += solution   (common_lib.h:182-192), from the LDS copy
+  if (lane == 0) {
     double E[9], Rn[9];
     so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
-    mat3_mul(ctl->cur.rot, E, Rn);
+    mat3_mul(s.cur, E, Rn);
     for (int i = 0; i < 9; i++) ctl->cur.rot[i] = Rn[i];
-    for (int i = 0; i < 3; i++) {
-      ctl->cur.pos[i] += s.sol[3 + i]; ctl->cur.vel[i] += s.sol[7 + i]; ctl->cur.bg[i] += s.sol[10 + i];
-      ctl->cur.ba[i] += s.sol[13 + i]; ctl->cur.grav[i] += s.sol[16 + i];
-    }
-    ctl->cur.inv_expo += s.sol[6];
+  } else if (lane >= 9 && lane < 25) {
+    reinterpret_cast<double *>(&ctl->cur)[lane] = s.cur[lane] + s.sol[lane - 6];
   }
   __syncthreads();
 }

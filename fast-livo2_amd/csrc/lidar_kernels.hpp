@@ -33,6 +33,7 @@ struct LidarKernelArgs {
   int32_t *match_plane; float *dis; float *pw; int32_t *normal_plane; double *var; double *r_inv; double *h_row;
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *prof;        // [waves][8] s_memtime stamps (profiling build only)
+  int32_t dbg;                     // access-pattern experiments (profiling build only)
 #endif
 };
 
@@ -487,6 +488,14 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
       const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
       n1 = load_slot(a.map.slots, g1); n2 = load_slot(a.map.slots, g2);
     }
+#ifdef LIVO2_PHASE_PROF
+    if (s.val >= 0 && a.dbg) {       // timing experiments only: force an access pattern on the plane gather
+      if (a.dbg == 1) s.val = 0;
+      else if (a.dbg == 2) s.val = (i >> 2) % a.map.n_planes;
+      else if (a.dbg == 3) s.val = (i >> 4) % a.map.n_planes;
+      else if (a.dbg == 4) s.val = (int)(((unsigned)i * 7919u) % (unsigned)a.map.n_planes);
+    }
+#endif
     if (s.val >= 0) load_plane(a.map.planes, s.val, p0);         // issued right behind the neighbour slots: same round trip
     // the neighbour slots return first (in order); keep only the three words a later visit needs
     if (nbr) {
@@ -569,27 +578,27 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
   PHASE(6);
 }
 
-// Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 32 slices
-// x 32 values: slice s adds blocks s, s+32, ... in order.  The rows were written by other CUs, so every dependent load is a full
-// ~1.5-us round trip (a single wave walking them serially cost ~20 us): each thread therefore issues ALL its loads (up to 16,
+// Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 16 slices
+// x 32 values: slice s adds blocks s, s+16, ... in order.  The rows were written by other CUs, so every dependent load is a full
+// ~1.5-us round trip (a single wave walking them serially cost ~20 us): each thread therefore issues ALL its loads (up to 32,
 // i.e. 512 rows = 131k points; beyond that a loop) before the first add.  The slices are then joined in fixed order.
-// Every thread of the block must call this.
-#define SOLVE_THREADS 1024
-__device__ inline void reduce_partials_block(const double *__restrict__ partials, int nblocks, double *scratch /*[32][33]*/, double *out /*[32]*/) {
-  const int t = threadIdx.x, kidx = t & 31, slice = t >> 5;       // 32 slices
-  double v[16];
+// Every thread of the block must call this.  (512 threads, not 1024: the register-resident solve of wave 0 needs > 128 VGPRs.)
+#define SOLVE_THREADS 512
+__device__ inline void reduce_partials_block(const double *__restrict__ partials, int nblocks, double *scratch /*[16][33]*/, double *out /*[32]*/) {
+  const int t = threadIdx.x, kidx = t & 31, slice = t >> 5;       // 16 slices
+  double v[32];
 #pragma unroll
-  for (int u = 0; u < 16; u++) { const int b = slice + 32 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
+  for (int u = 0; u < 32; u++) { const int b = slice + 16 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
   double acc = 0.0;
 #pragma unroll
-  for (int u = 0; u < 16; u++) acc += v[u];
-  for (int b = slice + 512; b < nblocks; b += 32) acc += partials[(size_t)b * 32 + kidx];
+  for (int u = 0; u < 32; u++) acc += v[u];
+  for (int b = slice + 512; b < nblocks; b += 16) acc += partials[(size_t)b * 32 + kidx];
   scratch[slice * 33 + kidx] = acc;
   __syncthreads();
   if (t < 32) {
     double r = scratch[t];
 #pragma unroll
-    for (int sl = 1; sl < 32; sl++) r += scratch[sl * 33 + t];
+    for (int sl = 1; sl < 16; sl++) r += scratch[sl * 33 + t];
     out[t] = r;
   }
   __syncthreads();
@@ -598,14 +607,28 @@ __device__ inline void reduce_partials_block(const double *__restrict__ partials
 // ---- reduction + solve + loop control ----------------------------------------------------------------------------------
 // mode 0: bare iterate (only reduce and publish sums_l) ; mode 1: full ESIKF iteration `iter` of `max_iter`;
 // mode 2: like 1 but never stops (benchmark: fixed iteration count).
+#ifdef LIVO2_PHASE_PROF
+#define SPHASE(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (sprof && threadIdx.x == 0) sprof[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SOLVE_PROF_PARAM , unsigned long long *sprof
+#else
+#define SPHASE(k) do { } while (0)
+#define SOLVE_PROF_PARAM
+#endif
 __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
-                                                              int max_iter) {
-  if (mode == 1 && ctl->hdr.stop) return;
+                                                              int max_iter SOLVE_PROF_PARAM) {
+  SPHASE(0);
   __shared__ SolveLds s;
-  __shared__ double scratch[32 * 33];
+  __shared__ double scratch[16 * 33];
   __shared__ double sums[32];
-  if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, 1.0, threadIdx.x);   // travels with the partial rows
+  // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
+  const int hdr_stop = ctl->hdr.stop, hdr_rematch = ctl->hdr.rematch_num;
+  double craw[6];
+  if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, 1.0, threadIdx.x, craw);
+  if (mode != 0 && threadIdx.x == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
+  SPHASE(1);
   reduce_partials_block(partials, nblocks, scratch, sums);
+  SPHASE(2);
+  if (mode == 1 && hdr_stop) return;
   if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
   const int lane = threadIdx.x;
   // expand symmetric 21 -> 6x6
@@ -622,15 +645,16 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
   if (lane < 6) out->Htz[lane] = s.htz[lane];
   if (lane == 0) { out->total_residual = sums[28]; out->n_eff = (int32_t)sums[27]; out->pad = 0; }
   if (mode == 0) return;
-
+  SPHASE(3);
   esikf_update_wave<6>(ctl, s, +1, lane);
+  SPHASE(4);
   if (lane < DS) ctl->lidar.iter_solution[iter][lane] = s.sol[lane];
 
   // convergence / rematch / covariance update (voxel_map.cpp:475-499)
   const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
   const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
   const bool conv = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
-  int rematch = ctl->hdr.rematch_num;
+  int rematch = hdr_rematch;
   if (conv || ((rematch == 0) && (iter == (max_iter - 2)))) rematch++;
   const bool stop_now = (rematch >= 2 || (iter == max_iter - 1));
   __syncthreads();
@@ -645,7 +669,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
       }
       ctl->cur.cov[e] = v;
     }
-    if (lane < 3) ctl->lidar.position_last[lane] = ctl->cur.pos[lane];
+    if (lane < 3) ctl->lidar.position_last[lane] = s.cur[9 + lane] + s.sol[3 + lane];
   }
   if (lane == 0) {
     ctl->hdr.rematch_num = rematch;
@@ -653,6 +677,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
     ctl->lidar.converged = conv ? 1 : 0;
     if (stop_now && mode == 1) ctl->hdr.stop = 1;
   }
+  SPHASE(5);
 }
 
 // copies the posterior into the result block after the loop (always runs)

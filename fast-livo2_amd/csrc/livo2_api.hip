@@ -36,7 +36,8 @@ struct livo2_ctx {
   bool has_map = false;
   DevMap map{};
   RootSlot *d_slots = nullptr; double *d_cand = nullptr; double *d_planes = nullptr;
-  std::vector<int32_t> plane_cand_pos;      // host: position of each plane in the candidate-gate array, or -1
+  std::vector<int32_t> plane_cand_pos;      // host: position of each (caller-indexed) plane in the candidate array, or -1
+  std::vector<int32_t> plane_internal, plane_orig;   // caller plane index <-> device (Morton-ordered) plane index
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -121,12 +122,19 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restr
   if (lane < k * k) s.hth[lane] = ctl->solve_hth[lane];
   if (lane < k) s.htz[lane] = ctl->solve_htz[lane];
   __syncthreads();
-  esikf_prefetch_wave(ctl, s, scale, lane);
+  double craw[6];
+  esikf_prefetch_wave(ctl, s, scale, lane, craw);
+  if (lane == 0) esikf_log_lane(ctl, s);
   __syncthreads();
   if (k == 6) esikf_update_wave<6>(ctl, s, sign, lane); else esikf_update_wave<7>(ctl, s, sign, lane);
   if (lane < DS) ctl->solve_solution[lane] = s.sol[lane];
 }
 
+#ifdef LIVO2_PHASE_PROF
+#define SOLVE_PROF_ARG , (ctx->d_prof ? ctx->d_prof + ctx->prof_waves * 8 : nullptr)
+#else
+#define SOLVE_PROF_ARG
+#endif
 int lidar_grid(int n) { int chunks = (n + LIDAR_BLOCK - 1) / LIDAR_BLOCK; int per_xcd = (chunks + 7) / 8; return std::max(8, per_xcd * 8); }
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
@@ -175,9 +183,10 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
 #ifdef LIVO2_PHASE_PROF
   {
     size_t waves = (size_t)lidar_grid(std::max(ctx->n, 1)) * 4;
-    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64); (void)e; ctx->prof_waves = waves; }
+    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64 + 128); (void)e; ctx->prof_waves = waves; }
     hipError_t e = hipMemsetAsync(ctx->d_prof, 0, waves * 64, ctx->stream); (void)e;
     a.prof = ctx->d_prof;
+    { const char *e = getenv("LIVO2_DBG"); a.dbg = e ? atoi(e) : 0; }
   }
 #endif
   const livo2_lidar_points &w = ctx->want_l;
@@ -211,6 +220,9 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
     for (size_t j = 0; j < n; j++) for (int e = 0; e < 9; e++) p->body_cov[(size_t)perm[j] * 9 + e] = cb[(size_t)map9[e] * n + j];
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  // device plane numbering (Morton order) -> the caller's
+  if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
+  if (p->normal_plane) for (size_t i = 0; i < n; i++) if (p->normal_plane[i] >= 0) p->normal_plane[i] = ctx->plane_orig[p->normal_plane[i]];
   return LIVO2_OK;
 }
 
@@ -323,16 +335,36 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
     for (int k = 0; k < 8; k++) { int c = m->node_child[(size_t)i * 8 + k]; if (c < -1 || c >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "node_child index out of range"); }
   }
   if (m->n_planes >= (1 << CAND_LAYER_SHIFT)) return fail(ctx, LIVO2_ERR_RANGE, "too many planes");
+  // Device plane order: roots along a Morton curve of their voxel key, each root's planes in depth-first order.  The scan is
+  // Morton-sorted too, so neighbouring lanes gather neighbouring (often contiguous) 256-B records: measured on the C2 scene the
+  // plane gather drops from ~random-access cost to within a few % of the fully contiguous floor.  The caller's plane numbering is
+  // kept at the boundary through plane_internal / plane_orig.
+  std::vector<int32_t> order(m->n_roots);
+  {
+    std::vector<std::pair<uint64_t, int32_t>> keyed(m->n_roots);
+    auto spread21 = [](uint64_t v) { v &= 0x1fffffull; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull; v = (v | v << 8) & 0x100f00f00f00f00full;
+                                     v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull; return v; };
+    for (int r = 0; r < m->n_roots; r++) {
+      const uint64_t x = (uint64_t)(m->root_key[(size_t)r * 3] + (1 << 20)), y = (uint64_t)(m->root_key[(size_t)r * 3 + 1] + (1 << 20)), z = (uint64_t)(m->root_key[(size_t)r * 3 + 2] + (1 << 20));
+      keyed[r] = {spread21(x) | (spread21(y) << 1) | (spread21(z) << 2), r};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    for (int r = 0; r < m->n_roots; r++) order[r] = keyed[r].second;
+  }
+  std::vector<int32_t> pin((size_t)std::max(1, m->n_planes), -1);       // caller index -> device index
+  int32_t next_plane = 0;
   // flatten every non-plane root into the depth-first list of its descendant planes (the walk of voxel_map.cpp:769-785)
   std::vector<int32_t> cand;
   std::vector<int32_t> cbegin(m->n_roots, 0), ccount(m->n_roots, 0);
   {
     struct Fr { int node, layer, next; };
     std::vector<Fr> st;
-    for (int r = 0; r < m->n_roots; r++) {
+    for (int oi = 0; oi < m->n_roots; oi++) {
+      const int r = order[oi];
       int root = m->root_node[r];
       if (root < 0 || root >= m->n_nodes) return fail(ctx, LIVO2_ERR_INVALID, "root_node index out of range");
       cbegin[r] = (int32_t)cand.size();
+      if (m->node_plane[root] >= 0 && pin[m->node_plane[root]] < 0) pin[m->node_plane[root]] = next_plane++;
       if (m->node_plane[root] < 0) {
         st.clear(); st.push_back({root, 0, 0});
         while (!st.empty()) {
@@ -342,12 +374,13 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
           if (child < 0) continue;
           int cl = f.layer + 1;
           int pl = m->node_plane[child];
-          if (pl >= 0) cand.push_back(pl | (cl << CAND_LAYER_SHIFT));
+          if (pl >= 0) { if (pin[pl] < 0) pin[pl] = next_plane++; cand.push_back(pin[pl] | (cl << CAND_LAYER_SHIFT)); }
           else { if (st.size() > 64) return fail(ctx, LIVO2_ERR_INVALID, "octree deeper than supported / cyclic"); st.push_back({child, cl, 0}); }
         }
       }
       ccount[r] = (int32_t)cand.size() - cbegin[r];
     }
+    for (int p = 0; p < m->n_planes; p++) if (pin[p] < 0) pin[p] = next_plane++;      // planes no root reaches
   }
   // 2-choice cuckoo table, load factor <= 0.25, one 64-B slot per bucket
   uint32_t cap = 64;
@@ -366,7 +399,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
       RootSlot cur{};
       cur.kx = (int32_t)kx; cur.ky = (int32_t)ky; cur.kz = (int32_t)kz;
       int pl = m->node_plane[m->root_node[r]];
-      cur.val = pl >= 0 ? pl : -2;
+      cur.val = pl >= 0 ? pin[pl] : -2;
       for (int k = 0; k < 3; k++) cur.center[k] = m->root_center[(size_t)r * 3 + k];
       cur.quarter = m->root_quarter[r]; cur.cand_begin = cbegin[r]; cur.cand_count = ccount[r];
       {   // duplicate keys are a caller error
@@ -388,7 +421,10 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   }
   std::vector<double> recs((size_t)std::max(1, m->n_planes) * PLANE_REC_DOUBLES, 0.0);
   for (int p = 0; p < m->n_planes; p++)
-    pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], m->plane_normal + (size_t)p * 3, m->plane_center + (size_t)p * 3, m->plane_var + (size_t)p * 36, m->plane_d[p], m->plane_radius[p]);
+    pack_plane(&recs[(size_t)pin[p] * PLANE_REC_DOUBLES], m->plane_normal + (size_t)p * 3, m->plane_center + (size_t)p * 3, m->plane_var + (size_t)p * 36, m->plane_d[p], m->plane_radius[p]);
+  ctx->plane_internal = pin;
+  ctx->plane_orig.assign(pin.size(), 0);
+  for (int p = 0; p < m->n_planes; p++) ctx->plane_orig[pin[p]] = p;
   // candidate lists hold whole record copies (one round trip per evaluated pair); remember where each plane sits for
   // livo2_map_update_planes
   ctx->plane_cand_pos.assign((size_t)std::max(1, m->n_planes), -1);
@@ -399,7 +435,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
     std::memcpy(g, &recs[(size_t)pl * PLANE_REC_DOUBLES], 28 * sizeof(double));
     int32_t meta[2] = {cand[k], 0};
     std::memcpy(&g[28], meta, 8);
-    ctx->plane_cand_pos[pl] = (int32_t)k;
+    ctx->plane_cand_pos[ctx->plane_orig[pl]] = (int32_t)k;
   }
 
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -428,14 +464,14 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   HIPCHK(hipSetDevice(ctx->device));
   std::vector<double> recs((size_t)n * PLANE_REC_DOUBLES);
   for (int p = 0; p < n; p++) pack_plane(&recs[(size_t)p * PLANE_REC_DOUBLES], normal + (size_t)p * 3, center + (size_t)p * 3, plane_var + (size_t)p * 36, d[p], radius[p]);
-  std::vector<int32_t> gpos(n);
-  for (int p = 0; p < n; p++) gpos[p] = ctx->plane_cand_pos[plane_idx[p]];
+  std::vector<int32_t> gpos(n), didx(n);
+  for (int p = 0; p < n; p++) { gpos[p] = ctx->plane_cand_pos[plane_idx[p]]; didx[p] = ctx->plane_internal[plane_idx[p]]; }
   double *d_recs = nullptr; int32_t *d_idx = nullptr, *d_gpos = nullptr;
   HIPCHK(hipMalloc((void **)&d_recs, recs.size() * 8));
   HIPCHK(hipMalloc((void **)&d_idx, (size_t)n * 4));
   HIPCHK(hipMalloc((void **)&d_gpos, (size_t)n * 4));
   HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(d_idx, plane_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_idx, didx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, d_gpos, n, ctx->d_planes, ctx->d_cand);
   HIPCHK(hipGetLastError());
@@ -513,7 +549,7 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1));
   { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
-  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations); t.done(); }
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations SOLVE_PROF_ARG); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -528,7 +564,7 @@ static int lidar_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo
   const int grid = lidar_grid(std::max(ctx->n, 1));
   for (int it = 0; it < iters; it++) {
     { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
-    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
+    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30) SOLVE_PROF_ARG); t.done(); }
   }
   hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);
   HIPCHK(hipGetLastError());
@@ -701,7 +737,7 @@ int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_sta
 // profiling build only: copy the per-wave phase stamps of the LAST residual launch to host memory
 int livo2_debug_phase_prof(livo2_ctx *ctx, unsigned long long *out, size_t max_waves, size_t *n_waves) {
   if (!ctx || !ctx->d_prof) return LIVO2_ERR_INVALID;
-  size_t w = std::min(max_waves, ctx->prof_waves);
+  size_t w = std::min(max_waves, ctx->prof_waves + 2);       // last two rows: solve-kernel stamps
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(out, ctx->d_prof, w * 64, hipMemcpyDeviceToHost));
   if (n_waves) *n_waves = w;

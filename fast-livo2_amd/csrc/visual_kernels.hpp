@@ -178,33 +178,39 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual(VisualKernelArgs 
 }
 
 // mode 0: bare evaluation -> ctl->sums_v ; mode 1: full ESIKF step (accept / revert / solve) ; mode 2: benchmark (always accept, never stop)
-#define VIS_SOLVE_THREADS 1000        // 25 slices x 40 values
-__global__ void __launch_bounds__(1024) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
+#define VIS_SOLVE_THREADS 480         // 12 slices x 40 values (<= 512 threads: the register-resident solve needs > 128 VGPRs)
+__global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
                                                              int iter, double img_point_cov) {
-  if (mode == 1 && iter > 0 && ctl->hdr.stop) return;
   __shared__ SolveLds s;
   __shared__ double sums[64];
-  __shared__ double scratch[25 * 41];
+  __shared__ double scratch[12 * 41];
+  // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
+  const int hdr_stop = ctl->hdr.stop, hdr_steps = ctl->hdr.n_steps;
+  const float hdr_last_error = ctl->hdr.last_error;
+  double craw[6];
+  if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, img_point_cov, threadIdx.x, craw);
+  if (mode != 0 && threadIdx.x == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
   {
-    // partial rows come from other CUs: every thread issues all its loads before the first add (slice s = rows s, s+25, ...)
-    const int t = threadIdx.x, kidx = t % VIS_PSTRIDE, slice = t / VIS_PSTRIDE;     // 25 slices
-    double v[16];
+    // partial rows come from other CUs: every thread issues all its loads before the first add (slice s = rows s, s+12, ...)
+    const int t = threadIdx.x, kidx = t % VIS_PSTRIDE, slice = t / VIS_PSTRIDE;     // 12 slices
+    double v[32];
 #pragma unroll
-    for (int u = 0; u < 16; u++) { const int b = slice + 25 * u; v[u] = (b < nblocks) ? partials[(size_t)b * VIS_PSTRIDE + kidx] : 0.0; }
+    for (int u = 0; u < 32; u++) { const int b = slice + 12 * u; v[u] = (b < nblocks) ? partials[(size_t)b * VIS_PSTRIDE + kidx] : 0.0; }
     double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; u++) acc += v[u];
-    for (int b = slice + 400; b < nblocks; b += 25) acc += partials[(size_t)b * VIS_PSTRIDE + kidx];
+    for (int u = 0; u < 32; u++) acc += v[u];
+    for (int b = slice + 384; b < nblocks; b += 12) acc += partials[(size_t)b * VIS_PSTRIDE + kidx];
     scratch[slice * 41 + kidx] = acc;
     __syncthreads();
     if (t < VIS_PSTRIDE) {
       double r = scratch[t];
 #pragma unroll
-      for (int sl = 1; sl < 25; sl++) r += scratch[sl * 41 + t];
+      for (int sl = 1; sl < 12; sl++) r += scratch[sl * 41 + t];
       sums[t] = r;
     }
     __syncthreads();
   }
+  if (mode == 1 && iter > 0 && hdr_stop) return;
   if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
   const int lane = threadIdx.x;
   if (lane < 49) {
@@ -226,24 +232,20 @@ __global__ void __launch_bounds__(1024) k_visual_solve(DevCtl *__restrict__ ctl,
     return;
   }
   const int nsl = sizeof(livo2_state) / sizeof(double);
-  if (iter == 0) {                                          // level entry: old_state = *state ; last_error = FLT_MAX (vio.cpp:1523,1528)
-    const double *src = reinterpret_cast<const double *>(&ctl->cur); double *dst = reinterpret_cast<double *>(&ctl->old);
-    for (int e = lane; e < nsl; e += LIVO2_WAVE) dst[e] = src[e];
-  }
-  const float last_error = (iter == 0) ? FLT_MAX : ctl->hdr.last_error;
-  __syncthreads();
+  // level entry (iter == 0): old_state = *state, last_error = FLT_MAX (vio.cpp:1523,1528) — the first evaluation is always accepted
+  // unless the error is NaN, in which case reverting to old_state == *state is a no-op.
+  const float last_error = (iter == 0) ? FLT_MAX : hdr_last_error;
   const bool accepted = (mode == 2) ? true : (error <= last_error);
-  const int step = ctl->hdr.n_steps;
+  const int step = hdr_steps;
   livo2_visual_step *st = (step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) ? &ctl->visual.steps[step] : nullptr;
   int stop = 0;
   if (accepted) {
-    {                                                       // old_state = *state (vio.cpp:1650)
-      const double *src = reinterpret_cast<const double *>(&ctl->cur); double *dst = reinterpret_cast<double *>(&ctl->old);
-      for (int e = lane; e < nsl; e += LIVO2_WAVE) dst[e] = src[e];
+    {                                                       // old_state = *state (vio.cpp:1650), from the prefetched copy
+      double *dst = reinterpret_cast<double *>(&ctl->old);
+      if (lane < 25) dst[lane] = s.cur[lane];
+#pragma unroll
+      for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; if (e < DS * DS) dst[25 + e] = craw[q]; }
     }
-    __syncthreads();
-    esikf_prefetch_wave(ctl, s, img_point_cov, lane);
-    __syncthreads();
     esikf_update_wave<7>(ctl, s, -1, lane);
     const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
     const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
@@ -254,8 +256,10 @@ __global__ void __launch_bounds__(1024) k_visual_solve(DevCtl *__restrict__ ctl,
       if (lane < DS) st->solution[lane] = s.sol[lane];
     }
   } else {                                                  // (*state) = old_state ; EKF_end (vio.cpp:1679-1680)
-    const double *src = reinterpret_cast<const double *>(&ctl->old); double *dst = reinterpret_cast<double *>(&ctl->cur);
-    for (int e = lane; e < nsl; e += LIVO2_WAVE) dst[e] = src[e];
+    if (iter > 0) {
+      const double *src = reinterpret_cast<const double *>(&ctl->old); double *dst = reinterpret_cast<double *>(&ctl->cur);
+      for (int e = lane; e < nsl; e += LIVO2_WAVE) dst[e] = src[e];
+    }
     stop = 1;
     if (st) {
       if (lane < 49) st->HtH[lane] = s.hth[lane];

@@ -34,6 +34,9 @@ def main():
     buf = np.zeros((W, 8), np.uint64)
     nw = C.c_size_t()
     assert fn(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), W, C.byref(nw)) == 0
+    sol = buf[nw.value - 2].astype(np.int64)
+    nw.value -= 2
+    print('solve kernel phases (us @2.1GHz): ' + ', '.join(f'{n} {(sol[k + 1] - sol[k]) / 2100.0:.2f}' for k, n in enumerate(['prefetch-issue', 'partial reduce', 'sums out', 'vec+GJ+gain+state', 'conv/cov/ctl'])))
     st = buf[:nw.value].astype(np.int64)
     st = st[st[:, 0] > 0]
     # stamps are per-XCD counters: normalise each XCD (block b runs on XCD b % 8) to its own first wave
