@@ -157,9 +157,20 @@ def main():
     res_us = 1e3 * ms_res / max(n_res, 1)
     sol_us = 1e3 * ms_sol / max(n_sol, 1)
     achieved = LIDAR_BYTES_PER_EVAL * n / (res_us * 1e-6) / 1e9
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    # HBM traffic per launch cannot be read from inside this process: it comes from the separate rocprofv3 --pmc passes recorded in
+    # profiles/ (only reported when they were taken on this very workload)
+    traffic, traffic_note = None, "no PMC pass recorded for this workload; see profiles/"
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if rec["points"] == n and rec["scan_order"] == args.scan_order:
+            traffic = (rec["fetch_size_kb_reported"] * rec["fetch_correction"] + rec["write_size_kb"]) * 1024.0
+            traffic_note = rec["source"]
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "k_lidar_residual", "kernel_us": res_us, "bytes_per_launch": LIDAR_BYTES_PER_EVAL * n, "solve_kernel_us": sol_us,
-                "traffic_note": "HBM PMC traffic: see profiles/ (FETCH_SIZE/WRITE_SIZE passes)"}
+                "timing": "HIP event pair around every launch on the launching stream (includes the dependent-launch gap; rocprofv3 kernel-only average in profiles/)",
+                "traffic_unit": "bytes/launch", "traffic_note": traffic_note}
 
     extra = {"frames_per_s": frames_per_s, "frame_points": n, "frames": int(F_per_rank * world),
              "frame_def": "set_scan (H2D + Morton sort + body cov) + full StateEstimation loop + result read-back"}
