@@ -160,6 +160,16 @@ class Context:
         self._chk(self.lib.livo2_visual_set_frame(self.h, abi.as_ptr(img, C.c_uint8), w, h, w, abi.as_ptr(pos, C.c_double), abi.as_ptr(warp_patch, C.c_float),
                                                   abi.as_ptr(search_levels, C.c_int32), abi.as_ptr(inv_expo_list, C.c_double), M, L))
 
+    def set_reference(self, ref_imgs, ref_img_idx, ref_px, ref_f, ref_R, ref_pos):
+        """inverse-compositional variant: reference patches of the points uploaded by set_frame"""
+        ref_imgs = np.ascontiguousarray(ref_imgs, np.uint8)
+        if ref_imgs.ndim == 2:
+            ref_imgs = ref_imgs[None]
+        idx = np.ascontiguousarray(ref_img_idx, np.int32)
+        px, f, R, pos = _f64(ref_px).reshape(-1, 2), _f64(ref_f).reshape(-1, 3), _f64(ref_R).reshape(-1, 9), _f64(ref_pos).reshape(-1, 3)
+        self._chk(self.lib.livo2_visual_set_reference(self.h, abi.as_ptr(ref_imgs, C.c_uint8), len(ref_imgs), abi.as_ptr(idx, C.c_int32), abi.as_ptr(px, C.c_double),
+                                                      abi.as_ptr(f, C.c_double), abi.as_ptr(R, C.c_double), abi.as_ptr(pos, C.c_double)))
+
     def visual_iterate(self, level, cur, cfg, rows=False):
         sums = VisualSums()
         errors = np.zeros(self.M, np.float32)

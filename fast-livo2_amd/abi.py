@@ -138,6 +138,7 @@ SIGNATURES = {
     "livo2_lidar_iterations_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), C.c_int32]),
     "livo2_visual_set_frame": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32),
                                          _P(C.c_double), C.c_int32, C.c_int32]),
+    "livo2_visual_set_reference": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, _P(C.c_int32), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "livo2_visual_iterate": (C.c_int, [_CTX, C.c_int32, _P(State), _P(VisualCfg), _P(VisualSums), _P(C.c_float), _P(C.c_double), _P(C.c_double)]),
     "livo2_visual_update": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg), _P(VisualResult), _P(C.c_float)]),
     "livo2_visual_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg)]),

@@ -5,7 +5,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "lidar_kernels.hpp"
-#include "visual_kernels.hpp"
+#include "visual_inverse_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -52,6 +52,10 @@ struct livo2_ctx {
   uint8_t *d_img = nullptr; size_t img_cap = 0; int width = 0, height = 0, stride = 0;
   double *d_pos = nullptr, *d_invexpo = nullptr; float *d_warp = nullptr; int32_t *d_search = nullptr; int M = 0, L = 0, M_cap = 0; size_t warp_cap = 0;
   float *d_errors = nullptr; double *d_zdbg = nullptr, *d_Hdbg = nullptr; int dbg_cap = 0;
+  // inverse-compositional reference data
+  bool has_ref = false;
+  uint8_t *d_ref_imgs = nullptr; size_t ref_img_cap = 0; int n_ref = 0;
+  int32_t *d_ref_idx = nullptr; double *d_ref_px = nullptr, *d_ref_f = nullptr, *d_ref_R = nullptr, *d_ref_pos = nullptr, *d_gref = nullptr, *d_mref = nullptr; int ref_cap = 0;
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
 #endif
@@ -228,7 +232,7 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
 
 int check_visual_cfg(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
   if (!cfg) return fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL");
-  if (cfg->inverse_composition_en) return fail(ctx, LIVO2_ERR_INVALID, "inverse_composition_en is not supported by this release");
+  if (cfg->inverse_composition_en && ctx->M > 0 && !ctx->has_ref) return fail(ctx, LIVO2_ERR_INVALID, "inverse_composition_en needs livo2_visual_set_reference after set_frame");
   if (cfg->max_iterations < 1 || cfg->max_iterations > LIVO2_MAX_ITERS) return fail(ctx, LIVO2_ERR_INVALID, "max_iterations out of range");
   if (cfg->patch_pyrimid_level < 1 || cfg->patch_pyrimid_level > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level out of range");
   if (ctx->M > 0 && cfg->patch_pyrimid_level > ctx->L) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level exceeds the uploaded warp_patch levels");
@@ -256,6 +260,13 @@ VisualKernelArgs make_visual_args(livo2_ctx *ctx, const livo2_visual_cfg *cfg, i
   for (int i = 0; i < 9; i++) nR[i] = -a.Rci[i];
   m3mul(nR, tmp, a.Jdp_dR);                                                                                            // Jdp_dR = -Rci * skew(Pic)
   return a;
+}
+
+VisualRefArgs make_ref_args(livo2_ctx *ctx) {
+  VisualRefArgs r{};
+  r.ref_imgs = ctx->d_ref_imgs; r.ref_idx = ctx->d_ref_idx; r.ref_px = ctx->d_ref_px; r.ref_f = ctx->d_ref_f; r.ref_R = ctx->d_ref_R; r.ref_pos = ctx->d_ref_pos;
+  r.gref = ctx->d_gref; r.mref = ctx->d_mref; r.n_ref = ctx->n_ref;
+  return r;
 }
 
 int visual_grid(int M) { return std::max(1, (M + VIS_WAVES - 1) / VIS_WAVES); }
@@ -294,7 +305,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (ctx->stream) e = hipStreamSynchronize(ctx->stream);
   void *dev[] = {ctx->d_ctl, ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
                  ctx->d_cb, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, ctx->d_sort_tmp, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
-                 ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg};
+                 ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg, ctx->d_ref_imgs, ctx->d_ref_idx, ctx->d_ref_px, ctx->d_ref_f, ctx->d_ref_R, ctx->d_ref_pos,
+                 ctx->d_gref, ctx->d_mref};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -632,6 +644,41 @@ int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, in
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->width = width; ctx->height = height; ctx->stride = stride; ctx->M = M; ctx->L = L;
   ctx->has_frame = true;
+  ctx->has_ref = false;
+  return LIVO2_OK;
+}
+
+int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t n_ref, const int32_t *ref_img_idx, const double *ref_px, const double *ref_f,
+                               const double *ref_R, const double *ref_pos) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->has_frame) return fail(ctx, LIVO2_ERR_NO_FRAME, "livo2_visual_set_frame has not been called");
+  const int M = ctx->M;
+  if (n_ref < 1 || !ref_imgs || (M > 0 && (!ref_img_idx || !ref_px || !ref_f || !ref_R || !ref_pos))) return fail(ctx, LIVO2_ERR_INVALID, "bad reference arrays");
+  for (int i = 0; i < M; i++) if (ref_img_idx[i] < 0 || ref_img_idx[i] >= n_ref) return fail(ctx, LIVO2_ERR_INVALID, "ref_img_idx out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t img_bytes = (size_t)ctx->stride * ctx->height;
+  int rc = ensure(ctx, ctx->d_ref_imgs, ctx->ref_img_cap, img_bytes * n_ref); if (rc) return rc;
+  if (M > ctx->ref_cap) {
+    hipError_t e;
+    if (ctx->d_ref_idx) { e = hipFree(ctx->d_ref_idx); e = hipFree(ctx->d_ref_px); e = hipFree(ctx->d_ref_f); e = hipFree(ctx->d_ref_R); e = hipFree(ctx->d_ref_pos); e = hipFree(ctx->d_gref); e = hipFree(ctx->d_mref); (void)e; }
+    const size_t cap = (size_t)std::max(M, 512);
+    HIPCHK(hipMalloc((void **)&ctx->d_ref_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_ref_px, cap * 16)); HIPCHK(hipMalloc((void **)&ctx->d_ref_f, cap * 24));
+    HIPCHK(hipMalloc((void **)&ctx->d_ref_R, cap * 72)); HIPCHK(hipMalloc((void **)&ctx->d_ref_pos, cap * 24));
+    HIPCHK(hipMalloc((void **)&ctx->d_gref, cap * 64 * 16)); HIPCHK(hipMalloc((void **)&ctx->d_mref, cap * 16 * 8));
+    ctx->ref_cap = (int)cap;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
+  if (M > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_ref_idx, ref_img_idx, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ref_px, ref_px, (size_t)M * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ref_f, ref_f, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ref_R, ref_R, (size_t)M * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ref_pos, ref_pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_ref = n_ref;
+  ctx->has_ref = true;
   return LIVO2_OK;
 }
 
@@ -659,10 +706,16 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   VisualKernelArgs a = make_visual_args(ctx, cfg, level);
   a.errors = ctx->d_errors; a.z = z ? ctx->d_zdbg : nullptr; a.H_sub = H_sub ? ctx->d_Hdbg : nullptr;
   const int grid = visual_grid(std::max(M, 1));
-  if (z || H_sub) {
-    // a skipped (out-of-image) patch leaves its rows untouched: clear them first
-    if (z) HIPCHK(hipMemsetAsync(ctx->d_zdbg, 0, (size_t)std::max(M, 1) * 64 * 8, ctx->stream));
-    if (H_sub) HIPCHK(hipMemsetAsync(ctx->d_Hdbg, 0, (size_t)std::max(M, 1) * 64 * 56, ctx->stream));
+  if (z) HIPCHK(hipMemsetAsync(ctx->d_zdbg, 0, (size_t)std::max(M, 1) * 64 * 8, ctx->stream));       // a skipped (out-of-image) patch leaves its rows untouched
+  if (H_sub) HIPCHK(hipMemsetAsync(ctx->d_Hdbg, 0, (size_t)std::max(M, 1) * 64 * 56, ctx->stream));
+  if (cfg->inverse_composition_en && M > 0) {
+    VisualRefArgs r = make_ref_args(ctx);
+    hipLaunchKernelGGL(k_visual_ref_precompute, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r);
+    Timed t(ctx, 1);
+    if (z || H_sub) hipLaunchKernelGGL(k_visual_inverse_residual<true>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r, ctx->d_ctl, ctx->d_partials, 0);
+    else hipLaunchKernelGGL(k_visual_inverse_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r, ctx->d_ctl, ctx->d_partials, 0);
+    t.done();
+  } else if (z || H_sub) {
     Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<true>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
   } else {
     Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
@@ -686,8 +739,19 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
   for (int level = level_hi; level >= level_lo; level--) {
     a = make_visual_args(ctx, cfg, level);
     a.errors = ctx->d_errors;
+    const bool inverse = cfg->inverse_composition_en != 0;
+    VisualRefArgs r{};
+    if (inverse) {             // has_ref_patch_cache = false at every level (vio.cpp:794-795)
+      r = make_ref_args(ctx);
+      hipLaunchKernelGGL(k_visual_ref_precompute, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r);
+    }
     for (int it = 0; it < iters; it++) {
-      { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0); t.done(); }
+      {
+        Timed t(ctx, 1);
+        if (inverse) hipLaunchKernelGGL(k_visual_inverse_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0);
+        else hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0);
+        t.done();
+      }
       { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
     }
   }

@@ -128,6 +128,23 @@ void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
   }
   dev_.check(livo2_visual_set_frame(dev_.ctx(), img.data, img.cols, img.rows, img.step, pos.data(), warp.data(), visual_submap->search_levels.data(),
                                     visual_submap->inv_expo_list.data(), M, L));
+  if (inverse_composition_en) {             // gather the reference patches (distinct reference images are uploaded once each)
+    std::vector<const uint8_t *> imgs; std::vector<int32_t> idx(M);
+    std::vector<double> px((size_t)M * 2), f((size_t)M * 3), R((size_t)M * 9), rp((size_t)M * 3);
+    for (int i = 0; i < M; i++) {
+      const Feature *ft = visual_submap->voxel_points[i]->ref_patch;
+      if (!ft || !ft->img_) throw std::runtime_error("inverse_composition_en: VisualPoint without ref_patch");
+      size_t k = 0; while (k < imgs.size() && imgs[k] != ft->img_) k++;
+      if (k == imgs.size()) imgs.push_back(ft->img_);
+      idx[i] = (int32_t)k;
+      std::memcpy(&px[(size_t)i * 2], ft->px_.data(), 16); std::memcpy(&f[(size_t)i * 3], ft->f_.data(), 24);
+      std::memcpy(&R[(size_t)i * 9], ft->R_f_w.data(), 72); std::memcpy(&rp[(size_t)i * 3], ft->pos.data(), 24);
+    }
+    const size_t bytes = (size_t)img.step * img.rows;
+    std::vector<uint8_t> stack(bytes * imgs.size());
+    for (size_t k = 0; k < imgs.size(); k++) std::memcpy(&stack[k * bytes], imgs[k], bytes);
+    dev_.check(livo2_visual_set_reference(dev_.ctx(), stack.data(), (int32_t)imgs.size(), idx.data(), px.data(), f.data(), R.data(), rp.data()));
+  }
   livo2_visual_cfg cfg{};
   cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = 0; cfg.cam.width = width; cfg.cam.height = height;
   std::memcpy(cfg.Rcl, Rcl.data(), 72); std::memcpy(cfg.Pcl, Pcl.data(), 24); std::memcpy(cfg.extR, extR.data(), 72); std::memcpy(cfg.extT, extT.data(), 24);

@@ -142,7 +142,14 @@ private:
 };
 
 // ---- visual ---------------------------------------------------------------------------------------------------------------
-struct VisualPoint { V3D pos_{}; };         // reference include/visual_point.h:23-46 (pos_ only)
+struct Feature {                            // reference include/feature.h:19-54 — what precomputeReferencePatches reads (vio.cpp:1346-1356)
+  const uint8_t *img_ = nullptr;            // reference gray image (same size / stride as the current frame)
+  std::array<double, 2> px_{};
+  V3D f_{};
+  M3D R_f_w{};                              // T_f_w_.rotation_matrix()
+  V3D pos{};                                // pos(): camera centre of the reference frame
+};
+struct VisualPoint { V3D pos_{}; Feature *ref_patch = nullptr; };   // reference include/visual_point.h:23-46
 
 struct SubSparseMap {                       // reference include/vio.h:26-57
   std::vector<float> errors;

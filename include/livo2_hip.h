@@ -184,7 +184,7 @@ typedef struct livo2_visual_cfg {
   int32_t patch_pyrimid_level;  /* vio/patch_pyrimid_level (L) */
   int32_t max_iterations;       /* vio/max_iterations */
   int32_t exposure_estimate_en; /* vio/exposure_estimate_en */
-  int32_t inverse_composition_en; /* vio/inverse_composition_en — must be 0 in this release (forward compositional only) */
+  int32_t inverse_composition_en; /* vio/inverse_composition_en: 1 = updateStateInverse (needs livo2_visual_set_reference) */
 } livo2_visual_cfg;
 
 /* Upload the current gray image (CV_8UC1, row stride `stride` bytes) and the visual sub-map arrays the update reads
@@ -192,6 +192,14 @@ typedef struct livo2_visual_cfg {
  * vector<vector<float>> flattened), search_levels ([M]), inv_expo_list ([M]).  M = total_points. */
 int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const double *pos,
                            const float *warp_patch, const int32_t *search_levels, const double *inv_expo_list, int32_t M, int32_t L);
+
+/* Inverse-compositional variant only (reference src/vio.cpp:1327-1518): the reference patch of every point, i.e. what
+ * precomputeReferencePatches reads through VisualPoint::ref_patch (include/feature.h:19-54, include/frame.h): the reference gray
+ * image (n_ref images of the same width/height/stride as the current frame; ref_img_idx[i] selects ref_patch->img_), ref_patch->px_
+ * ([M][2]), ref_patch->f_ ([M][3]), ref_patch->T_f_w_.rotation_matrix() ([M][9] row-major) and ref_patch->pos() ([M][3]).
+ * Call after livo2_visual_set_frame (same M); stays valid until the next set_frame. */
+int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t n_ref, const int32_t *ref_img_idx, const double *ref_px,
+                               const double *ref_f, const double *ref_R, const double *ref_pos);
 
 typedef struct livo2_visual_sums {
   double HtH[49];               /* H_sub^T H_sub, row-major 7x7 (vio.cpp:1660); row/col 6 zero if !exposure_estimate_en */
@@ -202,7 +210,8 @@ typedef struct livo2_visual_sums {
 } livo2_visual_sums;
 
 /* One evaluation at pyramid `level` for iterate `cur` (vio.cpp:1538-1636 + 1657-1662); no state update.
- * Optional outputs (NULL to skip): errors[M] = visual_submap->errors; z[M*64]; H_sub[M*64][7]. */
+ * Optional outputs (NULL to skip): errors[M] = visual_submap->errors; z[M*64]; H_sub[M*64][7].
+ * With cfg->inverse_composition_en the pass is precomputeReferencePatches(level) + one updateStateInverse evaluation (column 6 of H_sub is 0). */
 int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, const livo2_visual_cfg *cfg, livo2_visual_sums *sums,
                          float *errors, double *z, double *H_sub);
 

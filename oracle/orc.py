@@ -210,6 +210,27 @@ def visual_iterate(cfg, sc, level, cur, lib=None):
     return dict(z=z, H=H, errors=err, HtH=HtH.reshape(7, 7), Htz=Htz, error=e.value, n_meas=nm.value)
 
 
+def _ref_args(sc):
+    ri = np.ascontiguousarray(sc.ref_imgs, np.uint8); idx = np.ascontiguousarray(sc.ref_img_idx, np.int32)
+    px = np.ascontiguousarray(sc.ref_px, np.float64); f = np.ascontiguousarray(sc.ref_f, np.float64)
+    R = np.ascontiguousarray(sc.ref_R, np.float64); pos = np.ascontiguousarray(sc.ref_pos, np.float64)
+    sc._ref_keep = (ri, idx, px, f, R, pos)
+    return [_p(ri, C.c_uint8), _p(idx, C.c_int32), _p(px, C.c_double), _p(f, C.c_double), _p(R, C.c_double), _p(pos, C.c_double)]
+
+
+def visual_iterate_inverse(cfg, sc, level, cur, lib=None):
+    lib = lib or load()
+    M = len(sc.pos)
+    img = np.ascontiguousarray(sc.img, np.uint8); pos = np.ascontiguousarray(sc.pos, np.float64); wp = np.ascontiguousarray(sc.warp_patch, np.float32)
+    sl = np.ascontiguousarray(sc.search_levels, np.int32); ie = np.ascontiguousarray(sc.inv_expo_list, np.float64)
+    z, H, err = np.zeros(M * 64), np.zeros((M * 64, 6)), np.zeros(M, np.float32)
+    HtH, Htz, e, nm = np.zeros(36), np.zeros(6), C.c_float(), C.c_int()
+    lib.orc_visual_iterate_inverse(C.byref(cfg), _p(img, C.c_uint8), _p(pos, C.c_double), _p(wp, C.c_float), _p(sl, C.c_int32), _p(ie, C.c_double), C.c_int(M),
+                                   C.c_int(level), C.byref(cur), *_ref_args(sc), _p(z, C.c_double), _p(H, C.c_double), _p(err, C.c_float), _p(HtH, C.c_double),
+                                   _p(Htz, C.c_double), C.byref(e), C.byref(nm))
+    return dict(z=z, H=H, errors=err, HtH=HtH.reshape(6, 6), Htz=Htz, error=e.value, n_meas=nm.value)
+
+
 def visual_update(cfg, sc, state_in, prop, lib=None):
     lib = lib or load()
     M = len(sc.pos)
@@ -219,7 +240,8 @@ def visual_update(cfg, sc, state_in, prop, lib=None):
     trace = (VisualIterTrace * (8 * MAX_IT))()
     nt, secs = C.c_int(), C.c_double()
     G, RP = np.zeros(361), np.zeros(12)
+    refs = _ref_args(sc) if cfg.inverse_composition_en else [None] * 6
     lib.orc_visual_update(C.byref(cfg), _p(img, C.c_uint8), _p(pos, C.c_double), _p(wp, C.c_float), _p(sl, C.c_int32), _p(ie, C.c_double), C.c_int(M),
                           C.byref(state_in), C.byref(prop), C.byref(out), _p(err, C.c_float), C.cast(trace, C.c_void_p), C.byref(nt), C.byref(secs),
-                          _p(G, C.c_double), _p(RP, C.c_double), None, None, None, None, None, None)
+                          _p(G, C.c_double), _p(RP, C.c_double), *refs)
     return dict(state=out, errors=err, trace=[trace[i] for i in range(nt.value)], seconds=secs.value, G=G.reshape(19, 19), Rcw=RP[:9].reshape(3, 3), Pcw=RP[9:])

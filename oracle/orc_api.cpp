@@ -269,6 +269,26 @@ int orc_visual_iterate(const orc_visual_cfg *cfg, const uint8_t *img, const doub
   return 0;
 }
 
+// One inverse-compositional evaluation at `level`: precomputeReferencePatches(level) + the residual / Jacobian part of updateStateInverse
+// (src/vio.cpp:1327-1477) for the given state: z, H_sub (H_DIM x 6), errors, 6x6 / 6x1 sums, mean error.
+int orc_visual_iterate_inverse(const orc_visual_cfg *cfg, const uint8_t *img, const double *pos, const float *warp_patch, const int32_t *search_levels,
+                               const double *inv_expo_list, int M, int level, const StatePOD *state_cur, const uint8_t *ref_imgs, const int32_t *ref_img_idx,
+                               const double *ref_px, const double *ref_f, const double *ref_R, const double *ref_pos, double *z, double *H_sub6, float *errors,
+                               double *HtH36, double *Htz6, float *error, int *n_meas) {
+  VIOManager vio; SubSparseMap sm; std::vector<VisualPoint> pts;
+  setup_vio(vio, sm, pts, cfg, pos, warp_patch, search_levels, inv_expo_list, M, ref_imgs, ref_img_idx, ref_px, ref_f, ref_R, ref_pos);
+  StatesGroup st, prop; st.from_pod(*state_cur); prop.from_pod(*state_cur); vio.state = &st; vio.state_propagat = &prop;
+  vio.max_iterations = 1; vio.has_ref_patch_cache = false; vio.trace_.clear();
+  vio.updateStateInverse(img, level);
+  if (z) std::memcpy(z, vio.dump_z_.data(), vio.dump_z_.size() * 8);
+  if (H_sub6) std::memcpy(H_sub6, vio.dump_H_.data(), vio.dump_H_.size() * 8);
+  if (errors) std::memcpy(errors, sm.errors.data(), M * 4);
+  const VisualIterTrace &tr = vio.trace_.at(0);
+  for (int a = 0; a < 6; a++) { if (Htz6) Htz6[a] = tr.Htz[a]; for (int b = 0; b < 6; b++) if (HtH36) HtH36[a * 6 + b] = tr.HtH[a * 7 + b]; }
+  *error = tr.error; *n_meas = tr.n_meas;
+  return 0;
+}
+
 // Full computeJacobianAndUpdateEKF (src/vio.cpp:784-802).  `seconds` = wall time around it (src/vio.cpp:1808-1812 window).
 int orc_visual_update(const orc_visual_cfg *cfg, const uint8_t *img, const double *pos, const float *warp_patch, const int32_t *search_levels,
                       const double *inv_expo_list, int M, const StatePOD *state_in, const StatePOD *state_prop, StatePOD *state_out, float *errors,

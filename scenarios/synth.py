@@ -458,3 +458,29 @@ def visual_scenario(seed=3, n_patches=2000, L=4, rot_sigma_deg=0.05, pos_sigma=0
     tau_prior = tau_true * (1.0 + rng.normal(0, 0.01))
     return VisualScenario(img, pos, warp, search, inv_ref, R_true, t_true, tau_true, R_prior, t_prior, tau_prior, prior_cov(rng), extR, extT, Rcl, Pcl,
                           cam, cfg)
+
+
+def visual_inverse_scenario(seed=5, n_patches=300, L=4, n_ref=2, **kw):
+    """Inverse-compositional variant (reference src/vio.cpp:1327-1518): every point carries a reference patch = (reference image,
+    px_, bearing f_, R_ref_w, camera centre) taken at a reference pose; ref patches hold the reference-frame intensities (no exposure,
+    no search level).  Here the reference frames see the same synthetic texture from the TRUE pose, so the true pose is the optimum."""
+    vs = visual_scenario(seed=seed, n_patches=n_patches, L=L, **kw)
+    rng = np.random.default_rng(seed + 1000)
+    Rci, Pci = vio_constants(vs.extR, vs.extT, vs.Rcl, vs.Pcl)
+    Rcw = Rci @ vs.R_true.T
+    Pcw = -Rci @ vs.R_true.T @ vs.t_true + Pci
+    M = len(vs.pos)
+    vs.search_levels = np.zeros(M, np.int32)
+    vs.ref_imgs = np.stack([vs.img] * n_ref)
+    vs.ref_img_idx = rng.integers(0, n_ref, M).astype(np.int32)
+    p_c = vs.pos @ Rcw.T + Pcw
+    vs.ref_px = np.stack([vs.cam["fx"] * p_c[:, 0] / p_c[:, 2] + vs.cam["cx"], vs.cam["fy"] * p_c[:, 1] / p_c[:, 2] + vs.cam["cy"]], 1)
+    vs.ref_f = p_c / np.linalg.norm(p_c, axis=1, keepdims=True)
+    vs.ref_R = np.repeat(Rcw.reshape(1, 9), M, 0)
+    vs.ref_pos = np.repeat((-Rcw.T @ Pcw).reshape(1, 3), M, 0)
+    for i in range(M):
+        for lvl in range(L):
+            cur = sample_patch(vs.img, vs.ref_px[i], 1 << lvl).astype(np.float64)
+            vs.warp_patch[i, lvl] = (cur + rng.normal(0, 1.0, (8, 8))).astype(np.float32).ravel()
+    vs.tau_prior = 1.0
+    return vs

@@ -28,7 +28,7 @@ def states(sc, cls, R=None, t=None, inv_expo=1.0):
     return cur, prior
 
 
-def visual_cfg_product(sc, exposure=True, max_iterations=None):
+def visual_cfg_product(sc, exposure=True, max_iterations=None, inverse=False):
     livo2 = product()
     c = livo2.VisualCfg()
     c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = sc.cam["fx"], sc.cam["fy"], sc.cam["cx"], sc.cam["cy"]
@@ -37,7 +37,7 @@ def visual_cfg_product(sc, exposure=True, max_iterations=None):
     c.img_point_cov = float(sc.cfg["img_point_cov"])
     c.patch_pyrimid_level = int(sc.cfg["patch_pyrimid_level"])
     c.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
-    c.exposure_estimate_en, c.inverse_composition_en = int(exposure), 0
+    c.exposure_estimate_en, c.inverse_composition_en = int(exposure), int(inverse)
     return c
 
 

@@ -1,0 +1,71 @@
+"""GPU parity of the inverse-compositional visual update (vio/inverse_composition_en; reference src/vio.cpp:1327-1518) vs the oracle."""
+import numpy as np
+import pytest
+
+from scenarios import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vs_inv():
+    return synth.visual_inverse_scenario(seed=5, n_patches=300)
+
+
+def _upload(ctx, vs):
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    ctx.set_reference(vs.ref_imgs, vs.ref_img_idx, vs.ref_px, vs.ref_f, vs.ref_R, vs.ref_pos)
+
+
+@pytest.mark.parametrize("level", [3, 1, 0])
+def test_inverse_iterate_matches_oracle(ctx, livo2, orc, vs_inv, level):
+    vs = vs_inv
+    ocfg = orc.visual_cfg(vs, inverse=True)
+    pcfg = H.visual_cfg_product(vs, inverse=True)
+    ocur, _ = H.states(vs, orc.StatePOD)
+    pcur, _ = H.states(vs, livo2.State)
+    ref = orc.visual_iterate_inverse(ocfg, vs, level, ocur)
+    _upload(ctx, vs)
+    sums, errors, z, Hs = ctx.visual_iterate(level, pcur, pcfg, rows=True)
+    assert sums.n_meas == ref["n_meas"] == 64 * len(vs.pos)
+    assert np.array_equal(z, ref["z"]), np.abs(z - ref["z"]).max()          # all-float residual expression: bit-identical
+    assert H.relerr(Hs[:, :6], ref["H"]) < 1e-13 and not np.any(Hs[:, 6])
+    assert np.allclose(errors, ref["errors"], rtol=2e-6)
+    assert abs(sums.error - ref["error"]) <= 2e-6 * abs(ref["error"])
+    HtH = np.array(sums.HtH).reshape(7, 7)
+    assert H.relerr(HtH[:6, :6], ref["HtH"]) < 1e-11 and not np.any(HtH[6]) and not np.any(HtH[:, 6])
+    assert H.relerr(np.array(sums.Htz)[:6], ref["Htz"]) < 1e-10
+    sums2, errors2, _, _ = ctx.visual_iterate(level, pcur, pcfg, rows=False)
+    assert np.array_equal(np.array(sums2.HtH), np.array(sums.HtH)) and np.array_equal(errors2, errors)
+
+
+def test_inverse_full_update_matches_oracle(ctx, livo2, orc, vs_inv):
+    vs = vs_inv
+    ocfg = orc.visual_cfg(vs, inverse=True)
+    pcfg = H.visual_cfg_product(vs, inverse=True)
+    ocur, oprop = H.states(vs, orc.StatePOD)
+    pcur, pprop = H.states(vs, livo2.State)
+    ref = orc.visual_update(ocfg, vs, ocur, oprop)
+    _upload(ctx, vs)
+    res, errors = ctx.visual_update(pcur, pprop, pcfg)
+    assert res.n_steps == len(ref["trace"])
+    for k in range(res.n_steps):
+        a, b = res.steps[k], ref["trace"][k]
+        assert (a.level, a.iteration, a.accepted, a.n_meas) == (b.level, b.iteration, b.accepted, b.n_meas), k
+        assert abs(a.error - b.error) <= 4e-6 * abs(b.error)
+        if a.accepted:
+            assert H.relerr(np.array(a.solution), np.array(b.solution)) < 1e-6
+    d = H.state_diff(res.state, ref["state"])
+    assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-8, d
+    assert H.relerr(np.array(res.G).reshape(19, 19), ref["G"]) < 1e-7
+    assert np.allclose(errors, ref["errors"], rtol=1e-5)
+
+
+def test_inverse_needs_reference(ctx, livo2, vs_inv):
+    vs = vs_inv
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)       # invalidates earlier references
+    pcur, pprop = H.states(vs, livo2.State)
+    with pytest.raises(livo2.Livo2Error) as e:
+        ctx.visual_update(pcur, pprop, H.visual_cfg_product(vs, inverse=True))
+    assert e.value.code == livo2.abi.ERR_INVALID
