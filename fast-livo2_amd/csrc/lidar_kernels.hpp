@@ -19,6 +19,7 @@
 #define LIDAR_BLOCK 256
 #define LIDAR_NSUM 29       // 21 (sym HtH) + 6 (Htz) + n_eff + sum|r|
 #define LIDAR_LDS_BYTES ((LIDAR_BLOCK / LIVO2_WAVE) * 32 * 65 * 8)
+#define LIDAR_LDS_DUMP 512          // landing area of the software-prefetch loads (touch_line), behind the tiles
 
 struct LidarKernelArgs {
   const float *x, *y, *z;          // [n]
@@ -42,11 +43,33 @@ struct LidarKernelArgs {
 #define PHASE(k)                                                                                                   \
   do {                                                                                                             \
     __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);           \
-    if (a.prof && (threadIdx.x & 63) == 0) a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); \
+    if (a.prof && (threadIdx.x & 63) == 0) {                                                                       \
+      a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter();              \
+      if ((k) == 0 || (k) == 6) /* chip-wide 100 MHz clock: launch ramp and drain */                                \
+        a.prof[((size_t)gridDim.x * 4 + 2) * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   } while (0)
 #else
 #define PHASE(k) do { } while (0)
+#endif
+#ifdef LIVO2_PHASE_PROF
+// stamps inside the first round of the first cooperative visit (per wave): region behind the chip-wide clock stamps
+#define COOP_PROF_PARAM , unsigned long long *cprof
+#define COOP_PROF_ARG1 , a.prof
+#define COOP_PROF_ARG2 , nullptr
+#define CSTAMP(k)                                                                                                  \
+  do {                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);           \
+    if (cprof && base <= LIDAR_BLOCK && (threadIdx.x & 63) == 0)                                                    \
+      cprof[((size_t)gridDim.x * 4 + 2) * 8 + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (base ? 6 : 0) + (k)] = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  } while (0)
+#else
+#define COOP_PROF_PARAM
+#define COOP_PROF_ARG1
+#define COOP_PROF_ARG2
+#define CSTAMP(k) do { } while (0)
 #endif
 
 // ---- once per scan: spatial ordering --------------------------------------------------------------------------------------
@@ -265,6 +288,13 @@ __device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx
   if (radius_gate(p.n, p.c, p.d, p.radius, pt.pw, g)) sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pt, R, RE, sPrr, sPtt, best);
 }
 
+// Software prefetch (gfx950 has no prefetch instruction): a one-dword LDS-direct load (no destination VGPR) into a dump area
+// behind the block's tiles.  Nothing reads the dump; the point is that the line is now on its way to this CU's L2/L1.
+__device__ __forceinline__ void touch_line(const void *p) {
+  uint32_t keep_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep_m0) : "v"(p), "s"((uint32_t)LIDAR_LDS_BYTES) : "memory");
+}
+
 // ---- block-cooperative visit of non-plane roots ----------------------------------------------------------------------------
 // A non-plane root owns a flattened depth-first list of descendant planes.  Walking it inside the owning lane serialises up to 73
 // plane evaluations while the other lanes idle, and the kernel ends with its slowest wave (measured tail: 14 us against a 2.6 us
@@ -275,40 +305,64 @@ __device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx
 // (ties keep the first), which reproduces the serial recursion of build_single_residual exactly.
 struct __attribute__((aligned(16))) CoopLds {
   double ctx[LIDAR_BLOCK][18];       // owner context: pw pc pi q (3 each) Cb (6)
-  double res[LIDAR_BLOCK][10];       // pair result: prob, w, h[6], {float r, int32 plane}, accepted flag
+  double res[LIDAR_BLOCK][10];       // pair result: prob, w, h[6], {float r, int32 plane} (written for accepted pairs only)
   int32_t pair_owner[LIDAR_BLOCK];
   int32_t pair_cand[LIDAR_BLOCK];
-  int32_t wave_tot[8];
+  int32_t wave_tot[2][LIDAR_BLOCK / LIVO2_WAVE];       // one set per visit (first / neighbour): no barrier separates their plans
+  unsigned long long pass[LIDAR_BLOCK / LIVO2_WAVE];   // per evaluating wave: which of its slots hold an accepted plane
+  unsigned long long omax[LIDAR_BLOCK];                // per owner: largest accepted probability of the round (bit pattern)
+  int32_t omin[LIDAR_BLOCK];                           // per owner: first slot holding it
 };
 static_assert(sizeof(CoopLds) <= LIDAR_LDS_BYTES, "CoopLds must fit in the block's reduction tiles");
 
-// must be called by every thread of the block (cnt = 0 for threads without a pending candidate list)
-__device__ __forceinline__ int coop_visit(CoopLds &L, const DevMap &map, int cnt, int cand_begin, int max_layer, double sigma_num, const PointCtx &pt,
-                                          const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best) {
+// Planning half (every thread of the block calls it; cnt = 0 for threads without a pending candidate list): the pair counts are
+// prefix-summed over the block.  One barrier, LDS only — global loads issued before it (the plane
+// record of a plane-root lane) stay in flight across it, which is why the plan is made BEFORE those records are consumed.
+struct CoopPlan { int cnt, cand_begin, excl, W; };
+__device__ __forceinline__ CoopPlan coop_plan(CoopLds &L, int which, int cnt, int cand_begin) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (!__syncthreads_or(cnt > 0)) return 0;                  // block-uniform
-  if (cnt > 0) {
-    double *c = L.ctx[tid];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { c[k] = pt.pw[k]; c[3 + k] = pt.pc[k]; c[6 + k] = pt.pi[k]; c[9 + k] = pt.q[k]; }
-#pragma unroll
-    for (int k = 0; k < 6; k++) c[12 + k] = pt.Cb[k];
-  }
   int incl = cnt;                                            // inclusive prefix sum of the pair counts: wave scan + wave totals
 #pragma unroll
   for (int off = 1; off < LIVO2_WAVE; off <<= 1) { const int t = __shfl_up(incl, off, LIVO2_WAVE); if (lane >= off) incl += t; }
-  if (lane == LIVO2_WAVE - 1) L.wave_tot[wave] = incl;
+  if (lane == LIVO2_WAVE - 1) L.wave_tot[which][wave] = incl;
   __syncthreads();
   int woff = 0, W = 0;
 #pragma unroll
-  for (int w = 0; w < LIDAR_BLOCK / LIVO2_WAVE; w++) { const int t = L.wave_tot[w]; if (w < wave) woff += t; W += t; }
-  const int excl = woff + incl - cnt;
+  for (int w = 0; w < LIDAR_BLOCK / LIVO2_WAVE; w++) { const int t = L.wave_tot[which][w]; if (w < wave) woff += t; W += t; }
+  return {cnt, cand_begin, woff + incl - cnt, W};
+}
+
+// Every thread parks its point context in LDS before the first plan: evaluators read the owners' rows, and the thread itself
+// re-reads its own row after the evaluation instead of holding 36 VGPRs across it (the evaluation is the register peak).
+__device__ __forceinline__ void coop_park_ctx(CoopLds &L, const PointCtx &pt) {
+  double *c = L.ctx[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c[k] = pt.pw[k]; c[3 + k] = pt.pc[k]; c[6 + k] = pt.pi[k]; c[9 + k] = pt.q[k]; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) c[12 + k] = pt.Cb[k];
+}
+__device__ __forceinline__ void coop_unpark_ctx(const CoopLds &L, PointCtx &pt) {
+  const double *c = L.ctx[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pt.pw[k] = c[k]; pt.pc[k] = c[3 + k]; pt.pi[k] = c[6 + k]; pt.q[k] = c[9 + k]; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) pt.Cb[k] = c[12 + k];
+}
+
+// Evaluation half: every thread of the block calls it with its plan (W is block-uniform).
+__device__ __forceinline__ void coop_run(CoopLds &L, const DevMap &map, const CoopPlan &pl, int max_layer, double sigma_num,
+                                         const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cnt = pl.cnt, cand_begin = pl.cand_begin, excl = pl.excl, W = pl.W;
   for (int base = 0; base < W; base += LIDAR_BLOCK) {
+    CSTAMP(0);
     // owners publish the pairs that fall into this round
     const int k_lo = max(0, base - excl), k_hi = min(cnt, base + LIDAR_BLOCK - excl);
     for (int k = k_lo; k < k_hi; k++) { const int j = excl + k - base; L.pair_owner[j] = tid; L.pair_cand[j] = cand_begin + k; }
+    if (k_lo < k_hi) { L.omax[tid] = 0ull; L.omin[tid] = 0x7fffffff; }
     __syncthreads();
-    double r_prob = 0.0, r_w = 0.0, r_h[6] = {0, 0, 0, 0, 0, 0}, r_meta = 0.0, r_flag = 0.0;
+    CSTAMP(1);
+    double r_prob = 0.0, r_w = 0.0, r_h[6] = {0, 0, 0, 0, 0, 0}, r_meta = 0.0, r_flag = 0.0;   // r_flag: accepted
     if (base + tid < W) {
       const int owner = L.pair_owner[tid];
       PlaneRec p; int2 meta;
@@ -325,6 +379,7 @@ __device__ __forceinline__ int coop_visit(CoopLds &L, const DevMap &map, int cnt
         p.d = dr.x; p.radius = dr.y;
         meta = __builtin_bit_cast(int2, v[14].x);
       }
+      CSTAMP(2);
       if ((meta.x >> CAND_LAYER_SHIFT) <= max_layer) {
         const double *oc = L.ctx[owner];
         PointCtx pp;
@@ -352,21 +407,45 @@ __device__ __forceinline__ int coop_visit(CoopLds &L, const DevMap &map, int cnt
         }
       }
     }
-    {
+    // Fold = the reference's serial "first plane with the strictly largest probability" over each owner's list.  Walking the
+    // accepted result rows in the owner lane cost a dependent LDS round trip per accepted plane (~1.8 us in cluttered blocks,
+    // where a point passes both gates on several coplanar leaves), so the evaluators elect the winner instead: LDS max over
+    // the probability bits (accepted probabilities are non-negative, so the bit patterns order like the values), then LDS
+    // min over the slots holding that maximum (ascending slot = list order -> the first one), then the owner copies one row.
+    const unsigned long long pass = __ballot(r_flag != 0.0);
+    if (lane == 0) L.pass[wave] = pass;
+    const unsigned long long pbits = __builtin_bit_cast(unsigned long long, r_prob);
+    int owner_slot = 0;
+    if (r_flag != 0.0) {
+      owner_slot = L.pair_owner[tid];
+      atomicMax(&L.omax[owner_slot], pbits);
       double *o = L.res[tid];
       o[0] = r_prob; o[1] = r_w;
 #pragma unroll
       for (int u = 0; u < 6; u++) o[2 + u] = r_h[u];
-      o[8] = r_meta; o[9] = r_flag;
+      o[8] = r_meta;
     }
     __syncthreads();
-    // owners fold their pairs of this round, in list order
-    for (int k = k_lo; k < k_hi; k++) {
-      const double *o = L.res[excl + k - base];
-      if (o[9] != 0.0) {
+    CSTAMP(4);
+    if (r_flag != 0.0 && L.omax[owner_slot] == pbits) atomicMin(&L.omin[owner_slot], tid);
+    __syncthreads();
+    if (k_lo < k_hi) {
+      const int s_lo = excl + k_lo - base, s_hi = excl + k_hi - base;      // this owner's slots in the round: [s_lo, s_hi) within [0, 256]
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < LIDAR_BLOCK / LIVO2_WAVE; w++) {
+        const int lo = max(s_lo - 64 * w, 0), hi = min(s_hi - 64 * w, 64);
+        if (lo >= hi) continue;
+        unsigned long long m = L.pass[w] >> lo;
+        if (hi - lo < 64) m &= (1ull << (hi - lo)) - 1ull;
+        any = any || (m != 0ull);
+      }
+      if (any) {
         best.success = true;
-        if (o[0] > best.prob) {
-          best.prob = o[0]; best.prob_valid = true; best.w = o[1];
+        const double mp = __builtin_bit_cast(double, L.omax[tid]);
+        if (mp > best.prob) {
+          const double *o = L.res[L.omin[tid]];
+          best.prob = mp; best.prob_valid = true; best.w = o[1];
 #pragma unroll
           for (int u = 0; u < 6; u++) best.h[u] = o[2 + u];
           const int2 m2 = __builtin_bit_cast(int2, o[8]);
@@ -375,14 +454,14 @@ __device__ __forceinline__ int coop_visit(CoopLds &L, const DevMap &map, int cnt
       }
     }
     __syncthreads();
+    CSTAMP(5);
   }
-  return W;
 }
 
 // ---- fused per-iteration pass -----------------------------------------------------------------------------------------
 // One thread per point.  blockIdx is remapped so that consecutive point chunks land on the same XCD (dispatcher places
 // block b on XCD b % 8): neighbouring points share voxel planes, so each XCD's private 4-MiB L2 keeps one spatial slab.
-__global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+__global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop) {
   if (check_stop && ctl->hdr.stop) return;
   extern __shared__ __attribute__((aligned(16))) double lds_red[];
@@ -467,6 +546,7 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
   const bool f1 = in_range && slot_match(s1, key), f2 = in_range && slot_match(s2, key);
   const bool found = f1 || f2;
   RootRef s = {-1, 0, 0}, nb = {-1, 0, 0};
+  int plan1W = 0;
   {
     const RootSlot &sl = f1 ? s1 : s2;
     if (found) s = {sl.val, sl.cand_begin, sl.cand_count};
@@ -497,27 +577,39 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) k_lidar_residual(LidarKernelArgs 
     }
 #endif
     if (s.val >= 0) load_plane(a.map.planes, s.val, p0);         // issued right behind the neighbour slots: same round trip
+    // while that trip is in flight: plan the cooperative visit of the block's non-plane roots (LDS + one barrier only)
+    const CoopPlan plan1 = coop_plan(coop, 0, (s.val == -2) ? s.cand_count : 0, s.cand_begin);
     // the neighbour slots return first (in order); keep only the three words a later visit needs
     if (nbr) {
       if (slot_match(n1, nk)) nb = {n1.val, n1.cand_begin, n1.cand_count};
       else if (slot_match(n2, nk)) nb = {n2.val, n2.cand_begin, n2.cand_count};
     }
+    // A plane-root neighbour is visited only if the first visit fails, one dependent trip later: start pulling its two cache
+    // lines towards this CU now (a discarded dword per line), so that trip is an L2 hit instead of an HBM miss.
+    if (nb.val >= 0) { const double *q = a.map.planes + (size_t)nb.val * PLANE_REC_DOUBLES; touch_line(q); touch_line(q + 16); }
     if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
-  }
-  const int W1 = coop_visit(coop, a.map, (s.val == -2) ? s.cand_count : 0, s.cand_begin, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+    plan1W = plan1.W;
+    if (plan1.W > 0) {              // block-uniform
+      coop_park_ctx(coop, pt);      // (the first barrier inside coop_run orders these rows before the evaluators' reads)
+      coop_run(coop, a.map, plan1, a.max_layer, a.sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_ARG1);
+      coop_unpark_ctx(coop, pt);
+    }
 #ifdef LIVO2_PHASE_PROF
-  if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)W1;
-#else
-  (void)W1;
+    if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)plan1.W;
 #endif
+  }
   PHASE(3);
   {
     const bool retry = found && !best.success && nb.val != -1;
+    const CoopPlan plan2 = coop_plan(coop, 1, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin);
     if (retry && nb.val >= 0) {
       PlaneRec p1; load_plane(a.map.planes, nb.val, p1);
       visit_plane_root(p1, nb.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
     }
-    coop_visit(coop, a.map, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin, a.max_layer, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+    if (plan2.W > 0) {
+      if (plan1W == 0) coop_park_ctx(coop, pt);
+      coop_run(coop, a.map, plan2, a.max_layer, a.sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_ARG2);
+    }
   }
   PHASE(4);
   double acc[LIDAR_NSUM];
@@ -608,7 +700,7 @@ __device__ inline void reduce_partials_block(const double *__restrict__ partials
 // mode 0: bare iterate (only reduce and publish sums_l) ; mode 1: full ESIKF iteration `iter` of `max_iter`;
 // mode 2: like 1 but never stops (benchmark: fixed iteration count).
 #ifdef LIVO2_PHASE_PROF
-#define SPHASE(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (sprof && threadIdx.x == 0) sprof[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SPHASE(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (sprof && threadIdx.x == 0) { sprof[k] = __builtin_readcyclecounter(); if ((k) == 0 || (k) == 5) sprof[8 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SOLVE_PROF_PARAM , unsigned long long *sprof
 #else
 #define SPHASE(k) do { } while (0)

@@ -187,7 +187,7 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
 #ifdef LIVO2_PHASE_PROF
   {
     size_t waves = (size_t)lidar_grid(std::max(ctx->n, 1)) * 4;
-    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64 + 128); (void)e; ctx->prof_waves = waves; }
+    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64 + 128 + waves * 16 + waves * 128); (void)e; ctx->prof_waves = waves; }
     hipError_t e = hipMemsetAsync(ctx->d_prof, 0, waves * 64, ctx->stream); (void)e;
     a.prof = ctx->d_prof;
     { const char *e = getenv("LIVO2_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -560,7 +560,7 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1));
-  { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
+  { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
   { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations SOLVE_PROF_ARG); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
@@ -575,7 +575,7 @@ static int lidar_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1));
   for (int it = 0; it < iters; it++) {
-    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
+    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
     { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30) SOLVE_PROF_ARG); t.done(); }
   }
   hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);
@@ -801,9 +801,10 @@ int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_sta
 // profiling build only: copy the per-wave phase stamps of the LAST residual launch to host memory
 int livo2_debug_phase_prof(livo2_ctx *ctx, unsigned long long *out, size_t max_waves, size_t *n_waves) {
   if (!ctx || !ctx->d_prof) return LIVO2_ERR_INVALID;
-  size_t w = std::min(max_waves, ctx->prof_waves + 2);       // last two rows: solve-kernel stamps
+  // rows [0, waves): per-wave phase stamps; rows waves, waves+1: solve-kernel stamps; then waves x 2 chip-wide clock stamps
+  size_t w = std::min(max_waves, ctx->prof_waves + 2 + (ctx->prof_waves + 3) / 4 + 2 * ctx->prof_waves);
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(out, ctx->d_prof, w * 64, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, ctx->d_prof, std::min(w * 64, ctx->prof_waves * 208 + 128), hipMemcpyDeviceToHost));
   if (n_waves) *n_waves = w;
   return LIVO2_OK;
 }

@@ -34,8 +34,12 @@ def main():
     buf = np.zeros((W, 8), np.uint64)
     nw = C.c_size_t()
     assert fn(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), W, C.byref(nw)) == 0
-    sol = buf[nw.value - 2].astype(np.int64)
-    nw.value -= 2
+    waves = (nw.value - 2) * 4 // 13
+    cst = buf[waves + 2 + waves // 4:waves + 2 + waves // 4 + 2 * waves].reshape(waves, 16).astype(np.int64)   # stamps inside the first cooperative round
+    rt = buf[waves + 2:waves + 2 + waves // 4].reshape(-1)[:2 * waves].reshape(waves, 2).astype(np.int64)   # chip-wide 100 MHz stamps
+    sol = buf[waves].astype(np.int64)
+    sol_rt = buf[waves + 1, :2].astype(np.int64)
+    nw.value = waves
     print('solve kernel phases (us @2.1GHz): ' + ', '.join(f'{n} {(sol[k + 1] - sol[k]) / 2100.0:.2f}' for k, n in enumerate(['prefetch-issue', 'partial reduce', 'sums out', 'vec+GJ+gain+state', 'conv/cov/ctl'])))
     st = buf[:nw.value].astype(np.int64)
     st = st[st[:, 0] > 0]
@@ -68,6 +72,22 @@ def main():
             print(f"  waves with {lo}..{hi} candidate pairs: {m.sum():5d}  T3 mean {d3[m].mean():7.2f} p95 {np.percentile(d3[m], 95):7.2f} max {d3[m].max():7.2f}")
     slow = np.argsort(-d3)[:8]
     print('  slowest T3 waves (index, W, T3):', [(int(k), int(W[k]), round(float(d3[k]), 1)) for k in slow])
+    live = buf[:waves, 0] > 0
+    r0 = rt[live, 0].min()
+    start = (rt[live, 0] - r0) * 0.01; fin = (rt[live, 1] - r0) * 0.01
+    print(f"chip-wide clock (us): wave start p5 {np.percentile(start, 5):.2f} p50 {np.percentile(start, 50):.2f} p95 {np.percentile(start, 95):.2f} max {start.max():.2f}; "
+          f"wave end p5 {np.percentile(fin, 5):.2f} p50 {np.percentile(fin, 50):.2f} p95 {np.percentile(fin, 95):.2f} max {fin.max():.2f}; "
+          f"wave life p50 {np.percentile(fin - start, 50):.2f} max {(fin - start).max():.2f}")
+    print(f"solve kernel: starts {(sol_rt[0] - r0) * 0.01:.2f} us after the residual kernel's first wave ({(sol_rt[0] - rt[live, 1].max()) * 0.01:.2f} after its last), runs {(sol_rt[1] - sol_rt[0]) * 0.01:.2f}")
+    blk = np.arange(waves)[live] // 4
+    late = np.argsort(-fin)[:8]
+    print("  last waves to finish (wave, block, start, end, W):", [(int(np.arange(waves)[live][k]), int(blk[k]), round(float(start[k]), 2), round(float(fin[k]), 2), int(st[k, 7])) for k in late])
+    print("  their phases T1..T6 (us):", [[round(float(st[k, j] - st[k, j - 1]) / 2100.0, 2) for j in range(1, 7)] for k in late[::2]])
+    for k in late[::4]:
+        w = int(np.arange(waves)[live][k])
+        c = cst[w]
+        base0 = int(buf[w, 2])
+        print(f"  wave {w}: stamps after T2 end (us): round0 {[round((int(x) - base0) / 2100.0, 2) if x else None for x in c[:6]]} round1 {[round((int(x) - base0) / 2100.0, 2) if x else None for x in c[6:12]]}; T3 end {(int(buf[w, 3]) - base0) / 2100.0:.2f}")
     end = (st[:, 6] - t0) * tick_us
     print(f"wave end time: mean {end.mean():.2f} p50 {np.percentile(end, 50):.2f} p95 {np.percentile(end, 95):.2f} max {end.max():.2f} us")
 
