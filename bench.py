@@ -34,10 +34,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def make_states(livo2, sc):
-    from oracle.orc import make_state          # plain struct filler (no oracle compute)
-    cur = make_state(sc.R_prior, sc.t_prior, sc.P, inv_expo=getattr(sc, "tau_prior", 1.0), cls=livo2.State)
-    prop = make_state(sc.R_prior, sc.t_prior, sc.P, inv_expo=getattr(sc, "tau_prior", 1.0), cls=livo2.State)
-    return cur, prop
+    cur = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P, inv_expo=getattr(sc, "tau_prior", 1.0))
+    return cur, cur.copy()
 
 
 def cpu_baseline(sc, budget_s=20.0):
@@ -77,6 +75,7 @@ def main():
     ap.add_argument("--scan-order", choices=["voxelgrid", "random"], default="voxelgrid",
                     help="voxelgrid: scan passed through the 0.1 m centroid voxel-grid filter like feats_down_body (LIVMapper.cpp:351-352), "
                          "points ordered by leaf index; random: raw random-ray order (no spatial coherence)")
+    ap.add_argument("--batch", type=int, default=8, help="frames per launch in the batched-frames leg (extra.batched); 0 disables it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational visual / full-update legs")
     args = ap.parse_args()
@@ -210,6 +209,46 @@ def main():
             ctx.visual_update_async(vcur, vprop, vcfg); rv = ctx.visual_update_fetch()
         extra["visual_full_update_ms"] = (time.perf_counter() - t1) / reps * 1e3
         extra["visual_full_update_steps"] = int(rv.n_steps)
+
+    # ---- batched frames (BASELINE configs[4] shape, extra only): B scans of the C2 size against the resident map, one residual grid +
+    # one solve block per frame per ESIKF iteration.  Frames differ (own 97 % subset of the scan, own prior perturbation). ----
+    if args.batch > 0:
+        B = args.batch
+        rngb = np.random.default_rng(100 + rank)
+        scans, bst = [], []
+        for f in range(B):
+            keep = np.sort(rngb.permutation(n)[: int(0.97 * n)])
+            scans.append(sc.xyz[keep])
+            Rf = sc.R_prior @ synth.so3_exp(rngb.normal(0, np.deg2rad(0.2), 3))
+            bst.append(livo2.State.from_pose(Rf, sc.t_prior + rngb.normal(0, 0.02, 3), sc.P))
+        ctx.batch_set_scans(scans, cfg)
+        npts = int(sum(len(x) for x in scans))
+        ctx.batch_iterations_async(bst, bst, cfg, max(args.warmup, 1)); barrier()
+        tb0 = time.perf_counter()
+        ctx.batch_iterations_async(bst, bst, cfg, args.steps)
+        ctx.synchronize()
+        tb = frames.max_over_ranks(time.perf_counter() - tb0, dist, device="cuda")
+        ctx.kernel_timing(True); ctx.kernel_timing_read(0); ctx.kernel_timing_read(2)
+        ctx.batch_iterations_async(bst, bst, cfg, args.steps)
+        bms_res, bn_res = ctx.kernel_timing_read(0)
+        bms_sol, bn_sol = ctx.kernel_timing_read(2)
+        ctx.kernel_timing(False)
+        bres_us = 1e3 * bms_res / max(bn_res, 1)
+        # whole frames: upload + sort + full update + read-back, B at a time
+        ctx.batch_set_scans(scans, cfg); ctx.batch_update_async(bst, bst, cfg); ctx.batch_update_fetch()
+        barrier()
+        reps_b = 4
+        tb1 = time.perf_counter()
+        for _ in range(reps_b):
+            ctx.batch_set_scans(scans, cfg); ctx.batch_update_async(bst, bst, cfg); rb = ctx.batch_update_fetch()
+        tfb = frames.max_over_ranks(time.perf_counter() - tb1, dist, device="cuda")
+        bach = LIDAR_BYTES_PER_EVAL * npts / (bres_us * 1e-6) / 1e9
+        extra["batched"] = {"frames_per_launch": B, "points_per_launch": npts, "evals_per_s": world * npts * args.steps / tb, "ms_per_step": 1e3 * tb / args.steps,
+                            "residual_kernel_us": bres_us, "solve_kernel_us": 1e3 * bms_sol / max(bn_sol, 1),
+                            "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS,
+                                         "kernel": "k_lidar_residual_batch", "bytes_per_launch": LIDAR_BYTES_PER_EVAL * npts},
+                            "frames_per_s": world * B * reps_b / tfb, "full_update_iters": [int(r.n_iters) for r in rb],
+                            "note": "same kernels as the single-scan path, B independent (scan, state) problems per grid; results bit-identical to B single calls (tests/test_batch_gpu.py)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

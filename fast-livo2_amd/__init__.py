@@ -146,6 +146,37 @@ class Context:
     def lidar_iterations_async(self, state_in, prop, cfg, iters):
         self._chk(self.lib.livo2_lidar_iterations_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
 
+    # ---- batch of frames against the resident map --------------------------------------------------------------
+    def batch_set_scans(self, scans, cfg):
+        """scans: list of [n_f][3] float32 arrays (sensor frame), one per frame."""
+        counts = np.array([len(x) for x in scans], np.int32)
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(x, np.float32).reshape(-1, 3) for x in scans]), np.float32) if counts.sum() else np.zeros((0, 3), np.float32)
+        self._chk(self.lib.livo2_lidar_batch_set_scans(self.h, len(scans), abi.as_ptr(xyz, C.c_float), abi.as_ptr(counts, C.c_int32), C.byref(cfg)))
+        self.batch_n = len(scans)
+
+    @staticmethod
+    def _state_array(states):
+        arr = (State * len(states))()
+        for k, st in enumerate(states):
+            C.memmove(C.byref(arr, k * C.sizeof(State)), C.byref(st), C.sizeof(State))
+        return arr
+
+    def batch_update(self, states_in, props, cfg):
+        res = (LidarResult * self.batch_n)()
+        self._chk(self.lib.livo2_lidar_batch_update(self.h, self.batch_n, self._state_array(states_in), self._state_array(props), C.byref(cfg), res))
+        return list(res)
+
+    def batch_update_async(self, states_in, props, cfg):
+        self._chk(self.lib.livo2_lidar_batch_update_async(self.h, self.batch_n, self._state_array(states_in), self._state_array(props), C.byref(cfg)))
+
+    def batch_update_fetch(self):
+        res = (LidarResult * self.batch_n)()
+        self._chk(self.lib.livo2_lidar_batch_update_fetch(self.h, self.batch_n, res))
+        return list(res)
+
+    def batch_iterations_async(self, states_in, props, cfg, iters):
+        self._chk(self.lib.livo2_lidar_batch_iterations_async(self.h, self.batch_n, self._state_array(states_in), self._state_array(props), C.byref(cfg), int(iters)))
+
     # ---- visual ----------------------------------------------------------------------------------------------
     def set_frame(self, img, pos, warp_patch, search_levels, inv_expo_list):
         img = np.ascontiguousarray(img, np.uint8)

@@ -38,6 +38,16 @@ class State(C.Structure):
         s.cov[:] = cov.ravel().tolist()
         return s
 
+    @staticmethod
+    def from_pose(R, t, P, inv_expo=1.0):
+        """state at pose (R, t) with covariance P; velocity, biases and gravity zero (what the update does not read)."""
+        s = State()
+        s.rot[:] = np.asarray(R, float).ravel().tolist()
+        s.pos[:] = np.asarray(t, float).tolist()
+        s.inv_expo = float(inv_expo)
+        s.cov[:] = np.asarray(P, float).ravel().tolist()
+        return s
+
     def copy(self):
         o = State()
         C.memmove(C.byref(o), C.byref(self), C.sizeof(State))
@@ -136,6 +146,11 @@ SIGNATURES = {
     "livo2_lidar_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarPoints)]),
     "livo2_lidar_update_fetch": (C.c_int, [_CTX, _P(LidarResult), _P(LidarPoints)]),
     "livo2_lidar_iterations_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), C.c_int32]),
+    "livo2_lidar_batch_set_scans": (C.c_int, [_CTX, C.c_int32, _P(C.c_float), _P(C.c_int32), _P(LidarCfg)]),
+    "livo2_lidar_batch_update": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(LidarCfg), _P(LidarResult)]),
+    "livo2_lidar_batch_update_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(LidarCfg)]),
+    "livo2_lidar_batch_update_fetch": (C.c_int, [_CTX, C.c_int32, _P(LidarResult)]),
+    "livo2_lidar_batch_iterations_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(LidarCfg), C.c_int32]),
     "livo2_visual_set_frame": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32),
                                          _P(C.c_double), C.c_int32, C.c_int32]),
     "livo2_visual_set_reference": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, _P(C.c_int32), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),

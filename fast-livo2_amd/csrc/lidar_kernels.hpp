@@ -461,12 +461,15 @@ __device__ __forceinline__ void coop_run(CoopLds &L, const DevMap &map, const Co
 // ---- fused per-iteration pass -----------------------------------------------------------------------------------------
 // One thread per point.  blockIdx is remapped so that consecutive point chunks land on the same XCD (dispatcher places
 // block b on XCD b % 8): neighbouring points share voxel planes, so each XCD's private 4-MiB L2 keeps one spatial slab.
-__global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
-                                                                int check_stop) {
+// (pblock, pgrid): this block's index within the scan's own grid and that grid's size — blockIdx/gridDim for a single scan, the
+// frame-local values in a batched launch.  Row `pblock` of `partials` receives the block's sums, so a frame reduces in the same
+// order (bit-identical sums) whether it is launched alone or inside a batch.
+__device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const DevCtl *__restrict__ ctl, double *__restrict__ partials, int check_stop,
+                                                    int pblock, int pgrid) {
   if (check_stop && ctl->hdr.stop) return;
   extern __shared__ __attribute__((aligned(16))) double lds_red[];
-  const int per_xcd = gridDim.x >> 3;                            // host launches a multiple of 8 blocks
-  const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); // chunk index; chunks past the scan are empty
+  const int per_xcd = pgrid >> 3;                                // host launches a multiple of 8 blocks per scan
+  const int vb = (pblock & 7) * per_xcd + (pblock >> 3);         // chunk index; chunks past the scan are empty
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = vb * LIDAR_BLOCK + tid;            // position in the sorted scan
   const bool valid = i < a.n;
@@ -665,9 +668,26 @@ __global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_e
   __syncthreads();
   if (tid < 32) {
     const double v = ((lds_red[tid] + lds_red[32 + tid]) + lds_red[64 + tid]) + lds_red[96 + tid];
-    partials[(size_t)blockIdx.x * 32 + tid] = (tid < LIDAR_NSUM) ? v : 0.0;
+    partials[(size_t)pblock * 32 + tid] = (tid < LIDAR_NSUM) ? v : 0.0;
   }
   PHASE(6);
+}
+
+__global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+                                                                int check_stop) {
+  lidar_residual_body(a, ctl, partials, check_stop, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Batched launch: several independent (scan, state) problems against the resident map in ONE grid.  A single 100k-point scan is
+// 392 blocks — fewer than the 512 the chip holds at once — so its launch lasts as long as its slowest block (~2x the mean);
+// with several frames in the grid the CUs always have another block to start and the tail is paid once per batch.
+struct LidarBatchEntry { LidarKernelArgs a; DevCtl *ctl; double *partials; int32_t block_begin, nblocks; };
+__global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual_batch(const LidarBatchEntry *__restrict__ entries,
+                                                                const int32_t *__restrict__ block_frame, int check_stop) {
+  const int f = block_frame[blockIdx.x];                         // block-uniform: scalar loads
+  const LidarBatchEntry &e = entries[f];
+  const LidarKernelArgs a = e.a;
+  lidar_residual_body(a, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);
 }
 
 // Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 16 slices
@@ -706,8 +726,8 @@ __device__ inline void reduce_partials_block(const double *__restrict__ partials
 #define SPHASE(k) do { } while (0)
 #define SOLVE_PROF_PARAM
 #endif
-__global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
-                                                              int max_iter SOLVE_PROF_PARAM) {
+__device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
+                                                 int max_iter SOLVE_PROF_PARAM) {
   SPHASE(0);
   __shared__ SolveLds s;
   __shared__ double scratch[16 * 33];
@@ -772,8 +792,28 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
   SPHASE(5);
 }
 
+__global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
+                                                              int max_iter SOLVE_PROF_PARAM) {
+#ifdef LIVO2_PHASE_PROF
+  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, sprof);
+#else
+  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter);
+#endif
+}
+
+// one block per frame of a batch
+__global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve_batch(const LidarBatchEntry *__restrict__ entries, int mode, int iter, int max_iter) {
+  const LidarBatchEntry &e = entries[blockIdx.x];
+#ifdef LIVO2_PHASE_PROF
+  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, nullptr);
+#else
+  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter);
+#endif
+}
+
 // copies the posterior into the result block after the loop (always runs)
-__global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_finish(DevCtl *__restrict__ ctl) {
+__global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_finish(DevCtl *__restrict__ ctl_base) {
+  DevCtl *ctl = ctl_base + blockIdx.x;             // one block per frame (a single update has one)
   const int lane = threadIdx.x;
   const double *src = reinterpret_cast<const double *>(&ctl->cur);
   double *dst = reinterpret_cast<double *>(&ctl->lidar.state);

@@ -56,6 +56,17 @@ struct livo2_ctx {
   bool has_ref = false;
   uint8_t *d_ref_imgs = nullptr; size_t ref_img_cap = 0; int n_ref = 0;
   int32_t *d_ref_idx = nullptr; double *d_ref_px = nullptr, *d_ref_f = nullptr, *d_ref_R = nullptr, *d_ref_pos = nullptr, *d_gref = nullptr, *d_mref = nullptr; int ref_cap = 0;
+  // batch of frames (independent scans + states against the resident map, one grid per ESIKF iteration)
+  bool has_batch = false;
+  int bn = 0;                                // frames in the batch
+  std::vector<int32_t> b_count, b_off, b_grid, b_block_begin;   // per frame: points, first point, blocks, first block
+  int b_total = 0, b_cap = 0, b_blocks = 0;
+  float *bd_xyz_aos = nullptr, *bd_x = nullptr, *bd_y = nullptr, *bd_z = nullptr; double *bd_cb = nullptr;
+  uint32_t *bd_keys = nullptr, *bd_keys2 = nullptr; int32_t *bd_idx = nullptr, *bd_perm = nullptr;
+  double *bd_partials = nullptr; size_t b_partials_cap = 0;
+  int32_t *bd_block_frame = nullptr; size_t b_block_frame_cap = 0;
+  DevCtl *bd_ctl = nullptr; LidarBatchEntry *bd_entries = nullptr; HostIn *bd_in = nullptr; livo2_lidar_result *bd_results = nullptr;   // [LIVO2_MAX_BATCH]
+  HostIn *bh_in = nullptr; livo2_lidar_result *bh_results = nullptr; LidarBatchEntry *bh_entries = nullptr;                              // pinned
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
 #endif
@@ -306,10 +317,14 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   void *dev[] = {ctx->d_ctl, ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
                  ctx->d_cb, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, ctx->d_sort_tmp, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
                  ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg, ctx->d_ref_imgs, ctx->d_ref_idx, ctx->d_ref_px, ctx->d_ref_f, ctx->d_ref_R, ctx->d_ref_pos,
-                 ctx->d_gref, ctx->d_mref};
+                 ctx->d_gref, ctx->d_mref, ctx->bd_xyz_aos, ctx->bd_x, ctx->bd_y, ctx->bd_z, ctx->bd_cb, ctx->bd_keys, ctx->bd_keys2, ctx->bd_idx, ctx->bd_perm, ctx->bd_partials,
+                 ctx->bd_block_frame, ctx->bd_ctl, ctx->bd_entries, ctx->bd_in, ctx->bd_results};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
+  if (ctx->bh_in) e = hipHostFree(ctx->bh_in);
+  if (ctx->bh_results) e = hipHostFree(ctx->bh_results);
+  if (ctx->bh_entries) e = hipHostFree(ctx->bh_entries);
   for (auto &b : ctx->bins) for (auto &ev : b.used) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   if (ctx->own_stream && ctx->stream) e = hipStreamDestroy(ctx->stream);
@@ -611,6 +626,173 @@ int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, co
   if (iters < 1) return fail(ctx, LIVO2_ERR_INVALID, "iters must be >= 1");
   rc = ensure_lidar_outputs(ctx, nullptr); if (rc) return rc;
   return lidar_enqueue(ctx, state_in, prop, cfg, iters, 2);
+}
+
+// ---- batch of frames ---------------------------------------------------------------------------------------------------------
+// B independent StateEstimation problems (own scan, own states) against the resident map.  Every ESIKF iteration is ONE residual
+// grid over all frames plus one solve block per frame; a frame that has stopped (hdr.stop) drops out of later grids at its
+// blocks' first instruction.  Results are identical, bit for bit, to B separate livo2_lidar_update calls.
+namespace {
+
+__global__ void __launch_bounds__(LIVO2_WAVE) k_batch_scatter_in(const HostIn *__restrict__ in, DevCtl *__restrict__ ctl) {
+  const double *src = reinterpret_cast<const double *>(in + blockIdx.x);
+  double *dst = reinterpret_cast<double *>(ctl + blockIdx.x);
+  for (int e = threadIdx.x; e < (int)(sizeof(HostIn) / sizeof(double)); e += LIVO2_WAVE) dst[e] = src[e];
+}
+__global__ void __launch_bounds__(LIVO2_WAVE) k_batch_gather_out(const DevCtl *__restrict__ ctl, livo2_lidar_result *__restrict__ out) {
+  const double *src = reinterpret_cast<const double *>(&ctl[blockIdx.x].lidar);
+  double *dst = reinterpret_cast<double *>(out + blockIdx.x);
+  for (int e = threadIdx.x; e < (int)(sizeof(livo2_lidar_result) / sizeof(double)); e += LIVO2_WAVE) dst[e] = src[e];
+}
+static_assert(sizeof(HostIn) % 8 == 0 && sizeof(livo2_lidar_result) % 8 == 0 && sizeof(DevCtl) % 8 == 0, "copied as doubles");
+
+int batch_alloc_fixed(livo2_ctx *ctx) {
+  if (ctx->bd_ctl) return LIVO2_OK;
+  HIPCHK(hipMalloc((void **)&ctx->bd_ctl, sizeof(DevCtl) * LIVO2_MAX_BATCH));
+  HIPCHK(hipMalloc((void **)&ctx->bd_entries, sizeof(LidarBatchEntry) * LIVO2_MAX_BATCH));
+  HIPCHK(hipMalloc((void **)&ctx->bd_in, sizeof(HostIn) * LIVO2_MAX_BATCH));
+  HIPCHK(hipMalloc((void **)&ctx->bd_results, sizeof(livo2_lidar_result) * LIVO2_MAX_BATCH));
+  HIPCHK(hipHostMalloc((void **)&ctx->bh_in, sizeof(HostIn) * LIVO2_MAX_BATCH));
+  HIPCHK(hipHostMalloc((void **)&ctx->bh_results, sizeof(livo2_lidar_result) * LIVO2_MAX_BATCH));
+  HIPCHK(hipHostMalloc((void **)&ctx->bh_entries, sizeof(LidarBatchEntry) * LIVO2_MAX_BATCH));
+  HIPCHK(hipMemsetAsync(ctx->bd_ctl, 0, sizeof(DevCtl) * LIVO2_MAX_BATCH, ctx->stream));
+  return LIVO2_OK;
+}
+
+} // namespace
+
+int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *xyz, const int32_t *counts, const livo2_lidar_cfg *cfg) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n_frames < 1 || n_frames > LIVO2_MAX_BATCH) return fail(ctx, LIVO2_ERR_INVALID, "n_frames out of [1,LIVO2_MAX_BATCH]");
+  if (!counts) return fail(ctx, LIVO2_ERR_INVALID, "counts is NULL");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  long long total = 0;
+  for (int f = 0; f < n_frames; f++) { if (counts[f] < 0) return fail(ctx, LIVO2_ERR_INVALID, "negative point count"); total += counts[f]; }
+  if (total > 0 && !xyz) return fail(ctx, LIVO2_ERR_INVALID, "xyz is NULL");
+  if (total > (1ll << 30)) return fail(ctx, LIVO2_ERR_INVALID, "batch too large");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rc = batch_alloc_fixed(ctx); if (rc) return rc;
+  if ((int)total > ctx->b_cap) {
+    hipError_t e;
+    if (ctx->bd_x) { e = hipFree(ctx->bd_xyz_aos); e = hipFree(ctx->bd_x); e = hipFree(ctx->bd_y); e = hipFree(ctx->bd_z); e = hipFree(ctx->bd_cb); e = hipFree(ctx->bd_keys); e = hipFree(ctx->bd_keys2); e = hipFree(ctx->bd_idx); e = hipFree(ctx->bd_perm); (void)e; }
+    ctx->bd_x = nullptr;
+    size_t cap = std::max((size_t)total, (size_t)1024);
+    HIPCHK(hipMalloc((void **)&ctx->bd_xyz_aos, cap * 12)); HIPCHK(hipMalloc((void **)&ctx->bd_x, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_y, cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->bd_z, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_cb, cap * 48)); HIPCHK(hipMalloc((void **)&ctx->bd_keys, cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->bd_keys2, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_perm, cap * 4));
+    ctx->b_cap = (int)cap;
+  }
+  ctx->bn = n_frames; ctx->b_total = (int)total;
+  ctx->b_count.assign(counts, counts + n_frames);
+  ctx->b_off.resize(n_frames); ctx->b_grid.resize(n_frames); ctx->b_block_begin.resize(n_frames);
+  int off = 0, blocks = 0;
+  for (int f = 0; f < n_frames; f++) {
+    ctx->b_off[f] = off; ctx->b_grid[f] = lidar_grid(std::max(counts[f], 1)); ctx->b_block_begin[f] = blocks;
+    off += counts[f]; blocks += ctx->b_grid[f];
+  }
+  ctx->b_blocks = blocks;
+  rc = ensure(ctx, ctx->bd_partials, ctx->b_partials_cap, (size_t)blocks * 32); if (rc) return rc;
+  rc = ensure(ctx, ctx->bd_block_frame, ctx->b_block_frame_cap, (size_t)blocks); if (rc) return rc;
+  {
+    std::vector<int32_t> bf((size_t)blocks);
+    for (int f = 0; f < n_frames; f++) std::fill(bf.begin() + ctx->b_block_begin[f], bf.begin() + ctx->b_block_begin[f] + ctx->b_grid[f], f);
+    HIPCHK(hipMemcpy(ctx->bd_block_frame, bf.data(), (size_t)blocks * 4, hipMemcpyHostToDevice));
+  }
+  if (total > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->bd_xyz_aos, xyz, (size_t)total * 12, hipMemcpyHostToDevice, ctx->stream));
+    const double deg2rad = cfg->deg2rad != 0.0 ? cfg->deg2rad : 0.017453293;
+    int nmax = 0; for (int f = 0; f < n_frames; f++) nmax = std::max(nmax, counts[f]);
+    size_t need = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->bd_keys, ctx->bd_keys2, ctx->bd_idx, ctx->bd_perm, (size_t)nmax, 0, 30, ctx->stream));
+    if (need > ctx->sort_tmp_bytes) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (ctx->d_sort_tmp) HIPCHK(hipFree(ctx->d_sort_tmp));
+      ctx->d_sort_tmp = nullptr;
+      HIPCHK(hipMalloc(&ctx->d_sort_tmp, need + need / 2 + 256));
+      ctx->sort_tmp_bytes = need + need / 2 + 256;
+    }
+    for (int f = 0; f < n_frames; f++) {          // same per-scan pipeline as livo2_lidar_set_scan, on this frame's slice
+      const int n = counts[f], o = ctx->b_off[f];
+      if (n == 0) continue;
+      hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->bd_xyz_aos + (size_t)o * 3, n, (float)(1.0 / cfg->voxel_size), ctx->bd_keys + o, ctx->bd_idx + o);
+      size_t tmp_bytes = ctx->sort_tmp_bytes;
+      HIPCHK(rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->bd_keys + o, ctx->bd_keys2 + o, ctx->bd_idx + o, ctx->bd_perm + o, (size_t)n, 0, 30, ctx->stream));
+      hipLaunchKernelGGL(k_gather_xyz, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->bd_xyz_aos + (size_t)o * 3, ctx->bd_perm + o, n, ctx->bd_x + o, ctx->bd_y + o, ctx->bd_z + o);
+      hipLaunchKernelGGL(k_body_cov, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->bd_x + o, ctx->bd_y + o, ctx->bd_z + o, n, (float)cfg->dept_err, (float)cfg->beam_err,
+                         deg2rad, ctx->bd_cb + (size_t)o * 6);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->has_batch = true;
+  return LIVO2_OK;
+}
+
+static int batch_enqueue(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, int iters, int mode) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!state_in || !prop) return fail(ctx, LIVO2_ERR_INVALID, "state is NULL");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  if (!ctx->has_map) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_map_upload has not been called");
+  if (!ctx->has_batch) return fail(ctx, LIVO2_ERR_NO_SCAN, "livo2_lidar_batch_set_scans has not been called");
+  if (n_frames != ctx->bn) return fail(ctx, LIVO2_ERR_INVALID, "n_frames differs from the batch set by livo2_lidar_batch_set_scans");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));        // pinned staging blocks are reused
+  for (int f = 0; f < n_frames; f++) {
+    HostIn &h = ctx->bh_in[f];
+    h.cur = state_in[f]; h.prop = prop[f];
+    std::memset(&h.hdr, 0, sizeof(DevHeader));
+    h.hdr.last_error = FLT_MAX;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      h.hdr.RE[i * 3 + j] = (prop[f].rot[i * 3] * cfg->extR[j] + prop[f].rot[i * 3 + 1] * cfg->extR[3 + j]) + prop[f].rot[i * 3 + 2] * cfg->extR[6 + j];
+    LidarBatchEntry &e = ctx->bh_entries[f];
+    std::memset(&e, 0, sizeof(e));
+    const int o = ctx->b_off[f];
+    e.a.x = ctx->bd_x + o; e.a.y = ctx->bd_y + o; e.a.z = ctx->bd_z + o; e.a.cb = ctx->bd_cb + (size_t)o * 6; e.a.perm = ctx->bd_perm + o;
+    e.a.n = ctx->b_count[f]; e.a.max_layer = cfg->max_layer; e.a.map = ctx->map; e.a.voxel_size = cfg->voxel_size; e.a.sigma_num = cfg->sigma_num;
+    std::memcpy(e.a.ER, cfg->extR, 72); std::memcpy(e.a.Et, cfg->extT, 24);
+    e.ctl = ctx->bd_ctl + f; e.partials = ctx->bd_partials + (size_t)ctx->b_block_begin[f] * 32; e.block_begin = ctx->b_block_begin[f]; e.nblocks = ctx->b_grid[f];
+  }
+  HIPCHK(hipMemcpyAsync(ctx->bd_in, ctx->bh_in, sizeof(HostIn) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->bd_entries, ctx->bh_entries, sizeof(LidarBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_batch_scatter_in, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_in, ctx->bd_ctl);
+  for (int it = 0; it < iters; it++) {
+    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual_batch, dim3(ctx->b_blocks), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES + LIDAR_LDS_DUMP, ctx->stream, ctx->bd_entries, ctx->bd_block_frame, mode == 1 ? 1 : 0); t.done(); }
+    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve_batch, dim3(n_frames), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->bd_entries, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
+  }
+  hipLaunchKernelGGL(k_lidar_finish, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_ctl);
+  hipLaunchKernelGGL(k_batch_gather_out, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_ctl, ctx->bd_results);
+  HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+
+int livo2_lidar_batch_update_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg) {
+  if (!ctx || !cfg) return ctx ? fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL") : LIVO2_ERR_INVALID;
+  return batch_enqueue(ctx, n_frames, state_in, prop, cfg, cfg->max_iterations, 1);
+}
+
+int livo2_lidar_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_lidar_result *results) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!results) return fail(ctx, LIVO2_ERR_INVALID, "results is NULL");
+  if (!ctx->has_batch || n_frames != ctx->bn) return fail(ctx, LIVO2_ERR_INVALID, "n_frames differs from the batch set by livo2_lidar_batch_set_scans");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->bh_results, ctx->bd_results, sizeof(livo2_lidar_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(results, ctx->bh_results, sizeof(livo2_lidar_result) * n_frames);
+  return LIVO2_OK;
+}
+
+int livo2_lidar_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                             livo2_lidar_result *results) {
+  int rc = livo2_lidar_batch_update_async(ctx, n_frames, state_in, prop, cfg); if (rc) return rc;
+  return livo2_lidar_batch_update_fetch(ctx, n_frames, results);
+}
+
+int livo2_lidar_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                                       int32_t iters) {
+  if (!ctx || !cfg) return ctx ? fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL") : LIVO2_ERR_INVALID;
+  if (iters < 1) return fail(ctx, LIVO2_ERR_INVALID, "iters must be >= 1");
+  return batch_enqueue(ctx, n_frames, state_in, prop, cfg, iters, 2);
 }
 
 // ---- visual ------------------------------------------------------------------------------------------------------------------

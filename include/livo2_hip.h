@@ -23,6 +23,7 @@ extern "C" {
 #endif
 
 #define LIVO2_DIM_STATE 19      /* reference include/common_lib.h:30  (DIM_STATE) */
+#define LIVO2_MAX_BATCH 64      /* frames per livo2_lidar_batch_* call */
 #define LIVO2_MAX_ITERS 16      /* upper bound accepted for lio/vio max_iterations (reference default 5) */
 #define LIVO2_MAX_LEVELS 8      /* upper bound for vio/patch_pyrimid_level (reference default 4) */
 #define LIVO2_MAX_LAYER 4       /* upper bound for lio/max_layer (layer_init_num has 5 entries, voxel_map.cpp:46) */
@@ -164,6 +165,23 @@ int livo2_lidar_update_fetch(livo2_ctx *ctx, livo2_lidar_result *result, const l
  * without host interaction; used by bench.py to time the per-iteration cost. */
 int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
                                  int32_t iters);
+
+/* ---- batch of frames (offline / replay: BASELINE config "batched frames") ------------------------------------------
+ * n_frames independent VoxelMapManager::StateEstimation problems (src/voxel_map.cpp:338-511; call site LIVMapper.cpp:370) — each
+ * with its own feats_down_body scan, state_ and state_propagat — solved against the ONE resident map snapshot.  Every ESIKF
+ * iteration is a single residual grid over all frames plus one solve block per frame, so the GPU is kept full where a lone
+ * 100k-point scan leaves half of it idle; frames stop individually (convergence / rematch logic per frame).  Results are bit-identical
+ * to n_frames separate livo2_lidar_update calls.  Per-point outputs are not produced in batch mode.
+ * xyz: the scans concatenated, [sum(counts)][3] float32 (sensor frame); counts[f] = points of frame f (0 allowed). */
+int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *xyz, const int32_t *counts, const livo2_lidar_cfg *cfg);
+/* state_in[f], prop[f]: state_ / state_propagat of frame f; results[f] as livo2_lidar_update's. */
+int livo2_lidar_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
+                             livo2_lidar_result *results);
+int livo2_lidar_batch_update_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg);
+int livo2_lidar_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_lidar_result *results);
+/* fixed iteration count, no stopping (bench.py) */
+int livo2_lidar_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop,
+                                       const livo2_lidar_cfg *cfg, int32_t iters);
 
 /* ---- visual photometric update ---------------------------------------------------------------------------------- */
 /* vk::AbstractCamera as used on the path: cam->fx()/fy()/cx()/cy()/width()/height() already scaled (vio.cpp:45-54) and
