@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--scan-order", choices=["voxelgrid", "random"], default="voxelgrid",
                     help="voxelgrid: scan passed through the 0.1 m centroid voxel-grid filter like feats_down_body (LIVMapper.cpp:351-352), "
                          "points ordered by leaf index; random: raw random-ray order (no spatial coherence)")
-    ap.add_argument("--batch", type=int, default=8, help="frames per launch in the batched-frames leg (extra.batched); 0 disables it")
+    ap.add_argument("--batch", type=int, default=16, help="frames per launch in the batched-frames leg (extra.batched); 0 disables it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational visual / full-update legs")
     args = ap.parse_args()
