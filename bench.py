@@ -38,6 +38,25 @@ def make_states(livo2, sc):
     return cur, cur.copy()
 
 
+PLANE_FIT_BYTES_PER_POINT = 96.0        # point_w 24 + var 72 (each point read once per pass; second pass is the same lines)
+
+
+def plane_fit_groups(n_groups=20000, seed=4):
+    """voxel point groups of the size UpdateVoxelMap re-fits (6..60 points, update_size_threshold_ 5 .. max_points_num_ 50)"""
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(6, 61, n_groups)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    N = int(off[-1])
+    gid = np.repeat(np.arange(n_groups), cnt)
+    Q = np.linalg.qr(rng.normal(size=(n_groups, 3, 3)))[0]
+    ext = np.where((np.arange(n_groups) % 5 == 4)[:, None], [0.12, 0.11, 0.1], [0.15, 0.12, 0.01])       # 80 % planar patches, 20 % blobs
+    local = rng.normal(size=(N, 3)) * ext[gid]
+    pw = (np.einsum("nij,nj->ni", Q[gid], local) + rng.uniform(-40, 40, (n_groups, 3))[gid]).astype(np.float32).astype(np.float64)
+    A = rng.normal(size=(N, 3, 3))
+    var = 1e-4 * (A @ A.transpose(0, 2, 1) + 0.1 * np.eye(3))
+    return pw, var.reshape(N, 9), off
+
+
 def cpu_baseline(sc, budget_s=20.0):
     """Oracle (restated reference CPU path) timed on this host.  Bounded: at most `budget_s` seconds of StateEstimation calls."""
     from oracle import orc
@@ -61,7 +80,11 @@ def cpu_baseline(sc, budget_s=20.0):
             r = orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop, want_points=False)
             secs += r["seconds"]; evals += len(sc.xyz) * r["n_iters"]; runs += 1
         out[threads] = (evals / secs, runs)
-    return {"value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
+    pw, var, off = plane_fit_groups()
+    orc.init_plane_batch(pw, var, off, 0.0025, lib)
+    _, fit_s = orc.init_plane_batch(pw, var, off, 0.0025, lib)
+    return {"plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1,
+            "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "value_1thread": out[1][0], "host_cores": os.cpu_count()}
 
@@ -209,6 +232,20 @@ def main():
             ctx.visual_update_async(vcur, vprop, vcfg); rv = ctx.visual_update_fetch()
         extra["visual_full_update_ms"] = (time.perf_counter() - t1) / reps * 1e3
         extra["visual_full_update_steps"] = int(rv.n_steps)
+        # batched init_plane (plane fit + plane covariance) on the device
+        fpw, fvar, foff = plane_fit_groups()
+        ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)
+        us = []
+        t1 = time.perf_counter()
+        for _ in range(5):
+            fo = ctx.plane_fit_batch(fpw, fvar, foff, 0.0025); us.append(ctx.plane_fit_last_kernel_us())
+        t_e2e = (time.perf_counter() - t1) / 5
+        k_us = float(np.median(us))
+        extra["plane_fit"] = {"groups": len(foff) - 1, "points": len(fpw), "planes": int(sum(o.is_plane for o in fo)), "kernel_us": k_us,
+                              "points_per_s_kernel": len(fpw) / (k_us * 1e-6), "achieved_GBps": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9,
+                              "frac_of_hbm_peak": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "points_per_s_with_h2d_d2h": len(fpw) / t_e2e,
+                              "note": "k_plane_fit: 8 lanes per voxel group (64 for groups > 64 points); VoxelOctoTree::init_plane (voxel_map.cpp:55-135); CPU figure in cpu_baseline.plane_fit_points_per_s_1thread"}
 
     # ---- batched frames (BASELINE configs[4] shape, extra only): B scans of the C2 size against the resident map, one residual grid +
     # one solve block per frame per ESIKF iteration.  Frames differ (own 97 % subset of the scan, own prior perturbation). ----

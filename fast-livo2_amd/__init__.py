@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
+from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
 
 
 class Livo2Error(RuntimeError):
@@ -145,6 +145,22 @@ class Context:
 
     def lidar_iterations_async(self, state_in, prop, cfg, iters):
         self._chk(self.lib.livo2_lidar_iterations_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
+
+    # ---- map maintenance ---------------------------------------------------------------------------------------
+    def plane_fit_batch(self, point_w, var, offsets, planer_threshold, plane_idx=None):
+        """VoxelOctoTree::init_plane for every group [offsets[g], offsets[g+1]); returns a ctypes array of PlaneFit."""
+        pw = np.ascontiguousarray(point_w, np.float64).reshape(-1, 3)
+        v = np.ascontiguousarray(var, np.float64).reshape(-1, 9)
+        off = np.ascontiguousarray(offsets, np.int32)
+        G = len(off) - 1
+        out = (PlaneFit * max(G, 1))()
+        idx = None if plane_idx is None else np.ascontiguousarray(plane_idx, np.int32)
+        self._chk(self.lib.livo2_plane_fit_batch(self.h, abi.as_ptr(pw, C.c_double), abi.as_ptr(v, C.c_double), abi.as_ptr(off, C.c_int32), G,
+                                                 float(planer_threshold), abi.as_ptr(idx, C.c_int32) if idx is not None else None, out))
+        return out
+
+    def plane_fit_last_kernel_us(self):
+        return float(self.lib.livo2_plane_fit_last_kernel_us(self.h))
 
     # ---- batch of frames against the resident map --------------------------------------------------------------
     def batch_set_scans(self, scans, cfg):

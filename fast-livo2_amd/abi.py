@@ -100,6 +100,14 @@ class LidarResult(C.Structure):
                 ("iter_solution", (C.c_double * DIM_STATE) * MAX_ITERS), ("position_last", C.c_double * 3)]
 
 
+class PlaneFit(C.Structure):
+    """livo2_plane_fit == the VoxelPlane members init_plane writes (reference include/voxel_map.h:69-94)."""
+    _fields_ = [("center", C.c_double * 3), ("normal", C.c_double * 3), ("y_normal", C.c_double * 3), ("x_normal", C.c_double * 3),
+                ("covariance", C.c_double * 9), ("plane_var", C.c_double * 36), ("radius", C.c_float), ("min_eigen_value", C.c_float),
+                ("mid_eigen_value", C.c_float), ("max_eigen_value", C.c_float), ("d", C.c_float), ("points_size", C.c_int32),
+                ("is_plane", C.c_int32), ("pad", C.c_int32)]
+
+
 class Cam(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5),
                 ("distortion", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("pad", C.c_int32)]
@@ -140,6 +148,8 @@ SIGNATURES = {
     "livo2_ctx_kernel_timing_read": (C.c_int, [_CTX, C.c_int, _P(C.c_double), _P(C.c_int64), C.c_int]),
     "livo2_map_upload": (C.c_int, [_CTX, _P(MapView)]),
     "livo2_map_update_planes": (C.c_int, [_CTX, _P(C.c_int32), C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_float), _P(C.c_float)]),
+    "livo2_plane_fit_batch": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_int32, C.c_float, _P(C.c_int32), _P(PlaneFit)]),
+    "livo2_plane_fit_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_lidar_set_scan": (C.c_int, [_CTX, _P(C.c_float), C.c_int32, _P(LidarCfg)]),
     "livo2_lidar_iterate": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarSums), _P(LidarPoints)]),
     "livo2_lidar_update": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarResult), _P(LidarPoints)]),

@@ -6,6 +6,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include "lidar_kernels.hpp"
 #include "visual_inverse_kernels.hpp"
+#include "map_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -38,6 +39,13 @@ struct livo2_ctx {
   RootSlot *d_slots = nullptr; double *d_cand = nullptr; double *d_planes = nullptr;
   std::vector<int32_t> plane_cand_pos;      // host: position of each (caller-indexed) plane in the candidate array, or -1
   std::vector<int32_t> plane_internal, plane_orig;   // caller plane index <-> device (Morton-ordered) plane index
+  int32_t *d_plane_internal = nullptr, *d_plane_cand_pos = nullptr; size_t plane_tab_cap = 0, plane_tab_cap2 = 0;   // device copies for k_plane_fit
+  bool plane_tabs_fresh = false;
+  // plane fit staging
+  double *d_fit_pw = nullptr, *d_fit_var = nullptr; size_t fit_pw_cap = 0, fit_var_cap = 0;
+  int32_t *d_fit_off = nullptr, *d_fit_idx = nullptr, *d_fit_list = nullptr; size_t fit_off_cap = 0, fit_idx_cap = 0, fit_list_cap = 0;
+  livo2_plane_fit *d_fit_out = nullptr; size_t fit_out_cap = 0;
+  double fit_kernel_us = 0.0;
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -318,7 +326,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_cb, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, ctx->d_sort_tmp, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
                  ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg, ctx->d_ref_imgs, ctx->d_ref_idx, ctx->d_ref_px, ctx->d_ref_f, ctx->d_ref_R, ctx->d_ref_pos,
                  ctx->d_gref, ctx->d_mref, ctx->bd_xyz_aos, ctx->bd_x, ctx->bd_y, ctx->bd_z, ctx->bd_cb, ctx->bd_keys, ctx->bd_keys2, ctx->bd_idx, ctx->bd_perm, ctx->bd_partials,
-                 ctx->bd_block_frame, ctx->bd_ctl, ctx->bd_entries, ctx->bd_in, ctx->bd_results};
+                 ctx->bd_block_frame, ctx->bd_ctl, ctx->bd_entries, ctx->bd_in, ctx->bd_results, ctx->d_plane_internal, ctx->d_plane_cand_pos,
+                 ctx->d_fit_pw, ctx->d_fit_var, ctx->d_fit_off, ctx->d_fit_idx, ctx->d_fit_out, ctx->d_fit_list};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -478,6 +487,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   ctx->map.slots = ctx->d_slots; ctx->map.cand_rec = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = cap - 1;
   ctx->map.seed1 = seed1; ctx->map.seed2 = seed2; ctx->map.n_planes = m->n_planes;
   ctx->has_map = true;
+  ctx->plane_tabs_fresh = false;
   return LIVO2_OK;
 }
 
@@ -506,6 +516,69 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_gpos));
   return LIVO2_OK;
 }
+
+// ---- map maintenance: batched plane fit ----------------------------------------------------------------------------------------
+int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *var, const int32_t *offsets, int32_t n_groups, float planer_threshold,
+                          const int32_t *plane_idx, livo2_plane_fit *out) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n_groups < 0 || (n_groups > 0 && (!offsets || !out))) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (n_groups == 0) return LIVO2_OK;
+  if (offsets[0] != 0) return fail(ctx, LIVO2_ERR_INVALID, "offsets[0] must be 0");
+  for (int g = 0; g < n_groups; g++) if (offsets[g + 1] < offsets[g]) return fail(ctx, LIVO2_ERR_INVALID, "offsets must be non-decreasing");
+  const size_t N = (size_t)offsets[n_groups];
+  if (N > 0 && (!point_w || !var)) return fail(ctx, LIVO2_ERR_INVALID, "point_w / var is NULL");
+  if (plane_idx) {
+    if (!ctx->has_map) return fail(ctx, LIVO2_ERR_NO_MAP, "plane_idx given but no map uploaded");
+    for (int g = 0; g < n_groups; g++) if (plane_idx[g] >= ctx->map.n_planes) return fail(ctx, LIVO2_ERR_INVALID, "plane index out of range");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_fit_pw, ctx->fit_pw_cap, std::max(N * 3, (size_t)3)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_fit_var, ctx->fit_var_cap, std::max(N * 9, (size_t)9)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_fit_off, ctx->fit_off_cap, (size_t)n_groups + 1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_fit_idx, ctx->fit_idx_cap, (size_t)n_groups))) return rc;
+  if ((rc = ensure(ctx, ctx->d_fit_out, ctx->fit_out_cap, (size_t)n_groups))) return rc;
+  if ((rc = ensure(ctx, ctx->d_fit_list, ctx->fit_list_cap, (size_t)n_groups))) return rc;
+  if (plane_idx && !ctx->plane_tabs_fresh) {
+    const size_t np = ctx->plane_internal.size();
+    if ((rc = ensure(ctx, ctx->d_plane_internal, ctx->plane_tab_cap, std::max(np, (size_t)1)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_plane_cand_pos, ctx->plane_tab_cap2, std::max(np, (size_t)1)))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_plane_internal, ctx->plane_internal.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_plane_cand_pos, ctx->plane_cand_pos.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->plane_tabs_fresh = true;
+  }
+  if (N > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_fit_pw, point_w, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_fit_var, var, N * 72, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_fit_off, offsets, ((size_t)n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (plane_idx) HIPCHK(hipMemcpyAsync(ctx->d_fit_idx, plane_idx, (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+  // small voxels (the UpdateVoxelMap case) go 8 to a wave, large ones (BuildVoxelMap) get a whole wave
+  std::vector<int32_t> list((size_t)n_groups);
+  int n_small = 0, n_big = 0;
+  for (int g = 0; g < n_groups; g++) { if (offsets[g + 1] - offsets[g] <= 64) list[n_small++] = g; else list[n_groups - 1 - n_big++] = g; }
+  HIPCHK(hipMemcpyAsync(ctx->d_fit_list, list.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+  PlaneFitArgs a{};
+  a.pw = ctx->d_fit_pw; a.var = ctx->d_fit_var; a.offsets = ctx->d_fit_off; a.planer_threshold = planer_threshold; a.out = ctx->d_fit_out;
+  a.plane_idx = plane_idx ? ctx->d_fit_idx : nullptr; a.plane_internal = ctx->d_plane_internal; a.plane_cand_pos = ctx->d_plane_cand_pos;
+  a.planes = ctx->d_planes; a.cand = ctx->d_cand;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  const int tpb = FIT_WAVES * LIVO2_WAVE;
+  if (n_small) { a.list = ctx->d_fit_list; a.n_list = n_small; hipLaunchKernelGGL(k_plane_fit<8>, dim3((n_small * 8 + tpb - 1) / tpb), dim3(tpb), 0, ctx->stream, a); }
+  if (n_big) { a.list = ctx->d_fit_list + n_small; a.n_list = n_big; hipLaunchKernelGGL(k_plane_fit<64>, dim3((n_big * 64 + tpb - 1) / tpb), dim3(tpb), 0, ctx->stream, a); }
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, ctx->d_fit_out, (size_t)n_groups * sizeof(livo2_plane_fit), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  ctx->fit_kernel_us = 1e3 * ms;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  return LIVO2_OK;
+}
+double livo2_plane_fit_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->fit_kernel_us : 0.0; }
 
 // ---- LiDAR -----------------------------------------------------------------------------------------------------------------
 int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg) {

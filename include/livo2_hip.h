@@ -95,6 +95,26 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *map);
 int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n, const double *normal, const double *center,
                             const double *plane_var, const float *d, const float *radius);
 
+/* ---- map maintenance: batched plane fit ----------------------------------------------------------------
+ * VoxelOctoTree::init_plane (src/voxel_map.cpp:55-135) for n_groups voxels at once: group g owns points
+ * [offsets[g], offsets[g+1]) of point_w / var (pointWithVar::point_w, ::var of its temp_points_).  out[g] receives the VoxelPlane
+ * members init_plane writes (include/voxel_map.h:69-94).  If plane_idx != NULL and plane_idx[g] >= 0 and the fit is a plane, the
+ * record of that plane in the resident map is refreshed in place (as livo2_map_update_planes would) — the octree bookkeeping
+ * (UpdateOctoTree / cut_octo_tree, voxel_map.cpp:163-290) stays with the caller, who re-uploads the map when a fit changes the
+ * tree's shape (a plane lost, a voxel subdivided).  Eigen-decomposition: cyclic Jacobi (the reference's Eigen::EigenSolver is a
+ * third-party dependency); eigenvector signs are solver-dependent and cancel in everything downstream. */
+typedef struct livo2_plane_fit {
+  double center[3], normal[3], y_normal[3], x_normal[3];
+  double covariance[9];         /* covariance_, row-major */
+  double plane_var[36];         /* plane_var_, row-major 6x6 (zero when not a plane) */
+  float radius, min_eigen_value, mid_eigen_value, max_eigen_value, d;   /* float members of VoxelPlane */
+  int32_t points_size, is_plane, pad;
+} livo2_plane_fit;
+int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *var, const int32_t *offsets, int32_t n_groups,
+                          float planer_threshold, const int32_t *plane_idx, livo2_plane_fit *out);
+/* average kernel time of the last call's k_plane_fit launch in microseconds (HIP events on the ctx stream) */
+double livo2_plane_fit_last_kernel_us(const livo2_ctx *ctx);
+
 /* ---- LiDAR point-to-plane update ------------------------------------------------------------------------------ */
 /* Knobs of VoxelMapConfig the path reads (reference include/voxel_map.h:35-52, src/voxel_map.cpp:36-53) + extrinsics
  * extR_/extT_ (voxel_map.h:200-201).  deg2rad is PCL's DEG2RAD factor used by calcBodyCov (voxel_map.cpp:21); pass 0 for the

@@ -142,6 +142,38 @@ class OracleMap:
             pass
 
 
+class PlaneFit(C.Structure):
+    """VoxelPlane fields written by VoxelOctoTree::init_plane (include/voxel_map.h:69-94, src/voxel_map.cpp:55-135)."""
+    _fields_ = [("center", C.c_double * 3), ("normal", C.c_double * 3), ("y_normal", C.c_double * 3), ("x_normal", C.c_double * 3),
+                ("covariance", C.c_double * 9), ("plane_var", C.c_double * 36), ("radius", C.c_float), ("min_eigen_value", C.c_float),
+                ("mid_eigen_value", C.c_float), ("max_eigen_value", C.c_float), ("d", C.c_float), ("points_size", C.c_int32),
+                ("is_plane", C.c_int32), ("pad", C.c_int32)]
+
+
+def init_plane(point_w, var, planer_threshold, lib=None):
+    lib = lib or load()
+    pw = np.ascontiguousarray(point_w, np.float64).reshape(-1, 3)
+    v = np.ascontiguousarray(var, np.float64).reshape(-1, 9)
+    out = PlaneFit()
+    lib.orc_init_plane.restype = C.c_int
+    lib.orc_init_plane.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_float, C.POINTER(PlaneFit)]
+    lib.orc_init_plane(_p(pw, C.c_double), _p(v, C.c_double), len(pw), float(planer_threshold), C.byref(out))
+    return out
+
+
+def init_plane_batch(point_w, var, offsets, planer_threshold, lib=None):
+    """returns (array of PlaneFit, seconds spent inside the C++ loop)"""
+    lib = lib or load()
+    pw = np.ascontiguousarray(point_w, np.float64).reshape(-1, 3)
+    v = np.ascontiguousarray(var, np.float64).reshape(-1, 9)
+    off = np.ascontiguousarray(offsets, np.int32)
+    out = (PlaneFit * (len(off) - 1))()
+    lib.orc_init_plane_batch.restype = C.c_double
+    lib.orc_init_plane_batch.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_float, C.POINTER(PlaneFit)]
+    secs = lib.orc_init_plane_batch(_p(pw, C.c_double), _p(v, C.c_double), _p(off, C.c_int), len(off) - 1, float(planer_threshold), out)
+    return out, secs
+
+
 def lidar_cfg(c, extR, extT, num_threads=1, deg2rad=0.017453293):
     cfg = LidarCfg()
     cfg.max_iterations, cfg.max_layer = int(c["max_iterations"]), int(c["max_layer"])

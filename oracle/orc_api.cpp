@@ -318,6 +318,40 @@ void orc_calc_body_cov(const double *pb3, float range_inc, float degree_inc, dou
   if (pb_out3) std::memcpy(pb_out3, pb.a, 24);
 }
 
+// VoxelOctoTree::init_plane (src/voxel_map.cpp:55-135) on one group of points — checker of the device-side plane fit.
+// out: the VoxelPlane fields init_plane writes.  Returns is_plane_.
+struct PlaneFitPOD {
+  double center[3], normal[3], y_normal[3], x_normal[3], covariance[9], plane_var[36];
+  float radius, min_eigen_value, mid_eigen_value, max_eigen_value, d;
+  int32_t points_size, is_plane, pad;
+};
+int orc_init_plane(const double *point_w, const double *var9, int n, float planer_threshold, PlaneFitPOD *out) {
+  int id_counter = 0;
+  VoxelOctoTree node(2, 0, 5, 50, planer_threshold, &id_counter);
+  std::vector<MapPoint> pts((size_t)n);
+  for (int i = 0; i < n; i++) {
+    pts[i].point_w = vec3(point_w[3 * i], point_w[3 * i + 1], point_w[3 * i + 2]);
+    std::memcpy(pts[i].var.a, var9 + 9 * (size_t)i, 72);
+  }
+  VoxelPlane pl;
+  node.init_plane(pts, &pl);
+  std::memset(out, 0, sizeof(*out));
+  std::memcpy(out->center, pl.center_.a, 24); std::memcpy(out->normal, pl.normal_.a, 24);
+  std::memcpy(out->y_normal, pl.y_normal_.a, 24); std::memcpy(out->x_normal, pl.x_normal_.a, 24);
+  std::memcpy(out->covariance, pl.covariance_.a, 72); std::memcpy(out->plane_var, pl.plane_var_.a, 288);
+  out->radius = pl.radius_; out->min_eigen_value = pl.min_eigen_value_; out->mid_eigen_value = pl.mid_eigen_value_; out->max_eigen_value = pl.max_eigen_value_;
+  out->d = pl.d_; out->points_size = pl.points_size_; out->is_plane = pl.is_plane_ ? 1 : 0;
+  return out->is_plane;
+}
+
+// the same over many groups (serial like UpdateVoxelMap, src/voxel_map.cpp:609-641); returns the seconds spent (bench.py cpu leg)
+double orc_init_plane_batch(const double *point_w, const double *var9, const int *offsets, int n_groups, float planer_threshold, PlaneFitPOD *out) {
+  const double t0 = omp_get_wtime();
+  for (int g = 0; g < n_groups; g++)
+    orc_init_plane(point_w + 3 * (size_t)offsets[g], var9 + 9 * (size_t)offsets[g], offsets[g + 1] - offsets[g], planer_threshold, out + g);
+  return omp_get_wtime() - t0;
+}
+
 // State algebra (common_lib.h:182-206) and the 19x19 inverse, for known-answer tests.
 void orc_state_boxplus(const StatePOD *s, const double *d19, StatePOD *out) { StatesGroup g; g.from_pod(*s); VState d; std::memcpy(d.a, d19, 152); g += d; g.to_pod(*out); }
 void orc_state_boxminus(const StatePOD *a, const StatePOD *b, double *out19) { StatesGroup ga, gb; ga.from_pod(*a); gb.from_pod(*b); VState d = ga - gb; std::memcpy(out19, d.a, 152); }
