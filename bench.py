@@ -72,11 +72,12 @@ def cpu_baseline(sc, budget_s=20.0):
     om = orc.OracleMap.from_flat(sc.fmap, lib)
     cur, prop = H.states(sc, orc.StatePOD)
     out = {}
-    for threads in (4, 1):
+    ncores = os.cpu_count() or 1
+    for threads in (4, 1, ncores):
         cfg = orc.lidar_cfg(sc.cfg, sc.extR, sc.extT, num_threads=threads)
         orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop, want_points=False)      # warm-up
         secs, evals, runs = 0.0, 0, 0
-        while secs < budget_s * (0.7 if threads == 4 else 0.3) and runs < 40:
+        while secs < budget_s * (0.6 if threads == 4 else 0.2) and runs < 40:
             r = orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop, want_points=False)
             secs += r["seconds"]; evals += len(sc.xyz) * r["n_iters"]; runs += 1
         out[threads] = (evals / secs, runs)
@@ -86,7 +87,7 @@ def cpu_baseline(sc, budget_s=20.0):
     return {"plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1,
             "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
-            "value_1thread": out[1][0], "host_cores": os.cpu_count()}
+            "value_1thread": out[1][0], "value_all_cores": out[ncores][0], "host_cores": ncores}
 
 
 def main():
@@ -189,7 +190,17 @@ def main():
             traffic_note = rec["source"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+    # achievable HBM bandwidth on this box: a device-to-device copy of 1 GiB (read + write counted), SURVEY 8d
+    src_t = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); dst_t = torch.empty_like(src_t)
+    dst_t.copy_(src_t); torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        dst_t.copy_(src_t)
+    ev1.record(); torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src_t.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del src_t, dst_t
+    roofline = {"copy_kernel_GBps": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "k_lidar_residual", "kernel_us": res_us, "bytes_per_launch": LIDAR_BYTES_PER_EVAL * n, "solve_kernel_us": sol_us,
                 "timing": "HIP event pair around every launch on the launching stream (includes the dependent-launch gap; rocprofv3 kernel-only average in profiles/)",
                 "traffic_unit": "bytes/launch", "traffic_note": traffic_note}
@@ -232,6 +243,18 @@ def main():
             ctx.visual_update_async(vcur, vprop, vcfg); rv = ctx.visual_update_fetch()
         extra["visual_full_update_ms"] = (time.perf_counter() - t1) / reps * 1e3
         extra["visual_full_update_steps"] = int(rv.n_steps)
+        # C3 (BASELINE configs[2]): the LiDAR iteration of the 100k-point scan and the visual iteration of the 2k patches in flight together
+        # (two contexts = two streams on this GPU; the two updates of a frame are separate ESIKF updates in the reference, LIVMapper.cpp:370 / vio.cpp:1810)
+        ctx_v = livo2.Context(local_rank)
+        ctx_v.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+        ctx.lidar_iterations_async(cur, prop, cfg, 5); ctx_v.visual_iterations_async(0, vcur, vprop, vcfg, 5); ctx.synchronize(); ctx_v.synchronize()
+        t1 = time.perf_counter()
+        ctx.lidar_iterations_async(cur, prop, cfg, args.steps); ctx_v.visual_iterations_async(0, vcur, vprop, vcfg, args.steps)
+        ctx.synchronize(); ctx_v.synchronize()
+        dtc = time.perf_counter() - t1
+        extra["c3_lidar_plus_visual"] = {"evals_per_s": (n + 64.0 * len(vs.pos)) * args.steps / dtc, "lidar_points": n, "visual_patches": len(vs.pos),
+                                         "ms_per_step": 1e3 * dtc / args.steps, "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
+        ctx_v.close()
         # batched init_plane (plane fit + plane covariance) on the device
         fpw, fvar, foff = plane_fit_groups()
         ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)
@@ -282,7 +305,7 @@ def main():
         bach = LIDAR_BYTES_PER_EVAL * npts / (bres_us * 1e-6) / 1e9
         extra["batched"] = {"frames_per_launch": B, "points_per_launch": npts, "evals_per_s": world * npts * args.steps / tb, "ms_per_step": 1e3 * tb / args.steps,
                             "residual_kernel_us": bres_us, "solve_kernel_us": 1e3 * bms_sol / max(bn_sol, 1),
-                            "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS,
+                            "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS, "frac_of_copy_kernel": bach / copy_gbs,
                                          "kernel": "k_lidar_residual_batch", "bytes_per_launch": LIDAR_BYTES_PER_EVAL * npts},
                             "frames_per_s": world * B * reps_b / tfb, "full_update_iters": [int(r.n_iters) for r in rb],
                             "note": "same kernels as the single-scan path, B independent (scan, state) problems per grid; results bit-identical to B single calls (tests/test_batch_gpu.py)"}
