@@ -84,7 +84,11 @@ def cpu_baseline(sc, budget_s=20.0):
     pw, var, off = plane_fit_groups()
     orc.init_plane_batch(pw, var, off, 0.0025, lib)
     _, fit_s = orc.init_plane_batch(pw, var, off, 0.0025, lib)
-    return {"plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1,
+    from scenarios import synth as _synth
+    rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
+    orc.warp_candidates(rs, lib)
+    warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
+    return {"plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
             "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "value_1thread": out[1][0], "value_all_cores": out[ncores][0], "host_cores": ncores}
@@ -255,6 +259,20 @@ def main():
         extra["c3_lidar_plus_visual"] = {"evals_per_s": (n + 64.0 * len(vs.pos)) * args.steps / dtc, "lidar_points": n, "visual_patches": len(vs.pos),
                                          "ms_per_step": 1e3 * dtc / args.steps, "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
         ctx_v.close()
+        # per-point tail of retrieveFromVisualSparseMap (warp matrix, search level, warpAffine x L, getImagePatch, gates, compaction)
+        rs = synth.retrieve_scenario(seed=21, n_cand=2000)
+        ctx.retrieve_warp(rs, want_patches=False)
+        us, t1 = [], time.perf_counter()
+        for _ in range(5):
+            ro = ctx.retrieve_warp(rs, want_patches=False); us.append(ctx.retrieve_last_kernel_us())
+        t_e2e = (time.perf_counter() - t1) / 5
+        k_us = float(np.median(us))
+        Lr = int(rs.cfg["patch_pyrimid_level"])
+        bytes_per_cand = 200.0 + 81.0 * (Lr + 1) + 256.0 * Lr        # descriptors + (L reference windows + current window, u8) + warped patches written
+        extra["retrieve_warp"] = {"candidates": len(rs.pos), "accepted": ro["n_accepted"], "levels": Lr, "kernel_us": k_us,
+                                  "candidates_per_s_kernel": len(rs.pos) / (k_us * 1e-6), "bytes_per_candidate": bytes_per_cand,
+                                  "achieved_GBps": bytes_per_cand * len(rs.pos) / (k_us * 1e-6) / 1e9, "candidates_per_s_with_h2d_d2h": len(rs.pos) / t_e2e,
+                                  "note": "k_warp_candidates + k_warp_scan + k_warp_gather (vio.cpp:698-767); CPU figure in cpu_baseline.retrieve_candidates_per_s_1thread"}
         # batched init_plane (plane fit + plane covariance) on the device
         fpw, fvar, foff = plane_fit_groups()
         ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
+from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveOut, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
 
 
 class Livo2Error(RuntimeError):
@@ -206,6 +206,38 @@ class Context:
         self.M, self.L = M, L
         self._chk(self.lib.livo2_visual_set_frame(self.h, abi.as_ptr(img, C.c_uint8), w, h, w, abi.as_ptr(pos, C.c_double), abi.as_ptr(warp_patch, C.c_float),
                                                   abi.as_ptr(search_levels, C.c_int32), abi.as_ptr(inv_expo_list, C.c_double), M, L))
+
+    def retrieve_warp(self, rs, want_patches=True):
+        """Per-point tail of retrieveFromVisualSparseMap over a scenario-like object (img, ref_imgs, pos, normal, ref_*, R_cur, t_cur,
+        inv_expo_cur, cam, cfg); leaves the survivors resident as the frame.  Returns a dict of per-candidate arrays + n_accepted."""
+        n, L = len(rs.pos), int(rs.cfg["patch_pyrimid_level"])
+        c = RetrieveCfg()
+        c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = rs.cam["fx"], rs.cam["fy"], rs.cam["cx"], rs.cam["cy"]
+        c.cam.distortion, c.cam.width, c.cam.height = 0, rs.cam["width"], rs.cam["height"]
+        c.R_cur[:] = np.asarray(rs.R_cur, float).ravel().tolist(); c.t_cur[:] = np.asarray(rs.t_cur, float).tolist(); c.inv_expo_cur = float(rs.inv_expo_cur)
+        c.patch_pyrimid_level, c.normal_en, c.ncc_en = L, int(rs.cfg["normal_en"]), int(rs.cfg["ncc_en"])
+        c.ncc_thre, c.outlier_threshold = float(rs.cfg["ncc_thre"]), float(rs.cfg["outlier_threshold"])
+        img = np.ascontiguousarray(rs.img, np.uint8)
+        refs = np.ascontiguousarray(rs.ref_imgs, np.uint8)
+        keep = dict(pos=_f64(rs.pos), normal=_f64(rs.normal), px=_f64(rs.ref_px), f=_f64(rs.ref_f), R=_f64(rs.ref_R), t=_f64(rs.ref_t), ie=_f64(rs.ref_inv_expo),
+                    idx=np.ascontiguousarray(rs.ref_img_idx, np.int32), lvl=np.ascontiguousarray(rs.ref_level, np.int32))
+        cand = RetrieveCandidates(n, 0, abi.as_ptr(keep["pos"], C.c_double), abi.as_ptr(keep["normal"], C.c_double), abi.as_ptr(keep["idx"], C.c_int32),
+                                  abi.as_ptr(keep["px"], C.c_double), abi.as_ptr(keep["f"], C.c_double), abi.as_ptr(keep["R"], C.c_double),
+                                  abi.as_ptr(keep["t"], C.c_double), abi.as_ptr(keep["lvl"], C.c_int32), abi.as_ptr(keep["ie"], C.c_double))
+        res = dict(accepted=np.zeros(n, np.int32), search_level=np.zeros(n, np.int32), error=np.zeros(n, np.float32), ncc=np.zeros(n), A=np.zeros((n, 4)),
+                   patch_wrap=np.zeros((n, L, 64), np.float32) if want_patches else None)
+        out = RetrieveOut(abi.as_ptr(res["accepted"], C.c_int32), abi.as_ptr(res["search_level"], C.c_int32), abi.as_ptr(res["error"], C.c_float),
+                          abi.as_ptr(res["ncc"], C.c_double), abi.as_ptr(res["A"], C.c_double),
+                          abi.as_ptr(res["patch_wrap"], C.c_float) if want_patches else None)
+        na = C.c_int32(0)
+        self._chk(self.lib.livo2_visual_retrieve_warp(self.h, abi.as_ptr(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1], abi.as_ptr(refs, C.c_uint8),
+                                                      int(refs.shape[0]), C.byref(cand), C.byref(c), C.byref(out), C.byref(na)))
+        res["n_accepted"] = int(na.value)
+        self.M, self.L = int(na.value), L
+        return res
+
+    def retrieve_last_kernel_us(self):
+        return float(self.lib.livo2_visual_retrieve_last_kernel_us(self.h))
 
     def set_reference(self, ref_imgs, ref_img_idx, ref_px, ref_f, ref_R, ref_pos):
         """inverse-compositional variant: reference patches of the points uploaded by set_frame"""

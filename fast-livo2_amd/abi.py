@@ -113,6 +113,22 @@ class Cam(C.Structure):
                 ("distortion", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("pad", C.c_int32)]
 
 
+class RetrieveCfg(C.Structure):
+    _fields_ = [("cam", Cam), ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("inv_expo_cur", C.c_double), ("patch_pyrimid_level", C.c_int32),
+                ("normal_en", C.c_int32), ("ncc_en", C.c_int32), ("pad", C.c_int32), ("ncc_thre", C.c_double), ("outlier_threshold", C.c_double)]
+
+
+class RetrieveCandidates(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pad", C.c_int32), ("pos", C.POINTER(C.c_double)), ("normal", C.POINTER(C.c_double)), ("ref_img_idx", C.POINTER(C.c_int32)),
+                ("ref_px", C.POINTER(C.c_double)), ("ref_f", C.POINTER(C.c_double)), ("ref_R", C.POINTER(C.c_double)), ("ref_t", C.POINTER(C.c_double)), ("ref_level", C.POINTER(C.c_int32)),
+                ("ref_inv_expo", C.POINTER(C.c_double))]
+
+
+class RetrieveOut(C.Structure):
+    _fields_ = [("accepted", C.POINTER(C.c_int32)), ("search_level", C.POINTER(C.c_int32)), ("error", C.POINTER(C.c_float)), ("ncc", C.POINTER(C.c_double)),
+                ("A_cur_ref", C.POINTER(C.c_double)), ("patch_wrap", C.POINTER(C.c_float))]
+
+
 class VisualCfg(C.Structure):
     _fields_ = [("cam", Cam), ("Rcl", C.c_double * 9), ("Pcl", C.c_double * 3), ("extR", C.c_double * 9), ("extT", C.c_double * 3),
                 ("img_point_cov", C.c_double), ("patch_pyrimid_level", C.c_int32), ("max_iterations", C.c_int32),
@@ -164,6 +180,9 @@ SIGNATURES = {
     "livo2_visual_set_frame": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32),
                                          _P(C.c_double), C.c_int32, C.c_int32]),
     "livo2_visual_set_reference": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, _P(C.c_int32), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "livo2_visual_retrieve_warp": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_uint8), C.c_int32, _P(RetrieveCandidates), _P(RetrieveCfg),
+                                             _P(RetrieveOut), _P(C.c_int32)]),
+    "livo2_visual_retrieve_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_visual_iterate": (C.c_int, [_CTX, C.c_int32, _P(State), _P(VisualCfg), _P(VisualSums), _P(C.c_float), _P(C.c_double), _P(C.c_double)]),
     "livo2_visual_update": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg), _P(VisualResult), _P(C.c_float)]),
     "livo2_visual_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg)]),

@@ -7,6 +7,7 @@
 #include "lidar_kernels.hpp"
 #include "visual_inverse_kernels.hpp"
 #include "map_kernels.hpp"
+#include "retrieve_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -46,6 +47,10 @@ struct livo2_ctx {
   int32_t *d_fit_off = nullptr, *d_fit_idx = nullptr, *d_fit_list = nullptr; size_t fit_off_cap = 0, fit_idx_cap = 0, fit_list_cap = 0;
   livo2_plane_fit *d_fit_out = nullptr; size_t fit_out_cap = 0;
   double fit_kernel_us = 0.0;
+  // retrieval candidates (N2)
+  int cand_cap = 0; double *d_c_pos = nullptr, *d_c_normal = nullptr, *d_c_px = nullptr, *d_c_f = nullptr, *d_c_R = nullptr, *d_c_t = nullptr, *d_c_ie = nullptr, *d_c_ncc = nullptr, *d_c_A = nullptr;
+  int32_t *d_c_idx = nullptr, *d_c_lvl = nullptr, *d_c_acc = nullptr, *d_c_sl = nullptr, *d_c_slot = nullptr, *d_c_count = nullptr; float *d_c_err = nullptr, *d_c_patch = nullptr; size_t c_patch_cap = 0;
+  double retrieve_kernel_us = 0.0;
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -327,7 +332,9 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg, ctx->d_ref_imgs, ctx->d_ref_idx, ctx->d_ref_px, ctx->d_ref_f, ctx->d_ref_R, ctx->d_ref_pos,
                  ctx->d_gref, ctx->d_mref, ctx->bd_xyz_aos, ctx->bd_x, ctx->bd_y, ctx->bd_z, ctx->bd_cb, ctx->bd_keys, ctx->bd_keys2, ctx->bd_idx, ctx->bd_perm, ctx->bd_partials,
                  ctx->bd_block_frame, ctx->bd_ctl, ctx->bd_entries, ctx->bd_in, ctx->bd_results, ctx->d_plane_internal, ctx->d_plane_cand_pos,
-                 ctx->d_fit_pw, ctx->d_fit_var, ctx->d_fit_off, ctx->d_fit_idx, ctx->d_fit_out, ctx->d_fit_list};
+                 ctx->d_fit_pw, ctx->d_fit_var, ctx->d_fit_off, ctx->d_fit_idx, ctx->d_fit_out, ctx->d_fit_list,
+                 ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl, ctx->d_c_acc,
+                 ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -936,6 +943,109 @@ int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t 
   ctx->has_ref = true;
   return LIVO2_OK;
 }
+
+// ---- visual sub-map retrieval, per-point tail -----------------------------------------------------------------------------------
+int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const uint8_t *ref_imgs, int32_t n_ref,
+                               const livo2_retrieve_candidates *cand, const livo2_retrieve_cfg *cfg, livo2_retrieve_out *out, int32_t *n_accepted) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!img || width <= 0 || height <= 0 || stride < width) return fail(ctx, LIVO2_ERR_INVALID, "bad image");
+  if (!cand || !cfg || !n_accepted) return fail(ctx, LIVO2_ERR_INVALID, "cand / cfg / n_accepted is NULL");
+  const int n = cand->n, L = cfg->patch_pyrimid_level;
+  if (n < 0 || L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad candidate count or patch_pyrimid_level");
+  if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "retrieval needs a zero-distortion camera");
+  if (cfg->cam.width != width || cfg->cam.height != height) return fail(ctx, LIVO2_ERR_INVALID, "camera size differs from the image");
+  if (n > 0 && (!ref_imgs || n_ref < 1 || !cand->pos || !cand->normal || !cand->ref_img_idx || !cand->ref_px || !cand->ref_f || !cand->ref_R || !cand->ref_t ||
+                !cand->ref_level || !cand->ref_inv_expo)) return fail(ctx, LIVO2_ERR_INVALID, "bad candidate arrays");
+  for (int i = 0; i < n; i++) {
+    if (cand->ref_img_idx[i] < 0 || cand->ref_img_idx[i] >= n_ref) return fail(ctx, LIVO2_ERR_INVALID, "ref_img_idx out of range");
+    if (cand->ref_level[i] < 0 || cand->ref_level[i] > 8) return fail(ctx, LIVO2_ERR_RANGE, "ref_level out of [0,8]");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t img_bytes = (size_t)stride * height;
+  int rc = ensure(ctx, ctx->d_img, ctx->img_cap, img_bytes); if (rc) return rc;
+  if (n > 0) { rc = ensure(ctx, ctx->d_ref_imgs, ctx->ref_img_cap, img_bytes * n_ref); if (rc) return rc; }
+  if (n > ctx->cand_cap) {
+    void *old[] = {ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl,
+                   ctx->d_c_acc, ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_err};
+    for (void *p : old) if (p) { hipError_t e = hipFree(p); (void)e; }
+    const size_t cap = (size_t)std::max(n, 512);
+    HIPCHK(hipMalloc((void **)&ctx->d_c_pos, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_normal, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_px, cap * 16));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_f, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_R, cap * 72)); HIPCHK(hipMalloc((void **)&ctx->d_c_t, cap * 24));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_ie, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_ncc, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_A, cap * 32));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_lvl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_acc, cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_sl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_slot, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_err, cap * 4));
+    ctx->cand_cap = (int)cap;
+  }
+  if (!ctx->d_c_count) HIPCHK(hipMalloc((void **)&ctx->d_c_count, 64));
+  rc = ensure(ctx, ctx->d_c_patch, ctx->c_patch_cap, std::max((size_t)n * L * 64, (size_t)64)); if (rc) return rc;
+  // the frame arrays must be able to hold every candidate
+  if (n > ctx->M_cap) {
+    hipError_t e;
+    if (ctx->d_pos) { e = hipFree(ctx->d_pos); e = hipFree(ctx->d_invexpo); e = hipFree(ctx->d_search); e = hipFree(ctx->d_errors); (void)e; }
+    int cap = std::max(n, 512);
+    HIPCHK(hipMalloc((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_invexpo, (size_t)cap * 8));
+    HIPCHK(hipMalloc((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_errors, (size_t)cap * 4));
+    ctx->M_cap = cap;
+  }
+  rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)n * L * 64, (size_t)64)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)visual_grid(std::max(n, 1)) * VIS_PSTRIDE, (size_t)64)); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  int32_t count = 0;
+  ctx->retrieve_kernel_us = 0.0;
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_pos, cand->pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_normal, cand->normal, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_px, cand->ref_px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_f, cand->ref_f, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_R, cand->ref_R, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_t, cand->ref_t, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_ie, cand->ref_inv_expo, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_idx, cand->ref_img_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_c_lvl, cand->ref_level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    WarpKernelArgs a{};
+    a.img = ctx->d_img; a.ref_imgs = ctx->d_ref_imgs; a.width = width; a.height = height; a.stride = stride; a.n = n; a.L = L;
+    a.normal_en = cfg->normal_en; a.ncc_en = cfg->ncc_en; a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
+    a.inv_expo_cur = cfg->inv_expo_cur; a.ncc_thre = cfg->ncc_thre; a.outlier_threshold = cfg->outlier_threshold;
+    std::memcpy(a.R_cur, cfg->R_cur, 72); std::memcpy(a.t_cur, cfg->t_cur, 24);
+    a.pos = ctx->d_c_pos; a.normal = ctx->d_c_normal; a.ref_px = ctx->d_c_px; a.ref_f = ctx->d_c_f; a.ref_R = ctx->d_c_R; a.ref_t = ctx->d_c_t; a.ref_inv_expo = ctx->d_c_ie;
+    a.ref_img_idx = ctx->d_c_idx; a.ref_level = ctx->d_c_lvl; a.patch_all = ctx->d_c_patch; a.accepted = ctx->d_c_acc; a.search_level = ctx->d_c_sl;
+    a.error = ctx->d_c_err; a.ncc = ctx->d_c_ncc; a.A = ctx->d_c_A;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+    const int grid = (n + WARP_WAVES - 1) / WARP_WAVES;
+    hipLaunchKernelGGL(k_warp_candidates, dim3(grid), dim3(WARP_WAVES * LIVO2_WAVE), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_warp_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_c_acc, n, ctx->d_c_slot, ctx->d_c_count);
+    hipLaunchKernelGGL(k_warp_gather, dim3(grid), dim3(WARP_WAVES * LIVO2_WAVE), 0, ctx->stream, ctx->d_c_slot, n, L, ctx->d_c_patch, ctx->d_c_pos, ctx->d_c_sl,
+                       ctx->d_c_ie, ctx->d_warp, ctx->d_pos, ctx->d_search, ctx->d_invexpo);
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&count, ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out) {
+      if (out->accepted) HIPCHK(hipMemcpyAsync(out->accepted, ctx->d_c_acc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->search_level) HIPCHK(hipMemcpyAsync(out->search_level, ctx->d_c_sl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->error) HIPCHK(hipMemcpyAsync(out->error, ctx->d_c_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->ncc) HIPCHK(hipMemcpyAsync(out->ncc, ctx->d_c_ncc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->A_cur_ref) HIPCHK(hipMemcpyAsync(out->A_cur_ref, ctx->d_c_A, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->patch_wrap) HIPCHK(hipMemcpyAsync(out->patch_wrap, ctx->d_c_patch, (size_t)n * L * 256, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    ctx->retrieve_kernel_us = 1e3 * ms;
+    HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  } else {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  *n_accepted = count;
+  ctx->width = width; ctx->height = height; ctx->stride = stride; ctx->M = count; ctx->L = L;
+  ctx->has_frame = true;
+  ctx->has_ref = false;
+  return LIVO2_OK;
+}
+double livo2_visual_retrieve_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->retrieve_kernel_us : 0.0; }
 
 static int visual_ready(livo2_ctx *ctx, const livo2_state *a, const livo2_state *b, const livo2_visual_cfg *cfg) {
   if (!ctx) return LIVO2_ERR_INVALID;

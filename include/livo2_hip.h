@@ -239,6 +239,45 @@ int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, in
 int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t n_ref, const int32_t *ref_img_idx, const double *ref_px,
                                const double *ref_f, const double *ref_R, const double *ref_pos);
 
+/* ---- visual sub-map retrieval, per-point tail ----------------------------------------------------------------------
+ * VIOManager::retrieveFromVisualSparseMap keeps its grid / voxel / depth-continuity selection and reference-patch choice
+ * (src/vio.cpp:352-698); for the n points it selected, this call does what the loop body does next (src/vio.cpp:698-767):
+ * affine warp matrix (getWarpMatrixAffineHomography if normal_en, else getWarpMatrixAffine), getBestSearchLevel, warpAffine for
+ * patch_pyrimid_level levels, getImagePatch of the current image, photometric error + optional NCC gates — and leaves the SURVIVORS,
+ * in candidate order, resident as the frame of the next livo2_visual_update (it replaces livo2_visual_set_frame: pos, warp_patch,
+ * search_levels, inv_expo_list are produced on the device).  Per candidate: pos = pt->pos_, normal = pt->normal_, and of its ref_ftr
+ * (include/feature.h:19-54): ref_img_idx (index into ref_imgs, images of the current image's size), ref_px = px_, ref_f = f_,
+ * ref_R / ref_t = T_f_w_ rotation (row-major) / translation, ref_level = level_, ref_inv_expo = inv_expo_time_.
+ * Outputs (each may be NULL): accepted[n] (1 = appended to visual_submap), search_level[n], error[n] (the float photometric error),
+ * ncc[n], A_cur_ref[n][4] row-major, patch_wrap[n][L][64] (all candidates, for inspection).  *n_accepted = survivors.
+ * cam.distortion must be 0 (cam2world of a distorted vikit camera is not restated).  A candidate whose 9x9 current-image window
+ * leaves the image is rejected with error = +inf (the reference reads out of bounds there). */
+typedef struct livo2_retrieve_cfg {
+  livo2_cam cam;
+  double R_cur[9], t_cur[3];    /* new_frame_->T_f_w_ (frame from world), row-major rotation */
+  double inv_expo_cur;          /* state->inv_expo_time */
+  int32_t patch_pyrimid_level, normal_en, ncc_en, pad;
+  double ncc_thre, outlier_threshold;
+} livo2_retrieve_cfg;
+typedef struct livo2_retrieve_candidates {
+  int32_t n, pad;
+  const double *pos, *normal;
+  const int32_t *ref_img_idx;
+  const double *ref_px, *ref_f, *ref_R, *ref_t;
+  const int32_t *ref_level;
+  const double *ref_inv_expo;
+} livo2_retrieve_candidates;
+typedef struct livo2_retrieve_out {
+  int32_t *accepted, *search_level;
+  float *error;
+  double *ncc, *A_cur_ref;
+  float *patch_wrap;
+} livo2_retrieve_out;
+int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const uint8_t *ref_imgs, int32_t n_ref,
+                               const livo2_retrieve_candidates *cand, const livo2_retrieve_cfg *cfg, livo2_retrieve_out *out, int32_t *n_accepted);
+/* kernel time (k_warp_candidates + scan + gather) of the last call in microseconds (HIP events on the ctx stream) */
+double livo2_visual_retrieve_last_kernel_us(const livo2_ctx *ctx);
+
 typedef struct livo2_visual_sums {
   double HtH[49];               /* H_sub^T H_sub, row-major 7x7 (vio.cpp:1660); row/col 6 zero if !exposure_estimate_en */
   double Htz[7];                /* H_sub^T z (vio.cpp:1662) */

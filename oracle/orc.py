@@ -174,6 +174,36 @@ def init_plane_batch(point_w, var, offsets, planer_threshold, lib=None):
     return out, secs
 
 
+class WarpCfg(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("width", C.c_int32), ("height", C.c_int32),
+                ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("inv_expo_cur", C.c_double), ("patch_pyrimid_level", C.c_int32),
+                ("normal_en", C.c_int32), ("ncc_en", C.c_int32), ("pad", C.c_int32), ("ncc_thre", C.c_double), ("outlier_threshold", C.c_double)]
+
+
+def warp_candidates(rs, lib=None):
+    """Per-point tail of retrieveFromVisualSparseMap over a scenarios.synth.RetrieveScenario; returns a dict of per-candidate arrays."""
+    lib = lib or load()
+    c = WarpCfg()
+    c.fx, c.fy, c.cx, c.cy, c.width, c.height = rs.cam["fx"], rs.cam["fy"], rs.cam["cx"], rs.cam["cy"], rs.cam["width"], rs.cam["height"]
+    c.R_cur[:] = rs.R_cur.ravel().tolist(); c.t_cur[:] = rs.t_cur.tolist(); c.inv_expo_cur = rs.inv_expo_cur
+    c.patch_pyrimid_level, c.normal_en, c.ncc_en = int(rs.cfg["patch_pyrimid_level"]), int(rs.cfg["normal_en"]), int(rs.cfg["ncc_en"])
+    c.ncc_thre, c.outlier_threshold = float(rs.cfg["ncc_thre"]), float(rs.cfg["outlier_threshold"])
+    n, L = len(rs.pos), int(rs.cfg["patch_pyrimid_level"])
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)
+    pos, normal, px, f, R, t, ie = f64(rs.pos), f64(rs.normal), f64(rs.ref_px), f64(rs.ref_f), f64(rs.ref_R), f64(rs.ref_t), f64(rs.ref_inv_expo)
+    idx, lvl = np.ascontiguousarray(rs.ref_img_idx, np.int32), np.ascontiguousarray(rs.ref_level, np.int32)
+    img, refs = np.ascontiguousarray(rs.img, np.uint8), np.ascontiguousarray(rs.ref_imgs, np.uint8)
+    out = dict(accepted=np.zeros(n, np.int32), search_level=np.zeros(n, np.int32), error=np.zeros(n, np.float32), ncc=np.zeros(n), A=np.zeros((n, 4)),
+               patch_wrap=np.zeros((n, L, 64), np.float32))
+    lib.orc_warp_candidates.restype = C.c_double
+    lib.orc_warp_candidates.argtypes = [C.POINTER(WarpCfg), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int] + [C.c_void_p] * 15
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out["seconds"] = lib.orc_warp_candidates(C.byref(c), _p(img, C.c_uint8), _p(refs, C.c_uint8), n, vp(pos), vp(normal), vp(idx), vp(px), vp(f), vp(R), vp(t),
+                                             vp(lvl), vp(ie), vp(out["accepted"]), vp(out["search_level"]), vp(out["error"]), vp(out["ncc"]), vp(out["A"]),
+                                             vp(out["patch_wrap"]))
+    return out
+
+
 def lidar_cfg(c, extR, extT, num_threads=1, deg2rad=0.017453293):
     cfg = LidarCfg()
     cfg.max_iterations, cfg.max_layer = int(c["max_iterations"]), int(c["max_layer"])

@@ -9,6 +9,7 @@
 //   planes: normal f64[P][3], center f64[P][3], plane_var f64[P][36], d f32[P], radius f32[P]
 #include "orc_lidar.hpp"
 #include "orc_visual.hpp"
+#include "orc_warp.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -349,6 +350,44 @@ double orc_init_plane_batch(const double *point_w, const double *var9, const int
   const double t0 = omp_get_wtime();
   for (int g = 0; g < n_groups; g++)
     orc_init_plane(point_w + 3 * (size_t)offsets[g], var9 + 9 * (size_t)offsets[g], offsets[g + 1] - offsets[g], planer_threshold, out + g);
+  return omp_get_wtime() - t0;
+}
+
+// Per-point tail of retrieveFromVisualSparseMap (src/vio.cpp:698-767) for n candidates (orc_warp.hpp).  Arrays are per candidate;
+// ref_imgs holds n_ref images of cam.width x cam.height.  Outputs per candidate: accepted, search_level, error, ncc, A_cur_ref, and
+// patch_wrap [n][L*64]; the survivors in candidate order are what the reference appends to visual_submap.  Returns seconds spent.
+struct orc_warp_cfg {
+  double fx, fy, cx, cy; int32_t width, height;
+  double R_cur[9], t_cur[3], inv_expo_cur;
+  int32_t patch_pyrimid_level, normal_en, ncc_en, pad;
+  double ncc_thre, outlier_threshold;
+};
+double orc_warp_candidates(const orc_warp_cfg *c, const uint8_t *img, const uint8_t *ref_imgs, int n, const double *pos, const double *normal,
+                           const int32_t *ref_img_idx, const double *ref_px, const double *ref_f, const double *ref_R, const double *ref_t,
+                           const int32_t *ref_level, const double *ref_inv_expo, int32_t *accepted, int32_t *search_level, float *error, double *ncc,
+                           double *A4, float *patch_wrap) {
+  WarpCfg cfg;
+  cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = 0; cfg.cam.width = c->width; cfg.cam.height = c->height;
+  for (int k = 0; k < 5; k++) cfg.cam.d[k] = 0;
+  std::memcpy(cfg.R_cur.a, c->R_cur, 72); std::memcpy(cfg.t_cur.a, c->t_cur, 24);
+  cfg.inv_expo_cur = c->inv_expo_cur; cfg.patch_pyrimid_level = c->patch_pyrimid_level; cfg.normal_en = c->normal_en; cfg.ncc_en = c->ncc_en;
+  cfg.ncc_thre = c->ncc_thre; cfg.outlier_threshold = c->outlier_threshold;
+  const size_t img_bytes = (size_t)c->width * c->height;
+  const int L = c->patch_pyrimid_level;
+  const double t0 = omp_get_wtime();
+  for (int i = 0; i < n; i++) {
+    WarpCand w;
+    w.pos = vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); w.normal = vec3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+    w.img_ref = ref_imgs + img_bytes * ref_img_idx[i];
+    w.px_ref[0] = ref_px[2 * i]; w.px_ref[1] = ref_px[2 * i + 1];
+    w.f_ref = vec3(ref_f[3 * i], ref_f[3 * i + 1], ref_f[3 * i + 2]);
+    std::memcpy(w.R_ref.a, ref_R + 9 * (size_t)i, 72); w.t_ref = vec3(ref_t[3 * i], ref_t[3 * i + 1], ref_t[3 * i + 2]);
+    w.level_ref = ref_level[i]; w.inv_expo_ref = ref_inv_expo[i];
+    WarpOut o;
+    warp_candidate(cfg, img, w, patch_wrap + (size_t)i * L * 64, o);
+    accepted[i] = o.accepted; search_level[i] = o.search_level; error[i] = o.error; ncc[i] = o.ncc;
+    std::memcpy(A4 + 4 * (size_t)i, o.A, 32);
+  }
   return omp_get_wtime() - t0;
 }
 

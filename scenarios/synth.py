@@ -484,3 +484,68 @@ def visual_inverse_scenario(seed=5, n_patches=300, L=4, n_ref=2, **kw):
             vs.warp_patch[i, lvl] = (cur + rng.normal(0, 1.0, (8, 8))).astype(np.float32).ravel()
     vs.tau_prior = 1.0
     return vs
+
+
+# ---- candidates of retrieveFromVisualSparseMap's per-point tail (reference src/vio.cpp:598-767) -----------------------
+@dataclass
+class RetrieveScenario:
+    img: np.ndarray            # current image u8 [H,W]
+    ref_imgs: np.ndarray       # u8 [n_ref,H,W]
+    pos: np.ndarray            # [n,3] pt->pos_
+    normal: np.ndarray         # [n,3] pt->normal_
+    ref_img_idx: np.ndarray    # [n] int32
+    ref_px: np.ndarray         # [n,2] ref_ftr->px_
+    ref_f: np.ndarray          # [n,3] ref_ftr->f_
+    ref_R: np.ndarray          # [n,9] ref_ftr->T_f_w_ rotation
+    ref_t: np.ndarray          # [n,3] ref_ftr->T_f_w_ translation
+    ref_level: np.ndarray      # [n] int32
+    ref_inv_expo: np.ndarray   # [n]
+    R_cur: np.ndarray          # new_frame_->T_f_w_
+    t_cur: np.ndarray
+    inv_expo_cur: float
+    cam: dict
+    cfg: dict
+
+
+def retrieve_scenario(seed=21, n_cand=2000, n_ref=3, L=4, normal_en=True, ncc_en=False, outlier_threshold=1000.0, ncc_thre=0.5):
+    """Reference frames look at the same synthetic texture from poses near the current one (the same image is reused as their picture),
+    so most warps are near-identity and pass the photometric gate; a share of candidates gets a much closer reference camera
+    (det A > 3: search level 1-2), a strongly mis-registered reference (rejected by the gate) or a reference pixel near the border
+    (out-of-image samples = 0)."""
+    rng = np.random.default_rng(seed)
+    cam = dict(AVIA["cam"])
+    cfg = dict(AVIA["vio"])
+    cfg.update(patch_pyrimid_level=L, normal_en=int(normal_en), ncc_en=int(ncc_en), outlier_threshold=float(outlier_threshold), ncc_thre=float(ncc_thre))
+    img = make_image(rng, cam["width"], cam["height"], sigma=7.0)      # smooth texture: a 1-2 px mis-registration changes a patch only mildly
+    ref_imgs = np.stack([img] + [make_image(rng, cam["width"], cam["height"], sigma=7.0) for _ in range(n_ref - 1)])
+    R_cw = rot_from_rpy(0.03, -0.02, 0.4)
+    t_cw = np.array([0.3, -0.2, 0.1])
+    # points seen by the current camera, comfortably inside the image
+    u = rng.uniform(40, cam["width"] - 41, n_cand)
+    v = rng.uniform(40, cam["height"] - 41, n_cand)
+    depth = rng.uniform(2.0, 12.0, n_cand)
+    p_c = np.stack([(u - cam["cx"]) / cam["fx"] * depth, (v - cam["cy"]) / cam["fy"] * depth, depth], 1)
+    pos = (p_c - t_cw) @ R_cw                                  # R^T (p_c - t)
+    normal_c = -p_c / np.linalg.norm(p_c, axis=1, keepdims=True) + rng.normal(0, 0.2, (n_cand, 3))     # roughly facing the camera
+    normal_c /= np.linalg.norm(normal_c, axis=1, keepdims=True)
+    normal = normal_c @ R_cw
+    kind = rng.choice(4, n_cand, p=[0.7, 0.12, 0.1, 0.08])    # 0 near-identity, 1 close-up reference, 2 mis-registered, 3 border pixel
+    ref_R = np.zeros((n_cand, 9)); ref_t = np.zeros((n_cand, 3)); ref_px = np.zeros((n_cand, 2)); ref_f = np.zeros((n_cand, 3))
+    for i in range(n_cand):
+        rot_s, tr_s = (0.05, 0.004) if kind[i] != 2 else (3.0, 0.4)
+        dR = so3_exp(rng.normal(0, np.deg2rad(rot_s), 3))
+        dt = rng.normal(0, tr_s, 3)
+        if kind[i] == 1:
+            dt = dt + np.array([0, 0, -0.55 * depth[i]])       # reference camera at less than half the distance
+        R_rw = dR @ R_cw
+        t_rw = dR @ t_cw + dt
+        pr = R_rw @ pos[i] + t_rw
+        px = np.array([cam["fx"] * pr[0] / pr[2] + cam["cx"], cam["fy"] * pr[1] / pr[2] + cam["cy"]])
+        if kind[i] == 3:
+            px = np.array([rng.choice([3.2, cam["width"] - 4.7]), rng.uniform(20, cam["height"] - 20)])
+        ref_R[i] = R_rw.ravel(); ref_t[i] = t_rw; ref_px[i] = px
+        f = np.array([(px[0] - cam["cx"]) / cam["fx"], (px[1] - cam["cy"]) / cam["fy"], 1.0])
+        ref_f[i] = f / np.linalg.norm(f)
+    idx = np.where(kind == 2, rng.integers(1, n_ref, n_cand), 0).astype(np.int32) if n_ref > 1 else np.zeros(n_cand, np.int32)
+    return RetrieveScenario(img, ref_imgs, pos, normal, idx, ref_px, ref_f, ref_R, ref_t, rng.integers(0, 3, n_cand).astype(np.int32),
+                            rng.uniform(0.9, 1.1, n_cand), R_cw, t_cw, 1.02, cam, cfg)
