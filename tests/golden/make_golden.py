@@ -56,7 +56,29 @@ def visual():
         out_errors=full["errors"])
 
 
+def plane_fit():
+    from tests import plane_groups as PG
+    pw, var, off, kinds = PG.make_groups(seed=41, n_groups=24, big=(300,))
+    out, _ = orc.init_plane_batch(pw, var, off, 0.0025)
+    pick = lambda name, n: np.array([list(getattr(o, name)) for o in out]).reshape(len(out), n)
+    np.savez_compressed(os.path.join(OUT, "plane_fit_small.npz"), pw=pw, var=var, off=off, thr=0.0025, center=pick("center", 3), normal=pick("normal", 3),
+                        covariance=pick("covariance", 9), plane_var=pick("plane_var", 36), radius=np.array([o.radius for o in out], np.float32),
+                        d=np.array([o.d for o in out], np.float32), eig=np.array([[o.min_eigen_value, o.mid_eigen_value, o.max_eigen_value] for o in out], np.float32),
+                        is_plane=np.array([o.is_plane for o in out], np.int32))
+
+
+def retrieve():
+    rs = synth.retrieve_scenario(seed=42, n_cand=40, n_ref=2)
+    # (the 640x512 images are not stored: the fixture keeps the scenario seed and an image checksum)
+    o = orc.warp_candidates(rs)
+    np.savez_compressed(os.path.join(OUT, "retrieve_small.npz"), seed=42, n_cand=40, n_ref=2, img_sum=int(rs.img.astype(np.int64).sum()),
+                        accepted=o["accepted"], search_level=o["search_level"], error=o["error"], ncc=o["ncc"], A=o["A"],
+                        patch_wrap_l0=o["patch_wrap"][:, 0], patch_wrap_sum=o["patch_wrap"].astype(np.float64).sum(axis=(1, 2)))
+
+
 if __name__ == "__main__":
+    plane_fit()
+    retrieve()
     lidar()
     visual()
     for f in ("lidar_small.npz", "visual_small.npz"):
