@@ -1,6 +1,7 @@
 // See livo2_host.hpp.  Pure data movement between the reference-shaped containers and the C ABI.
 #include "livo2_host.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 namespace livo2 {
@@ -65,6 +66,33 @@ void VoxelMapManager::RefreshPlanes(const std::vector<const VoxelPlane *> &plane
   dev_.check(livo2_map_update_planes(dev_.ctx(), idx.data(), (int32_t)idx.size(), n.data(), c.data(), pv.data(), d.data(), r.data()));
 }
 
+void VoxelMapManager::FitPlanes(const std::vector<VoxelOctoTree *> &voxels) {
+  const int G = (int)voxels.size();
+  if (G == 0) return;
+  std::vector<double> pw, var; std::vector<int32_t> off{0}, pidx(G, -1);
+  for (int g = 0; g < G; g++) {
+    for (const pointWithVar &pv : voxels[g]->temp_points_) { pw.insert(pw.end(), pv.point_w.begin(), pv.point_w.end()); var.insert(var.end(), pv.var.begin(), pv.var.end()); }
+    off.push_back((int32_t)(pw.size() / 3));
+    if (!map_dirty_) { auto it = plane_index_.find(voxels[g]->plane_ptr_); if (it != plane_index_.end()) pidx[g] = it->second; }
+  }
+  std::vector<livo2_plane_fit> fit(G);
+  // all voxels of one tree share planer_threshold_ (reference include/voxel_map.h:147)
+  dev_.check(livo2_plane_fit_batch(dev_.ctx(), pw.data(), var.data(), off.data(), G, voxels[0]->planer_threshold_, map_dirty_ ? nullptr : pidx.data(), fit.data()));
+  for (int g = 0; g < G; g++) {
+    VoxelPlane *p = voxels[g]->plane_ptr_;
+    const livo2_plane_fit &f = fit[g];
+    const bool was_plane = p->is_plane_;
+    std::memcpy(p->center_.data(), f.center, 24); std::memcpy(p->covariance_.data(), f.covariance, 72); p->points_size_ = f.points_size;
+    std::memcpy(p->plane_var_.data(), f.plane_var, 288); std::memcpy(p->normal_.data(), f.normal, 24); p->radius_ = f.radius;
+    if (f.is_plane) {
+      std::memcpy(p->y_normal_.data(), f.y_normal, 24); std::memcpy(p->x_normal_.data(), f.x_normal, 24);
+      p->min_eigen_value_ = f.min_eigen_value; p->mid_eigen_value_ = f.mid_eigen_value; p->max_eigen_value_ = f.max_eigen_value; p->d_ = f.d;
+    }
+    p->is_plane_ = f.is_plane != 0; p->is_update_ = true;
+    if (p->is_plane_ != was_plane || (p->is_plane_ && pidx[g] < 0)) map_dirty_ = true;      // the snapshot's shape changed: re-flatten before the next update
+  }
+}
+
 void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   if (map_dirty_) FlattenAndUpload();
   const int n = (int)feats_down_body_.size();
@@ -117,17 +145,54 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   effct_feat_num_ = (int)ptpl_list_.size();
 }
 
+void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands) {
+  const int n = (int)cands.size(), L = patch_pyrimid_level;
+  std::vector<double> pos((size_t)n * 3), nrm((size_t)n * 3), px((size_t)n * 2), f((size_t)n * 3), R((size_t)n * 9), t((size_t)n * 3), ie(n);
+  std::vector<int32_t> idx(n), lvl(n);
+  std::vector<const uint8_t *> imgs;
+  for (int i = 0; i < n; i++) {
+    const VisualPoint *pt = cands[i].pt; const Feature *ft = cands[i].ref_ftr;
+    size_t k = 0; while (k < imgs.size() && imgs[k] != ft->img_) k++;
+    if (k == imgs.size()) imgs.push_back(ft->img_);
+    idx[i] = (int32_t)k; lvl[i] = ft->level_; ie[i] = ft->inv_expo_time_;
+    std::memcpy(&pos[(size_t)i * 3], pt->pos_.data(), 24); std::memcpy(&nrm[(size_t)i * 3], pt->normal_.data(), 24);
+    std::memcpy(&px[(size_t)i * 2], ft->px_.data(), 16); std::memcpy(&f[(size_t)i * 3], ft->f_.data(), 24);
+    std::memcpy(&R[(size_t)i * 9], ft->R_f_w.data(), 72); std::memcpy(&t[(size_t)i * 3], ft->t_f_w.data(), 24);
+  }
+  const size_t bytes = (size_t)img.step * img.rows;
+  std::vector<uint8_t> pool(bytes * std::max<size_t>(imgs.size(), 1));
+  for (size_t k = 0; k < imgs.size(); k++) std::memcpy(&pool[k * bytes], imgs[k], bytes);
+  livo2_retrieve_candidates cd{n, 0, pos.data(), nrm.data(), idx.data(), px.data(), f.data(), R.data(), t.data(), lvl.data(), ie.data()};
+  livo2_retrieve_cfg rc{};
+  rc.cam.fx = fx; rc.cam.fy = fy; rc.cam.cx = cx; rc.cam.cy = cy; rc.cam.distortion = 0; rc.cam.width = width; rc.cam.height = height;
+  std::memcpy(rc.R_cur, R_f_w_new.data(), 72); std::memcpy(rc.t_cur, t_f_w_new.data(), 24);
+  rc.inv_expo_cur = state->inv_expo_time; rc.patch_pyrimid_level = L; rc.normal_en = normal_en; rc.ncc_en = ncc_en; rc.ncc_thre = ncc_thre; rc.outlier_threshold = outlier_threshold;
+  std::vector<int32_t> acc(n), sl(n); std::vector<float> err(n);
+  livo2_retrieve_out ro{acc.data(), sl.data(), err.data(), nullptr, nullptr, nullptr};
+  int32_t n_acc = 0;
+  dev_.check(livo2_visual_retrieve_warp(dev_.ctx(), img.data, img.cols, img.rows, img.step, pool.data(), (int32_t)imgs.size(), &cd, &rc, &ro, &n_acc));
+  SubSparseMap &sm = *visual_submap;       // reference src/vio.cpp:762-767 (warp_patch stays on the device)
+  sm.voxel_points.clear(); sm.search_levels.clear(); sm.errors.clear(); sm.inv_expo_list.clear(); sm.warp_patch.clear();
+  for (int i = 0; i < n; i++) if (acc[i]) {
+    sm.voxel_points.push_back(cands[i].pt); sm.search_levels.push_back(sl[i]); sm.errors.push_back(err[i]); sm.inv_expo_list.push_back(cands[i].ref_ftr->inv_expo_time_);
+  }
+  total_points = n_acc;
+  frame_resident_ = true;
+}
+
 void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
   if (total_points == 0) return;            // reference src/vio.cpp:786
   const int M = total_points, L = patch_pyrimid_level;
   std::vector<double> pos((size_t)M * 3);
   std::vector<float> warp((size_t)M * L * 64);
-  for (int i = 0; i < M; i++) {
+  for (int i = 0; i < M && !frame_resident_; i++) {
     std::memcpy(&pos[(size_t)i * 3], visual_submap->voxel_points[i]->pos_.data(), 24);
     std::memcpy(&warp[(size_t)i * L * 64], visual_submap->warp_patch[i].data(), (size_t)L * 64 * sizeof(float));   // ragged vector<vector<float>> -> [M][L][64]
   }
-  dev_.check(livo2_visual_set_frame(dev_.ctx(), img.data, img.cols, img.rows, img.step, pos.data(), warp.data(), visual_submap->search_levels.data(),
-                                    visual_submap->inv_expo_list.data(), M, L));
+  if (!frame_resident_)
+    dev_.check(livo2_visual_set_frame(dev_.ctx(), img.data, img.cols, img.rows, img.step, pos.data(), warp.data(), visual_submap->search_levels.data(),
+                                      visual_submap->inv_expo_list.data(), M, L));
+  frame_resident_ = false;
   if (inverse_composition_en) {             // gather the reference patches (distinct reference images are uploaded once each)
     std::vector<const uint8_t *> imgs; std::vector<int32_t> idx(M);
     std::vector<double> px((size_t)M * 2), f((size_t)M * 3), R((size_t)M * 9), rp((size_t)M * 3);

@@ -62,10 +62,12 @@ struct PointToPlane {                       // reference include/voxel_map.h:54-
   float dis_to_plane_ = 0;
 };
 
-struct VoxelPlane {                         // reference include/voxel_map.h:69-94 (fields the update reads)
-  V3D center_{}, normal_{};
+struct VoxelPlane {                         // reference include/voxel_map.h:69-94 (fields the update reads and init_plane writes)
+  V3D center_{}, normal_{}, y_normal_{}, x_normal_{};
+  M3D covariance_{};
   std::array<double, 36> plane_var_{};
-  float radius_ = 0, d_ = 0;
+  float radius_ = 0, d_ = 0, min_eigen_value_ = 1, mid_eigen_value_ = 1, max_eigen_value_ = 1;
+  int points_size_ = 0;
   bool is_plane_ = false, is_update_ = false;
 };
 
@@ -80,7 +82,9 @@ struct VoxelLocationHash {                  // reference include/voxel_map.h:109
   }
 };
 
-struct VoxelOctoTree {                      // reference include/voxel_map.h:129-183 (fields the update reads)
+struct VoxelOctoTree {                      // reference include/voxel_map.h:129-183 (fields the update / the plane fit read)
+  std::vector<pointWithVar> temp_points_;
+  float planer_threshold_ = 0.0025f;
   VoxelPlane *plane_ptr_ = new VoxelPlane;
   int layer_ = 0;
   VoxelOctoTree *leaves_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -132,6 +136,10 @@ public:
 
   void StateEstimation(StatesGroup &state_propagat);   // reference src/voxel_map.cpp:338-511
 
+  // VoxelOctoTree::init_plane(temp_points_, plane_ptr_) (reference src/voxel_map.cpp:55-135) for many voxels in one device call; planes
+  // that are in the uploaded snapshot and stay planes are refreshed in place on the device, a changed is_plane_ marks the map dirty.
+  void FitPlanes(const std::vector<VoxelOctoTree *> &voxels);
+
 private:
   void FlattenAndUpload();
   Device &dev_;
@@ -142,14 +150,17 @@ private:
 };
 
 // ---- visual ---------------------------------------------------------------------------------------------------------------
-struct Feature {                            // reference include/feature.h:19-54 — what precomputeReferencePatches reads (vio.cpp:1346-1356)
+struct Feature {                            // reference include/feature.h:19-54 — what precomputeReferencePatches (vio.cpp:1346-1356) and the retrieval loop (vio.cpp:698-767) read
   const uint8_t *img_ = nullptr;            // reference gray image (same size / stride as the current frame)
   std::array<double, 2> px_{};
   V3D f_{};
   M3D R_f_w{};                              // T_f_w_.rotation_matrix()
+  V3D t_f_w{};                              // T_f_w_.translation()
   V3D pos{};                                // pos(): camera centre of the reference frame
+  int level_ = 0;
+  double inv_expo_time_ = 1.0;
 };
-struct VisualPoint { V3D pos_{}; Feature *ref_patch = nullptr; };   // reference include/visual_point.h:23-46
+struct VisualPoint { V3D pos_{}, normal_{}; Feature *ref_patch = nullptr; };   // reference include/visual_point.h:23-46
 
 struct SubSparseMap {                       // reference include/vio.h:26-57
   std::vector<float> errors;
@@ -170,7 +181,10 @@ public:
   int width = 0, height = 0;
   int patch_pyrimid_level = 4, patch_size = 8, max_iterations = 5, total_points = 0;
   double img_point_cov = 100;
-  bool exposure_estimate_en = true, inverse_composition_en = false;
+  bool exposure_estimate_en = true, inverse_composition_en = false, normal_en = true, ncc_en = false;
+  double ncc_thre = 0, outlier_threshold = 1000;
+  M3D R_f_w_new{{1, 0, 0, 0, 1, 0, 0, 0, 1}};   // new_frame_->T_f_w_ (reference include/frame.h:34)
+  V3D t_f_w_new{};
   SubSparseMap *visual_submap = nullptr;
   std::array<double, LIVO2_DIM_STATE * LIVO2_DIM_STATE> G{}, H_T_H{};
 
@@ -179,8 +193,15 @@ public:
   void setLidarToCameraExtrinsic(const M3D &R, const V3D &P) { Rcl = R; Pcl = P; }                     // reference src/vio.cpp:33-37
   void computeJacobianAndUpdateEKF(const GrayImage &img);                                              // reference src/vio.cpp:784-802
 
+  // Tail of retrieveFromVisualSparseMap (reference src/vio.cpp:698-767) for the points the host-side selection kept: warp, search level,
+  // patches, gates on the device; fills visual_submap (voxel_points, search_levels, errors, inv_expo_list) and total_points, and leaves
+  // the survivors resident as the frame of the next computeJacobianAndUpdateEKF (which then uploads nothing but the states).
+  struct Candidate { VisualPoint *pt; Feature *ref_ftr; };
+  void warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands);
+
 private:
   Device &dev_;
+  bool frame_resident_ = false;             // set by warpAndGateCandidates, consumed by computeJacobianAndUpdateEKF
 };
 
 } // namespace livo2

@@ -29,6 +29,8 @@ static StatesGroup state_from(const std::vector<double> &v) {       // 25 scalar
 }
 static std::vector<double> state_to(const StatesGroup &s) { livo2_state a; s.to_abi(a); std::vector<double> v(sizeof(a) / 8); std::memcpy(v.data(), &a, sizeof(a)); return v; }
 
+static std::vector<VoxelOctoTree *> g_node_of_plane;     // plane index of the dump -> its octree node (for the FitPlanes leg)
+
 static VoxelOctoTree *build(int node, int layer, const std::vector<int32_t> &node_plane, const std::vector<int32_t> &node_child, const std::vector<double> &pn,
                             const std::vector<double> &pc, const std::vector<double> &pv, const std::vector<float> &pd, const std::vector<float> &pr) {
   VoxelOctoTree *t = new VoxelOctoTree; t->layer_ = layer;
@@ -38,6 +40,8 @@ static VoxelOctoTree *build(int node, int layer, const std::vector<int32_t> &nod
     for (int k = 0; k < 3; k++) { p->normal_[k] = pn[pi * 3 + k]; p->center_[k] = pc[pi * 3 + k]; }
     for (int k = 0; k < 36; k++) p->plane_var_[k] = pv[(size_t)pi * 36 + k];
     p->d_ = pd[pi]; p->radius_ = pr[pi]; p->is_plane_ = true;
+    if ((size_t)pi >= g_node_of_plane.size()) g_node_of_plane.resize(pi + 1, nullptr);
+    g_node_of_plane[pi] = t;
   }
   for (int k = 0; k < 8; k++) { int c = node_child[(size_t)node * 8 + k]; if (c >= 0) t->leaves_[k] = build(c, layer + 1, node_plane, node_child, pn, pc, pv, pd, pr); }
   return t;
@@ -81,6 +85,32 @@ int main(int argc, char **argv) {
       wr(dir, "out_ptpl_dis", dis.data(), dis.size()); wr(dir, "out_ptpl_pw", ptw.data(), ptw.size());
       int32_t eff = vm.effct_feat_num_; wr(dir, "out_effct", &eff, 1);
       std::printf("lidar: effct_feat_num_=%d\n", vm.effct_feat_num_);
+      // ---- UpdateVoxelMap's re-fits in bulk (src/voxel_map.cpp:55-135 via VoxelMapManager::FitPlanes), then the next frame's update ----
+      auto fit_plane = rd<int32_t>(dir, "fit_plane");
+      if (!fit_plane.empty()) {
+        auto fpw = rd<double>(dir, "fit_pw"), fvar = rd<double>(dir, "fit_var"); auto foff = rd<int32_t>(dir, "fit_off");
+        std::vector<VoxelOctoTree *> voxels;
+        for (size_t g = 0; g < fit_plane.size(); g++) {
+          VoxelOctoTree *t = g_node_of_plane[fit_plane[g]];
+          t->temp_points_.clear();
+          for (int i = foff[g]; i < foff[g + 1]; i++) {
+            pointWithVar pv;
+            for (int k = 0; k < 3; k++) pv.point_w[k] = fpw[(size_t)i * 3 + k];
+            for (int k = 0; k < 9; k++) pv.var[k] = fvar[(size_t)i * 9 + k];
+            t->temp_points_.push_back(pv);
+          }
+          voxels.push_back(t);
+        }
+        vm.FitPlanes(voxels);
+        std::vector<double> fc, fn; std::vector<float> fr; std::vector<int32_t> fis;
+        for (auto *t : voxels) { const VoxelPlane *p = t->plane_ptr_; fc.insert(fc.end(), p->center_.begin(), p->center_.end()); fn.insert(fn.end(), p->normal_.begin(), p->normal_.end()); fr.push_back(p->radius_); fis.push_back(p->is_plane_); }
+        wr(dir, "fit_out_center", fc.data(), fc.size()); wr(dir, "fit_out_normal", fn.data(), fn.size()); wr(dir, "fit_out_radius", fr.data(), fr.size()); wr(dir, "fit_out_is_plane", fis.data(), fis.size());
+        vm.state_ = state_from(rd<double>(dir, "state_in"));
+        vm.StateEstimation(prop);
+        auto so2 = state_to(vm.state_);
+        wr(dir, "out_state2", so2.data(), so2.size());
+        std::printf("fit: %zu voxels re-fitted\n", voxels.size());
+      }
     }
     // ---- visual -----------------------------------------------------------------------------------------------------------
     auto img = rd<uint8_t>(dir, "img");
@@ -113,6 +143,42 @@ int main(int argc, char **argv) {
       wr(dir, "vis_out_errors", sm.errors.data(), sm.errors.size());
       wr(dir, "vis_out_G", vio.G.data(), vio.G.size());
       std::printf("visual: M=%d\n", M);
+      // ---- retrieveFromVisualSparseMap's per-point tail on the device, then the visual update on the retrieved frame ----
+      auto rcfg = rd<double>(dir, "retr_cfg");     // R_cur9 t_cur3 inv_expo_cur normal_en ncc_en ncc_thre outlier_threshold L
+      if (!rcfg.empty()) {
+        auto rimg = rd<uint8_t>(dir, "retr_img"), rrefs = rd<uint8_t>(dir, "retr_ref_imgs");
+        auto rpos = rd<double>(dir, "retr_pos"), rnrm = rd<double>(dir, "retr_normal"), rpx = rd<double>(dir, "retr_ref_px"), rf = rd<double>(dir, "retr_ref_f");
+        auto rR = rd<double>(dir, "retr_ref_R"), rt = rd<double>(dir, "retr_ref_t"), rie = rd<double>(dir, "retr_ref_inv_expo");
+        auto ridx = rd<int32_t>(dir, "retr_ref_img_idx"), rlvl = rd<int32_t>(dir, "retr_ref_level");
+        const int n = (int)ridx.size();
+        const size_t bytes = (size_t)vio.width * vio.height;
+        std::vector<VisualPoint> rp(n); std::vector<Feature> ft(n); std::vector<VIOManager::Candidate> cands(n);
+        for (int i = 0; i < n; i++) {
+          for (int k = 0; k < 3; k++) { rp[i].pos_[k] = rpos[(size_t)i * 3 + k]; rp[i].normal_[k] = rnrm[(size_t)i * 3 + k]; ft[i].f_[k] = rf[(size_t)i * 3 + k]; ft[i].t_f_w[k] = rt[(size_t)i * 3 + k]; }
+          for (int k = 0; k < 9; k++) ft[i].R_f_w[k] = rR[(size_t)i * 9 + k];
+          ft[i].px_ = {rpx[(size_t)i * 2], rpx[(size_t)i * 2 + 1]}; ft[i].img_ = rrefs.data() + bytes * ridx[i]; ft[i].level_ = rlvl[i]; ft[i].inv_expo_time_ = rie[i];
+          cands[i] = {&rp[i], &ft[i]};
+        }
+        for (int k = 0; k < 9; k++) vio.R_f_w_new[k] = rcfg[k];
+        for (int k = 0; k < 3; k++) vio.t_f_w_new[k] = rcfg[9 + k];
+        StatesGroup st2 = state_from(rd<double>(dir, "retr_state_in")), prop2 = state_from(rd<double>(dir, "retr_state_prop"));
+        st2.inv_expo_time = rcfg[12];
+        vio.patch_pyrimid_level = (int)rcfg[17];
+        vio.state = &st2; vio.state_propagat = &prop2;
+        vio.normal_en = rcfg[13] != 0; vio.ncc_en = rcfg[14] != 0; vio.ncc_thre = rcfg[15]; vio.outlier_threshold = rcfg[16];
+        SubSparseMap sm2; vio.visual_submap = &sm2;
+        GrayImage g2{rimg.data(), vio.width, vio.height, vio.width};
+        vio.warpAndGateCandidates(g2, cands);
+        std::vector<int32_t> kept;
+        for (auto *p : sm2.voxel_points) kept.push_back((int32_t)(p - rp.data()));
+        wr(dir, "retr_out_kept", kept.data(), kept.size()); wr(dir, "retr_out_errors", sm2.errors.data(), sm2.errors.size());
+        std::vector<int32_t> sl2(sm2.search_levels.begin(), sm2.search_levels.end());
+        wr(dir, "retr_out_search", sl2.data(), sl2.size());
+        vio.computeJacobianAndUpdateEKF(g2);
+        auto so2 = state_to(st2);
+        wr(dir, "retr_out_state", so2.data(), so2.size());
+        std::printf("retrieve: %d of %d candidates kept\n", vio.total_points, n);
+      }
     }
   } catch (const std::exception &e) { std::fprintf(stderr, "shim_demo: %s\n", e.what()); return 1; }
   return 0;

@@ -507,7 +507,7 @@ class RetrieveScenario:
     cfg: dict
 
 
-def retrieve_scenario(seed=21, n_cand=2000, n_ref=3, L=4, normal_en=True, ncc_en=False, outlier_threshold=1000.0, ncc_thre=0.5):
+def retrieve_scenario(seed=21, n_cand=2000, n_ref=3, L=4, normal_en=True, ncc_en=False, outlier_threshold=1000.0, ncc_thre=0.5, margin=40):
     """Reference frames look at the same synthetic texture from poses near the current one (the same image is reused as their picture),
     so most warps are near-identity and pass the photometric gate; a share of candidates gets a much closer reference camera
     (det A > 3: search level 1-2), a strongly mis-registered reference (rejected by the gate) or a reference pixel near the border
@@ -521,8 +521,8 @@ def retrieve_scenario(seed=21, n_cand=2000, n_ref=3, L=4, normal_en=True, ncc_en
     R_cw = rot_from_rpy(0.03, -0.02, 0.4)
     t_cw = np.array([0.3, -0.2, 0.1])
     # points seen by the current camera, comfortably inside the image
-    u = rng.uniform(40, cam["width"] - 41, n_cand)
-    v = rng.uniform(40, cam["height"] - 41, n_cand)
+    u = rng.uniform(margin, cam["width"] - 1 - margin, n_cand)
+    v = rng.uniform(margin, cam["height"] - 1 - margin, n_cand)
     depth = rng.uniform(2.0, 12.0, n_cand)
     p_c = np.stack([(u - cam["cx"]) / cam["fx"] * depth, (v - cam["cy"]) / cam["fy"] * depth, depth], 1)
     pos = (p_c - t_cw) @ R_cw                                  # R^T (p_c - t)

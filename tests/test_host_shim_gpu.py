@@ -45,6 +45,32 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     vcur, vprop = H.states(vs, orc.StatePOD)
     _state_vec(vcur).tofile(os.path.join(d, "vis_state_in.bin")); _state_vec(vprop).tofile(os.path.join(d, "vis_state_prop.bin"))
 
+    # FitPlanes leg: re-fit 60 planes of the map from fresh point groups near them, then run the update again on the refreshed map
+    from tests import plane_groups as PG
+    rng = np.random.default_rng(5)
+    fit_idx = rng.permutation(fm.n_planes)[:60].astype(np.int32)
+    fpts, fvar, foff = [], [], [0]
+    for p in fit_idx:
+        n = int(rng.integers(8, 40))
+        Q, _ = np.linalg.qr(np.c_[fm.plane_normal[p], rng.normal(size=(3, 2))])
+        q = (rng.normal(size=(n, 3)) * np.array([0.004, 0.12, 0.1])) @ Q.T + fm.plane_center[p]
+        fpts.append(q.astype(np.float32).astype(np.float64)); fvar.append(PG.random_spd(rng, n)); foff.append(foff[-1] + n)
+    fpts, fvar, foff = np.concatenate(fpts), np.concatenate(fvar).reshape(-1, 9), np.array(foff, np.int32)
+    fit_idx.tofile(os.path.join(d, "fit_plane.bin")); fpts.tofile(os.path.join(d, "fit_pw.bin")); fvar.tofile(os.path.join(d, "fit_var.bin")); foff.tofile(os.path.join(d, "fit_off.bin"))
+    # retrieval leg
+    # (L = 2 and a 72-px margin keep every patch of the later visual update inside the image: the oracle, like the reference, reads out of bounds otherwise)
+    rs = synth.retrieve_scenario(seed=19, n_cand=300, L=2, margin=72)
+    np.concatenate([rs.R_cur.ravel(), rs.t_cur, [rs.inv_expo_cur, rs.cfg["normal_en"], rs.cfg["ncc_en"], rs.cfg["ncc_thre"], rs.cfg["outlier_threshold"], 2]]).astype(np.float64).tofile(os.path.join(d, "retr_cfg.bin"))
+    # the IMU state whose camera pose is the retrieval's new_frame_->T_f_w_ (Rcw = Rci Rwi^T, Pcw = -Rcw Pwi + Pci, vio.cpp:1540-1543)
+    Rci, Pci = synth.vio_constants(vs.extR, vs.extT, vs.Rcl, vs.Pcl)
+    vs_r = synth.visual_scenario(seed=18, n_patches=4, L=2, R_true=rs.R_cur.T @ Rci, t_true=rs.R_cur.T @ (Pci - rs.t_cur))
+    rcur, rprop = H.states(vs_r, orc.StatePOD)
+    _state_vec(rcur).tofile(os.path.join(d, "retr_state_in.bin")); _state_vec(rprop).tofile(os.path.join(d, "retr_state_prop.bin"))
+    rs.img.tofile(os.path.join(d, "retr_img.bin")); rs.ref_imgs.tofile(os.path.join(d, "retr_ref_imgs.bin"))
+    for name in ("pos", "normal", "ref_px", "ref_f", "ref_R", "ref_t", "ref_inv_expo"):
+        np.ascontiguousarray(getattr(rs, name), np.float64).tofile(os.path.join(d, "retr_" + name + ".bin"))
+    rs.ref_img_idx.astype(np.int32).tofile(os.path.join(d, "retr_ref_img_idx.bin")); rs.ref_level.astype(np.int32).tofile(os.path.join(d, "retr_ref_level.bin"))
+
     r = subprocess.run([DEMO, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
 
@@ -64,3 +90,35 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     assert np.allclose(vout[:25], vrefv[:25], rtol=0, atol=1e-9) and H.relerr(vout[25:], vrefv[25:]) < 1e-8
     assert np.allclose(np.fromfile(os.path.join(d, "vis_out_errors.bin"), dtype=np.float32), vref["errors"], rtol=1e-5)
     assert H.relerr(np.fromfile(os.path.join(d, "vis_out_G.bin")).reshape(19, 19), vref["G"]) < 1e-7
+
+    # FitPlanes: fitted members vs the oracle's init_plane, and the second update vs the same refresh done through the Python ABI wrappers
+    fits = [orc.init_plane(fpts[foff[g]:foff[g + 1]], fvar[foff[g]:foff[g + 1]], 0.0025) for g in range(len(fit_idx))]
+    assert np.array_equal(np.fromfile(os.path.join(d, "fit_out_is_plane.bin"), dtype=np.int32), np.array([f.is_plane for f in fits]))
+    assert np.allclose(np.fromfile(os.path.join(d, "fit_out_center.bin")).reshape(-1, 3), np.array([list(f.center) for f in fits]), rtol=1e-13)
+    assert np.allclose(np.fromfile(os.path.join(d, "fit_out_normal.bin")).reshape(-1, 3), np.array([list(f.normal) for f in fits]), atol=1e-6)
+    assert np.allclose(np.fromfile(os.path.join(d, "fit_out_radius.bin"), dtype=np.float32), np.array([f.radius for f in fits]), rtol=1e-5)
+    ctx = livo2.Context(0)
+    ctx.upload_map(fm)
+    ctx.update_planes(fit_idx, np.array([list(f.normal) for f in fits]), np.array([list(f.center) for f in fits]), np.array([list(f.plane_var) for f in fits]),
+                      np.array([f.d for f in fits], np.float32), np.array([f.radius for f in fits], np.float32))
+    pcur, pprop = H.states(sc, livo2.State)
+    ctx.set_scan(sc.xyz, H.lidar_cfg_product(sc))
+    res2, _ = ctx.lidar_update(pcur, pprop, H.lidar_cfg_product(sc))
+    out2 = np.fromfile(os.path.join(d, "out_state2.bin"))
+    ref2 = _state_vec(res2.state)
+    assert np.allclose(out2[:25], ref2[:25], rtol=0, atol=1e-6) and H.relerr(out2[25:], ref2[25:]) < 1e-4
+    assert np.abs(out2[:25] - out[:25]).max() > 1e-9          # the refreshed planes did change the estimate
+    ctx.close()
+
+    # retrieval: survivors (order, errors, search levels) vs the oracle, visual update on the resident frame vs the oracle on the survivors
+    wref = orc.warp_candidates(rs)
+    keep = np.nonzero(wref["accepted"])[0]
+    assert np.array_equal(np.fromfile(os.path.join(d, "retr_out_kept.bin"), dtype=np.int32), keep)
+    assert np.array_equal(np.fromfile(os.path.join(d, "retr_out_errors.bin"), dtype=np.float32), wref["error"][keep])
+    assert np.array_equal(np.fromfile(os.path.join(d, "retr_out_search.bin"), dtype=np.int32), wref["search_level"][keep])
+    vs_r.img, vs_r.pos, vs_r.warp_patch, vs_r.search_levels, vs_r.inv_expo_list = rs.img, rs.pos[keep], wref["patch_wrap"][keep], wref["search_level"][keep], rs.ref_inv_expo[keep]
+    rcur.inv_expo = rs.inv_expo_cur
+    vref2 = orc.visual_update(orc.visual_cfg(vs_r), vs_r, rcur, rprop)
+    vout2 = np.fromfile(os.path.join(d, "retr_out_state.bin"))
+    vref2v = _state_vec(vref2["state"])
+    assert np.allclose(vout2[:25], vref2v[:25], rtol=0, atol=1e-8) and H.relerr(vout2[25:], vref2v[25:]) < 1e-7
