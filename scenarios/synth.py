@@ -330,13 +330,15 @@ def prior_cov(rng):
 
 
 def lidar_scenario(seed=1, n_points=10000, room=(20.0, 20.0, 6.0), n_boxes=8, full_sphere=False, map_rays_factor=12, downsample=None,
-                   rot_sigma_deg=0.5, pos_sigma=0.03, cfg=None):
-    """C1/C2-style scenario: map from a dense first sweep at the true pose, test scan with fresh noise, perturbed prior."""
+                   rot_sigma_deg=0.5, pos_sigma=0.03, cfg=None, extR=None, extT=None):
+    """C1/C2-style scenario: map from a dense first sweep at the true pose, test scan with fresh noise, perturbed prior.
+    extR / extT: LiDAR->IMU extrinsics (default: avia.yaml's identity rotation; HILTI22.yaml has a non-identity one, quirk Q6)."""
     rng = np.random.default_rng(seed)
     c = dict(AVIA["lio"])
     if cfg:
         c.update(cfg)
-    extR, extT = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy()
+    extR = AVIA["extrinsic_R"].copy() if extR is None else np.asarray(extR, np.float64)
+    extT = AVIA["extrinsic_T"].copy() if extT is None else np.asarray(extT, np.float64)
     scene = make_room(rng, room, n_boxes)
     R_true = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
     t_true = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
