@@ -88,7 +88,14 @@ def cpu_baseline(sc, budget_s=20.0):
     rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
     orc.warp_candidates(rs, lib)
     warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
-    return {"plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
+    raw = _synth.raw_scan_scenario(seed=51, n_raw=240000)
+    tpre = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
+        orc.voxel_grid(u_, raw.leaf, lib)
+        tpre.append(time.perf_counter() - t0)
+    return {"preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
             "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "value_1thread": out[1][0], "value_all_cores": out[ncores][0], "host_cores": ncores}
@@ -259,6 +266,21 @@ def main():
         extra["c3_lidar_plus_visual"] = {"evals_per_s": (n + 64.0 * len(vs.pos)) * args.steps / dtc, "lidar_points": n, "visual_patches": len(vs.pos),
                                          "ms_per_step": 1e3 * dtc / args.steps, "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
         ctx_v.close()
+        # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
+        raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
+        ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)
+        us, t1 = [], time.perf_counter()
+        for _ in range(5):
+            nd, _, _ = ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False); us.append(ctx.preprocess_last_kernel_us())
+        t_e2e = (time.perf_counter() - t1) / 5
+        k_us = float(np.median(us))
+        extra["preprocess_scan"] = {"raw_points": len(raw.xyz), "feats_down_size": nd, "imu_poses": len(raw.poses), "kernel_us": k_us,
+                                    "points_per_s_kernel": len(raw.xyz) / (k_us * 1e-6), "achieved_GBps": 44.0 * len(raw.xyz) / (k_us * 1e-6) / 1e9,
+                                    "points_per_s_with_h2d_and_scan_setup": len(raw.xyz) / t_e2e,
+                                    "note": "k_undistort + voxel grid (min/max, keys, rocPRIM radix sort, heads, scan, centroids); 44 B/point = xyz+time read, xyz written, "
+                                            "xyz re-read, centroid share; the event span covers ~20 small launches (rocprofv3: ~115 us of kernel time at 240k points, the rest is enqueue gaps); "
+                                            "CPU figure in cpu_baseline.preprocess_points_per_s_1thread"}
+        ctx.set_scan(sc.xyz, cfg)
         # per-point tail of retrieveFromVisualSparseMap (warp matrix, search level, warpAffine x L, getImagePatch, gates, compaction)
         rs = synth.retrieve_scenario(seed=21, n_cand=2000)
         ctx.retrieve_warp(rs, want_patches=False)

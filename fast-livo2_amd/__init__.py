@@ -111,6 +111,25 @@ class Context:
     _POINT_FIELDS = {"match_plane": (np.int32, 1), "dis_to_plane": (np.float32, 1), "point_w": (np.float32, 3), "normal_plane": (np.int32, 1),
                      "var": (np.float64, 9), "body_cov": (np.float64, 9), "r_inv": (np.float64, 1), "h_row": (np.float64, 6)}
 
+    def preprocess_scan(self, xyz, curvature, poses, rot_end, pos_end, leaf, cfg, want=True):
+        """Raw scan -> undistortion -> voxel grid -> resident scan.  poses: [K][22] Pose6D rows.  Returns (n_down, feats_undistort, feats_down_body)."""
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        cur = np.ascontiguousarray(curvature, np.float32)
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 22)
+        re, pe = _f64(rot_end), _f64(pos_end)
+        n = len(x)
+        und = np.zeros((n, 3), np.float32) if want else None
+        down = np.zeros((max(n, 1), 3), np.float32) if want else None
+        nd = C.c_int32(0)
+        self._chk(self.lib.livo2_lidar_preprocess_scan(self.h, abi.as_ptr(x, C.c_float), abi.as_ptr(cur, C.c_float), n, P.ctypes.data_as(C.c_void_p), len(P),
+                                                       abi.as_ptr(re, C.c_double), abi.as_ptr(pe, C.c_double), float(leaf), C.byref(cfg), C.byref(nd),
+                                                       abi.as_ptr(und, C.c_float) if want else None, abi.as_ptr(down, C.c_float) if want else None))
+        self.n = int(nd.value)
+        return self.n, und, (down[: self.n] if want else None)
+
+    def preprocess_last_kernel_us(self):
+        return float(self.lib.livo2_lidar_preprocess_last_kernel_us(self.h))
+
     def _points(self, want):
         if not want:
             return None, {}

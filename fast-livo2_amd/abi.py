@@ -167,6 +167,9 @@ SIGNATURES = {
     "livo2_plane_fit_batch": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_int32, C.c_float, _P(C.c_int32), _P(PlaneFit)]),
     "livo2_plane_fit_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_lidar_set_scan": (C.c_int, [_CTX, _P(C.c_float), C.c_int32, _P(LidarCfg)]),
+    "livo2_lidar_preprocess_scan": (C.c_int, [_CTX, _P(C.c_float), _P(C.c_float), C.c_int32, C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_double), C.c_double,
+                                              _P(LidarCfg), _P(C.c_int32), _P(C.c_float), _P(C.c_float)]),
+    "livo2_lidar_preprocess_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_lidar_iterate": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarSums), _P(LidarPoints)]),
     "livo2_lidar_update": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarResult), _P(LidarPoints)]),
     "livo2_lidar_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarPoints)]),

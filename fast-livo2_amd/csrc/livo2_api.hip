@@ -4,10 +4,12 @@
 // here: every entry point either drives the HIP kernels or fails.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include "lidar_kernels.hpp"
 #include "visual_inverse_kernels.hpp"
 #include "map_kernels.hpp"
 #include "retrieve_kernels.hpp"
+#include "preprocess_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -51,6 +53,10 @@ struct livo2_ctx {
   int cand_cap = 0; double *d_c_pos = nullptr, *d_c_normal = nullptr, *d_c_px = nullptr, *d_c_f = nullptr, *d_c_R = nullptr, *d_c_t = nullptr, *d_c_ie = nullptr, *d_c_ncc = nullptr, *d_c_A = nullptr;
   int32_t *d_c_idx = nullptr, *d_c_lvl = nullptr, *d_c_acc = nullptr, *d_c_sl = nullptr, *d_c_slot = nullptr, *d_c_count = nullptr; float *d_c_err = nullptr, *d_c_patch = nullptr; size_t c_patch_cap = 0;
   double retrieve_kernel_us = 0.0;
+  // raw-scan pre-stage (N3)
+  float *d_raw = nullptr, *d_curv = nullptr; size_t raw_cap = 0, curv_cap = 0; double *d_poses = nullptr; size_t poses_cap = 0;
+  int32_t *d_vg_head = nullptr, *d_vg_slot = nullptr, *d_vg_misc = nullptr; size_t vg_head_cap = 0, vg_slot_cap = 0;
+  double preprocess_kernel_us = 0.0;
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -334,7 +340,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->bd_block_frame, ctx->bd_ctl, ctx->bd_entries, ctx->bd_in, ctx->bd_results, ctx->d_plane_internal, ctx->d_plane_cand_pos,
                  ctx->d_fit_pw, ctx->d_fit_var, ctx->d_fit_off, ctx->d_fit_idx, ctx->d_fit_out, ctx->d_fit_list,
                  ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl, ctx->d_c_acc,
-                 ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch};
+                 ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch, ctx->d_raw, ctx->d_curv, ctx->d_poses, ctx->d_vg_head, ctx->d_vg_slot, ctx->d_vg_misc};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -588,12 +594,9 @@ int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *v
 double livo2_plane_fit_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->fit_kernel_us : 0.0; }
 
 // ---- LiDAR -----------------------------------------------------------------------------------------------------------------
-int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg) {
-  if (!ctx) return LIVO2_ERR_INVALID;
-  if (n < 0 || (n > 0 && !xyz)) return fail(ctx, LIVO2_ERR_INVALID, "bad scan");
-  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+namespace {
+// device buffers of one scan of up to n points
+int scan_reserve(livo2_ctx *ctx, int n) {
   if (n > ctx->n_cap) {
     hipError_t e;
     if (ctx->d_x) { e = hipFree(ctx->d_xyz_aos); e = hipFree(ctx->d_x); e = hipFree(ctx->d_y); e = hipFree(ctx->d_z); e = hipFree(ctx->d_cb); e = hipFree(ctx->d_keys); e = hipFree(ctx->d_keys2); e = hipFree(ctx->d_idx); e = hipFree(ctx->d_perm); (void)e; }
@@ -605,23 +608,29 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
     HIPCHK(hipMalloc((void **)&ctx->d_idx, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_perm, (size_t)cap * 4));
     ctx->n_cap = cap;
   }
+  return LIVO2_OK;
+}
+int sort_reserve(livo2_ctx *ctx, size_t need) {
+  if (need > ctx->sort_tmp_bytes) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_sort_tmp) HIPCHK(hipFree(ctx->d_sort_tmp));
+    ctx->d_sort_tmp = nullptr;
+    HIPCHK(hipMalloc(&ctx->d_sort_tmp, need + need / 2 + 256));
+    ctx->sort_tmp_bytes = need + need / 2 + 256;
+  }
+  return LIVO2_OK;
+}
+// d_xyz_aos[0..n) holds feats_down_body: Morton order of the body-frame cells (cell = voxel_size), SoA gather, body covariance
+int scan_pipeline(livo2_ctx *ctx, int n, const livo2_lidar_cfg *cfg) {
   ctx->n = n;
   const int grid = lidar_grid(std::max(n, 1));
-  rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * 32, (size_t)64));
+  int rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * 32, (size_t)64));
   if (rc) return rc;
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    // Morton order of the body-frame cells (cell = voxel_size), then gather into SoA
     hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, n, (float)(1.0 / cfg->voxel_size), ctx->d_keys, ctx->d_idx);
     size_t need = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 30, ctx->stream));
-    if (need > ctx->sort_tmp_bytes) {
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      if (ctx->d_sort_tmp) HIPCHK(hipFree(ctx->d_sort_tmp));
-      ctx->d_sort_tmp = nullptr;
-      HIPCHK(hipMalloc(&ctx->d_sort_tmp, need + need / 2 + 256));
-      ctx->sort_tmp_bytes = need + need / 2 + 256;
-    }
+    rc = sort_reserve(ctx, need); if (rc) return rc;
     size_t tmp_bytes = ctx->sort_tmp_bytes;
     HIPCHK(rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 30, ctx->stream));
     hipLaunchKernelGGL(k_gather_xyz, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, ctx->d_perm, n, ctx->d_x, ctx->d_y, ctx->d_z);
@@ -631,10 +640,103 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
                        deg2rad, ctx->d_cb);
     HIPCHK(hipGetLastError());
   }
+  return LIVO2_OK;
+}
+} // namespace
+
+int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n < 0 || (n > 0 && !xyz)) return fail(ctx, LIVO2_ERR_INVALID, "bad scan");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rc = scan_reserve(ctx, n); if (rc) return rc;
+  if (n > 0) HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  rc = scan_pipeline(ctx, n, cfg); if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));      // xyz is caller memory: do not return before the copy has consumed it
   ctx->has_scan = true;
   return LIVO2_OK;
 }
+
+// Raw scan -> undistortion -> voxel-grid filter -> the scan of the next update, all on the device.
+int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *curvature, int32_t n, const livo2_imu_pose *poses, int32_t n_poses,
+                                const double *rot_end, const double *pos_end, double leaf_size, const livo2_lidar_cfg *cfg, int32_t *n_down,
+                                float *feats_undistort, float *feats_down_body) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n < 0 || (n > 0 && (!xyz || !curvature)) || n_poses < 0 || (n_poses > 0 && !poses) || !rot_end || !pos_end || !n_down) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!(leaf_size > 0)) return fail(ctx, LIVO2_ERR_INVALID, "leaf_size must be > 0");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  for (int k = 1; k < n_poses; k++) if (poses[k].offset_time < poses[k - 1].offset_time) return fail(ctx, LIVO2_ERR_INVALID, "IMU poses must be ordered by offset_time");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rc = scan_reserve(ctx, n); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_raw, ctx->raw_cap, std::max((size_t)n * 3, (size_t)3)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_curv, ctx->curv_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_poses, ctx->poses_cap, std::max((size_t)n_poses * 22, (size_t)22)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_vg_head, ctx->vg_head_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_vg_slot, ctx->vg_slot_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
+  if (!ctx->d_vg_misc) HIPCHK(hipMalloc((void **)&ctx->d_vg_misc, 64));      // bounds[6] float, overflow flag, leaf count
+  *n_down = 0;
+  if (n == 0) { rc = scan_pipeline(ctx, 0, cfg); if (rc) return rc; ctx->has_scan = true; return LIVO2_OK; }
+  static_assert(sizeof(livo2_imu_pose) == 22 * 8, "livo2_imu_pose is 22 doubles");
+  HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_poses > 0) HIPCHK(hipMemcpyAsync(ctx->d_poses, poses, (size_t)n_poses * sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_vg_misc, 0, 64, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_vg_misc, 0xFF, 12, ctx->stream));           // min codes
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  if (n_poses >= 2) {
+    UndistortArgs u{};
+    u.xyz = ctx->d_raw; u.curvature = ctx->d_curv; u.poses = ctx->d_poses; u.n = n; u.n_poses = n_poses;
+    // extR_Ri = Lid_rot_to_IMU^T * rot_end^T ; exrR_extT = Lid_rot_to_IMU^T * Lid_offset_to_IMU   (IMU_Processing.cpp:497-498)
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) u.extR_Ri[i * 3 + j] = (cfg->extR[0 * 3 + i] * rot_end[j * 3 + 0] + cfg->extR[1 * 3 + i] * rot_end[j * 3 + 1]) + cfg->extR[2 * 3 + i] * rot_end[j * 3 + 2];
+      u.exrR_extT[i] = (cfg->extR[0 * 3 + i] * cfg->extT[0] + cfg->extR[1 * 3 + i] * cfg->extT[1]) + cfg->extR[2 * 3 + i] * cfg->extT[2];
+    }
+    std::memcpy(u.ER, cfg->extR, 72); std::memcpy(u.Et, cfg->extT, 24); std::memcpy(u.pos_end, pos_end, 24);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u);
+  }
+  uint32_t *bounds = reinterpret_cast<uint32_t *>(ctx->d_vg_misc);
+  int32_t *flag = ctx->d_vg_misc + 8, *count = ctx->d_vg_misc + 9;
+  const float inv_leaf = 1.0f / (float)leaf_size;
+  hipLaunchKernelGGL(k_vg_minmax, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, ctx->stream, ctx->d_raw, n, bounds);
+  hipLaunchKernelGGL(k_vg_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_raw, n, inv_leaf, bounds, ctx->d_keys, ctx->d_idx, flag);
+  size_t need = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 31, ctx->stream));
+  rc = sort_reserve(ctx, need); if (rc) return rc;
+  size_t tmp_bytes = ctx->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 31, ctx->stream));
+  hipLaunchKernelGGL(k_vg_heads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_keys2, n, ctx->d_vg_head);
+  {   // leaf number of every head = exclusive scan of the head flags (device-wide; a one-block scan cost 350 us at 240k points)
+    size_t scan_need = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, scan_need, ctx->d_vg_head, ctx->d_vg_slot, 0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
+    rc = sort_reserve(ctx, scan_need); if (rc) return rc;
+    size_t scan_bytes = ctx->sort_tmp_bytes;
+    HIPCHK(rocprim::exclusive_scan(ctx->d_sort_tmp, scan_bytes, ctx->d_vg_head, ctx->d_vg_slot, 0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
+  }
+  hipLaunchKernelGGL(k_vg_centroid, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_keys2, ctx->d_perm, ctx->d_vg_head, ctx->d_vg_slot, n, ctx->d_xyz_aos, count);
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipGetLastError());
+  int32_t misc[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(misc, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (feats_undistort) HIPCHK(hipMemcpyAsync(feats_undistort, ctx->d_raw, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  ctx->preprocess_kernel_us = 1e3 * ms;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  if (misc[0]) return fail(ctx, LIVO2_ERR_RANGE, "leaf size too small for the cloud: the voxel grid overflows int32 (pcl::VoxelGrid refuses it too)");
+  const int m = misc[1];
+  if (feats_down_body && m > 0) HIPCHK(hipMemcpyAsync(feats_down_body, ctx->d_xyz_aos, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
+  rc = scan_pipeline(ctx, m, cfg); if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n_down = m;
+  ctx->has_scan = true;
+  return LIVO2_OK;
+}
+double livo2_lidar_preprocess_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->preprocess_kernel_us : 0.0; }
 
 static int lidar_ready(livo2_ctx *ctx, const livo2_state *a, const livo2_state *b, const livo2_lidar_cfg *cfg) {
   if (!ctx) return LIVO2_ERR_INVALID;

@@ -135,6 +135,24 @@ typedef struct livo2_lidar_cfg {
  * (calcBodyCov per point, voxel_map.cpp:349-360).  The scan stays resident until the next set_scan. */
 int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg);
 
+/* Raw scan -> feats_down_body on the device: ImuProcess::UndistortPcl's backward propagation of every point to the
+ * scan-end pose (src/IMU_Processing.cpp:494-539: xyz [n][3] and curvature [n] = PointType x,y,z,curvature of pcl_wait_proc, sorted by
+ * curvature like the reference sorts it, IMU_Processing.cpp:154-156; poses = IMUpose, rot_end / pos_end = state_inout after the forward
+ * propagation; Lid_rot_to_IMU / Lid_offset_to_IMU = cfg->extR / extT) followed by downSizeFilterSurf (pcl::VoxelGrid centroid filter,
+ * leaf_size = filter_size_surf, src/LIVMapper.cpp:351-352), and then the per-scan work of livo2_lidar_set_scan on the result — the
+ * filtered cloud becomes the scan of the next livo2_lidar_update without a host round trip.  *n_down = feats_down_size_.
+ * feats_undistort ([n][3]) and feats_down_body (capacity [n][3]) receive copies when not NULL (the caller needs feats_down_body for
+ * pv_list_ / UpdateVoxelMap).  n_poses < 2: no undistortion.  pcl::VoxelGrid is third-party (parity unpinned); the order of
+ * summation inside a leaf is the input order here (unspecified in PCL). */
+typedef struct livo2_imu_pose {   /* Pose6D (msg/Pose6D.msg, include/common_lib.h:225-242) */
+  double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9];
+} livo2_imu_pose;
+int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *curvature, int32_t n, const livo2_imu_pose *poses, int32_t n_poses,
+                                const double *rot_end, const double *pos_end, double leaf_size, const livo2_lidar_cfg *cfg, int32_t *n_down,
+                                float *feats_undistort, float *feats_down_body);
+/* kernel time (undistort + voxel grid, without the Morton/body-cov stage) of the last call in microseconds */
+double livo2_lidar_preprocess_last_kernel_us(const livo2_ctx *ctx);
+
 /* Result of ONE residual+Jacobian+reduction pass (voxel_map.cpp:374-466 without the solve). */
 typedef struct livo2_lidar_sums {
   double HtH[36];               /* Hsub_T_R_inv * Hsub, row-major 6x6 (voxel_map.cpp:466) */

@@ -204,6 +204,34 @@ def warp_candidates(rs, lib=None):
     return out
 
 
+def undistort(xyz, curvature, poses, rot_end, pos_end, extR, extT, lib=None):
+    """ImuProcess::UndistortPcl backward loop (src/IMU_Processing.cpp:494-539) on a copy of xyz; poses: [n_poses][22] (Pose6D rows)."""
+    lib = lib or load()
+    out = np.ascontiguousarray(xyz, np.float32).copy()
+    cur = np.ascontiguousarray(curvature, np.float32)
+    P = np.ascontiguousarray(poses, np.float64).reshape(-1, 22)
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)
+    a, b, c, d = f64(rot_end), f64(pos_end), f64(extR), f64(extT)
+    lib.orc_undistort.restype = None
+    lib.orc_undistort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib.orc_undistort(vp(out), vp(cur), len(out), vp(P), len(P), vp(a), vp(b), vp(c), vp(d))
+    return out
+
+
+def voxel_grid(xyz, leaf, lib=None):
+    """pcl::VoxelGrid centroid filter as restated in orc_preprocess.hpp; returns [m][3] float32 (ascending leaf index)."""
+    lib = lib or load()
+    x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros_like(x)
+    lib.orc_voxel_grid.restype = C.c_int
+    lib.orc_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    m = lib.orc_voxel_grid(x.ctypes.data_as(C.c_void_p), len(x), float(leaf), out.ctypes.data_as(C.c_void_p))
+    if m < 0:
+        raise OverflowError("leaf grid overflows int32")
+    return out[:m].copy()
+
+
 def lidar_cfg(c, extR, extT, num_threads=1, deg2rad=0.017453293):
     cfg = LidarCfg()
     cfg.max_iterations, cfg.max_layer = int(c["max_iterations"]), int(c["max_layer"])

@@ -10,6 +10,7 @@
 #include "orc_lidar.hpp"
 #include "orc_visual.hpp"
 #include "orc_warp.hpp"
+#include "orc_preprocess.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -389,6 +390,23 @@ double orc_warp_candidates(const orc_warp_cfg *c, const uint8_t *img, const uint
     std::memcpy(A4 + 4 * (size_t)i, o.A, 32);
   }
   return omp_get_wtime() - t0;
+}
+
+// Per-scan pre-stage (orc_preprocess.hpp): undistortion in place, then the voxel-grid filter.  poses: n_poses x 22 doubles (Pose6D).
+void orc_undistort(float *xyz, const float *curvature, int n, const double *poses22, int n_poses, const double *rot_end9, const double *pos_end3,
+                   const double *extR9, const double *extT3) {
+  std::vector<Pose6D> P((size_t)n_poses);
+  for (int i = 0; i < n_poses; i++) std::memcpy(&P[i], poses22 + 22 * (size_t)i, sizeof(Pose6D));
+  M3 Re, ER; V3 pe, Et;
+  std::memcpy(Re.a, rot_end9, 72); std::memcpy(ER.a, extR9, 72); std::memcpy(pe.a, pos_end3, 24); std::memcpy(Et.a, extT3, 24);
+  undistort_points(xyz, curvature, n, P.data(), n_poses, Re, pe, ER, Et);
+}
+static_assert(sizeof(Pose6D) == 22 * 8, "Pose6D is 22 doubles");
+int orc_voxel_grid(const float *xyz, int n, float leaf, float *out_xyz /*capacity n*3*/) {
+  std::vector<float> o;
+  const int m = voxel_grid_filter(xyz, n, leaf, o);
+  if (m > 0) std::memcpy(out_xyz, o.data(), o.size() * 4);
+  return m;
 }
 
 // State algebra (common_lib.h:182-206) and the 19x19 inverse, for known-answer tests.

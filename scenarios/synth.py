@@ -551,3 +551,45 @@ def retrieve_scenario(seed=21, n_cand=2000, n_ref=3, L=4, normal_en=True, ncc_en
     idx = np.where(kind == 2, rng.integers(1, n_ref, n_cand), 0).astype(np.int32) if n_ref > 1 else np.zeros(n_cand, np.int32)
     return RetrieveScenario(img, ref_imgs, pos, normal, idx, ref_px, ref_f, ref_R, ref_t, rng.integers(0, 3, n_cand).astype(np.int32),
                             rng.uniform(0.9, 1.1, n_cand), R_cw, t_cw, 1.02, cam, cfg)
+
+
+# ---- raw scan + IMU poses for the pre-stage (reference src/IMU_Processing.cpp:494-539, src/LIVMapper.cpp:351-352) -----------
+@dataclass
+class RawScanScenario:
+    xyz: np.ndarray            # f32 [n,3] raw points, LiDAR frame
+    curvature: np.ndarray      # f32 [n] ms from the scan start, ascending
+    poses: np.ndarray          # f64 [K,22] Pose6D rows: offset_time, acc3, gyr3, vel3, pos3, rot9
+    rot_end: np.ndarray
+    pos_end: np.ndarray
+    extR: np.ndarray
+    extT: np.ndarray
+    leaf: float
+    cfg: dict
+
+
+def raw_scan_scenario(seed=51, n_raw=24000, scan_ms=100.0, imu_hz=200.0, extR=None, extT=None, leaf=None):
+    """A Livox-Avia-like raw scan (24 000 points / 100 ms, src/preprocess.cpp:185) taken while the IMU moves: per-point time stamps and the
+    IMUpose list the forward propagation would have left (one Pose6D per IMU sample, piecewise-constant angular rate and acceleration)."""
+    rng = np.random.default_rng(seed)
+    c = dict(AVIA["lio"])
+    extR = AVIA["extrinsic_R"].copy() if extR is None else np.asarray(extR, np.float64)
+    extT = AVIA["extrinsic_T"].copy() if extT is None else np.asarray(extT, np.float64)
+    scene = make_room(rng, (20.0, 20.0, 6.0), 8)
+    R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
+    t0 = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    xyz = lidar_scan(rng, scene, R0, t0, extR, extT, n_raw, c["dept_err"], c["beam_err"], AVIA["blind"], False)
+    cur = np.sort(rng.uniform(0.0, scan_ms, len(xyz))).astype(np.float32)
+    cur[0] = np.float32(0.0)
+    K = int(round(scan_ms / 1000.0 * imu_hz)) + 1
+    poses = np.zeros((K, 22))
+    R, p, v = R0.copy(), t0.copy(), np.array([0.8, -0.3, 0.05])
+    dt = 1.0 / imu_hz
+    for k in range(K):
+        gyr = np.array([0.2, -0.35, 0.5]) + rng.normal(0, 0.05, 3)
+        acc = np.array([0.3, 0.2, -0.1]) + rng.normal(0, 0.1, 3)
+        poses[k, 0] = k * dt
+        poses[k, 1:4], poses[k, 4:7], poses[k, 7:10], poses[k, 10:13], poses[k, 13:22] = acc, gyr, v, p, R.ravel()
+        R = R @ so3_exp(gyr * dt)
+        p = p + v * dt + 0.5 * acc * dt * dt
+        v = v + acc * dt
+    return RawScanScenario(np.ascontiguousarray(xyz, np.float32), cur, poses, R, p, extR, extT, float(AVIA["filter_size_surf"] if leaf is None else leaf), c)
