@@ -266,6 +266,35 @@ def main():
         extra["c3_lidar_plus_visual"] = {"evals_per_s": (n + 64.0 * len(vs.pos)) * args.steps / dtc, "lidar_points": n, "visual_patches": len(vs.pos),
                                          "ms_per_step": 1e3 * dtc / args.steps, "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
         ctx_v.close()
+        # One Avia-sized frame through every device stage built so far (C1 sizes: 24 000 raw points / scan, a few hundred patches): the
+        # reference's budget for this is 100 ms per frame on <= 4 host threads
+        sc1 = synth.lidar_scenario(seed=1, n_points=10000, downsample=0.1)
+        raw1 = synth.raw_scan_scenario(seed=1, n_raw=24000)
+        cfg1 = H.lidar_cfg_product(sc1)
+        cur1, prop1 = make_states(livo2, sc1)
+        rs1 = synth.retrieve_scenario(seed=2, n_cand=400)
+        vs1 = synth.visual_scenario(seed=3, n_patches=8); vs1.img, vs1.cam = rs1.img, rs1.cam
+        vcfg1 = H.visual_cfg_product(vs1)
+        vcur1, vprop1 = make_states(livo2, vs1)
+        fpw1, fvar1, foff1 = plane_fit_groups(n_groups=800, seed=5)
+        ctx.upload_map(sc1.fmap)
+        stage = {}
+        for rep in range(6):
+            t = [time.perf_counter()]
+            nd1 = ctx.preprocess_scan(raw1.xyz, raw1.curvature, raw1.poses, raw1.rot_end, raw1.pos_end, raw1.leaf, cfg1, want=False)[0]; t.append(time.perf_counter())
+            ctx.set_scan(sc1.xyz, cfg1)                                   # (the synthetic raw scan is not registered to this map: update the matching scan)
+            t.append(time.perf_counter())
+            ctx.lidar_update(cur1, prop1, cfg1); t.append(time.perf_counter())
+            ctx.plane_fit_batch(fpw1, fvar1, foff1, 0.0025); t.append(time.perf_counter())
+            ctx.retrieve_warp(rs1, want_patches=False); t.append(time.perf_counter())
+            ctx.visual_update(vcur1, vprop1, vcfg1); t.append(time.perf_counter())
+            if rep:
+                for name, a, b in (("preprocess_scan", 0, 1), ("lidar_update", 2, 3), ("plane_fit_800_voxels", 3, 4), ("retrieve_warp_400", 4, 5), ("visual_update", 5, 6)):
+                    stage.setdefault(name, []).append((t[b] - t[a]) * 1e3)
+        extra["avia_frame_stages_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
+        extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
+        extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
+        ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
         # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
         raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
         ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)
