@@ -88,6 +88,9 @@ def cpu_baseline(sc, budget_s=20.0):
     rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
     orc.warp_candidates(rs, lib)
     warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
+    ss = _synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
+    orc.visual_select(ss, lib)
+    sel_s = min(orc.visual_select(ss, lib)["seconds"] for _ in range(3))
     raw = _synth.raw_scan_scenario(seed=51, n_raw=240000)
     tpre = []
     for _ in range(3):
@@ -95,7 +98,7 @@ def cpu_baseline(sc, budget_s=20.0):
         u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
         orc.voxel_grid(u_, raw.leaf, lib)
         tpre.append(time.perf_counter() - t0)
-    return {"preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
+    return {"select_seconds_1thread": sel_s, "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
             "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "value_1thread": out[1][0], "value_all_cores": out[ncores][0], "host_cores": ncores}
@@ -310,6 +313,18 @@ def main():
                                             "xyz re-read, centroid share; the event span covers ~20 small launches (rocprofv3: ~115 us of kernel time at 240k points, the rest is enqueue gaps); "
                                             "CPU figure in cpu_baseline.preprocess_points_per_s_1thread"}
         ctx.set_scan(sc.xyz, cfg)
+        # selection half of retrieveFromVisualSparseMap (scan voxels + depth image, nearest visual point per grid cell, depth continuity)
+        ss = synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
+        ctx.visual_map_upload(ss.pos, ss.keys, ss.active)
+        ctx.visual_select(ss)
+        us, t1 = [], time.perf_counter()
+        for _ in range(5):
+            so = ctx.visual_select(ss); us.append(ctx.select_last_kernel_us())
+        t_e2e = (time.perf_counter() - t1) / 5
+        k_us = float(np.median(us))
+        extra["visual_select"] = {"scan_points": len(ss.pg), "visual_map_points": len(ss.pos), "cells_selected": int((so["cell_point"] >= 0).sum()), "kernel_us": k_us,
+                                  "visual_points_per_s_kernel": len(ss.pos) / (k_us * 1e-6), "calls_per_s_with_h2d_d2h": 1.0 / t_e2e,
+                                  "note": "memsets + k_sel_scan + k_sel_points + k_sel_cells (vio.cpp:385-486, 598-635) with the visual map resident; CPU figure in cpu_baseline.select_seconds_1thread"}
         # per-point tail of retrieveFromVisualSparseMap (warp matrix, search level, warpAffine x L, getImagePatch, gates, compaction)
         rs = synth.retrieve_scenario(seed=21, n_cand=2000)
         ctx.retrieve_warp(rs, want_patches=False)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveOut, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
+from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveOut, SelectCfg, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
 
 
 class Livo2Error(RuntimeError):
@@ -225,6 +225,32 @@ class Context:
         self.M, self.L = M, L
         self._chk(self.lib.livo2_visual_set_frame(self.h, abi.as_ptr(img, C.c_uint8), w, h, w, abi.as_ptr(pos, C.c_double), abi.as_ptr(warp_patch, C.c_float),
                                                   abi.as_ptr(search_levels, C.c_int32), abi.as_ptr(inv_expo_list, C.c_double), M, L))
+
+    def visual_map_upload(self, pos, keys=None, active=None):
+        pos = _f64(pos).reshape(-1, 3)
+        k = None if keys is None else np.ascontiguousarray(keys, np.int64)
+        a = None if active is None else np.ascontiguousarray(active, np.uint8)
+        self.n_vm = len(pos)
+        self._chk(self.lib.livo2_visual_map_upload(self.h, len(pos), abi.as_ptr(pos, C.c_double), abi.as_ptr(k, C.c_int64) if k is not None else None,
+                                                   abi.as_ptr(a, C.c_uint8) if a is not None else None))
+
+    def visual_select(self, ss):
+        """Selection half of retrieveFromVisualSparseMap over a scenario-like object (pg, R_cur, t_cur, cam, border, grid_*)."""
+        c = SelectCfg()
+        c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"]
+        c.cam.distortion, c.cam.width, c.cam.height = 0, ss.cam["width"], ss.cam["height"]
+        c.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); c.t_cur[:] = np.asarray(ss.t_cur, float).tolist()
+        c.border, c.grid_size, c.grid_n_width, c.grid_n_height, c.patch_size_half = int(ss.border), int(ss.grid_size), int(ss.grid_n_width), int(ss.grid_n_height), 4
+        length = int(ss.grid_n_width) * int(ss.grid_n_height)
+        pg = _f64(ss.pg).reshape(-1, 3)
+        out = dict(cell_point=np.zeros(length, np.int32), cell_dist=np.zeros(length, np.float32), discont=np.zeros(length, np.uint8), in_fov=np.zeros(max(self.n_vm, 1), np.uint8))
+        self._chk(self.lib.livo2_visual_select(self.h, abi.as_ptr(pg, C.c_double), len(pg), C.byref(c), abi.as_ptr(out["cell_point"], C.c_int32),
+                                               abi.as_ptr(out["cell_dist"], C.c_float), abi.as_ptr(out["discont"], C.c_uint8), abi.as_ptr(out["in_fov"], C.c_uint8)))
+        out["in_fov"] = out["in_fov"][: self.n_vm]
+        return out
+
+    def select_last_kernel_us(self):
+        return float(self.lib.livo2_visual_select_last_kernel_us(self.h))
 
     def retrieve_warp(self, rs, want_patches=True):
         """Per-point tail of retrieveFromVisualSparseMap over a scenario-like object (img, ref_imgs, pos, normal, ref_*, R_cur, t_cur,

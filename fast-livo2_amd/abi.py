@@ -129,6 +129,11 @@ class RetrieveOut(C.Structure):
                 ("A_cur_ref", C.POINTER(C.c_double)), ("patch_wrap", C.POINTER(C.c_float))]
 
 
+class SelectCfg(C.Structure):
+    _fields_ = [("cam", Cam), ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_width", C.c_int32),
+                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32)]
+
+
 class VisualCfg(C.Structure):
     _fields_ = [("cam", Cam), ("Rcl", C.c_double * 9), ("Pcl", C.c_double * 3), ("extR", C.c_double * 9), ("extT", C.c_double * 3),
                 ("img_point_cov", C.c_double), ("patch_pyrimid_level", C.c_int32), ("max_iterations", C.c_int32),
@@ -183,6 +188,9 @@ SIGNATURES = {
     "livo2_visual_set_frame": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32),
                                          _P(C.c_double), C.c_int32, C.c_int32]),
     "livo2_visual_set_reference": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, _P(C.c_int32), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "livo2_visual_map_upload": (C.c_int, [_CTX, C.c_int32, _P(C.c_double), _P(C.c_int64), _P(C.c_uint8)]),
+    "livo2_visual_select": (C.c_int, [_CTX, _P(C.c_double), C.c_int32, _P(SelectCfg), _P(C.c_int32), _P(C.c_float), _P(C.c_uint8), _P(C.c_uint8)]),
+    "livo2_visual_select_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_visual_retrieve_warp": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_uint8), C.c_int32, _P(RetrieveCandidates), _P(RetrieveCfg),
                                              _P(RetrieveOut), _P(C.c_int32)]),
     "livo2_visual_retrieve_last_kernel_us": (C.c_double, [_CTX]),

@@ -10,6 +10,7 @@
 #include "map_kernels.hpp"
 #include "retrieve_kernels.hpp"
 #include "preprocess_kernels.hpp"
+#include "select_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -57,6 +58,12 @@ struct livo2_ctx {
   float *d_raw = nullptr, *d_curv = nullptr; size_t raw_cap = 0, curv_cap = 0; double *d_poses = nullptr; size_t poses_cap = 0;
   int32_t *d_vg_head = nullptr, *d_vg_slot = nullptr, *d_vg_misc = nullptr; size_t vg_head_cap = 0, vg_slot_cap = 0;
   double preprocess_kernel_us = 0.0;
+  // visual map mirror + selection (N2)
+  bool has_vmap = false; int n_vm = 0; double *d_vm_pos = nullptr; size_t vm_pos_cap = 0; unsigned long long *d_vm_pkey = nullptr; size_t vm_pkey_cap = 0;
+  uint8_t *d_vm_active = nullptr, *d_vm_fov = nullptr; size_t vm_active_cap = 0, vm_fov_cap = 0;
+  double *d_sel_pg = nullptr; size_t sel_pg_cap = 0; unsigned long long *d_sel_set = nullptr, *d_sel_depth = nullptr, *d_sel_best = nullptr; size_t sel_set_cap = 0, sel_depth_cap = 0, sel_best_cap = 0;
+  int32_t *d_sel_type = nullptr, *d_sel_point = nullptr, *d_sel_flag = nullptr; float *d_sel_dist = nullptr; uint8_t *d_sel_disc = nullptr; size_t sel_type_cap = 0, sel_point_cap = 0, sel_dist_cap = 0, sel_disc_cap = 0;
+  double select_kernel_us = 0.0;
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -340,7 +347,9 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->bd_block_frame, ctx->bd_ctl, ctx->bd_entries, ctx->bd_in, ctx->bd_results, ctx->d_plane_internal, ctx->d_plane_cand_pos,
                  ctx->d_fit_pw, ctx->d_fit_var, ctx->d_fit_off, ctx->d_fit_idx, ctx->d_fit_out, ctx->d_fit_list,
                  ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl, ctx->d_c_acc,
-                 ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch, ctx->d_raw, ctx->d_curv, ctx->d_poses, ctx->d_vg_head, ctx->d_vg_slot, ctx->d_vg_misc};
+                 ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch, ctx->d_raw, ctx->d_curv, ctx->d_poses, ctx->d_vg_head, ctx->d_vg_slot, ctx->d_vg_misc,
+                 ctx->d_vm_pos, ctx->d_vm_pkey, ctx->d_vm_active, ctx->d_vm_fov, ctx->d_sel_pg, ctx->d_sel_set, ctx->d_sel_depth, ctx->d_sel_best, ctx->d_sel_type, ctx->d_sel_point,
+                 ctx->d_sel_flag, ctx->d_sel_dist, ctx->d_sel_disc};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -1045,6 +1054,106 @@ int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t 
   ctx->has_ref = true;
   return LIVO2_OK;
 }
+
+// ---- visual sub-map retrieval, selection half -----------------------------------------------------------------------------------
+int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const int64_t *voxel_key, const uint8_t *active) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n < 0 || (n > 0 && !pos)) return fail(ctx, LIVO2_ERR_INVALID, "bad visual map arrays");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_vm_pos, ctx->vm_pos_cap, std::max((size_t)n * 3, (size_t)3)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_vm_pkey, ctx->vm_pkey_cap, std::max((size_t)n, (size_t)1)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_vm_active, ctx->vm_active_cap, std::max((size_t)n, (size_t)1)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_vm_fov, ctx->vm_fov_cap, std::max((size_t)n, (size_t)1)))) return rc;
+  if (!ctx->d_sel_flag) HIPCHK(hipMalloc((void **)&ctx->d_sel_flag, 64));
+  HIPCHK(hipMemsetAsync(ctx->d_sel_flag, 0, 64, ctx->stream));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_vm_pos, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (active) HIPCHK(hipMemcpyAsync(ctx->d_vm_active, active, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    else HIPCHK(hipMemsetAsync(ctx->d_vm_active, 1, (size_t)n, ctx->stream));
+    if (voxel_key) {
+      std::vector<unsigned long long> pk((size_t)n);
+      const long long B = 1ll << 20;
+      for (int i = 0; i < n; i++) {
+        const int64_t *k = voxel_key + 3 * (size_t)i;
+        if (k[0] < -B || k[0] >= B || k[1] < -B || k[1] >= B || k[2] < -B || k[2] >= B) return fail(ctx, LIVO2_ERR_RANGE, "visual voxel key outside 21 bits per axis");
+        pk[i] = ((unsigned long long)(k[0] + B) << 42) | ((unsigned long long)(k[1] + B) << 21) | (unsigned long long)(k[2] + B);
+      }
+      HIPCHK(hipMemcpy(ctx->d_vm_pkey, pk.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    } else {
+      hipLaunchKernelGGL(k_sel_point_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_vm_pos, n, ctx->d_vm_pkey, ctx->d_sel_flag);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  int32_t flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (flag) return fail(ctx, LIVO2_ERR_RANGE, "visual voxel key outside 21 bits per axis");
+  ctx->n_vm = n; ctx->has_vmap = true;
+  return LIVO2_OK;
+}
+
+int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const livo2_select_cfg *cfg, int32_t *cell_point, float *cell_dist, uint8_t *cell_disc,
+                        uint8_t *point_in_fov) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!cfg || n_pg < 0 || (n_pg > 0 && !pg) || !cell_point) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!ctx->has_vmap) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_map_upload has not been called");
+  if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "selection needs a zero-distortion camera");
+  const int length = cfg->grid_n_width * cfg->grid_n_height;
+  if (cfg->grid_size < 1 || cfg->grid_n_width < 1 || cfg->grid_n_height < 1 || length > (1 << 20) || cfg->cam.width < 1 || cfg->cam.height < 1 || cfg->patch_size_half < 0 ||
+      cfg->border < cfg->patch_size_half) return fail(ctx, LIVO2_ERR_INVALID, "bad grid / border (the 9x9 depth window must stay inside the image: border >= patch_size_half)");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t px = (size_t)cfg->cam.width * cfg->cam.height;
+  size_t cap = 1024; while (cap < 2 * (size_t)std::max(n_pg, 1)) cap <<= 1;
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_sel_pg, ctx->sel_pg_cap, std::max((size_t)n_pg * 3, (size_t)3)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_set, ctx->sel_set_cap, cap))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_depth, ctx->sel_depth_cap, px))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_best, ctx->sel_best_cap, (size_t)length))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_type, ctx->sel_type_cap, (size_t)length))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_point, ctx->sel_point_cap, (size_t)length))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_dist, ctx->sel_dist_cap, (size_t)length))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sel_disc, ctx->sel_disc_cap, (size_t)length))) return rc;
+  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
+  SelectArgs a{};
+  a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
+  std::memcpy(a.R, cfg->R_cur, 72); std::memcpy(a.t, cfg->t_cur, 24);
+  for (int r = 0; r < 3; r++) a.cam_pos[r] = ((cfg->R_cur[r] * cfg->t_cur[0] + cfg->R_cur[3 + r] * cfg->t_cur[1]) + cfg->R_cur[6 + r] * cfg->t_cur[2]) * (-1.0);   // new_frame_->pos()
+  a.width = cfg->cam.width; a.height = cfg->cam.height; a.border = cfg->border; a.grid_size = cfg->grid_size; a.grid_n_width = cfg->grid_n_width; a.length = length;
+  a.patch_size_half = cfg->patch_size_half; a.n_pg = n_pg; a.n_pts = ctx->n_vm;
+  a.pg = ctx->d_sel_pg; a.pos = ctx->d_vm_pos; a.pkey = ctx->d_vm_pkey; a.active = ctx->d_vm_active; a.set = ctx->d_sel_set; a.mask = (uint32_t)(cap - 1);
+  a.depth = ctx->d_sel_depth; a.cell_best = ctx->d_sel_best; a.cell_type = ctx->d_sel_type; a.in_fov = ctx->d_vm_fov; a.range_flag = ctx->d_sel_flag;
+  a.cell_point = ctx->d_sel_point; a.cell_dist = ctx->d_sel_dist; a.cell_discont = ctx->d_sel_disc;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_sel_flag, 0, 64, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_sel_set, 0xFF, cap * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_sel_depth, 0, px * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_sel_best, 0xFF, (size_t)length * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_sel_type, 0, (size_t)length * 4, ctx->stream));
+  if (n_pg > 0) hipLaunchKernelGGL(k_sel_scan, dim3((n_pg + 255) / 256), dim3(256), 0, ctx->stream, a);
+  if (ctx->n_vm > 0) hipLaunchKernelGGL(k_sel_points, dim3((ctx->n_vm + 255) / 256), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_sel_cells, dim3((length + 255) / 256), dim3(256), 0, ctx->stream, a);
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipGetLastError());
+  int32_t flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(cell_point, ctx->d_sel_point, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (cell_dist) HIPCHK(hipMemcpyAsync(cell_dist, ctx->d_sel_dist, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (cell_disc) HIPCHK(hipMemcpyAsync(cell_disc, ctx->d_sel_disc, (size_t)length, hipMemcpyDeviceToHost, ctx->stream));
+  if (point_in_fov && ctx->n_vm > 0) HIPCHK(hipMemcpyAsync(point_in_fov, ctx->d_vm_fov, (size_t)ctx->n_vm, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  ctx->select_kernel_us = 1e3 * ms;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  if (flag) return fail(ctx, LIVO2_ERR_RANGE, "scan voxel key outside 21 bits per axis");
+  return LIVO2_OK;
+}
+double livo2_visual_select_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->select_kernel_us : 0.0; }
 
 // ---- visual sub-map retrieval, per-point tail -----------------------------------------------------------------------------------
 int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const uint8_t *ref_imgs, int32_t n_ref,

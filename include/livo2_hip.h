@@ -257,6 +257,30 @@ int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, in
 int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t n_ref, const int32_t *ref_img_idx, const double *ref_px,
                                const double *ref_f, const double *ref_R, const double *ref_pos);
 
+/* ---- visual sub-map retrieval, selection half -----------------------------------------------------------------------
+ * VIOManager::retrieveFromVisualSparseMap, src/vio.cpp:352-486 and 598-635 (raycast_en = false): the points of the current scan
+ * (pv_list_.point_w) mark the voxels to look into and fill the depth image; among the visual map points filed under those voxels the
+ * nearest one per image grid cell is selected; the depth-continuity test then vets each selected point.  The visual map is mirrored
+ * on the device as flat arrays: pos = VisualPoint::pos_, voxel_key = the VOXEL_LOCATION the point is filed under in feat_map
+ * (NULL: recomputed with insertPointIntoVoxelMap's formula, src/vio.cpp:227-236), active = (pt != nullptr && pt->obs_.size() > 0)
+ * (NULL: all active).  Keys must fit 21 bits per axis (LIVO2_ERR_RANGE otherwise).
+ * livo2_visual_select outputs, per grid cell c in [0, grid_n_width * grid_n_height): cell_point[c] = index of retrieve_voxel_points[c]
+ * in the uploaded arrays or -1 (grid_num[c] != TYPE_MAP), cell_dist[c] = map_dist[c], cell_discontinuous[c] = 1 if the loop at
+ * vio.cpp:612-635 would skip the point; per visual point: point_in_fov[i] = it passed isInFrame (voxel_in_fov of its voxel = any of its
+ * points).  The host then picks ref_ftr for the surviving cells (vio.cpp:640-695) and hands them to livo2_visual_retrieve_warp.
+ * Exactly equidistant points of one cell: the lowest index wins (the reference: the last one in unordered_map iteration order). */
+int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n_points, const double *pos, const int64_t *voxel_key, const uint8_t *active);
+typedef struct livo2_select_cfg {
+  livo2_cam cam;
+  double R_cur[9], t_cur[3];    /* new_frame_->T_f_w_ */
+  int32_t border;               /* (patch_size_half + 1) * (1 << patch_pyrimid_level), src/vio.cpp:154 */
+  int32_t grid_size, grid_n_width, grid_n_height;   /* src/vio.cpp:67-78 */
+  int32_t patch_size_half, pad;
+} livo2_select_cfg;
+int livo2_visual_select(livo2_ctx *ctx, const double *pg_point_w, int32_t n_pg, const livo2_select_cfg *cfg, int32_t *cell_point, float *cell_dist,
+                        uint8_t *cell_discontinuous, uint8_t *point_in_fov);
+double livo2_visual_select_last_kernel_us(const livo2_ctx *ctx);
+
 /* ---- visual sub-map retrieval, per-point tail ----------------------------------------------------------------------
  * VIOManager::retrieveFromVisualSparseMap keeps its grid / voxel / depth-continuity selection and reference-patch choice
  * (src/vio.cpp:352-698); for the n points it selected, this call does what the loop body does next (src/vio.cpp:698-767):

@@ -232,6 +232,43 @@ def voxel_grid(xyz, leaf, lib=None):
     return out[:m].copy()
 
 
+class SelectCfg(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("width", C.c_int32), ("height", C.c_int32),
+                ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_width", C.c_int32),
+                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32)]
+
+
+def visual_select(ss, lib=None):
+    """Selection half of retrieveFromVisualSparseMap over a scenarios.synth.SelectScenario; returns per-cell / per-point arrays."""
+    lib = lib or load()
+    c = SelectCfg()
+    c.fx, c.fy, c.cx, c.cy, c.width, c.height = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"], ss.cam["width"], ss.cam["height"]
+    c.R_cur[:] = ss.R_cur.ravel().tolist(); c.t_cur[:] = ss.t_cur.tolist()
+    c.border, c.grid_size, c.grid_n_width, c.grid_n_height, c.patch_size_half = ss.border, ss.grid_size, ss.grid_n_width, ss.grid_n_height, 4
+    length = ss.grid_n_width * ss.grid_n_height
+    pg = np.ascontiguousarray(ss.pg, np.float64); pos = np.ascontiguousarray(ss.pos, np.float64)
+    keys = np.ascontiguousarray(ss.keys, np.int64); act = np.ascontiguousarray(ss.active, np.uint8)
+    out = dict(cell_point=np.zeros(length, np.int32), cell_dist=np.zeros(length, np.float32), cell_type=np.zeros(length, np.int32), discont=np.zeros(length, np.int32),
+               in_fov=np.zeros(len(pos), np.int32), depth_img=np.zeros((ss.cam["height"], ss.cam["width"]), np.float32))
+    lib.orc_visual_select.restype = C.c_double
+    lib.orc_visual_select.argtypes = [C.POINTER(SelectCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out["seconds"] = lib.orc_visual_select(C.byref(c), vp(pg), len(pg), vp(pos), vp(keys), vp(act), len(pos), vp(out["cell_point"]), vp(out["cell_dist"]),
+                                           vp(out["cell_type"]), vp(out["discont"]), vp(out["in_fov"]), vp(out["depth_img"]))
+    return out
+
+
+def feat_map_keys(pos, lib=None):
+    lib = lib or load()
+    pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 3)
+    keys = np.zeros((len(pos), 3), np.int64)
+    lib.orc_feat_map_key.restype = None
+    lib.orc_feat_map_key.argtypes = [C.c_void_p, C.c_void_p]
+    for i in range(len(pos)):
+        lib.orc_feat_map_key(pos[i].ctypes.data_as(C.c_void_p), keys[i].ctypes.data_as(C.c_void_p))
+    return keys
+
+
 def lidar_cfg(c, extR, extT, num_threads=1, deg2rad=0.017453293):
     cfg = LidarCfg()
     cfg.max_iterations, cfg.max_layer = int(c["max_iterations"]), int(c["max_layer"])

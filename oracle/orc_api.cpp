@@ -11,6 +11,7 @@
 #include "orc_visual.hpp"
 #include "orc_warp.hpp"
 #include "orc_preprocess.hpp"
+#include "orc_select.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -408,6 +409,27 @@ int orc_voxel_grid(const float *xyz, int n, float leaf, float *out_xyz /*capacit
   if (m > 0) std::memcpy(out_xyz, o.data(), o.size() * 4);
   return m;
 }
+
+// Selection half of retrieveFromVisualSparseMap (orc_select.hpp).  keys: [n_pts][3] int64 feat_map keys (NULL: computed from pos with
+// insertPointIntoVoxelMap's formula).  Returns seconds.
+struct orc_select_cfg { double fx, fy, cx, cy; int32_t width, height; double R_cur[9], t_cur[3]; int32_t border, grid_size, grid_n_width, grid_n_height, patch_size_half, pad; };
+double orc_visual_select(const orc_select_cfg *c, const double *pg, int n_pg, const double *pos, const int64_t *keys, const uint8_t *active, int n_pts,
+                         int32_t *cell_point, float *cell_dist, int32_t *cell_type, int32_t *discont, int32_t *in_fov, float *depth_img) {
+  SelectCfg cfg;
+  cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = 0; cfg.cam.width = c->width; cfg.cam.height = c->height;
+  for (int k = 0; k < 5; k++) cfg.cam.d[k] = 0;
+  std::memcpy(cfg.R_cur.a, c->R_cur, 72); std::memcpy(cfg.t_cur.a, c->t_cur, 24);
+  cfg.border = c->border; cfg.grid_size = c->grid_size; cfg.grid_n_width = c->grid_n_width; cfg.grid_n_height = c->grid_n_height; cfg.patch_size_half = c->patch_size_half;
+  std::vector<VisualMapPoint> pts((size_t)n_pts);
+  for (int i = 0; i < n_pts; i++) {
+    pts[i].pos = vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); pts[i].active = active ? active[i] : 1;
+    if (keys) for (int j = 0; j < 3; j++) pts[i].key[j] = keys[3 * (size_t)i + j]; else feat_map_key(pts[i].pos, pts[i].key);
+  }
+  const double t0 = omp_get_wtime();
+  visual_select(cfg, pg, n_pg, pts.data(), n_pts, cell_point, cell_dist, cell_type, discont, in_fov, depth_img);
+  return omp_get_wtime() - t0;
+}
+void orc_feat_map_key(const double *pos3, int64_t *key3) { feat_map_key(vec3(pos3[0], pos3[1], pos3[2]), key3); }
 
 // State algebra (common_lib.h:182-206) and the 19x19 inverse, for known-answer tests.
 void orc_state_boxplus(const StatePOD *s, const double *d19, StatePOD *out) { StatesGroup g; g.from_pod(*s); VState d; std::memcpy(d.a, d19, 152); g += d; g.to_pod(*out); }

@@ -593,3 +593,56 @@ def raw_scan_scenario(seed=51, n_raw=24000, scan_ms=100.0, imu_hz=200.0, extR=No
         p = p + v * dt + 0.5 * acc * dt * dt
         v = v + acc * dt
     return RawScanScenario(np.ascontiguousarray(xyz, np.float32), cur, poses, R, p, extR, extT, float(AVIA["filter_size_surf"] if leaf is None else leaf), c)
+
+
+# ---- inputs of retrieveFromVisualSparseMap's selection half (reference src/vio.cpp:352-486, 598-635) ---------------------------
+@dataclass
+class SelectScenario:
+    pg: np.ndarray             # [n_pg,3] pv_list_ point_w of the current scan
+    pos: np.ndarray            # [n,3] visual map points (VisualPoint::pos_)
+    keys: np.ndarray           # [n,3] int64 feat_map voxel each point is filed under (insertPointIntoVoxelMap)
+    active: np.ndarray         # [n] uint8: pt != nullptr && obs_.size() > 0
+    R_cur: np.ndarray          # new_frame_->T_f_w_
+    t_cur: np.ndarray
+    cam: dict
+    border: int
+    grid_size: int
+    grid_n_width: int
+    grid_n_height: int
+
+
+def feat_map_key_np(pos):
+    """insertPointIntoVoxelMap's key (reference src/vio.cpp:227-236): float(p / 0.5), -1 for negatives, truncation."""
+    loc = (np.asarray(pos, np.float64) / 0.5).astype(np.float32)
+    loc = np.where(loc < 0, (loc.astype(np.float64) - 1.0).astype(np.float32), loc)
+    return loc.astype(np.int64)
+
+
+def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17):
+    rng = np.random.default_rng(seed)
+    cam = dict(AVIA["cam"])
+    extR, extT, Rcl, Pcl = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy(), AVIA["Rcl"].copy(), AVIA["Pcl"].copy()
+    c = dict(AVIA["lio"])
+    scene = make_room(rng, (20.0, 20.0, 6.0), 8)
+    R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
+    t0 = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    xyz = lidar_scan(rng, scene, R0, t0, extR, extT, n_pg + 3 * n_vis, c["dept_err"], c["beam_err"], AVIA["blind"], False).astype(np.float64)
+    pw = (xyz @ extR.T + extT) @ R0.T + t0
+    pg = pw[:n_pg].astype(np.float32).astype(np.float64)            # point_w comes from a float32 cloud
+    pos = pw[n_pg:][rng.permutation(len(pw) - n_pg)[:n_vis]] + rng.normal(0, 0.01, (n_vis, 3))
+    pos[: n_vis // 20] = -pos[: n_vis // 20] + 2 * t0               # a few points behind the camera
+    # foreground clutter in the scan: points ~1 m closer on (almost) the same rays as some visual points -> their depth-image neighbourhood
+    # disagrees with the visual point's depth by more than 0.5 m (the depth-continuity test rejects those)
+    k0, k1 = n_vis // 20, n_vis // 20 + n_vis // 12
+    ray = t0 - pos[k0:k1]
+    fg = pos[k0:k1] + ray / np.linalg.norm(ray, axis=1, keepdims=True) * rng.uniform(0.8, 1.4, (k1 - k0, 1)) + rng.normal(0, 0.01, (k1 - k0, 3))
+    pg = np.concatenate([pg, fg.astype(np.float32).astype(np.float64)])[rng.permutation(len(pg) + len(fg))]
+    Rci, Pci = vio_constants(extR, extT, Rcl, Pcl)
+    R_cur = Rci @ R0.T
+    t_cur = -Rci @ R0.T @ t0 + Pci
+    grid_size = int(cam["height"] / grid_n_height)                   # vio.cpp:74-76
+    gh = int(np.ceil(float(int(cam["height"] / grid_size))))
+    gw = int(np.ceil(float(int(cam["width"] / grid_size))))
+    border = (4 + 1) * (1 << L)                                      # vio.cpp:154
+    active = (rng.uniform(size=n_vis) > 0.05).astype(np.uint8)
+    return SelectScenario(pg, pos, feat_map_key_np(pos), active, R_cur, t_cur, cam, border, grid_size, gw, gh)
