@@ -88,6 +88,10 @@ def cpu_baseline(sc, budget_s=20.0):
     rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
     orc.warp_candidates(rs, lib)
     warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
+    from tests import imu_inputs as IMU
+    ist = IMU.make_state(orc, orc.StatePOD, 0)
+    orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)
+    imu_us = 1e6 * min(orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)[2] for _ in range(5))
     ss = _synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
     orc.visual_select(ss, lib)
     sel_s = min(orc.visual_select(ss, lib)["seconds"] for _ in range(3))
@@ -98,7 +102,7 @@ def cpu_baseline(sc, budget_s=20.0):
         u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
         orc.voxel_grid(u_, raw.leaf, lib)
         tpre.append(time.perf_counter() - t0)
-    return {"select_seconds_1thread": sel_s, "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
+    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
             "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "value_1thread": out[1][0], "value_all_cores": out[ncores][0], "host_cores": ncores}
@@ -298,6 +302,22 @@ def main():
         extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
         extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
         ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
+        # IMU forward propagation (20 samples = 100 ms at 200 Hz)
+        from tests import imu_inputs as IMU
+        ist = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P); ist.grav[:] = [0.0, 0.0, -9.81]
+        icfg = livo2.ImuCfg()
+        for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+            getattr(icfg, k)[:] = IMU.CFG[k]
+        icfg.cov_inv_expo, icfg.G_m_s2, icfg.mean_acc_norm = IMU.CFG["cov_inv_expo"], IMU.CFG["G_m_s2"], IMU.CFG["mean_acc_norm"]
+        icfg.ba_bg_est_en = icfg.gravity_est_en = icfg.exposure_estimate_en = 1
+        isteps = IMU.make_steps(0, n=20)
+        ctx.imu_propagate(ist, isteps, icfg)
+        us = []
+        for _ in range(5):
+            ctx.imu_propagate(ist, isteps, icfg); us.append(ctx.imu_last_kernel_us())
+        extra["imu_propagate"] = {"samples": 20, "kernel_us": float(np.median(us)), "us_per_sample": float(np.median(us)) / 20,
+                                  "note": "k_imu_propagate: one block, sequential over the samples (19x19 F P F^T + Q per sample); latency-bound, on par with a host core "
+                                          "(cpu_baseline.imu_propagate_us_20_samples) — built so that state_propagat / IMUpose can be produced next to their consumers"}
         # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
         raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
         ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)

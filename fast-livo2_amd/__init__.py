@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (Cam, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveOut, SelectCfg, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
+from .abi import (Cam, ImuCfg, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveOut, SelectCfg, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
 
 
 class Livo2Error(RuntimeError):
@@ -164,6 +164,18 @@ class Context:
 
     def lidar_iterations_async(self, state_in, prop, cfg, iters):
         self._chk(self.lib.livo2_lidar_iterations_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
+
+    # ---- IMU forward propagation ----------------------------------------------------------------------------------
+    def imu_propagate(self, state_in, steps, cfg):
+        """steps: [n][8] = gyr3, acc3, dt, offs_t (averaged raw measurements); cfg: abi.ImuCfg.  Returns (state_out, poses [n][22])."""
+        S = np.ascontiguousarray(steps, np.float64).reshape(-1, 8)
+        out = State()
+        poses = np.zeros((max(len(S), 1), 22))
+        self._chk(self.lib.livo2_imu_propagate(self.h, C.byref(state_in), S.ctypes.data_as(C.c_void_p), len(S), C.byref(cfg), C.byref(out), poses.ctypes.data_as(C.c_void_p)))
+        return out, poses[: len(S)]
+
+    def imu_last_kernel_us(self):
+        return float(self.lib.livo2_imu_propagate_last_kernel_us(self.h))
 
     # ---- map maintenance ---------------------------------------------------------------------------------------
     def plane_fit_batch(self, point_w, var, offsets, planer_threshold, plane_idx=None):

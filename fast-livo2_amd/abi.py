@@ -129,6 +129,12 @@ class RetrieveOut(C.Structure):
                 ("A_cur_ref", C.POINTER(C.c_double)), ("patch_wrap", C.POINTER(C.c_float))]
 
 
+class ImuCfg(C.Structure):
+    _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3), ("cov_bias_acc", C.c_double * 3), ("cov_inv_expo", C.c_double),
+                ("G_m_s2", C.c_double), ("mean_acc_norm", C.c_double), ("ba_bg_est_en", C.c_int32), ("gravity_est_en", C.c_int32), ("exposure_estimate_en", C.c_int32),
+                ("pad", C.c_int32)]
+
+
 class SelectCfg(C.Structure):
     _fields_ = [("cam", Cam), ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_width", C.c_int32),
                 ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32)]
@@ -169,6 +175,8 @@ SIGNATURES = {
     "livo2_ctx_kernel_timing_read": (C.c_int, [_CTX, C.c_int, _P(C.c_double), _P(C.c_int64), C.c_int]),
     "livo2_map_upload": (C.c_int, [_CTX, _P(MapView)]),
     "livo2_map_update_planes": (C.c_int, [_CTX, _P(C.c_int32), C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_float), _P(C.c_float)]),
+    "livo2_imu_propagate": (C.c_int, [_CTX, _P(State), C.c_void_p, C.c_int32, _P(ImuCfg), _P(State), C.c_void_p]),
+    "livo2_imu_propagate_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_plane_fit_batch": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_int32, C.c_float, _P(C.c_int32), _P(PlaneFit)]),
     "livo2_plane_fit_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_lidar_set_scan": (C.c_int, [_CTX, _P(C.c_float), C.c_int32, _P(LidarCfg)]),

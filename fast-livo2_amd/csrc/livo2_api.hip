@@ -11,6 +11,7 @@
 #include "retrieve_kernels.hpp"
 #include "preprocess_kernels.hpp"
 #include "select_kernels.hpp"
+#include "imu_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -64,6 +65,9 @@ struct livo2_ctx {
   double *d_sel_pg = nullptr; size_t sel_pg_cap = 0; unsigned long long *d_sel_set = nullptr, *d_sel_depth = nullptr, *d_sel_best = nullptr; size_t sel_set_cap = 0, sel_depth_cap = 0, sel_best_cap = 0;
   int32_t *d_sel_type = nullptr, *d_sel_point = nullptr, *d_sel_flag = nullptr; float *d_sel_dist = nullptr; uint8_t *d_sel_disc = nullptr; size_t sel_type_cap = 0, sel_point_cap = 0, sel_dist_cap = 0, sel_disc_cap = 0;
   double select_kernel_us = 0.0;
+  // IMU propagation (N4)
+  double *d_imu_steps = nullptr, *d_imu_poses = nullptr; size_t imu_steps_cap = 0, imu_poses_cap = 0; livo2_state *d_imu_state = nullptr;   // [2]: in, out
+  double imu_kernel_us = 0.0;
   // scan
   bool has_scan = false;
   int n = 0, n_cap = 0;
@@ -349,7 +353,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl, ctx->d_c_acc,
                  ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch, ctx->d_raw, ctx->d_curv, ctx->d_poses, ctx->d_vg_head, ctx->d_vg_slot, ctx->d_vg_misc,
                  ctx->d_vm_pos, ctx->d_vm_pkey, ctx->d_vm_active, ctx->d_vm_fov, ctx->d_sel_pg, ctx->d_sel_set, ctx->d_sel_depth, ctx->d_sel_best, ctx->d_sel_type, ctx->d_sel_point,
-                 ctx->d_sel_flag, ctx->d_sel_dist, ctx->d_sel_disc};
+                 ctx->d_sel_flag, ctx->d_sel_dist, ctx->d_sel_disc, ctx->d_imu_steps, ctx->d_imu_poses, ctx->d_imu_state};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -538,6 +542,43 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_gpos));
   return LIVO2_OK;
 }
+
+// ---- IMU forward propagation -----------------------------------------------------------------------------------------------------
+int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu_step *steps, int32_t n, const livo2_imu_cfg *cfg, livo2_state *state_out,
+                        livo2_imu_pose *poses) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!state_in || !state_out || !cfg || n < 0 || n > 65536 || (n > 0 && (!steps || !poses))) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!(cfg->mean_acc_norm > 0)) return fail(ctx, LIVO2_ERR_INVALID, "mean_acc_norm must be > 0");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_imu_steps, ctx->imu_steps_cap, std::max((size_t)n * 8, (size_t)8)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_imu_poses, ctx->imu_poses_cap, std::max((size_t)n * 22, (size_t)22)))) return rc;
+  if (!ctx->d_imu_state) HIPCHK(hipMalloc((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
+  static_assert(sizeof(livo2_imu_step) == 64, "livo2_imu_step is 8 doubles");
+  HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) HIPCHK(hipMemcpyAsync(ctx->d_imu_steps, steps, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
+  ImuKernelArgs a{};
+  a.steps = ctx->d_imu_steps; a.n = n; a.ba_bg_est_en = cfg->ba_bg_est_en; a.gravity_est_en = cfg->gravity_est_en; a.exposure_estimate_en = cfg->exposure_estimate_en;
+  std::memcpy(a.cov_gyr, cfg->cov_gyr, 24); std::memcpy(a.cov_acc, cfg->cov_acc, 24); std::memcpy(a.cov_bias_gyr, cfg->cov_bias_gyr, 24); std::memcpy(a.cov_bias_acc, cfg->cov_bias_acc, 24);
+  a.cov_inv_expo = cfg->cov_inv_expo; a.G_m_s2 = cfg->G_m_s2; a.mean_acc_norm = cfg->mean_acc_norm;
+  a.in = ctx->d_imu_state; a.out = ctx->d_imu_state + 1; a.poses = ctx->d_imu_poses;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(k_imu_propagate, dim3(1), dim3(IMU_THREADS), 0, ctx->stream, a);
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(state_out, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
+  if (n > 0) HIPCHK(hipMemcpyAsync(poses, ctx->d_imu_poses, (size_t)n * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  ctx->imu_kernel_us = 1e3 * ms;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  return LIVO2_OK;
+}
+double livo2_imu_propagate_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->imu_kernel_us : 0.0; }
 
 // ---- map maintenance: batched plane fit ----------------------------------------------------------------------------------------
 int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *var, const int32_t *offsets, int32_t n_groups, float planer_threshold,

@@ -95,6 +95,23 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *map);
 int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n, const double *normal, const double *center,
                             const double *plane_var, const float *d, const float *radius);
 
+/* ---- IMU forward propagation ----------------------------------------------------------------------------------------
+ * The forward loop of ImuProcess::UndistortPcl (src/IMU_Processing.cpp:298-445): state_in = state_inout at prop_beg_time; per IMU sample
+ * pair a step carries the averaged raw measurements 0.5 * (head + tail) (335-341), dt and offs_t — the time-stamp logic that yields them
+ * (332, 355-372) stays with the caller.  state_out = state_propagat (rot_end, pos_end, vel_end, cov; biases, gravity, inv_expo_time
+ * unchanged); poses[n_steps] = the Pose6D pushed per sample (the entry at offset 0, IMU_Processing.cpp:281, is the caller's).
+ * cfg: cov_gyr / cov_acc / cov_bias_gyr / cov_bias_acc / cov_inv_expo (IMU_Processing.cpp:19-23, 92-100), G_m_s2 (common_lib.h:29),
+ * mean_acc_norm = mean_acc.norm() (353), and the three estimation switches (386-390, 395). */
+typedef struct livo2_imu_step { double gyr[3], acc[3], dt, offs_t; } livo2_imu_step;
+typedef struct livo2_imu_cfg {
+  double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm;
+  int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en, pad;
+} livo2_imu_cfg;
+struct livo2_imu_pose;
+int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu_step *steps, int32_t n_steps, const livo2_imu_cfg *cfg,
+                        livo2_state *state_out, struct livo2_imu_pose *poses);
+double livo2_imu_propagate_last_kernel_us(const livo2_ctx *ctx);
+
 /* ---- map maintenance: batched plane fit ----------------------------------------------------------------
  * VoxelOctoTree::init_plane (src/voxel_map.cpp:55-135) for n_groups voxels at once: group g owns points
  * [offsets[g], offsets[g+1]) of point_w / var (pointWithVar::point_w, ::var of its temp_points_).  out[g] receives the VoxelPlane

@@ -269,6 +269,34 @@ def feat_map_keys(pos, lib=None):
     return keys
 
 
+class ImuCfg(C.Structure):
+    _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3), ("cov_bias_acc", C.c_double * 3), ("cov_inv_expo", C.c_double),
+                ("G_m_s2", C.c_double), ("mean_acc_norm", C.c_double), ("ba_bg_est_en", C.c_int32), ("gravity_est_en", C.c_int32), ("exposure_estimate_en", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+def imu_cfg(d, cls=ImuCfg):
+    c = cls()
+    for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+        getattr(c, k)[:] = [float(x) for x in d[k]]
+    c.cov_inv_expo, c.G_m_s2, c.mean_acc_norm = float(d["cov_inv_expo"]), float(d["G_m_s2"]), float(d["mean_acc_norm"])
+    c.ba_bg_est_en, c.gravity_est_en, c.exposure_estimate_en = int(d["ba_bg_est_en"]), int(d["gravity_est_en"]), int(d["exposure_estimate_en"])
+    return c
+
+
+def imu_propagate(state_in, steps, cfg_dict, lib=None):
+    """IMU forward propagation (src/IMU_Processing.cpp:298-445); steps: [n][8] = gyr3, acc3, dt, offs_t.  Returns (state_out, poses [n][22], seconds)."""
+    lib = lib or load()
+    S = np.ascontiguousarray(steps, np.float64).reshape(-1, 8)
+    out = StatePOD()
+    poses = np.zeros((max(len(S), 1), 22))
+    c = imu_cfg(cfg_dict)
+    lib.orc_imu_propagate.restype = C.c_double
+    lib.orc_imu_propagate.argtypes = [C.POINTER(StatePOD), C.c_void_p, C.c_int, C.POINTER(ImuCfg), C.POINTER(StatePOD), C.c_void_p]
+    secs = lib.orc_imu_propagate(C.byref(state_in), S.ctypes.data_as(C.c_void_p), len(S), C.byref(c), C.byref(out), poses.ctypes.data_as(C.c_void_p))
+    return out, poses[: len(S)], secs
+
+
 def lidar_cfg(c, extR, extT, num_threads=1, deg2rad=0.017453293):
     cfg = LidarCfg()
     cfg.max_iterations, cfg.max_layer = int(c["max_iterations"]), int(c["max_layer"])

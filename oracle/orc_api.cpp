@@ -12,6 +12,7 @@
 #include "orc_warp.hpp"
 #include "orc_preprocess.hpp"
 #include "orc_select.hpp"
+#include "orc_imu.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -430,6 +431,25 @@ double orc_visual_select(const orc_select_cfg *c, const double *pg, int n_pg, co
   return omp_get_wtime() - t0;
 }
 void orc_feat_map_key(const double *pos3, int64_t *key3) { feat_map_key(vec3(pos3[0], pos3[1], pos3[2]), key3); }
+
+// IMU forward propagation (orc_imu.hpp).  steps: n x 8 doubles (gyr3, acc3, dt, offs_t); cfg: 13 doubles + 3 flags; poses out: n x 22 doubles.
+struct orc_imu_cfg { double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm; int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en, pad; };
+double orc_imu_propagate(const StatePOD *in, const double *steps8, int n, const orc_imu_cfg *c, StatePOD *out, double *poses22) {
+  StatesGroup st; st.from_pod(*in);
+  ImuCfg cfg;
+  std::memcpy(cfg.cov_gyr, c->cov_gyr, 24); std::memcpy(cfg.cov_acc, c->cov_acc, 24); std::memcpy(cfg.cov_bias_gyr, c->cov_bias_gyr, 24); std::memcpy(cfg.cov_bias_acc, c->cov_bias_acc, 24);
+  cfg.cov_inv_expo = c->cov_inv_expo; cfg.G_m_s2 = c->G_m_s2; cfg.mean_acc_norm = c->mean_acc_norm;
+  cfg.ba_bg_est_en = c->ba_bg_est_en; cfg.gravity_est_en = c->gravity_est_en; cfg.exposure_estimate_en = c->exposure_estimate_en;
+  std::vector<ImuStep> S((size_t)n); std::vector<Pose6D> P((size_t)n);
+  static_assert(sizeof(ImuStep) == 64, "ImuStep is 8 doubles");
+  if (n) std::memcpy(S.data(), steps8, (size_t)n * 64);
+  const double t0 = omp_get_wtime();
+  imu_propagate(st, S.data(), n, cfg, P.data());
+  const double dt = omp_get_wtime() - t0;
+  st.to_pod(*out);
+  if (n) std::memcpy(poses22, P.data(), (size_t)n * sizeof(Pose6D));
+  return dt;
+}
 
 // State algebra (common_lib.h:182-206) and the 19x19 inverse, for known-answer tests.
 void orc_state_boxplus(const StatePOD *s, const double *d19, StatePOD *out) { StatesGroup g; g.from_pod(*s); VState d; std::memcpy(d.a, d19, 152); g += d; g.to_pod(*out); }
