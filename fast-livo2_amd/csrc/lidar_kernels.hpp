@@ -34,7 +34,6 @@ struct LidarKernelArgs {
   int32_t *match_plane; float *dis; float *pw; int32_t *normal_plane; double *var; double *r_inv; double *h_row;
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *prof;        // [waves][8] s_memtime stamps (profiling build only)
-  int32_t dbg;                     // access-pattern experiments (profiling build only)
 #endif
 };
 
@@ -249,17 +248,6 @@ __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double
   }
 }
 
-// covariance part of a plane record (21 doubles at offset 6) in one batch of 16-B loads
-__device__ __forceinline__ void load_plane_S(const double *__restrict__ planes, int32_t pidx, double *S) {
-  const double2 *P2 = reinterpret_cast<const double2 *>(planes + (size_t)pidx * PLANE_REC_DOUBLES + 6);
-  double2 v[11];
-#pragma unroll
-  for (int q = 0; q < 11; q++) v[q] = P2[q];
-#pragma unroll
-  for (int q = 0; q < 10; q++) { S[2 * q] = v[q].x; S[2 * q + 1] = v[q].y; }
-  S[20] = v[10].x;
-}
-
 __device__ __forceinline__ bool slot_match(const RootSlot &s, const int32_t key[3]) { return s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]; }
 
 __device__ __forceinline__ RootSlot load_slot(const RootSlot *__restrict__ slots, uint32_t h) {
@@ -274,12 +262,10 @@ __device__ __forceinline__ RootSlot load_slot(const RootSlot *__restrict__ slots
 }
 
 // Visit one root voxel (build_single_residual from layer 0).
-//  * plane root: the whole 256-B record in one batch, radius gate, 3-sigma gate.
-//  * non-plane root: the depth-first list of descendant planes (layers <= max_layer) was flattened at upload into contiguous 64-B
-//    GATE records {normal_, center_, d_, radius_, plane index|layer}; four of them travel per round trip, the radius gate runs on
-//    all four, and the 168-B covariance part is fetched only for the planes that pass it.  A k-candidate voxel thus costs
-//    ceil(k/4) + (#planes passing the radius gate) round trips instead of the 2k of walking the octree node by node — the tail of
-//    this kernel (it ends with its slowest wave).  Candidates are still evaluated in depth-first order, so ties keep the first.
+//  * plane root: the whole 256-B record in one batch, radius gate, 3-sigma gate (visit_plane_root).
+//  * non-plane root: the depth-first list of descendant planes (layers <= max_layer) was flattened at upload into contiguous copies
+//    of their 256-B records (word [28] = plane index | layer); the block evaluates all such (point, candidate) pairs cooperatively
+//    (coop_plan / coop_run below), in depth-first order so that ties keep the first.
 struct RootRef { int32_t val, cand_begin, cand_count; };   // what a visit needs from a RootSlot
 
 __device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *R, const double *RE,
@@ -571,14 +557,6 @@ __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, co
       const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
       n1 = load_slot(a.map.slots, g1); n2 = load_slot(a.map.slots, g2);
     }
-#ifdef LIVO2_PHASE_PROF
-    if (s.val >= 0 && a.dbg) {       // timing experiments only: force an access pattern on the plane gather
-      if (a.dbg == 1) s.val = 0;
-      else if (a.dbg == 2) s.val = (i >> 2) % a.map.n_planes;
-      else if (a.dbg == 3) s.val = (i >> 4) % a.map.n_planes;
-      else if (a.dbg == 4) s.val = (int)(((unsigned)i * 7919u) % (unsigned)a.map.n_planes);
-    }
-#endif
     if (s.val >= 0) load_plane(a.map.planes, s.val, p0);         // issued right behind the neighbour slots: same round trip
     // while that trip is in flight: plan the cooperative visit of the block's non-plane roots (LDS + one barrier only)
     const CoopPlan plan1 = coop_plan(coop, 0, (s.val == -2) ? s.cand_count : 0, s.cand_begin);

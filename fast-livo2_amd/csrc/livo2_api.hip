@@ -231,7 +231,6 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
     if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64 + 128 + waves * 16 + waves * 128); (void)e; ctx->prof_waves = waves; }
     hipError_t e = hipMemsetAsync(ctx->d_prof, 0, waves * 64, ctx->stream); (void)e;
     a.prof = ctx->d_prof;
-    { const char *e = getenv("LIVO2_DBG"); a.dbg = e ? atoi(e) : 0; }
   }
 #endif
   const livo2_lidar_points &w = ctx->want_l;
