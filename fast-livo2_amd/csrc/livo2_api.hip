@@ -1176,7 +1176,7 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
   HIPCHK(hipMemsetAsync(ctx->d_sel_type, 0, (size_t)length * 4, ctx->stream));
   if (n_pg > 0) hipLaunchKernelGGL(k_sel_scan, dim3((n_pg + 255) / 256), dim3(256), 0, ctx->stream, a);
   if (ctx->n_vm > 0) hipLaunchKernelGGL(k_sel_points, dim3((ctx->n_vm + 255) / 256), dim3(256), 0, ctx->stream, a);
-  hipLaunchKernelGGL(k_sel_cells, dim3((length + 255) / 256), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_sel_cells, dim3((length + 3) / 4), dim3(256), 0, ctx->stream, a);
   HIPCHK(hipEventRecord(e1, ctx->stream));
   HIPCHK(hipGetLastError());
   int32_t flag = 0;

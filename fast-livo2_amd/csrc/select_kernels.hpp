@@ -5,7 +5,7 @@
 //   B  k_sel_points  every visual map point whose feat_map voxel is in that set: behind-camera / in-frame tests, grid cell, and the
 //                    nearest point per cell (64-bit atomicMin on {float distance bits, point index}; the reference's `<=` lets the last
 //                    VISITED of exactly equidistant points win, here the lowest index does — float ties only);
-//   C  k_sel_cells   per grid cell: the depth-continuity test of the selected point against the 9x9 depth-image window.
+//   C  k_sel_cells   per grid cell (one wave): the depth-continuity test of the selected point against the 9x9 depth-image window.
 // The visual map lives on the device as flat arrays (position, the voxel it is filed under, active flag), uploaded by
 // livo2_visual_map_upload.  Both voxel-key formulas are the reference's own, mismatch for negative coordinates included
 // (vio.cpp:392-396 vs 232-236).  vikit's world2cam / isInFrame restated (zero-distortion pinhole): parity unpinned at that boundary.
@@ -128,10 +128,12 @@ __global__ void __launch_bounds__(256) k_sel_points(SelectArgs a) {
   a.in_fov[i] = fov;
 }
 
+// one wave per grid cell: the lanes share the (2 patch_size_half + 1)^2 depth-image window of the selected point
 __global__ void __launch_bounds__(256) k_sel_cells(SelectArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= a.length) return;
-  int32_t point = -1; float dist = 10000.0f; uint8_t discont = 0;
+  int32_t point = -1; float dist = 10000.0f; bool discont = false;
   const unsigned long long best = a.cell_best[c];
   if (a.cell_type[c] == 1 && best != SEL_EMPTY) {
     const float d = __builtin_bit_cast(float, (uint32_t)(best >> 32));
@@ -141,14 +143,16 @@ __global__ void __launch_bounds__(256) k_sel_cells(SelectArgs a) {
       double pc3[3], px[2];
       sel_project(a, p, pc3, px);
       const int u0 = (int)px[0], v0 = (int)px[1];
-      for (int u = -a.patch_size_half; u <= a.patch_size_half; u++)
-        for (int v = -a.patch_size_half; v <= a.patch_size_half; v++) {
-          if (u == 0 && v == 0) continue;
-          const float depth = __builtin_bit_cast(float, (uint32_t)a.depth[(size_t)a.width * (v + v0) + u + u0]);
-          if (depth == 0.f) continue;
-          if (fabs(pc3[2] - (double)depth) > 0.5) discont = 1;
-        }
+      const int side = 2 * a.patch_size_half + 1;
+      for (int k = lane; k < side * side; k += 64) {
+        const int u = k / side - a.patch_size_half, v = k % side - a.patch_size_half;
+        if (u == 0 && v == 0) continue;
+        const float depth = __builtin_bit_cast(float, (uint32_t)a.depth[(size_t)a.width * (v + v0) + u + u0]);
+        if (depth == 0.f) continue;
+        if (fabs(pc3[2] - (double)depth) > 0.5) discont = true;
+      }
     }
   }
-  a.cell_point[c] = point; a.cell_dist[c] = dist; a.cell_discont[c] = discont;
+  const bool any = __ballot(discont) != 0ull;
+  if (lane == 0) { a.cell_point[c] = point; a.cell_dist[c] = dist; a.cell_discont[c] = any ? 1 : 0; }
 }
