@@ -66,6 +66,188 @@ void VoxelMapManager::RefreshPlanes(const std::vector<const VoxelPlane *> &plane
   dev_.check(livo2_map_update_planes(dev_.ctx(), idx.data(), (int32_t)idx.size(), n.data(), c.data(), pv.data(), d.data(), r.data()));
 }
 
+// ---- map maintenance with device-side plane fits ---------------------------------------------------------------------------------------
+VoxelOctoTree *VoxelOctoTree::clone() const {
+  VoxelOctoTree *c = new VoxelOctoTree(max_layer_, layer_, points_size_threshold_, max_points_num_, planer_threshold_);
+  c->temp_points_ = temp_points_; *c->plane_ptr_ = *plane_ptr_;
+  std::memcpy(c->voxel_center_, voxel_center_, sizeof(voxel_center_)); c->quater_length_ = quater_length_;
+  c->octo_state_ = octo_state_; c->new_points_ = new_points_; c->update_size_threshold_ = update_size_threshold_;
+  c->init_octo_ = init_octo_; c->update_enable_ = update_enable_; c->layer_init_num_ = layer_init_num_;
+  for (int k = 0; k < 8; k++) c->leaves_[k] = leaves_[k] ? leaves_[k]->clone() : nullptr;
+  return c;
+}
+
+namespace {
+
+typedef std::vector<uint8_t> NodePath;                       // child indices from the root
+struct FitRequest { NodePath path; int seq; std::vector<pointWithVar> points; };
+typedef std::map<std::pair<NodePath, int>, livo2_plane_fit> FitCache;
+
+// One replay of a root voxel's share of the scan on a scratch copy of its subtree.  The octree logic below is the reference's
+// (UpdateOctoTree / init_octo_tree / cut_octo_tree, src/voxel_map.cpp:137-290) with init_plane replaced by a lookup of the device's
+// answer; a missing answer is queued and the replay abandoned at the next point where the control flow would depend on it.
+struct Replay {
+  const FitCache &cache;
+  std::vector<FitRequest> requests;
+  std::map<NodePath, int> calls;                             // init_plane calls seen per node in this replay
+  bool pending = false;
+  explicit Replay(const FitCache &c) : cache(c) {}
+
+  bool fit(VoxelOctoTree *node, const NodePath &path) {      // VoxelOctoTree::init_plane(node->temp_points_, node->plane_ptr_)
+    const int seq = calls[path]++;
+    auto it = cache.find({path, seq});
+    if (it == cache.end()) { requests.push_back({path, seq, node->temp_points_}); pending = true; return false; }
+    const livo2_plane_fit &f = it->second;
+    VoxelPlane *p = node->plane_ptr_;
+    std::memcpy(p->center_.data(), f.center, 24); std::memcpy(p->covariance_.data(), f.covariance, 72); std::memcpy(p->plane_var_.data(), f.plane_var, 288);
+    std::memcpy(p->normal_.data(), f.normal, 24); p->points_size_ = f.points_size; p->radius_ = f.radius;
+    if (f.is_plane) {
+      std::memcpy(p->y_normal_.data(), f.y_normal, 24); std::memcpy(p->x_normal_.data(), f.x_normal, 24);
+      p->min_eigen_value_ = f.min_eigen_value; p->mid_eigen_value_ = f.mid_eigen_value; p->max_eigen_value_ = f.max_eigen_value; p->d_ = f.d;
+    }
+    p->is_plane_ = f.is_plane != 0; p->is_update_ = true;
+    return true;
+  }
+
+  VoxelOctoTree *new_leaf(VoxelOctoTree *n, const int xyz[3]) {          // voxel_map.cpp:179-186 / 255-262
+    VoxelOctoTree *l = new VoxelOctoTree(n->max_layer_, n->layer_ + 1, n->layer_init_num_[n->layer_ + 1], n->max_points_num_, n->planer_threshold_);
+    l->layer_init_num_ = n->layer_init_num_;
+    for (int k = 0; k < 3; k++) l->voxel_center_[k] = n->voxel_center_[k] + (2 * xyz[k] - 1) * n->quater_length_;
+    l->quater_length_ = n->quater_length_ / 2;
+    return l;
+  }
+  static int leaf_of(const VoxelOctoTree *n, const pointWithVar &pv, int xyz[3]) {
+    for (int k = 0; k < 3; k++) xyz[k] = pv.point_w[k] > n->voxel_center_[k] ? 1 : 0;
+    return 4 * xyz[0] + 2 * xyz[1] + xyz[2];
+  }
+
+  void cut_octo_tree(VoxelOctoTree *n, const NodePath &path) {           // voxel_map.cpp:163-217
+    if (n->layer_ >= n->max_layer_) { n->octo_state_ = 0; return; }
+    for (const pointWithVar &pv : n->temp_points_) {
+      int xyz[3]; const int leafnum = leaf_of(n, pv, xyz);
+      if (!n->leaves_[leafnum]) n->leaves_[leafnum] = new_leaf(n, xyz);
+      n->leaves_[leafnum]->temp_points_.push_back(pv);
+      n->leaves_[leafnum]->new_points_++;
+    }
+    for (int i = 0; i < 8; i++) {
+      VoxelOctoTree *l = n->leaves_[i];
+      if (!l || (int)l->temp_points_.size() <= l->points_size_threshold_) continue;
+      NodePath lp = path; lp.push_back((uint8_t)i);
+      if (!fit(l, lp)) continue;                                           // the siblings' fits do not depend on this one: ask for all of them in one sweep
+      if (l->plane_ptr_->is_plane_) {
+        l->octo_state_ = 0;
+        if ((int)l->temp_points_.size() > l->max_points_num_) { l->update_enable_ = false; std::vector<pointWithVar>().swap(l->temp_points_); n->new_points_ = 0; }
+      } else { l->octo_state_ = 1; cut_octo_tree(l, lp); }
+      l->init_octo_ = true;
+      l->new_points_ = 0;
+    }
+  }
+
+  void init_octo_tree(VoxelOctoTree *n, const NodePath &path) {          // voxel_map.cpp:137-161
+    if ((int)n->temp_points_.size() <= n->points_size_threshold_) return;
+    if (!fit(n, path)) return;
+    if (n->plane_ptr_->is_plane_) {
+      n->octo_state_ = 0;
+      if ((int)n->temp_points_.size() > n->max_points_num_) { n->update_enable_ = false; std::vector<pointWithVar>().swap(n->temp_points_); n->new_points_ = 0; }
+    } else { n->octo_state_ = 1; cut_octo_tree(n, path); }
+    n->init_octo_ = true;
+    n->new_points_ = 0;
+  }
+
+  void UpdateOctoTree(VoxelOctoTree *n, const NodePath &path, const pointWithVar &pv) {   // voxel_map.cpp:219-290
+    if (!n->init_octo_) {
+      n->new_points_++; n->temp_points_.push_back(pv);
+      if ((int)n->temp_points_.size() > n->points_size_threshold_) init_octo_tree(n, path);
+      return;
+    }
+    if (n->plane_ptr_->is_plane_) {
+      if (n->update_enable_) {
+        n->new_points_++; n->temp_points_.push_back(pv);
+        if (n->new_points_ > n->update_size_threshold_) { if (!fit(n, path)) return; n->new_points_ = 0; }
+        if ((int)n->temp_points_.size() >= n->max_points_num_) { n->update_enable_ = false; std::vector<pointWithVar>().swap(n->temp_points_); n->new_points_ = 0; }
+      }
+      return;
+    }
+    if (n->layer_ < n->max_layer_) {
+      int xyz[3]; const int leafnum = leaf_of(n, pv, xyz);
+      if (!n->leaves_[leafnum]) n->leaves_[leafnum] = new_leaf(n, xyz);
+      NodePath lp = path; lp.push_back((uint8_t)leafnum);
+      UpdateOctoTree(n->leaves_[leafnum], lp, pv);
+    } else if (n->update_enable_) {
+      n->new_points_++; n->temp_points_.push_back(pv);
+      if (n->new_points_ > n->update_size_threshold_) { if (!fit(n, path)) return; n->new_points_ = 0; }
+      if ((int)n->temp_points_.size() > n->max_points_num_) { n->update_enable_ = false; std::vector<pointWithVar>().swap(n->temp_points_); n->new_points_ = 0; }
+    }
+  }
+};
+
+struct RootWork { VOXEL_LOCATION key; std::vector<int> points; FitCache cache; bool done = false; };
+
+} // namespace
+
+void VoxelMapManager::maintain(const std::vector<pointWithVar> &input_points, bool build) {
+  const float voxel_size = (float)config_setting_.max_voxel_size_;
+  const float planer_threshold = (float)config_setting_.planner_threshold_;
+  // root voxel of every point, in input order (voxel_map.cpp:559-567 / 617-625: float division, -1 for negatives, truncation)
+  std::unordered_map<VOXEL_LOCATION, size_t, VoxelLocationHash> index;
+  std::vector<RootWork> work;
+  for (size_t i = 0; i < input_points.size(); i++) {
+    float loc_xyz[3];
+    for (int j = 0; j < 3; j++) { loc_xyz[j] = (float)(input_points[i].point_w[j] / voxel_size); if (loc_xyz[j] < 0) loc_xyz[j] -= 1.0; }
+    const VOXEL_LOCATION position((int64_t)loc_xyz[0], (int64_t)loc_xyz[1], (int64_t)loc_xyz[2]);
+    auto it = index.find(position);
+    if (it == index.end()) { it = index.emplace(position, work.size()).first; work.push_back(RootWork{position, {}, {}, false}); }
+    work[it->second].points.push_back((int)i);
+  }
+  last_fit_rounds_ = 0; last_fit_count_ = 0;
+  size_t remaining = work.size();
+  while (remaining > 0) {
+    std::vector<double> pw, var; std::vector<int32_t> off{0};
+    struct Owner { size_t w; NodePath path; int seq; };
+    std::vector<Owner> owners;
+    for (size_t w = 0; w < work.size(); w++) {
+      RootWork &rw = work[w];
+      if (rw.done) continue;
+      auto it = voxel_map_.find(rw.key);
+      VoxelOctoTree *root;
+      if (it != voxel_map_.end()) root = it->second->clone();
+      else {                                                             // voxel_map.cpp:574-583 / 630-637
+        root = new VoxelOctoTree(config_setting_.max_layer_, 0, config_setting_.layer_init_num_[0], config_setting_.max_points_num_, planer_threshold);
+        root->layer_init_num_ = config_setting_.layer_init_num_;
+        root->quater_length_ = voxel_size / 4;
+        root->voxel_center_[0] = (0.5 + rw.key.x) * voxel_size; root->voxel_center_[1] = (0.5 + rw.key.y) * voxel_size; root->voxel_center_[2] = (0.5 + rw.key.z) * voxel_size;
+      }
+      Replay rp(rw.cache);
+      if (build) {                                                       // BuildVoxelMap: all points first, then init_octo_tree (voxel_map.cpp:568-590)
+        for (int i : rw.points) { root->temp_points_.push_back(input_points[i]); root->new_points_++; }
+        rp.init_octo_tree(root, NodePath());
+      } else {
+        for (int i : rw.points) { rp.UpdateOctoTree(root, NodePath(), input_points[i]); if (rp.pending) break; }
+      }
+      if (!rp.pending) {
+        if (it != voxel_map_.end()) { delete it->second; it->second = root; } else voxel_map_[rw.key] = root;
+        rw.done = true; remaining--;
+        continue;
+      }
+      delete root;
+      for (FitRequest &rq : rp.requests) {
+        for (const pointWithVar &pv : rq.points) { pw.insert(pw.end(), pv.point_w.begin(), pv.point_w.end()); var.insert(var.end(), pv.var.begin(), pv.var.end()); }
+        off.push_back((int32_t)(pw.size() / 3));
+        owners.push_back({w, rq.path, rq.seq});
+      }
+    }
+    if (owners.empty()) break;
+    std::vector<livo2_plane_fit> fit(owners.size());
+    dev_.check(livo2_plane_fit_batch(dev_.ctx(), pw.data(), var.data(), off.data(), (int32_t)owners.size(), planer_threshold, nullptr, fit.data()));
+    for (size_t g = 0; g < owners.size(); g++) work[owners[g].w].cache[{owners[g].path, owners[g].seq}] = fit[g];
+    last_fit_rounds_++; last_fit_count_ += (int)owners.size();
+  }
+  map_dirty_ = true;                                                      // the snapshot is re-flattened before the next StateEstimation
+}
+
+void VoxelMapManager::BuildVoxelMap(const std::vector<pointWithVar> &input_points) { maintain(input_points, true); }
+void VoxelMapManager::UpdateVoxelMap(const std::vector<pointWithVar> &input_points) { maintain(input_points, false); }
+
 void VoxelMapManager::FitPlanes(const std::vector<VoxelOctoTree *> &voxels) {
   const int G = (int)voxels.size();
   if (G == 0) return;

@@ -11,6 +11,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -82,7 +83,7 @@ struct VoxelLocationHash {                  // reference include/voxel_map.h:109
   }
 };
 
-struct VoxelOctoTree {                      // reference include/voxel_map.h:129-183 (fields the update / the plane fit read)
+struct VoxelOctoTree {                      // reference include/voxel_map.h:129-183
   std::vector<pointWithVar> temp_points_;
   float planer_threshold_ = 0.0025f;
   VoxelPlane *plane_ptr_ = new VoxelPlane;
@@ -90,13 +91,26 @@ struct VoxelOctoTree {                      // reference include/voxel_map.h:129
   VoxelOctoTree *leaves_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double voxel_center_[3] = {0, 0, 0};
   float quater_length_ = 0;
+  // map-maintenance state (UpdateOctoTree / init_octo_tree / cut_octo_tree, reference src/voxel_map.cpp:137-290)
+  int octo_state_ = 0, new_points_ = 0, points_size_threshold_ = 5, update_size_threshold_ = 5, max_points_num_ = 50, max_layer_ = 2;
+  bool init_octo_ = false, update_enable_ = true;
+  std::vector<int> layer_init_num_;
+  VoxelOctoTree() = default;
+  VoxelOctoTree(int max_layer, int layer, int points_size_threshold, int max_points_num, float planer_threshold)    // voxel_map.h:151-163
+      : planer_threshold_(planer_threshold), layer_(layer), points_size_threshold_(points_size_threshold), max_points_num_(max_points_num), max_layer_(max_layer) {}
+  VoxelOctoTree *clone() const;             // deep copy of the subtree
   ~VoxelOctoTree() { for (auto *l : leaves_) delete l; delete plane_ptr_; }
+  VoxelOctoTree(const VoxelOctoTree &) = delete;
+  VoxelOctoTree &operator=(const VoxelOctoTree &) = delete;
 };
 
 struct VoxelMapConfig {                     // reference include/voxel_map.h:35-52
   double max_voxel_size_ = 0.5;
   int max_layer_ = 2, max_iterations_ = 5;
   double beam_err_ = 0.05, dept_err_ = 0.02, sigma_num_ = 3;
+  std::vector<int> layer_init_num_{5, 5, 5, 5, 5};
+  int max_points_num_ = 50;
+  double planner_threshold_ = 0.0025;       // local_map / min_eigen_value
 };
 
 class Device {                              // one GPU + stream, shared by the two managers of a LIVMapper
@@ -140,8 +154,18 @@ public:
   // that are in the uploaded snapshot and stay planes are refreshed in place on the device, a changed is_plane_ marks the map dirty.
   void FitPlanes(const std::vector<VoxelOctoTree *> &voxels);
 
+  // BuildVoxelMap / UpdateVoxelMap (reference src/voxel_map.cpp:532-591, 609-641) with the reference's own schedule — every point goes
+  // through UpdateOctoTree in input order, re-fits every update_size_threshold_ points, subdivision of non-planar voxels — but with every
+  // init_plane evaluated on the device: root voxels are independent, so each touched root is replayed on a scratch copy until all the
+  // fits it asks for are known; the fits requested in one sweep over the roots go to the device as ONE livo2_plane_fit_batch call.
+  // input_points carry point_w and var (BuildVoxelMap's own var computation, voxel_map.cpp:546-553, is the caller's here).
+  void BuildVoxelMap(const std::vector<pointWithVar> &input_points);
+  void UpdateVoxelMap(const std::vector<pointWithVar> &input_points);
+  int last_fit_rounds_ = 0, last_fit_count_ = 0;      // device batches / plane fits of the last Build / Update call
+
 private:
   void FlattenAndUpload();
+  void maintain(const std::vector<pointWithVar> &input_points, bool build);
   Device &dev_;
   bool map_dirty_ = true;
   std::unordered_map<const VoxelPlane *, int32_t> plane_index_;

@@ -2,6 +2,8 @@
 // fills a VoxelMapManager (pointer-based voxel_map_, feats_down_body_, state_) / a VIOManager (visual_submap, *state) from a dump
 // directory written by tests/test_host_shim_gpu.py, calls StateEstimation / computeJacobianAndUpdateEKF, and writes what the rest
 // of the pipeline would read back.  Usage: shim_demo <dir>
+#include <algorithm>
+#include <array>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -45,6 +47,43 @@ static VoxelOctoTree *build(int node, int layer, const std::vector<int32_t> &nod
   }
   for (int k = 0; k < 8; k++) { int c = node_child[(size_t)node * 8 + k]; if (c >= 0) t->leaves_[k] = build(c, layer + 1, node_plane, node_child, pn, pc, pv, pd, pr); }
   return t;
+}
+
+// flat dump of a VoxelMapManager's map in the layout of livo2_map_view (roots sorted by key, nodes depth-first)
+struct FlatOut { std::vector<int64_t> root_key; std::vector<int32_t> root_node, node_plane, node_child; std::vector<double> root_center, pn, pc, pv; std::vector<float> root_quarter, pd, pr; };
+static int32_t dump_node(const VoxelOctoTree *t, FlatOut &f) {
+  const int32_t me = (int32_t)f.node_plane.size();
+  f.node_plane.push_back(-1); f.node_child.insert(f.node_child.end(), 8, -1);
+  const VoxelPlane *p = t->plane_ptr_;
+  if (p->is_plane_) {
+    f.node_plane[me] = (int32_t)f.pd.size();
+    f.pn.insert(f.pn.end(), p->normal_.begin(), p->normal_.end()); f.pc.insert(f.pc.end(), p->center_.begin(), p->center_.end());
+    f.pv.insert(f.pv.end(), p->plane_var_.begin(), p->plane_var_.end()); f.pd.push_back(p->d_); f.pr.push_back(p->radius_);
+  }
+  for (int k = 0; k < 8; k++) if (t->leaves_[k]) { const int32_t c = dump_node(t->leaves_[k], f); f.node_child[(size_t)me * 8 + k] = c; }
+  return me;
+}
+static void dump_map(const VoxelMapManager &vm, const std::string &dir, const std::string &prefix) {
+  std::vector<std::pair<std::array<int64_t, 3>, const VoxelOctoTree *>> roots;
+  for (const auto &kv : vm.voxel_map_) roots.push_back({{kv.first.x, kv.first.y, kv.first.z}, kv.second});
+  std::sort(roots.begin(), roots.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+  FlatOut f;
+  for (const auto &r : roots) {
+    f.root_key.insert(f.root_key.end(), r.first.begin(), r.first.end());
+    for (int k = 0; k < 3; k++) f.root_center.push_back(r.second->voxel_center_[k]);
+    f.root_quarter.push_back(r.second->quater_length_);
+    f.root_node.push_back(dump_node(r.second, f));
+  }
+  wr(dir, (prefix + "root_key").c_str(), f.root_key.data(), f.root_key.size()); wr(dir, (prefix + "root_node").c_str(), f.root_node.data(), f.root_node.size());
+  wr(dir, (prefix + "root_center").c_str(), f.root_center.data(), f.root_center.size()); wr(dir, (prefix + "root_quarter").c_str(), f.root_quarter.data(), f.root_quarter.size());
+  wr(dir, (prefix + "node_plane").c_str(), f.node_plane.data(), f.node_plane.size()); wr(dir, (prefix + "node_child").c_str(), f.node_child.data(), f.node_child.size());
+  wr(dir, (prefix + "plane_normal").c_str(), f.pn.data(), f.pn.size()); wr(dir, (prefix + "plane_center").c_str(), f.pc.data(), f.pc.size());
+  wr(dir, (prefix + "plane_var").c_str(), f.pv.data(), f.pv.size()); wr(dir, (prefix + "plane_d").c_str(), f.pd.data(), f.pd.size()); wr(dir, (prefix + "plane_radius").c_str(), f.pr.data(), f.pr.size());
+}
+static std::vector<pointWithVar> points_from(const std::vector<double> &pw, const std::vector<double> &var) {
+  std::vector<pointWithVar> v(pw.size() / 3);
+  for (size_t i = 0; i < v.size(); i++) { for (int k = 0; k < 3; k++) v[i].point_w[k] = pw[i * 3 + k]; for (int k = 0; k < 9; k++) v[i].var[k] = var[i * 9 + k]; }
+  return v;
 }
 
 int main(int argc, char **argv) {
@@ -110,6 +149,27 @@ int main(int argc, char **argv) {
         auto so2 = state_to(vm.state_);
         wr(dir, "out_state2", so2.data(), so2.size());
         std::printf("fit: %zu voxels re-fitted\n", voxels.size());
+      }
+    }
+    // ---- BuildVoxelMap + UpdateVoxelMap with device-side plane fits (src/voxel_map.cpp:532-591, 609-641) ---------------------------
+    auto bld_pw = rd<double>(dir, "bld_pw");
+    if (!bld_pw.empty()) {
+      auto mc = rd<double>(dir, "map_cfg");       // voxel_size, max_layer, max_points_num, planner_threshold, layer_init_num x5
+      VoxelMapManager vm(dev);
+      vm.config_setting_.max_voxel_size_ = mc[0]; vm.config_setting_.max_layer_ = (int)mc[1]; vm.config_setting_.max_points_num_ = (int)mc[2];
+      vm.config_setting_.planner_threshold_ = mc[3];
+      vm.config_setting_.layer_init_num_.assign(5, 5);
+      for (int k = 0; k < 5; k++) vm.config_setting_.layer_init_num_[k] = (int)mc[4 + k];
+      vm.BuildVoxelMap(points_from(bld_pw, rd<double>(dir, "bld_var")));
+      std::printf("BuildVoxelMap: %zu roots, %d plane fits in %d device batches\n", vm.voxel_map_.size(), vm.last_fit_count_, vm.last_fit_rounds_);
+      dump_map(vm, dir, "bld_out_");
+      int32_t st[2] = {vm.last_fit_count_, vm.last_fit_rounds_}; wr(dir, "bld_out_stats", st, 2);
+      auto upd_pw = rd<double>(dir, "upd_pw");
+      if (!upd_pw.empty()) {
+        vm.UpdateVoxelMap(points_from(upd_pw, rd<double>(dir, "upd_var")));
+        std::printf("UpdateVoxelMap: %zu roots, %d plane fits in %d device batches\n", vm.voxel_map_.size(), vm.last_fit_count_, vm.last_fit_rounds_);
+        dump_map(vm, dir, "upd_out_");
+        int32_t su[2] = {vm.last_fit_count_, vm.last_fit_rounds_}; wr(dir, "upd_out_stats", su, 2);
       }
     }
     // ---- visual -----------------------------------------------------------------------------------------------------------
