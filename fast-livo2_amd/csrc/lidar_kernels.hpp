@@ -291,14 +291,17 @@ __device__ __forceinline__ void touch_line(const void *p) {
 // (ties keep the first), which reproduces the serial recursion of build_single_residual exactly.
 struct __attribute__((aligned(16))) CoopLds {
   double ctx[LIDAR_BLOCK][18];       // owner context: pw pc pi q (3 each) Cb (6)
-  double res[LIDAR_BLOCK][10];       // pair result: prob, w, h[6], {float r, int32 plane} (written for accepted pairs only)
-  int32_t pair_owner[LIDAR_BLOCK];
-  int32_t pair_cand[LIDAR_BLOCK];
-  int32_t wave_tot[2][LIDAR_BLOCK / LIVO2_WAVE];       // one set per visit (first / neighbour): no barrier separates their plans
-  unsigned long long pass[LIDAR_BLOCK / LIVO2_WAVE];   // per evaluating wave: which of its slots hold an accepted plane
+  double res[LIDAR_BLOCK][10];       // result rows of accepted pairs: prob, w, h[6], {float r, int32 plane}
   unsigned long long omax[LIDAR_BLOCK];                // per owner: largest accepted probability of the round (bit pattern)
   int32_t omin[LIDAR_BLOCK];                           // per owner: first slot holding it
+  int32_t pair_cand[2 * LIDAR_BLOCK];                  // per slot of the round: candidate record
+  uint8_t pair_owner[2 * LIDAR_BLOCK];                 //                        owning thread
+  uint8_t slot_row[2 * LIDAR_BLOCK];                   //                        result row of an accepted pair
+  uint8_t oacc[LIDAR_BLOCK];                           // per owner: some pair of the round was accepted
+  int32_t wave_tot[2][LIDAR_BLOCK / LIVO2_WAVE];       // one set per visit (first / neighbour): no barrier separates their plans
+  int32_t res_count, overflow;                         // double rounds: rows handed out, more than LIDAR_BLOCK accepted pairs
 };
+static_assert(LIDAR_BLOCK <= 256, "pair_owner / slot_row are bytes");
 static_assert(sizeof(CoopLds) <= LIDAR_LDS_BYTES, "CoopLds must fit in the block's reduction tiles");
 
 // Planning half (every thread of the block calls it; cnt = 0 for threads without a pending candidate list): the pair counts are
@@ -335,112 +338,153 @@ __device__ __forceinline__ void coop_unpark_ctx(const CoopLds &L, PointCtx &pt) 
   for (int k = 0; k < 6; k++) pt.Cb[k] = c[12 + k];
 }
 
+// One round of the evaluation half over the slots [base, base + PAIRS * 256) of the block's pair list; every thread evaluates PAIRS pairs.
+//  PAIRS == 1: the whole 256-B record in one batch of loads (one round trip), as everywhere else in this kernel.
+//  PAIRS == 2 (blocks with more than 256 pairs left — the slowest blocks of a launch): gate first.  Both pairs' gate words
+//    {normal_, center_, d_, radius_, meta} are fetched together (they sit in both 128-B lines of the record, so the whole record is
+//    on its way to this CU), the radius gate runs on both, and the covariance part is read — now an L1/L2 hit — only for a pair
+//    that passed: one cold round trip and one set of barriers for up to 512 pairs instead of two of each.  Accepted pairs take
+//    result rows from an LDS counter; should more than 256 of them turn up the round reports failure and the caller repeats the
+//    slots with PAIRS == 1.
+// Fold = the reference's serial "first plane with the strictly largest probability" over each owner's list: the evaluators elect
+// the winner — LDS max over the probability bit patterns (accepted probabilities are non-negative, so the patterns order like the
+// values), then LDS min over the slots holding that maximum (ascending slot = list order -> the first one) — and the owner copies
+// one row (walking its accepted rows cost a dependent LDS round trip per accepted plane, ~1.8 us in cluttered blocks).
+template <int PAIRS> __device__ __forceinline__ bool coop_round(CoopLds &L, const DevMap &map, const CoopPlan &pl, int base, int max_layer, double sigma_num,
+                                                              const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
+  const int tid = threadIdx.x;
+  const int cnt = pl.cnt, cand_begin = pl.cand_begin, excl = pl.excl, W = pl.W;
+  constexpr int SPAN = PAIRS * LIDAR_BLOCK;
+  CSTAMP(0);
+  // owners publish the pairs that fall into this round
+  const int k_lo = max(0, base - excl), k_hi = min(cnt, base + SPAN - excl);
+  for (int k = k_lo; k < k_hi; k++) { const int j = excl + k - base; L.pair_owner[j] = (uint8_t)tid; L.pair_cand[j] = cand_begin + k; }
+  if (k_lo < k_hi) { L.omax[tid] = 0ull; L.omin[tid] = 0x7fffffff; L.oacc[tid] = 0; }
+  if (PAIRS > 1 && tid == 0) { L.res_count = 0; L.overflow = 0; }
+  __syncthreads();
+  CSTAMP(1);
+  bool act[PAIRS], acc[PAIRS];
+  int owner[PAIRS];
+  unsigned long long pbits[PAIRS];
+  double n[PAIRS][3], c[PAIRS][3], S20[PAIRS];
+  float d[PAIRS], radius[PAIRS];
+  int2 meta[PAIRS];
+  const double2 *P2[PAIRS];
+#pragma unroll
+  for (int q = 0; q < PAIRS; q++) {
+    const int s = tid + q * LIDAR_BLOCK;
+    act[q] = base + s < W; acc[q] = false; owner[q] = 0; pbits[q] = 0ull;
+    P2[q] = reinterpret_cast<const double2 *>(map.cand_rec + (size_t)(act[q] ? L.pair_cand[s] : 0) * PLANE_REC_DOUBLES);
+    if (act[q]) owner[q] = L.pair_owner[s];
+  }
+  double2 g0[PAIRS], g1[PAIRS], g2[PAIRS], g13[PAIRS], g14[PAIRS];
+  double2 sv[10];                                                   // covariance words 3..12 of ONE record at a time
+  if (PAIRS == 1) {
+    if (act[0]) {
+      g0[0] = P2[0][0]; g1[0] = P2[0][1]; g2[0] = P2[0][2];
+#pragma unroll
+      for (int w = 0; w < 10; w++) sv[w] = P2[0][3 + w];
+      g13[0] = P2[0][13]; g14[0] = P2[0][14];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < PAIRS; q++)
+      if (act[q]) { g0[q] = P2[q][0]; g1[q] = P2[q][1]; g2[q] = P2[q][2]; g13[q] = P2[q][13]; g14[q] = P2[q][14]; }
+  }
+  CSTAMP(2);
+  GateOut g[PAIRS];
+  bool pass[PAIRS];
+#pragma unroll
+  for (int q = 0; q < PAIRS; q++) {
+    pass[q] = false;
+    if (act[q]) {
+      n[q][0] = g0[q].x; n[q][1] = g0[q].y; n[q][2] = g1[q].x; c[q][0] = g1[q].y; c[q][1] = g2[q].x; c[q][2] = g2[q].y;
+      S20[q] = g13[q].x;
+      const float2 dr = __builtin_bit_cast(float2, g13[q].y);
+      d[q] = dr.x; radius[q] = dr.y;
+      meta[q] = __builtin_bit_cast(int2, g14[q].x);
+      if ((meta[q].x >> CAND_LAYER_SHIFT) <= max_layer) {
+        const double *oc = L.ctx[owner[q]];
+        const double pw[3] = {oc[0], oc[1], oc[2]};
+        pass[q] = radius_gate(n[q], c[q], d[q], radius[q], pw, g[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PAIRS; q++) {
+    if (!pass[q]) continue;
+    if (PAIRS > 1) {
+#pragma unroll
+      for (int w = 0; w < 10; w++) sv[w] = P2[q][3 + w];
+    }
+    double S[21];
+#pragma unroll
+    for (int w = 0; w < 10; w++) { S[2 * w] = sv[w].x; S[2 * w + 1] = sv[w].y; }
+    S[20] = S20[q];
+    const double *oc = L.ctx[owner[q]];
+    PointCtx pp;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pp.pw[k] = oc[k]; pp.pc[k] = oc[3 + k]; pp.pi[k] = oc[6 + k]; pp.q[k] = oc[9 + k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) pp.Cb[k] = oc[12 + k];
+    Best tb; tb.success = false; tb.prob_valid = false; tb.prob = 0.0; tb.dis2 = 0.0; tb.sigma = 1.0; tb.w = 0.0; tb.plane = -1; tb.r = 0.f;
+#pragma unroll
+    for (int u = 0; u < 6; u++) tb.h[u] = 0.0;
+    sigma_gate_and_row(n[q], c[q], S, g[q], meta[q].x & CAND_PLANE_MASK, sigma_num, pp, R, RE, sPrr, sPtt, tb);
+    if (tb.success) {
+      const double prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
+      int row = tid;
+      if (PAIRS > 1) row = atomicAdd(&L.res_count, 1);
+      if (row < LIDAR_BLOCK) {
+        acc[q] = true;
+        pbits[q] = __builtin_bit_cast(unsigned long long, prob);
+        L.slot_row[tid + q * LIDAR_BLOCK] = (uint8_t)row;
+        L.oacc[owner[q]] = 1;
+        atomicMax(&L.omax[owner[q]], pbits[q]);
+        double *o = L.res[row];
+        o[0] = prob; o[1] = tb.w;
+#pragma unroll
+        for (int u = 0; u < 6; u++) o[2 + u] = tb.h[u];
+        o[8] = __builtin_bit_cast(double, make_int2(__builtin_bit_cast(int, tb.r), tb.plane));
+      } else L.overflow = 1;
+    }
+  }
+  __syncthreads();
+  CSTAMP(4);
+  if (PAIRS > 1 && L.overflow) { __syncthreads(); return false; }   // (block-uniform; the barrier keeps the flag readable until everyone has seen it)
+#pragma unroll
+  for (int q = 0; q < PAIRS; q++)
+    if (acc[q] && L.omax[owner[q]] == pbits[q]) atomicMin(&L.omin[owner[q]], tid + q * LIDAR_BLOCK);
+  __syncthreads();
+  if (k_lo < k_hi && L.oacc[tid]) {
+    best.success = true;
+    const double mp = __builtin_bit_cast(double, L.omax[tid]);
+    if (mp > best.prob) {
+      const double *o = L.res[L.slot_row[L.omin[tid]]];
+      best.prob = mp; best.prob_valid = true; best.w = o[1];
+#pragma unroll
+      for (int u = 0; u < 6; u++) best.h[u] = o[2 + u];
+      const int2 m2 = __builtin_bit_cast(int2, o[8]);
+      best.r = __builtin_bit_cast(float, m2.x); best.plane = m2.y;
+    }
+  }
+  __syncthreads();
+  CSTAMP(5);
+  return true;
+}
+
 // Evaluation half: every thread of the block calls it with its plan (W is block-uniform).
 __device__ __forceinline__ void coop_run(CoopLds &L, const DevMap &map, const CoopPlan &pl, int max_layer, double sigma_num,
                                          const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cnt = pl.cnt, cand_begin = pl.cand_begin, excl = pl.excl, W = pl.W;
-  for (int base = 0; base < W; base += LIDAR_BLOCK) {
-    CSTAMP(0);
-    // owners publish the pairs that fall into this round
-    const int k_lo = max(0, base - excl), k_hi = min(cnt, base + LIDAR_BLOCK - excl);
-    for (int k = k_lo; k < k_hi; k++) { const int j = excl + k - base; L.pair_owner[j] = tid; L.pair_cand[j] = cand_begin + k; }
-    if (k_lo < k_hi) { L.omax[tid] = 0ull; L.omin[tid] = 0x7fffffff; }
-    __syncthreads();
-    CSTAMP(1);
-    double r_prob = 0.0, r_w = 0.0, r_h[6] = {0, 0, 0, 0, 0, 0}, r_meta = 0.0, r_flag = 0.0;   // r_flag: accepted
-    if (base + tid < W) {
-      const int owner = L.pair_owner[tid];
-      PlaneRec p; int2 meta;
-      {
-        const double2 *P2 = reinterpret_cast<const double2 *>(map.cand_rec + (size_t)L.pair_cand[tid] * PLANE_REC_DOUBLES);
-        double2 v[15];
-#pragma unroll
-        for (int q = 0; q < 15; q++) v[q] = P2[q];
-        p.n[0] = v[0].x; p.n[1] = v[0].y; p.n[2] = v[1].x; p.c[0] = v[1].y; p.c[1] = v[2].x; p.c[2] = v[2].y;
-#pragma unroll
-        for (int q = 0; q < 10; q++) { p.S[2 * q] = v[3 + q].x; p.S[2 * q + 1] = v[3 + q].y; }
-        p.S[20] = v[13].x;
-        const float2 dr = __builtin_bit_cast(float2, v[13].y);
-        p.d = dr.x; p.radius = dr.y;
-        meta = __builtin_bit_cast(int2, v[14].x);
-      }
-      CSTAMP(2);
-      if ((meta.x >> CAND_LAYER_SHIFT) <= max_layer) {
-        const double *oc = L.ctx[owner];
-        PointCtx pp;
-#pragma unroll
-        for (int k = 0; k < 3; k++) pp.pw[k] = oc[k];
-        GateOut g;
-        if (radius_gate(p.n, p.c, p.d, p.radius, pp.pw, g)) {
-          const int32_t pidx = meta.x & CAND_PLANE_MASK;
-#pragma unroll
-          for (int k = 0; k < 3; k++) { pp.pc[k] = oc[3 + k]; pp.pi[k] = oc[6 + k]; pp.q[k] = oc[9 + k]; }
-#pragma unroll
-          for (int k = 0; k < 6; k++) pp.Cb[k] = oc[12 + k];
-          Best tb; tb.success = false; tb.prob_valid = false; tb.prob = 0.0; tb.dis2 = 0.0; tb.sigma = 1.0; tb.w = 0.0; tb.plane = -1; tb.r = 0.f;
-#pragma unroll
-          for (int u = 0; u < 6; u++) tb.h[u] = 0.0;
-          sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pp, R, RE, sPrr, sPtt, tb);
-          if (tb.success) {
-            r_flag = 1.0;
-            r_prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
-            r_w = tb.w;
-#pragma unroll
-            for (int u = 0; u < 6; u++) r_h[u] = tb.h[u];
-            r_meta = __builtin_bit_cast(double, make_int2(__builtin_bit_cast(int, tb.r), tb.plane));
-          }
-        }
-      }
-    }
-    // Fold = the reference's serial "first plane with the strictly largest probability" over each owner's list.  Walking the
-    // accepted result rows in the owner lane cost a dependent LDS round trip per accepted plane (~1.8 us in cluttered blocks,
-    // where a point passes both gates on several coplanar leaves), so the evaluators elect the winner instead: LDS max over
-    // the probability bits (accepted probabilities are non-negative, so the bit patterns order like the values), then LDS
-    // min over the slots holding that maximum (ascending slot = list order -> the first one), then the owner copies one row.
-    const unsigned long long pass = __ballot(r_flag != 0.0);
-    if (lane == 0) L.pass[wave] = pass;
-    const unsigned long long pbits = __builtin_bit_cast(unsigned long long, r_prob);
-    int owner_slot = 0;
-    if (r_flag != 0.0) {
-      owner_slot = L.pair_owner[tid];
-      atomicMax(&L.omax[owner_slot], pbits);
-      double *o = L.res[tid];
-      o[0] = r_prob; o[1] = r_w;
-#pragma unroll
-      for (int u = 0; u < 6; u++) o[2 + u] = r_h[u];
-      o[8] = r_meta;
-    }
-    __syncthreads();
-    CSTAMP(4);
-    if (r_flag != 0.0 && L.omax[owner_slot] == pbits) atomicMin(&L.omin[owner_slot], tid);
-    __syncthreads();
-    if (k_lo < k_hi) {
-      const int s_lo = excl + k_lo - base, s_hi = excl + k_hi - base;      // this owner's slots in the round: [s_lo, s_hi) within [0, 256]
-      bool any = false;
-#pragma unroll
-      for (int w = 0; w < LIDAR_BLOCK / LIVO2_WAVE; w++) {
-        const int lo = max(s_lo - 64 * w, 0), hi = min(s_hi - 64 * w, 64);
-        if (lo >= hi) continue;
-        unsigned long long m = L.pass[w] >> lo;
-        if (hi - lo < 64) m &= (1ull << (hi - lo)) - 1ull;
-        any = any || (m != 0ull);
-      }
-      if (any) {
-        best.success = true;
-        const double mp = __builtin_bit_cast(double, L.omax[tid]);
-        if (mp > best.prob) {
-          const double *o = L.res[L.omin[tid]];
-          best.prob = mp; best.prob_valid = true; best.w = o[1];
-#pragma unroll
-          for (int u = 0; u < 6; u++) best.h[u] = o[2 + u];
-          const int2 m2 = __builtin_bit_cast(int2, o[8]);
-          best.r = __builtin_bit_cast(float, m2.x); best.plane = m2.y;
-        }
-      }
-    }
-    __syncthreads();
-    CSTAMP(5);
+#ifdef LIVO2_PHASE_PROF
+#define COOP_PROF_FWD , cprof
+#else
+#define COOP_PROF_FWD
+#endif
+  for (int base = 0; base < pl.W;) {
+    if (pl.W - base > LIDAR_BLOCK && coop_round<2>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD)) { base += 2 * LIDAR_BLOCK; continue; }
+    coop_round<1>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD);
+    base += LIDAR_BLOCK;
   }
 }
 
