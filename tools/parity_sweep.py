@@ -71,7 +71,65 @@ def main():
         print(seed, len(vs.pos), len(a), int(a == b), f"{d['R']:.2e}", f"{d['t']:.2e}", f"{d['inv_expo']:.2e}", f"{d['P']:.2e}", flush=True)
     print(f"# visual summary: {rows} scalar residual rows, {steps_bad} scenarios with a different accept/revert sequence, worst dR {worst['R']:.2e}, "
           f"dt {worst['t']:.2e}, dP rel {worst['P']:.2e}")
+    widened_rows(ctx, livo2)
     ctx.close()
+
+
+def widened_rows(ctx, livo2):
+    """plane fit, retrieval (selection + tail), pre-stage, IMU propagation — several seeds each."""
+    from tests import imu_inputs as IMU
+    from tests import plane_groups as PG
+    print("# plane fit (livo2_plane_fit_batch vs init_plane): seed groups planes decision_flips worst_normal_err worst_plane_var_rel")
+    for seed in range(500, 505):
+        pw, var, off, kinds = PG.make_groups(seed=seed, n_groups=600, big=(400, 3000))
+        out = ctx.plane_fit_batch(pw, var, off, 0.0025)
+        ref, _ = orc.init_plane_batch(pw, var, off, 0.0025)
+        flips, wn, wv, planes = 0, 0.0, 0.0, 0
+        for g in range(len(off) - 1):
+            if ref[g].is_plane and abs(ref[g].min_eigen_value - 0.0025) < 1e-7:
+                continue
+            flips += int(out[g].is_plane != ref[g].is_plane)
+            if ref[g].is_plane and out[g].is_plane:
+                planes += 1
+                gap = max(ref[g].mid_eigen_value - ref[g].min_eigen_value, 1e-12)
+                wn = max(wn, float(np.linalg.norm(np.array(out[g].normal) - np.array(ref[g].normal))) / max(1.0, ref[g].max_eigen_value / gap))
+                q = np.array(ref[g].plane_var)
+                wv = max(wv, float(np.linalg.norm(np.array(out[g].plane_var) - q) / np.linalg.norm(q)) / max(1.0, ref[g].max_eigen_value / gap))
+        print(seed, len(off) - 1, planes, flips, f"{wn:.2e}", f"{wv:.2e}", flush=True)
+    print("# retrieval tail (livo2_visual_retrieve_warp vs orc_warp): seed candidates accepted accept_mismatch search_level_mismatch patch_mismatch error_mismatch")
+    for k, seed in enumerate(range(510, 515)):
+        rs = synth.retrieve_scenario(seed=seed, n_cand=2000, normal_en=bool(k % 2 == 0), ncc_en=bool(k % 3 == 0), ncc_thre=0.9)
+        ref, out = orc.warp_candidates(rs), ctx.retrieve_warp(rs)
+        print(seed, len(rs.pos), int(ref["accepted"].sum()), int((out["accepted"] != ref["accepted"]).sum()), int((out["search_level"] != ref["search_level"]).sum()),
+              int((out["patch_wrap"] != ref["patch_wrap"]).sum()), int((out["error"] != ref["error"]).sum()), flush=True)
+    print("# retrieval selection (livo2_visual_select vs orc_select): seed scan_points visual_points cells cell_mismatch dist_mismatch discont_mismatch in_fov_mismatch")
+    for seed in range(520, 525):
+        ss = synth.select_scenario(seed=seed, n_pg=10000, n_vis=30000)
+        ref = orc.visual_select(ss)
+        ctx.visual_map_upload(ss.pos, ss.keys, ss.active)
+        out = ctx.visual_select(ss)
+        print(seed, len(ss.pg), len(ss.pos), int((ref["cell_point"] >= 0).sum()), int((out["cell_point"] != ref["cell_point"]).sum()), int((out["cell_dist"] != ref["cell_dist"]).sum()),
+              int((out["discont"].astype(np.int32) != ref["discont"]).sum()), int((out["in_fov"].astype(np.int32) != ref["in_fov"]).sum()), flush=True)
+    print("# pre-stage (livo2_lidar_preprocess_scan vs orc_preprocess): seed raw_points undistorted_coords_differing max_ulp feats_down voxel_grid_mismatch")
+    for k, seed in enumerate(range(530, 535)):
+        rs = synth.raw_scan_scenario(seed=seed, n_raw=24000, extR=None if k % 2 else synth.rot_from_rpy(0.1, -0.05, 0.02 * k))
+        c = livo2.LidarCfg()
+        c.max_iterations, c.max_layer = 5, 2
+        c.sigma_num, c.dept_err, c.beam_err, c.voxel_size, c.deg2rad = 3.0, 0.02, 0.05, 0.5, 0.017453293
+        c.extR[:] = rs.extR.ravel().tolist(); c.extT[:] = rs.extT.tolist()
+        nd, und, down = ctx.preprocess_scan(rs.xyz, rs.curvature, rs.poses, rs.rot_end, rs.pos_end, rs.leaf, c)
+        ref_u = orc.undistort(rs.xyz, rs.curvature, rs.poses, rs.rot_end, rs.pos_end, rs.extR, rs.extT)
+        ulp = np.abs(und - ref_u) / np.spacing(np.maximum(np.abs(ref_u), 1e-3).astype(np.float32))
+        ref_d = orc.voxel_grid(und, rs.leaf)
+        print(seed, len(rs.xyz), int((und != ref_u).sum()), f"{ulp.max():.1f}", nd, int(nd != len(ref_d)) + (int((down != ref_d).sum()) if nd == len(ref_d) else 0), flush=True)
+    print("# IMU propagation (livo2_imu_propagate vs orc_imu): seed samples dR dpos dvel dP_rel poses_abs")
+    for seed, n in ((540, 20), (541, 40), (542, 200), (543, 7), (544, 1000)):
+        steps = IMU.make_steps(seed, n=n)
+        ref, rposes, _ = orc.imu_propagate(IMU.make_state(orc, orc.StatePOD, seed), steps, IMU.CFG)
+        out, poses = ctx.imu_propagate(IMU.make_state(orc, livo2.State, seed), steps, orc.imu_cfg(IMU.CFG, cls=livo2.ImuCfg))
+        a, b = orc.state_arrays(out), orc.state_arrays(ref)
+        print(seed, n, f"{np.abs(a['R'] - b['R']).max():.2e}", f"{np.abs(a['t'] - b['t']).max():.2e}", f"{np.abs(a['vel'] - b['vel']).max():.2e}",
+              f"{np.abs(a['P'] - b['P']).max() / np.abs(b['P']).max():.2e}", f"{np.abs(poses - rposes).max():.2e}", flush=True)
 
 
 if __name__ == "__main__":
