@@ -284,7 +284,8 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
   std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
   static_assert(sizeof(PointXYZ) == 12, "xyz AoS");
-  dev_.check(livo2_lidar_set_scan(dev_.ctx(), n ? &feats_down_body_[0].x : nullptr, n, &cfg));
+  if (!scan_resident_) dev_.check(livo2_lidar_set_scan(dev_.ctx(), n ? &feats_down_body_[0].x : nullptr, n, &cfg));
+  scan_resident_ = false;
 
   std::vector<int32_t> match(n), normal_plane(n);
   std::vector<float> dis(n), pw((size_t)n * 3);
@@ -325,6 +326,71 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     }
   }
   effct_feat_num_ = (int)ptpl_list_.size();
+}
+
+void VoxelMapManager::UndistortAndDownsample(const std::vector<PointXYZ> &pcl_wait_proc, const std::vector<float> &curvature, const std::vector<livo2_imu_pose> &IMUpose,
+                                             const StatesGroup &state_end, double filter_size_surf) {
+  const int n = (int)pcl_wait_proc.size();
+  livo2_lidar_cfg cfg{};
+  cfg.max_iterations = config_setting_.max_iterations_; cfg.max_layer = config_setting_.max_layer_; cfg.sigma_num = config_setting_.sigma_num_;
+  cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
+  std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
+  feats_down_body_.assign((size_t)std::max(n, 1), PointXYZ{0, 0, 0});
+  int32_t n_down = 0;
+  dev_.check(livo2_lidar_preprocess_scan(dev_.ctx(), n ? &pcl_wait_proc[0].x : nullptr, curvature.data(), n, IMUpose.data(), (int32_t)IMUpose.size(), state_end.rot_end.data(),
+                                         state_end.pos_end.data(), filter_size_surf, &cfg, &n_down, nullptr, &feats_down_body_[0].x));
+  feats_down_body_.resize(n_down);
+  feats_down_size_ = n_down;
+  scan_resident_ = true;
+}
+
+void ImuProcess::ForwardPropagate(StatesGroup &state_inout, const std::vector<livo2_imu_step> &steps) {
+  livo2_imu_cfg c{};
+  std::memcpy(c.cov_gyr, cov_gyr.data(), 24); std::memcpy(c.cov_acc, cov_acc.data(), 24); std::memcpy(c.cov_bias_gyr, cov_bias_gyr.data(), 24); std::memcpy(c.cov_bias_acc, cov_bias_acc.data(), 24);
+  c.cov_inv_expo = cov_inv_expo; c.G_m_s2 = 9.81;                                  // reference include/common_lib.h:29
+  c.mean_acc_norm = std::sqrt(mean_acc[0] * mean_acc[0] + mean_acc[1] * mean_acc[1] + mean_acc[2] * mean_acc[2]);
+  c.ba_bg_est_en = ba_bg_est_en; c.gravity_est_en = gravity_est_en; c.exposure_estimate_en = exposure_estimate_en;
+  livo2_state s_in, s_out;
+  state_inout.to_abi(s_in);
+  std::vector<livo2_imu_pose> pushed(std::max<size_t>(steps.size(), 1));
+  dev_.check(livo2_imu_propagate(dev_.ctx(), &s_in, steps.data(), (int32_t)steps.size(), &c, &s_out, pushed.data()));
+  state_inout.from_abi(s_out);
+  IMUpose.insert(IMUpose.end(), pushed.begin(), pushed.begin() + steps.size());
+}
+
+std::vector<VisualPoint *> VIOManager::selectFromVisualSparseMap(const std::vector<pointWithVar> &pg) {
+  if (feat_map.empty()) return {};                                                // reference src/vio.cpp:354
+  if (feat_map_dirty_) {                                                          // flat mirror: index i <-> VisualPoint*
+    std::vector<double> pos; std::vector<int64_t> key; std::vector<uint8_t> act;
+    mirror_.clear();
+    for (const auto &kv : feat_map)
+      for (VisualPoint *pt : kv.second->voxel_points) {
+        mirror_.push_back(pt);
+        act.push_back(pt != nullptr && !pt->obs_.empty());
+        for (int k = 0; k < 3; k++) pos.push_back(pt ? pt->pos_[k] : 0.0);
+        key.push_back(kv.first.x); key.push_back(kv.first.y); key.push_back(kv.first.z);
+      }
+    dev_.check(livo2_visual_map_upload(dev_.ctx(), (int32_t)mirror_.size(), pos.data(), key.data(), act.data()));
+    feat_map_dirty_ = false;
+  }
+  if (grid_n_width == 0) {                                                        // reference src/vio.cpp:67-78
+    if (grid_size > 10) { grid_n_width = (int)std::ceil((double)(width / grid_size)); grid_n_height = (int)std::ceil((double)(height / grid_size)); }
+    else { grid_size = height / grid_n_height; grid_n_height = (int)std::ceil((double)(height / grid_size)); grid_n_width = (int)std::ceil((double)(width / grid_size)); }
+  }
+  const int length = grid_n_width * grid_n_height;
+  std::vector<double> pgw(pg.size() * 3);
+  for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24);
+  livo2_select_cfg sc{};
+  sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = 0; sc.cam.width = width; sc.cam.height = height;
+  std::memcpy(sc.R_cur, R_f_w_new.data(), 72); std::memcpy(sc.t_cur, t_f_w_new.data(), 24);
+  sc.border = border; sc.grid_size = grid_size; sc.grid_n_width = grid_n_width; sc.grid_n_height = grid_n_height; sc.patch_size_half = patch_size / 2;
+  std::vector<int32_t> cell(length); std::vector<uint8_t> disc(length);
+  map_dist.assign(length, 10000.0f);
+  dev_.check(livo2_visual_select(dev_.ctx(), pgw.data(), (int32_t)pg.size(), &sc, cell.data(), map_dist.data(), disc.data(), nullptr));
+  std::vector<VisualPoint *> kept;
+  for (int i = 0; i < length; i++)
+    if (cell[i] >= 0 && !disc[i]) { VisualPoint *pt = mirror_[cell[i]]; if (pt->is_normal_initialized_) kept.push_back(pt); }   // vio.cpp:598-644
+  return kept;
 }
 
 void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands) {

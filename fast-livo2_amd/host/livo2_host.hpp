@@ -150,6 +150,12 @@ public:
 
   void StateEstimation(StatesGroup &state_propagat);   // reference src/voxel_map.cpp:338-511
 
+  // ImuProcess::UndistortPcl's backward loop + downSizeFilterSurf (reference src/IMU_Processing.cpp:494-539, src/LIVMapper.cpp:351-352) on
+  // the device: raw scan (x, y, z, curvature[ms], sorted by curvature) + IMUpose + the scan-end pose in, feats_down_body_ out — and the
+  // filtered cloud stays resident, so the next StateEstimation uploads no scan.
+  void UndistortAndDownsample(const std::vector<PointXYZ> &pcl_wait_proc, const std::vector<float> &curvature, const std::vector<livo2_imu_pose> &IMUpose,
+                              const StatesGroup &state_end, double filter_size_surf);
+
   // VoxelOctoTree::init_plane(temp_points_, plane_ptr_) (reference src/voxel_map.cpp:55-135) for many voxels in one device call; planes
   // that are in the uploaded snapshot and stay planes are refreshed in place on the device, a changed is_plane_ marks the map dirty.
   void FitPlanes(const std::vector<VoxelOctoTree *> &voxels);
@@ -168,9 +174,25 @@ private:
   void maintain(const std::vector<pointWithVar> &input_points, bool build);
   Device &dev_;
   bool map_dirty_ = true;
+  bool scan_resident_ = false;              // set by UndistortAndDownsample, consumed by StateEstimation
   std::unordered_map<const VoxelPlane *, int32_t> plane_index_;
   std::vector<const VoxelPlane *> plane_by_index_;
   std::vector<int> plane_layer_;
+};
+
+// ---- IMU ------------------------------------------------------------------------------------------------------------------
+class ImuProcess {                          // reference include/IMU_Processing.h (members the forward propagation reads / writes)
+public:
+  V3D cov_acc{{0.1, 0.1, 0.1}}, cov_gyr{{0.1, 0.1, 0.1}}, cov_bias_gyr{{0.1, 0.1, 0.1}}, cov_bias_acc{{0.1, 0.1, 0.1}}, mean_acc{{0, 0, -1.0}};   // IMU_Processing.cpp:19-24
+  double cov_inv_expo = 0.2;
+  bool ba_bg_est_en = true, gravity_est_en = true, exposure_estimate_en = true;
+  std::vector<livo2_imu_pose> IMUpose;      // Pose6D list (msg/Pose6D.msg)
+  explicit ImuProcess(Device &dev) : dev_(dev) {}
+  // The forward loop of UndistortPcl (reference src/IMU_Processing.cpp:322-445) for the steps its time-stamp logic produced: one step per
+  // processed IMU pair = averaged raw gyro / accelerometer sample, dt, offs_t.  Appends one Pose6D per step to IMUpose and advances state_inout.
+  void ForwardPropagate(StatesGroup &state_inout, const std::vector<livo2_imu_step> &steps);
+private:
+  Device &dev_;
 };
 
 // ---- visual ---------------------------------------------------------------------------------------------------------------
@@ -184,7 +206,12 @@ struct Feature {                            // reference include/feature.h:19-54
   int level_ = 0;
   double inv_expo_time_ = 1.0;
 };
-struct VisualPoint { V3D pos_{}, normal_{}; Feature *ref_patch = nullptr; };   // reference include/visual_point.h:23-46
+struct VisualPoint { V3D pos_{}, normal_{}; Feature *ref_patch = nullptr; std::vector<Feature *> obs_; bool is_normal_initialized_ = true; };   // reference include/visual_point.h:23-46
+
+struct VOXEL_POINTS {                       // reference include/vio.h:59-69
+  std::vector<VisualPoint *> voxel_points;
+  int count = 0;
+};
 
 struct SubSparseMap {                       // reference include/vio.h:26-57
   std::vector<float> errors;
@@ -223,9 +250,19 @@ public:
   struct Candidate { VisualPoint *pt; Feature *ref_ftr; };
   void warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands);
 
+  // Selection half of retrieveFromVisualSparseMap (reference src/vio.cpp:385-486, 598-635): mirrors feat_map on the device (whenever
+  // feat_map_dirty_ is set), runs the scan-voxel / depth-image / nearest-point-per-cell / depth-continuity stages there and returns, in grid
+  // order, the points the loop at vio.cpp:598 would go on with (retrieve_voxel_points[i] of the TYPE_MAP cells that pass the depth test).
+  std::unordered_map<VOXEL_LOCATION, VOXEL_POINTS *, VoxelLocationHash> feat_map;
+  int grid_size = 5, grid_n_width = 0, grid_n_height = 17, border = 80;     // reference src/vio.cpp:67-78, 154
+  bool feat_map_dirty_ = true;
+  std::vector<float> map_dist;              // per grid cell, as the reference keeps it
+  std::vector<VisualPoint *> selectFromVisualSparseMap(const std::vector<pointWithVar> &pg);
+
 private:
   Device &dev_;
   bool frame_resident_ = false;             // set by warpAndGateCandidates, consumed by computeJacobianAndUpdateEKF
+  std::vector<VisualPoint *> mirror_;       // device index -> VisualPoint*
 };
 
 } // namespace livo2

@@ -151,6 +151,38 @@ int main(int argc, char **argv) {
         std::printf("fit: %zu voxels re-fitted\n", voxels.size());
       }
     }
+    // ---- IMU forward propagation, then undistortion + down-sampling of a raw scan with the poses it produced (src/IMU_Processing.cpp:298-539) ----
+    auto imu_steps = rd<double>(dir, "imu_steps");     // [n][8]
+    if (!imu_steps.empty()) {
+      ImuProcess imu(dev);
+      auto ic = rd<double>(dir, "imu_cfg");            // cov_gyr3 cov_acc3 cov_bias_gyr3 cov_bias_acc3 cov_inv_expo mean_acc3 flags3
+      for (int k = 0; k < 3; k++) { imu.cov_gyr[k] = ic[k]; imu.cov_acc[k] = ic[3 + k]; imu.cov_bias_gyr[k] = ic[6 + k]; imu.cov_bias_acc[k] = ic[9 + k]; imu.mean_acc[k] = ic[13 + k]; }
+      imu.cov_inv_expo = ic[12]; imu.ba_bg_est_en = ic[16] != 0; imu.gravity_est_en = ic[17] != 0; imu.exposure_estimate_en = ic[18] != 0;
+      StatesGroup st = state_from(rd<double>(dir, "imu_state_in"));
+      std::vector<livo2_imu_step> steps(imu_steps.size() / 8);
+      std::memcpy(steps.data(), imu_steps.data(), imu_steps.size() * 8);
+      livo2_imu_pose first{};                            // IMUpose[0] = set_pose6d(0.0, acc_s_last, angvel_last, vel_end, pos_end, rot_end) (IMU_Processing.cpp:281)
+      for (int k = 0; k < 3; k++) { first.vel[k] = st.vel_end[k]; first.pos[k] = st.pos_end[k]; }
+      for (int k = 0; k < 9; k++) first.rot[k] = st.rot_end[k];
+      imu.IMUpose.push_back(first);
+      imu.ForwardPropagate(st, steps);
+      auto so = state_to(st);
+      wr(dir, "imu_out_state", so.data(), so.size());
+      wr(dir, "imu_out_poses", (const double *)imu.IMUpose.data(), imu.IMUpose.size() * 22);
+      auto raw = rd<float>(dir, "raw_xyz"); auto cur = rd<float>(dir, "raw_curvature");
+      if (!raw.empty()) {
+        auto rc = rd<double>(dir, "raw_cfg");            // extR9 extT3 leaf voxel_size
+        VoxelMapManager vm(dev);
+        for (int k = 0; k < 9; k++) vm.extR_[k] = rc[k];
+        for (int k = 0; k < 3; k++) vm.extT_[k] = rc[9 + k];
+        vm.config_setting_.max_voxel_size_ = rc[13];
+        std::vector<PointXYZ> pts(raw.size() / 3);
+        std::memcpy(pts.data(), raw.data(), raw.size() * 4);
+        vm.UndistortAndDownsample(pts, cur, imu.IMUpose, st, rc[12]);
+        wr(dir, "raw_out_down", &vm.feats_down_body_[0].x, vm.feats_down_body_.size() * 3);
+        std::printf("pre-stage: %zu raw points -> %d\n", pts.size(), vm.feats_down_size_);
+      }
+    }
     // ---- BuildVoxelMap + UpdateVoxelMap with device-side plane fits (src/voxel_map.cpp:532-591, 609-641) ---------------------------
     auto bld_pw = rd<double>(dir, "bld_pw");
     if (!bld_pw.empty()) {
@@ -228,6 +260,36 @@ int main(int argc, char **argv) {
         vio.normal_en = rcfg[13] != 0; vio.ncc_en = rcfg[14] != 0; vio.ncc_thre = rcfg[15]; vio.outlier_threshold = rcfg[16];
         SubSparseMap sm2; vio.visual_submap = &sm2;
         GrayImage g2{rimg.data(), vio.width, vio.height, vio.width};
+        // selection half first, when the dump carries a visual map: feat_map filled the way insertPointIntoVoxelMap files points (vio.cpp:227-244)
+        auto sel_pos = rd<double>(dir, "sel_pos");
+        if (!sel_pos.empty()) {
+          auto sel_key = rd<int64_t>(dir, "sel_keys"); auto sel_act = rd<uint8_t>(dir, "sel_active"); auto sel_pg = rd<double>(dir, "sel_pg");
+          auto sg = rd<double>(dir, "sel_cfg");          // R_cur9 t_cur3 border grid_n_height
+          const size_t nv = sel_act.size();
+          std::vector<VisualPoint> vp(nv); std::vector<Feature> dummy(1);
+          for (size_t i = 0; i < nv; i++) {
+            for (int k = 0; k < 3; k++) vp[i].pos_[k] = sel_pos[i * 3 + k];
+            if (sel_act[i]) vp[i].obs_.push_back(&dummy[0]);
+            const VOXEL_LOCATION key(sel_key[i * 3], sel_key[i * 3 + 1], sel_key[i * 3 + 2]);
+            auto it = vio.feat_map.find(key);
+            if (it == vio.feat_map.end()) it = vio.feat_map.emplace(key, new VOXEL_POINTS).first;
+            it->second->voxel_points.push_back(&vp[i]); it->second->count++;
+          }
+          M3D Rk = vio.R_f_w_new; V3D tk = vio.t_f_w_new;
+          for (int k = 0; k < 9; k++) vio.R_f_w_new[k] = sg[k];
+          for (int k = 0; k < 3; k++) vio.t_f_w_new[k] = sg[9 + k];
+          vio.border = (int)sg[12]; vio.grid_n_height = (int)sg[13]; vio.grid_size = 5; vio.grid_n_width = 0;
+          std::vector<pointWithVar> pg(sel_pg.size() / 3);
+          for (size_t i = 0; i < pg.size(); i++) for (int k = 0; k < 3; k++) pg[i].point_w[k] = sel_pg[i * 3 + k];
+          auto kept_pts = vio.selectFromVisualSparseMap(pg);
+          std::vector<int32_t> kept_idx;
+          for (VisualPoint *p : kept_pts) kept_idx.push_back((int32_t)(p - vp.data()));
+          wr(dir, "sel_out_kept", kept_idx.data(), kept_idx.size()); wr(dir, "sel_out_map_dist", vio.map_dist.data(), vio.map_dist.size());
+          std::printf("select: %zu points kept of %zu grid cells\n", kept_idx.size(), vio.map_dist.size());
+          for (auto &kv : vio.feat_map) delete kv.second;
+          vio.feat_map.clear(); vio.feat_map_dirty_ = true;
+          vio.R_f_w_new = Rk; vio.t_f_w_new = tk;
+        }
         vio.warpAndGateCandidates(g2, cands);
         std::vector<int32_t> kept;
         for (auto *p : sm2.voxel_points) kept.push_back((int32_t)(p - rp.data()));

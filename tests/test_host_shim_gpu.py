@@ -71,6 +71,22 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
         np.ascontiguousarray(getattr(rs, name), np.float64).tofile(os.path.join(d, "retr_" + name + ".bin"))
     rs.ref_img_idx.astype(np.int32).tofile(os.path.join(d, "retr_ref_img_idx.bin")); rs.ref_level.astype(np.int32).tofile(os.path.join(d, "retr_ref_level.bin"))
 
+    # ImuProcess::ForwardPropagate, then VoxelMapManager::UndistortAndDownsample with the poses it produced
+    from tests import imu_inputs as IMU
+    isteps = IMU.make_steps(7, n=20)
+    ist = IMU.make_state(orc, orc.StatePOD, 7)
+    isteps.tofile(os.path.join(d, "imu_steps.bin")); _state_vec(ist).tofile(os.path.join(d, "imu_state_in.bin"))
+    mean_acc = np.array([0.0, 0.0, -IMU.CFG["mean_acc_norm"]])
+    np.concatenate([IMU.CFG["cov_gyr"], IMU.CFG["cov_acc"], IMU.CFG["cov_bias_gyr"], IMU.CFG["cov_bias_acc"], [IMU.CFG["cov_inv_expo"]], mean_acc, [1, 1, 1]]).astype(np.float64).tofile(os.path.join(d, "imu_cfg.bin"))
+    raw = synth.raw_scan_scenario(seed=20, n_raw=8000)
+    raw.xyz.tofile(os.path.join(d, "raw_xyz.bin")); raw.curvature.tofile(os.path.join(d, "raw_curvature.bin"))
+    np.concatenate([raw.extR.ravel(), raw.extT, [raw.leaf, 0.5]]).astype(np.float64).tofile(os.path.join(d, "raw_cfg.bin"))
+    # selection half of the retrieval
+    ss = synth.select_scenario(seed=21, n_pg=5000, n_vis=4000)
+    ss.pos.tofile(os.path.join(d, "sel_pos.bin")); ss.keys.astype(np.int64).tofile(os.path.join(d, "sel_keys.bin")); ss.active.astype(np.uint8).tofile(os.path.join(d, "sel_active.bin"))
+    ss.pg.tofile(os.path.join(d, "sel_pg.bin"))
+    np.concatenate([ss.R_cur.ravel(), ss.t_cur, [ss.border, ss.grid_n_height]]).astype(np.float64).tofile(os.path.join(d, "sel_cfg.bin"))
+
     r = subprocess.run([DEMO, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
 
@@ -122,3 +138,22 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     vout2 = np.fromfile(os.path.join(d, "retr_out_state.bin"))
     vref2v = _state_vec(vref2["state"])
     assert np.allclose(vout2[:25], vref2v[:25], rtol=0, atol=1e-8) and H.relerr(vout2[25:], vref2v[25:]) < 1e-7
+
+    # IMU propagation and the pre-stage through the shim
+    iref, iposes, _ = orc.imu_propagate(ist, isteps, IMU.CFG)
+    iout = np.fromfile(os.path.join(d, "imu_out_state.bin"))
+    irefv = _state_vec(iref)
+    assert np.allclose(iout[:25], irefv[:25], rtol=0, atol=1e-12) and H.relerr(iout[25:], irefv[25:]) < 1e-12
+    poses = np.fromfile(os.path.join(d, "imu_out_poses.bin")).reshape(-1, 22)
+    assert len(poses) == len(isteps) + 1 and np.abs(poses[1:] - iposes).max() < 1e-11
+    so = orc.state_arrays(iref)
+    und = orc.undistort(raw.xyz, raw.curvature, poses, so["R"], so["t"], raw.extR, raw.extT)
+    down_ref = orc.voxel_grid(und, raw.leaf)
+    down = np.fromfile(os.path.join(d, "raw_out_down.bin"), dtype=np.float32).reshape(-1, 3)
+    assert down.shape == down_ref.shape and np.abs(down - down_ref).max() < 1e-5
+
+    # selection through the shim: the points the loop at vio.cpp:598 goes on with, in grid order
+    sref = orc.visual_select(ss)
+    keep_ref = [int(p) for p, dsc in zip(sref["cell_point"], sref["discont"]) if p >= 0 and not dsc]
+    assert list(np.fromfile(os.path.join(d, "sel_out_kept.bin"), dtype=np.int32)) == keep_ref and len(keep_ref) > 50
+    assert np.array_equal(np.fromfile(os.path.join(d, "sel_out_map_dist.bin"), dtype=np.float32), sref["cell_dist"])
