@@ -204,6 +204,62 @@ int main(int argc, char **argv) {
         int32_t su[2] = {vm.last_fit_count_, vm.last_fit_rounds_}; wr(dir, "upd_out_stats", su, 2);
       }
     }
+    // ---- a LIO sequence the way LIVMapper::handleLIO drives it (src/LIVMapper.cpp:357-426): per frame StateEstimation on the propagated
+    // state, then the world points / covariances of the scan from the posterior (413-423) and UpdateVoxelMap with them ---------------------
+    auto seq_counts = rd<int32_t>(dir, "seq_counts");
+    if (!seq_counts.empty()) {
+      auto mc = rd<double>(dir, "seq_map_cfg"); auto lc = rd<double>(dir, "seq_lidar_cfg");
+      auto scans = rd<float>(dir, "seq_scans"); auto motion = rd<double>(dir, "seq_motion"); auto qd = rd<double>(dir, "seq_q");
+      VoxelMapManager vm(dev);
+      vm.config_setting_.max_voxel_size_ = mc[0]; vm.config_setting_.max_layer_ = (int)mc[1]; vm.config_setting_.max_points_num_ = (int)mc[2]; vm.config_setting_.planner_threshold_ = mc[3];
+      vm.config_setting_.layer_init_num_.assign(5, 5);
+      for (int k = 0; k < 5; k++) vm.config_setting_.layer_init_num_[k] = (int)mc[4 + k];
+      vm.config_setting_.max_iterations_ = (int)lc[0]; vm.config_setting_.sigma_num_ = lc[2]; vm.config_setting_.dept_err_ = lc[3]; vm.config_setting_.beam_err_ = lc[4];
+      for (int k = 0; k < 9; k++) vm.extR_[k] = lc[6 + k];
+      for (int k = 0; k < 3; k++) vm.extT_[k] = lc[15 + k];
+      vm.BuildVoxelMap(points_from(rd<double>(dir, "seq_bld_pw"), rd<double>(dir, "seq_bld_var")));
+      StatesGroup post = state_from(rd<double>(dir, "seq_state0"));
+      std::vector<double> traj;
+      size_t off = 0;
+      for (size_t f = 0; f < seq_counts.size(); f++) {
+        StatesGroup prop = post;                                        // stand-in for the IMU propagation: posterior (+) commanded motion, inflated covariance
+        const double *mo = &motion[f * 12];
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 3; c++) prop.rot_end[r * 3 + c] = post.rot_end[r * 3] * mo[c] + post.rot_end[r * 3 + 1] * mo[3 + c] + post.rot_end[r * 3 + 2] * mo[6 + c];
+          prop.pos_end[r] = post.pos_end[r] + mo[9 + r];
+        }
+        for (int k = 0; k < LIVO2_DIM_STATE; k++) prop.cov[k * LIVO2_DIM_STATE + k] += qd[k];
+        const int n = seq_counts[f];
+        vm.feats_down_body_.resize(n);
+        std::memcpy(vm.feats_down_body_.data(), &scans[off * 3], (size_t)n * 12); off += n;
+        vm.state_ = prop;
+        vm.StateEstimation(prop);
+        post = vm.state_;
+        // LIVMapper.cpp:413-423: world points (float cloud) and their covariance from the posterior
+        M3D RE;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RE[r * 3 + c] = post.rot_end[r * 3] * vm.extR_[c] + post.rot_end[r * 3 + 1] * vm.extR_[3 + c] + post.rot_end[r * 3 + 2] * vm.extR_[6 + c];
+        for (int i = 0; i < n; i++) {
+          pointWithVar &pv = vm.pv_list_[i];
+          const PointXYZ &p = vm.feats_down_body_[i];
+          double pi[3];
+          for (int r = 0; r < 3; r++) pi[r] = vm.extR_[r * 3] * p.x + vm.extR_[r * 3 + 1] * p.y + vm.extR_[r * 3 + 2] * p.z + vm.extT_[r];
+          for (int r = 0; r < 3; r++) pv.point_w[r] = (double)(float)(post.rot_end[r * 3] * pi[0] + post.rot_end[r * 3 + 1] * pi[1] + post.rot_end[r * 3 + 2] * pi[2] + post.pos_end[r]);
+          const M3D &X = vm.cross_mat_list_[i], &Cb = vm.body_cov_list_[i];
+          double A[9], B[9];
+          for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { A[r * 3 + c] = RE[r * 3] * Cb[c] + RE[r * 3 + 1] * Cb[3 + c] + RE[r * 3 + 2] * Cb[6 + c];
+                                                                     B[r * 3 + c] = X[r * 3] * post.cov[0 * 19 + c] + X[r * 3 + 1] * post.cov[1 * 19 + c] + X[r * 3 + 2] * post.cov[2 * 19 + c]; }
+          for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+            pv.var[r * 3 + c] = (A[r * 3] * RE[c * 3] + A[r * 3 + 1] * RE[c * 3 + 1] + A[r * 3 + 2] * RE[c * 3 + 2]) + (B[r * 3] * X[c * 3] + B[r * 3 + 1] * X[c * 3 + 1] + B[r * 3 + 2] * X[c * 3 + 2]) +
+                                post.cov[(3 + r) * 19 + 3 + c];
+        }
+        vm.UpdateVoxelMap(vm.pv_list_);
+        auto so = state_to(post);
+        traj.insert(traj.end(), so.begin(), so.begin() + 12);            // rot9 pos3
+        std::printf("seq frame %zu: effct_feat_num_=%d, %d plane fits in %d batches\n", f, vm.effct_feat_num_, vm.last_fit_count_, vm.last_fit_rounds_);
+      }
+      wr(dir, "seq_out_traj", traj.data(), traj.size());
+      dump_map(vm, dir, "seq_out_");
+    }
     // ---- visual -----------------------------------------------------------------------------------------------------------
     auto img = rd<uint8_t>(dir, "img");
     if (!img.empty()) {

@@ -31,7 +31,9 @@ def _canon(fm):
     return {tuple(int(x) for x in k): (node(int(r)), fm.root_center[i], fm.root_quarter[i]) for i, (k, r) in enumerate(zip(fm.root_key, fm.root_node))}
 
 
-def _compare(a, b):
+def _compare(a, b, loose=False):
+    """loose: the two maps were fed world points derived from two posteriors that agree to ~1e-9 (float32 world points can differ by an ulp)"""
+    tol = 1e5 if loose else 1.0
     ca, cb = _canon(a), _canon(b)
     assert set(ca) == set(cb), "different sets of root voxels"
     n_planes = 0
@@ -44,10 +46,10 @@ def _compare(a, b):
         if x[0] >= 0:
             n_planes += 1
             i, j = x[0], y[0]
-            np.testing.assert_allclose(a.plane_center[i], b.plane_center[j], rtol=1e-13)
-            assert np.linalg.norm(a.plane_normal[i] - b.plane_normal[j]) < 1e-6
-            assert abs(a.plane_radius[i] - b.plane_radius[j]) <= 1e-5 * b.plane_radius[j] and abs(a.plane_d[i] - b.plane_d[j]) < 1e-4
-            assert np.linalg.norm(a.plane_var[i] - b.plane_var[j]) < 1e-4 * np.linalg.norm(b.plane_var[j]) + 1e-18
+            np.testing.assert_allclose(a.plane_center[i], b.plane_center[j], rtol=1e-13 * tol, atol=1e-13 * tol)
+            assert np.linalg.norm(a.plane_normal[i] - b.plane_normal[j]) < 1e-6 * (100 if loose else 1)
+            assert abs(a.plane_radius[i] - b.plane_radius[j]) <= 1e-5 * (10 if loose else 1) * b.plane_radius[j] and abs(a.plane_d[i] - b.plane_d[j]) < 1e-4 * (10 if loose else 1)
+            assert np.linalg.norm(a.plane_var[i] - b.plane_var[j]) < 1e-4 * (100 if loose else 1) * np.linalg.norm(b.plane_var[j]) + 1e-18
         for p, q in zip(x[1], y[1]):
             walk(p, q)
     for k in ca:
