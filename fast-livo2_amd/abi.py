@@ -171,6 +171,7 @@ SIGNATURES = {
     "livo2_ctx_stream": (C.c_void_p, [_CTX]),
     "livo2_ctx_synchronize": (C.c_int, [_CTX]),
     "livo2_version": (C.c_char_p, []),
+    "livo2_abi_sizeof": (C.c_int32, [C.c_char_p]),
     "livo2_ctx_kernel_timing": (C.c_int, [_CTX, C.c_int]),
     "livo2_ctx_kernel_timing_read": (C.c_int, [_CTX, C.c_int, _P(C.c_double), _P(C.c_int64), C.c_int]),
     "livo2_map_upload": (C.c_int, [_CTX, _P(MapView)]),

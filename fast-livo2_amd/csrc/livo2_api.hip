@@ -316,6 +316,16 @@ int visual_grid(int M) { return std::max(1, (M + VIS_WAVES - 1) / VIS_WAVES); }
 extern "C" {
 
 const char *livo2_version(void) { return "livo2_hip 0.1 (gfx950)"; }
+int32_t livo2_abi_sizeof(const char *name) {
+  if (!name) return 0;
+#define LIVO2_SZ(T) if (std::strcmp(name, #T) == 0) return (int32_t)sizeof(T);
+  LIVO2_SZ(livo2_state) LIVO2_SZ(livo2_map_view) LIVO2_SZ(livo2_lidar_cfg) LIVO2_SZ(livo2_lidar_sums) LIVO2_SZ(livo2_lidar_points) LIVO2_SZ(livo2_lidar_result)
+  LIVO2_SZ(livo2_cam) LIVO2_SZ(livo2_visual_cfg) LIVO2_SZ(livo2_visual_sums) LIVO2_SZ(livo2_visual_step) LIVO2_SZ(livo2_visual_result)
+  LIVO2_SZ(livo2_plane_fit) LIVO2_SZ(livo2_imu_step) LIVO2_SZ(livo2_imu_cfg) LIVO2_SZ(livo2_imu_pose) LIVO2_SZ(livo2_select_cfg)
+  LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out)
+#undef LIVO2_SZ
+  return 0;
+}
 
 static int ctx_create_impl(int device, void *stream, bool external, livo2_ctx **out) {
   if (!out) return LIVO2_ERR_INVALID;

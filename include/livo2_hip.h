@@ -64,6 +64,9 @@ const char *livo2_last_error(const livo2_ctx *ctx);
 void *livo2_ctx_stream(livo2_ctx *ctx);                 /* the hipStream_t this ctx launches on */
 int livo2_ctx_synchronize(livo2_ctx *ctx);
 const char *livo2_version(void);
+/* sizeof() of a struct of this header as the library was compiled ("livo2_state", "livo2_lidar_cfg", ...), 0 for an unknown name: lets a
+ * foreign-language binding check its mirror of the layouts at load time. */
+int32_t livo2_abi_sizeof(const char *struct_name);
 
 /* Per-kernel timing with HIP events on the ctx stream (off by default; adds an event pair per launch).
  * which: 0 = LiDAR residual kernel, 1 = visual residual kernel, 2 = ESIKF solve kernels. */

@@ -32,6 +32,24 @@ def test_struct_layouts_match_header(livo2):
     assert C.sizeof(a.LidarCfg) == 8 + 8 * 5 + 8 * 12
 
 
+def test_ctypes_mirrors_have_the_compiled_sizes(livo2):
+    """every struct of the header, as compiled into the library, against its ctypes mirror (padding included)"""
+    a = livo2.abi
+    lib = a.load_library()
+    mirrors = dict(livo2_state=a.State, livo2_map_view=a.MapView, livo2_lidar_cfg=a.LidarCfg, livo2_lidar_sums=a.LidarSums, livo2_lidar_points=a.LidarPoints,
+                   livo2_lidar_result=a.LidarResult, livo2_cam=a.Cam, livo2_visual_cfg=a.VisualCfg, livo2_visual_sums=a.VisualSums, livo2_visual_step=a.VisualStep,
+                   livo2_visual_result=a.VisualResult, livo2_plane_fit=a.PlaneFit, livo2_imu_cfg=a.ImuCfg, livo2_select_cfg=a.SelectCfg, livo2_retrieve_cfg=a.RetrieveCfg,
+                   livo2_retrieve_candidates=a.RetrieveCandidates, livo2_retrieve_out=a.RetrieveOut)
+    for name, cls in mirrors.items():
+        assert lib.livo2_abi_sizeof(name.encode()) == C.sizeof(cls), name
+    assert lib.livo2_abi_sizeof(b"livo2_imu_step") == 64 and lib.livo2_abi_sizeof(b"livo2_imu_pose") == 176
+    assert lib.livo2_abi_sizeof(b"no_such_struct") == 0
+    # every struct the header defines is covered by the query
+    text = open(a.HEADER_PATH).read()
+    for name in set(re.findall(r"typedef struct (livo2_[a-z0-9_]+)\s*\{", text)):       # (livo2_ctx is opaque)
+        assert lib.livo2_abi_sizeof(name.encode()) > 0, name
+
+
 def test_version_string(livo2):
     assert b"gfx950" in livo2.abi.load_library().livo2_version()
 
