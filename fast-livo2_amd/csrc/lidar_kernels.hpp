@@ -16,9 +16,11 @@
 #pragma once
 #include "esikf_solve.hpp"
 
-#define LIDAR_BLOCK 256
+#define LIDAR_BLOCK 256          // threads (= points) per block of a single-scan launch
+#define LIDAR_BLOCK_BATCH 128    // ... of a batched launch: finer blocks keep more of them in flight per CU (2 waves + 32 KB LDS each)
 #define LIDAR_NSUM 29       // 21 (sym HtH) + 6 (Htz) + n_eff + sum|r|
-#define LIDAR_LDS_BYTES ((LIDAR_BLOCK / LIVO2_WAVE) * 32 * 65 * 8)
+#define LIDAR_LDS_BYTES_OF(B) (((B) / LIVO2_WAVE) * 32 * 65 * 8)
+#define LIDAR_LDS_BYTES LIDAR_LDS_BYTES_OF(LIDAR_BLOCK)
 #define LIDAR_LDS_DUMP 512          // landing area of the software-prefetch loads (touch_line), behind the tiles
 
 struct LidarKernelArgs {
@@ -276,9 +278,9 @@ __device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx
 
 // Software prefetch (gfx950 has no prefetch instruction): a one-dword LDS-direct load (no destination VGPR) into a dump area
 // behind the block's tiles.  Nothing reads the dump; the point is that the line is now on its way to this CU's L2/L1.
-__device__ __forceinline__ void touch_line(const void *p) {
+template <int BLOCK> __device__ __forceinline__ void touch_line(const void *p) {
   uint32_t keep_m0;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep_m0) : "v"(p), "s"((uint32_t)LIDAR_LDS_BYTES) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep_m0) : "v"(p), "s"((uint32_t)LIDAR_LDS_BYTES_OF(BLOCK)) : "memory");
 }
 
 // ---- block-cooperative visit of non-plane roots ----------------------------------------------------------------------------
@@ -289,26 +291,26 @@ __device__ __forceinline__ void touch_line(const void *p) {
 // pair per round (whole 256-B record copy from the candidate-ordered array: one round trip -> radius gate -> 3-sigma gate ->
 // probability and measurement row), and the owner folds the results of its pairs IN LIST ORDER with the reference's strict '>'
 // (ties keep the first), which reproduces the serial recursion of build_single_residual exactly.
-struct __attribute__((aligned(16))) CoopLds {
-  double ctx[LIDAR_BLOCK][18];       // owner context: pw pc pi q (3 each) Cb (6)
-  double res[LIDAR_BLOCK][10];       // result rows of accepted pairs: prob, w, h[6], {float r, int32 plane}
-  unsigned long long omax[LIDAR_BLOCK];                // per owner: largest accepted probability of the round (bit pattern)
-  int32_t omin[LIDAR_BLOCK];                           // per owner: first slot holding it
-  int32_t pair_cand[2 * LIDAR_BLOCK];                  // per slot of the round: candidate record
-  uint8_t pair_owner[2 * LIDAR_BLOCK];                 //                        owning thread
-  uint8_t slot_row[2 * LIDAR_BLOCK];                   //                        result row of an accepted pair
-  uint8_t oacc[LIDAR_BLOCK];                           // per owner: some pair of the round was accepted
-  int32_t wave_tot[2][LIDAR_BLOCK / LIVO2_WAVE];       // one set per visit (first / neighbour): no barrier separates their plans
-  int32_t res_count, overflow;                         // double rounds: rows handed out, more than LIDAR_BLOCK accepted pairs
+template <int BLOCK> struct __attribute__((aligned(16))) CoopLds {
+  double ctx[BLOCK][18];       // owner context: pw pc pi q (3 each) Cb (6)
+  double res[BLOCK][10];       // result rows of accepted pairs: prob, w, h[6], {float r, int32 plane}
+  unsigned long long omax[BLOCK];                // per owner: largest accepted probability of the round (bit pattern)
+  int32_t omin[BLOCK];                           // per owner: first slot holding it
+  int32_t pair_cand[2 * BLOCK];                  // per slot of the round: candidate record
+  uint8_t pair_owner[2 * BLOCK];                 //                        owning thread
+  uint8_t slot_row[2 * BLOCK];                   //                        result row of an accepted pair
+  uint8_t oacc[BLOCK];                           // per owner: some pair of the round was accepted
+  int32_t wave_tot[2][BLOCK / LIVO2_WAVE];       // one set per visit (first / neighbour): no barrier separates their plans
+  int32_t res_count, overflow;                         // double rounds: rows handed out, more than BLOCK accepted pairs
 };
-static_assert(LIDAR_BLOCK <= 256, "pair_owner / slot_row are bytes");
-static_assert(sizeof(CoopLds) <= LIDAR_LDS_BYTES, "CoopLds must fit in the block's reduction tiles");
+static_assert(sizeof(CoopLds<256>) <= LIDAR_LDS_BYTES_OF(256) && sizeof(CoopLds<128>) <= LIDAR_LDS_BYTES_OF(128) && sizeof(CoopLds<64>) <= LIDAR_LDS_BYTES_OF(64),
+              "CoopLds must fit in the block's reduction tiles (pair_owner / slot_row are bytes: BLOCK <= 256)");
 
 // Planning half (every thread of the block calls it; cnt = 0 for threads without a pending candidate list): the pair counts are
 // prefix-summed over the block.  One barrier, LDS only — global loads issued before it (the plane
 // record of a plane-root lane) stay in flight across it, which is why the plan is made BEFORE those records are consumed.
 struct CoopPlan { int cnt, cand_begin, excl, W; };
-__device__ __forceinline__ CoopPlan coop_plan(CoopLds &L, int which, int cnt, int cand_begin) {
+template <int BLOCK> __device__ __forceinline__ CoopPlan coop_plan(CoopLds<BLOCK> &L, int which, int cnt, int cand_begin) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int incl = cnt;                                            // inclusive prefix sum of the pair counts: wave scan + wave totals
 #pragma unroll
@@ -317,20 +319,20 @@ __device__ __forceinline__ CoopPlan coop_plan(CoopLds &L, int which, int cnt, in
   __syncthreads();
   int woff = 0, W = 0;
 #pragma unroll
-  for (int w = 0; w < LIDAR_BLOCK / LIVO2_WAVE; w++) { const int t = L.wave_tot[which][w]; if (w < wave) woff += t; W += t; }
+  for (int w = 0; w < BLOCK / LIVO2_WAVE; w++) { const int t = L.wave_tot[which][w]; if (w < wave) woff += t; W += t; }
   return {cnt, cand_begin, woff + incl - cnt, W};
 }
 
 // Every thread parks its point context in LDS before the first plan: evaluators read the owners' rows, and the thread itself
 // re-reads its own row after the evaluation instead of holding 36 VGPRs across it (the evaluation is the register peak).
-__device__ __forceinline__ void coop_park_ctx(CoopLds &L, const PointCtx &pt) {
+template <int BLOCK> __device__ __forceinline__ void coop_park_ctx(CoopLds<BLOCK> &L, const PointCtx &pt) {
   double *c = L.ctx[threadIdx.x];
 #pragma unroll
   for (int k = 0; k < 3; k++) { c[k] = pt.pw[k]; c[3 + k] = pt.pc[k]; c[6 + k] = pt.pi[k]; c[9 + k] = pt.q[k]; }
 #pragma unroll
   for (int k = 0; k < 6; k++) c[12 + k] = pt.Cb[k];
 }
-__device__ __forceinline__ void coop_unpark_ctx(const CoopLds &L, PointCtx &pt) {
+template <int BLOCK> __device__ __forceinline__ void coop_unpark_ctx(const CoopLds<BLOCK> &L, PointCtx &pt) {
   const double *c = L.ctx[threadIdx.x];
 #pragma unroll
   for (int k = 0; k < 3; k++) { pt.pw[k] = c[k]; pt.pc[k] = c[3 + k]; pt.pi[k] = c[6 + k]; pt.q[k] = c[9 + k]; }
@@ -350,11 +352,11 @@ __device__ __forceinline__ void coop_unpark_ctx(const CoopLds &L, PointCtx &pt) 
 // the winner — LDS max over the probability bit patterns (accepted probabilities are non-negative, so the patterns order like the
 // values), then LDS min over the slots holding that maximum (ascending slot = list order -> the first one) — and the owner copies
 // one row (walking its accepted rows cost a dependent LDS round trip per accepted plane, ~1.8 us in cluttered blocks).
-template <int PAIRS> __device__ __forceinline__ bool coop_round(CoopLds &L, const DevMap &map, const CoopPlan &pl, int base, int max_layer, double sigma_num,
+template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int base, int max_layer, double sigma_num,
                                                               const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
   const int tid = threadIdx.x;
   const int cnt = pl.cnt, cand_begin = pl.cand_begin, excl = pl.excl, W = pl.W;
-  constexpr int SPAN = PAIRS * LIDAR_BLOCK;
+  constexpr int SPAN = PAIRS * BLOCK;
   CSTAMP(0);
   // owners publish the pairs that fall into this round
   const int k_lo = max(0, base - excl), k_hi = min(cnt, base + SPAN - excl);
@@ -372,7 +374,7 @@ template <int PAIRS> __device__ __forceinline__ bool coop_round(CoopLds &L, cons
   const double2 *P2[PAIRS];
 #pragma unroll
   for (int q = 0; q < PAIRS; q++) {
-    const int s = tid + q * LIDAR_BLOCK;
+    const int s = tid + q * BLOCK;
     act[q] = base + s < W; acc[q] = false; owner[q] = 0; pbits[q] = 0ull;
     P2[q] = reinterpret_cast<const double2 *>(map.cand_rec + (size_t)(act[q] ? L.pair_cand[s] : 0) * PLANE_REC_DOUBLES);
     if (act[q]) owner[q] = L.pair_owner[s];
@@ -435,10 +437,10 @@ template <int PAIRS> __device__ __forceinline__ bool coop_round(CoopLds &L, cons
       const double prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
       int row = tid;
       if (PAIRS > 1) row = atomicAdd(&L.res_count, 1);
-      if (row < LIDAR_BLOCK) {
+      if (row < BLOCK) {
         acc[q] = true;
         pbits[q] = __builtin_bit_cast(unsigned long long, prob);
-        L.slot_row[tid + q * LIDAR_BLOCK] = (uint8_t)row;
+        L.slot_row[tid + q * BLOCK] = (uint8_t)row;
         L.oacc[owner[q]] = 1;
         atomicMax(&L.omax[owner[q]], pbits[q]);
         double *o = L.res[row];
@@ -454,7 +456,7 @@ template <int PAIRS> __device__ __forceinline__ bool coop_round(CoopLds &L, cons
   if (PAIRS > 1 && L.overflow) { __syncthreads(); return false; }   // (block-uniform; the barrier keeps the flag readable until everyone has seen it)
 #pragma unroll
   for (int q = 0; q < PAIRS; q++)
-    if (acc[q] && L.omax[owner[q]] == pbits[q]) atomicMin(&L.omin[owner[q]], tid + q * LIDAR_BLOCK);
+    if (acc[q] && L.omax[owner[q]] == pbits[q]) atomicMin(&L.omin[owner[q]], tid + q * BLOCK);
   __syncthreads();
   if (k_lo < k_hi && L.oacc[tid]) {
     best.success = true;
@@ -474,7 +476,7 @@ template <int PAIRS> __device__ __forceinline__ bool coop_round(CoopLds &L, cons
 }
 
 // Evaluation half: every thread of the block calls it with its plan (W is block-uniform).
-__device__ __forceinline__ void coop_run(CoopLds &L, const DevMap &map, const CoopPlan &pl, int max_layer, double sigma_num,
+template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int max_layer, double sigma_num,
                                          const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
 #ifdef LIVO2_PHASE_PROF
 #define COOP_PROF_FWD , cprof
@@ -482,9 +484,9 @@ __device__ __forceinline__ void coop_run(CoopLds &L, const DevMap &map, const Co
 #define COOP_PROF_FWD
 #endif
   for (int base = 0; base < pl.W;) {
-    if (pl.W - base > LIDAR_BLOCK && coop_round<2>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD)) { base += 2 * LIDAR_BLOCK; continue; }
-    coop_round<1>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD);
-    base += LIDAR_BLOCK;
+    if (pl.W - base > BLOCK && coop_round<2, BLOCK>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD)) { base += 2 * BLOCK; continue; }
+    coop_round<1, BLOCK>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD);
+    base += BLOCK;
   }
 }
 
@@ -493,18 +495,18 @@ __device__ __forceinline__ void coop_run(CoopLds &L, const DevMap &map, const Co
 // block b on XCD b % 8): neighbouring points share voxel planes, so each XCD's private 4-MiB L2 keeps one spatial slab.
 // (pblock, pgrid): this block's index within the scan's own grid and that grid's size — blockIdx/gridDim for a single scan, the
 // frame-local values in a batched launch.  Row `pblock` of `partials` receives the block's sums, so a frame reduces in the same
-// order (bit-identical sums) whether it is launched alone or inside a batch.
-__device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const DevCtl *__restrict__ ctl, double *__restrict__ partials, int check_stop,
+// order whether it is launched alone or inside a batch (for the same BLOCK).
+template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const DevCtl *__restrict__ ctl, double *__restrict__ partials, int check_stop,
                                                     int pblock, int pgrid) {
   if (check_stop && ctl->hdr.stop) return;
   extern __shared__ __attribute__((aligned(16))) double lds_red[];
   const int per_xcd = pgrid >> 3;                                // host launches a multiple of 8 blocks per scan
   const int vb = (pblock & 7) * per_xcd + (pblock >> 3);         // chunk index; chunks past the scan are empty
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = vb * LIDAR_BLOCK + tid;            // position in the sorted scan
+  const int i = vb * BLOCK + tid;            // position in the sorted scan
   const bool valid = i < a.n;
   const int ic = valid ? i : 0;                    // clamped index: invalid lanes compute on point 0 and contribute nothing
-  CoopLds &coop = *reinterpret_cast<CoopLds *>(lds_red);       // aliases the block's reduction tiles (used strictly before them)
+  CoopLds<BLOCK> &coop = *reinterpret_cast<CoopLds<BLOCK> *>(lds_red);       // aliases the block's reduction tiles (used strictly before them)
 
   PHASE(0);
   // wave-uniform state (scalar loads)
@@ -611,7 +613,7 @@ __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, co
     }
     // A plane-root neighbour is visited only if the first visit fails, one dependent trip later: start pulling its two cache
     // lines towards this CU now (a discarded dword per line), so that trip is an L2 hit instead of an HBM miss.
-    if (nb.val >= 0) { const double *q = a.map.planes + (size_t)nb.val * PLANE_REC_DOUBLES; touch_line(q); touch_line(q + 16); }
+    if (nb.val >= 0) { const double *q = a.map.planes + (size_t)nb.val * PLANE_REC_DOUBLES; touch_line<BLOCK>(q); touch_line<BLOCK>(q + 16); }
     if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
     plan1W = plan1.W;
     if (plan1.W > 0) {              // block-uniform
@@ -689,7 +691,9 @@ __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, co
   }
   __syncthreads();
   if (tid < 32) {
-    const double v = ((lds_red[tid] + lds_red[32 + tid]) + lds_red[64 + tid]) + lds_red[96 + tid];
+    double v = lds_red[tid];
+#pragma unroll
+    for (int w = 1; w < BLOCK / LIVO2_WAVE; w++) v = v + lds_red[32 * w + tid];
     partials[(size_t)pblock * 32 + tid] = (tid < LIDAR_NSUM) ? v : 0.0;
   }
   PHASE(6);
@@ -697,19 +701,19 @@ __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, co
 
 __global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop) {
-  lidar_residual_body(a, ctl, partials, check_stop, (int)blockIdx.x, (int)gridDim.x);
+  lidar_residual_body<LIDAR_BLOCK>(a, ctl, partials, check_stop, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Batched launch: several independent (scan, state) problems against the resident map in ONE grid.  A single 100k-point scan is
 // 392 blocks — fewer than the 512 the chip holds at once — so its launch lasts as long as its slowest block (~2x the mean);
 // with several frames in the grid the CUs always have another block to start and the tail is paid once per batch.
 struct LidarBatchEntry { LidarKernelArgs a; DevCtl *ctl; double *partials; int32_t block_begin, nblocks; };
-__global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual_batch(const LidarBatchEntry *__restrict__ entries,
+__global__ void __launch_bounds__(LIDAR_BLOCK_BATCH) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual_batch(const LidarBatchEntry *__restrict__ entries,
                                                                 const int32_t *__restrict__ block_frame, int check_stop) {
   const int f = block_frame[blockIdx.x];                         // block-uniform: scalar loads
   const LidarBatchEntry &e = entries[f];
   const LidarKernelArgs a = e.a;
-  lidar_residual_body(a, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);
+  lidar_residual_body<LIDAR_BLOCK_BATCH>(a, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);
 }
 
 // Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 16 slices

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restr
 #else
 #define SOLVE_PROF_ARG
 #endif
-int lidar_grid(int n) { int chunks = (n + LIDAR_BLOCK - 1) / LIDAR_BLOCK; int per_xcd = (chunks + 7) / 8; return std::max(8, per_xcd * 8); }
+int lidar_grid(int n, int block = LIDAR_BLOCK) { int chunks = (n + block - 1) / block; int per_xcd = (chunks + 7) / 8; return std::max(8, per_xcd * 8); }
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   if (!cfg) return fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL");
@@ -872,7 +872,8 @@ int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, co
 // ---- batch of frames ---------------------------------------------------------------------------------------------------------
 // B independent StateEstimation problems (own scan, own states) against the resident map.  Every ESIKF iteration is ONE residual
 // grid over all frames plus one solve block per frame; a frame that has stopped (hdr.stop) drops out of later grids at its
-// blocks' first instruction.  Results are identical, bit for bit, to B separate livo2_lidar_update calls.
+// blocks' first instruction.  Same per-point arithmetic and decisions as B separate livo2_lidar_update calls; the partial sums are grouped in
+// LIDAR_BLOCK_BATCH-point blocks here (LIDAR_BLOCK there), so the results agree to rounding, not to the last bit.
 namespace {
 
 __global__ void __launch_bounds__(LIVO2_WAVE) k_batch_scatter_in(const HostIn *__restrict__ in, DevCtl *__restrict__ ctl) {
@@ -929,7 +930,7 @@ int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *x
   ctx->b_off.resize(n_frames); ctx->b_grid.resize(n_frames); ctx->b_block_begin.resize(n_frames);
   int off = 0, blocks = 0;
   for (int f = 0; f < n_frames; f++) {
-    ctx->b_off[f] = off; ctx->b_grid[f] = lidar_grid(std::max(counts[f], 1)); ctx->b_block_begin[f] = blocks;
+    ctx->b_off[f] = off; ctx->b_grid[f] = lidar_grid(std::max(counts[f], 1), LIDAR_BLOCK_BATCH); ctx->b_block_begin[f] = blocks;
     off += counts[f]; blocks += ctx->b_grid[f];
   }
   ctx->b_blocks = blocks;
@@ -998,7 +999,7 @@ static int batch_enqueue(livo2_ctx *ctx, int32_t n_frames, const livo2_state *st
   HIPCHK(hipMemcpyAsync(ctx->bd_entries, ctx->bh_entries, sizeof(LidarBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_batch_scatter_in, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_in, ctx->bd_ctl);
   for (int it = 0; it < iters; it++) {
-    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual_batch, dim3(ctx->b_blocks), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES + LIDAR_LDS_DUMP, ctx->stream, ctx->bd_entries, ctx->bd_block_frame, mode == 1 ? 1 : 0); t.done(); }
+    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual_batch, dim3(ctx->b_blocks), dim3(LIDAR_BLOCK_BATCH), LIDAR_LDS_BYTES_OF(LIDAR_BLOCK_BATCH) + LIDAR_LDS_DUMP, ctx->stream, ctx->bd_entries, ctx->bd_block_frame, mode == 1 ? 1 : 0); t.done(); }
     { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve_batch, dim3(n_frames), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->bd_entries, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
   }
   hipLaunchKernelGGL(k_lidar_finish, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_ctl);

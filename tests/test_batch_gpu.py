@@ -1,6 +1,8 @@
 """GPU parity of the batched-frames path (livo2_lidar_batch_*): several independent StateEstimation problems against one resident
-map in one grid per ESIKF iteration.  Every frame must come out bit-identical to its own livo2_lidar_update call and within the
-usual tolerance of the CPU oracle (src/voxel_map.cpp:338-511 restated in oracle/)."""
+map in one grid per ESIKF iteration.  Every frame must make the same discrete decisions as its own livo2_lidar_update call (iteration
+count, n_eff per iteration) and agree with it to rounding (the batched grid uses 128-point blocks, the single-scan grid 256-point
+blocks: same per-point arithmetic, different grouping of the partial sums), and be within the usual tolerance of the CPU oracle
+(src/voxel_map.cpp:338-511 restated in oracle/).  Two batched runs are bit-identical to each other."""
 import ctypes as C
 
 import numpy as np
@@ -66,7 +68,13 @@ def test_batch_equals_single_and_oracle(ctx, livo2, orc, sc):
     batch = ctx.batch_update([c for c, _ in pstates], [p for _, p in pstates], pcfg)
     assert len(batch) == len(scans)
     for f, (b, s_) in enumerate(zip(batch, single)):
-        assert _bytes(b) == _bytes(s_), f"frame {f}: batched result differs from the single-frame call"
+        assert b.n_iters == s_.n_iters and b.converged == s_.converged, f"frame {f}"
+        for it in range(b.n_iters):
+            assert b.iter_sums[it].n_eff == s_.iter_sums[it].n_eff
+            assert H.relerr(np.array(b.iter_sums[it].HtH), np.array(s_.iter_sums[it].HtH)) < 1e-12 or b.iter_sums[it].n_eff == 0
+            assert np.abs(np.array(b.iter_solution[it]) - np.array(s_.iter_solution[it])).max() < 1e-12
+        d = H.state_diff(b.state, s_.state)
+        assert d["R"] < 1e-13 and d["t"] < 1e-13 and d["P"] < 1e-11, (f, d)
     # reference 2: the oracle
     for f, (xyz, (R, t)) in enumerate(zip(scans, poses)):
         if len(xyz) == 0:
