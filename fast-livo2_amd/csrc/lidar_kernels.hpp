@@ -718,19 +718,20 @@ __global__ void __launch_bounds__(LIDAR_BLOCK_BATCH) __attribute__((amdgpu_waves
 
 // Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 16 slices
 // x 32 values: slice s adds blocks s, s+16, ... in order.  The rows were written by other CUs, so every dependent load is a full
-// ~1.5-us round trip (a single wave walking them serially cost ~20 us): each thread therefore issues ALL its loads (up to 32,
-// i.e. 512 rows = 131k points; beyond that a loop) before the first add.  The slices are then joined in fixed order.
+// ~1.5-us round trip (a single wave walking them serially cost ~20 us): each thread therefore issues its loads in batches of 32
+// (512 rows = 131k points of a single scan per batch) before the first add of the batch.  The slices are then joined in fixed order.
 // Every thread of the block must call this.  (512 threads, not 1024: the register-resident solve of wave 0 needs > 128 VGPRs.)
 #define SOLVE_THREADS 512
 __device__ inline void reduce_partials_block(const double *__restrict__ partials, int nblocks, double *scratch /*[16][33]*/, double *out /*[32]*/) {
   const int t = threadIdx.x, kidx = t & 31, slice = t >> 5;       // 16 slices
-  double v[32];
-#pragma unroll
-  for (int u = 0; u < 32; u++) { const int b = slice + 16 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
   double acc = 0.0;
+  for (int base = 0; base < nblocks; base += 512) {                  // 512 rows per pass: every pass issues its 32 loads before the first add
+    double v[32];
 #pragma unroll
-  for (int u = 0; u < 32; u++) acc += v[u];
-  for (int b = slice + 512; b < nblocks; b += 16) acc += partials[(size_t)b * 32 + kidx];
+    for (int u = 0; u < 32; u++) { const int b = base + slice + 16 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 32; u++) acc += v[u];
+  }
   scratch[slice * 33 + kidx] = acc;
   __syncthreads();
   if (t < 32) {
