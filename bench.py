@@ -431,7 +431,7 @@ def main():
                             "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS, "frac_of_copy_kernel": bach / copy_gbs,
                                          "kernel": "k_lidar_residual_batch", "bytes_per_launch": LIDAR_BYTES_PER_EVAL * npts},
                             "frames_per_s": world * B * reps_b / tfb, "full_update_iters": [int(r.n_iters) for r in rb],
-                            "note": "same device code as the single-scan path with 128-point blocks, B independent (scan, state) problems per grid; same decisions as B single calls, sums equal to rounding (tests/test_batch_gpu.py)"}
+                            "note": "same device code as the single-scan path with 64-point blocks, B independent (scan, state) problems per grid; same decisions as B single calls, sums equal to rounding (tests/test_batch_gpu.py)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -229,7 +229,7 @@ int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, co
  * with its own feats_down_body scan, state_ and state_propagat — solved against the ONE resident map snapshot.  Every ESIKF
  * iteration is a single residual grid over all frames plus one solve block per frame, so the GPU is kept full where a lone
  * 100k-point scan leaves half of it idle; frames stop individually (convergence / rematch logic per frame).  Every frame makes the same
- * discrete decisions as its own livo2_lidar_update call and agrees with it to rounding (the batched grid groups the partial sums in 128-point blocks,
+ * discrete decisions as its own livo2_lidar_update call and agrees with it to rounding (the batched grid groups the partial sums in 64-point blocks,
  * the single-scan grid in 256-point blocks); repeated batched runs are bit-identical.  Per-point outputs are not produced in batch mode.
  * xyz: the scans concatenated, [sum(counts)][3] float32 (sensor frame); counts[f] = points of frame f (0 allowed). */
 int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *xyz, const int32_t *counts, const livo2_lidar_cfg *cfg);

@@ -1,6 +1,6 @@
 """GPU parity of the batched-frames path (livo2_lidar_batch_*): several independent StateEstimation problems against one resident
 map in one grid per ESIKF iteration.  Every frame must make the same discrete decisions as its own livo2_lidar_update call (iteration
-count, n_eff per iteration) and agree with it to rounding (the batched grid uses 128-point blocks, the single-scan grid 256-point
+count, n_eff per iteration) and agree with it to rounding (the batched grid uses 64-point blocks, the single-scan grid 256-point
 blocks: same per-point arithmetic, different grouping of the partial sums), and be within the usual tolerance of the CPU oracle
 (src/voxel_map.cpp:338-511 restated in oracle/).  Two batched runs are bit-identical to each other."""
 import ctypes as C
