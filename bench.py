@@ -95,6 +95,10 @@ def cpu_baseline(sc, budget_s=20.0):
     ss = _synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
     orc.visual_select(ss, lib)
     sel_s = min(orc.visual_select(ss, lib)["seconds"] for _ in range(3))
+    cs = _synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)
+    tch = []
+    for _ in range(3):
+        t0 = time.perf_counter(); orc.visual_retrieve(cs, lib); tch.append(time.perf_counter() - t0)
     raw = _synth.raw_scan_scenario(seed=51, n_raw=240000)
     tpre = []
     for _ in range(3):
@@ -102,7 +106,7 @@ def cpu_baseline(sc, budget_s=20.0):
         u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
         orc.voxel_grid(u_, raw.leaf, lib)
         tpre.append(time.perf_counter() - t0)
-    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
+    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre), "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s,
             "value": out[4][0], "unit": "evals/s", "cores": 4, "kind": kind,
             "sample": f"{out[4][1]} full StateEstimation calls (5 iterations each) on the same {len(sc.xyz)}-point scan, OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "value_1thread": out[1][0], "value_all_cores": out[ncores][0], "host_cores": ncores}
@@ -378,6 +382,22 @@ def main():
                                   "candidates_per_s_kernel": len(rs.pos) / (k_us * 1e-6), "bytes_per_candidate": bytes_per_cand,
                                   "achieved_GBps": bytes_per_cand * len(rs.pos) / (k_us * 1e-6) / 1e9, "candidates_per_s_with_h2d_d2h": len(rs.pos) / t_e2e,
                                   "note": "k_warp_candidates + k_warp_scan + k_warp_gather (vio.cpp:698-767); CPU figure in cpu_baseline.retrieve_candidates_per_s_1thread"}
+        # the whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail), map + observations resident
+        cs = synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)     # grid_size 5 as in config/avia.yaml
+        ctx.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)
+        ctx.visual_obs_upload(cs)
+        ctx.visual_retrieve_from_map(cs, want_patches=False)
+        us, t1 = [], time.perf_counter()
+        for _ in range(5):
+            ctx.visual_obs_upload(cs)                      # resets ref_patch: every call makes the first-time choices again
+            co = ctx.visual_retrieve_from_map(cs, want_patches=False); us.append(ctx.retrieve_from_map_last_kernel_us())
+        t_e2e = (time.perf_counter() - t1) / 5
+        k_us = float(np.median(us))
+        extra["retrieve_from_map"] = {"scan_points": len(cs.sel.pg), "visual_map_points": len(cs.sel.pos), "observations": int(cs.obs_offset[-1]),
+                                      "grid_cells": int(cs.sel.grid_n_width * cs.sel.grid_n_height), "candidates": co["n_candidates"], "accepted": co["n_accepted"],
+                                      "kernel_us": k_us, "calls_per_s_with_obs_upload_h2d_d2h": 1.0 / t_e2e,
+                                      "note": "selection + k_choose_ref + scan + k_gather_candidates + tail in one chain of launches (vio.cpp:352-780), no host round trip; "
+                                              "CPU figure in cpu_baseline.retrieve_from_map_seconds_1thread"}
         # batched init_plane (plane fit + plane covariance) on the device
         fpw, fvar, foff = plane_fit_groups()
         ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (Cam, ImuCfg, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveOut, SelectCfg, State, VisualCfg, VisualResult, VisualSums)  # noqa: F401
+from .abi import (Cam, ImuCfg, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveChainOut, RetrieveOut, SelectCfg, State, VisualCfg, VisualObs, VisualResult, VisualSums)  # noqa: F401
 
 
 class Livo2Error(RuntimeError):
@@ -278,9 +278,13 @@ class Context:
         refs = np.ascontiguousarray(rs.ref_imgs, np.uint8)
         keep = dict(pos=_f64(rs.pos), normal=_f64(rs.normal), px=_f64(rs.ref_px), f=_f64(rs.ref_f), R=_f64(rs.ref_R), t=_f64(rs.ref_t), ie=_f64(rs.ref_inv_expo),
                     idx=np.ascontiguousarray(rs.ref_img_idx, np.int32), lvl=np.ascontiguousarray(rs.ref_level, np.int32))
+        rid = getattr(rs, "ref_id", None)
+        if rid is not None:
+            keep["id"] = np.ascontiguousarray(rid, np.int32)
         cand = RetrieveCandidates(n, 0, abi.as_ptr(keep["pos"], C.c_double), abi.as_ptr(keep["normal"], C.c_double), abi.as_ptr(keep["idx"], C.c_int32),
                                   abi.as_ptr(keep["px"], C.c_double), abi.as_ptr(keep["f"], C.c_double), abi.as_ptr(keep["R"], C.c_double),
-                                  abi.as_ptr(keep["t"], C.c_double), abi.as_ptr(keep["lvl"], C.c_int32), abi.as_ptr(keep["ie"], C.c_double))
+                                  abi.as_ptr(keep["t"], C.c_double), abi.as_ptr(keep["lvl"], C.c_int32), abi.as_ptr(keep["ie"], C.c_double),
+                                  abi.as_ptr(keep["id"], C.c_int32) if rid is not None else None)
         res = dict(accepted=np.zeros(n, np.int32), search_level=np.zeros(n, np.int32), error=np.zeros(n, np.float32), ncc=np.zeros(n), A=np.zeros((n, 4)),
                    patch_wrap=np.zeros((n, L, 64), np.float32) if want_patches else None)
         out = RetrieveOut(abi.as_ptr(res["accepted"], C.c_int32), abi.as_ptr(res["search_level"], C.c_int32), abi.as_ptr(res["error"], C.c_float),
@@ -295,6 +299,61 @@ class Context:
 
     def retrieve_last_kernel_us(self):
         return float(self.lib.livo2_visual_retrieve_last_kernel_us(self.h))
+
+    def visual_obs_upload(self, cs):
+        """Observation table of the visual map (after visual_map_upload, same point order) from a scenario-like object with obs_offset, obs_*,
+        normal, normal_initialized, ref_patch, ref_imgs (scenarios.synth.RetrieveChainScenario)."""
+        refs = np.ascontiguousarray(cs.ref_imgs, np.uint8)
+        k = dict(off=np.ascontiguousarray(cs.obs_offset, np.int32), id=np.ascontiguousarray(cs.obs_id, np.int32), img=np.ascontiguousarray(cs.obs_img_idx, np.int32),
+                 px=_f64(cs.obs_px), f=_f64(cs.obs_f), R=_f64(cs.obs_R), t=_f64(cs.obs_t), lvl=np.ascontiguousarray(cs.obs_level, np.int32), ie=_f64(cs.obs_inv_expo),
+                 patch=np.ascontiguousarray(cs.obs_patch, np.float32), normal=_f64(cs.normal), ninit=np.ascontiguousarray(cs.normal_initialized, np.uint8),
+                 rp=np.ascontiguousarray(cs.ref_patch, np.int32))
+        o = VisualObs(len(k["id"]), int(refs.shape[0]), abi.as_ptr(k["off"], C.c_int32), abi.as_ptr(k["id"], C.c_int32), abi.as_ptr(k["img"], C.c_int32),
+                      abi.as_ptr(k["px"], C.c_double), abi.as_ptr(k["f"], C.c_double), abi.as_ptr(k["R"], C.c_double), abi.as_ptr(k["t"], C.c_double),
+                      abi.as_ptr(k["lvl"], C.c_int32), abi.as_ptr(k["ie"], C.c_double), abi.as_ptr(k["patch"], C.c_float), abi.as_ptr(k["normal"], C.c_double),
+                      abi.as_ptr(k["ninit"], C.c_uint8), abi.as_ptr(k["rp"], C.c_int32), abi.as_ptr(refs, C.c_uint8), int(refs.shape[2]), int(refs.shape[1]),
+                      int(refs.shape[2]), 0)
+        self._chk(self.lib.livo2_visual_obs_upload(self.h, C.byref(o)))
+
+    def visual_retrieve_from_map(self, cs, want_patches=True):
+        """The whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail) over a RetrieveChainScenario-like object
+        whose points / observations were uploaded with visual_map_upload + visual_obs_upload.  Returns the stage outputs (same names as
+        oracle.orc.visual_retrieve) and leaves the survivors resident as the frame."""
+        ss, L = cs.sel, int(cs.cfg["patch_pyrimid_level"])
+        sc = SelectCfg()
+        sc.cam.fx, sc.cam.fy, sc.cam.cx, sc.cam.cy = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"]
+        sc.cam.distortion, sc.cam.width, sc.cam.height = 0, ss.cam["width"], ss.cam["height"]
+        sc.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); sc.t_cur[:] = np.asarray(ss.t_cur, float).tolist()
+        sc.border, sc.grid_size, sc.grid_n_width, sc.grid_n_height, sc.patch_size_half = int(ss.border), int(ss.grid_size), int(ss.grid_n_width), int(ss.grid_n_height), 4
+        c = RetrieveCfg()
+        c.cam = sc.cam
+        c.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); c.t_cur[:] = np.asarray(ss.t_cur, float).tolist(); c.inv_expo_cur = float(cs.inv_expo_cur)
+        c.patch_pyrimid_level, c.normal_en, c.ncc_en = L, int(cs.cfg["normal_en"]), int(cs.cfg["ncc_en"])
+        c.ncc_thre, c.outlier_threshold = float(cs.cfg["ncc_thre"]), float(cs.cfg["outlier_threshold"])
+        length = int(ss.grid_n_width) * int(ss.grid_n_height)
+        img, pg = np.ascontiguousarray(cs.img, np.uint8), _f64(ss.pg).reshape(-1, 3)
+        r = dict(cell_point=np.zeros(length, np.int32), cell_dist=np.zeros(length, np.float32), discont=np.zeros(length, np.uint8), cell_obs=np.zeros(length, np.int32),
+                 ref_patch=np.zeros(max(self.n_vm, 1), np.int32), cand_cell=np.zeros(length, np.int32), sub_point=np.zeros(length, np.int32), sub_obs=np.zeros(length, np.int32))
+        t = dict(accepted=np.zeros(length, np.int32), search_level=np.zeros(length, np.int32), error=np.zeros(length, np.float32), ncc=np.zeros(length), A=np.zeros((length, 4)),
+                 patch_wrap=np.zeros((length, L, 64), np.float32) if want_patches else None)
+        out = RetrieveChainOut(abi.as_ptr(r["cell_point"], C.c_int32), abi.as_ptr(r["cell_dist"], C.c_float), abi.as_ptr(r["discont"], C.c_uint8),
+                               abi.as_ptr(r["cell_obs"], C.c_int32), abi.as_ptr(r["ref_patch"], C.c_int32), abi.as_ptr(r["cand_cell"], C.c_int32),
+                               RetrieveOut(abi.as_ptr(t["accepted"], C.c_int32), abi.as_ptr(t["search_level"], C.c_int32), abi.as_ptr(t["error"], C.c_float),
+                                           abi.as_ptr(t["ncc"], C.c_double), abi.as_ptr(t["A"], C.c_double), abi.as_ptr(t["patch_wrap"], C.c_float) if want_patches else None),
+                               abi.as_ptr(r["sub_point"], C.c_int32), abi.as_ptr(r["sub_obs"], C.c_int32))
+        nc, na = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.livo2_visual_retrieve_from_map(self.h, abi.as_ptr(img, C.c_uint8), img.shape[1], img.shape[0], img.shape[1], abi.as_ptr(pg, C.c_double), len(pg),
+                                                          C.byref(sc), C.byref(c), C.byref(out), C.byref(nc), C.byref(na)))
+        nc, na = int(nc.value), int(na.value)
+        r["ref_patch"] = r["ref_patch"][: self.n_vm]
+        r["cand_cell"], r["sub_point"], r["sub_obs"] = r["cand_cell"][:nc], r["sub_point"][:na], r["sub_obs"][:na]
+        r["tail"] = {k: (v[:nc] if v is not None else None) for k, v in t.items()}
+        r["n_candidates"], r["n_accepted"] = nc, na
+        self.M, self.L = na, L
+        return r
+
+    def retrieve_from_map_last_kernel_us(self):
+        return float(self.lib.livo2_visual_retrieve_from_map_last_kernel_us(self.h))
 
     def set_reference(self, ref_imgs, ref_img_idx, ref_px, ref_f, ref_R, ref_pos):
         """inverse-compositional variant: reference patches of the points uploaded by set_frame"""

@@ -121,12 +121,27 @@ class RetrieveCfg(C.Structure):
 class RetrieveCandidates(C.Structure):
     _fields_ = [("n", C.c_int32), ("pad", C.c_int32), ("pos", C.POINTER(C.c_double)), ("normal", C.POINTER(C.c_double)), ("ref_img_idx", C.POINTER(C.c_int32)),
                 ("ref_px", C.POINTER(C.c_double)), ("ref_f", C.POINTER(C.c_double)), ("ref_R", C.POINTER(C.c_double)), ("ref_t", C.POINTER(C.c_double)), ("ref_level", C.POINTER(C.c_int32)),
-                ("ref_inv_expo", C.POINTER(C.c_double))]
+                ("ref_inv_expo", C.POINTER(C.c_double)), ("ref_id", C.POINTER(C.c_int32))]
 
 
 class RetrieveOut(C.Structure):
     _fields_ = [("accepted", C.POINTER(C.c_int32)), ("search_level", C.POINTER(C.c_int32)), ("error", C.POINTER(C.c_float)), ("ncc", C.POINTER(C.c_double)),
                 ("A_cur_ref", C.POINTER(C.c_double)), ("patch_wrap", C.POINTER(C.c_float))]
+
+
+class VisualObs(C.Structure):
+    """livo2_visual_obs: CSR mirror of VisualPoint::obs_ (include/feature.h, include/visual_point.h of the reference)"""
+    _fields_ = [("n_obs", C.c_int32), ("n_ref", C.c_int32), ("point_offset", C.POINTER(C.c_int32)), ("id", C.POINTER(C.c_int32)), ("img_idx", C.POINTER(C.c_int32)),
+                ("px", C.POINTER(C.c_double)), ("f", C.POINTER(C.c_double)), ("R", C.POINTER(C.c_double)), ("t", C.POINTER(C.c_double)), ("level", C.POINTER(C.c_int32)),
+                ("inv_expo", C.POINTER(C.c_double)), ("patch", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_double)), ("normal_initialized", C.POINTER(C.c_uint8)),
+                ("ref_patch", C.POINTER(C.c_int32)), ("ref_imgs", C.POINTER(C.c_uint8)), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+class RetrieveChainOut(C.Structure):
+    _fields_ = [("cell_point", C.POINTER(C.c_int32)), ("cell_dist", C.POINTER(C.c_float)), ("cell_discontinuous", C.POINTER(C.c_uint8)), ("cell_obs", C.POINTER(C.c_int32)),
+                ("ref_patch", C.POINTER(C.c_int32)), ("cand_cell", C.POINTER(C.c_int32)), ("tail", RetrieveOut), ("sub_point", C.POINTER(C.c_int32)),
+                ("sub_obs", C.POINTER(C.c_int32))]
 
 
 class ImuCfg(C.Structure):
@@ -203,6 +218,10 @@ SIGNATURES = {
     "livo2_visual_retrieve_warp": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_uint8), C.c_int32, _P(RetrieveCandidates), _P(RetrieveCfg),
                                              _P(RetrieveOut), _P(C.c_int32)]),
     "livo2_visual_retrieve_last_kernel_us": (C.c_double, [_CTX]),
+    "livo2_visual_obs_upload": (C.c_int, [_CTX, _P(VisualObs)]),
+    "livo2_visual_retrieve_from_map": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), C.c_int32, _P(SelectCfg), _P(RetrieveCfg),
+                                                 _P(RetrieveChainOut), _P(C.c_int32), _P(C.c_int32)]),
+    "livo2_visual_retrieve_from_map_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_visual_iterate": (C.c_int, [_CTX, C.c_int32, _P(State), _P(VisualCfg), _P(VisualSums), _P(C.c_float), _P(C.c_double), _P(C.c_double)]),
     "livo2_visual_update": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg), _P(VisualResult), _P(C.c_float)]),
     "livo2_visual_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg)]),

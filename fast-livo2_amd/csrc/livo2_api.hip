@@ -11,6 +11,7 @@
 #include "retrieve_kernels.hpp"
 #include "preprocess_kernels.hpp"
 #include "select_kernels.hpp"
+#include "choice_kernels.hpp"
 #include "imu_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
@@ -65,6 +66,18 @@ struct livo2_ctx {
   double *d_sel_pg = nullptr; size_t sel_pg_cap = 0; unsigned long long *d_sel_set = nullptr, *d_sel_depth = nullptr, *d_sel_best = nullptr; size_t sel_set_cap = 0, sel_depth_cap = 0, sel_best_cap = 0;
   int32_t *d_sel_type = nullptr, *d_sel_point = nullptr, *d_sel_flag = nullptr; float *d_sel_dist = nullptr; uint8_t *d_sel_disc = nullptr; size_t sel_type_cap = 0, sel_point_cap = 0, sel_dist_cap = 0, sel_disc_cap = 0;
   double select_kernel_us = 0.0;
+  // observation table of the visual map, reference-patch choice, chained retrieval (N2)
+  bool has_obs = false; int n_obs = 0, ob_n_ref = 0, ob_w = 0, ob_h = 0, ob_stride = 0;
+  int32_t *d_ob_off = nullptr, *d_ob_id = nullptr, *d_ob_img = nullptr, *d_ob_lvl = nullptr, *d_vm_refpatch = nullptr;
+  size_t ob_off_cap = 0, ob_id_cap = 0, ob_img_cap = 0, ob_lvl_cap = 0, vm_refpatch_cap = 0;
+  double *d_ob_px = nullptr, *d_ob_f = nullptr, *d_ob_R = nullptr, *d_ob_t = nullptr, *d_ob_ie = nullptr, *d_vm_normal = nullptr;
+  size_t ob_px_cap = 0, ob_f_cap = 0, ob_R_cap = 0, ob_t_cap = 0, ob_ie_cap = 0, vm_normal_cap = 0;
+  float *d_ob_patch = nullptr; size_t ob_patch_cap = 0; uint8_t *d_vm_ninit = nullptr, *d_ob_imgs = nullptr; size_t vm_ninit_cap = 0, ob_imgs_cap = 0;
+  int32_t *d_ch_obs = nullptr, *d_ch_flag = nullptr, *d_ch_slot = nullptr, *d_cand_cell = nullptr, *d_cand_point = nullptr, *d_cand_obs = nullptr, *d_sub_point = nullptr,
+          *d_sub_obs = nullptr, *d_ch_count = nullptr;
+  size_t ch_obs_cap = 0, ch_flag_cap = 0, ch_slot_cap = 0, cand_cell_cap = 0, cand_point_cap = 0, cand_obs_cap = 0, sub_point_cap = 0, sub_obs_cap = 0;
+  int32_t *d_c_id = nullptr, *d_c_leader = nullptr, *d_ld_keys = nullptr, *d_ld_vals = nullptr; size_t c_id_cap = 0, c_leader_cap = 0, ld_keys_cap = 0, ld_vals_cap = 0;
+  double chain_kernel_us = 0.0;
   // IMU propagation (N4)
   double *d_imu_steps = nullptr, *d_imu_poses = nullptr; size_t imu_steps_cap = 0, imu_poses_cap = 0; livo2_state *d_imu_state = nullptr;   // [2]: in, out
   double imu_kernel_us = 0.0;
@@ -322,7 +335,7 @@ int32_t livo2_abi_sizeof(const char *name) {
   LIVO2_SZ(livo2_state) LIVO2_SZ(livo2_map_view) LIVO2_SZ(livo2_lidar_cfg) LIVO2_SZ(livo2_lidar_sums) LIVO2_SZ(livo2_lidar_points) LIVO2_SZ(livo2_lidar_result)
   LIVO2_SZ(livo2_cam) LIVO2_SZ(livo2_visual_cfg) LIVO2_SZ(livo2_visual_sums) LIVO2_SZ(livo2_visual_step) LIVO2_SZ(livo2_visual_result)
   LIVO2_SZ(livo2_plane_fit) LIVO2_SZ(livo2_imu_step) LIVO2_SZ(livo2_imu_cfg) LIVO2_SZ(livo2_imu_pose) LIVO2_SZ(livo2_select_cfg)
-  LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out)
+  LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out)
 #undef LIVO2_SZ
   return 0;
 }
@@ -362,7 +375,10 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl, ctx->d_c_acc,
                  ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_count, ctx->d_c_err, ctx->d_c_patch, ctx->d_raw, ctx->d_curv, ctx->d_poses, ctx->d_vg_head, ctx->d_vg_slot, ctx->d_vg_misc,
                  ctx->d_vm_pos, ctx->d_vm_pkey, ctx->d_vm_active, ctx->d_vm_fov, ctx->d_sel_pg, ctx->d_sel_set, ctx->d_sel_depth, ctx->d_sel_best, ctx->d_sel_type, ctx->d_sel_point,
-                 ctx->d_sel_flag, ctx->d_sel_dist, ctx->d_sel_disc, ctx->d_imu_steps, ctx->d_imu_poses, ctx->d_imu_state};
+                 ctx->d_sel_flag, ctx->d_sel_dist, ctx->d_sel_disc, ctx->d_imu_steps, ctx->d_imu_poses, ctx->d_imu_state,
+                 ctx->d_ob_off, ctx->d_ob_id, ctx->d_ob_img, ctx->d_ob_lvl, ctx->d_vm_refpatch, ctx->d_ob_px, ctx->d_ob_f, ctx->d_ob_R, ctx->d_ob_t, ctx->d_ob_ie, ctx->d_vm_normal,
+                 ctx->d_ob_patch, ctx->d_vm_ninit, ctx->d_ob_imgs, ctx->d_ch_obs, ctx->d_ch_flag, ctx->d_ch_slot, ctx->d_cand_cell, ctx->d_cand_point, ctx->d_cand_obs,
+                 ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -1142,20 +1158,17 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (flag) return fail(ctx, LIVO2_ERR_RANGE, "visual voxel key outside 21 bits per axis");
   ctx->n_vm = n; ctx->has_vmap = true;
+  ctx->has_obs = false;                       // the observation table belongs to the previous point set
   return LIVO2_OK;
 }
 
-int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const livo2_select_cfg *cfg, int32_t *cell_point, float *cell_dist, uint8_t *cell_disc,
-                        uint8_t *point_in_fov) {
-  if (!ctx) return LIVO2_ERR_INVALID;
-  if (!cfg || n_pg < 0 || (n_pg > 0 && !pg) || !cell_point) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+// selection stage: buffers for n_pg scan points and `length` grid cells; *cap_out = capacity of the scan-voxel hash set
+static int select_reserve(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n_pg, size_t *cap_out) {
   if (!ctx->has_vmap) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_map_upload has not been called");
   if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "selection needs a zero-distortion camera");
   const int length = cfg->grid_n_width * cfg->grid_n_height;
   if (cfg->grid_size < 1 || cfg->grid_n_width < 1 || cfg->grid_n_height < 1 || length > (1 << 20) || cfg->cam.width < 1 || cfg->cam.height < 1 || cfg->patch_size_half < 0 ||
       cfg->border < cfg->patch_size_half) return fail(ctx, LIVO2_ERR_INVALID, "bad grid / border (the 9x9 depth window must stay inside the image: border >= patch_size_half)");
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   const size_t px = (size_t)cfg->cam.width * cfg->cam.height;
   size_t cap = 1024; while (cap < 2 * (size_t)std::max(n_pg, 1)) cap <<= 1;
   int rc;
@@ -1167,19 +1180,26 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
   if ((rc = ensure(ctx, ctx->d_sel_point, ctx->sel_point_cap, (size_t)length))) return rc;
   if ((rc = ensure(ctx, ctx->d_sel_dist, ctx->sel_dist_cap, (size_t)length))) return rc;
   if ((rc = ensure(ctx, ctx->d_sel_disc, ctx->sel_disc_cap, (size_t)length))) return rc;
-  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
+  *cap_out = cap;
+  return LIVO2_OK;
+}
+
+// new_frame_->pos() = -(R^T t)
+static void frame_pos(const double *R, const double *t, double *o) { for (int r = 0; r < 3; r++) o[r] = ((R[r] * t[0] + R[3 + r] * t[1]) + R[6 + r] * t[2]) * (-1.0); }
+
+// selection stage: resets + the three kernels on the ctx stream (the scan points are already in d_sel_pg)
+static int select_enqueue(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n_pg, size_t cap) {
+  const int length = cfg->grid_n_width * cfg->grid_n_height;
+  const size_t px = (size_t)cfg->cam.width * cfg->cam.height;
   SelectArgs a{};
   a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
   std::memcpy(a.R, cfg->R_cur, 72); std::memcpy(a.t, cfg->t_cur, 24);
-  for (int r = 0; r < 3; r++) a.cam_pos[r] = ((cfg->R_cur[r] * cfg->t_cur[0] + cfg->R_cur[3 + r] * cfg->t_cur[1]) + cfg->R_cur[6 + r] * cfg->t_cur[2]) * (-1.0);   // new_frame_->pos()
+  frame_pos(cfg->R_cur, cfg->t_cur, a.cam_pos);
   a.width = cfg->cam.width; a.height = cfg->cam.height; a.border = cfg->border; a.grid_size = cfg->grid_size; a.grid_n_width = cfg->grid_n_width; a.length = length;
   a.patch_size_half = cfg->patch_size_half; a.n_pg = n_pg; a.n_pts = ctx->n_vm;
   a.pg = ctx->d_sel_pg; a.pos = ctx->d_vm_pos; a.pkey = ctx->d_vm_pkey; a.active = ctx->d_vm_active; a.set = ctx->d_sel_set; a.mask = (uint32_t)(cap - 1);
   a.depth = ctx->d_sel_depth; a.cell_best = ctx->d_sel_best; a.cell_type = ctx->d_sel_type; a.in_fov = ctx->d_vm_fov; a.range_flag = ctx->d_sel_flag;
   a.cell_point = ctx->d_sel_point; a.cell_dist = ctx->d_sel_dist; a.cell_discont = ctx->d_sel_disc;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_sel_flag, 0, 64, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_sel_set, 0xFF, cap * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_sel_depth, 0, px * 8, ctx->stream));
@@ -1188,8 +1208,25 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
   if (n_pg > 0) hipLaunchKernelGGL(k_sel_scan, dim3((n_pg + 255) / 256), dim3(256), 0, ctx->stream, a);
   if (ctx->n_vm > 0) hipLaunchKernelGGL(k_sel_points, dim3((ctx->n_vm + 255) / 256), dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_sel_cells, dim3((length + 3) / 4), dim3(256), 0, ctx->stream, a);
-  HIPCHK(hipEventRecord(e1, ctx->stream));
   HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+
+int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const livo2_select_cfg *cfg, int32_t *cell_point, float *cell_dist, uint8_t *cell_disc,
+                        uint8_t *point_in_fov) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!cfg || n_pg < 0 || (n_pg > 0 && !pg) || !cell_point) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  size_t cap = 0;
+  int rc = select_reserve(ctx, cfg, n_pg, &cap); if (rc) return rc;
+  const int length = cfg->grid_n_width * cfg->grid_n_height;
+  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  if ((rc = select_enqueue(ctx, cfg, n_pg, cap))) return rc;
+  HIPCHK(hipEventRecord(e1, ctx->stream));
   int32_t flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(cell_point, ctx->d_sel_point, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1207,6 +1244,85 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
 double livo2_visual_select_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->select_kernel_us : 0.0; }
 
 // ---- visual sub-map retrieval, per-point tail -----------------------------------------------------------------------------------
+// tail stage: candidate arrays, per-candidate outputs and the frame arrays for up to n candidates
+static int tail_reserve(livo2_ctx *ctx, int n, int L) {
+  if (n > ctx->cand_cap) {
+    void *old[] = {ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl,
+                   ctx->d_c_acc, ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_err};
+    for (void *p : old) if (p) { hipError_t e = hipFree(p); (void)e; }
+    const size_t cap = (size_t)std::max(n, 512);
+    HIPCHK(hipMalloc((void **)&ctx->d_c_pos, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_normal, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_px, cap * 16));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_f, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_R, cap * 72)); HIPCHK(hipMalloc((void **)&ctx->d_c_t, cap * 24));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_ie, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_ncc, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_A, cap * 32));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_lvl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_acc, cap * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_c_sl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_slot, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_err, cap * 4));
+    ctx->cand_cap = (int)cap;
+  }
+  if (!ctx->d_c_count) HIPCHK(hipMalloc((void **)&ctx->d_c_count, 64));
+  int rc = ensure(ctx, ctx->d_c_patch, ctx->c_patch_cap, std::max((size_t)n * L * 64, (size_t)64)); if (rc) return rc;
+  size_t ld = 1024; while (ld < 2 * (size_t)std::max(n, 1)) ld <<= 1;
+  if ((rc = ensure(ctx, ctx->d_c_id, ctx->c_id_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_c_leader, ctx->c_leader_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ld_keys, ctx->ld_keys_cap, ld))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ld_vals, ctx->ld_vals_cap, ld))) return rc;
+  // the frame arrays must be able to hold every candidate
+  if (n > ctx->M_cap) {
+    hipError_t e;
+    if (ctx->d_pos) { e = hipFree(ctx->d_pos); e = hipFree(ctx->d_invexpo); e = hipFree(ctx->d_search); e = hipFree(ctx->d_errors); (void)e; }
+    int cap = std::max(n, 512);
+    HIPCHK(hipMalloc((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_invexpo, (size_t)cap * 8));
+    HIPCHK(hipMalloc((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_errors, (size_t)cap * 4));
+    ctx->M_cap = cap;
+  }
+  if ((rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)n * L * 64, (size_t)64)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)visual_grid(std::max(n, 1)) * VIS_PSTRIDE, (size_t)64)))) return rc;
+  return LIVO2_OK;
+}
+
+// tail stage: warp_map leaders (!normal_en with ids), k_warp_candidates, scan of the accept flags, gather into the frame arrays.  n = number of
+// candidates or, with n_dev, its upper bound (the count itself is read on the device).  The candidate arrays d_c_* are filled already.
+static int tail_enqueue(livo2_ctx *ctx, const livo2_retrieve_cfg *cfg, int width, int height, int stride, const uint8_t *d_ref_imgs, int n, const int32_t *n_dev,
+                        bool have_ids, const int32_t *cand_point, const int32_t *cand_obs) {
+  const int L = cfg->patch_pyrimid_level;
+  const bool lead = have_ids && !cfg->normal_en;
+  if (lead) {
+    size_t ld = 1024; while (ld < 2 * (size_t)std::max(n, 1)) ld <<= 1;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ctx->d_ld_keys, LEADER_EMPTY, ld, ctx->stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ctx->d_ld_vals, LEADER_EMPTY, ld, ctx->stream));
+    hipLaunchKernelGGL(k_leader_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_c_id, n_dev, n, ctx->d_ld_keys, ctx->d_ld_vals, (uint32_t)(ld - 1));
+    hipLaunchKernelGGL(k_leader_lookup, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_c_id, n_dev, n, ctx->d_ld_keys, ctx->d_ld_vals, (uint32_t)(ld - 1),
+                       ctx->d_c_leader);
+  }
+  WarpKernelArgs a{};
+  a.img = ctx->d_img; a.ref_imgs = d_ref_imgs; a.width = width; a.height = height; a.stride = stride; a.n = n; a.L = L;
+  a.normal_en = cfg->normal_en; a.ncc_en = cfg->ncc_en; a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
+  a.inv_expo_cur = cfg->inv_expo_cur; a.ncc_thre = cfg->ncc_thre; a.outlier_threshold = cfg->outlier_threshold;
+  std::memcpy(a.R_cur, cfg->R_cur, 72); std::memcpy(a.t_cur, cfg->t_cur, 24);
+  a.pos = ctx->d_c_pos; a.normal = ctx->d_c_normal; a.ref_px = ctx->d_c_px; a.ref_f = ctx->d_c_f; a.ref_R = ctx->d_c_R; a.ref_t = ctx->d_c_t; a.ref_inv_expo = ctx->d_c_ie;
+  a.ref_img_idx = ctx->d_c_idx; a.ref_level = ctx->d_c_lvl; a.patch_all = ctx->d_c_patch; a.accepted = ctx->d_c_acc; a.search_level = ctx->d_c_sl;
+  a.error = ctx->d_c_err; a.ncc = ctx->d_c_ncc; a.A = ctx->d_c_A; a.n_dev = n_dev; a.leader = lead ? ctx->d_c_leader : nullptr;
+  const int grid = (n + WARP_WAVES - 1) / WARP_WAVES;
+  hipLaunchKernelGGL(k_warp_candidates, dim3(grid), dim3(WARP_WAVES * LIVO2_WAVE), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_warp_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_c_acc, n, n_dev, ctx->d_c_slot, ctx->d_c_count);
+  hipLaunchKernelGGL(k_warp_gather, dim3(grid), dim3(WARP_WAVES * LIVO2_WAVE), 0, ctx->stream, ctx->d_c_slot, n, n_dev, L, ctx->d_c_patch, ctx->d_c_pos, ctx->d_c_sl,
+                     ctx->d_c_ie, ctx->d_warp, ctx->d_pos, ctx->d_search, ctx->d_invexpo, cand_point, cand_obs, cand_point ? ctx->d_sub_point : nullptr,
+                     cand_obs ? ctx->d_sub_obs : nullptr);
+  HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+
+// per-candidate outputs of the tail stage -> host (n candidates)
+static int tail_fetch(livo2_ctx *ctx, const livo2_retrieve_out *out, int n, int L) {
+  if (!out || n <= 0) return LIVO2_OK;
+  if (out->accepted) HIPCHK(hipMemcpyAsync(out->accepted, ctx->d_c_acc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->search_level) HIPCHK(hipMemcpyAsync(out->search_level, ctx->d_c_sl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->error) HIPCHK(hipMemcpyAsync(out->error, ctx->d_c_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->ncc) HIPCHK(hipMemcpyAsync(out->ncc, ctx->d_c_ncc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->A_cur_ref) HIPCHK(hipMemcpyAsync(out->A_cur_ref, ctx->d_c_A, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->patch_wrap) HIPCHK(hipMemcpyAsync(out->patch_wrap, ctx->d_c_patch, (size_t)n * L * 256, hipMemcpyDeviceToHost, ctx->stream));
+  return LIVO2_OK;
+}
+
 int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const uint8_t *ref_imgs, int32_t n_ref,
                                const livo2_retrieve_candidates *cand, const livo2_retrieve_cfg *cfg, livo2_retrieve_out *out, int32_t *n_accepted) {
   if (!ctx) return LIVO2_ERR_INVALID;
@@ -1221,37 +1337,14 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
   for (int i = 0; i < n; i++) {
     if (cand->ref_img_idx[i] < 0 || cand->ref_img_idx[i] >= n_ref) return fail(ctx, LIVO2_ERR_INVALID, "ref_img_idx out of range");
     if (cand->ref_level[i] < 0 || cand->ref_level[i] > 8) return fail(ctx, LIVO2_ERR_RANGE, "ref_level out of [0,8]");
+    if (cand->ref_id && cand->ref_id[i] == LEADER_EMPTY) return fail(ctx, LIVO2_ERR_RANGE, "ref_id must differ from INT32_MAX");
   }
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const size_t img_bytes = (size_t)stride * height;
   int rc = ensure(ctx, ctx->d_img, ctx->img_cap, img_bytes); if (rc) return rc;
   if (n > 0) { rc = ensure(ctx, ctx->d_ref_imgs, ctx->ref_img_cap, img_bytes * n_ref); if (rc) return rc; }
-  if (n > ctx->cand_cap) {
-    void *old[] = {ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl,
-                   ctx->d_c_acc, ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_err};
-    for (void *p : old) if (p) { hipError_t e = hipFree(p); (void)e; }
-    const size_t cap = (size_t)std::max(n, 512);
-    HIPCHK(hipMalloc((void **)&ctx->d_c_pos, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_normal, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_px, cap * 16));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_f, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_R, cap * 72)); HIPCHK(hipMalloc((void **)&ctx->d_c_t, cap * 24));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_ie, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_ncc, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_A, cap * 32));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_lvl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_acc, cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_sl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_slot, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_err, cap * 4));
-    ctx->cand_cap = (int)cap;
-  }
-  if (!ctx->d_c_count) HIPCHK(hipMalloc((void **)&ctx->d_c_count, 64));
-  rc = ensure(ctx, ctx->d_c_patch, ctx->c_patch_cap, std::max((size_t)n * L * 64, (size_t)64)); if (rc) return rc;
-  // the frame arrays must be able to hold every candidate
-  if (n > ctx->M_cap) {
-    hipError_t e;
-    if (ctx->d_pos) { e = hipFree(ctx->d_pos); e = hipFree(ctx->d_invexpo); e = hipFree(ctx->d_search); e = hipFree(ctx->d_errors); (void)e; }
-    int cap = std::max(n, 512);
-    HIPCHK(hipMalloc((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_invexpo, (size_t)cap * 8));
-    HIPCHK(hipMalloc((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_errors, (size_t)cap * 4));
-    ctx->M_cap = cap;
-  }
-  rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)n * L * 64, (size_t)64)); if (rc) return rc;
-  rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)visual_grid(std::max(n, 1)) * VIS_PSTRIDE, (size_t)64)); if (rc) return rc;
+  if ((rc = tail_reserve(ctx, n, L))) return rc;
   HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
   int32_t count = 0;
   ctx->retrieve_kernel_us = 0.0;
@@ -1266,33 +1359,14 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
     HIPCHK(hipMemcpyAsync(ctx->d_c_ie, cand->ref_inv_expo, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_c_idx, cand->ref_img_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_c_lvl, cand->ref_level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    WarpKernelArgs a{};
-    a.img = ctx->d_img; a.ref_imgs = ctx->d_ref_imgs; a.width = width; a.height = height; a.stride = stride; a.n = n; a.L = L;
-    a.normal_en = cfg->normal_en; a.ncc_en = cfg->ncc_en; a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
-    a.inv_expo_cur = cfg->inv_expo_cur; a.ncc_thre = cfg->ncc_thre; a.outlier_threshold = cfg->outlier_threshold;
-    std::memcpy(a.R_cur, cfg->R_cur, 72); std::memcpy(a.t_cur, cfg->t_cur, 24);
-    a.pos = ctx->d_c_pos; a.normal = ctx->d_c_normal; a.ref_px = ctx->d_c_px; a.ref_f = ctx->d_c_f; a.ref_R = ctx->d_c_R; a.ref_t = ctx->d_c_t; a.ref_inv_expo = ctx->d_c_ie;
-    a.ref_img_idx = ctx->d_c_idx; a.ref_level = ctx->d_c_lvl; a.patch_all = ctx->d_c_patch; a.accepted = ctx->d_c_acc; a.search_level = ctx->d_c_sl;
-    a.error = ctx->d_c_err; a.ncc = ctx->d_c_ncc; a.A = ctx->d_c_A;
+    if (cand->ref_id) HIPCHK(hipMemcpyAsync(ctx->d_c_id, cand->ref_id, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, ctx->stream));
-    const int grid = (n + WARP_WAVES - 1) / WARP_WAVES;
-    hipLaunchKernelGGL(k_warp_candidates, dim3(grid), dim3(WARP_WAVES * LIVO2_WAVE), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_warp_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_c_acc, n, ctx->d_c_slot, ctx->d_c_count);
-    hipLaunchKernelGGL(k_warp_gather, dim3(grid), dim3(WARP_WAVES * LIVO2_WAVE), 0, ctx->stream, ctx->d_c_slot, n, L, ctx->d_c_patch, ctx->d_c_pos, ctx->d_c_sl,
-                       ctx->d_c_ie, ctx->d_warp, ctx->d_pos, ctx->d_search, ctx->d_invexpo);
+    if ((rc = tail_enqueue(ctx, cfg, width, height, stride, ctx->d_ref_imgs, n, nullptr, cand->ref_id != nullptr, nullptr, nullptr))) return rc;
     HIPCHK(hipEventRecord(e1, ctx->stream));
-    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&count, ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out) {
-      if (out->accepted) HIPCHK(hipMemcpyAsync(out->accepted, ctx->d_c_acc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->search_level) HIPCHK(hipMemcpyAsync(out->search_level, ctx->d_c_sl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->error) HIPCHK(hipMemcpyAsync(out->error, ctx->d_c_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->ncc) HIPCHK(hipMemcpyAsync(out->ncc, ctx->d_c_ncc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->A_cur_ref) HIPCHK(hipMemcpyAsync(out->A_cur_ref, ctx->d_c_A, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->patch_wrap) HIPCHK(hipMemcpyAsync(out->patch_wrap, ctx->d_c_patch, (size_t)n * L * 256, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    if ((rc = tail_fetch(ctx, out, n, L))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -1308,6 +1382,156 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
   return LIVO2_OK;
 }
 double livo2_visual_retrieve_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->retrieve_kernel_us : 0.0; }
+
+// ---- visual sub-map retrieval, the whole function: selection -> reference-patch choice -> tail as one chain ----------------------------
+int livo2_visual_obs_upload(livo2_ctx *ctx, const livo2_visual_obs *o) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!o) return fail(ctx, LIVO2_ERR_INVALID, "obs is NULL");
+  if (!ctx->has_vmap) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_map_upload has not been called");
+  const int n = ctx->n_vm, m = o->n_obs;
+  if (m < 0 || o->n_ref < 0 || !o->point_offset || !o->normal || !o->normal_initialized || !o->ref_patch) return fail(ctx, LIVO2_ERR_INVALID, "bad observation table");
+  if (m > 0 && (!o->id || !o->img_idx || !o->px || !o->f || !o->R || !o->t || !o->level || !o->inv_expo || !o->patch || !o->ref_imgs || o->n_ref < 1 || o->width < 1 ||
+                o->height < 1 || o->stride < o->width)) return fail(ctx, LIVO2_ERR_INVALID, "bad observation arrays / reference images");
+  if (o->point_offset[0] != 0 || o->point_offset[n] != m) return fail(ctx, LIVO2_ERR_INVALID, "point_offset must run from 0 to n_obs");
+  for (int i = 0; i < n; i++) {
+    if (o->point_offset[i + 1] < o->point_offset[i]) return fail(ctx, LIVO2_ERR_INVALID, "point_offset must not decrease");
+    const int r = o->ref_patch[i];
+    if (r != -1 && (r < o->point_offset[i] || r >= o->point_offset[i + 1])) return fail(ctx, LIVO2_ERR_INVALID, "ref_patch is not an observation of its point");
+  }
+  for (int k = 0; k < m; k++) {
+    if (o->img_idx[k] < 0 || o->img_idx[k] >= o->n_ref) return fail(ctx, LIVO2_ERR_INVALID, "img_idx out of range");
+    if (o->level[k] < 0 || o->level[k] > 8) return fail(ctx, LIVO2_ERR_RANGE, "level out of [0,8]");
+    if (o->id[k] == LEADER_EMPTY) return fail(ctx, LIVO2_ERR_RANGE, "id must differ from INT32_MAX");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t m1 = (size_t)std::max(m, 1), n1 = (size_t)std::max(n, 1), img_bytes = (size_t)o->stride * o->height;
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_ob_off, ctx->ob_off_cap, (size_t)n + 1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_id, ctx->ob_id_cap, m1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_img, ctx->ob_img_cap, m1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_lvl, ctx->ob_lvl_cap, m1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_px, ctx->ob_px_cap, m1 * 2))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_f, ctx->ob_f_cap, m1 * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_R, ctx->ob_R_cap, m1 * 9))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_t, ctx->ob_t_cap, m1 * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_ie, ctx->ob_ie_cap, m1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_patch, ctx->ob_patch_cap, m1 * 64))) return rc;
+  if ((rc = ensure(ctx, ctx->d_vm_normal, ctx->vm_normal_cap, n1 * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->d_vm_ninit, ctx->vm_ninit_cap, n1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_vm_refpatch, ctx->vm_refpatch_cap, n1))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ob_imgs, ctx->ob_imgs_cap, std::max(img_bytes * (size_t)o->n_ref, (size_t)64)))) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_ob_off, o->point_offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_vm_normal, o->normal, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_vm_ninit, o->normal_initialized, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_vm_refpatch, o->ref_patch, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (m > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_id, o->id, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_img, o->img_idx, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_lvl, o->level, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_px, o->px, (size_t)m * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_f, o->f, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_R, o->R, (size_t)m * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_t, o->t, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_ie, o->inv_expo, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_patch, o->patch, (size_t)m * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ob_imgs, o->ref_imgs, img_bytes * (size_t)o->n_ref, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_obs = m; ctx->ob_n_ref = o->n_ref; ctx->ob_w = o->width; ctx->ob_h = o->height; ctx->ob_stride = o->stride;
+  ctx->has_obs = true;
+  return LIVO2_OK;
+}
+
+int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const double *pg, int32_t n_pg,
+                                   const livo2_select_cfg *sel, const livo2_retrieve_cfg *cfg, livo2_retrieve_chain_out *out, int32_t *n_candidates, int32_t *n_accepted) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!img || width <= 0 || height <= 0 || stride < width) return fail(ctx, LIVO2_ERR_INVALID, "bad image");
+  if (!sel || !cfg || !n_accepted || n_pg < 0 || (n_pg > 0 && !pg)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!ctx->has_obs) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_obs_upload has not been called (after livo2_visual_map_upload)");
+  const int L = cfg->patch_pyrimid_level;
+  if (L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad patch_pyrimid_level");
+  if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "retrieval needs a zero-distortion camera");
+  if (cfg->cam.width != width || cfg->cam.height != height || sel->cam.width != width || sel->cam.height != height) return fail(ctx, LIVO2_ERR_INVALID, "camera size differs from the image");
+  if (ctx->n_obs > 0 && (ctx->ob_w != width || ctx->ob_h != height || ctx->ob_stride != stride)) return fail(ctx, LIVO2_ERR_INVALID, "reference images differ in size from the image");
+  if (sel->border < 4) return fail(ctx, LIVO2_ERR_INVALID, "border must keep the 8x8 patch of a selected point inside the image (>= 4)");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  size_t cap = 0;
+  int rc = select_reserve(ctx, sel, n_pg, &cap); if (rc) return rc;
+  const int length = sel->grid_n_width * sel->grid_n_height;
+  const size_t len = (size_t)length, img_bytes = (size_t)stride * height;
+  if ((rc = ensure(ctx, ctx->d_img, ctx->img_cap, img_bytes))) return rc;
+  if ((rc = tail_reserve(ctx, length, L))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ch_obs, ctx->ch_obs_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ch_flag, ctx->ch_flag_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_ch_slot, ctx->ch_slot_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_cand_cell, ctx->cand_cell_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_cand_point, ctx->cand_point_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_cand_obs, ctx->cand_obs_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sub_point, ctx->sub_point_cap, len))) return rc;
+  if ((rc = ensure(ctx, ctx->d_sub_obs, ctx->sub_obs_cap, len))) return rc;
+  if (!ctx->d_ch_count) HIPCHK(hipMalloc((void **)&ctx->d_ch_count, 64));
+  HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  // 1. selection
+  if ((rc = select_enqueue(ctx, sel, n_pg, cap))) return rc;
+  // 2. reference-patch choice, then the chosen pairs lined up as candidates in grid-cell order
+  ChoiceArgs ca{};
+  ca.normal_en = cfg->normal_en; ca.length = length;
+  frame_pos(sel->R_cur, sel->t_cur, ca.cam_pos);
+  ca.cell_point = ctx->d_sel_point; ca.cell_discont = ctx->d_sel_disc; ca.pos = ctx->d_vm_pos; ca.obs_offset = ctx->d_ob_off; ca.obs_id = ctx->d_ob_id;
+  ca.obs_R = ctx->d_ob_R; ca.obs_t = ctx->d_ob_t; ca.obs_patch = ctx->d_ob_patch; ca.normal_init = ctx->d_vm_ninit; ca.ref_patch = ctx->d_vm_refpatch;
+  ca.cell_obs = ctx->d_ch_obs; ca.cell_flag = ctx->d_ch_flag;
+  hipLaunchKernelGGL(k_choose_ref, dim3((length + CHOICE_WAVES - 1) / CHOICE_WAVES), dim3(CHOICE_WAVES * LIVO2_WAVE), 0, ctx->stream, ca);
+  hipLaunchKernelGGL(k_warp_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_ch_flag, length, (const int32_t *)nullptr, ctx->d_ch_slot, ctx->d_ch_count);
+  GatherCandArgs ga{};
+  ga.length = length; ga.slot = ctx->d_ch_slot; ga.cell_point = ctx->d_sel_point; ga.cell_obs = ctx->d_ch_obs; ga.pos = ctx->d_vm_pos; ga.normal = ctx->d_vm_normal;
+  ga.obs_id = ctx->d_ob_id; ga.obs_img_idx = ctx->d_ob_img; ga.obs_level = ctx->d_ob_lvl; ga.obs_px = ctx->d_ob_px; ga.obs_f = ctx->d_ob_f; ga.obs_R = ctx->d_ob_R;
+  ga.obs_t = ctx->d_ob_t; ga.obs_inv_expo = ctx->d_ob_ie;
+  ga.c_pos = ctx->d_c_pos; ga.c_normal = ctx->d_c_normal; ga.c_px = ctx->d_c_px; ga.c_f = ctx->d_c_f; ga.c_R = ctx->d_c_R; ga.c_t = ctx->d_c_t; ga.c_ie = ctx->d_c_ie;
+  ga.c_idx = ctx->d_c_idx; ga.c_lvl = ctx->d_c_lvl; ga.c_id = ctx->d_c_id; ga.cand_cell = ctx->d_cand_cell; ga.cand_point = ctx->d_cand_point; ga.cand_obs = ctx->d_cand_obs;
+  hipLaunchKernelGGL(k_gather_candidates, dim3((length + 7) / 8), dim3(256), 0, ctx->stream, ga);
+  HIPCHK(hipGetLastError());
+  // 3. tail over the candidates (their number stays on the device), survivors -> the resident frame
+  if ((rc = tail_enqueue(ctx, cfg, width, height, stride, ctx->d_ob_imgs, length, ctx->d_ch_count, true, ctx->d_cand_point, ctx->d_cand_obs))) return rc;
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  int32_t counts[2] = {0, 0}, flag = 0;
+  HIPCHK(hipMemcpyAsync(&counts[0], ctx->d_ch_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&counts[1], ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  ctx->chain_kernel_us = 1e3 * ms;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  if (flag) return fail(ctx, LIVO2_ERR_RANGE, "scan voxel key outside 21 bits per axis");
+  const int nc = counts[0], na = counts[1];
+  if (out) {
+    if (out->cell_point) HIPCHK(hipMemcpyAsync(out->cell_point, ctx->d_sel_point, len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_dist) HIPCHK(hipMemcpyAsync(out->cell_dist, ctx->d_sel_dist, len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_discontinuous) HIPCHK(hipMemcpyAsync(out->cell_discontinuous, ctx->d_sel_disc, len, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_obs) HIPCHK(hipMemcpyAsync(out->cell_obs, ctx->d_ch_obs, len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->ref_patch && ctx->n_vm > 0) HIPCHK(hipMemcpyAsync(out->ref_patch, ctx->d_vm_refpatch, (size_t)ctx->n_vm * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cand_cell && nc > 0) HIPCHK(hipMemcpyAsync(out->cand_cell, ctx->d_cand_cell, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = tail_fetch(ctx, &out->tail, nc, L))) return rc;
+    if (out->sub_point && na > 0) HIPCHK(hipMemcpyAsync(out->sub_point, ctx->d_sub_point, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->sub_obs && na > 0) HIPCHK(hipMemcpyAsync(out->sub_obs, ctx->d_sub_obs, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  if (n_candidates) *n_candidates = nc;
+  *n_accepted = na;
+  ctx->width = width; ctx->height = height; ctx->stride = stride; ctx->M = na; ctx->L = L;
+  ctx->has_frame = true;
+  ctx->has_ref = false;
+  return LIVO2_OK;
+}
+double livo2_visual_retrieve_from_map_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->chain_kernel_us : 0.0; }
 
 static int visual_ready(livo2_ctx *ctx, const livo2_state *a, const livo2_state *b, const livo2_visual_cfg *cfg) {
   if (!ctx) return LIVO2_ERR_INVALID;

@@ -23,6 +23,8 @@ struct WarpKernelArgs {
   double R_cur[9], t_cur[3];
   const double *pos, *normal, *ref_px, *ref_f, *ref_R, *ref_t, *ref_inv_expo;
   const int32_t *ref_img_idx, *ref_level;
+  const int32_t *n_dev;             // candidate count on the device (chained retrieval); NULL: n
+  const int32_t *leader;            // !normal_en: the candidate whose warp this one reuses (warp_map, vio.cpp:716-734); NULL: itself
   float *patch_all;                 // [n][L][64]
   int32_t *accepted, *search_level;
   float *error;
@@ -57,14 +59,17 @@ __global__ void __launch_bounds__(WARP_WAVES *LIVO2_WAVE) k_warp_candidates(Warp
   __shared__ float s_pair[WARP_WAVES][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WARP_WAVES + wave);
-  if (i >= a.n) return;
+  if (i >= (a.n_dev ? a.n_dev[0] : a.n)) return;
   // ---- candidate-constant algebra (every lane, same values) ----
-  double pos[3], Rr[9], tr[3], pxr[2];
+  // the warp matrix comes from candidate j: i itself, or with !normal_en the first candidate whose ref_ftr was made in the same frame
+  const int j = (a.leader && !a.normal_en) ? a.leader[i] : i;
+  double pos[3], posj[3], Rr[9], tr[3], pxr[2], pxj[2];
 #pragma unroll
-  for (int k = 0; k < 3; k++) { pos[k] = a.pos[(size_t)i * 3 + k]; tr[k] = a.ref_t[(size_t)i * 3 + k]; }
+  for (int k = 0; k < 3; k++) { pos[k] = a.pos[(size_t)i * 3 + k]; posj[k] = a.pos[(size_t)j * 3 + k]; tr[k] = a.ref_t[(size_t)j * 3 + k]; }
 #pragma unroll
-  for (int k = 0; k < 9; k++) Rr[k] = a.ref_R[(size_t)i * 9 + k];
+  for (int k = 0; k < 9; k++) Rr[k] = a.ref_R[(size_t)j * 9 + k];
   pxr[0] = a.ref_px[(size_t)i * 2]; pxr[1] = a.ref_px[(size_t)i * 2 + 1];
+  pxj[0] = a.ref_px[(size_t)j * 2]; pxj[1] = a.ref_px[(size_t)j * 2 + 1];
   double Rcr[9], tcr[3];                                            // T_cur_ref = T_cur * T_ref^-1
 #pragma unroll
   for (int r = 0; r < 3; r++)
@@ -115,18 +120,18 @@ __global__ void __launch_bounds__(WARP_WAVES *LIVO2_WAVE) k_warp_candidates(Warp
   } else {
     double f[3], rp[3], q[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) f[k] = a.ref_f[(size_t)i * 3 + k];
+    for (int k = 0; k < 3; k++) f[k] = a.ref_f[(size_t)j * 3 + k];
     w_mat3t_vec(Rr, tr, rp);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { rp[k] = rp[k] * (-1.0); q[k] = rp[k] - pos[k]; }            // Feature::pos() - pt->pos_
+    for (int k = 0; k < 3; k++) { rp[k] = rp[k] * (-1.0); q[k] = rp[k] - posj[k]; }           // Feature::pos() - pt->pos_
     const double depth = sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
-    const int lr = a.ref_level[i];
+    const int lr = a.ref_level[j];
     const double step = (double)(4 * (1 << lr) * (1 << 0));
     double xr[3], xdu[3], xdv[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) xr[k] = f[k] * depth;
-    w_cam2world(a, pxr[0] + step, pxr[1], xdu);
-    w_cam2world(a, pxr[0], pxr[1] + step, xdv);
+    w_cam2world(a, pxj[0] + step, pxj[1], xdu);
+    w_cam2world(a, pxj[0], pxj[1] + step, xdv);
     const double su = xr[2] / xdu[2], sv = xr[2] / xdv[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) { xdu[k] = xdu[k] * su; xdv[k] = xdv[k] * sv; }
@@ -214,10 +219,12 @@ __global__ void __launch_bounds__(WARP_WAVES *LIVO2_WAVE) k_warp_candidates(Warp
 }
 
 // exclusive scan of the accept flags (one block): slot[i] = position among the survivors or -1 ; count[0] = number of survivors
-__global__ void __launch_bounds__(1024) k_warp_scan(const int32_t *__restrict__ accepted, int n, int32_t *__restrict__ slot, int32_t *__restrict__ count) {
+__global__ void __launch_bounds__(1024) k_warp_scan(const int32_t *__restrict__ accepted, int n, const int32_t *__restrict__ n_dev, int32_t *__restrict__ slot,
+                                                    int32_t *__restrict__ count) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (n_dev) n = n_dev[0];
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int start = 0; start < n; start += 1024) {
@@ -241,12 +248,17 @@ __global__ void __launch_bounds__(1024) k_warp_scan(const int32_t *__restrict__ 
 }
 
 // survivors -> the resident frame arrays, in candidate order (visual_submap push_backs, vio.cpp:762-767)
-__global__ void __launch_bounds__(WARP_WAVES *LIVO2_WAVE) k_warp_gather(const int32_t *__restrict__ slot, int n, int L, const float *__restrict__ patch_all,
-                                                                       const double *__restrict__ pos, const int32_t *__restrict__ search_level,
-                                                                       const double *__restrict__ ref_inv_expo, float *__restrict__ warp, double *__restrict__ fpos,
-                                                                       int32_t *__restrict__ fsearch, double *__restrict__ finvexpo) {
+// (cand_point / cand_obs -> sub_point / sub_obs: which visual point and observation each survivor is; NULL outside the chained retrieval)
+__global__ void __launch_bounds__(WARP_WAVES *LIVO2_WAVE) k_warp_gather(const int32_t *__restrict__ slot, int n, const int32_t *__restrict__ n_dev, int L,
+                                                                       const float *__restrict__ patch_all, const double *__restrict__ pos,
+                                                                       const int32_t *__restrict__ search_level, const double *__restrict__ ref_inv_expo,
+                                                                       float *__restrict__ warp, double *__restrict__ fpos, int32_t *__restrict__ fsearch,
+                                                                       double *__restrict__ finvexpo, const int32_t *__restrict__ cand_point,
+                                                                       const int32_t *__restrict__ cand_obs, int32_t *__restrict__ sub_point,
+                                                                       int32_t *__restrict__ sub_obs) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * WARP_WAVES + (threadIdx.x >> 6);
+  if (n_dev) n = n_dev[0];
   if (i >= n) return;
   const int s = slot[i];
   if (s < 0) return;
@@ -254,4 +266,6 @@ __global__ void __launch_bounds__(WARP_WAVES *LIVO2_WAVE) k_warp_gather(const in
   if (lane < 3) fpos[(size_t)s * 3 + lane] = pos[(size_t)i * 3 + lane];
   if (lane == 3) fsearch[s] = search_level[i];
   if (lane == 4) finvexpo[s] = ref_inv_expo[i];
+  if (lane == 5 && sub_point) sub_point[s] = cand_point[i];
+  if (lane == 6 && sub_obs) sub_obs[s] = cand_obs[i];
 }

@@ -288,7 +288,8 @@ int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t 
  * livo2_visual_select outputs, per grid cell c in [0, grid_n_width * grid_n_height): cell_point[c] = index of retrieve_voxel_points[c]
  * in the uploaded arrays or -1 (grid_num[c] != TYPE_MAP), cell_dist[c] = map_dist[c], cell_discontinuous[c] = 1 if the loop at
  * vio.cpp:612-635 would skip the point; per visual point: point_in_fov[i] = it passed isInFrame (voxel_in_fov of its voxel = any of its
- * points).  The host then picks ref_ftr for the surviving cells (vio.cpp:640-695) and hands them to livo2_visual_retrieve_warp.
+ * points).  The host then picks ref_ftr for the surviving cells (vio.cpp:640-695) and hands them to livo2_visual_retrieve_warp — or
+ * livo2_visual_retrieve_from_map (below) runs selection, choice and tail as one chain on the device.
  * Exactly equidistant points of one cell: the lowest index wins (the reference: the last one in unordered_map iteration order). */
 int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n_points, const double *pos, const int64_t *voxel_key, const uint8_t *active);
 typedef struct livo2_select_cfg {
@@ -310,7 +311,10 @@ double livo2_visual_select_last_kernel_us(const livo2_ctx *ctx);
  * in candidate order, resident as the frame of the next livo2_visual_update (it replaces livo2_visual_set_frame: pos, warp_patch,
  * search_levels, inv_expo_list are produced on the device).  Per candidate: pos = pt->pos_, normal = pt->normal_, and of its ref_ftr
  * (include/feature.h:19-54): ref_img_idx (index into ref_imgs, images of the current image's size), ref_px = px_, ref_f = f_,
- * ref_R / ref_t = T_f_w_ rotation (row-major) / translation, ref_level = level_, ref_inv_expo = inv_expo_time_.
+ * ref_R / ref_t = T_f_w_ rotation (row-major) / translation, ref_level = level_, ref_inv_expo = inv_expo_time_, ref_id = id_ (may be
+ * NULL).  warp_map (src/vio.cpp:369, 716-734, !normal_en only): the reference caches the warp under ref_ftr->id_, and id_ is the id of the
+ * FRAME the feature was made in (vio.cpp:882, 961), so every candidate reuses A_cur_ref and search_level of the FIRST candidate of this call
+ * whose ref_ftr has the same id_; with ref_id given that is reproduced, with NULL every candidate computes its own.
  * Outputs (each may be NULL): accepted[n] (1 = appended to visual_submap), search_level[n], error[n] (the float photometric error),
  * ncc[n], A_cur_ref[n][4] row-major, patch_wrap[n][L][64] (all candidates, for inspection).  *n_accepted = survivors.
  * cam.distortion must be 0 (cam2world of a distorted vikit camera is not restated).  A candidate whose 9x9 current-image window
@@ -329,6 +333,7 @@ typedef struct livo2_retrieve_candidates {
   const double *ref_px, *ref_f, *ref_R, *ref_t;
   const int32_t *ref_level;
   const double *ref_inv_expo;
+  const int32_t *ref_id;        /* may be NULL; values must differ from INT32_MAX */
 } livo2_retrieve_candidates;
 typedef struct livo2_retrieve_out {
   int32_t *accepted, *search_level;
@@ -340,6 +345,52 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
                                const livo2_retrieve_candidates *cand, const livo2_retrieve_cfg *cfg, livo2_retrieve_out *out, int32_t *n_accepted);
 /* kernel time (k_warp_candidates + scan + gather) of the last call in microseconds (HIP events on the ctx stream) */
 double livo2_visual_retrieve_last_kernel_us(const livo2_ctx *ctx);
+
+/* ---- visual sub-map retrieval, the whole function ---------------------------------------------------------------------
+ * VIOManager::retrieveFromVisualSparseMap, src/vio.cpp:352-780 (raycast_en = false), as ONE chain of launches: selection (above) ->
+ * reference-patch choice (vio.cpp:644-696: is_normal_initialized_ gate; normal_en: the observation whose stored patch_ differs least from
+ * the patches of the point's observations made in OTHER frames, computed once and kept in ref_patch / has_ref_patch_; !normal_en:
+ * VisualPoint::getCloseViewObs, src/visual_point.cpp:57-95) -> per-point tail (above), the survivors left resident as the frame of the next
+ * livo2_visual_update.  No host round trip between the stages.
+ * The observations of the visual map are mirrored next to the points of livo2_visual_map_upload (call that first; same point order):
+ * a CSR table over VisualPoint::obs_ in list order.  Per observation (include/feature.h:19-54): id = id_, img_idx = which of ref_imgs is
+ * img_, px = px_, f = f_, R / t = T_f_w_, level = level_, inv_expo = inv_expo_time_, patch = patch_ (64 floats).  Per point
+ * (include/visual_point.h): normal = normal_, normal_initialized = is_normal_initialized_, ref_patch = GLOBAL index of pt->ref_patch in the
+ * observation arrays, -1 = !has_ref_patch_.  ref_imgs: n_ref gray images of the current image's width / height / stride.
+ * A point all of whose >= 2 observations carry one id_ has no valid score (0/0; the reference then reads an uninitialised pointer): it is
+ * skipped and keeps ref_patch = -1. */
+typedef struct livo2_visual_obs {
+  int32_t n_obs, n_ref;
+  const int32_t *point_offset;  /* [n_points + 1] */
+  const int32_t *id, *img_idx;
+  const double *px, *f, *R, *t;
+  const int32_t *level;
+  const double *inv_expo;
+  const float *patch;
+  const double *normal;
+  const uint8_t *normal_initialized;
+  const int32_t *ref_patch;
+  const uint8_t *ref_imgs;
+  int32_t width, height, stride, pad;
+} livo2_visual_obs;
+int livo2_visual_obs_upload(livo2_ctx *ctx, const livo2_visual_obs *obs);
+/* Outputs, each may be NULL.  length = grid_n_width * grid_n_height.  Per cell [length]: cell_point / cell_dist / cell_discontinuous as
+ * livo2_visual_select, cell_obs = global index of the chosen ref_ftr or -1 (no candidate from this cell).  ref_patch [n_points]: pt->ref_patch
+ * after the call (the device copy is updated too, so the next call sees it).  Per candidate, in grid-cell order, arrays of CAPACITY length:
+ * cand_cell, and the members of `tail` as in livo2_visual_retrieve_warp (patch_wrap: [length][L][64]).  Per survivor (capacity length):
+ * sub_point / sub_obs = visual_submap->voxel_points[k] (index into the uploaded points) and its ref_ftr. */
+typedef struct livo2_retrieve_chain_out {
+  int32_t *cell_point; float *cell_dist; uint8_t *cell_discontinuous; int32_t *cell_obs;
+  int32_t *ref_patch;
+  int32_t *cand_cell;
+  livo2_retrieve_out tail;
+  int32_t *sub_point, *sub_obs;
+} livo2_retrieve_chain_out;
+int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const double *pg_point_w, int32_t n_pg,
+                                   const livo2_select_cfg *sel, const livo2_retrieve_cfg *cfg, livo2_retrieve_chain_out *out, int32_t *n_candidates,
+                                   int32_t *n_accepted);
+/* kernel time of the whole chain of the last call in microseconds (HIP events on the ctx stream) */
+double livo2_visual_retrieve_from_map_last_kernel_us(const livo2_ctx *ctx);
 
 typedef struct livo2_visual_sums {
   double HtH[49];               /* H_sub^T H_sub, row-major 7x7 (vio.cpp:1660); row/col 6 zero if !exposure_estimate_en */

@@ -181,7 +181,8 @@ class WarpCfg(C.Structure):
 
 
 def warp_candidates(rs, lib=None):
-    """Per-point tail of retrieveFromVisualSparseMap over a scenarios.synth.RetrieveScenario; returns a dict of per-candidate arrays."""
+    """Per-point tail of retrieveFromVisualSparseMap over a scenarios.synth.RetrieveScenario; returns a dict of per-candidate arrays.
+    rs.ref_id (optional attribute) = ref_ftr->id_ per candidate: the warp_map reuse of the !normal_en branch (src/vio.cpp:716-734)."""
     lib = lib or load()
     c = WarpCfg()
     c.fx, c.fy, c.cx, c.cy, c.width, c.height = rs.cam["fx"], rs.cam["fy"], rs.cam["cx"], rs.cam["cy"], rs.cam["width"], rs.cam["height"]
@@ -196,11 +197,13 @@ def warp_candidates(rs, lib=None):
     out = dict(accepted=np.zeros(n, np.int32), search_level=np.zeros(n, np.int32), error=np.zeros(n, np.float32), ncc=np.zeros(n), A=np.zeros((n, 4)),
                patch_wrap=np.zeros((n, L, 64), np.float32))
     lib.orc_warp_candidates.restype = C.c_double
-    lib.orc_warp_candidates.argtypes = [C.POINTER(WarpCfg), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int] + [C.c_void_p] * 15
+    lib.orc_warp_candidates.argtypes = [C.POINTER(WarpCfg), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int] + [C.c_void_p] * 16
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rid = getattr(rs, "ref_id", None)
+    rid = None if rid is None else np.ascontiguousarray(rid, np.int32)
     out["seconds"] = lib.orc_warp_candidates(C.byref(c), _p(img, C.c_uint8), _p(refs, C.c_uint8), n, vp(pos), vp(normal), vp(idx), vp(px), vp(f), vp(R), vp(t),
-                                             vp(lvl), vp(ie), vp(out["accepted"]), vp(out["search_level"]), vp(out["error"]), vp(out["ncc"]), vp(out["A"]),
-                                             vp(out["patch_wrap"]))
+                                             vp(lvl), vp(ie), None if rid is None else vp(rid), vp(out["accepted"]), vp(out["search_level"]), vp(out["error"]),
+                                             vp(out["ncc"]), vp(out["A"]), vp(out["patch_wrap"]))
     return out
 
 
@@ -256,6 +259,49 @@ def visual_select(ss, lib=None):
     out["seconds"] = lib.orc_visual_select(C.byref(c), vp(pg), len(pg), vp(pos), vp(keys), vp(act), len(pos), vp(out["cell_point"]), vp(out["cell_dist"]),
                                            vp(out["cell_type"]), vp(out["discont"]), vp(out["in_fov"]), vp(out["depth_img"]))
     return out
+
+
+def choose_ref(cs, cell_point, cell_discont, ref_patch=None, lib=None):
+    """Reference-patch choice (src/vio.cpp:644-696) over a scenarios.synth.RetrieveChainScenario for the cells of one selection.
+    Returns (cell_obs [length] int32: global observation index of ref_ftr or -1, ref_patch [n] int32 after the call)."""
+    lib = lib or load()
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)
+    cp, cd = np.ascontiguousarray(cell_point, np.int32), np.ascontiguousarray(cell_discont, np.int32)
+    rp = np.ascontiguousarray(cs.ref_patch if ref_patch is None else ref_patch, np.int32).copy()
+    R, t, pos = f64(cs.sel.R_cur), f64(cs.sel.t_cur), f64(cs.sel.pos)
+    off, oid = np.ascontiguousarray(cs.obs_offset, np.int32), np.ascontiguousarray(cs.obs_id, np.int32)
+    oR, ot, op = f64(cs.obs_R), f64(cs.obs_t), np.ascontiguousarray(cs.obs_patch, np.float32)
+    ni = np.ascontiguousarray(cs.normal_initialized, np.uint8)
+    out = np.zeros(len(cp), np.int32)
+    lib.orc_choose_ref.restype = None
+    lib.orc_choose_ref.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 11
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.orc_choose_ref(int(cs.cfg["normal_en"]), vp(R), vp(t), len(cp), vp(cp), vp(cd), vp(pos), vp(off), vp(oid), vp(oR), vp(ot), vp(op), vp(ni), vp(rp), vp(out))
+    return out, rp
+
+
+class _Cand:
+    pass
+
+
+def visual_retrieve(cs, lib=None):
+    """The whole retrieveFromVisualSparseMap (raycast_en = false) over a RetrieveChainScenario: selection -> reference-patch choice -> warp / gate
+    tail.  Returns the stage outputs: sel (dict of visual_select), cell_obs, ref_patch, cand_cell (grid cell of every candidate, ascending),
+    cand_point, cand_obs, tail (dict of warp_candidates), and the appended sub-map: sub_point, sub_obs (survivors in order)."""
+    lib = lib or load()
+    sel = visual_select(cs.sel, lib)
+    cell_obs, ref_patch = choose_ref(cs, sel["cell_point"], sel["discont"], lib=lib)
+    cand_cell = np.nonzero(cell_obs >= 0)[0].astype(np.int32)
+    cand_point, cand_obs = sel["cell_point"][cand_cell], cell_obs[cand_cell]
+    r = _Cand()
+    r.cam, r.cfg, r.img, r.ref_imgs, r.R_cur, r.t_cur, r.inv_expo_cur = cs.sel.cam, cs.cfg, cs.img, cs.ref_imgs, cs.sel.R_cur, cs.sel.t_cur, cs.inv_expo_cur
+    r.pos, r.normal = cs.sel.pos[cand_point], cs.normal[cand_point]
+    r.ref_img_idx, r.ref_px, r.ref_f, r.ref_R, r.ref_t = cs.obs_img_idx[cand_obs], cs.obs_px[cand_obs], cs.obs_f[cand_obs], cs.obs_R[cand_obs], cs.obs_t[cand_obs]
+    r.ref_level, r.ref_inv_expo, r.ref_id = cs.obs_level[cand_obs], cs.obs_inv_expo[cand_obs], cs.obs_id[cand_obs]
+    tail = warp_candidates(r, lib)
+    keep = tail["accepted"] != 0
+    return dict(sel=sel, cell_obs=cell_obs, ref_patch=ref_patch, cand_cell=cand_cell, cand_point=cand_point, cand_obs=cand_obs, tail=tail,
+                sub_point=cand_point[keep], sub_obs=cand_obs[keep])
 
 
 def feat_map_keys(pos, lib=None):

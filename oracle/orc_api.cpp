@@ -12,6 +12,7 @@
 #include "orc_warp.hpp"
 #include "orc_preprocess.hpp"
 #include "orc_select.hpp"
+#include "orc_choice.hpp"
 #include "orc_imu.hpp"
 #include <chrono>
 
@@ -358,7 +359,9 @@ double orc_init_plane_batch(const double *point_w, const double *var9, const int
 
 // Per-point tail of retrieveFromVisualSparseMap (src/vio.cpp:698-767) for n candidates (orc_warp.hpp).  Arrays are per candidate;
 // ref_imgs holds n_ref images of cam.width x cam.height.  Outputs per candidate: accepted, search_level, error, ncc, A_cur_ref, and
-// patch_wrap [n][L*64]; the survivors in candidate order are what the reference appends to visual_submap.  Returns seconds spent.
+// patch_wrap [n][L*64]; the survivors in candidate order are what the reference appends to visual_submap.  ref_id (may be NULL) =
+// ref_ftr->id_: with !normal_en the warp of the first candidate carrying an id is reused by all later candidates with the same id
+// (warp_map, src/vio.cpp:716-734).  Returns seconds spent.
 struct orc_warp_cfg {
   double fx, fy, cx, cy; int32_t width, height;
   double R_cur[9], t_cur[3], inv_expo_cur;
@@ -367,8 +370,8 @@ struct orc_warp_cfg {
 };
 double orc_warp_candidates(const orc_warp_cfg *c, const uint8_t *img, const uint8_t *ref_imgs, int n, const double *pos, const double *normal,
                            const int32_t *ref_img_idx, const double *ref_px, const double *ref_f, const double *ref_R, const double *ref_t,
-                           const int32_t *ref_level, const double *ref_inv_expo, int32_t *accepted, int32_t *search_level, float *error, double *ncc,
-                           double *A4, float *patch_wrap) {
+                           const int32_t *ref_level, const double *ref_inv_expo, const int32_t *ref_id, int32_t *accepted, int32_t *search_level, float *error,
+                           double *ncc, double *A4, float *patch_wrap) {
   WarpCfg cfg;
   cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = 0; cfg.cam.width = c->width; cfg.cam.height = c->height;
   for (int k = 0; k < 5; k++) cfg.cam.d[k] = 0;
@@ -378,6 +381,7 @@ double orc_warp_candidates(const orc_warp_cfg *c, const uint8_t *img, const uint
   const size_t img_bytes = (size_t)c->width * c->height;
   const int L = c->patch_pyrimid_level;
   const double t0 = omp_get_wtime();
+  std::unordered_map<int, std::pair<int, std::array<double, 4>>> warp_map;      // id_ -> (search_level, A_cur_ref); cleared per call (vio.cpp:369)
   for (int i = 0; i < n; i++) {
     WarpCand w;
     w.pos = vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); w.normal = vec3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
@@ -387,7 +391,12 @@ double orc_warp_candidates(const orc_warp_cfg *c, const uint8_t *img, const uint
     std::memcpy(w.R_ref.a, ref_R + 9 * (size_t)i, 72); w.t_ref = vec3(ref_t[3 * i], ref_t[3 * i + 1], ref_t[3 * i + 2]);
     w.level_ref = ref_level[i]; w.inv_expo_ref = ref_inv_expo[i];
     WarpOut o;
-    warp_candidate(cfg, img, w, patch_wrap + (size_t)i * L * 64, o);
+    if (!cfg.normal_en && ref_id) {
+      auto iter_warp = warp_map.find(ref_id[i]);
+      if (iter_warp != warp_map.end()) { o.search_level = iter_warp->second.first; std::memcpy(o.A, iter_warp->second.second.data(), 32); }
+      else { warp_matrix(cfg, w, o); warp_map[ref_id[i]] = {o.search_level, {o.A[0], o.A[1], o.A[2], o.A[3]}}; }
+    } else warp_matrix(cfg, w, o);
+    warp_finish(cfg, img, w, patch_wrap + (size_t)i * L * 64, o);
     accepted[i] = o.accepted; search_level[i] = o.search_level; error[i] = o.error; ncc[i] = o.ncc;
     std::memcpy(A4 + 4 * (size_t)i, o.A, 32);
   }
@@ -431,6 +440,37 @@ double orc_visual_select(const orc_select_cfg *c, const double *pg, int n_pg, co
   return omp_get_wtime() - t0;
 }
 void orc_feat_map_key(const double *pos3, int64_t *key3) { feat_map_key(vec3(pos3[0], pos3[1], pos3[2]), key3); }
+
+// Reference-patch choice of retrieveFromVisualSparseMap (orc_choice.hpp) for the n_cells grid cells of one call.  cell_point / cell_discont: as
+// produced by orc_visual_select.  The observations are a CSR table over the visual points: obs_offset[n_pts + 1]; per observation id_, T_f_w_
+// (R row-major, t) and patch_ (64 floats); per point is_normal_initialized_ and ref_patch (GLOBAL observation index, -1 = !has_ref_patch_; updated in
+// place like pt->ref_patch / has_ref_patch_).  cell_obs[c] = global index of ref_ftr, or -1 where the loop body `continue`s before the warp.
+void orc_choose_ref(int normal_en, const double *R_cur9, const double *t_cur3, int n_cells, const int32_t *cell_point, const int32_t *cell_discont, const double *pos,
+                    const int32_t *obs_offset, const int32_t *obs_id, const double *obs_R, const double *obs_t, const float *obs_patch,
+                    const uint8_t *normal_initialized, int32_t *ref_patch, int32_t *cell_obs) {
+  M3 Rc; V3 tc;
+  std::memcpy(Rc.a, R_cur9, 72); std::memcpy(tc.a, t_cur3, 24);
+  const V3 framepos = (Rc.T() * tc) * (-1.0);                       // new_frame_->pos()
+  for (int c = 0; c < n_cells; c++) {
+    cell_obs[c] = -1;
+    const int p = cell_point[c];
+    if (p < 0 || cell_discont[c]) continue;                         // vio.cpp:601-640
+    if (!normal_initialized[p]) continue;                           // vio.cpp:650
+    const int b = obs_offset[p], n = obs_offset[p + 1] - b;
+    std::vector<ObsRef> obs((size_t)n);
+    for (int k = 0; k < n; k++) {
+      obs[k].id = obs_id[b + k]; std::memcpy(obs[k].R.a, obs_R + 9 * (size_t)(b + k), 72); std::memcpy(obs[k].t.a, obs_t + 3 * (size_t)(b + k), 24);
+      obs[k].patch = obs_patch + 64 * (size_t)(b + k);
+    }
+    int chosen;
+    if (normal_en) {
+      int has = ref_patch[p] >= 0, ref = has ? ref_patch[p] - b : -1;
+      chosen = choose_ref_by_patches(obs.data(), n, 64, has, ref);
+      ref_patch[p] = has ? b + ref : -1;
+    } else chosen = getCloseViewObs(framepos, vec3(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2]), obs.data(), n);
+    cell_obs[c] = chosen < 0 ? -1 : b + chosen;
+  }
+}
 
 // IMU forward propagation (orc_imu.hpp).  steps: n x 8 doubles (gyr3, acc3, dt, offs_t); cfg: 13 doubles + 3 flags; poses out: n x 22 doubles.
 struct orc_imu_cfg { double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm; int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en, pad; };

@@ -9,6 +9,9 @@
 //   getImagePatch                   src/vio.cpp:203-225      (current image, level 0)
 //   photometric error, NCC, gates   src/vio.cpp:742-760, calculateNCC 333-350
 //   appended outputs                src/vio.cpp:762-767      (visual_submap->{voxel_points, search_levels, errors, warp_patch, inv_expo_list})
+//   warp_map                        src/vio.cpp:369, 716-734 (!normal_en only: the warp is cached under ref_ftr->id_, and id_ is the id of the FRAME the
+//                                   feature was created in (vio.cpp:882, 961) — every later point of this call whose ref_ftr comes from the same frame
+//                                   reuses the FIRST such point's A_cur_ref and search_level instead of computing its own; restated in orc_api.cpp)
 //
 // Third-party arithmetic NOT under /root/reference (rpg_vikit, xuankuzcr fork, unpinned — README.md:76-84), restated from its
 // published sources, PARITY UNPINNED:
@@ -153,13 +156,11 @@ inline double calculateNCC(const float *ref_patch, const float *cur_patch, int p
 
 struct WarpOut { int accepted, search_level; float error; double ncc; double A[4]; };
 
-// body of the per-point loop, src/vio.cpp:698-767 ; patch_wrap: [L*64]
-inline void warp_candidate(const WarpCfg &cfg, const uint8_t *img, const WarpCand &c, float *patch_wrap, WarpOut &o) {
-  const int patch_size = 8, patch_size_half = 4, patch_size_total = 64;
+// first half of the loop body, src/vio.cpp:698-735: the affine warp reference -> current and its search level
+inline void warp_matrix(const WarpCfg &cfg, const WarpCand &c, WarpOut &o) {
+  const int patch_size_half = 4;
   const M3 R_cur_ref = cfg.R_cur * c.R_ref.T();                               // new_frame_->T_f_w_ * ref_ftr->T_f_w_.inverse()
   const V3 t_cur_ref = cfg.t_cur - R_cur_ref * c.t_ref;
-  double pc[2];
-  cfg.cam.world2cam(cfg.R_cur * c.pos + cfg.t_cur, pc);                       // new_frame_->w2c(pt->pos_), vio.cpp:606
   if (cfg.normal_en) {
     V3 nv = c.R_ref * c.normal; nv = nv / norm(nv);                           // vio.cpp:701
     const V3 pf = c.R_ref * c.pos + c.t_ref;                                  // vio.cpp:703
@@ -169,6 +170,13 @@ inline void warp_candidate(const WarpCfg &cfg, const uint8_t *img, const WarpCan
     getWarpMatrixAffine(cfg.cam, c.px_ref, c.f_ref, norm(ref_pos - c.pos), R_cur_ref, t_cur_ref, c.level_ref, 0, patch_size_half, o.A);
   }
   o.search_level = getBestSearchLevel(o.A, 2);
+}
+
+// second half, src/vio.cpp:738-767, with o.A / o.search_level given; patch_wrap: [L*64]
+inline void warp_finish(const WarpCfg &cfg, const uint8_t *img, const WarpCand &c, float *patch_wrap, WarpOut &o) {
+  const int patch_size = 8, patch_size_half = 4, patch_size_total = 64;
+  double pc[2];
+  cfg.cam.world2cam(cfg.R_cur * c.pos + cfg.t_cur, pc);                       // new_frame_->w2c(pt->pos_), vio.cpp:606
   for (int k = 0; k < patch_size_total * cfg.patch_pyrimid_level; k++) patch_wrap[k] = 0.f;   // std::vector<float> patch_wrap(warp_len)
   for (int pyramid_level = 0; pyramid_level <= cfg.patch_pyrimid_level - 1; pyramid_level++)
     warpAffine(o.A, c.img_ref, cfg.cam.width, cfg.cam.height, c.px_ref, o.search_level, pyramid_level, patch_size_half, patch_wrap);
@@ -182,6 +190,12 @@ inline void warp_candidate(const WarpCfg &cfg, const uint8_t *img, const WarpCan
   o.accepted = 1;
   if (cfg.ncc_en && o.ncc < cfg.ncc_thre) o.accepted = 0;
   if (error > cfg.outlier_threshold * patch_size_total) o.accepted = 0;
+}
+
+// body of the per-point loop, src/vio.cpp:698-767, for a ref_ftr that meets no warp_map entry
+inline void warp_candidate(const WarpCfg &cfg, const uint8_t *img, const WarpCand &c, float *patch_wrap, WarpOut &o) {
+  warp_matrix(cfg, c, o);
+  warp_finish(cfg, img, c, patch_wrap, o);
 }
 
 } // namespace orc

@@ -646,3 +646,92 @@ def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17):
     border = (4 + 1) * (1 << L)                                      # vio.cpp:154
     active = (rng.uniform(size=n_vis) > 0.05).astype(np.uint8)
     return SelectScenario(pg, pos, feat_map_key_np(pos), active, R_cur, t_cur, cam, border, grid_size, gw, gh)
+
+
+# ---- the whole retrieveFromVisualSparseMap: selection -> reference-patch choice -> warp/gate tail (reference src/vio.cpp:352-780) -----------
+@dataclass
+class RetrieveChainScenario:
+    sel: SelectScenario        # scan points, visual points, current pose, grid
+    img: np.ndarray            # current image u8 [H,W]
+    ref_imgs: np.ndarray       # u8 [n_ref,H,W]: Feature::img_ of every frame that observed something
+    normal: np.ndarray         # [n,3] VisualPoint::normal_
+    normal_initialized: np.ndarray   # [n] uint8 is_normal_initialized_
+    ref_patch: np.ndarray      # [n] int32: global observation index of pt->ref_patch, -1 = !has_ref_patch_
+    obs_offset: np.ndarray     # [n+1] int32: CSR over pt->obs_ (list order)
+    obs_id: np.ndarray         # per observation: Feature::id_ (= id of the frame it was made in)
+    obs_img_idx: np.ndarray    # index into ref_imgs
+    obs_px: np.ndarray         # [m,2] px_
+    obs_f: np.ndarray          # [m,3] f_
+    obs_R: np.ndarray          # [m,9] T_f_w_ rotation
+    obs_t: np.ndarray          # [m,3] T_f_w_ translation
+    obs_level: np.ndarray      # [m] int32 level_
+    obs_inv_expo: np.ndarray   # [m] inv_expo_time_
+    obs_patch: np.ndarray      # [m,64] float32 patch_
+    inv_expo_cur: float
+    cfg: dict                  # patch_pyrimid_level, normal_en, ncc_en, ncc_thre, outlier_threshold
+
+
+def retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=20000, L=4, grid_n_height=17, normal_en=True, ncc_en=False, ncc_thre=0.5, outlier_threshold=1000.0,
+                            max_obs=6):
+    """Visual points of select_scenario, each observed by 1..max_obs features made in a handful of earlier frames: frames 0-3 stand close to the
+    current pose and show the current texture (their patches warp almost identically and pass the gates), frame 4 is a close-up with another
+    texture, frame 5 looks at the scene from the side (more than 60 degrees off: getCloseViewObs rejects it).  A share of points carries two
+    observations of ONE frame (same id_), only same-id observations, a preset ref_patch, or an uninitialised normal."""
+    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height)
+    rng = np.random.default_rng(seed + 1000)
+    cam = base.cam
+    W, H = cam["width"], cam["height"]
+    img = make_image(rng, W, H, sigma=7.0)
+    n_frames = 6
+    ref_imgs = np.stack([img, img, img, img, make_image(rng, W, H, sigma=7.0), make_image(rng, W, H, sigma=7.0)])
+    cam_pos = -base.R_cur.T @ base.t_cur
+    fr_R, fr_t = [], []
+    for k in range(n_frames):
+        rot_s, tr_s = [(0.02, 0.002), (0.05, 0.004), (0.1, 0.01), (0.3, 0.03), (0.1, 0.01), (0.1, 0.01)][k]
+        dR = so3_exp(rng.normal(0, np.deg2rad(rot_s), 3))
+        R_fw = dR @ base.R_cur
+        c_w = cam_pos + rng.normal(0, tr_s, 3)
+        if k == 4:
+            c_w = c_w + base.R_cur.T @ np.array([0.0, 0.0, 1.2])          # 1.2 m closer along the optical axis
+        if k == 5:
+            c_w = c_w + base.R_cur.T @ np.array([25.0, 0.0, 2.0])         # far to the side
+        fr_R.append(R_fw); fr_t.append(-R_fw @ c_w)
+    fr_ie = rng.uniform(0.9, 1.1, n_frames)
+    n = len(base.pos)
+    n_obs = rng.integers(1, max_obs + 1, n)
+    kind = rng.choice(4, n, p=[0.8, 0.08, 0.06, 0.06])          # 1: two observations of one frame, 2: only one id, 3: side view among them
+    offs = np.zeros(n + 1, np.int32)
+    ids, iidx, px_l, f_l, R_l, t_l, lvl_l, ie_l, patch_l = [], [], [], [], [], [], [], [], []
+    for i in range(n):
+        m = int(n_obs[i])
+        frames = rng.choice(5, m, p=[0.3, 0.25, 0.2, 0.15, 0.1])
+        if kind[i] == 1 and m >= 2:
+            frames[1] = frames[0]
+        elif kind[i] == 2:
+            frames[:] = frames[0]
+        elif kind[i] == 3:
+            frames[rng.integers(0, m)] = 5
+            if rng.uniform() < 0.5:
+                frames[:] = 5
+        for k in frames:
+            pr = fr_R[k] @ base.pos[i] + fr_t[k]
+            z = pr[2] if abs(pr[2]) > 1e-3 else 1e-3
+            px = np.array([cam["fx"] * pr[0] / z + cam["cx"], cam["fy"] * pr[1] / z + cam["cy"]]) + rng.normal(0, 0.3, 2)
+            px = np.clip(px, [6.0, 6.0], [W - 7.0, H - 7.0])
+            f = np.array([(px[0] - cam["cx"]) / cam["fx"], (px[1] - cam["cy"]) / cam["fy"], 1.0])
+            xi, yi = int(px[0]), int(px[1])
+            patch = ref_imgs[k][yi - 4:yi + 4, xi - 4:xi + 4].astype(np.float32).ravel() + rng.normal(0, 2.0, 64).astype(np.float32)
+            ids.append(100 + k); iidx.append(k); px_l.append(px); f_l.append(f / np.linalg.norm(f)); R_l.append(fr_R[k].ravel()); t_l.append(fr_t[k])
+            lvl_l.append(rng.integers(0, 3)); ie_l.append(fr_ie[k]); patch_l.append(patch)
+        offs[i + 1] = offs[i] + m
+    to_cam = cam_pos - base.pos
+    normal = to_cam / np.linalg.norm(to_cam, axis=1, keepdims=True) + rng.normal(0, 0.2, (n, 3))
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    ninit = (rng.uniform(size=n) > 0.07).astype(np.uint8)
+    ref_patch = np.full(n, -1, np.int32)
+    preset = (rng.uniform(size=n) < 0.4) & (n_obs >= 2)
+    ref_patch[preset] = offs[:-1][preset] + (rng.integers(0, 1 << 30, preset.sum()) % n_obs[preset])
+    cfg = dict(patch_pyrimid_level=L, normal_en=int(normal_en), ncc_en=int(ncc_en), ncc_thre=float(ncc_thre), outlier_threshold=float(outlier_threshold))
+    return RetrieveChainScenario(base, img, ref_imgs, normal, ninit, ref_patch, offs, np.array(ids, np.int32), np.array(iidx, np.int32), np.array(px_l),
+                                 np.array(f_l), np.array(R_l), np.array(t_l), np.array(lvl_l, np.int32), np.array(ie_l), np.array(patch_l, np.float32),
+                                 1.02, cfg)
