@@ -358,32 +358,81 @@ void ImuProcess::ForwardPropagate(StatesGroup &state_inout, const std::vector<li
   IMUpose.insert(IMUpose.end(), pushed.begin(), pushed.begin() + steps.size());
 }
 
-std::vector<VisualPoint *> VIOManager::selectFromVisualSparseMap(const std::vector<pointWithVar> &pg) {
-  if (feat_map.empty()) return {};                                                // reference src/vio.cpp:354
-  if (feat_map_dirty_) {                                                          // flat mirror: index i <-> VisualPoint*
-    std::vector<double> pos; std::vector<int64_t> key; std::vector<uint8_t> act;
-    mirror_.clear();
-    for (const auto &kv : feat_map)
-      for (VisualPoint *pt : kv.second->voxel_points) {
-        mirror_.push_back(pt);
-        act.push_back(pt != nullptr && !pt->obs_.empty());
-        for (int k = 0; k < 3; k++) pos.push_back(pt ? pt->pos_[k] : 0.0);
-        key.push_back(kv.first.x); key.push_back(kv.first.y); key.push_back(kv.first.z);
+// flat mirror of feat_map on the device: index i <-> VisualPoint* (and, with_obs, observation index <-> Feature*)
+void VIOManager::mirrorFeatMap(bool with_obs, const GrayImage *img) {
+  if (!feat_map_dirty_ && (!with_obs || obs_resident_)) return;
+  std::vector<double> pos; std::vector<int64_t> key; std::vector<uint8_t> act;
+  mirror_.clear();
+  for (const auto &kv : feat_map)
+    for (VisualPoint *pt : kv.second->voxel_points) {
+      mirror_.push_back(pt);
+      act.push_back(pt != nullptr && !pt->obs_.empty());
+      for (int k = 0; k < 3; k++) pos.push_back(pt ? pt->pos_[k] : 0.0);
+      key.push_back(kv.first.x); key.push_back(kv.first.y); key.push_back(kv.first.z);
+    }
+  dev_.check(livo2_visual_map_upload(dev_.ctx(), (int32_t)mirror_.size(), pos.data(), key.data(), act.data()));
+  feat_map_dirty_ = false; obs_resident_ = false;
+  if (!with_obs) return;
+  const size_t n = mirror_.size();
+  std::vector<int32_t> off(n + 1, 0), id, iidx, lvl, refp(n, -1);
+  std::vector<double> px, f, R, t, ie, nrm(n * 3, 0.0);
+  std::vector<float> patch;
+  std::vector<uint8_t> ninit(n, 0);
+  std::vector<const uint8_t *> imgs;
+  obs_mirror_.clear();
+  for (size_t i = 0; i < n; i++) {
+    const VisualPoint *pt = mirror_[i];
+    if (pt) {
+      std::memcpy(&nrm[i * 3], pt->normal_.data(), 24);
+      ninit[i] = pt->is_normal_initialized_;
+      for (Feature *ft : pt->obs_) {
+        if (pt->has_ref_patch_ && ft == pt->ref_patch) refp[i] = (int32_t)obs_mirror_.size();
+        size_t k = 0; while (k < imgs.size() && imgs[k] != ft->img_) k++;
+        if (k == imgs.size()) imgs.push_back(ft->img_);
+        obs_mirror_.push_back(ft);
+        id.push_back(ft->id_); iidx.push_back((int32_t)k); lvl.push_back(ft->level_); ie.push_back(ft->inv_expo_time_);
+        px.insert(px.end(), ft->px_.begin(), ft->px_.end()); f.insert(f.end(), ft->f_.begin(), ft->f_.end());
+        R.insert(R.end(), ft->R_f_w.begin(), ft->R_f_w.end()); t.insert(t.end(), ft->t_f_w.begin(), ft->t_f_w.end());
+        if (!ft->patch_) throw std::runtime_error("retrieveFromVisualSparseMap: Feature without patch_");
+        patch.insert(patch.end(), ft->patch_, ft->patch_ + 64);
       }
-    dev_.check(livo2_visual_map_upload(dev_.ctx(), (int32_t)mirror_.size(), pos.data(), key.data(), act.data()));
-    feat_map_dirty_ = false;
+    }
+    off[i + 1] = (int32_t)obs_mirror_.size();
   }
-  if (grid_n_width == 0) {                                                        // reference src/vio.cpp:67-78
-    if (grid_size > 10) { grid_n_width = (int)std::ceil((double)(width / grid_size)); grid_n_height = (int)std::ceil((double)(height / grid_size)); }
-    else { grid_size = height / grid_n_height; grid_n_height = (int)std::ceil((double)(height / grid_size)); grid_n_width = (int)std::ceil((double)(width / grid_size)); }
-  }
-  const int length = grid_n_width * grid_n_height;
-  std::vector<double> pgw(pg.size() * 3);
-  for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24);
+  const size_t bytes = (size_t)img->step * img->rows;
+  std::vector<uint8_t> pool(bytes * std::max<size_t>(imgs.size(), 1));
+  for (size_t k = 0; k < imgs.size(); k++) std::memcpy(&pool[k * bytes], imgs[k], bytes);
+  livo2_visual_obs o{};
+  o.n_obs = (int32_t)obs_mirror_.size(); o.n_ref = (int32_t)imgs.size(); o.point_offset = off.data(); o.id = id.data(); o.img_idx = iidx.data();
+  o.px = px.data(); o.f = f.data(); o.R = R.data(); o.t = t.data(); o.level = lvl.data(); o.inv_expo = ie.data(); o.patch = patch.data();
+  o.normal = nrm.data(); o.normal_initialized = ninit.data(); o.ref_patch = refp.data(); o.ref_imgs = pool.data();
+  o.width = img->cols; o.height = img->rows; o.stride = img->step;
+  dev_.check(livo2_visual_obs_upload(dev_.ctx(), &o));
+  obs_resident_ = true;
+}
+
+void VIOManager::gridSetup() {                                                    // reference src/vio.cpp:67-78
+  if (grid_n_width != 0) return;
+  if (grid_size > 10) { grid_n_width = (int)std::ceil((double)(width / grid_size)); grid_n_height = (int)std::ceil((double)(height / grid_size)); }
+  else { grid_size = height / grid_n_height; grid_n_height = (int)std::ceil((double)(height / grid_size)); grid_n_width = (int)std::ceil((double)(width / grid_size)); }
+}
+
+livo2_select_cfg VIOManager::selectCfg() const {
   livo2_select_cfg sc{};
   sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = 0; sc.cam.width = width; sc.cam.height = height;
   std::memcpy(sc.R_cur, R_f_w_new.data(), 72); std::memcpy(sc.t_cur, t_f_w_new.data(), 24);
   sc.border = border; sc.grid_size = grid_size; sc.grid_n_width = grid_n_width; sc.grid_n_height = grid_n_height; sc.patch_size_half = patch_size / 2;
+  return sc;
+}
+
+std::vector<VisualPoint *> VIOManager::selectFromVisualSparseMap(const std::vector<pointWithVar> &pg) {
+  if (feat_map.empty()) return {};                                                // reference src/vio.cpp:354
+  mirrorFeatMap(false, nullptr);
+  gridSetup();
+  const int length = grid_n_width * grid_n_height;
+  std::vector<double> pgw(pg.size() * 3);
+  for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24);
+  const livo2_select_cfg sc = selectCfg();
   std::vector<int32_t> cell(length); std::vector<uint8_t> disc(length);
   map_dist.assign(length, 10000.0f);
   dev_.check(livo2_visual_select(dev_.ctx(), pgw.data(), (int32_t)pg.size(), &sc, cell.data(), map_dist.data(), disc.data(), nullptr));
@@ -391,6 +440,39 @@ std::vector<VisualPoint *> VIOManager::selectFromVisualSparseMap(const std::vect
   for (int i = 0; i < length; i++)
     if (cell[i] >= 0 && !disc[i]) { VisualPoint *pt = mirror_[cell[i]]; if (pt->is_normal_initialized_) kept.push_back(pt); }   // vio.cpp:598-644
   return kept;
+}
+
+void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg) {
+  if (feat_map.empty()) return;                                                   // reference src/vio.cpp:354
+  SubSparseMap &sm = *visual_submap;                                              // visual_submap->reset(), vio.cpp:359
+  sm.voxel_points.clear(); sm.search_levels.clear(); sm.errors.clear(); sm.inv_expo_list.clear(); sm.warp_patch.clear();
+  mirrorFeatMap(true, &img);
+  gridSetup();
+  const int length = grid_n_width * grid_n_height, L = patch_pyrimid_level;
+  std::vector<double> pgw(pg.size() * 3);
+  for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24);
+  const livo2_select_cfg sc = selectCfg();
+  livo2_retrieve_cfg rc{};
+  rc.cam = sc.cam;
+  std::memcpy(rc.R_cur, R_f_w_new.data(), 72); std::memcpy(rc.t_cur, t_f_w_new.data(), 24);
+  rc.inv_expo_cur = state->inv_expo_time; rc.patch_pyrimid_level = L; rc.normal_en = normal_en; rc.ncc_en = ncc_en; rc.ncc_thre = ncc_thre; rc.outlier_threshold = outlier_threshold;
+  std::vector<int32_t> cell(length), cobs(length), acc(length), sl(length), cand_cell(length);
+  std::vector<float> err(length);
+  map_dist.assign(length, 10000.0f);
+  livo2_retrieve_chain_out out{};
+  out.cell_point = cell.data(); out.cell_dist = map_dist.data(); out.cell_obs = cobs.data(); out.cand_cell = cand_cell.data();
+  out.tail.accepted = acc.data(); out.tail.search_level = sl.data(); out.tail.error = err.data();
+  int32_t n_cand = 0, n_acc = 0;
+  dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, pgw.data(), (int32_t)pg.size(), &sc, &rc, &out, &n_cand, &n_acc));
+  for (int i = 0; i < n_cand; i++) {
+    const int c = cand_cell[i];
+    VisualPoint *pt = mirror_[cell[c]]; Feature *ref_ftr = obs_mirror_[cobs[c]];
+    if (normal_en) { pt->ref_patch = ref_ftr; pt->has_ref_patch_ = true; }        // vio.cpp:660-661, 689-690
+    if (!acc[i]) continue;
+    sm.voxel_points.push_back(pt); sm.search_levels.push_back(sl[i]); sm.errors.push_back(err[i]); sm.inv_expo_list.push_back(ref_ftr->inv_expo_time_);   // vio.cpp:762-767
+  }
+  total_points = n_acc;
+  frame_resident_ = true;
 }
 
 void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands) {

@@ -196,7 +196,9 @@ private:
 };
 
 // ---- visual ---------------------------------------------------------------------------------------------------------------
-struct Feature {                            // reference include/feature.h:19-54 — what precomputeReferencePatches (vio.cpp:1346-1356) and the retrieval loop (vio.cpp:698-767) read
+struct Feature {                            // reference include/feature.h:19-54 — what precomputeReferencePatches (vio.cpp:1346-1356) and the retrieval loop (vio.cpp:644-767) read
+  int id_ = 0;                              // id of the frame the feature was made in (vio.cpp:882, 961)
+  const float *patch_ = nullptr;            // patch_size_total floats, level 0
   const uint8_t *img_ = nullptr;            // reference gray image (same size / stride as the current frame)
   std::array<double, 2> px_{};
   V3D f_{};
@@ -206,7 +208,12 @@ struct Feature {                            // reference include/feature.h:19-54
   int level_ = 0;
   double inv_expo_time_ = 1.0;
 };
-struct VisualPoint { V3D pos_{}, normal_{}; Feature *ref_patch = nullptr; std::vector<Feature *> obs_; bool is_normal_initialized_ = true; };   // reference include/visual_point.h:23-46
+struct VisualPoint {                        // reference include/visual_point.h:23-46
+  V3D pos_{}, normal_{};
+  Feature *ref_patch = nullptr;
+  std::vector<Feature *> obs_;              // (std::list in the reference; the order is what matters)
+  bool is_normal_initialized_ = true, has_ref_patch_ = false;
+};
 
 struct VOXEL_POINTS {                       // reference include/vio.h:59-69
   std::vector<VisualPoint *> voxel_points;
@@ -259,10 +266,21 @@ public:
   std::vector<float> map_dist;              // per grid cell, as the reference keeps it
   std::vector<VisualPoint *> selectFromVisualSparseMap(const std::vector<pointWithVar> &pg);
 
+  // The whole retrieveFromVisualSparseMap (reference src/vio.cpp:352-780, raycast_en = false; call site src/vio.cpp:1808) as one chain on the
+  // device: selection, reference-patch choice (pt->ref_patch / has_ref_patch_ are written back for the points it went through), warp and gates.
+  // Fills visual_submap (voxel_points, search_levels, errors, inv_expo_list), map_dist and total_points; the survivors stay resident as the frame
+  // of the next computeJacobianAndUpdateEKF.  feat_map_dirty_ must be set whenever feat_map, an obs_ list, a normal or a ref_patch changed on the host.
+  void retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg);
+
 private:
   Device &dev_;
   bool frame_resident_ = false;             // set by warpAndGateCandidates, consumed by computeJacobianAndUpdateEKF
   std::vector<VisualPoint *> mirror_;       // device index -> VisualPoint*
+  std::vector<Feature *> obs_mirror_;       // device observation index -> Feature*
+  bool obs_resident_ = false;
+  void mirrorFeatMap(bool with_obs, const GrayImage *img);
+  void gridSetup();
+  livo2_select_cfg selectCfg() const;
 };
 
 } // namespace livo2

@@ -357,6 +357,60 @@ int main(int argc, char **argv) {
         wr(dir, "retr_out_state", so2.data(), so2.size());
         std::printf("retrieve: %d of %d candidates kept\n", vio.total_points, n);
       }
+      // ---- the whole retrieveFromVisualSparseMap through the shim (selection -> reference-patch choice -> tail), then the visual update ----
+      auto ccfg = rd<double>(dir, "chain_cfg");    // R_cur9 t_cur3 inv_expo_cur normal_en ncc_en ncc_thre outlier_threshold L border grid_n_height
+      if (!ccfg.empty()) {
+        auto cimg = rd<uint8_t>(dir, "chain_img"), crefs = rd<uint8_t>(dir, "chain_ref_imgs");
+        auto cpg = rd<double>(dir, "chain_pg"), cpos = rd<double>(dir, "chain_pos"), cnrm = rd<double>(dir, "chain_normal");
+        auto ckey = rd<int64_t>(dir, "chain_keys"); auto cninit = rd<uint8_t>(dir, "chain_ninit"); auto crefp = rd<int32_t>(dir, "chain_ref_patch");
+        auto ooff = rd<int32_t>(dir, "chain_obs_offset"), oid = rd<int32_t>(dir, "chain_obs_id"), oimg = rd<int32_t>(dir, "chain_obs_img_idx"), olvl = rd<int32_t>(dir, "chain_obs_level");
+        auto opx = rd<double>(dir, "chain_obs_px"), of = rd<double>(dir, "chain_obs_f"), oR = rd<double>(dir, "chain_obs_R"), ot = rd<double>(dir, "chain_obs_t"), oie = rd<double>(dir, "chain_obs_inv_expo");
+        auto opatch = rd<float>(dir, "chain_obs_patch");
+        const size_t nv = cninit.size(), no = oid.size(), bytes = (size_t)vio.width * vio.height;
+        std::vector<VisualPoint> vp(nv); std::vector<Feature> ft(no);
+        for (size_t k = 0; k < no; k++) {
+          ft[k].id_ = oid[k]; ft[k].patch_ = opatch.data() + 64 * k; ft[k].img_ = crefs.data() + bytes * oimg[k]; ft[k].px_ = {opx[k * 2], opx[k * 2 + 1]};
+          ft[k].level_ = olvl[k]; ft[k].inv_expo_time_ = oie[k];
+          for (int j = 0; j < 3; j++) { ft[k].f_[j] = of[k * 3 + j]; ft[k].t_f_w[j] = ot[k * 3 + j]; }
+          for (int j = 0; j < 9; j++) ft[k].R_f_w[j] = oR[k * 9 + j];
+        }
+        for (size_t i = 0; i < nv; i++) {
+          for (int k = 0; k < 3; k++) { vp[i].pos_[k] = cpos[i * 3 + k]; vp[i].normal_[k] = cnrm[i * 3 + k]; }
+          vp[i].is_normal_initialized_ = cninit[i] != 0;
+          for (int k = ooff[i]; k < ooff[i + 1]; k++) vp[i].obs_.push_back(&ft[k]);
+          if (crefp[i] >= 0) { vp[i].ref_patch = &ft[crefp[i]]; vp[i].has_ref_patch_ = true; }
+          const VOXEL_LOCATION key(ckey[i * 3], ckey[i * 3 + 1], ckey[i * 3 + 2]);
+          auto it = vio.feat_map.find(key);
+          if (it == vio.feat_map.end()) it = vio.feat_map.emplace(key, new VOXEL_POINTS).first;
+          it->second->voxel_points.push_back(&vp[i]); it->second->count++;
+        }
+        vio.feat_map_dirty_ = true;
+        for (int k = 0; k < 9; k++) vio.R_f_w_new[k] = ccfg[k];
+        for (int k = 0; k < 3; k++) vio.t_f_w_new[k] = ccfg[9 + k];
+        StatesGroup st3 = state_from(rd<double>(dir, "chain_state_in")), prop3 = state_from(rd<double>(dir, "chain_state_prop"));
+        st3.inv_expo_time = ccfg[12];
+        vio.normal_en = ccfg[13] != 0; vio.ncc_en = ccfg[14] != 0; vio.ncc_thre = ccfg[15]; vio.outlier_threshold = ccfg[16]; vio.patch_pyrimid_level = (int)ccfg[17];
+        vio.border = (int)ccfg[18]; vio.grid_n_height = (int)ccfg[19]; vio.grid_size = 5; vio.grid_n_width = 0;
+        vio.state = &st3; vio.state_propagat = &prop3;
+        SubSparseMap sm3; vio.visual_submap = &sm3;
+        GrayImage g3{cimg.data(), vio.width, vio.height, vio.width};
+        std::vector<pointWithVar> pg(cpg.size() / 3);
+        for (size_t i = 0; i < pg.size(); i++) for (int k = 0; k < 3; k++) pg[i].point_w[k] = cpg[i * 3 + k];
+        vio.retrieveFromVisualSparseMap(g3, pg);                        // <- the reference call site (src/vio.cpp:1808)
+        std::vector<int32_t> kept, kept_obs, refp(nv, -1), sl3(sm3.search_levels.begin(), sm3.search_levels.end());
+        for (size_t k = 0; k < sm3.voxel_points.size(); k++) { kept.push_back((int32_t)(sm3.voxel_points[k] - vp.data())); kept_obs.push_back((int32_t)(sm3.voxel_points[k]->ref_patch ? sm3.voxel_points[k]->ref_patch - ft.data() : -1)); }
+        for (size_t i = 0; i < nv; i++) if (vp[i].has_ref_patch_) refp[i] = (int32_t)(vp[i].ref_patch - ft.data());
+        wr(dir, "chain_out_kept", kept.data(), kept.size()); wr(dir, "chain_out_kept_ref", kept_obs.data(), kept_obs.size());
+        wr(dir, "chain_out_errors", sm3.errors.data(), sm3.errors.size()); wr(dir, "chain_out_search", sl3.data(), sl3.size());
+        wr(dir, "chain_out_inv_expo", sm3.inv_expo_list.data(), sm3.inv_expo_list.size());
+        wr(dir, "chain_out_ref_patch", refp.data(), refp.size()); wr(dir, "chain_out_map_dist", vio.map_dist.data(), vio.map_dist.size());
+        vio.computeJacobianAndUpdateEKF(g3);
+        auto so3 = state_to(st3);
+        wr(dir, "chain_out_state", so3.data(), so3.size());
+        std::printf("retrieveFromVisualSparseMap: %d points in the sub-map (%zu visual points, %zu observations)\n", vio.total_points, nv, no);
+        for (auto &kv : vio.feat_map) delete kv.second;
+        vio.feat_map.clear();
+      }
     }
   } catch (const std::exception &e) { std::fprintf(stderr, "shim_demo: %s\n", e.what()); return 1; }
   return 0;

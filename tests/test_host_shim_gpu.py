@@ -157,3 +157,56 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     keep_ref = [int(p) for p, dsc in zip(sref["cell_point"], sref["discont"]) if p >= 0 and not dsc]
     assert list(np.fromfile(os.path.join(d, "sel_out_kept.bin"), dtype=np.int32)) == keep_ref and len(keep_ref) > 50
     assert np.array_equal(np.fromfile(os.path.join(d, "sel_out_map_dist.bin"), dtype=np.float32), sref["cell_dist"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normal_en", [True, False])
+def test_shim_retrieve_from_visual_sparse_map(tmp_path, orc, normal_en):
+    """VIOManager::retrieveFromVisualSparseMap through the shim (feat_map of VisualPoints with their Feature lists -> device mirror -> one chain
+    of launches), then computeJacobianAndUpdateEKF on the resident sub-map — against the chained oracle."""
+    d = str(tmp_path)
+    L = 2                                           # like the retrieval leg above: keeps every patch of the later update inside the image
+    cs = synth.retrieve_chain_scenario(seed=91, n_pg=6000, n_vis=7000, L=L, grid_n_height=34, normal_en=normal_en)
+    cs.sel.active[:] = 1                            # the shim derives `active` from obs_.size() > 0, and every point here has observations
+    vs = synth.visual_scenario(seed=18, n_patches=4, L=L)
+    Rci, Pci = synth.vio_constants(vs.extR, vs.extT, vs.Rcl, vs.Pcl)
+    R_cur, t_cur = cs.sel.R_cur, cs.sel.t_cur
+    vs_c = synth.visual_scenario(seed=18, n_patches=4, L=L, R_true=R_cur.T @ Rci, t_true=R_cur.T @ (Pci - t_cur))   # the IMU state whose camera pose is new_frame_->T_f_w_
+    ccur, cprop = H.states(vs_c, orc.StatePOD)
+    cs.img.tofile(os.path.join(d, "img.bin"))
+    np.concatenate([[vs.cam["fx"], vs.cam["fy"], vs.cam["cx"], vs.cam["cy"], vs.cam["width"], vs.cam["height"], vs.cfg["img_point_cov"], L, vs.cfg["max_iterations"], 1.0],
+                    vs.Rcl.ravel(), vs.Pcl, vs.extR.ravel(), vs.extT]).astype(np.float64).tofile(os.path.join(d, "vis_cfg.bin"))
+    _state_vec(ccur).tofile(os.path.join(d, "vis_state_in.bin")); _state_vec(cprop).tofile(os.path.join(d, "vis_state_prop.bin"))
+    _state_vec(ccur).tofile(os.path.join(d, "chain_state_in.bin")); _state_vec(cprop).tofile(os.path.join(d, "chain_state_prop.bin"))
+    np.concatenate([R_cur.ravel(), t_cur, [cs.inv_expo_cur, cs.cfg["normal_en"], cs.cfg["ncc_en"], cs.cfg["ncc_thre"], cs.cfg["outlier_threshold"], L, cs.sel.border,
+                                          cs.sel.grid_n_height]]).astype(np.float64).tofile(os.path.join(d, "chain_cfg.bin"))
+    cs.img.tofile(os.path.join(d, "chain_img.bin")); cs.ref_imgs.tofile(os.path.join(d, "chain_ref_imgs.bin"))
+    f64, i32 = (lambda a: np.ascontiguousarray(a, np.float64)), (lambda a: np.ascontiguousarray(a, np.int32))
+    for name, arr in (("pg", f64(cs.sel.pg)), ("pos", f64(cs.sel.pos)), ("normal", f64(cs.normal)), ("keys", np.ascontiguousarray(cs.sel.keys, np.int64)),
+                      ("ninit", np.ascontiguousarray(cs.normal_initialized, np.uint8)), ("ref_patch", i32(cs.ref_patch)), ("obs_offset", i32(cs.obs_offset)),
+                      ("obs_id", i32(cs.obs_id)), ("obs_img_idx", i32(cs.obs_img_idx)), ("obs_level", i32(cs.obs_level)), ("obs_px", f64(cs.obs_px)), ("obs_f", f64(cs.obs_f)),
+                      ("obs_R", f64(cs.obs_R)), ("obs_t", f64(cs.obs_t)), ("obs_inv_expo", f64(cs.obs_inv_expo)), ("obs_patch", np.ascontiguousarray(cs.obs_patch, np.float32))):
+        arr.tofile(os.path.join(d, "chain_" + name + ".bin"))
+    r = subprocess.run([DEMO, d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "retrieveFromVisualSparseMap" in r.stdout
+
+    ref = orc.visual_retrieve(cs)
+    keep = ref["tail"]["accepted"] == 1
+    assert keep.sum() > 40
+    rd = lambda name, dt: np.fromfile(os.path.join(d, "chain_out_" + name + ".bin"), dtype=dt)
+    assert np.array_equal(rd("kept", np.int32), ref["sub_point"])                       # visual_submap->voxel_points, in order
+    assert np.array_equal(rd("errors", np.float32), ref["tail"]["error"][keep])
+    assert np.array_equal(rd("search", np.int32), ref["tail"]["search_level"][keep])
+    assert np.array_equal(rd("inv_expo", np.float64), cs.obs_inv_expo[ref["sub_obs"]])
+    assert np.array_equal(rd("map_dist", np.float32), ref["sel"]["cell_dist"])
+    assert np.array_equal(rd("ref_patch", np.int32), ref["ref_patch"])                  # pt->ref_patch / has_ref_patch_ written back
+    if normal_en:
+        assert np.array_equal(rd("kept_ref", np.int32), ref["sub_obs"])                 # with normal_en ref_ftr IS pt->ref_patch
+    vs_c.img, vs_c.pos, vs_c.warp_patch = cs.img, cs.sel.pos[ref["sub_point"]], ref["tail"]["patch_wrap"][keep]
+    vs_c.search_levels, vs_c.inv_expo_list = ref["tail"]["search_level"][keep], cs.obs_inv_expo[ref["sub_obs"]]
+    ccur.inv_expo = cs.inv_expo_cur
+    vref = orc.visual_update(orc.visual_cfg(vs_c), vs_c, ccur, cprop)
+    vout = rd("state", np.float64)
+    vrefv = _state_vec(vref["state"])
+    assert np.allclose(vout[:25], vrefv[:25], rtol=0, atol=1e-8) and H.relerr(vout[25:], vrefv[25:]) < 1e-7
