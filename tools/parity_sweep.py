@@ -76,7 +76,7 @@ def main():
 
 
 def widened_rows(ctx, livo2):
-    """plane fit, retrieval (selection + tail), pre-stage, IMU propagation — several seeds each."""
+    """plane fit, retrieval (selection, tail, whole chain), pre-stage, IMU propagation — several seeds each."""
     from tests import imu_inputs as IMU
     from tests import plane_groups as PG
     print("# plane fit (livo2_plane_fit_batch vs init_plane): seed groups planes decision_flips worst_normal_err worst_plane_var_rel")
@@ -110,6 +110,20 @@ def widened_rows(ctx, livo2):
         out = ctx.visual_select(ss)
         print(seed, len(ss.pg), len(ss.pos), int((ref["cell_point"] >= 0).sum()), int((out["cell_point"] != ref["cell_point"]).sum()), int((out["cell_dist"] != ref["cell_dist"]).sum()),
               int((out["discont"].astype(np.int32) != ref["discont"]).sum()), int((out["in_fov"].astype(np.int32) != ref["in_fov"]).sum()), flush=True)
+    print("# retrieval chain (livo2_visual_retrieve_from_map vs orc select -> choice -> tail): seed normal_en cells candidates accepted cell_obs_mismatch ref_patch_mismatch "
+          "candidate_order_mismatch patch_mismatch error_mismatch submap_mismatch")
+    for k, seed in enumerate(range(525, 530)):
+        cs = synth.retrieve_chain_scenario(seed=seed, n_pg=10000, n_vis=20000, grid_n_height=(17, 51, 102)[k % 3], normal_en=bool(k % 2 == 0), ncc_en=bool(k % 3 == 0), ncc_thre=0.8)
+        ref = orc.visual_retrieve(cs)
+        ctx.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)
+        ctx.visual_obs_upload(cs)
+        out = ctx.visual_retrieve_from_map(cs)
+        same_n = out["n_candidates"] == len(ref["cand_cell"])
+        sub_bad = int(out["n_accepted"] != len(ref["sub_point"]) or not np.array_equal(out["sub_point"], ref["sub_point"]) or not np.array_equal(out["sub_obs"], ref["sub_obs"]))
+        print(seed, int(cs.cfg["normal_en"]), len(out["cell_point"]), out["n_candidates"], out["n_accepted"], int((out["cell_obs"] != ref["cell_obs"]).sum()),
+              int((out["ref_patch"] != ref["ref_patch"]).sum()), int(not same_n or not np.array_equal(out["cand_cell"], ref["cand_cell"])),
+              int((out["tail"]["patch_wrap"] != ref["tail"]["patch_wrap"]).sum()) if same_n else -1, int((out["tail"]["error"] != ref["tail"]["error"]).sum()) if same_n else -1,
+              sub_bad, flush=True)
     print("# pre-stage (livo2_lidar_preprocess_scan vs orc_preprocess): seed raw_points undistorted_coords_differing max_ulp feats_down voxel_grid_mismatch")
     for k, seed in enumerate(range(530, 535)):
         rs = synth.raw_scan_scenario(seed=seed, n_raw=24000, extR=None if k % 2 else synth.rot_from_rpy(0.1, -0.05, 0.02 * k))
