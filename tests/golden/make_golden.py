@@ -76,9 +76,25 @@ def retrieve():
                         patch_wrap_l0=o["patch_wrap"][:, 0], patch_wrap_sum=o["patch_wrap"].astype(np.float64).sum(axis=(1, 2)))
 
 
+def retrieve_chain():
+    """Whole retrieveFromVisualSparseMap (selection -> reference-patch choice -> tail) for both choice modes; like `retrieve`, the fixture keeps the
+    scenario seed and checksums of the generated inputs instead of the images and the observation table."""
+    keep = {}
+    for mode, normal_en in (("n", True), ("c", False)):
+        cs = synth.retrieve_chain_scenario(seed=43, n_pg=2500, n_vis=3000, grid_n_height=34, normal_en=normal_en)
+        o = orc.visual_retrieve(cs)
+        keep.update({mode + "_cell_point": o["sel"]["cell_point"], mode + "_cell_dist": o["sel"]["cell_dist"], mode + "_discont": o["sel"]["discont"],
+                     mode + "_cell_obs": o["cell_obs"], mode + "_ref_patch": o["ref_patch"], mode + "_cand_cell": o["cand_cell"], mode + "_sub_point": o["sub_point"],
+                     mode + "_sub_obs": o["sub_obs"], mode + "_search_level": o["tail"]["search_level"], mode + "_error": o["tail"]["error"],
+                     mode + "_accepted": o["tail"]["accepted"], mode + "_A": o["tail"]["A"]})
+    np.savez_compressed(os.path.join(OUT, "retrieve_chain_small.npz"), seed=43, n_pg=2500, n_vis=3000, grid_n_height=34, img_sum=int(cs.img.astype(np.int64).sum()),
+                        patch_sum=float(cs.obs_patch.astype(np.float64).sum()), n_obs=int(cs.obs_offset[-1]), **keep)
+
+
 if __name__ == "__main__":
     plane_fit()
     retrieve()
+    retrieve_chain()
     lidar()
     visual()
     for f in ("lidar_small.npz", "visual_small.npz"):
