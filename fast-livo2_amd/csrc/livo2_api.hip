@@ -114,6 +114,7 @@ struct livo2_ctx {
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
 #endif
   // timing
+  hipEvent_t span0 = nullptr, span1 = nullptr;   // bracket the kernels of one synchronous call (the *_last_kernel_us queries)
   bool timing = false;
   TimingBin bins[3];
   std::vector<EvPair> ev_pool;
@@ -355,6 +356,7 @@ static int ctx_create_impl(int device, void *stream, bool external, livo2_ctx **
   else { if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LIVO2_ERR_HIP; } ctx->own_stream = true; }
   if (hipMalloc((void **)&ctx->d_ctl, sizeof(DevCtl)) != hipSuccess || hipHostMalloc((void **)&ctx->h_in, sizeof(HostIn)) != hipSuccess ||
       hipHostMalloc(&ctx->h_out, sizeof(DevCtl)) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
+  if (hipEventCreate(&ctx->span0) != hipSuccess || hipEventCreate(&ctx->span1) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   if (hipMemsetAsync(ctx->d_ctl, 0, sizeof(DevCtl), ctx->stream) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   *out = ctx;
   return LIVO2_OK;
@@ -387,6 +389,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (ctx->bh_entries) e = hipHostFree(ctx->bh_entries);
   for (auto &b : ctx->bins) for (auto &ev : b.used) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
+  if (ctx->span0) e = hipEventDestroy(ctx->span0);
+  if (ctx->span1) e = hipEventDestroy(ctx->span1);
   if (ctx->own_stream && ctx->stream) e = hipStreamDestroy(ctx->stream);
   (void)e;
   delete ctx;
@@ -588,19 +592,16 @@ int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2
   std::memcpy(a.cov_gyr, cfg->cov_gyr, 24); std::memcpy(a.cov_acc, cfg->cov_acc, 24); std::memcpy(a.cov_bias_gyr, cfg->cov_bias_gyr, 24); std::memcpy(a.cov_bias_acc, cfg->cov_bias_acc, 24);
   a.cov_inv_expo = cfg->cov_inv_expo; a.G_m_s2 = cfg->G_m_s2; a.mean_acc_norm = cfg->mean_acc_norm;
   a.in = ctx->d_imu_state; a.out = ctx->d_imu_state + 1; a.poses = ctx->d_imu_poses;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   hipLaunchKernelGGL(k_imu_propagate, dim3(1), dim3(IMU_THREADS), 0, ctx->stream, a);
-  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(state_out, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
   if (n > 0) HIPCHK(hipMemcpyAsync(poses, ctx->d_imu_poses, (size_t)n * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->imu_kernel_us = 1e3 * ms;
-  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   return LIVO2_OK;
 }
 double livo2_imu_propagate_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->imu_kernel_us : 0.0; }
@@ -650,20 +651,17 @@ int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *v
   a.pw = ctx->d_fit_pw; a.var = ctx->d_fit_var; a.offsets = ctx->d_fit_off; a.planer_threshold = planer_threshold; a.out = ctx->d_fit_out;
   a.plane_idx = plane_idx ? ctx->d_fit_idx : nullptr; a.plane_internal = ctx->d_plane_internal; a.plane_cand_pos = ctx->d_plane_cand_pos;
   a.planes = ctx->d_planes; a.cand = ctx->d_cand;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   const int tpb = FIT_WAVES * LIVO2_WAVE;
   if (n_small) { a.list = ctx->d_fit_list; a.n_list = n_small; hipLaunchKernelGGL(k_plane_fit<8>, dim3((n_small * 8 + tpb - 1) / tpb), dim3(tpb), 0, ctx->stream, a); }
   if (n_big) { a.list = ctx->d_fit_list + n_small; a.n_list = n_big; hipLaunchKernelGGL(k_plane_fit<64>, dim3((n_big * 64 + tpb - 1) / tpb), dim3(tpb), 0, ctx->stream, a); }
-  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, ctx->d_fit_out, (size_t)n_groups * sizeof(livo2_plane_fit), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->fit_kernel_us = 1e3 * ms;
-  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   return LIVO2_OK;
 }
 double livo2_plane_fit_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->fit_kernel_us : 0.0; }
@@ -759,9 +757,7 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
   if (n_poses > 0) HIPCHK(hipMemcpyAsync(ctx->d_poses, poses, (size_t)n_poses * sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_vg_misc, 0, 64, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_vg_misc, 0xFF, 12, ctx->stream));           // min codes
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   if (n_poses >= 2) {
     UndistortArgs u{};
     u.xyz = ctx->d_raw; u.curvature = ctx->d_curv; u.poses = ctx->d_poses; u.n = n; u.n_poses = n_poses;
@@ -792,16 +788,15 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
     HIPCHK(rocprim::exclusive_scan(ctx->d_sort_tmp, scan_bytes, ctx->d_vg_head, ctx->d_vg_slot, 0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
   }
   hipLaunchKernelGGL(k_vg_centroid, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_keys2, ctx->d_perm, ctx->d_vg_head, ctx->d_vg_slot, n, ctx->d_xyz_aos, count);
-  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   HIPCHK(hipGetLastError());
   int32_t misc[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(misc, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
   if (feats_undistort) HIPCHK(hipMemcpyAsync(feats_undistort, ctx->d_raw, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->preprocess_kernel_us = 1e3 * ms;
-  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   if (misc[0]) return fail(ctx, LIVO2_ERR_RANGE, "leaf size too small for the cloud: the voxel grid overflows int32 (pcl::VoxelGrid refuses it too)");
   const int m = misc[1];
   if (feats_down_body && m > 0) HIPCHK(hipMemcpyAsync(feats_down_body, ctx->d_xyz_aos, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
@@ -1222,11 +1217,9 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
   int rc = select_reserve(ctx, cfg, n_pg, &cap); if (rc) return rc;
   const int length = cfg->grid_n_width * cfg->grid_n_height;
   if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   if ((rc = select_enqueue(ctx, cfg, n_pg, cap))) return rc;
-  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   int32_t flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(cell_point, ctx->d_sel_point, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1235,9 +1228,8 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
   if (point_in_fov && ctx->n_vm > 0) HIPCHK(hipMemcpyAsync(point_in_fov, ctx->d_vm_fov, (size_t)ctx->n_vm, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->select_kernel_us = 1e3 * ms;
-  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   if (flag) return fail(ctx, LIVO2_ERR_RANGE, "scan voxel key outside 21 bits per axis");
   return LIVO2_OK;
 }
@@ -1360,18 +1352,15 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
     HIPCHK(hipMemcpyAsync(ctx->d_c_idx, cand->ref_img_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_c_lvl, cand->ref_level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (cand->ref_id) HIPCHK(hipMemcpyAsync(ctx->d_c_id, cand->ref_id, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
     if ((rc = tail_enqueue(ctx, cfg, width, height, stride, ctx->d_ref_imgs, n, nullptr, cand->ref_id != nullptr, nullptr, nullptr))) return rc;
-    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
     HIPCHK(hipMemcpyAsync(&count, ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = tail_fetch(ctx, out, n, L))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
     ctx->retrieve_kernel_us = 1e3 * ms;
-    HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   } else {
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
@@ -1476,9 +1465,7 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if (!ctx->d_ch_count) HIPCHK(hipMalloc((void **)&ctx->d_ch_count, 64));
   HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   // 1. selection
   if ((rc = select_enqueue(ctx, sel, n_pg, cap))) return rc;
   // 2. reference-patch choice, then the chosen pairs lined up as candidates in grid-cell order
@@ -1500,16 +1487,15 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   HIPCHK(hipGetLastError());
   // 3. tail over the candidates (their number stays on the device), survivors -> the resident frame
   if ((rc = tail_enqueue(ctx, cfg, width, height, stride, ctx->d_ob_imgs, length, ctx->d_ch_count, true, ctx->d_cand_point, ctx->d_cand_obs))) return rc;
-  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   int32_t counts[2] = {0, 0}, flag = 0;
   HIPCHK(hipMemcpyAsync(&counts[0], ctx->d_ch_count, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&counts[1], ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->chain_kernel_us = 1e3 * ms;
-  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   if (flag) return fail(ctx, LIVO2_ERR_RANGE, "scan voxel key outside 21 bits per axis");
   const int nc = counts[0], na = counts[1];
   if (out) {

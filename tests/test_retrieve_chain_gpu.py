@@ -116,3 +116,37 @@ def test_retrieve_warp_reuses_warps_per_frame_id(ctx, orc):
     for i, k in enumerate(rs.ref_id):
         lead.setdefault(int(k), i)
     assert all(np.array_equal(ref["A"][i], ref["A"][lead[int(k)]]) for i, k in enumerate(rs.ref_id))
+
+
+def test_chain_argument_errors(livo2):
+    """Error behaviour of the chained retrieval: order of the uploads, consistency of the observation table, value ranges."""
+    c = livo2.Context(0)
+    cs = synth.retrieve_chain_scenario(seed=87, n_pg=800, n_vis=600, normal_en=True)
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.visual_obs_upload(cs)                                        # no visual map yet
+    assert e.value.code == livo2.abi.ERR_NO_MAP
+    c.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.visual_retrieve_from_map(cs)                                 # points without their observations
+    assert e.value.code == livo2.abi.ERR_NO_MAP
+    keep = cs.ref_patch.copy()
+    p = int(np.nonzero(cs.obs_offset[1:] - cs.obs_offset[:-1] >= 1)[0][0])
+    cs.ref_patch[p] = cs.obs_offset[p + 1]                             # an observation of the NEXT point
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.visual_obs_upload(cs)
+    assert e.value.code == livo2.abi.ERR_INVALID
+    cs.ref_patch = keep
+    ids = cs.obs_id.copy()
+    cs.obs_id[3] = 2**31 - 1                                           # reserved value of the warp_map table
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.visual_obs_upload(cs)
+    assert e.value.code == livo2.abi.ERR_RANGE
+    cs.obs_id = ids
+    c.visual_obs_upload(cs)
+    out = c.visual_retrieve_from_map(cs)
+    assert out["n_candidates"] > 0
+    c.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)        # a new point set drops the old observation table
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.visual_retrieve_from_map(cs)
+    assert e.value.code == livo2.abi.ERR_NO_MAP
+    c.close()
