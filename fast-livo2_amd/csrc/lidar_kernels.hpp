@@ -16,7 +16,9 @@
 #pragma once
 #include "esikf_solve.hpp"
 
-#define LIDAR_BLOCK 256          // threads (= points) per block of a single-scan launch
+#ifndef LIDAR_BLOCK
+#define LIDAR_BLOCK 256          // threads (= points) per block of a single-scan launch (overridable: tools/block_probe.py)
+#endif
 #define LIDAR_BLOCK_BATCH 64    // ... of a batched launch: single-wave blocks (17 KB LDS each) keep eight of them in flight per CU and make every barrier of
                                 // the cooperative visit wave-local: 126 us (256) -> 109 us (128) -> 102 us (64) per 16 frames of 91k points
 #define LIDAR_NSUM 29       // 21 (sym HtH) + 6 (Htz) + n_eff + sum|r|
