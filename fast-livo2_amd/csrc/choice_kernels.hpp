@@ -142,19 +142,30 @@ __global__ void __launch_bounds__(256) k_gather_candidates(GatherCandArgs a) {
 __device__ __forceinline__ uint32_t leader_hash(int32_t id) { uint32_t h = (uint32_t)id * 0x9E3779B1u; return h ^ (h >> 15); }
 
 // warp_map: table of {id -> lowest candidate index carrying it}.  keys / vals: capacity mask + 1, initialised to LEADER_EMPTY.
+// (a call has a handful of frame ids for thousands of candidates: the lanes of a wave that carry the same id send ONE pair of atomics, from the lowest
+// lane = the lowest candidate index of the group; with one atomic pair per candidate the kernel took 27 us on six hot addresses)
 __global__ void __launch_bounds__(256) k_leader_insert(const int32_t *__restrict__ id, const int32_t *__restrict__ n_dev, int n_host, int32_t *keys, int32_t *vals,
                                                        uint32_t mask) {
   const int n = n_dev ? n_dev[0] : n_host;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t key = id[i];
-  uint32_t h = leader_hash(key) & mask;
-  for (;;) {
-    const int32_t old = atomicCAS(&keys[h], LEADER_EMPTY, key);
-    if (old == LEADER_EMPTY || old == key) break;
-    h = (h + 1) & mask;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  const bool act = i < n;
+  const int32_t key = act ? id[i] : 0;
+  unsigned long long todo = __ballot(act);
+  while (todo) {                                                      // wave-uniform: one turn per distinct id in the wave
+    const int first = __ffsll((long long)todo) - 1;
+    const int32_t k0 = __shfl(key, first, 64);
+    const unsigned long long same = __ballot(act && key == k0) & todo;
+    if (lane == first) {
+      uint32_t h = leader_hash(k0) & mask;
+      for (;;) {
+        const int32_t old = atomicCAS(&keys[h], LEADER_EMPTY, k0);
+        if (old == LEADER_EMPTY || old == k0) break;
+        h = (h + 1) & mask;
+      }
+      atomicMin(&vals[h], i);
+    }
+    todo &= ~same;
   }
-  atomicMin(&vals[h], i);
 }
 __global__ void __launch_bounds__(256) k_leader_lookup(const int32_t *__restrict__ id, const int32_t *__restrict__ n_dev, int n_host, const int32_t *__restrict__ keys,
                                                        const int32_t *__restrict__ vals, uint32_t mask, int32_t *__restrict__ leader) {

@@ -1195,11 +1195,10 @@ static int select_enqueue(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n
   a.pg = ctx->d_sel_pg; a.pos = ctx->d_vm_pos; a.pkey = ctx->d_vm_pkey; a.active = ctx->d_vm_active; a.set = ctx->d_sel_set; a.mask = (uint32_t)(cap - 1);
   a.depth = ctx->d_sel_depth; a.cell_best = ctx->d_sel_best; a.cell_type = ctx->d_sel_type; a.in_fov = ctx->d_vm_fov; a.range_flag = ctx->d_sel_flag;
   a.cell_point = ctx->d_sel_point; a.cell_dist = ctx->d_sel_dist; a.cell_discont = ctx->d_sel_disc;
-  HIPCHK(hipMemsetAsync(ctx->d_sel_flag, 0, 64, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_sel_set, 0xFF, cap * 8, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_sel_depth, 0, px * 8, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_sel_best, 0xFF, (size_t)length * 8, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_sel_type, 0, (size_t)length * 4, ctx->stream));
+  {
+    const size_t most = std::max(std::max(cap, px), std::max((size_t)length, (size_t)16));
+    hipLaunchKernelGGL(k_sel_reset, dim3((unsigned)((most + 255) / 256)), dim3(256), 0, ctx->stream, a, (uint32_t)cap, (uint32_t)px);
+  }
   if (n_pg > 0) hipLaunchKernelGGL(k_sel_scan, dim3((n_pg + 255) / 256), dim3(256), 0, ctx->stream, a);
   if (ctx->n_vm > 0) hipLaunchKernelGGL(k_sel_points, dim3((ctx->n_vm + 255) / 256), dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_sel_cells, dim3((length + 3) / 4), dim3(256), 0, ctx->stream, a);

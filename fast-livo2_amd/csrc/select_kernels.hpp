@@ -64,6 +64,15 @@ __global__ void __launch_bounds__(256) k_sel_point_keys(const double *__restrict
   pkey[i] = pk;
 }
 
+// per-call reset of the selection state in ONE launch (five fill launches of ~4.4 us each before): empty voxel set, zero depth image, empty cells
+__global__ void __launch_bounds__(256) k_sel_reset(SelectArgs a, uint32_t set_cap, uint32_t pixels) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < set_cap) a.set[i] = SEL_EMPTY;
+  if (i < pixels) a.depth[i] = 0ull;
+  if (i < (uint32_t)a.length) { a.cell_best[i] = SEL_EMPTY; a.cell_type[i] = 0; }
+  if (i < 16) a.range_flag[i] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_sel_scan(SelectArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pg) return;

@@ -84,3 +84,10 @@ def test_retrieve_edge_cases(ctx, orc):
     r2.ref_img_idx = rs.ref_img_idx.copy(); r2.ref_img_idx[3] = 99
     with pytest.raises(Exception):
         ctx.retrieve_warp(r2)
+
+
+def test_many_candidates(ctx, orc):
+    """More than 16 384 candidates: the compaction scan takes its long-run path (more than 16 flags per thread)."""
+    rs = synth.retrieve_scenario(seed=24, n_cand=17500, L=2)
+    ref, out = _compare(ctx, orc, rs)
+    assert 0.4 < ref["accepted"].mean() < 0.95
