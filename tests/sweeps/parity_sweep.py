@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Parity sweep on a GPU box: full LiDAR and visual ESIKF updates through the C ABI against the oracle over many seeded scenarios.
 Prints one line per scenario and a summary (matched-plane flips, float32 residual mismatches, worst accumulated delta-x relative error,
-worst covariance relative error).  Usage: python tools/parity_sweep.py [n_lidar_seeds] [n_visual_seeds] > profiles/rNN_parity_sweep.txt"""
+worst covariance relative error).  Usage: python tests/sweeps/parity_sweep.py [n_lidar_seeds] [n_visual_seeds] > profiles/rNN_parity_sweep.txt"""
 import importlib
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import orc  # noqa: E402  (checker only)
 from scenarios import synth  # noqa: E402

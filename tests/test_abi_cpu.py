@@ -75,3 +75,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+    # nothing outside tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg loads the oracle either
+    for sub in ("tools", "scenarios", "include"):
+        for dp, _, files in os.walk(os.path.join(root, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".h")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(sub, f)
+    import ast
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in ast.walk(fn))
+        assert uses == (fn.name == "cpu_baseline"), fn.name
+    assert not any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in tree.body)
+    tree = ast.parse(open(os.path.join(root, "__graft_entry__.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in ast.walk(fn))
+        assert uses == (fn.name == "smoke"), fn.name
