@@ -324,6 +324,36 @@ def main():
         extra["avia_frame_stages_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
         extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
         extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
+        # The LiDAR-inertial part of a frame as ONE call (livo2_lio_frame: IMU propagation -> undistortion + voxel grid -> StateEstimation) next to the same
+        # three stages called one after the other, on a raw scan that is registered to its map
+        try:
+            lf = synth.lio_frame_scenario(seed=61, n_raw=24000, n_steps=20)
+            lcfg = H.lidar_cfg_product(lf.sc)
+            lst = livo2.State.from_pose(lf.sc.R_prior, lf.sc.t_prior, lf.sc.P)
+            lst.inv_expo = lf.inv_expo; lst.vel[:] = lf.vel.tolist(); lst.bg[:] = lf.bg.tolist(); lst.ba[:] = lf.ba.tolist(); lst.grav[:] = lf.grav.tolist()
+            licfg = livo2.ImuCfg()
+            for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+                getattr(licfg, k)[:] = lf.imu[k]
+            licfg.cov_inv_expo, licfg.G_m_s2, licfg.mean_acc_norm = lf.imu["cov_inv_expo"], lf.imu["G_m_s2"], lf.imu["mean_acc_norm"]
+            licfg.ba_bg_est_en = licfg.gravity_est_en = licfg.exposure_estimate_en = 1
+            ctx.upload_map(lf.sc.fmap)
+            t_seq, t_one = [], []
+            for rep in range(6):
+                t0 = time.perf_counter()
+                lprop, lposes = ctx.imu_propagate(lst, lf.steps, licfg)
+                ctx.preprocess_scan(lf.sc.xyz, lf.curvature, np.vstack([lf.first_pose, lposes]), np.array(lprop.rot).reshape(3, 3), np.array(lprop.pos), synth.AVIA["filter_size_surf"], lcfg, want=False)
+                lres_seq, _ = ctx.lidar_update(lprop, lprop, lcfg)
+                t1 = time.perf_counter()
+                lres, lnd, _, _ = ctx.lio_frame(lst, lf.steps, licfg, lf.first_pose, lf.sc.xyz, lf.curvature, synth.AVIA["filter_size_surf"], lcfg, want_poses=False)
+                t2 = time.perf_counter()
+                if rep:
+                    t_seq.append((t1 - t0) * 1e3); t_one.append((t2 - t1) * 1e3)
+            extra["lio_frame"] = {"raw_points": len(lf.sc.xyz), "feats_down_size": int(lnd), "imu_steps": len(lf.steps), "iterations": int(lres.n_iters),
+                                  "one_call_ms": float(np.median(t_one)), "three_calls_ms": float(np.median(t_seq)), "same_result": bytes(lres.state) == bytes(lres_seq.state),
+                                  "note": "livo2_lio_frame vs livo2_imu_propagate + livo2_lidar_preprocess_scan + livo2_lidar_update through the Python wrappers, host-synchronous, "
+                                          "incl. H2D of the raw scan and D2H of the result; state_propagat, IMUpose and feats_down_body stay on the device in the one-call form"}
+        except Exception as exc:                                   # informational leg: never take the bench line down with it
+            extra["lio_frame"] = {"error": repr(exc)}
         ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
         # IMU forward propagation (20 samples = 100 ms at 200 Hz)
         from tests import imu_inputs as IMU

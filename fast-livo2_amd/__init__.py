@@ -127,6 +127,21 @@ class Context:
         self.n = int(nd.value)
         return self.n, und, (down[: self.n] if want else None)
 
+    def lio_frame(self, state_in, steps, imu_cfg, first_pose, xyz, curvature, leaf, cfg, want_poses=True):
+        """One LiDAR-inertial frame in one call: IMU forward propagation -> undistortion + voxel grid -> StateEstimation(state_propagat).
+        steps: [n][8]; first_pose: [22] (IMUpose[0]).  Returns (LidarResult, n_down, state_propagat, poses [n][22] or None)."""
+        S = np.ascontiguousarray(steps, np.float64).reshape(-1, 8)
+        fp = np.ascontiguousarray(first_pose, np.float64).reshape(22)
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        cur = np.ascontiguousarray(curvature, np.float32)
+        prop, res, nd = State(), LidarResult(), C.c_int32(0)
+        poses = np.zeros((max(len(S), 1), 22)) if want_poses else None
+        self._chk(self.lib.livo2_lio_frame(self.h, C.byref(state_in), S.ctypes.data_as(C.c_void_p), len(S), C.byref(imu_cfg), fp.ctypes.data_as(C.c_void_p),
+                                           abi.as_ptr(x, C.c_float), abi.as_ptr(cur, C.c_float), len(x), float(leaf), C.byref(cfg), C.byref(prop),
+                                           poses.ctypes.data_as(C.c_void_p) if want_poses else None, C.byref(nd), C.byref(res)))
+        self.n = int(nd.value)
+        return res, self.n, prop, (poses[: len(S)] if want_poses else None)
+
     def preprocess_last_kernel_us(self):
         return float(self.lib.livo2_lidar_preprocess_last_kernel_us(self.h))
 

@@ -204,6 +204,8 @@ SIGNATURES = {
     "livo2_lidar_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), _P(LidarPoints)]),
     "livo2_lidar_update_fetch": (C.c_int, [_CTX, _P(LidarResult), _P(LidarPoints)]),
     "livo2_lidar_iterations_async": (C.c_int, [_CTX, _P(State), _P(State), _P(LidarCfg), C.c_int32]),
+    "livo2_lio_frame": (C.c_int, [_CTX, _P(State), C.c_void_p, C.c_int32, _P(ImuCfg), C.c_void_p, _P(C.c_float), _P(C.c_float), C.c_int32, C.c_double, _P(LidarCfg),
+                                  _P(State), C.c_void_p, _P(C.c_int32), _P(LidarResult)]),
     "livo2_lidar_batch_set_scans": (C.c_int, [_CTX, C.c_int32, _P(C.c_float), _P(C.c_int32), _P(LidarCfg)]),
     "livo2_lidar_batch_update": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(LidarCfg), _P(LidarResult)]),
     "livo2_lidar_batch_update_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(LidarCfg)]),

@@ -175,6 +175,18 @@ __global__ void k_scatter_planes(const double *__restrict__ recs, const int32_t 
   if (gp >= 0 && k < 28) gates[(size_t)gp * PLANE_REC_DOUBLES + k] = v;
 }
 
+// head of DevCtl from a state that is already on the device (livo2_lio_frame: state_ = state_propagat = the IMU propagation's result): what
+// upload_states() sends from the host — cur, prop, a cleared header, RE = rot_end * extR with the same expression
+struct Mat9 { double v[9]; };
+__global__ void __launch_bounds__(256) k_ctl_from_state(DevCtl *__restrict__ ctl, const livo2_state *__restrict__ st, Mat9 extR) {
+  const int t = threadIdx.x;
+  const double *src = reinterpret_cast<const double *>(st);
+  double *c = reinterpret_cast<double *>(&ctl->cur), *p = reinterpret_cast<double *>(&ctl->prop);
+  for (int k = t; k < (int)(sizeof(livo2_state) / 8); k += 256) { const double v = src[k]; c[k] = v; p[k] = v; }
+  if (t == 0) { ctl->hdr.stop = 0; ctl->hdr.rematch_num = 0; ctl->hdr.reserved = 0; ctl->hdr.last_error = FLT_MAX; ctl->hdr.n_steps = 0; ctl->hdr.pad[0] = ctl->hdr.pad[1] = ctl->hdr.pad[2] = 0; }
+  if (t < 9) { const int i = t / 3, j = t % 3; ctl->hdr.RE[t] = (st->rot[i * 3] * extR.v[j] + st->rot[i * 3 + 1] * extR.v[3 + j]) + st->rot[i * 3 + 2] * extR.v[6 + j]; }
+}
+
 __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restrict__ ctl, int k, double scale, int sign) {
   __shared__ SolveLds s;
   const int lane = threadIdx.x;
@@ -573,6 +585,15 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
 }
 
 // ---- IMU forward propagation -----------------------------------------------------------------------------------------------------
+static ImuKernelArgs make_imu_args(livo2_ctx *ctx, const livo2_imu_cfg *cfg, int n, double *poses) {
+  ImuKernelArgs a{};
+  a.steps = ctx->d_imu_steps; a.n = n; a.ba_bg_est_en = cfg->ba_bg_est_en; a.gravity_est_en = cfg->gravity_est_en; a.exposure_estimate_en = cfg->exposure_estimate_en;
+  std::memcpy(a.cov_gyr, cfg->cov_gyr, 24); std::memcpy(a.cov_acc, cfg->cov_acc, 24); std::memcpy(a.cov_bias_gyr, cfg->cov_bias_gyr, 24); std::memcpy(a.cov_bias_acc, cfg->cov_bias_acc, 24);
+  a.cov_inv_expo = cfg->cov_inv_expo; a.G_m_s2 = cfg->G_m_s2; a.mean_acc_norm = cfg->mean_acc_norm;
+  a.in = ctx->d_imu_state; a.out = ctx->d_imu_state + 1; a.poses = poses;
+  return a;
+}
+
 int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu_step *steps, int32_t n, const livo2_imu_cfg *cfg, livo2_state *state_out,
                         livo2_imu_pose *poses) {
   if (!ctx) return LIVO2_ERR_INVALID;
@@ -587,11 +608,7 @@ int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2
   static_assert(sizeof(livo2_imu_step) == 64, "livo2_imu_step is 8 doubles");
   HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
   if (n > 0) HIPCHK(hipMemcpyAsync(ctx->d_imu_steps, steps, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
-  ImuKernelArgs a{};
-  a.steps = ctx->d_imu_steps; a.n = n; a.ba_bg_est_en = cfg->ba_bg_est_en; a.gravity_est_en = cfg->gravity_est_en; a.exposure_estimate_en = cfg->exposure_estimate_en;
-  std::memcpy(a.cov_gyr, cfg->cov_gyr, 24); std::memcpy(a.cov_acc, cfg->cov_acc, 24); std::memcpy(a.cov_bias_gyr, cfg->cov_bias_gyr, 24); std::memcpy(a.cov_bias_acc, cfg->cov_bias_acc, 24);
-  a.cov_inv_expo = cfg->cov_inv_expo; a.G_m_s2 = cfg->G_m_s2; a.mean_acc_norm = cfg->mean_acc_norm;
-  a.in = ctx->d_imu_state; a.out = ctx->d_imu_state + 1; a.poses = ctx->d_imu_poses;
+  ImuKernelArgs a = make_imu_args(ctx, cfg, n, ctx->d_imu_poses);
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   hipLaunchKernelGGL(k_imu_propagate, dim3(1), dim3(IMU_THREADS), 0, ctx->stream, a);
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
@@ -731,42 +748,33 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
   return LIVO2_OK;
 }
 
-// Raw scan -> undistortion -> voxel-grid filter -> the scan of the next update, all on the device (SURVEY 8f N3).
-int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *curvature, int32_t n, const livo2_imu_pose *poses, int32_t n_poses,
-                                const double *rot_end, const double *pos_end, double leaf_size, const livo2_lidar_cfg *cfg, int32_t *n_down,
-                                float *feats_undistort, float *feats_down_body) {
-  if (!ctx) return LIVO2_ERR_INVALID;
-  if (n < 0 || (n > 0 && (!xyz || !curvature)) || n_poses < 0 || (n_poses > 0 && !poses) || !rot_end || !pos_end || !n_down) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
-  if (!(leaf_size > 0)) return fail(ctx, LIVO2_ERR_INVALID, "leaf_size must be > 0");
-  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
-  for (int k = 1; k < n_poses; k++) if (poses[k].offset_time < poses[k - 1].offset_time) return fail(ctx, LIVO2_ERR_INVALID, "IMU poses must be ordered by offset_time");
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  rc = scan_reserve(ctx, n); if (rc) return rc;
+namespace {
+// buffers of the pre-stage for n raw points and n_poses IMU poses
+int preprocess_reserve(livo2_ctx *ctx, int n, int n_poses) {
+  int rc = scan_reserve(ctx, n); if (rc) return rc;
   rc = ensure(ctx, ctx->d_raw, ctx->raw_cap, std::max((size_t)n * 3, (size_t)3)); if (rc) return rc;
   rc = ensure(ctx, ctx->d_curv, ctx->curv_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
   rc = ensure(ctx, ctx->d_poses, ctx->poses_cap, std::max((size_t)n_poses * 22, (size_t)22)); if (rc) return rc;
   rc = ensure(ctx, ctx->d_vg_head, ctx->vg_head_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
   rc = ensure(ctx, ctx->d_vg_slot, ctx->vg_slot_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
   if (!ctx->d_vg_misc) HIPCHK(hipMalloc((void **)&ctx->d_vg_misc, 64));      // bounds[6] float, overflow flag, leaf count
-  *n_down = 0;
-  if (n == 0) { rc = scan_pipeline(ctx, 0, cfg); if (rc) return rc; ctx->has_scan = true; return LIVO2_OK; }
-  static_assert(sizeof(livo2_imu_pose) == 22 * 8, "livo2_imu_pose is 22 doubles");
-  HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (n_poses > 0) HIPCHK(hipMemcpyAsync(ctx->d_poses, poses, (size_t)n_poses * sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));
+  return LIVO2_OK;
+}
+// undistortion + voxel grid of the n > 0 raw points in d_raw / d_curv with the poses in d_poses: kernels only.  The scan-end pose comes from the host
+// (rot_end / pos_end) or, with end_state, from a state on the device.  Leaves the leaves in d_xyz_aos, the overflow flag and the leaf count in d_vg_misc[8], [9].
+int preprocess_enqueue(livo2_ctx *ctx, int n, int n_poses, const livo2_lidar_cfg *cfg, double leaf_size, const double *rot_end, const double *pos_end, const livo2_state *end_state) {
   HIPCHK(hipMemsetAsync(ctx->d_vg_misc, 0, 64, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_vg_misc, 0xFF, 12, ctx->stream));           // min codes
-  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   if (n_poses >= 2) {
     UndistortArgs u{};
-    u.xyz = ctx->d_raw; u.curvature = ctx->d_curv; u.poses = ctx->d_poses; u.n = n; u.n_poses = n_poses;
+    u.xyz = ctx->d_raw; u.curvature = ctx->d_curv; u.poses = ctx->d_poses; u.n = n; u.n_poses = n_poses; u.end_state = end_state;
     // extR_Ri = Lid_rot_to_IMU^T * rot_end^T ; exrR_extT = Lid_rot_to_IMU^T * Lid_offset_to_IMU   (IMU_Processing.cpp:497-498)
     for (int i = 0; i < 3; i++) {
-      for (int j = 0; j < 3; j++) u.extR_Ri[i * 3 + j] = (cfg->extR[0 * 3 + i] * rot_end[j * 3 + 0] + cfg->extR[1 * 3 + i] * rot_end[j * 3 + 1]) + cfg->extR[2 * 3 + i] * rot_end[j * 3 + 2];
+      if (!end_state) for (int j = 0; j < 3; j++) u.extR_Ri[i * 3 + j] = (cfg->extR[0 * 3 + i] * rot_end[j * 3 + 0] + cfg->extR[1 * 3 + i] * rot_end[j * 3 + 1]) + cfg->extR[2 * 3 + i] * rot_end[j * 3 + 2];
       u.exrR_extT[i] = (cfg->extR[0 * 3 + i] * cfg->extT[0] + cfg->extR[1 * 3 + i] * cfg->extT[1]) + cfg->extR[2 * 3 + i] * cfg->extT[2];
     }
-    std::memcpy(u.ER, cfg->extR, 72); std::memcpy(u.Et, cfg->extT, 24); std::memcpy(u.pos_end, pos_end, 24);
+    std::memcpy(u.ER, cfg->extR, 72); std::memcpy(u.Et, cfg->extT, 24);
+    if (!end_state) std::memcpy(u.pos_end, pos_end, 24);
     hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u);
   }
   uint32_t *bounds = reinterpret_cast<uint32_t *>(ctx->d_vg_misc);
@@ -776,7 +784,7 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
   hipLaunchKernelGGL(k_vg_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_raw, n, inv_leaf, bounds, ctx->d_keys, ctx->d_idx, flag);
   size_t need = 0;
   HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 31, ctx->stream));
-  rc = sort_reserve(ctx, need); if (rc) return rc;
+  int rc = sort_reserve(ctx, need); if (rc) return rc;
   size_t tmp_bytes = ctx->sort_tmp_bytes;
   HIPCHK(rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, (size_t)n, 0, 31, ctx->stream));
   hipLaunchKernelGGL(k_vg_heads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_keys2, n, ctx->d_vg_head);
@@ -788,10 +796,34 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
     HIPCHK(rocprim::exclusive_scan(ctx->d_sort_tmp, scan_bytes, ctx->d_vg_head, ctx->d_vg_slot, 0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
   }
   hipLaunchKernelGGL(k_vg_centroid, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_keys2, ctx->d_perm, ctx->d_vg_head, ctx->d_vg_slot, n, ctx->d_xyz_aos, count);
-  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+} // namespace
+
+// Raw scan -> undistortion -> voxel-grid filter -> the scan of the next update, all on the device (SURVEY 8f N3).
+int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *curvature, int32_t n, const livo2_imu_pose *poses, int32_t n_poses,
+                                const double *rot_end, const double *pos_end, double leaf_size, const livo2_lidar_cfg *cfg, int32_t *n_down,
+                                float *feats_undistort, float *feats_down_body) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n < 0 || (n > 0 && (!xyz || !curvature)) || n_poses < 0 || (n_poses > 0 && !poses) || !rot_end || !pos_end || !n_down) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!(leaf_size > 0)) return fail(ctx, LIVO2_ERR_INVALID, "leaf_size must be > 0");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  for (int k = 1; k < n_poses; k++) if (poses[k].offset_time < poses[k - 1].offset_time) return fail(ctx, LIVO2_ERR_INVALID, "IMU poses must be ordered by offset_time");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rc = preprocess_reserve(ctx, n, n_poses); if (rc) return rc;
+  *n_down = 0;
+  if (n == 0) { rc = scan_pipeline(ctx, 0, cfg); if (rc) return rc; ctx->has_scan = true; return LIVO2_OK; }
+  static_assert(sizeof(livo2_imu_pose) == 22 * 8, "livo2_imu_pose is 22 doubles");
+  HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_poses > 0) HIPCHK(hipMemcpyAsync(ctx->d_poses, poses, (size_t)n_poses * sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
+  rc = preprocess_enqueue(ctx, n, n_poses, cfg, leaf_size, rot_end, pos_end, nullptr); if (rc) return rc;
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   int32_t misc[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(misc, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(misc, ctx->d_vg_misc + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
   if (feats_undistort) HIPCHK(hipMemcpyAsync(feats_undistort, ctx->d_raw, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
@@ -836,8 +868,13 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   return fetch_lidar_points(ctx, points);
 }
 
+static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int iters, int mode);
 static int lidar_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, int iters, int mode) {
   int rc = upload_states(ctx, state_in, prop, cfg->extR); if (rc) return rc;
+  return lidar_enqueue_loop(ctx, cfg, iters, mode);
+}
+// the iterations of one update on the states already in d_ctl
+static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int iters, int mode) {
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1));
@@ -871,6 +908,56 @@ int livo2_lidar_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_
                        const livo2_lidar_points *points) {
   int rc = livo2_lidar_update_async(ctx, state_in, prop, cfg, points); if (rc) return rc;
   return livo2_lidar_update_fetch(ctx, result, points);
+}
+
+// ---- one LiDAR-inertial frame: IMU forward propagation -> undistortion + voxel grid -> StateEstimation(state_propagat), state and scan never leave the device
+int livo2_lio_frame(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu_step *steps, int32_t n_steps, const livo2_imu_cfg *imu_cfg, const livo2_imu_pose *first_pose,
+                    const float *xyz, const float *curvature, int32_t n, double leaf_size, const livo2_lidar_cfg *cfg, livo2_state *state_propagat, livo2_imu_pose *poses,
+                    int32_t *n_down, livo2_lidar_result *result) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!state_in || !imu_cfg || !first_pose || !n_down || !result || n_steps < 0 || n_steps > 65536 || (n_steps > 0 && !steps) || n < 0 || (n > 0 && (!xyz || !curvature)))
+    return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (!(imu_cfg->mean_acc_norm > 0)) return fail(ctx, LIVO2_ERR_INVALID, "mean_acc_norm must be > 0");
+  if (!(leaf_size > 0)) return fail(ctx, LIVO2_ERR_INVALID, "leaf_size must be > 0");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  if (!ctx->has_map) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_map_upload has not been called");
+  for (int k = 0; k < n_steps; k++) if (steps[k].offs_t < (k ? steps[k - 1].offs_t : first_pose->offset_time)) return fail(ctx, LIVO2_ERR_INVALID, "IMU steps must be ordered by offs_t");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int n_poses = n_steps + 1;
+  if ((rc = ensure(ctx, ctx->d_imu_steps, ctx->imu_steps_cap, std::max((size_t)n_steps * 8, (size_t)8)))) return rc;
+  if (!ctx->d_imu_state) HIPCHK(hipMalloc((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
+  if ((rc = preprocess_reserve(ctx, n, n_poses))) return rc;
+  *n_down = 0;
+  HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
+  if (n_steps > 0) HIPCHK(hipMemcpyAsync(ctx->d_imu_steps, steps, (size_t)n_steps * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_poses, first_pose, sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));      // IMUpose[0] (IMU_Processing.cpp:312-313)
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  // 1. forward propagation: d_imu_state[1] = state_propagat, IMUpose[1..] behind the first pose
+  ImuKernelArgs ia = make_imu_args(ctx, imu_cfg, n_steps, ctx->d_poses + 22);
+  hipLaunchKernelGGL(k_imu_propagate, dim3(1), dim3(IMU_THREADS), 0, ctx->stream, ia);
+  HIPCHK(hipGetLastError());
+  // 2. backward propagation to the scan-end pose (read from the device state) + voxel grid
+  if (n > 0) { rc = preprocess_enqueue(ctx, n, n_poses, cfg, leaf_size, nullptr, nullptr, ctx->d_imu_state + 1); if (rc) return rc; }
+  int32_t misc[2] = {0, 0};
+  if (n > 0) HIPCHK(hipMemcpyAsync(misc, ctx->d_vg_misc + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (state_propagat) HIPCHK(hipMemcpyAsync(state_propagat, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
+  if (poses && n_steps > 0) HIPCHK(hipMemcpyAsync(poses, ctx->d_poses + 22, (size_t)n_steps * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));        // the leaf count sizes the launches of the update
+  if (misc[0]) return fail(ctx, LIVO2_ERR_RANGE, "leaf size too small for the cloud: the voxel grid overflows int32 (pcl::VoxelGrid refuses it too)");
+  const int m = misc[1];
+  if ((rc = scan_pipeline(ctx, m, cfg))) return rc;
+  ctx->has_scan = true;
+  *n_down = m;
+  // 3. StateEstimation(state_propagat) with state_ = state_propagat (LIVMapper.cpp:366-370)
+  if ((rc = ensure_lidar_outputs(ctx, nullptr))) return rc;
+  Mat9 er; std::memcpy(er.v, cfg->extR, 72);
+  hipLaunchKernelGGL(k_ctl_from_state, dim3(1), dim3(256), 0, ctx->stream, ctx->d_ctl, ctx->d_imu_state + 1, er);
+  if ((rc = lidar_enqueue_loop(ctx, cfg, cfg->max_iterations, 1))) return rc;
+  return livo2_lidar_update_fetch(ctx, result, nullptr);
 }
 
 int livo2_lidar_iterations_async(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, int32_t iters) {

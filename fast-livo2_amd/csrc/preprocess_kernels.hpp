@@ -12,9 +12,10 @@ struct UndistortArgs {
   const double *poses;           // [n_poses][22] Pose6D: offset_time, acc3, gyr3, vel3, pos3, rot9
   int32_t n, n_poses;
   double extR_Ri[9], exrR_extT[3], ER[9], Et[3], pos_end[3];
+  const livo2_state *end_state;  // scan-end state still on the device (livo2_lio_frame): extR_Ri / pos_end are then derived from it here; NULL: the values above
 };
 
-__device__ __forceinline__ void undistort_one(const UndistortArgs &a, const double *head, double t, float *p) {
+__device__ __forceinline__ void undistort_one(const UndistortArgs &a, const double *extR_Ri, const double *pos_end, const double *head, double t, float *p) {
   const double dt = t - head[0];
   const double *acc = head + 1, *gyr = head + 4, *vel = head + 7, *pos = head + 10, *Rimu = head + 13;
   double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -34,14 +35,14 @@ __device__ __forceinline__ void undistort_one(const UndistortArgs &a, const doub
   mat3_mul(Rimu, E, Ri);
   double T[3], q[3], w[3], o[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) T[k] = ((pos[k] + vel[k] * dt) + ((acc[k] * 0.5) * dt) * dt) - a.pos_end[k];
+  for (int k = 0; k < 3; k++) T[k] = ((pos[k] + vel[k] * dt) + ((acc[k] * 0.5) * dt) * dt) - pos_end[k];
   const double P[3] = {(double)p[0], (double)p[1], (double)p[2]};
 #pragma unroll
   for (int k = 0; k < 3; k++) q[k] = ((a.ER[k * 3] * P[0] + a.ER[k * 3 + 1] * P[1]) + a.ER[k * 3 + 2] * P[2]) + a.Et[k];
 #pragma unroll
   for (int k = 0; k < 3; k++) w[k] = ((Ri[k * 3] * q[0] + Ri[k * 3 + 1] * q[1]) + Ri[k * 3 + 2] * q[2]) + T[k];
 #pragma unroll
-  for (int k = 0; k < 3; k++) o[k] = ((a.extR_Ri[k * 3] * w[0] + a.extR_Ri[k * 3 + 1] * w[1]) + a.extR_Ri[k * 3 + 2] * w[2]) - a.exrR_extT[k];
+  for (int k = 0; k < 3; k++) o[k] = ((extR_Ri[k * 3] * w[0] + extR_Ri[k * 3 + 1] * w[1]) + extR_Ri[k * 3 + 2] * w[2]) - a.exrR_extT[k];
   p[0] = (float)o[0]; p[1] = (float)o[1]; p[2] = (float)o[2];
 }
 
@@ -57,8 +58,23 @@ __global__ void __launch_bounds__(256) k_undistort(UndistortArgs a) {
   int h = lo - 1;
   if (h < 0) return;
   float p[3] = {a.xyz[(size_t)i * 3], a.xyz[(size_t)i * 3 + 1], a.xyz[(size_t)i * 3 + 2]};
+  double eRi[9], pe[3];
+  if (a.end_state) {                                                // the same expressions the host side of livo2_lidar_preprocess_scan evaluates
+    const double *re = a.end_state->rot, *pz = a.end_state->pos;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) eRi[r * 3 + c] = (a.ER[0 * 3 + r] * re[c * 3 + 0] + a.ER[1 * 3 + r] * re[c * 3 + 1]) + a.ER[2 * 3 + r] * re[c * 3 + 2];
+      pe[r] = pz[r];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) eRi[k] = a.extR_Ri[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pe[k] = a.pos_end[k];
+  }
   const int h_stop = (i == 0) ? 0 : h;
-  for (; h >= h_stop; h--) undistort_one(a, a.poses + (size_t)h * 22, t, p);
+  for (; h >= h_stop; h--) undistort_one(a, eRi, pe, a.poses + (size_t)h * 22, t, p);
   a.xyz[(size_t)i * 3] = p[0]; a.xyz[(size_t)i * 3 + 1] = p[1]; a.xyz[(size_t)i * 3 + 2] = p[2];
 }
 

@@ -431,6 +431,20 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
 int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_state *state_in, const livo2_state *prop,
                                   const livo2_visual_cfg *cfg, int32_t iters);
 
+/* ---- one LiDAR-inertial frame on the device (N4 -> N3 -> the update) ------------------------------------------------------
+ * What LIVMapper::handleLIO does with a synchronised (scan, IMU) package before the map update (src/LIVMapper.cpp:342-377):
+ * ImuProcess::UndistortPcl forward loop (src/IMU_Processing.cpp:322-445) -> state_propagat and IMUpose; its backward loop (494-539) and
+ * downSizeFilterSurf (LIVMapper.cpp:351-352) -> feats_down_body; voxelmap_manager->StateEstimation(state_propagat) with state_ = state_propagat
+ * (LIVMapper.cpp:366-370).  One call: the previous state, the IMU steps and the raw scan go in, the posterior comes out; state_propagat,
+ * IMUpose and feats_down_body stay on the device (state_propagat / poses [n_steps] are copied out only if non-NULL), one host round trip
+ * (the number of voxel-grid leaves) instead of the three calls' six.  first_pose = the Pose6D the reference pushes before the loop
+ * (set_pose6d(0, acc_s_last, angvel_last, vel, pos, rot), IMU_Processing.cpp:312-313), so that IMUpose = {first_pose, one pose per step}.
+ * The result equals, bit for bit, livo2_imu_propagate + livo2_lidar_preprocess_scan(poses = IMUpose, rot_end / pos_end of state_propagat) +
+ * livo2_lidar_update(state_propagat, state_propagat) called in sequence; afterwards the scan is resident like after livo2_lidar_set_scan. */
+int livo2_lio_frame(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu_step *steps, int32_t n_steps, const livo2_imu_cfg *imu_cfg,
+                    const livo2_imu_pose *first_pose, const float *xyz, const float *curvature, int32_t n, double leaf_size, const livo2_lidar_cfg *cfg,
+                    livo2_state *state_propagat, livo2_imu_pose *poses, int32_t *n_down, livo2_lidar_result *result);
+
 /* ---- ESIKF solve alone (voxel_map.cpp:468-474 with sign=+1,k=6,meas_cov_scale=1; vio.cpp:1661-1669 with sign=-1,k=7,
  * meas_cov_scale=img_point_cov) — runs the same device kernel the update loops use. ------------------------------ */
 int livo2_esikf_solve(livo2_ctx *ctx, const double *HtH /*k*k*/, const double *Htz /*k*/, int32_t k, double meas_cov_scale, int32_t sign,

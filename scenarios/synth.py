@@ -735,3 +735,35 @@ def retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=20000, L=4, grid_n_height
     return RetrieveChainScenario(base, img, ref_imgs, normal, ninit, ref_patch, offs, np.array(ids, np.int32), np.array(iidx, np.int32), np.array(px_l),
                                  np.array(f_l), np.array(R_l), np.array(t_l), np.array(lvl_l, np.int32), np.array(ie_l), np.array(patch_l, np.float32),
                                  1.02, cfg)
+
+
+# ---- one LiDAR-inertial frame: IMU steps + raw scan registered to a map (reference src/LIVMapper.cpp:342-377) --------------------------------
+@dataclass
+class LioFrameScenario:
+    sc: LidarScenario          # map, extrinsics, prior pose / covariance; sc.xyz = the RAW scan (LiDAR frame, not down-sampled)
+    curvature: np.ndarray      # f32 [n] ms from the scan start, ascending
+    steps: np.ndarray          # [n_steps,8] gyr3 acc3 dt offs_t
+    first_pose: np.ndarray     # [22] IMUpose[0] = set_pose6d(0, acc_s_last, angvel_last, vel, pos, rot)
+    vel: np.ndarray
+    bg: np.ndarray
+    ba: np.ndarray
+    grav: np.ndarray
+    inv_expo: float
+    imu: dict                  # covariances, G_m_s2, mean_acc_norm, flags
+
+
+def lio_frame_scenario(seed=61, n_raw=20000, n_steps=20):
+    """A sensor almost at rest at the LiDAR scenario's prior pose: raw scan with per-point times over 100 ms, IMU steps that measure gravity (+ bias, + noise),
+    so that the propagated state stays within a few mm of the pose the scan was taken from and the update matches most points."""
+    sc = lidar_scenario(seed=seed, n_points=n_raw, downsample=None)
+    rng = np.random.default_rng(seed + 7)
+    imu = dict(cov_gyr=[0.1, 0.1, 0.1], cov_acc=[0.1, 0.12, 0.09], cov_bias_gyr=[1e-4, 1.2e-4, 0.9e-4], cov_bias_acc=[1e-4, 1e-4, 2e-4], cov_inv_expo=0.2,
+               G_m_s2=9.81, mean_acc_norm=9.79, ba_bg_est_en=1, gravity_est_en=1, exposure_estimate_en=1)
+    curv = np.sort(rng.uniform(0.0, 100.0, len(sc.xyz))).astype(np.float32)
+    grav, vel = np.array([0.0, 0.0, -9.81]), np.array([0.02, -0.01, 0.005])
+    bg, ba = np.array([1e-3, -2e-3, 5e-4]), np.array([0.01, -0.02, 0.015])
+    dt = 0.1 / max(n_steps, 1)
+    rest = sc.R_prior.T @ (-grav) * imu["mean_acc_norm"] / imu["G_m_s2"] + ba          # specific force in sensor units + bias (IMU_Processing.cpp:375-379)
+    steps = np.c_[rng.normal(0, 0.01, (n_steps, 3)) + bg, rng.normal(0, 0.02, (n_steps, 3)) + rest, np.full(n_steps, dt), np.arange(1, n_steps + 1) * dt]
+    first = np.concatenate([[0.0], np.zeros(3), np.zeros(3), vel, sc.t_prior, sc.R_prior.ravel()])
+    return LioFrameScenario(sc, curv, steps, first, vel, bg, ba, grav, 0.97, imu)
