@@ -249,199 +249,207 @@ def main():
     extra = {"frames_per_s": frames_per_s, "frames_per_s_two_contexts": frames_per_s_2ctx, "frame_points": n, "frames": int(F_per_rank * world),
              "frame_def": "set_scan (H2D + Morton sort + body cov) + full StateEstimation loop + result read-back"}
     if rank == 0 and not args.no_extra:
-        # full StateEstimation (<=5 iterations with convergence logic), end-to-end incl. result read-back
-        reps = 20
-        ctx.lidar_update_async(cur, prop, cfg); r0 = ctx.lidar_update_fetch()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            ctx.lidar_update_async(cur, prop, cfg); r0 = ctx.lidar_update_fetch()
-        dt = (time.perf_counter() - t1) / reps
-        extra["lidar_full_update_ms"] = dt * 1e3
-        extra["lidar_full_update_iters"] = int(r0.n_iters)
-        extra["lidar_n_eff"] = int(r0.iter_sums[r0.n_iters - 1].n_eff)
-        # visual C3: 2k patches
-        vs = synth.visual_scenario(seed=3, n_patches=2000)
-        vcfg = H.visual_cfg_product(vs)
-        vcur, vprop = make_states(livo2, vs)
-        ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-        ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.warmup or 1); ctx.synchronize()
-        t1 = time.perf_counter()
-        ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.steps); ctx.synchronize()
-        dtv = time.perf_counter() - t1
-        extra["visual_evals_per_s"] = 64.0 * len(vs.pos) * args.steps / dtv
-        extra["visual_patches"] = len(vs.pos)
-        ctx.kernel_timing(True); ctx.kernel_timing_read(1)
-        ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.steps)
-        ms_v, n_v = ctx.kernel_timing_read(1)
-        ctx.kernel_timing(False)
-        v_us = 1e3 * ms_v / max(n_v, 1)
-        extra["visual_kernel_us"] = v_us
-        extra["visual_achieved_GBps"] = VISUAL_BYTES_PER_PATCH * len(vs.pos) / (v_us * 1e-6) / 1e9
-        reps = 20
-        ctx.visual_update_async(vcur, vprop, vcfg); ctx.visual_update_fetch()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            ctx.visual_update_async(vcur, vprop, vcfg); rv = ctx.visual_update_fetch()
-        extra["visual_full_update_ms"] = (time.perf_counter() - t1) / reps * 1e3
-        extra["visual_full_update_steps"] = int(rv.n_steps)
-        # C3 (BASELINE configs[2]): the LiDAR iteration of the 100k-point scan and the visual iteration of the 2k patches in flight together
-        # (two contexts = two streams on this GPU; the two updates of a frame are separate ESIKF updates in the reference, LIVMapper.cpp:370 / vio.cpp:1810)
-        ctx_v = livo2.Context(local_rank)
-        ctx_v.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-        ctx.lidar_iterations_async(cur, prop, cfg, 5); ctx_v.visual_iterations_async(0, vcur, vprop, vcfg, 5); ctx.synchronize(); ctx_v.synchronize()
-        t1 = time.perf_counter()
-        ctx.lidar_iterations_async(cur, prop, cfg, args.steps); ctx_v.visual_iterations_async(0, vcur, vprop, vcfg, args.steps)
-        ctx.synchronize(); ctx_v.synchronize()
-        dtc = time.perf_counter() - t1
-        extra["c3_lidar_plus_visual"] = {"evals_per_s": (n + 64.0 * len(vs.pos)) * args.steps / dtc, "lidar_points": n, "visual_patches": len(vs.pos),
-                                         "ms_per_step": 1e3 * dtc / args.steps, "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
-        ctx_v.close()
-        # One Avia-sized frame through every device stage built so far (C1 sizes: 24 000 raw points / scan, a few hundred patches): the
-        # reference's budget for this is 100 ms per frame on <= 4 host threads
-        sc1 = synth.lidar_scenario(seed=1, n_points=10000, downsample=0.1)
-        raw1 = synth.raw_scan_scenario(seed=1, n_raw=24000)
-        cfg1 = H.lidar_cfg_product(sc1)
-        cur1, prop1 = make_states(livo2, sc1)
-        rs1 = synth.retrieve_scenario(seed=2, n_cand=400)
-        vs1 = synth.visual_scenario(seed=3, n_patches=8); vs1.img, vs1.cam = rs1.img, rs1.cam
-        vcfg1 = H.visual_cfg_product(vs1)
-        vcur1, vprop1 = make_states(livo2, vs1)
-        fpw1, fvar1, foff1 = plane_fit_groups(n_groups=800, seed=5)
-        ctx.upload_map(sc1.fmap)
-        stage = {}
-        for rep in range(6):
-            t = [time.perf_counter()]
-            nd1 = ctx.preprocess_scan(raw1.xyz, raw1.curvature, raw1.poses, raw1.rot_end, raw1.pos_end, raw1.leaf, cfg1, want=False)[0]; t.append(time.perf_counter())
-            ctx.set_scan(sc1.xyz, cfg1)                                   # (the synthetic raw scan is not registered to this map: update the matching scan)
-            t.append(time.perf_counter())
-            ctx.lidar_update(cur1, prop1, cfg1); t.append(time.perf_counter())
-            ctx.plane_fit_batch(fpw1, fvar1, foff1, 0.0025); t.append(time.perf_counter())
-            ctx.retrieve_warp(rs1, want_patches=False); t.append(time.perf_counter())
-            ctx.visual_update(vcur1, vprop1, vcfg1); t.append(time.perf_counter())
-            if rep:
-                for name, a, b in (("preprocess_scan", 0, 1), ("lidar_update", 2, 3), ("plane_fit_800_voxels", 3, 4), ("retrieve_warp_400", 4, 5), ("visual_update", 5, 6)):
-                    stage.setdefault(name, []).append((t[b] - t[a]) * 1e3)
-        extra["avia_frame_stages_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
-        extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
-        extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
-        # The LiDAR-inertial part of a frame as ONE call (livo2_lio_frame: IMU propagation -> undistortion + voxel grid -> StateEstimation) next to the same
-        # three stages called one after the other, on a raw scan that is registered to its map
         try:
-            lf = synth.lio_frame_scenario(seed=61, n_raw=24000, n_steps=20)
-            lcfg = H.lidar_cfg_product(lf.sc)
-            lst = livo2.State.from_pose(lf.sc.R_prior, lf.sc.t_prior, lf.sc.P)
-            lst.inv_expo = lf.inv_expo; lst.vel[:] = lf.vel.tolist(); lst.bg[:] = lf.bg.tolist(); lst.ba[:] = lf.ba.tolist(); lst.grav[:] = lf.grav.tolist()
-            licfg = livo2.ImuCfg()
-            for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
-                getattr(licfg, k)[:] = lf.imu[k]
-            licfg.cov_inv_expo, licfg.G_m_s2, licfg.mean_acc_norm = lf.imu["cov_inv_expo"], lf.imu["G_m_s2"], lf.imu["mean_acc_norm"]
-            licfg.ba_bg_est_en = licfg.gravity_est_en = licfg.exposure_estimate_en = 1
-            ctx.upload_map(lf.sc.fmap)
-            t_seq, t_one = [], []
+            # full StateEstimation (<=5 iterations with convergence logic), end-to-end incl. result read-back
+            reps = 20
+            ctx.lidar_update_async(cur, prop, cfg); r0 = ctx.lidar_update_fetch()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ctx.lidar_update_async(cur, prop, cfg); r0 = ctx.lidar_update_fetch()
+            dt = (time.perf_counter() - t1) / reps
+            extra["lidar_full_update_ms"] = dt * 1e3
+            extra["lidar_full_update_iters"] = int(r0.n_iters)
+            extra["lidar_n_eff"] = int(r0.iter_sums[r0.n_iters - 1].n_eff)
+            # visual C3: 2k patches
+            vs = synth.visual_scenario(seed=3, n_patches=2000)
+            vcfg = H.visual_cfg_product(vs)
+            vcur, vprop = make_states(livo2, vs)
+            ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+            ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.warmup or 1); ctx.synchronize()
+            t1 = time.perf_counter()
+            ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.steps); ctx.synchronize()
+            dtv = time.perf_counter() - t1
+            extra["visual_evals_per_s"] = 64.0 * len(vs.pos) * args.steps / dtv
+            extra["visual_patches"] = len(vs.pos)
+            ctx.kernel_timing(True); ctx.kernel_timing_read(1)
+            ctx.visual_iterations_async(0, vcur, vprop, vcfg, args.steps)
+            ms_v, n_v = ctx.kernel_timing_read(1)
+            ctx.kernel_timing(False)
+            v_us = 1e3 * ms_v / max(n_v, 1)
+            extra["visual_kernel_us"] = v_us
+            extra["visual_achieved_GBps"] = VISUAL_BYTES_PER_PATCH * len(vs.pos) / (v_us * 1e-6) / 1e9
+            reps = 20
+            ctx.visual_update_async(vcur, vprop, vcfg); ctx.visual_update_fetch()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ctx.visual_update_async(vcur, vprop, vcfg); rv = ctx.visual_update_fetch()
+            extra["visual_full_update_ms"] = (time.perf_counter() - t1) / reps * 1e3
+            extra["visual_full_update_steps"] = int(rv.n_steps)
+            # C3 (BASELINE configs[2]): the LiDAR iteration of the 100k-point scan and the visual iteration of the 2k patches in flight together
+            # (two contexts = two streams on this GPU; the two updates of a frame are separate ESIKF updates in the reference, LIVMapper.cpp:370 / vio.cpp:1810)
+            ctx_v = livo2.Context(local_rank)
+            ctx_v.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+            ctx.lidar_iterations_async(cur, prop, cfg, 5); ctx_v.visual_iterations_async(0, vcur, vprop, vcfg, 5); ctx.synchronize(); ctx_v.synchronize()
+            t1 = time.perf_counter()
+            ctx.lidar_iterations_async(cur, prop, cfg, args.steps); ctx_v.visual_iterations_async(0, vcur, vprop, vcfg, args.steps)
+            ctx.synchronize(); ctx_v.synchronize()
+            dtc = time.perf_counter() - t1
+            extra["c3_lidar_plus_visual"] = {"evals_per_s": (n + 64.0 * len(vs.pos)) * args.steps / dtc, "lidar_points": n, "visual_patches": len(vs.pos),
+                                             "ms_per_step": 1e3 * dtc / args.steps, "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
+            ctx_v.close()
+            # One Avia-sized frame through every device stage built so far (C1 sizes: 24 000 raw points / scan, a few hundred patches): the
+            # reference's budget for this is 100 ms per frame on <= 4 host threads
+            sc1 = synth.lidar_scenario(seed=1, n_points=10000, downsample=0.1)
+            raw1 = synth.raw_scan_scenario(seed=1, n_raw=24000)
+            cfg1 = H.lidar_cfg_product(sc1)
+            cur1, prop1 = make_states(livo2, sc1)
+            rs1 = synth.retrieve_scenario(seed=2, n_cand=400)
+            vs1 = synth.visual_scenario(seed=3, n_patches=8); vs1.img, vs1.cam = rs1.img, rs1.cam
+            vcfg1 = H.visual_cfg_product(vs1)
+            vcur1, vprop1 = make_states(livo2, vs1)
+            fpw1, fvar1, foff1 = plane_fit_groups(n_groups=800, seed=5)
+            ctx.upload_map(sc1.fmap)
+            stage = {}
             for rep in range(6):
-                t0 = time.perf_counter()
-                lprop, lposes = ctx.imu_propagate(lst, lf.steps, licfg)
-                ctx.preprocess_scan(lf.sc.xyz, lf.curvature, np.vstack([lf.first_pose, lposes]), np.array(lprop.rot).reshape(3, 3), np.array(lprop.pos), synth.AVIA["filter_size_surf"], lcfg, want=False)
-                lres_seq, _ = ctx.lidar_update(lprop, lprop, lcfg)
-                t1 = time.perf_counter()
-                lres, lnd, _, _ = ctx.lio_frame(lst, lf.steps, licfg, lf.first_pose, lf.sc.xyz, lf.curvature, synth.AVIA["filter_size_surf"], lcfg, want_poses=False)
-                t2 = time.perf_counter()
+                t = [time.perf_counter()]
+                nd1 = ctx.preprocess_scan(raw1.xyz, raw1.curvature, raw1.poses, raw1.rot_end, raw1.pos_end, raw1.leaf, cfg1, want=False)[0]; t.append(time.perf_counter())
+                ctx.set_scan(sc1.xyz, cfg1)                                   # (the synthetic raw scan is not registered to this map: update the matching scan)
+                t.append(time.perf_counter())
+                ctx.lidar_update(cur1, prop1, cfg1); t.append(time.perf_counter())
+                ctx.plane_fit_batch(fpw1, fvar1, foff1, 0.0025); t.append(time.perf_counter())
+                ctx.retrieve_warp(rs1, want_patches=False); t.append(time.perf_counter())
+                ctx.visual_update(vcur1, vprop1, vcfg1); t.append(time.perf_counter())
                 if rep:
-                    t_seq.append((t1 - t0) * 1e3); t_one.append((t2 - t1) * 1e3)
-            extra["lio_frame"] = {"raw_points": len(lf.sc.xyz), "feats_down_size": int(lnd), "imu_steps": len(lf.steps), "iterations": int(lres.n_iters),
-                                  "one_call_ms": float(np.median(t_one)), "three_calls_ms": float(np.median(t_seq)), "same_result": bytes(lres.state) == bytes(lres_seq.state),
-                                  "note": "livo2_lio_frame vs livo2_imu_propagate + livo2_lidar_preprocess_scan + livo2_lidar_update through the Python wrappers, host-synchronous, "
-                                          "incl. H2D of the raw scan and D2H of the result; state_propagat, IMUpose and feats_down_body stay on the device in the one-call form"}
-        except Exception as exc:                                   # informational leg: never take the bench line down with it
-            extra["lio_frame"] = {"error": repr(exc)}
-        ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
-        # IMU forward propagation (20 samples = 100 ms at 200 Hz)
-        from tests import imu_inputs as IMU
-        ist = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P); ist.grav[:] = [0.0, 0.0, -9.81]
-        icfg = livo2.ImuCfg()
-        for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
-            getattr(icfg, k)[:] = IMU.CFG[k]
-        icfg.cov_inv_expo, icfg.G_m_s2, icfg.mean_acc_norm = IMU.CFG["cov_inv_expo"], IMU.CFG["G_m_s2"], IMU.CFG["mean_acc_norm"]
-        icfg.ba_bg_est_en = icfg.gravity_est_en = icfg.exposure_estimate_en = 1
-        isteps = IMU.make_steps(0, n=20)
-        ctx.imu_propagate(ist, isteps, icfg)
-        us = []
-        for _ in range(5):
-            ctx.imu_propagate(ist, isteps, icfg); us.append(ctx.imu_last_kernel_us())
-        extra["imu_propagate"] = {"samples": 20, "kernel_us": float(np.median(us)), "us_per_sample": float(np.median(us)) / 20,
-                                  "note": "k_imu_propagate: one block, sequential over the samples (19x19 F P F^T + Q per sample); latency-bound, on par with a host core "
-                                          "(cpu_baseline.imu_propagate_us_20_samples) — built so that state_propagat / IMUpose can be produced next to their consumers"}
-        # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
-        raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
-        ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)
-        us, t1 = [], time.perf_counter()
-        for _ in range(5):
-            nd, _, _ = ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False); us.append(ctx.preprocess_last_kernel_us())
-        t_e2e = (time.perf_counter() - t1) / 5
-        k_us = float(np.median(us))
-        extra["preprocess_scan"] = {"raw_points": len(raw.xyz), "feats_down_size": nd, "imu_poses": len(raw.poses), "kernel_us": k_us,
-                                    "points_per_s_kernel": len(raw.xyz) / (k_us * 1e-6), "achieved_GBps": 44.0 * len(raw.xyz) / (k_us * 1e-6) / 1e9,
-                                    "points_per_s_with_h2d_and_scan_setup": len(raw.xyz) / t_e2e,
-                                    "note": "k_undistort + voxel grid (min/max, keys, rocPRIM radix sort, heads, scan, centroids); 44 B/point = xyz+time read, xyz written, "
-                                            "xyz re-read, centroid share; the event span covers ~20 small launches (rocprofv3: ~115 us of kernel time at 240k points, the rest is enqueue gaps); "
-                                            "CPU figure in cpu_baseline.preprocess_points_per_s_1thread"}
-        ctx.set_scan(sc.xyz, cfg)
-        # selection half of retrieveFromVisualSparseMap (scan voxels + depth image, nearest visual point per grid cell, depth continuity)
-        ss = synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
-        ctx.visual_map_upload(ss.pos, ss.keys, ss.active)
-        ctx.visual_select(ss)
-        us, t1 = [], time.perf_counter()
-        for _ in range(5):
-            so = ctx.visual_select(ss); us.append(ctx.select_last_kernel_us())
-        t_e2e = (time.perf_counter() - t1) / 5
-        k_us = float(np.median(us))
-        extra["visual_select"] = {"scan_points": len(ss.pg), "visual_map_points": len(ss.pos), "cells_selected": int((so["cell_point"] >= 0).sum()), "kernel_us": k_us,
-                                  "visual_points_per_s_kernel": len(ss.pos) / (k_us * 1e-6), "calls_per_s_with_h2d_d2h": 1.0 / t_e2e,
-                                  "note": "memsets + k_sel_scan + k_sel_points + k_sel_cells (vio.cpp:385-486, 598-635) with the visual map resident; CPU figure in cpu_baseline.select_seconds_1thread"}
-        # per-point tail of retrieveFromVisualSparseMap (warp matrix, search level, warpAffine x L, getImagePatch, gates, compaction)
-        rs = synth.retrieve_scenario(seed=21, n_cand=2000)
-        ctx.retrieve_warp(rs, want_patches=False)
-        us, t1 = [], time.perf_counter()
-        for _ in range(5):
-            ro = ctx.retrieve_warp(rs, want_patches=False); us.append(ctx.retrieve_last_kernel_us())
-        t_e2e = (time.perf_counter() - t1) / 5
-        k_us = float(np.median(us))
-        Lr = int(rs.cfg["patch_pyrimid_level"])
-        bytes_per_cand = 200.0 + 81.0 * (Lr + 1) + 256.0 * Lr        # descriptors + (L reference windows + current window, u8) + warped patches written
-        extra["retrieve_warp"] = {"candidates": len(rs.pos), "accepted": ro["n_accepted"], "levels": Lr, "kernel_us": k_us,
-                                  "candidates_per_s_kernel": len(rs.pos) / (k_us * 1e-6), "bytes_per_candidate": bytes_per_cand,
-                                  "achieved_GBps": bytes_per_cand * len(rs.pos) / (k_us * 1e-6) / 1e9, "candidates_per_s_with_h2d_d2h": len(rs.pos) / t_e2e,
-                                  "note": "k_warp_candidates + k_warp_scan + k_warp_gather (vio.cpp:698-767); CPU figure in cpu_baseline.retrieve_candidates_per_s_1thread"}
-        # the whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail), map + observations resident
-        cs = synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)     # grid_size 5 as in config/avia.yaml
-        ctx.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)
-        ctx.visual_obs_upload(cs)
-        ctx.visual_retrieve_from_map(cs, want_patches=False)
-        us, t1 = [], time.perf_counter()
-        for _ in range(5):
-            ctx.visual_obs_upload(cs)                      # resets ref_patch: every call makes the first-time choices again
-            co = ctx.visual_retrieve_from_map(cs, want_patches=False); us.append(ctx.retrieve_from_map_last_kernel_us())
-        t_e2e = (time.perf_counter() - t1) / 5
-        k_us = float(np.median(us))
-        extra["retrieve_from_map"] = {"scan_points": len(cs.sel.pg), "visual_map_points": len(cs.sel.pos), "observations": int(cs.obs_offset[-1]),
-                                      "grid_cells": int(cs.sel.grid_n_width * cs.sel.grid_n_height), "candidates": co["n_candidates"], "accepted": co["n_accepted"],
-                                      "kernel_us": k_us, "calls_per_s_with_obs_upload_h2d_d2h": 1.0 / t_e2e,
-                                      "note": "selection + k_choose_ref + scan + k_gather_candidates + tail in one chain of launches (vio.cpp:352-780), no host round trip; "
-                                              "CPU figure in cpu_baseline.retrieve_from_map_seconds_1thread"}
-        # batched init_plane (plane fit + plane covariance) on the device
-        fpw, fvar, foff = plane_fit_groups()
-        ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)
-        us = []
-        t1 = time.perf_counter()
-        for _ in range(5):
-            fo = ctx.plane_fit_batch(fpw, fvar, foff, 0.0025); us.append(ctx.plane_fit_last_kernel_us())
-        t_e2e = (time.perf_counter() - t1) / 5
-        k_us = float(np.median(us))
-        extra["plane_fit"] = {"groups": len(foff) - 1, "points": len(fpw), "planes": int(sum(o.is_plane for o in fo)), "kernel_us": k_us,
-                              "points_per_s_kernel": len(fpw) / (k_us * 1e-6), "achieved_GBps": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9,
-                              "frac_of_hbm_peak": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              "points_per_s_with_h2d_d2h": len(fpw) / t_e2e,
-                              "note": "k_plane_fit: 8 lanes per voxel group (64 for groups > 64 points); VoxelOctoTree::init_plane (voxel_map.cpp:55-135); CPU figure in cpu_baseline.plane_fit_points_per_s_1thread"}
+                    for name, a, b in (("preprocess_scan", 0, 1), ("lidar_update", 2, 3), ("plane_fit_800_voxels", 3, 4), ("retrieve_warp_400", 4, 5), ("visual_update", 5, 6)):
+                        stage.setdefault(name, []).append((t[b] - t[a]) * 1e3)
+            extra["avia_frame_stages_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
+            extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
+            extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
+            # The LiDAR-inertial part of a frame as ONE call (livo2_lio_frame: IMU propagation -> undistortion + voxel grid -> StateEstimation) next to the same
+            # three stages called one after the other, on a raw scan that is registered to its map
+            try:
+                lf = synth.lio_frame_scenario(seed=61, n_raw=24000, n_steps=20)
+                lcfg = H.lidar_cfg_product(lf.sc)
+                lst = livo2.State.from_pose(lf.sc.R_prior, lf.sc.t_prior, lf.sc.P)
+                lst.inv_expo = lf.inv_expo; lst.vel[:] = lf.vel.tolist(); lst.bg[:] = lf.bg.tolist(); lst.ba[:] = lf.ba.tolist(); lst.grav[:] = lf.grav.tolist()
+                licfg = livo2.ImuCfg()
+                for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+                    getattr(licfg, k)[:] = lf.imu[k]
+                licfg.cov_inv_expo, licfg.G_m_s2, licfg.mean_acc_norm = lf.imu["cov_inv_expo"], lf.imu["G_m_s2"], lf.imu["mean_acc_norm"]
+                licfg.ba_bg_est_en = licfg.gravity_est_en = licfg.exposure_estimate_en = 1
+                ctx.upload_map(lf.sc.fmap)
+                t_seq, t_one = [], []
+                for rep in range(6):
+                    t0 = time.perf_counter()
+                    lprop, lposes = ctx.imu_propagate(lst, lf.steps, licfg)
+                    ctx.preprocess_scan(lf.sc.xyz, lf.curvature, np.vstack([lf.first_pose, lposes]), np.array(lprop.rot).reshape(3, 3), np.array(lprop.pos), synth.AVIA["filter_size_surf"], lcfg, want=False)
+                    lres_seq, _ = ctx.lidar_update(lprop, lprop, lcfg)
+                    t1 = time.perf_counter()
+                    lres, lnd, _, _ = ctx.lio_frame(lst, lf.steps, licfg, lf.first_pose, lf.sc.xyz, lf.curvature, synth.AVIA["filter_size_surf"], lcfg, want_poses=False)
+                    t2 = time.perf_counter()
+                    if rep:
+                        t_seq.append((t1 - t0) * 1e3); t_one.append((t2 - t1) * 1e3)
+                extra["lio_frame"] = {"raw_points": len(lf.sc.xyz), "feats_down_size": int(lnd), "imu_steps": len(lf.steps), "iterations": int(lres.n_iters),
+                                      "one_call_ms": float(np.median(t_one)), "three_calls_ms": float(np.median(t_seq)), "same_result": bytes(lres.state) == bytes(lres_seq.state),
+                                      "note": "livo2_lio_frame vs livo2_imu_propagate + livo2_lidar_preprocess_scan + livo2_lidar_update through the Python wrappers, host-synchronous, "
+                                              "incl. H2D of the raw scan and D2H of the result; state_propagat, IMUpose and feats_down_body stay on the device in the one-call form"}
+            except Exception as exc:                                   # informational leg: never take the bench line down with it
+                extra["lio_frame"] = {"error": repr(exc)}
+            ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
+            # IMU forward propagation (20 samples = 100 ms at 200 Hz)
+            from tests import imu_inputs as IMU
+            ist = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P); ist.grav[:] = [0.0, 0.0, -9.81]
+            icfg = livo2.ImuCfg()
+            for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+                getattr(icfg, k)[:] = IMU.CFG[k]
+            icfg.cov_inv_expo, icfg.G_m_s2, icfg.mean_acc_norm = IMU.CFG["cov_inv_expo"], IMU.CFG["G_m_s2"], IMU.CFG["mean_acc_norm"]
+            icfg.ba_bg_est_en = icfg.gravity_est_en = icfg.exposure_estimate_en = 1
+            isteps = IMU.make_steps(0, n=20)
+            ctx.imu_propagate(ist, isteps, icfg)
+            us = []
+            for _ in range(5):
+                ctx.imu_propagate(ist, isteps, icfg); us.append(ctx.imu_last_kernel_us())
+            extra["imu_propagate"] = {"samples": 20, "kernel_us": float(np.median(us)), "us_per_sample": float(np.median(us)) / 20,
+                                      "note": "k_imu_propagate: one block, sequential over the samples (19x19 F P F^T + Q per sample); latency-bound, on par with a host core "
+                                              "(cpu_baseline.imu_propagate_us_20_samples) — built so that state_propagat / IMUpose can be produced next to their consumers"}
+            # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
+            raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
+            ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)
+            us, t1 = [], time.perf_counter()
+            for _ in range(5):
+                nd, _, _ = ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False); us.append(ctx.preprocess_last_kernel_us())
+            t_e2e = (time.perf_counter() - t1) / 5
+            k_us = float(np.median(us))
+            extra["preprocess_scan"] = {"raw_points": len(raw.xyz), "feats_down_size": nd, "imu_poses": len(raw.poses), "kernel_us": k_us,
+                                        "points_per_s_kernel": len(raw.xyz) / (k_us * 1e-6), "achieved_GBps": 44.0 * len(raw.xyz) / (k_us * 1e-6) / 1e9,
+                                        "points_per_s_with_h2d_and_scan_setup": len(raw.xyz) / t_e2e,
+                                        "note": "k_undistort + voxel grid (min/max, keys, rocPRIM radix sort, heads, scan, centroids); 44 B/point = xyz+time read, xyz written, "
+                                                "xyz re-read, centroid share; the event span covers ~20 small launches (rocprofv3: ~115 us of kernel time at 240k points, the rest is enqueue gaps); "
+                                                "CPU figure in cpu_baseline.preprocess_points_per_s_1thread"}
+            ctx.set_scan(sc.xyz, cfg)
+            # selection half of retrieveFromVisualSparseMap (scan voxels + depth image, nearest visual point per grid cell, depth continuity)
+            ss = synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
+            ctx.visual_map_upload(ss.pos, ss.keys, ss.active)
+            ctx.visual_select(ss)
+            us, t1 = [], time.perf_counter()
+            for _ in range(5):
+                so = ctx.visual_select(ss); us.append(ctx.select_last_kernel_us())
+            t_e2e = (time.perf_counter() - t1) / 5
+            k_us = float(np.median(us))
+            extra["visual_select"] = {"scan_points": len(ss.pg), "visual_map_points": len(ss.pos), "cells_selected": int((so["cell_point"] >= 0).sum()), "kernel_us": k_us,
+                                      "visual_points_per_s_kernel": len(ss.pos) / (k_us * 1e-6), "calls_per_s_with_h2d_d2h": 1.0 / t_e2e,
+                                      "note": "memsets + k_sel_scan + k_sel_points + k_sel_cells (vio.cpp:385-486, 598-635) with the visual map resident; CPU figure in cpu_baseline.select_seconds_1thread"}
+            # per-point tail of retrieveFromVisualSparseMap (warp matrix, search level, warpAffine x L, getImagePatch, gates, compaction)
+            rs = synth.retrieve_scenario(seed=21, n_cand=2000)
+            ctx.retrieve_warp(rs, want_patches=False)
+            us, t1 = [], time.perf_counter()
+            for _ in range(5):
+                ro = ctx.retrieve_warp(rs, want_patches=False); us.append(ctx.retrieve_last_kernel_us())
+            t_e2e = (time.perf_counter() - t1) / 5
+            k_us = float(np.median(us))
+            Lr = int(rs.cfg["patch_pyrimid_level"])
+            bytes_per_cand = 200.0 + 81.0 * (Lr + 1) + 256.0 * Lr        # descriptors + (L reference windows + current window, u8) + warped patches written
+            extra["retrieve_warp"] = {"candidates": len(rs.pos), "accepted": ro["n_accepted"], "levels": Lr, "kernel_us": k_us,
+                                      "candidates_per_s_kernel": len(rs.pos) / (k_us * 1e-6), "bytes_per_candidate": bytes_per_cand,
+                                      "achieved_GBps": bytes_per_cand * len(rs.pos) / (k_us * 1e-6) / 1e9, "candidates_per_s_with_h2d_d2h": len(rs.pos) / t_e2e,
+                                      "note": "k_warp_candidates + k_warp_scan + k_warp_gather (vio.cpp:698-767); CPU figure in cpu_baseline.retrieve_candidates_per_s_1thread"}
+            # the whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail), map + observations resident
+            cs = synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)     # grid_size 5 as in config/avia.yaml
+            ctx.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)
+            ctx.visual_obs_upload(cs)
+            ctx.visual_retrieve_from_map(cs, want_patches=False)
+            us, t1 = [], time.perf_counter()
+            for _ in range(5):
+                ctx.visual_obs_upload(cs)                      # resets ref_patch: every call makes the first-time choices again
+                co = ctx.visual_retrieve_from_map(cs, want_patches=False); us.append(ctx.retrieve_from_map_last_kernel_us())
+            t_e2e = (time.perf_counter() - t1) / 5
+            k_us = float(np.median(us))
+            extra["retrieve_from_map"] = {"scan_points": len(cs.sel.pg), "visual_map_points": len(cs.sel.pos), "observations": int(cs.obs_offset[-1]),
+                                          "grid_cells": int(cs.sel.grid_n_width * cs.sel.grid_n_height), "candidates": co["n_candidates"], "accepted": co["n_accepted"],
+                                          "kernel_us": k_us, "calls_per_s_with_obs_upload_h2d_d2h": 1.0 / t_e2e,
+                                          "note": "selection + k_choose_ref + scan + k_gather_candidates + tail in one chain of launches (vio.cpp:352-780), no host round trip; "
+                                                  "CPU figure in cpu_baseline.retrieve_from_map_seconds_1thread"}
+            # batched init_plane (plane fit + plane covariance) on the device
+            fpw, fvar, foff = plane_fit_groups()
+            ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)
+            us = []
+            t1 = time.perf_counter()
+            for _ in range(5):
+                fo = ctx.plane_fit_batch(fpw, fvar, foff, 0.0025); us.append(ctx.plane_fit_last_kernel_us())
+            t_e2e = (time.perf_counter() - t1) / 5
+            k_us = float(np.median(us))
+            extra["plane_fit"] = {"groups": len(foff) - 1, "points": len(fpw), "planes": int(sum(o.is_plane for o in fo)), "kernel_us": k_us,
+                                  "points_per_s_kernel": len(fpw) / (k_us * 1e-6), "achieved_GBps": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9,
+                                  "frac_of_hbm_peak": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  "points_per_s_with_h2d_d2h": len(fpw) / t_e2e,
+                                  "note": "k_plane_fit: 8 lanes per voxel group (64 for groups > 64 points); VoxelOctoTree::init_plane (voxel_map.cpp:55-135); CPU figure in cpu_baseline.plane_fit_points_per_s_1thread"}
+        except Exception as exc:                                   # informational legs must never take the bench line down with them
+            extra["error"] = repr(exc)
+            try:
+                ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)  # the batched leg below expects the C2 map and scan resident
+            except Exception:
+                pass
+
 
     # ---- batched frames (BASELINE configs[4] shape, extra only): B scans of the C2 size against the resident map, one residual grid +
     # one solve block per frame per ESIKF iteration.  Frames differ (own 97 % subset of the scan, own prior perturbation). ----
