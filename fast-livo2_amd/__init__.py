@@ -36,6 +36,7 @@ class Context:
         if rc != abi.OK:
             raise Livo2Error(rc, "livo2_ctx_create failed (no gfx950 device / HIP runtime?)")
         self.h = h
+        self.device = int(device)
         self._keep = {}
         self.n = 0
         self.M = 0

@@ -24,6 +24,7 @@
 namespace {
 
 struct HostIn { livo2_state cur, prop; DevHeader hdr; };      // pinned mirror of the head of DevCtl
+#define IN_RING 16
 
 struct EvPair { hipEvent_t a, b; };
 
@@ -37,7 +38,10 @@ struct livo2_ctx {
   bool own_stream = false;
   std::string err;
   DevCtl *d_ctl = nullptr;
-  HostIn *h_in = nullptr;                   // pinned
+  HostIn *h_in = nullptr;                   // pinned ring of IN_RING staging blocks: an update's H2D never waits for the previous update
+  hipEvent_t in_ev[16] = {};                // recorded behind the H2D that reads slot k
+  bool in_used[16] = {};
+  int in_next = 0;
   void *h_out = nullptr;                    // pinned, sizeof(livo2_visual_result) (largest result)
   // map
   bool has_map = false;
@@ -116,7 +120,7 @@ struct livo2_ctx {
   // timing
   hipEvent_t span0 = nullptr, span1 = nullptr;   // bracket the kernels of one synchronous call (the *_last_kernel_us queries)
   bool timing = false;
-  TimingBin bins[3];
+  TimingBin bins[4];
   std::vector<EvPair> ev_pool;
 };
 
@@ -146,7 +150,7 @@ struct Timed {                 // RAII-free helper: brackets one launch with an 
   livo2_ctx *ctx; int bin; EvPair ev{}; bool on = false;
   Timed(livo2_ctx *c, int b) : ctx(c), bin(b) {
     if (!c->timing) return;
-    if (c->bins[b].used.size() >= 8192) return;
+    if (c->bins[b].used.size() >= 65536) return;
     if (c->ev_pool.empty()) { if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return; }
     else { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
     on = true;
@@ -217,16 +221,22 @@ int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
 }
 
 int upload_states(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *prop, const double *extR = nullptr) {
-  // the pinned staging block is reused by every call: the previous H2D must have been consumed
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->h_in->cur = *cur; ctx->h_in->prop = *prop;
-  std::memset(&ctx->h_in->hdr, 0, sizeof(DevHeader));
-  ctx->h_in->hdr.last_error = FLT_MAX;
+  // pinned staging ring: slot k is rewritten only after the H2D that read it last has completed (an event per slot), so a caller that
+  // enqueues update after update (livo2_*_update_async) never blocks here until IN_RING updates are in flight
+  const int k = ctx->in_next;
+  ctx->in_next = (k + 1) % IN_RING;
+  if (ctx->in_used[k]) HIPCHK(hipEventSynchronize(ctx->in_ev[k]));
+  HostIn *h = ctx->h_in + k;
+  h->cur = *cur; h->prop = *prop;
+  std::memset(&h->hdr, 0, sizeof(DevHeader));
+  h->hdr.last_error = FLT_MAX;
   if (extR) {            // state_propagat.rot_end * extR_ (voxel_map.cpp:445) is constant during one update
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
-      ctx->h_in->hdr.RE[i * 3 + j] = (prop->rot[i * 3] * extR[j] + prop->rot[i * 3 + 1] * extR[3 + j]) + prop->rot[i * 3 + 2] * extR[6 + j];
+      h->hdr.RE[i * 3 + j] = (prop->rot[i * 3] * extR[j] + prop->rot[i * 3 + 1] * extR[3 + j]) + prop->rot[i * 3 + 2] * extR[6 + j];
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_ctl, ctx->h_in, sizeof(HostIn), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_ctl, h, sizeof(HostIn), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->in_ev[k], ctx->stream));
+  ctx->in_used[k] = true;
   return LIVO2_OK;
 }
 
@@ -366,9 +376,10 @@ static int ctx_create_impl(int device, void *stream, bool external, livo2_ctx **
   ctx->device = device;
   if (external) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LIVO2_ERR_HIP; } ctx->own_stream = true; }
-  if (hipMalloc((void **)&ctx->d_ctl, sizeof(DevCtl)) != hipSuccess || hipHostMalloc((void **)&ctx->h_in, sizeof(HostIn)) != hipSuccess ||
+  if (hipMalloc((void **)&ctx->d_ctl, sizeof(DevCtl)) != hipSuccess || hipHostMalloc((void **)&ctx->h_in, sizeof(HostIn) * IN_RING) != hipSuccess ||
       hipHostMalloc(&ctx->h_out, sizeof(DevCtl)) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   if (hipEventCreate(&ctx->span0) != hipSuccess || hipEventCreate(&ctx->span1) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
+  for (int k = 0; k < IN_RING; k++) if (hipEventCreateWithFlags(&ctx->in_ev[k], hipEventDisableTiming) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   if (hipMemsetAsync(ctx->d_ctl, 0, sizeof(DevCtl), ctx->stream) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   *out = ctx;
   return LIVO2_OK;
@@ -401,6 +412,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (ctx->bh_entries) e = hipHostFree(ctx->bh_entries);
   for (auto &b : ctx->bins) for (auto &ev : b.used) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
+  for (int k = 0; k < IN_RING; k++) if (ctx->in_ev[k]) e = hipEventDestroy(ctx->in_ev[k]);
   if (ctx->span0) e = hipEventDestroy(ctx->span0);
   if (ctx->span1) e = hipEventDestroy(ctx->span1);
   if (ctx->own_stream && ctx->stream) e = hipStreamDestroy(ctx->stream);
@@ -414,7 +426,7 @@ int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; 
 
 int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable) { if (!ctx) return LIVO2_ERR_INVALID; ctx->timing = enable != 0; return LIVO2_OK; }
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset) {
-  if (!ctx || which < 0 || which > 2) return LIVO2_ERR_INVALID;
+  if (!ctx || which < 0 || which > 3) return LIVO2_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   TimingBin &b = ctx->bins[which];
   for (auto &ev : b.used) { float ms = 0; if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { b.total_ms += ms; b.launches++; } ctx->ev_pool.push_back(ev); }
@@ -1643,7 +1655,7 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   } else {
     Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
   }
-  { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov); t.done(); }
+  { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_v, sizeof(livo2_visual_sums), hipMemcpyDeviceToHost, ctx->stream));
   if (errors && M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1675,7 +1687,7 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
         else hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0);
         t.done();
       }
-      { Timed t(ctx, 2); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
+      { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
     }
   }
   hipLaunchKernelGGL(k_visual_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, a, mode == 1 ? 1 : 0);

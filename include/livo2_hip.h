@@ -69,7 +69,7 @@ const char *livo2_version(void);
 int32_t livo2_abi_sizeof(const char *struct_name);
 
 /* Per-kernel timing with HIP events on the ctx stream (off by default; adds an event pair per launch).
- * which: 0 = LiDAR residual kernel, 1 = visual residual kernel, 2 = ESIKF solve kernels. */
+ * which: 0 = LiDAR residual kernel, 1 = visual residual kernel, 2 = LiDAR solve kernel (and livo2_esikf_solve), 3 = visual solve kernel. */
 int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
 

@@ -54,6 +54,9 @@ struct Exporter {
 
 extern "C" {
 
+// summation-order model of the long reductions (orc_math.hpp): 0 = strict left-to-right (parity checker), 1 = Eigen-like (sensitivity study only)
+void orc_set_sum_model(int mode, int kc, int lanes) { orc::sum_model().mode = mode; orc::sum_model().kc = kc > 0 ? kc : 256; orc::sum_model().lanes = (lanes == 2 || lanes == 4 || lanes == 8) ? lanes : 4; }
+
 struct orc_lidar_cfg {
   int max_iterations; int max_layer;
   double sigma_num, dept_err, beam_err, voxel_size, deg2rad;

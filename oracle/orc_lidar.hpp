@@ -261,15 +261,10 @@ public:
       for (int k = 0; k < 6; k++) { Hsub[(size_t)i * 6 + k] = h[k]; Hsub_T_R_inv[(size_t)k * n + i] = h[k] * R_inv[i]; }
       meas_vec[i] = -ptpl.dis_to_plane_;
     }
+    // HTz = Hsub_T_R_inv * meas_vec (:464, a column-major GEMV in Eigen), H_T_H = Hsub_T_R_inv * Hsub (:466, a GEMM); order of additions: orc_math.hpp
     for (int a = 0; a < 6; a++) {
-      double s = 0.0;
-      for (int i = 0; i < n; i++) s += Hsub_T_R_inv[(size_t)a * n + i] * meas_vec[i];
-      HTz6[a] = s;
-      for (int b = 0; b < 6; b++) {
-        double t = 0.0;
-        for (int i = 0; i < n; i++) t += Hsub_T_R_inv[(size_t)a * n + i] * Hsub[(size_t)i * 6 + b];
-        HtH6[a * 6 + b] = t;
-      }
+      HTz6[a] = long_dot_gemv_colmajor(&Hsub_T_R_inv[(size_t)a * n], 1, meas_vec.data(), 1, (size_t)n);
+      for (int b = 0; b < 6; b++) HtH6[a * 6 + b] = long_dot_gemm(&Hsub_T_R_inv[(size_t)a * n], 1, &Hsub[b], 6, (size_t)n);
     }
     dump_Rinv_ = R_inv; dump_H_ = Hsub;
   }

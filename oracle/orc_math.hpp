@@ -27,6 +27,46 @@ template <int R, int C> struct Mat {
 typedef Mat<3, 1> V3;
 typedef Mat<3, 3> M3;
 
+// ---- summation-order model of the two long reductions of the path (voxel_map.cpp:464-466, vio.cpp:1660-1662) -------------------------
+// The reference evaluates them with Eigen (GEMM / GEMV), whose order of additions depends on the Eigen version, the SIMD width and the
+// cache-derived blocking of the build.  Mode 0 (the parity checker): strict left-to-right, one rounding per operation.  Mode 1
+// ("Eigen-like", tools/oracle_sensitivity.py only): GEMM = the depth is cut into panels of `kc` (Eigen's gebp blocking), a panel is a
+// sequential FMA chain, panels are added in order; column-major GEMV = one sequential FMA chain; row-major GEMV = `lanes` interleaved
+// FMA chains (a SIMD packet) reduced pairwise, the tail added sequentially.  Used to bound how far the reference's OWN build can move
+// the answer (profiles/r02_oracle_sensitivity.txt); never by the parity tests.
+struct SumModel { int mode = 0, kc = 256, lanes = 4; };
+inline SumModel &sum_model() { static SumModel m; return m; }
+inline double long_dot_gemm(const double *a, size_t sa, const double *b, size_t sb, size_t n) {
+  const SumModel &m = sum_model();
+  double s = 0.0;
+  if (m.mode == 0) { for (size_t i = 0; i < n; i++) s += a[i * sa] * b[i * sb]; return s; }
+  for (size_t p0 = 0; p0 < n; p0 += (size_t)m.kc) {
+    const size_t p1 = p0 + (size_t)m.kc < n ? p0 + (size_t)m.kc : n;
+    double p = 0.0;
+    for (size_t i = p0; i < p1; i++) p = std::fma(a[i * sa], b[i * sb], p);
+    s = s + p;
+  }
+  return s;
+}
+inline double long_dot_gemv_colmajor(const double *a, size_t sa, const double *b, size_t sb, size_t n) {
+  double s = 0.0;
+  if (sum_model().mode == 0) { for (size_t i = 0; i < n; i++) s += a[i * sa] * b[i * sb]; return s; }
+  for (size_t i = 0; i < n; i++) s = std::fma(a[i * sa], b[i * sb], s);
+  return s;
+}
+inline double long_dot_gemv_rowmajor(const double *a, size_t sa, const double *b, size_t sb, size_t n) {
+  const SumModel &m = sum_model();
+  double s = 0.0;
+  if (m.mode == 0) { for (size_t i = 0; i < n; i++) s += a[i * sa] * b[i * sb]; return s; }
+  double lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t L = (size_t)m.lanes, nb = n / L * L;
+  for (size_t i = 0; i < nb; i += L) for (size_t l = 0; l < L; l++) lane[l] = std::fma(a[(i + l) * sa], b[(i + l) * sb], lane[l]);
+  for (size_t w = L / 2; w >= 1; w /= 2) for (size_t l = 0; l < w; l++) lane[l] = lane[l] + lane[l + w];     // predux: (p0+p2)+(p1+p3) for 4 lanes
+  s = lane[0];
+  for (size_t i = nb; i < n; i++) s = std::fma(a[i * sa], b[i * sb], s);
+  return s;
+}
+
 template <int R, int K, int C> inline Mat<R, C> operator*(const Mat<R, K> &A, const Mat<K, C> &B) {
   Mat<R, C> o;
   for (int i = 0; i < R; i++)

@@ -205,10 +205,9 @@ public:
         H_T_H = MState::Zero();
         G = MState::Zero();
         double HtH7[49], HTz[7];
-        for (int a = 0; a < 7; a++) {
-          double s = 0.0; for (int r = 0; r < H_DIM; r++) s += H_sub[(size_t)r * 7 + a] * z[r];
-          HTz[a] = s;
-          for (int b = 0; b < 7; b++) { double t = 0.0; for (int r = 0; r < H_DIM; r++) t += H_sub[(size_t)r * 7 + a] * H_sub[(size_t)r * 7 + b]; HtH7[a * 7 + b] = t; H_T_H(a, b) = t; }
+        for (int a = 0; a < 7; a++) {                       // H_sub^T z: row-major GEMV in Eigen (:1662); H_sub^T H_sub: GEMM (:1660); order of additions: orc_math.hpp
+          HTz[a] = long_dot_gemv_rowmajor(&H_sub[a], 7, z.data(), 1, (size_t)H_DIM);
+          for (int b = 0; b < 7; b++) { const double t = long_dot_gemm(&H_sub[a], 7, &H_sub[b], 7, (size_t)H_DIM); HtH7[a * 7 + b] = t; H_T_H(a, b) = t; }
         }
         MState Pinv, K_1;
         inverse_lu<ORC_DIM_STATE>(state->cov / img_point_cov, Pinv);
@@ -352,9 +351,8 @@ public:
         G = MState::Zero();
         double HtH6[36], HTz[6];
         for (int a = 0; a < 6; a++) {
-          double s = 0.0; for (int r = 0; r < H_DIM; r++) s += H_sub[(size_t)r * 6 + a] * z[r];
-          HTz[a] = s;
-          for (int b = 0; b < 6; b++) { double t = 0.0; for (int r = 0; r < H_DIM; r++) t += H_sub[(size_t)r * 6 + a] * H_sub[(size_t)r * 6 + b]; HtH6[a * 6 + b] = t; H_T_H(a, b) = t; }
+          HTz[a] = long_dot_gemv_rowmajor(&H_sub[a], 6, z.data(), 1, (size_t)H_DIM);
+          for (int b = 0; b < 6; b++) { const double t = long_dot_gemm(&H_sub[a], 6, &H_sub[b], 6, (size_t)H_DIM); HtH6[a * 6 + b] = t; H_T_H(a, b) = t; }
         }
         MState Pinv, K_1;
         inverse_lu<ORC_DIM_STATE>(state->cov / img_point_cov, Pinv);

@@ -330,7 +330,7 @@ def prior_cov(rng):
 
 
 def lidar_scenario(seed=1, n_points=10000, room=(20.0, 20.0, 6.0), n_boxes=8, full_sphere=False, map_rays_factor=12, downsample=None,
-                   rot_sigma_deg=0.5, pos_sigma=0.03, cfg=None, extR=None, extT=None):
+                   rot_sigma_deg=0.5, pos_sigma=0.03, cfg=None, extR=None, extT=None, test_rays=None, thin="head"):
     """C1/C2-style scenario: map from a dense first sweep at the true pose, test scan with fresh noise, perturbed prior.
     extR / extT: LiDAR->IMU extrinsics (default: avia.yaml's identity rotation; HILTI22.yaml has a non-identity one, quirk Q6)."""
     rng = np.random.default_rng(seed)
@@ -353,10 +353,12 @@ def lidar_scenario(seed=1, n_points=10000, room=(20.0, 20.0, 6.0), n_boxes=8, fu
     fmap = build_voxel_map(pw, var, c["voxel_size"], c["max_layer"], c["layer_init_num"], c["min_eigen_value"])
     # test scan
     over = 1.6 if downsample else 1.25
-    xyz = lidar_scan(rng, scene, R_true, t_true, extR, extT, int(n_points * over) + 64, c["dept_err"], c["beam_err"], AVIA["blind"], full_sphere)
+    xyz = lidar_scan(rng, scene, R_true, t_true, extR, extT, int(test_rays) if test_rays else int(n_points * over) + 64, c["dept_err"], c["beam_err"], AVIA["blind"], full_sphere)
     if downsample:
         xyz = voxel_grid_downsample(xyz, downsample)
-    xyz = xyz[:n_points] if len(xyz) >= n_points else xyz
+    if len(xyz) > n_points:
+        # "head": the first n_points (of a voxel-grid cloud: the low leaf indices); "random": an order-preserving random subset of exactly n_points
+        xyz = xyz[:n_points] if thin == "head" else xyz[np.sort(np.random.default_rng(seed + 7919).permutation(len(xyz))[:n_points])]
     dth = rng.normal(0, np.deg2rad(rot_sigma_deg), 3)
     dp = rng.normal(0, pos_sigma, 3)
     R_prior = R_true @ so3_exp(dth)

@@ -1,0 +1,340 @@
+"""Informational legs of bench.py: the widened rows of SURVEY 8(f) (N1-N4) measured one by one.  Not part of the headline; every function
+returns a dict that bench.py files under `extra`."""
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+PLANE_FIT_BYTES_PER_POINT = 96.0
+
+
+def plane_fit_groups(n_groups=20000, seed=4):
+    """voxel point groups of the size UpdateVoxelMap re-fits (6..60 points, update_size_threshold_ 5 .. max_points_num_ 50)"""
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(6, 61, n_groups)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    N = int(off[-1])
+    gid = np.repeat(np.arange(n_groups), cnt)
+    Q = np.linalg.qr(rng.normal(size=(n_groups, 3, 3)))[0]
+    ext = np.where((np.arange(n_groups) % 5 == 4)[:, None], [0.12, 0.11, 0.1], [0.15, 0.12, 0.01])       # 80 % planar patches, 20 % blobs
+    local = rng.normal(size=(N, 3)) * ext[gid]
+    pw = (np.einsum("nij,nj->ni", Q[gid], local) + rng.uniform(-40, 40, (n_groups, 3))[gid]).astype(np.float32).astype(np.float64)
+    A = rng.normal(size=(N, 3, 3))
+    var = 1e-4 * (A @ A.transpose(0, 2, 1) + 0.1 * np.eye(3))
+    return pw, var.reshape(N, 9), off
+
+
+
+def make_states(livo2, sc):
+    cur = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P, inv_expo=getattr(sc, "tau_prior", 1.0))
+    return cur, cur.copy()
+
+
+LIDAR_BYTES_PER_EVAL = 276.0
+VISUAL_BYTES_PER_PATCH = 413.0
+
+
+def _timed_iters(ctx, fn, steps, bins):
+    """run fn(steps) once untimed-by-events for wall clock, once with events; returns (wall seconds, [us per launch of each bin])"""
+    fn(max(steps // 10, 1)); ctx.synchronize()
+    t0 = time.perf_counter(); fn(steps); ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.kernel_timing(True)
+    for b in bins:
+        ctx.kernel_timing_read(b)
+    fn(steps)
+    us = []
+    for b in bins:
+        ms, n = ctx.kernel_timing_read(b)
+        us.append(1e3 * ms / max(n, 1))
+    ctx.kernel_timing(False)
+    return dt, us
+
+
+def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
+    """Legs around the headline: the C4 frame one ESIKF iteration at a time, C2 (round-1 headline, BASELINE configs[1]), C3 (configs[2]), frames batched per
+    launch (configs[4] shape on one GPU), whole frames per second including the PCIe legs.  `w` is bench.C4 (resident on ctx); the C4 map / scan are
+    NOT resident any more on return (widened_rows re-uploads what it needs)."""
+    extra = {}
+    steps = 100
+    cur, vcur = w.lid[0], w.vis[0]
+    # C4 frame, fixed iteration counts (no convergence stop): cost of ONE iteration of each update
+    dt, (res_us, sol_us) = _timed_iters(ctx, lambda k: ctx.lidar_iterations_async(cur, cur, w.cfg, k), steps, (0, 2))
+    dtv, (vres_us, vsol_us) = _timed_iters(ctx, lambda k: ctx.visual_iterations_async(0, vcur, vcur, w.vcfg, k), steps, (1, 3))
+    extra["c4_single_iteration"] = {
+        "lidar": {"points": w.N, "evals_per_s": w.N * steps / dt, "us_per_iteration": 1e6 * dt / steps, "residual_kernel_us": res_us, "solve_kernel_us": sol_us,
+                  "achieved_GBps": LIDAR_BYTES_PER_EVAL * w.N / (res_us * 1e-6) / 1e9, "frac": LIDAR_BYTES_PER_EVAL * w.N / (res_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+        "visual_level0": {"patches": w.M, "evals_per_s": 64.0 * w.M * steps / dtv, "us_per_iteration": 1e6 * dtv / steps, "residual_kernel_us": vres_us, "solve_kernel_us": vsol_us,
+                          "achieved_GBps": VISUAL_BYTES_PER_PATCH * w.M / (vres_us * 1e-6) / 1e9, "frac": VISUAL_BYTES_PER_PATCH * w.M / (vres_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+        "note": "fixed iteration count, no convergence stop (livo2_*_iterations_async): every launch executes"}
+    # whole frames per second with the PCIe legs: scan + image + sub-map H2D (pageable caller memory), Morton sort / body covariance, both updates, per-point outputs
+    # (pv_list_ / ptpl_list_ members of SURVEY 8b) D2H, results D2H.  The map stays resident (map maintenance is its own leg).
+    want = ("match_plane", "dis_to_plane", "point_w", "normal_plane", "var", "body_cov")
+    def live_frame(f):
+        ctx.set_scan(w.sc.xyz, w.cfg)
+        r, pts = ctx.lidar_update(w.lid[f], w.lid[f], w.cfg, want=want)
+        ctx.set_frame(w.vs.img, w.vs.pos, w.vs.warp_patch, w.vs.search_levels, w.vs.inv_expo_list)
+        v, err = ctx.visual_update(w.vis[f], w.vis[f], w.vcfg)
+        return r, v
+    live_frame(0)
+    t0 = time.perf_counter()
+    for f in range(w.F):
+        live_frame(f)
+    dtl = time.perf_counter() - t0
+    bytes_frame = w.N * 12 + w.vs.img.size + w.M * (24 + 4 + 8 + 256 * w.vs.warp_patch.shape[1]) + w.N * (4 + 4 + 12 + 4 + 72 + 72) + w.M * 4
+    extra["frames_per_s_live"] = {"value": w.F / dtl, "ms_per_frame": 1e3 * dtl / w.F, "pcie_bytes_per_frame": int(bytes_frame),
+                                  "def": "set_scan (H2D + Morton sort + body cov) + full LiDAR update + per-point outputs (match, residual, point_w, normal, var, body_cov: 168 B/point) D2H + "
+                                         "set_frame (image + sub-map H2D) + full visual update + errors D2H, host-synchronous Python calls, pageable host memory; map resident"}
+
+    # ---- C2 (BASELINE configs[1], the round-1 headline): 100k-ray scan -> 0.1 m voxel grid, ONE ESIKF iteration per step ------------------------------
+    sc2 = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12, downsample=synth.AVIA["filter_size_surf"])
+    cfg2 = H.lidar_cfg_product(sc2)
+    cur2, _ = make_states(livo2, sc2)
+    n2 = len(sc2.xyz)
+    ctx.upload_map(sc2.fmap); ctx.set_scan(sc2.xyz, cfg2)
+    steps = 200
+    dt, (res_us, sol_us) = _timed_iters(ctx, lambda k: ctx.lidar_iterations_async(cur2, cur2, cfg2, k), steps, (0, 2))
+    ach = LIDAR_BYTES_PER_EVAL * n2 / (res_us * 1e-6) / 1e9
+    extra["c2_lidar_single_iteration"] = {"points": n2, "evals_per_s": n2 * steps / dt, "us_per_iteration": 1e6 * dt / steps, "residual_kernel_us": res_us, "solve_kernel_us": sol_us,
+                                          "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBS, "frac_of_copy_kernel": ach / copy_gbs,
+                                          "note": "round-1 headline workload (100k rays -> 0.1 m voxel grid), one ESIKF iteration per step"}
+    # C3 (configs[2]): C2 LiDAR iteration + 2k-patch visual iteration in flight together on two streams of this GPU
+    vs3 = synth.visual_scenario(seed=3, n_patches=2000)
+    vcfg3 = H.visual_cfg_product(vs3)
+    vcur3, _ = make_states(livo2, vs3)
+    ctx_v = livo2.Context(ctx.device)
+    ctx_v.set_frame(vs3.img, vs3.pos, vs3.warp_patch, vs3.search_levels, vs3.inv_expo_list)
+    ctx.lidar_iterations_async(cur2, cur2, cfg2, 5); ctx_v.visual_iterations_async(0, vcur3, vcur3, vcfg3, 5); ctx.synchronize(); ctx_v.synchronize()
+    t1 = time.perf_counter()
+    ctx.lidar_iterations_async(cur2, cur2, cfg2, steps); ctx_v.visual_iterations_async(0, vcur3, vcur3, vcfg3, steps)
+    ctx.synchronize(); ctx_v.synchronize()
+    dtc = time.perf_counter() - t1
+    extra["c3_lidar_plus_visual"] = {"evals_per_s": (n2 + 64.0 * len(vs3.pos)) * steps / dtc, "lidar_points": n2, "visual_patches": len(vs3.pos), "ms_per_step": 1e3 * dtc / steps,
+                                     "note": "one LiDAR ESIKF iteration and one visual iteration (level 0) per step on two streams"}
+    ctx_v.close()
+    # frames batched per launch (configs[4] shape on one GPU): B scans of the C2 size against the resident map, one residual grid + one solve block per frame per iteration
+    if args.batch > 0:
+        B = args.batch
+        rngb = np.random.default_rng(100)
+        scans, bst = [], []
+        for f in range(B):
+            keep = np.sort(rngb.permutation(n2)[: int(0.97 * n2)])
+            scans.append(sc2.xyz[keep])
+            Rf = sc2.R_prior @ synth.so3_exp(rngb.normal(0, np.deg2rad(0.2), 3))
+            bst.append(livo2.State.from_pose(Rf, sc2.t_prior + rngb.normal(0, 0.02, 3), sc2.P))
+        ctx.batch_set_scans(scans, cfg2)
+        npts = int(sum(len(x) for x in scans))
+        steps = 50
+        tb, (bres_us, bsol_us) = _timed_iters(ctx, lambda k: ctx.batch_iterations_async(bst, bst, cfg2, k), steps, (0, 2))
+        ctx.batch_set_scans(scans, cfg2); ctx.batch_update_async(bst, bst, cfg2); ctx.batch_update_fetch()
+        reps_b = 4
+        tb1 = time.perf_counter()
+        for _ in range(reps_b):
+            ctx.batch_set_scans(scans, cfg2); ctx.batch_update_async(bst, bst, cfg2); rb = ctx.batch_update_fetch()
+        tfb = time.perf_counter() - tb1
+        bach = LIDAR_BYTES_PER_EVAL * npts / (bres_us * 1e-6) / 1e9
+        traffic_b, note_b = _load_traffic("r02_traffic_batched.json", points=npts)
+        extra["batched"] = {"frames_per_launch": B, "points_per_launch": npts, "evals_per_s": npts * steps / tb, "ms_per_step": 1e3 * tb / steps,
+                            "residual_kernel_us": bres_us, "solve_kernel_us": bsol_us,
+                            "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS, "frac_of_copy_kernel": bach / copy_gbs,
+                                         "kernel": "k_lidar_residual_batch", "bytes_per_launch": LIDAR_BYTES_PER_EVAL * npts, "traffic": traffic_b, "traffic_note": note_b},
+                            "frames_per_s": B * reps_b / tfb, "full_update_iters": [int(r.n_iters) for r in rb],
+                            "note": "same device code as the single-scan path with 64-point blocks, B independent (scan, state) problems per grid; the frames share ONE map snapshot, so most "
+                                    "plane-record reads are cache hits (see extra.out_of_cache for the leg whose working set exceeds the 256 MiB Infinity Cache)"}
+    return extra
+
+
+def _load_traffic(name, **match):
+    import json
+    import os
+    try:
+        rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)))
+        if all(rec.get(k) == v for k, v in match.items()):
+            return (rec["fetch_size_kb_reported"] * rec["fetch_correction"] + rec["write_size_kb"]) * 1024.0, rec["source"]
+    except Exception:
+        pass
+    return None, "no PMC pass recorded for this workload; see profiles/"
+
+
+def cpu_widened_rows(lib):
+    """oracle timings of the widened rows on one host core (the figures the widened_rows notes refer to)"""
+    from oracle import orc
+    from scenarios import synth as _synth
+    from tests import imu_inputs as IMU
+    pw, var, off = plane_fit_groups()
+    orc.init_plane_batch(pw, var, off, 0.0025, lib)
+    _, fit_s = orc.init_plane_batch(pw, var, off, 0.0025, lib)
+    rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
+    orc.warp_candidates(rs, lib)
+    warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
+    ist = IMU.make_state(orc, orc.StatePOD, 0)
+    orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)
+    imu_us = 1e6 * min(orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)[2] for _ in range(5))
+    ss = _synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
+    orc.visual_select(ss, lib)
+    sel_s = min(orc.visual_select(ss, lib)["seconds"] for _ in range(3))
+    cs = _synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)
+    tch = []
+    for _ in range(3):
+        t0 = time.perf_counter(); orc.visual_retrieve(cs, lib); tch.append(time.perf_counter() - t0)
+    raw = _synth.raw_scan_scenario(seed=51, n_raw=240000)
+    tpre = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
+        orc.voxel_grid(u_, raw.leaf, lib)
+        tpre.append(time.perf_counter() - t0)
+    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
+            "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s}
+
+
+def widened_rows(ctx, livo2, synth, H, sc, cfg):
+    """N1-N4 legs; leaves the map and scan of `sc` resident again on return."""
+    extra = {}
+    # One Avia-sized frame through every device stage built so far (C1 sizes: 24 000 raw points / scan, a few hundred patches): the
+    # reference's budget for this is 100 ms per frame on <= 4 host threads
+    sc1 = synth.lidar_scenario(seed=1, n_points=10000, downsample=0.1)
+    raw1 = synth.raw_scan_scenario(seed=1, n_raw=24000)
+    cfg1 = H.lidar_cfg_product(sc1)
+    cur1, prop1 = make_states(livo2, sc1)
+    rs1 = synth.retrieve_scenario(seed=2, n_cand=400)
+    vs1 = synth.visual_scenario(seed=3, n_patches=8); vs1.img, vs1.cam = rs1.img, rs1.cam
+    vcfg1 = H.visual_cfg_product(vs1)
+    vcur1, vprop1 = make_states(livo2, vs1)
+    fpw1, fvar1, foff1 = plane_fit_groups(n_groups=800, seed=5)
+    ctx.upload_map(sc1.fmap)
+    stage = {}
+    for rep in range(6):
+        t = [time.perf_counter()]
+        nd1 = ctx.preprocess_scan(raw1.xyz, raw1.curvature, raw1.poses, raw1.rot_end, raw1.pos_end, raw1.leaf, cfg1, want=False)[0]; t.append(time.perf_counter())
+        ctx.set_scan(sc1.xyz, cfg1)                                   # (the synthetic raw scan is not registered to this map: update the matching scan)
+        t.append(time.perf_counter())
+        ctx.lidar_update(cur1, prop1, cfg1); t.append(time.perf_counter())
+        ctx.plane_fit_batch(fpw1, fvar1, foff1, 0.0025); t.append(time.perf_counter())
+        ctx.retrieve_warp(rs1, want_patches=False); t.append(time.perf_counter())
+        ctx.visual_update(vcur1, vprop1, vcfg1); t.append(time.perf_counter())
+        if rep:
+            for name, a, b in (("preprocess_scan", 0, 1), ("lidar_update", 2, 3), ("plane_fit_800_voxels", 3, 4), ("retrieve_warp_400", 4, 5), ("visual_update", 5, 6)):
+                stage.setdefault(name, []).append((t[b] - t[a]) * 1e3)
+    extra["avia_frame_stages_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
+    extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
+    extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
+    # The LiDAR-inertial part of a frame as ONE call (livo2_lio_frame: IMU propagation -> undistortion + voxel grid -> StateEstimation) next to the same
+    # three stages called one after the other, on a raw scan that is registered to its map
+    try:
+        lf = synth.lio_frame_scenario(seed=61, n_raw=24000, n_steps=20)
+        lcfg = H.lidar_cfg_product(lf.sc)
+        lst = livo2.State.from_pose(lf.sc.R_prior, lf.sc.t_prior, lf.sc.P)
+        lst.inv_expo = lf.inv_expo; lst.vel[:] = lf.vel.tolist(); lst.bg[:] = lf.bg.tolist(); lst.ba[:] = lf.ba.tolist(); lst.grav[:] = lf.grav.tolist()
+        licfg = livo2.ImuCfg()
+        for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+            getattr(licfg, k)[:] = lf.imu[k]
+        licfg.cov_inv_expo, licfg.G_m_s2, licfg.mean_acc_norm = lf.imu["cov_inv_expo"], lf.imu["G_m_s2"], lf.imu["mean_acc_norm"]
+        licfg.ba_bg_est_en = licfg.gravity_est_en = licfg.exposure_estimate_en = 1
+        ctx.upload_map(lf.sc.fmap)
+        t_seq, t_one = [], []
+        for rep in range(6):
+            t0 = time.perf_counter()
+            lprop, lposes = ctx.imu_propagate(lst, lf.steps, licfg)
+            ctx.preprocess_scan(lf.sc.xyz, lf.curvature, np.vstack([lf.first_pose, lposes]), np.array(lprop.rot).reshape(3, 3), np.array(lprop.pos), synth.AVIA["filter_size_surf"], lcfg, want=False)
+            lres_seq, _ = ctx.lidar_update(lprop, lprop, lcfg)
+            t1 = time.perf_counter()
+            lres, lnd, _, _ = ctx.lio_frame(lst, lf.steps, licfg, lf.first_pose, lf.sc.xyz, lf.curvature, synth.AVIA["filter_size_surf"], lcfg, want_poses=False)
+            t2 = time.perf_counter()
+            if rep:
+                t_seq.append((t1 - t0) * 1e3); t_one.append((t2 - t1) * 1e3)
+        extra["lio_frame"] = {"raw_points": len(lf.sc.xyz), "feats_down_size": int(lnd), "imu_steps": len(lf.steps), "iterations": int(lres.n_iters),
+                              "one_call_ms": float(np.median(t_one)), "three_calls_ms": float(np.median(t_seq)), "same_result": bytes(lres.state) == bytes(lres_seq.state),
+                              "note": "livo2_lio_frame vs livo2_imu_propagate + livo2_lidar_preprocess_scan + livo2_lidar_update through the Python wrappers, host-synchronous, "
+                                      "incl. H2D of the raw scan and D2H of the result; state_propagat, IMUpose and feats_down_body stay on the device in the one-call form"}
+    except Exception as exc:                                   # informational leg: never take the bench line down with it
+        extra["lio_frame"] = {"error": repr(exc)}
+    ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
+    # IMU forward propagation (20 samples = 100 ms at 200 Hz)
+    from tests import imu_inputs as IMU
+    ist = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P); ist.grav[:] = [0.0, 0.0, -9.81]
+    icfg = livo2.ImuCfg()
+    for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+        getattr(icfg, k)[:] = IMU.CFG[k]
+    icfg.cov_inv_expo, icfg.G_m_s2, icfg.mean_acc_norm = IMU.CFG["cov_inv_expo"], IMU.CFG["G_m_s2"], IMU.CFG["mean_acc_norm"]
+    icfg.ba_bg_est_en = icfg.gravity_est_en = icfg.exposure_estimate_en = 1
+    isteps = IMU.make_steps(0, n=20)
+    ctx.imu_propagate(ist, isteps, icfg)
+    us = []
+    for _ in range(5):
+        ctx.imu_propagate(ist, isteps, icfg); us.append(ctx.imu_last_kernel_us())
+    extra["imu_propagate"] = {"samples": 20, "kernel_us": float(np.median(us)), "us_per_sample": float(np.median(us)) / 20,
+                              "note": "k_imu_propagate: one block, sequential over the samples (19x19 F P F^T + Q per sample); latency-bound, on par with a host core "
+                                      "(cpu_baseline.imu_propagate_us_20_samples) — built so that state_propagat / IMUpose can be produced next to their consumers"}
+    # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
+    raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
+    ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)
+    us, t1 = [], time.perf_counter()
+    for _ in range(5):
+        nd, _, _ = ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False); us.append(ctx.preprocess_last_kernel_us())
+    t_e2e = (time.perf_counter() - t1) / 5
+    k_us = float(np.median(us))
+    extra["preprocess_scan"] = {"raw_points": len(raw.xyz), "feats_down_size": nd, "imu_poses": len(raw.poses), "kernel_us": k_us,
+                                "points_per_s_kernel": len(raw.xyz) / (k_us * 1e-6), "achieved_GBps": 44.0 * len(raw.xyz) / (k_us * 1e-6) / 1e9,
+                                "points_per_s_with_h2d_and_scan_setup": len(raw.xyz) / t_e2e,
+                                "note": "k_undistort + voxel grid (min/max, keys, rocPRIM radix sort, heads, scan, centroids); 44 B/point = xyz+time read, xyz written, "
+                                        "xyz re-read, centroid share; the event span covers ~20 small launches (rocprofv3: ~115 us of kernel time at 240k points, the rest is enqueue gaps); "
+                                        "CPU figure in cpu_baseline.preprocess_points_per_s_1thread"}
+    ctx.set_scan(sc.xyz, cfg)
+    # selection half of retrieveFromVisualSparseMap (scan voxels + depth image, nearest visual point per grid cell, depth continuity)
+    ss = synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
+    ctx.visual_map_upload(ss.pos, ss.keys, ss.active)
+    ctx.visual_select(ss)
+    us, t1 = [], time.perf_counter()
+    for _ in range(5):
+        so = ctx.visual_select(ss); us.append(ctx.select_last_kernel_us())
+    t_e2e = (time.perf_counter() - t1) / 5
+    k_us = float(np.median(us))
+    extra["visual_select"] = {"scan_points": len(ss.pg), "visual_map_points": len(ss.pos), "cells_selected": int((so["cell_point"] >= 0).sum()), "kernel_us": k_us,
+                              "visual_points_per_s_kernel": len(ss.pos) / (k_us * 1e-6), "calls_per_s_with_h2d_d2h": 1.0 / t_e2e,
+                              "note": "memsets + k_sel_scan + k_sel_points + k_sel_cells (vio.cpp:385-486, 598-635) with the visual map resident; CPU figure in cpu_baseline.select_seconds_1thread"}
+    # per-point tail of retrieveFromVisualSparseMap (warp matrix, search level, warpAffine x L, getImagePatch, gates, compaction)
+    rs = synth.retrieve_scenario(seed=21, n_cand=2000)
+    ctx.retrieve_warp(rs, want_patches=False)
+    us, t1 = [], time.perf_counter()
+    for _ in range(5):
+        ro = ctx.retrieve_warp(rs, want_patches=False); us.append(ctx.retrieve_last_kernel_us())
+    t_e2e = (time.perf_counter() - t1) / 5
+    k_us = float(np.median(us))
+    Lr = int(rs.cfg["patch_pyrimid_level"])
+    bytes_per_cand = 200.0 + 81.0 * (Lr + 1) + 256.0 * Lr        # descriptors + (L reference windows + current window, u8) + warped patches written
+    extra["retrieve_warp"] = {"candidates": len(rs.pos), "accepted": ro["n_accepted"], "levels": Lr, "kernel_us": k_us,
+                              "candidates_per_s_kernel": len(rs.pos) / (k_us * 1e-6), "bytes_per_candidate": bytes_per_cand,
+                              "achieved_GBps": bytes_per_cand * len(rs.pos) / (k_us * 1e-6) / 1e9, "candidates_per_s_with_h2d_d2h": len(rs.pos) / t_e2e,
+                              "note": "k_warp_candidates + k_warp_scan + k_warp_gather (vio.cpp:698-767); CPU figure in cpu_baseline.retrieve_candidates_per_s_1thread"}
+    # the whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail), map + observations resident
+    cs = synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)     # grid_size 5 as in config/avia.yaml
+    ctx.visual_map_upload(cs.sel.pos, cs.sel.keys, cs.sel.active)
+    ctx.visual_obs_upload(cs)
+    ctx.visual_retrieve_from_map(cs, want_patches=False)
+    us, t1 = [], time.perf_counter()
+    for _ in range(5):
+        ctx.visual_obs_upload(cs)                      # resets ref_patch: every call makes the first-time choices again
+        co = ctx.visual_retrieve_from_map(cs, want_patches=False); us.append(ctx.retrieve_from_map_last_kernel_us())
+    t_e2e = (time.perf_counter() - t1) / 5
+    k_us = float(np.median(us))
+    extra["retrieve_from_map"] = {"scan_points": len(cs.sel.pg), "visual_map_points": len(cs.sel.pos), "observations": int(cs.obs_offset[-1]),
+                                  "grid_cells": int(cs.sel.grid_n_width * cs.sel.grid_n_height), "candidates": co["n_candidates"], "accepted": co["n_accepted"],
+                                  "kernel_us": k_us, "calls_per_s_with_obs_upload_h2d_d2h": 1.0 / t_e2e,
+                                  "note": "selection + k_choose_ref + scan + k_gather_candidates + tail in one chain of launches (vio.cpp:352-780), no host round trip; "
+                                          "CPU figure in cpu_baseline.retrieve_from_map_seconds_1thread"}
+    # batched init_plane (plane fit + plane covariance) on the device
+    fpw, fvar, foff = plane_fit_groups()
+    ctx.plane_fit_batch(fpw, fvar, foff, 0.0025)
+    us = []
+    t1 = time.perf_counter()
+    for _ in range(5):
+        fo = ctx.plane_fit_batch(fpw, fvar, foff, 0.0025); us.append(ctx.plane_fit_last_kernel_us())
+    t_e2e = (time.perf_counter() - t1) / 5
+    k_us = float(np.median(us))
+    extra["plane_fit"] = {"groups": len(foff) - 1, "points": len(fpw), "planes": int(sum(o.is_plane for o in fo)), "kernel_us": k_us,
+                          "points_per_s_kernel": len(fpw) / (k_us * 1e-6), "achieved_GBps": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9,
+                          "frac_of_hbm_peak": PLANE_FIT_BYTES_PER_POINT * len(fpw) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "points_per_s_with_h2d_d2h": len(fpw) / t_e2e,
+                          "note": "k_plane_fit: 8 lanes per voxel group (64 for groups > 64 points); VoxelOctoTree::init_plane (voxel_map.cpp:55-135); CPU figure in cpu_baseline.plane_fit_points_per_s_1thread"}
+    return extra
