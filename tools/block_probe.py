@@ -17,10 +17,15 @@ from tests import helpers as H  # noqa: E402
 livo2 = importlib.import_module("fast-livo2_amd")
 abi = livo2.abi
 base = abi.LIB_PATH
-sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12, downsample=synth.AVIA["filter_size_surf"])
+args = [a for a in sys.argv[1:] if a != "c4"]
+if "c4" in sys.argv[1:]:                      # the bench's C4 frame (200 000 post-filter points)
+    import bench
+    sc = bench.c4_frame(4, 200000, 4000)[0]
+else:
+    sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12, downsample=synth.AVIA["filter_size_surf"])
 small = synth.lidar_scenario(seed=1, n_points=24000, downsample=0.1)
 ref_state = None
-for suffix in (sys.argv[1:] or ["", "b128", "b64"]):
+for suffix in (args or ["", "b128", "b64"]):
     path = base if not suffix else base.replace(".so", "_" + suffix + ".so")
     if not os.path.exists(path):
         print(suffix, "missing", path); continue

@@ -19,18 +19,22 @@ def main():
     from scenarios import synth
     from tests import helpers as H
     import bench
-    sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12,
-                              downsample=(0.1 if order == "voxelgrid" else None))
+    from tools import bench_legs
+    if order == "c4":
+        sc = bench.c4_frame(4, 200000, 4000)[0]
+    else:
+        sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12,
+                                  downsample=(0.1 if order == "voxelgrid" else None))
     ctx = livo2.Context(0)
     cfg = H.lidar_cfg_product(sc)
     ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
-    cur, prop = bench.make_states(livo2, sc)
+    cur, prop = bench_legs.make_states(livo2, sc)
     ctx.lidar_iterations_async(cur, prop, cfg, 10); ctx.synchronize()
     ctx.lidar_iterations_async(cur, prop, cfg, 5); ctx.synchronize()
     fn = ctx.lib.livo2_debug_phase_prof
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
-    W = 1 << 16
+    W = 1 << 17
     buf = np.zeros((W, 8), np.uint64)
     nw = C.c_size_t()
     assert fn(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), W, C.byref(nw)) == 0
