@@ -158,7 +158,7 @@ class C4:
 
     def __init__(self, ctx, livo2, synth, H, sc, vs, F, seed):
         self.ctx, self.sc, self.vs, self.F = ctx, sc, vs, F
-        self.cfg, self.vcfg = H.lidar_cfg_product(sc), H.visual_cfg_product(vs)
+        self.cfg, self.vcfg = H.lidar_cfg_product(sc), H.visual_cfg_product(vs, mp_proc_num=4)      # MP_PROC_NUM = 4: the reference build on any host with > 4 cores
         ctx.upload_map(sc.fmap)
         ctx.set_scan(sc.xyz, self.cfg)
         ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
@@ -242,7 +242,39 @@ def cpu_baseline(sc, vs, budget_s=20.0):
                       f"computeJacobianAndUpdateEKF window (vio.cpp:1808-1812), OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "lidar_evals_per_s": o4["lidar"], "visual_evals_per_s": o4["visual"], "lidar_update_ms": o4["lidar_ms"], "visual_update_ms": o4["visual_ms"],
             "value_1thread": out[1]["value"], "lidar_evals_per_s_1thread": out[1]["lidar"], "visual_evals_per_s_1thread": out[1]["visual"],
-            "value_all_cores": out[ncores]["value"], "host_cores": ncores}, lib
+            "value_all_cores": out[ncores]["value"], "host_cores": ncores}, (orc, lib)
+
+
+def cpu_widened_rows(orc, lib):
+    """oracle timings of the widened rows on one host core (the figures the widened_rows notes refer to)"""
+    from scenarios import synth as _synth
+    from tests import imu_inputs as IMU
+    from tools.bench_legs import plane_fit_groups
+    pw, var, off = plane_fit_groups()
+    orc.init_plane_batch(pw, var, off, 0.0025, lib)
+    _, fit_s = orc.init_plane_batch(pw, var, off, 0.0025, lib)
+    rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
+    orc.warp_candidates(rs, lib)
+    warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
+    ist = IMU.make_state(orc, orc.StatePOD, 0)
+    orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)
+    imu_us = 1e6 * min(orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)[2] for _ in range(5))
+    ss = _synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
+    orc.visual_select(ss, lib)
+    sel_s = min(orc.visual_select(ss, lib)["seconds"] for _ in range(3))
+    cs = _synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)
+    tch = []
+    for _ in range(3):
+        t0 = time.perf_counter(); orc.visual_retrieve(cs, lib); tch.append(time.perf_counter() - t0)
+    raw = _synth.raw_scan_scenario(seed=51, n_raw=240000)
+    tpre = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
+        orc.voxel_grid(u_, raw.leaf, lib)
+        tpre.append(time.perf_counter() - t0)
+    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
+            "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s}
 
 
 def main():
@@ -345,9 +377,9 @@ def main():
                 extra["widened_rows_error"] = repr(exc)
         if not args.no_cpu:
             try:
-                cpu, lib = cpu_baseline(sc, vs)
+                cpu, (orc_mod, lib) = cpu_baseline(sc, vs)
                 if not args.no_extra:
-                    cpu.update(legs.cpu_widened_rows(lib))
+                    cpu.update(cpu_widened_rows(orc_mod, lib))
             except Exception as exc:
                 extra["cpu_baseline_error"] = repr(exc)
 

@@ -404,6 +404,37 @@ class Context:
         self._chk(self.lib.livo2_visual_update_fetch(self.h, C.byref(res), None))
         return res
 
+    # ---- batch of frames, visual -----------------------------------------------------------------------------------
+    def visual_batch_set_frames(self, frames):
+        """frames: list of (img [h][w] u8, pos [M][3], warp_patch [M][L][64], search_levels [M], inv_expo_list [M]); all images of one size, one L."""
+        imgs = np.ascontiguousarray(np.stack([np.asarray(f[0], np.uint8) for f in frames]))
+        h, w = imgs.shape[1:]
+        counts = np.array([len(f[1]) for f in frames], np.int32)
+        L = max([np.asarray(f[2]).reshape(len(f[1]), -1, 64).shape[1] for f in frames if len(f[1])] or [1])
+        pos = _f64(np.concatenate([np.asarray(f[1], np.float64).reshape(-1, 3) for f in frames]))
+        warp = np.ascontiguousarray(np.concatenate([np.asarray(f[2], np.float32).reshape(len(f[1]), L, 64) for f in frames]), np.float32)
+        sl = np.ascontiguousarray(np.concatenate([np.asarray(f[3], np.int32).reshape(-1) for f in frames]), np.int32)
+        ie = _f64(np.concatenate([np.asarray(f[4], np.float64).reshape(-1) for f in frames]))
+        self._chk(self.lib.livo2_visual_batch_set_frames(self.h, len(frames), abi.as_ptr(imgs, C.c_uint8), w, h, w, abi.as_ptr(pos, C.c_double), abi.as_ptr(warp, C.c_float),
+                                                         abi.as_ptr(sl, C.c_int32), abi.as_ptr(ie, C.c_double), abi.as_ptr(counts, C.c_int32), L))
+        self.vbatch_n = len(frames)
+
+    def visual_batch_update(self, states_in, props, cfg):
+        res = (VisualResult * self.vbatch_n)()
+        self._chk(self.lib.livo2_visual_batch_update(self.h, self.vbatch_n, self._state_array(states_in), self._state_array(props), C.byref(cfg), res))
+        return list(res)
+
+    def visual_batch_update_async(self, states_in, props, cfg):
+        self._chk(self.lib.livo2_visual_batch_update_async(self.h, self.vbatch_n, self._state_array(states_in), self._state_array(props), C.byref(cfg)))
+
+    def visual_batch_update_fetch(self):
+        res = (VisualResult * self.vbatch_n)()
+        self._chk(self.lib.livo2_visual_batch_update_fetch(self.h, self.vbatch_n, res))
+        return list(res)
+
+    def visual_batch_iterations_async(self, level, states_in, props, cfg, iters):
+        self._chk(self.lib.livo2_visual_batch_iterations_async(self.h, self.vbatch_n, int(level), self._state_array(states_in), self._state_array(props), C.byref(cfg), int(iters)))
+
     def visual_iterations_async(self, level, state_in, prop, cfg, iters):
         self._chk(self.lib.livo2_visual_iterations_async(self.h, int(level), C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
 

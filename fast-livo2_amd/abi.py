@@ -158,7 +158,7 @@ class SelectCfg(C.Structure):
 class VisualCfg(C.Structure):
     _fields_ = [("cam", Cam), ("Rcl", C.c_double * 9), ("Pcl", C.c_double * 3), ("extR", C.c_double * 9), ("extT", C.c_double * 3),
                 ("img_point_cov", C.c_double), ("patch_pyrimid_level", C.c_int32), ("max_iterations", C.c_int32),
-                ("exposure_estimate_en", C.c_int32), ("inverse_composition_en", C.c_int32)]
+                ("exposure_estimate_en", C.c_int32), ("inverse_composition_en", C.c_int32), ("mp_proc_num", C.c_int32), ("pad", C.c_int32)]
 
 
 class VisualSums(C.Structure):
@@ -229,6 +229,12 @@ SIGNATURES = {
     "livo2_visual_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg)]),
     "livo2_visual_update_fetch": (C.c_int, [_CTX, _P(VisualResult), _P(C.c_float)]),
     "livo2_visual_iterations_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg), C.c_int32]),
+    "livo2_visual_batch_set_frames": (C.c_int, [_CTX, C.c_int32, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32), _P(C.c_double),
+                                                _P(C.c_int32), C.c_int32]),
+    "livo2_visual_batch_update": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg), _P(VisualResult)]),
+    "livo2_visual_batch_update_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg)]),
+    "livo2_visual_batch_update_fetch": (C.c_int, [_CTX, C.c_int32, _P(VisualResult)]),
+    "livo2_visual_batch_iterations_async": (C.c_int, [_CTX, C.c_int32, C.c_int32, _P(State), _P(State), _P(VisualCfg), C.c_int32]),
     "livo2_esikf_solve": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), C.c_int32, C.c_double, C.c_int32, _P(State), _P(State), _P(State),
                                     _P(C.c_double), _P(C.c_double)]),
 }

@@ -10,7 +10,7 @@
 // so one k x k Gauss-Jordan replaces both 19x19 LU inversions.  Algebraically identical; measured agreement with the
 // double-inversion form on the test scenes is ~1e-15 relative (tests/test_solve_gpu.py), far inside the 1e-5 contract.
 // The whole 19-dim algebra stays on the device so the <=5-iteration loop never returns to the host.
-// Launch geometry: ONE wave (64 threads); LDS hand-offs are ordered by __syncthreads() on a 1-wave block.
+// Launch geometry: ONE wave (64 threads) of whatever block calls it; LDS hand-offs inside the wave are ordered by wave_sync(), never by a workgroup barrier.
 #pragma once
 #include "livo2_device.hpp"
 
@@ -66,7 +66,7 @@ __device__ inline void esikf_log_lane(const DevCtl *ctl, SolveLds &s) {
 //   x = K_1[r, 0:k]; G[r, :], the Kalman solution entry and the state update follow without further LDS round trips.
 //   (The LDS Gauss-Jordan this replaces cost 2.5 us of barriers and dependent LDS latency on the critical wave.)
 template <int k>
-__device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sign, const int lane) {
+__device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane) {
   if (lane < k * k) {                                        // S = I + H_k P'_kk, row-major stride k
     const int i = lane / k, j = lane % k;
     double v = (i == j) ? 1.0 : 0.0;
@@ -75,7 +75,7 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sig
     s.aug[lane] = v;
   }
   if (lane >= 9 && lane < 25) s.vec[lane - 6] = s.prop[lane] - s.cur[lane];     // pos, inv_expo, vel, bg, ba, grav parts of vec
-  __syncthreads();
+  wave_sync();
   const int r = lane < DS ? lane : DS - 1;
   double A[k][k], b[k];
 #pragma unroll
@@ -114,7 +114,8 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sig
     for (int j = i + 1; j < k; j++) t = fma(-A[i][j], x[j], t);
     x[i] = t / A[i][i];
   }
-  double g[KMAX], kz = 0.0, gv = 0.0;                        // G[r, 0:k] = K_1[r, 0:k] H_k
+  double kz = 0.0, gv = 0.0;                                 // G[r, 0:k] = K_1[r, 0:k] H_k
+  double g[KMAX];
 #pragma unroll
   for (int c = 0; c < k; c++) {
     double t = 0.0;
@@ -126,11 +127,18 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sig
   }
   if (lane < DS) {
 #pragma unroll
-    for (int c = 0; c < KMAX; c++) { const double t = (c < k) ? g[c] : 0.0; s.G[r * KMAX + c] = t; ctl->G[r * DS + c] = t; }   // columns >= KMAX of ctl->G stay zero
+    for (int c = 0; c < KMAX; c++) s.G[r * KMAX + c] = (c < k) ? g[c] : 0.0;
     s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
   }
-  __syncthreads();
-  // state += solution   (common_lib.h:182-192), from the LDS copy
+  wave_sync();
+}
+
+// Part 3: publish G (zero-padded 19x19 in ctl->G) and apply  state += solution  (common_lib.h:182-192) to ctl->cur, from the LDS copies.
+__device__ inline void esikf_commit_wave(DevCtl *ctl, SolveLds &s, const int lane) {
+  if (lane < DS) {
+#pragma unroll
+    for (int c = 0; c < KMAX; c++) ctl->G[lane * DS + c] = s.G[lane * KMAX + c];      // columns >= KMAX of ctl->G stay zero
+  }
   if (lane == 0) {
     double E[9], Rn[9];
     so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
@@ -139,5 +147,10 @@ __device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sig
   } else if (lane >= 9 && lane < 25) {
     reinterpret_cast<double *>(&ctl->cur)[lane] = s.cur[lane] + s.sol[lane - 6];
   }
-  __syncthreads();
+}
+
+template <int k>
+__device__ inline void esikf_update_wave(DevCtl *ctl, SolveLds &s, const int sign, const int lane) {
+  esikf_solve_wave<k>(s, sign, lane);
+  esikf_commit_wave(ctl, s, lane);
 }

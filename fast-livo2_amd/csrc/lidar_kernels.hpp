@@ -771,7 +771,7 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
   reduce_partials_block(partials, nblocks, scratch, sums);
   SPHASE(2);
   if (mode == 1 && hdr_stop) return;
-  if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
+  if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave: wave-local synchronisation only from here on
   const int lane = threadIdx.x;
   // expand symmetric 21 -> 6x6
   if (lane < 36) {
@@ -781,7 +781,7 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
     s.hth[lane] = sums[idx];
   }
   if (lane < 6) s.htz[lane] = sums[21 + lane];
-  __syncthreads();
+  wave_sync();
   livo2_lidar_sums *out = (mode == 0) ? &ctl->sums_l : &ctl->lidar.iter_sums[iter];
   if (lane < 36) out->HtH[lane] = s.hth[lane];
   if (lane < 6) out->Htz[lane] = s.htz[lane];
@@ -799,7 +799,7 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
   int rematch = hdr_rematch;
   if (conv || ((rematch == 0) && (iter == (max_iter - 2)))) rematch++;
   const bool stop_now = (rematch >= 2 || (iter == max_iter - 1));
-  __syncthreads();
+  wave_sync();
   if (stop_now && mode == 1) {
     // cov = (I - G) * cov ; s.P holds cov (meas_cov_scale = 1) and G is zero beyond column 5
     for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {

@@ -114,6 +114,15 @@ struct livo2_ctx {
   int32_t *bd_block_frame = nullptr; size_t b_block_frame_cap = 0;
   DevCtl *bd_ctl = nullptr; LidarBatchEntry *bd_entries = nullptr; HostIn *bd_in = nullptr; livo2_lidar_result *bd_results = nullptr;   // [LIVO2_MAX_BATCH]
   HostIn *bh_in = nullptr; livo2_lidar_result *bh_results = nullptr; LidarBatchEntry *bh_entries = nullptr;                              // pinned
+  // batch of frames, visual (own images / sub-maps / states, lockstep (level, iteration) grids); shares bd_ctl / bd_in / bh_in with the LiDAR batch
+  bool has_vbatch = false;
+  int vbn = 0, vb_total = 0, vb_blocks = 0, vb_L = 0, vb_w = 0, vb_h = 0, vb_stride = 0;
+  std::vector<int32_t> vb_count, vb_off, vb_grid, vb_block_begin;
+  uint8_t *vbd_img = nullptr; size_t vb_img_cap = 0;
+  double *vbd_pos = nullptr, *vbd_invexpo = nullptr, *vbd_partials = nullptr; float *vbd_warp = nullptr, *vbd_errors = nullptr; int32_t *vbd_search = nullptr, *vbd_block_frame = nullptr;
+  size_t vb_pos_cap = 0, vb_invexpo_cap = 0, vb_partials_cap = 0, vb_warp_cap = 0, vb_errors_cap = 0, vb_search_cap = 0, vb_block_frame_cap = 0;
+  VisualBatchEntry *vbd_entries = nullptr, *vbh_entries = nullptr;      // [LIVO2_MAX_BATCH], device / pinned
+  livo2_visual_result *vbd_results = nullptr, *vbh_results = nullptr;   // [LIVO2_MAX_BATCH], device / pinned
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
 #endif
@@ -313,6 +322,7 @@ int check_visual_cfg(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
   if (cfg->patch_pyrimid_level < 1 || cfg->patch_pyrimid_level > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level out of range");
   if (ctx->M > 0 && cfg->patch_pyrimid_level > ctx->L) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level exceeds the uploaded warp_patch levels");
   if (!(cfg->img_point_cov > 0)) return fail(ctx, LIVO2_ERR_INVALID, "img_point_cov must be > 0");
+  if (cfg->mp_proc_num < 0 || cfg->mp_proc_num > LIVO2_WAVE) return fail(ctx, LIVO2_ERR_INVALID, "mp_proc_num out of [0,64]");
   return LIVO2_OK;
 }
 
@@ -345,7 +355,10 @@ VisualRefArgs make_ref_args(livo2_ctx *ctx) {
   return r;
 }
 
-int visual_grid(int M) { return std::max(1, (M + VIS_WAVES - 1) / VIS_WAVES); }
+int visual_grid(int M) { return std::max(1, (M + VIS_PPB - 1) / VIS_PPB); }          // forward-compositional kernels: VIS_PPB patches per block
+int visual_grid_inverse(int M) { return std::max(1, (M + VIS_WAVES - 1) / VIS_WAVES); }   // inverse-compositional kernels: one patch per wave
+// updateStateInverse has no OpenMP loop (vio.cpp:1422-1477): its frame error is always the serial sum
+VisualSolveArgs visual_solve_args(livo2_ctx *ctx, const livo2_visual_cfg *cfg) { return VisualSolveArgs{ctx->d_errors, ctx->M, cfg->inverse_composition_en ? 1 : cfg->mp_proc_num}; }
 
 } // namespace
 
@@ -403,13 +416,16 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sel_flag, ctx->d_sel_dist, ctx->d_sel_disc, ctx->d_imu_steps, ctx->d_imu_poses, ctx->d_imu_state,
                  ctx->d_ob_off, ctx->d_ob_id, ctx->d_ob_img, ctx->d_ob_lvl, ctx->d_vm_refpatch, ctx->d_ob_px, ctx->d_ob_f, ctx->d_ob_R, ctx->d_ob_t, ctx->d_ob_ie, ctx->d_vm_normal,
                  ctx->d_ob_patch, ctx->d_vm_ninit, ctx->d_ob_imgs, ctx->d_ch_obs, ctx->d_ch_flag, ctx->d_ch_slot, ctx->d_cand_cell, ctx->d_cand_point, ctx->d_cand_obs,
-                 ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals};
+                 ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
+                 ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
   if (ctx->bh_in) e = hipHostFree(ctx->bh_in);
   if (ctx->bh_results) e = hipHostFree(ctx->bh_results);
   if (ctx->bh_entries) e = hipHostFree(ctx->bh_entries);
+  if (ctx->vbh_entries) e = hipHostFree(ctx->vbh_entries);
+  if (ctx->vbh_results) e = hipHostFree(ctx->vbh_results);
   for (auto &b : ctx->bins) for (auto &ev : b.used) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (int k = 0; k < IN_RING; k++) if (ctx->in_ev[k]) e = hipEventDestroy(ctx->in_ev[k]);
@@ -1166,7 +1182,7 @@ int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, in
     ctx->M_cap = cap;
   }
   rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)M * L * 64, (size_t)64)); if (rc) return rc;
-  const int grid = visual_grid(std::max(M, 1));
+  const int grid = visual_grid_inverse(std::max(M, 1));     // the larger of the two grids
   rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * VIS_PSTRIDE, (size_t)64)); if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ctx->d_img, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream));
   if (M > 0) {
@@ -1365,7 +1381,7 @@ static int tail_reserve(livo2_ctx *ctx, int n, int L) {
     ctx->M_cap = cap;
   }
   if ((rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)n * L * 64, (size_t)64)))) return rc;
-  if ((rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)visual_grid(std::max(n, 1)) * VIS_PSTRIDE, (size_t)64)))) return rc;
+  if ((rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)visual_grid_inverse(std::max(n, 1)) * VIS_PSTRIDE, (size_t)64)))) return rc;
   return LIVO2_OK;
 }
 
@@ -1640,7 +1656,7 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   rc = upload_states(ctx, cur, cur); if (rc) return rc;
   VisualKernelArgs a = make_visual_args(ctx, cfg, level);
   a.errors = ctx->d_errors; a.z = z ? ctx->d_zdbg : nullptr; a.H_sub = H_sub ? ctx->d_Hdbg : nullptr;
-  const int grid = visual_grid(std::max(M, 1));
+  const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(M, 1)) : visual_grid(std::max(M, 1));
   if (z) HIPCHK(hipMemsetAsync(ctx->d_zdbg, 0, (size_t)std::max(M, 1) * 64 * 8, ctx->stream));       // a skipped (out-of-image) patch leaves its rows untouched
   if (H_sub) HIPCHK(hipMemsetAsync(ctx->d_Hdbg, 0, (size_t)std::max(M, 1) * 64 * 56, ctx->stream));
   if (cfg->inverse_composition_en && M > 0) {
@@ -1655,7 +1671,7 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   } else {
     Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done();
   }
-  { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov); t.done(); }
+  { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(512), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov, visual_solve_args(ctx, cfg)); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_v, sizeof(livo2_visual_sums), hipMemcpyDeviceToHost, ctx->stream));
   if (errors && M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1669,7 +1685,7 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
 static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, int level_hi, int level_lo,
                           int iters, int mode) {
   int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
-  const int grid = visual_grid(std::max(ctx->M, 1));
+  const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(ctx->M, 1)) : visual_grid(std::max(ctx->M, 1));
   VisualKernelArgs a{};
   for (int level = level_hi; level >= level_lo; level--) {
     a = make_visual_args(ctx, cfg, level);
@@ -1687,7 +1703,7 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
         else hipLaunchKernelGGL(k_visual_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0);
         t.done();
       }
-      { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(VIS_SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov); t.done(); }
+      { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(512), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov, visual_solve_args(ctx, cfg)); t.done(); }
     }
   }
   hipLaunchKernelGGL(k_visual_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, a, mode == 1 ? 1 : 0);
@@ -1732,7 +1748,148 @@ int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_sta
   return visual_enqueue(ctx, state_in, prop, cfg, level, level, iters, 2);
 }
 
+// ---- batch of frames, visual ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish_batch(const VisualBatchEntry *__restrict__ entries, int update_cov) {
+  const VisualBatchEntry &e = entries[blockIdx.x];
+  visual_finish_body(e.ctl, e.a, (update_cov && e.a.M > 0) ? 1 : 0);      // total_points == 0: no update, the covariance stays (vio.cpp:786)
+}
+__global__ void __launch_bounds__(256) k_vbatch_gather_out(const VisualBatchEntry *__restrict__ entries, livo2_visual_result *__restrict__ out) {
+  const double *src = reinterpret_cast<const double *>(&entries[blockIdx.x].ctl->visual);
+  double *dst = reinterpret_cast<double *>(out + blockIdx.x);
+  for (int e = threadIdx.x; e < (int)(sizeof(livo2_visual_result) / sizeof(double)); e += 256) dst[e] = src[e];
+}
+static_assert(sizeof(livo2_visual_result) % 8 == 0, "copied as doubles");
+} // namespace
+
+int livo2_visual_batch_set_frames(livo2_ctx *ctx, int32_t n_frames, const uint8_t *imgs, int32_t width, int32_t height, int32_t stride, const double *pos,
+                                  const float *warp_patch, const int32_t *search_levels, const double *inv_expo_list, const int32_t *counts, int32_t L) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (n_frames < 1 || n_frames > LIVO2_MAX_BATCH) return fail(ctx, LIVO2_ERR_INVALID, "n_frames out of [1,LIVO2_MAX_BATCH]");
+  if (!imgs || width <= 0 || height <= 0 || stride < width) return fail(ctx, LIVO2_ERR_INVALID, "bad image");
+  if (!counts || L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad counts / L");
+  long long total = 0;
+  for (int f = 0; f < n_frames; f++) { if (counts[f] < 0) return fail(ctx, LIVO2_ERR_INVALID, "negative patch count"); total += counts[f]; }
+  if (total > (1ll << 26)) return fail(ctx, LIVO2_ERR_INVALID, "batch too large");
+  if (total > 0 && (!pos || !warp_patch || !search_levels || !inv_expo_list)) return fail(ctx, LIVO2_ERR_INVALID, "bad sub-map arrays");
+  for (long long i = 0; i < total; i++) if (search_levels[i] < 0 || search_levels[i] > 8) return fail(ctx, LIVO2_ERR_RANGE, "search_level out of [0,8]");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc = batch_alloc_fixed(ctx); if (rc) return rc;
+  if (!ctx->vbd_entries) {
+    HIPCHK(hipMalloc((void **)&ctx->vbd_entries, sizeof(VisualBatchEntry) * LIVO2_MAX_BATCH));
+    HIPCHK(hipMalloc((void **)&ctx->vbd_results, sizeof(livo2_visual_result) * LIVO2_MAX_BATCH));
+    HIPCHK(hipHostMalloc((void **)&ctx->vbh_entries, sizeof(VisualBatchEntry) * LIVO2_MAX_BATCH));
+    HIPCHK(hipHostMalloc((void **)&ctx->vbh_results, sizeof(livo2_visual_result) * LIVO2_MAX_BATCH));
+  }
+  const size_t img_bytes = (size_t)stride * height, T = (size_t)std::max<long long>(total, 1);
+  if ((rc = ensure(ctx, ctx->vbd_img, ctx->vb_img_cap, img_bytes * n_frames))) return rc;
+  if ((rc = ensure(ctx, ctx->vbd_pos, ctx->vb_pos_cap, T * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->vbd_invexpo, ctx->vb_invexpo_cap, T))) return rc;
+  if ((rc = ensure(ctx, ctx->vbd_search, ctx->vb_search_cap, T))) return rc;
+  if ((rc = ensure(ctx, ctx->vbd_errors, ctx->vb_errors_cap, T))) return rc;
+  if ((rc = ensure(ctx, ctx->vbd_warp, ctx->vb_warp_cap, T * L * 64))) return rc;
+  ctx->vbn = n_frames; ctx->vb_total = (int)total; ctx->vb_L = L; ctx->vb_w = width; ctx->vb_h = height; ctx->vb_stride = stride;
+  ctx->vb_count.assign(counts, counts + n_frames);
+  ctx->vb_off.resize(n_frames); ctx->vb_grid.resize(n_frames); ctx->vb_block_begin.resize(n_frames);
+  int off = 0, blocks = 0;
+  for (int f = 0; f < n_frames; f++) { ctx->vb_off[f] = off; ctx->vb_grid[f] = visual_grid(std::max(counts[f], 1)); ctx->vb_block_begin[f] = blocks; off += counts[f]; blocks += ctx->vb_grid[f]; }
+  ctx->vb_blocks = blocks;
+  if ((rc = ensure(ctx, ctx->vbd_partials, ctx->vb_partials_cap, (size_t)blocks * VIS_PSTRIDE))) return rc;
+  if ((rc = ensure(ctx, ctx->vbd_block_frame, ctx->vb_block_frame_cap, (size_t)blocks))) return rc;
+  {
+    std::vector<int32_t> bf((size_t)blocks);
+    for (int f = 0; f < n_frames; f++) std::fill(bf.begin() + ctx->vb_block_begin[f], bf.begin() + ctx->vb_block_begin[f] + ctx->vb_grid[f], f);
+    HIPCHK(hipMemcpy(ctx->vbd_block_frame, bf.data(), (size_t)blocks * 4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpyAsync(ctx->vbd_img, imgs, img_bytes * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  if (total > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->vbd_pos, pos, (size_t)total * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->vbd_warp, warp_patch, (size_t)total * L * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->vbd_search, search_levels, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->vbd_invexpo, inv_expo_list, (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->has_vbatch = true;
+  return LIVO2_OK;
+}
+
+static int vbatch_enqueue(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, int level_hi, int level_lo,
+                          int iters, int mode) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!state_in || !prop || !cfg) return fail(ctx, LIVO2_ERR_INVALID, "state / cfg is NULL");
+  if (!ctx->has_vbatch) return fail(ctx, LIVO2_ERR_NO_FRAME, "livo2_visual_batch_set_frames has not been called");
+  if (n_frames != ctx->vbn) return fail(ctx, LIVO2_ERR_INVALID, "n_frames differs from the batch set by livo2_visual_batch_set_frames");
+  if (cfg->inverse_composition_en) return fail(ctx, LIVO2_ERR_INVALID, "the batched visual update is forward-compositional only");
+  if (cfg->max_iterations < 1 || cfg->max_iterations > LIVO2_MAX_ITERS || cfg->patch_pyrimid_level < 1 || cfg->patch_pyrimid_level > ctx->vb_L || !(cfg->img_point_cov > 0) ||
+      cfg->mp_proc_num < 0 || cfg->mp_proc_num > LIVO2_WAVE)
+    return fail(ctx, LIVO2_ERR_INVALID, "bad visual cfg");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));        // pinned staging blocks are reused
+  // per-frame kernel arguments: the camera / extrinsic constants of make_visual_args on this frame's slices
+  const int keepM = ctx->M, keepL = ctx->L;
+  for (int f = 0; f < n_frames; f++) {
+    HostIn &h = ctx->bh_in[f];
+    h.cur = state_in[f]; h.prop = prop[f];
+    std::memset(&h.hdr, 0, sizeof(DevHeader));
+    h.hdr.last_error = FLT_MAX;
+    VisualBatchEntry &e = ctx->vbh_entries[f];
+    ctx->M = ctx->vb_count[f]; ctx->L = ctx->vb_L;
+    e.a = make_visual_args(ctx, cfg, 0);
+    const size_t o = (size_t)ctx->vb_off[f];
+    e.a.img = ctx->vbd_img + (size_t)f * ctx->vb_stride * ctx->vb_h; e.a.width = ctx->vb_w; e.a.height = ctx->vb_h; e.a.stride = ctx->vb_stride;
+    e.a.pos = ctx->vbd_pos + o * 3; e.a.warp = ctx->vbd_warp + o * ctx->vb_L * 64; e.a.search_levels = ctx->vbd_search + o; e.a.inv_expo = ctx->vbd_invexpo + o;
+    e.a.errors = ctx->vbd_errors + o; e.a.z = nullptr; e.a.H_sub = nullptr;
+    e.ctl = ctx->bd_ctl + f; e.partials = ctx->vbd_partials + (size_t)ctx->vb_block_begin[f] * VIS_PSTRIDE; e.block_begin = ctx->vb_block_begin[f]; e.nblocks = ctx->vb_grid[f];
+  }
+  ctx->M = keepM; ctx->L = keepL;
+  HIPCHK(hipMemcpyAsync(ctx->bd_in, ctx->bh_in, sizeof(HostIn) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->vbd_entries, ctx->vbh_entries, sizeof(VisualBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_batch_scatter_in, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_in, ctx->bd_ctl);
+  for (int level = level_hi; level >= level_lo; level--)
+    for (int it = 0; it < iters; it++) {
+      { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_residual_batch, dim3(ctx->vb_blocks), dim3(VIS_BLOCK), 0, ctx->stream, ctx->vbd_entries, ctx->vbd_block_frame, level, (mode == 1 && it > 0) ? 1 : 0); t.done(); }
+      { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve_batch, dim3(n_frames), dim3(512), 0, ctx->stream, ctx->vbd_entries, mode, level, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov, cfg->mp_proc_num); t.done(); }
+    }
+  hipLaunchKernelGGL(k_visual_finish_batch, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->vbd_entries, mode == 1 ? 1 : 0);
+  hipLaunchKernelGGL(k_vbatch_gather_out, dim3(n_frames), dim3(256), 0, ctx->stream, ctx->vbd_entries, ctx->vbd_results);
+  HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+
+int livo2_visual_batch_update_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg) {
+  if (!ctx || !cfg) return ctx ? fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL") : LIVO2_ERR_INVALID;
+  return vbatch_enqueue(ctx, n_frames, state_in, prop, cfg, cfg->patch_pyrimid_level - 1, 0, cfg->max_iterations, 1);
+}
+int livo2_visual_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_visual_result *results) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!results) return fail(ctx, LIVO2_ERR_INVALID, "results is NULL");
+  if (!ctx->has_vbatch || n_frames != ctx->vbn) return fail(ctx, LIVO2_ERR_INVALID, "n_frames differs from the batch set by livo2_visual_batch_set_frames");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->vbh_results, ctx->vbd_results, sizeof(livo2_visual_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(results, ctx->vbh_results, sizeof(livo2_visual_result) * n_frames);
+  return LIVO2_OK;
+}
+int livo2_visual_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, livo2_visual_result *results) {
+  int rc = livo2_visual_batch_update_async(ctx, n_frames, state_in, prop, cfg); if (rc) return rc;
+  return livo2_visual_batch_update_fetch(ctx, n_frames, results);
+}
+int livo2_visual_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, int32_t level, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg,
+                                        int32_t iters) {
+  if (!ctx || !cfg) return ctx ? fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL") : LIVO2_ERR_INVALID;
+  if (iters < 1 || level < 0 || level >= cfg->patch_pyrimid_level) return fail(ctx, LIVO2_ERR_INVALID, "bad iters/level");
+  return vbatch_enqueue(ctx, n_frames, state_in, prop, cfg, level, level, iters, 2);
+}
+
 #ifdef LIVO2_PHASE_PROF
+// profiling build only: per-wave stamps of the LAST k_visual_residual launch, [waves][8] (tools/vis_phase.py)
+int livo2_debug_vis_prof(livo2_ctx *ctx, unsigned long long *out, size_t n_waves) {
+  if (!ctx || !out) return LIVO2_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis_prof), std::min(n_waves, (size_t)VIS_PROF_WAVES) * 64));
+  return LIVO2_OK;
+}
 // profiling build only: copy the per-wave phase stamps of the LAST residual launch to host memory
 int livo2_debug_phase_prof(livo2_ctx *ctx, unsigned long long *out, size_t max_waves, size_t *n_waves) {
   if (!ctx || !ctx->d_prof) return LIVO2_ERR_INVALID;

@@ -135,6 +135,12 @@ __device__ inline void so3_log(const double *R, double *o) {
   else { double f = 0.5 * theta / sin(theta); o[0] = f * K0; o[1] = f * K1; o[2] = f * K2; }
 }
 
+// LDS hand-off inside ONE wave: orders this wave's LDS writes before its later LDS reads without a workgroup barrier (s_barrier counts every wave of the
+// block, so a phase that only one wave executes must not use __syncthreads())
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // wave-64 all-reduce (sum) of a double through the LDS crossbar (ds_bpermute, no LDS storage)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -37,9 +37,6 @@ __device__ __forceinline__ Anchor make_anchor(double pcx, double pcy, int scale)
   A.w_br = su * sv;
   return A;
 }
-__device__ __forceinline__ void vis_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 __global__ void __launch_bounds__(VIS_BLOCK) k_visual_ref_precompute(VisualKernelArgs a, VisualRefArgs r) {
   __shared__ float Wf[VIS_WAVES][11 * 11 + 3];
@@ -97,6 +94,7 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_inverse_residual(VisualKer
                                                                        double *__restrict__ partials, int check_stop) {
   if (check_stop && ctl->hdr.stop) return;
   __shared__ float Wf[VIS_WAVES][9 * 9 + 3];
+  __shared__ double Rr[VIS_WAVES][LIVO2_WAVE];
   __shared__ double red[VIS_WAVES][VIS_PSTRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int patch = blockIdx.x * VIS_WAVES + wave;
@@ -163,9 +161,14 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_inverse_residual(VisualKer
           h[6] = 0.0;
         }
       }
-      const double Sgz0 = wave_sum(g0 * res), Sgz1 = wave_sum(g1 * res), Szz = wave_sum(res * res);
+      const double Sgz0 = wave_sum(g0 * res), Sgz1 = wave_sum(g1 * res);
       const double S00 = mr[12], S01 = mr[13], S11 = mr[14];
-      const float patch_error = (float)Szz;
+      // float patch_error += res * res in pixel order (vio.cpp:1469), every lane runs the chain from broadcast LDS reads
+      Rr[wave][lane] = res * res;
+      vis_wave_sync();
+      float patch_error = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 64; i++) patch_error = (float)((double)patch_error + Rr[wave][i]);
       if (a.errors && lane == 0) a.errors[patch] = patch_error;
       if (lane < 28) {
         int rr = 0, q = lane;

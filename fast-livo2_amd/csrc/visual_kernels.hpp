@@ -17,6 +17,8 @@
 #define VIS_WAVES (VIS_BLOCK / LIVO2_WAVE)
 #define VIS_NSUM 37          // 28 (sym 7x7) + 7 + err_sum + n_meas
 #define VIS_PSTRIDE 40
+#define VIS_NMOM 10          // 9 moment products + res^2 per pixel
+#define VIS_TPITCH 65        // row pitch of the per-wave transpose tile in doubles (consecutive lanes -> consecutive 8-B words)
 
 struct VisualKernelArgs {
   const uint8_t *img; int32_t width, height, stride;
@@ -24,8 +26,15 @@ struct VisualKernelArgs {
   int32_t M, L, level, exposure_en;
   double fx, fy, cx, cy, d[5]; int32_t distortion; int32_t pad;
   double Rci[9], Pci[3], Jdp_dR[9];            // initializeVIO constants (vio.cpp:57-65), Jdphi_dR == Rci
-  float *errors; double *z; double *H_sub;     // optional outputs (device pointers or null)
+  float *errors; double *z; double *H_sub;     // errors: always written; z / H_sub: optional debug outputs (device pointers or null)
 };
+
+__device__ __forceinline__ void vis_wave_sync() { wave_sync(); }
+// value held by lane `src` (a compile-time constant) as a wave-uniform scalar: two v_readlane_b32, no LDS traffic
+template <int SRC> __device__ __forceinline__ double lane_value(double v) {
+  const int2 w = __builtin_bit_cast(int2, v);
+  return __builtin_bit_cast(double, make_int2(__builtin_amdgcn_readlane(w.x, SRC), __builtin_amdgcn_readlane(w.y, SRC)));
+}
 
 // Jacobian row chain of the reference for an image-gradient row g (vio.cpp:1611-1617)
 __device__ __forceinline__ void jac_row(double g0, double g1, const double Jpi[6], const double pf[3], const double *Rci, const double *JdpdR,
@@ -46,184 +55,429 @@ __device__ __forceinline__ void jac_row(double g0, double g1, const double Jpi[6
   }
 }
 
-template <bool DEBUG_ROWS>
-__global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual(VisualKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
-                                                               int check_stop) {
-  if (check_stop && ctl->hdr.stop) return;
-  __shared__ float Wf[VIS_WAVES][11 * 11 + 3];
-  __shared__ float Bf[VIS_WAVES][10 * 10 + 4];
-  __shared__ double red[VIS_WAVES][VIS_PSTRIDE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int patch = blockIdx.x * VIS_WAVES + wave;          // wave-uniform
-  double out_val = 0.0;                                      // lane q < VIS_NSUM holds value q of this patch
-
-  if (patch < a.M) {
-    const double *Rwi = ctl->cur.rot, *Pwi = ctl->cur.pos;
-    const double tau = ctl->cur.inv_expo;
-    double Rcw[9], Pcw[3];
-    mat3_mul_Bt(a.Rci, Rwi, Rcw);                            // Rcw = Rci * Rwi^T
-#pragma unroll
-    for (int j = 0; j < 3; j++) Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * Pwi[0] + Rcw[j * 3 + 1] * Pwi[1]) + Rcw[j * 3 + 2] * Pwi[2]);
-    const double p0 = a.pos[(size_t)patch * 3], p1 = a.pos[(size_t)patch * 3 + 1], p2 = a.pos[(size_t)patch * 3 + 2];
-    double pf[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) pf[j] = ((Rcw[j * 3] * p0 + Rcw[j * 3 + 1] * p1) + Rcw[j * 3 + 2] * p2) + Pcw[j];
-    // pc = cam->world2cam(pf)
-    double pcx, pcy;
-    {
-      double u0 = pf[0] / pf[2], u1 = pf[1] / pf[2];
-      if (!a.distortion) { pcx = a.fx * u0 + a.cx; pcy = a.fy * u1 + a.cy; }
-      else {
-        double x = u0, y = u1, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-        double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-        double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
-        double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2, yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
-        pcx = xd * a.fx + a.cx; pcy = yd * a.fy + a.cy;
-      }
-    }
-    // computeProjectionJacobian (vio.cpp:189-201)
-    double Jpi[6];
-    {
-      const double z_inv = 1. / pf[2], z_inv_2 = z_inv * z_inv;
-      Jpi[0] = a.fx * z_inv; Jpi[1] = 0.0; Jpi[2] = -a.fx * pf[0] * z_inv_2;
-      Jpi[3] = 0.0; Jpi[4] = a.fy * z_inv; Jpi[5] = -a.fy * pf[1] * z_inv_2;
-    }
-    const int search_level = a.search_levels[patch];
-    const int scale = 1 << (a.level + search_level);
-    const float inv_scale = 1.0f / (float)scale;
-    const float u_ref = (float)pcx, v_ref = (float)pcy;
-    const int u_ref_i = (int)(floorf((float)(pcx / scale)) * (float)scale);
-    const int v_ref_i = (int)(floorf((float)(pcy / scale)) * (float)scale);
-    const float subpix_u = (u_ref - (float)u_ref_i) / (float)scale;
-    const float subpix_v = (v_ref - (float)v_ref_i) / (float)scale;
-    const float w_tl = (float)((1.0 - (double)subpix_u) * (1.0 - (double)subpix_v));
-    const float w_tr = (float)((double)subpix_u * (1.0 - (double)subpix_v));
-    const float w_bl = (float)((1.0 - (double)subpix_u) * (double)subpix_v);
-    const float w_br = subpix_u * subpix_v;
-    // the reference reads this window unchecked (vio.cpp:1595-1609); a window leaving the image is skipped here
-    const bool inside = (u_ref_i - 5 * scale >= 0) && (u_ref_i + 5 * scale < a.width) && (v_ref_i - 5 * scale >= 0) && (v_ref_i + 5 * scale < a.height);
-    if (inside) {
-      // stage the 11x11 strided window as float
-      for (int e = lane; e < 121; e += LIVO2_WAVE) {
-        int wr = e / 11, wc = e - wr * 11;
-        Wf[wave][e] = (float)a.img[(size_t)(v_ref_i + (wr - 5) * scale) * a.stride + (u_ref_i + (wc - 5) * scale)];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      for (int e = lane; e < 100; e += LIVO2_WAVE) {
-        int br = e / 10, bc = e - br * 10;
-        const float *w = &Wf[wave][br * 11 + bc];
-        Bf[wave][e] = ((w_tl * w[0] + w_tr * w[1]) + w_bl * w[11]) + w_br * w[12];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int x = lane >> 3, y = lane & 7;
-      const float *b = &Bf[wave][(x + 1) * 10 + (y + 1)];
-      const float du = 0.5f * (b[1] - b[-1]);
-      const float dv = 0.5f * (b[10] - b[-10]);
-      const double cur = (double)b[0];
-      const double g0 = ((double)du * tau) * (double)inv_scale;
-      const double g1 = ((double)dv * tau) * (double)inv_scale;
-      const double Pref = (double)a.warp[((size_t)patch * a.L + a.level) * 64 + lane];
-      const double res = tau * cur - a.inv_expo[patch] * Pref;
-      const double cexp = a.exposure_en ? cur : 0.0;
-      if (DEBUG_ROWS) {
-        double row[6];
-        jac_row(g0, g1, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, row);
-        if (a.z) a.z[(size_t)patch * 64 + lane] = res;
-        if (a.H_sub) {
-          double *h = a.H_sub + ((size_t)patch * 64 + lane) * 7;
-#pragma unroll
-          for (int k = 0; k < 6; k++) h[k] = row[k];
-          h[6] = cexp;
-        }
-      }
-      // 10 moment sums over the 64 pixels
-      const double Sg00 = wave_sum(g0 * g0), Sg01 = wave_sum(g0 * g1), Sg11 = wave_sum(g1 * g1);
-      const double Sgc0 = wave_sum(g0 * cexp), Sgc1 = wave_sum(g1 * cexp), Scc = wave_sum(cexp * cexp);
-      const double Sgr0 = wave_sum(g0 * res), Sgr1 = wave_sum(g1 * res), Scr = wave_sum(cexp * res), Srr = wave_sum(res * res);
-      const float patch_error = (float)Srr;
-      if (a.errors && lane == 0) a.errors[patch] = patch_error;
-      // patch-constant M (2x6)
-      double M0[6], M1[6];
-      jac_row(1.0, 0.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M0);
-      jac_row(0.0, 1.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M1);
-      // lane q: value q of the 37-vector.  q<28: upper-tri (r<=c) of the 7x7 ; 28..34: Htz ; 35: err ; 36: n_meas
-      if (lane < 28) {
-        int r = 0, q = lane;
-        while (q >= 7 - r) { q -= 7 - r; r++; }
-        int c = r + q;
-        double m0r = 0, m1r = 0, m0c = 0, m1c = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) { if (k == r) { m0r = M0[k]; m1r = M1[k]; } if (k == c) { m0c = M0[k]; m1c = M1[k]; } }
-        if (c < 6) out_val = (m0r * m0c) * Sg00 + (m0r * m1c + m1r * m0c) * Sg01 + (m1r * m1c) * Sg11;
-        else if (r < 6) out_val = m0r * Sgc0 + m1r * Sgc1;
-        else out_val = Scc;
-      } else if (lane < 35) {
-        int r = lane - 28;
-        double m0r = 0, m1r = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) if (k == r) { m0r = M0[k]; m1r = M1[k]; }
-        out_val = (r < 6) ? (m0r * Sgr0 + m1r * Sgr1) : Scr;
-      } else if (lane == 35) out_val = (double)patch_error;
-      else if (lane == 36) out_val = 64.0;
-    } else if (a.errors && lane == 0) a.errors[patch] = 0.f;
+// pc = cam->world2cam(pf): vk::PinholeCamera (rpg_vikit): projection to z = 1, optional radial-tangential distortion d0..d4, then fx, fy, cx, cy
+__device__ __forceinline__ void vis_world2cam(const VisualKernelArgs &a, const double pf[3], double &pcx, double &pcy) {
+  const double u0 = pf[0] / pf[2], u1 = pf[1] / pf[2];
+  if (!a.distortion) { pcx = a.fx * u0 + a.cx; pcy = a.fy * u1 + a.cy; }
+  else {
+    const double x = u0, y = u1, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    const double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
+    const double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2, yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
+    pcx = xd * a.fx + a.cx; pcy = yd * a.fy + a.cy;
   }
+}
+
+#ifdef LIVO2_PHASE_PROF
+#define VIS_PROF_WAVES (1 << 14)
+__device__ unsigned long long g_vis_prof[VIS_PROF_WAVES][8];
+// drain every outstanding memory op, then stamp (slot 0 and 7: chip-wide 100 MHz clock, the others: this CU's cycle counter)
+#define VPHASE(k)                                                                                                            \
+  do {                                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);                     \
+    const unsigned gw = blockIdx.x * VIS_WAVES + (threadIdx.x >> 6);                                                         \
+    if ((threadIdx.x & 63) == 0 && gw < VIS_PROF_WAVES)                                                                      \
+      g_vis_prof[gw][k] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  } while (0)
+// solve kernel: wave w stamps row VIS_PROF_WAVES - 1 - w (block 0 only)
+#define VSPHASE(k)                                                                                                           \
+  do {                                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);                     \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0)                                                                          \
+      g_vis_prof[VIS_PROF_WAVES - 1 - (threadIdx.x >> 6)][k] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  } while (0)
+#else
+#define VPHASE(k) do { } while (0)
+#define VSPHASE(k) do { } while (0)
+#endif
+
+// Mapping: a wave owns VIS_PPW = 4 patches, 16 lanes each, every lane 4 pixels (pixel p = j + 16k of its patch, j = lane & 15: the reference's loop index
+// p = 8x + y).  Why not a wave per patch (round 1): everything that is constant over a patch — Rcw, pf, the projection with its three f64 divisions, Jpi, the 2x6 M —
+// was evaluated redundantly by 64 lanes, ~500 of the ~890 VALU instructions a wave issued; with 4 waves per SIMD the kernel was VALU-bound (PMC: 3.6 k VALU-busy
+// cycles per wave, kernel 11 us for 4 000 patches although a wave's memory chain is ~3 us).  Now one instruction stream covers four patches.
+#define VIS_PPW 4
+#define VIS_LPP (LIVO2_WAVE / VIS_PPW)
+#define VIS_PPB (VIS_WAVES * VIS_PPW)        // patches per block = rows of `partials` saved: 4 000 patches -> 125 rows
+
+// Per-wave LDS: the staging buffers of the windows (Wf) and of the bilinear grids (Bf) alias the transpose tile T that the reduction uses afterwards.
+struct __attribute__((aligned(16))) VisWaveLds {
+  union {
+    struct { float Wf[VIS_PPW][11 * 11 + 3]; float Bf[VIS_PPW][10 * 10 + 4]; } st;
+    double T[9 * VIS_TPITCH];
+  };
+  double Rr[VIS_PPW][64];      // res^2 per pixel, pixel order
+  double S[VIS_PPW][9];        // the 9 moment sums of each patch
+  double Mx[VIS_PPW][12];      // patch-constant 2x6 M
+  float pe[VIS_PPW]; float nm[VIS_PPW];
+};
+
+// value q of a patch's 37-vector from its moment sums S and its M:  q<28: upper-tri (r<=c) of the 7x7 ; 28..34: Htz ; 35: err ; 36: n_meas.
+// (r, c) of lane q are found once, before the first memory wait (vis_rc); the four M entries a lane needs are then four independent LDS reads per patch.
+struct VisRC { int r, c; };
+__device__ __forceinline__ VisRC vis_rc(int q) {
+  VisRC o = {0, 0};
+  if (q < 28) {
+    int r = 0, t = q;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (t >= 7 - r) { t -= 7 - r; r++; }
+    o.r = r; o.c = r + t;
+  } else if (q < 35) { o.r = q - 28; o.c = 7; }
+  return o;
+}
+__device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, const double *Mx, float pe, float nm) {
+  const int r = rc.r < 6 ? rc.r : 0, c = rc.c < 6 ? rc.c : 0;                 // clamped: the loads below are unconditional
+  const double m0r = Mx[r], m1r = Mx[6 + r], m0c = Mx[c], m1c = Mx[6 + c];
+  const double Sg00 = S[0], Sg01 = S[1], Sg11 = S[2], Sgc0 = S[3], Sgc1 = S[4], Scc = S[5], Sgr0 = S[6], Sgr1 = S[7], Scr = S[8];
+  double v;
+  if (q < 28) {
+    if (rc.c < 6) v = (m0r * m0c) * Sg00 + (m0r * m1c + m1r * m0c) * Sg01 + (m1r * m1c) * Sg11;
+    else if (rc.r < 6) v = m0r * Sgc0 + m1r * Sgc1;
+    else v = Scc;
+  } else if (q < 35) v = (rc.r < 6) ? (m0r * Sgr0 + m1r * Sgr1) : Scr;
+  else if (q == 35) v = (double)pe;
+  else if (q == 36) v = (double)nm;
+  else v = 0.0;
+  return v;
+}
+
+// Four patches per wave (the body shared by the single-frame and the batched kernel).  patch0 = first patch of this wave.  Returns lane q's value q (q < 37) of the
+// SUM of the wave's patch vectors (slot order).
+template <bool DEBUG_ROWS>
+__device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const DevCtl *__restrict__ ctl, VisWaveLds &L, int patch0, int lane) {
+  const int slot = lane / VIS_LPP, j = lane % VIS_LPP;
+  const VisRC rc = vis_rc(lane);
+  const int patch_raw = patch0 + slot;
+  const bool valid = patch_raw < a.M;
+  const int patch = valid ? patch_raw : a.M - 1;            // clamped: invalid slots compute on the last patch and contribute nothing
+  // loads that do not depend on the state go first, so they travel together with the scalar loads of the state
+  const double p0 = a.pos[(size_t)patch * 3], p1 = a.pos[(size_t)patch * 3 + 1], p2 = a.pos[(size_t)patch * 3 + 2];
+  const int search_level = a.search_levels[patch];
+  const double inv_ref_expo = a.inv_expo[patch];
+  float Pref[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) Pref[k] = a.warp[((size_t)patch * a.L + a.level) * 64 + j + VIS_LPP * k];
+  const double *Rwi = ctl->cur.rot, *Pwi = ctl->cur.pos;
+  const double tau = ctl->cur.inv_expo;
+  VPHASE(1);
+  double Rcw[9], Pcw[3];
+  mat3_mul_Bt(a.Rci, Rwi, Rcw);                            // Rcw = Rci * Rwi^T
+#pragma unroll
+  for (int i = 0; i < 3; i++) Pcw[i] = a.Pci[i] - ((Rcw[i * 3] * Pwi[0] + Rcw[i * 3 + 1] * Pwi[1]) + Rcw[i * 3 + 2] * Pwi[2]);
+  double pf[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) pf[i] = ((Rcw[i * 3] * p0 + Rcw[i * 3 + 1] * p1) + Rcw[i * 3 + 2] * p2) + Pcw[i];
+  double pcx, pcy;
+  vis_world2cam(a, pf, pcx, pcy);
+  const int scale = 1 << (a.level + search_level);
+  const float inv_scale = 1.0f / (float)scale;
+  const float u_ref = (float)pcx, v_ref = (float)pcy;
+  const int u_ref_i = (int)(floorf((float)(pcx / scale)) * (float)scale);
+  const int v_ref_i = (int)(floorf((float)(pcy / scale)) * (float)scale);
+  // the reference reads this window unchecked (vio.cpp:1595-1609); a window leaving the image is skipped here
+  const bool inside = (u_ref_i - 5 * scale >= 0) && (u_ref_i + 5 * scale < a.width) && (v_ref_i - 5 * scale >= 0) && (v_ref_i + 5 * scale < a.height);
+  const bool ok = valid && inside;
+  // the 11x11 strided window of the lane's patch: 8 byte loads per lane, all issued before the projection Jacobian below
+  uint8_t px[8];
+  {
+    const size_t base = ok ? (size_t)(v_ref_i - 5 * scale) * a.stride + (size_t)(u_ref_i - 5 * scale) : 0;
+    const int sc = ok ? scale : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int e = j + VIS_LPP * k < 121 ? j + VIS_LPP * k : 120;
+      const int wr = e / 11, wc = e - wr * 11;
+      px[k] = a.img[base + (size_t)(wr * sc) * a.stride + (size_t)(wc * sc)];
+    }
+  }
+  VPHASE(2);
+  const float subpix_u = (u_ref - (float)u_ref_i) / (float)scale;
+  const float subpix_v = (v_ref - (float)v_ref_i) / (float)scale;
+  const float w_tl = (float)((1.0 - (double)subpix_u) * (1.0 - (double)subpix_v));
+  const float w_tr = (float)((double)subpix_u * (1.0 - (double)subpix_v));
+  const float w_bl = (float)((1.0 - (double)subpix_u) * (double)subpix_v);
+  const float w_br = subpix_u * subpix_v;
+  // computeProjectionJacobian (vio.cpp:189-201) and the patch-constant 2x6 M
+  double Jpi[6];
+  {
+    const double z_inv = 1. / pf[2], z_inv_2 = z_inv * z_inv;
+    Jpi[0] = a.fx * z_inv; Jpi[1] = 0.0; Jpi[2] = -a.fx * pf[0] * z_inv_2;
+    Jpi[3] = 0.0; Jpi[4] = a.fy * z_inv; Jpi[5] = -a.fy * pf[1] * z_inv_2;
+  }
+  {
+    double M0[6], M1[6];
+    jac_row(1.0, 0.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M0);
+    jac_row(0.0, 1.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M1);
+    if (j == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) { L.Mx[slot][k] = M0[k]; L.Mx[slot][6 + k] = M1[k]; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int e = j + VIS_LPP * k; if (e < 121) L.st.Wf[slot][e] = (float)px[k]; }
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const int e = j + VIS_LPP * k;
+    if (e < 100) {
+      const int br = e / 10, bc = e - br * 10;
+      const float *w = &L.st.Wf[slot][br * 11 + bc];
+      L.st.Bf[slot][e] = ((w_tl * w[0] + w_tr * w[1]) + w_bl * w[11]) + w_br * w[12];      // the reference's float expression (vio.cpp:1600-1620)
+    }
+  }
+  wave_sync();
+  VPHASE(3);
+  double acc[9];
+#pragma unroll
+  for (int v = 0; v < 9; v++) acc[v] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int p = j + VIS_LPP * k, x = p >> 3, y = p & 7;
+    const float *b = &L.st.Bf[slot][(x + 1) * 10 + (y + 1)];
+    const float du = 0.5f * (b[1] - b[-1]);
+    const float dv = 0.5f * (b[10] - b[-10]);
+    const double cur = (double)b[0];
+    const double g0 = ((double)du * tau) * (double)inv_scale;
+    const double g1 = ((double)dv * tau) * (double)inv_scale;
+    const double res = tau * cur - inv_ref_expo * (double)Pref[k];
+    const double cexp = a.exposure_en ? cur : 0.0;
+    if (DEBUG_ROWS && ok) {
+      double row[6];
+      jac_row(g0, g1, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, row);
+      if (a.z) a.z[(size_t)patch * 64 + p] = res;
+      if (a.H_sub) {
+        double *h = a.H_sub + ((size_t)patch * 64 + p) * 7;
+#pragma unroll
+        for (int c = 0; c < 6; c++) h[c] = row[c];
+        h[6] = cexp;
+      }
+    }
+    acc[0] += g0 * g0; acc[1] += g0 * g1; acc[2] += g1 * g1; acc[3] += g0 * cexp; acc[4] += g1 * cexp; acc[5] += cexp * cexp;
+    acc[6] += g0 * res; acc[7] += g1 * res; acc[8] += cexp * res;
+    L.Rr[slot][p] = res * res;
+  }
+  wave_sync();                                              // the staging buffers alias the tile written next
+  VPHASE(4);
+#pragma unroll
+  for (int v = 0; v < 9; v++) L.T[v * VIS_TPITCH + lane] = ok ? acc[v] : 0.0;
+  wave_sync();
+  {
+    // lane 4v+q adds columns [16q, 16q+16) of row v = the 16 lanes of patch slot q (16 independent LDS reads)
+    const int v = lane >> 2, q = lane & 3;
+    if (v < 9) {
+      const double *row = L.T + v * VIS_TPITCH + q * VIS_LPP;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < VIS_LPP; i += 4) { s0 += row[i]; s1 += row[i + 1]; s2 += row[i + 2]; s3 += row[i + 3]; }
+      L.S[q][v] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  // patch error: the reference's accumulator is a FLOAT updated in pixel order, `patch_error += res * res` = float(double(patch_error) + res*res)
+  // (vio.cpp:1563,1624); the 16 lanes of a slot run that 64-step chain from broadcast LDS reads, so errors[] equals the CPU loop bit for bit
+  float pe = 0.0f;
+#ifndef VIS_EXP_NOCHAIN
+  {
+    const double *rr = L.Rr[slot];
+#pragma unroll
+    for (int i = 0; i < 64; i++) pe = (float)((double)pe + rr[i]);
+  }
+#endif
+  if (!ok) pe = 0.0f;
+  if (j == 0) {
+    if (valid) a.errors[patch] = pe;
+    L.pe[slot] = pe; L.nm[slot] = ok ? 64.0f : 0.0f;
+  }
+  wave_sync();
+  VPHASE(5);
+  double out_val = 0.0;
+  if (lane < VIS_NSUM) {
+#pragma unroll
+    for (int sl = 0; sl < VIS_PPW; sl++) out_val += vis_expand(lane, rc, L.S[sl], L.Mx[sl], L.pe[sl], L.nm[sl]);
+  }
+  return out_val;
+}
+
+// the block's 8 wave vectors -> one partial row (fixed order: deterministic)
+__device__ __forceinline__ void vis_block_store(double (*red)[VIS_PSTRIDE], double out_val, double *__restrict__ partial_row) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (lane < VIS_PSTRIDE) red[wave][lane] = out_val;
   __syncthreads();
   if (tid < VIS_PSTRIDE) {
     double v = red[0][tid];
 #pragma unroll
     for (int w = 1; w < VIS_WAVES; w++) v = v + red[w][tid];
-    partials[(size_t)blockIdx.x * VIS_PSTRIDE + tid] = v;
+    partial_row[tid] = v;
   }
 }
 
+template <bool DEBUG_ROWS>
+__global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual(VisualKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+                                                               int check_stop) {
+  VPHASE(0);
+  if (check_stop && ctl->hdr.stop) return;
+  __shared__ VisWaveLds lds[VIS_WAVES];
+  __shared__ double red[VIS_WAVES][VIS_PSTRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int patch0 = (blockIdx.x * VIS_WAVES + wave) * VIS_PPW;   // wave-uniform
+  double out_val = 0.0;                                      // lane q < VIS_NSUM holds value q of this wave's patches
+  if (patch0 < a.M) out_val = visual_wave_body<DEBUG_ROWS>(a, ctl, lds[wave], patch0, lane);
+  VPHASE(6);
+  vis_block_store(red, out_val, partials + (size_t)blockIdx.x * VIS_PSTRIDE);
+  VPHASE(7);
+}
+
+// Batched launch: several independent computeJacobianAndUpdateEKF problems (own image, own sub-map, own state) in ONE grid per (level, iteration) —
+// the visual counterpart of k_lidar_residual_batch.  A frame whose level has ended (hdr.stop) drops out at its blocks' first instruction.
+struct VisualBatchEntry { VisualKernelArgs a; DevCtl *ctl; double *partials; int32_t block_begin, nblocks; };
+__global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual_batch(const VisualBatchEntry *__restrict__ entries, const int32_t *__restrict__ block_frame, int level, int check_stop) {
+  const int f = block_frame[blockIdx.x];
+  const VisualBatchEntry &e = entries[f];
+  if (e.a.M == 0 || (check_stop && e.ctl->hdr.stop)) return;      // total_points == 0: computeJacobianAndUpdateEKF returns at once (vio.cpp:786)
+  __shared__ VisWaveLds lds[VIS_WAVES];
+  __shared__ double red[VIS_WAVES][VIS_PSTRIDE];
+  VisualKernelArgs a = e.a;
+  a.level = level;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pblock = (int)blockIdx.x - e.block_begin;
+  const int patch0 = (pblock * VIS_WAVES + wave) * VIS_PPW;
+  double out_val = 0.0;
+  if (patch0 < a.M) out_val = visual_wave_body<false>(a, e.ctl, lds[wave], patch0, lane);
+  vis_block_store(red, out_val, e.partials + (size_t)pblock * VIS_PSTRIDE);
+}
+
+// ---- reduction + accept / revert + solve --------------------------------------------------------------------------------------------
 // mode 0: bare evaluation -> ctl->sums_v ; mode 1: full ESIKF step (accept / revert / solve) ; mode 2: benchmark (always accept, never stop)
-#define VIS_SOLVE_THREADS 480         // 12 slices x 40 values (<= 512 threads: the register-resident solve needs > 128 VGPRs)
-__global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
-                                                             int iter, double img_point_cov) {
+// Roles inside the 512-thread block (every wave stays alive to the last barrier):
+//   all waves : issue their partial-row loads (12 slices x 40 values, up to 48 rows per thread in flight at once = 576 rows per pass) and stage errors[] in LDS
+//   wave 0    : prefetch of P / states (before the rows arrive), then the 19-dim algebra, SPECULATIVELY (nothing is written to HBM yet)
+//   wave 1    : Log(cur^T prop) while the rows are in flight
+//   wave 2    : the frame error with the reference's float accumulation order — lane t adds the per-patch errors of OpenMP thread t's static block in
+//               index order (vio.cpp:1554, 1634), the T partial sums are joined in thread order (error_threads = MP_PROC_NUM of the reference build)
+//   then      : one barrier; wave 0 compares `error <= last_error` (vio.cpp:1648) and commits either the update or the revert.
+#define VIS_SOLVE_THREADS 480         // 12 slices x 40 values
+#define VIS_ERR_STAGE 8192            // per-patch errors staged per pass (floats)
+struct VisualSolveArgs { const float *errors; int32_t M, error_threads; };
+
+// acc + e[lo] + e[lo+1] + ... in this order, one float rounding per add (the serial CPU loop).  The adds are a dependent chain; the LDS reads are not, but
+// the compiler sinks them next to their first use (measured: 14.5 cycles per element, one exposed LDS round trip per 16 adds).  The reads are therefore issued
+// through asm statements in program order — 16 values ahead of the adds — and joined with an s_waitcnt that names the registers it releases.
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct F16 { v4f a, b, c, d; };
+__device__ __forceinline__ void lds_issue16(F16 &v, const float *p, float &acc) {
+  const uint32_t addr = (uint32_t)(uintptr_t)p;             // LDS addresses are 32-bit
+  // `acc` is tied to the statement so that the adds that follow in program order stay behind the issue (plain ALU code may otherwise cross an asm volatile)
+  asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48"
+               : "=&v"(v.a), "=&v"(v.b), "=&v"(v.c), "=&v"(v.d), "+v"(acc) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_land16(F16 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.a), "+v"(v.b), "+v"(v.c), "+v"(v.d)); }
+__device__ __forceinline__ float add16(float acc, const F16 &v) {
+  acc += v.a.x; acc += v.a.y; acc += v.a.z; acc += v.a.w; acc += v.b.x; acc += v.b.y; acc += v.b.z; acc += v.b.w;
+  acc += v.c.x; acc += v.c.y; acc += v.c.z; acc += v.c.w; acc += v.d.x; acc += v.d.y; acc += v.d.z; acc += v.d.w;
+  return acc;
+}
+__device__ __forceinline__ float float_chain(const float *e, int lo, int hi, float acc) {
+  int i = lo;
+  for (; i < hi && (i & 3); i++) acc += e[i];
+  if (i + 16 <= hi) {
+    F16 A, B;
+    lds_issue16(A, e + i, acc); lds_land16(A);
+    for (; i + 48 <= hi; i += 32) {
+      lds_issue16(B, e + i + 16, acc);
+      acc = add16(acc, A);
+      lds_land16(B);
+      lds_issue16(A, e + i + 32, acc);
+      acc = add16(acc, B);
+      lds_land16(A);
+    }
+    acc = add16(acc, A);
+    i += 16;
+  }
+  for (; i < hi; i++) acc += e[i];
+  return acc;
+}
+
+__device__ __forceinline__ void visual_solve_body(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level, int iter,
+                                                  double img_point_cov, VisualSolveArgs va) {
   __shared__ SolveLds s;
   __shared__ double sums[64];
   __shared__ double scratch[12 * 41];
+  __shared__ __attribute__((aligned(16))) float errs[VIS_ERR_STAGE];
+  __shared__ float err_chunk[LIVO2_WAVE];
+  __shared__ float err_total;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  VSPHASE(0);
   // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
   const int hdr_stop = ctl->hdr.stop, hdr_steps = ctl->hdr.n_steps;
   const float hdr_last_error = ctl->hdr.last_error;
   double craw[6];
-  if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, img_point_cov, threadIdx.x, craw);
-  if (mode != 0 && threadIdx.x == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
+  if (mode != 0 && wave == 0) esikf_prefetch_wave(ctl, s, img_point_cov, lane, craw);
+  if (mode != 0 && t == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
   {
-    // partial rows come from other CUs: every thread issues all its loads before the first add (slice s = rows s, s+12, ...)
-    const int t = threadIdx.x, kidx = t % VIS_PSTRIDE, slice = t / VIS_PSTRIDE;     // 12 slices
-    double v[32];
-#pragma unroll
-    for (int u = 0; u < 32; u++) { const int b = slice + 12 * u; v[u] = (b < nblocks) ? partials[(size_t)b * VIS_PSTRIDE + kidx] : 0.0; }
+    const int kidx = t % VIS_PSTRIDE, slice = t / VIS_PSTRIDE;     // 12 slices (threads >= 480 idle here)
     double acc = 0.0;
+    if (t < VIS_SOLVE_THREADS) {
+      for (int base = 0; base < nblocks; base += 12 * 48) {
+        double v[48];
 #pragma unroll
-    for (int u = 0; u < 32; u++) acc += v[u];
-    for (int b = slice + 384; b < nblocks; b += 12) acc += partials[(size_t)b * VIS_PSTRIDE + kidx];
-    scratch[slice * 41 + kidx] = acc;
-    __syncthreads();
-    if (t < VIS_PSTRIDE) {
-      double r = scratch[t];
+        for (int u = 0; u < 48; u++) { const int b = base + slice + 12 * u; v[u] = (b < nblocks) ? partials[(size_t)b * VIS_PSTRIDE + kidx] : 0.0; }
 #pragma unroll
-      for (int sl = 1; sl < 12; sl++) r += scratch[sl * 41 + t];
-      sums[t] = r;
+        for (int u = 0; u < 48; u++) acc += v[u];
+      }
+      scratch[slice * 41 + kidx] = acc;
     }
-    __syncthreads();
   }
-  if (mode == 1 && iter > 0 && hdr_stop) return;
-  if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave; s_barrier only counts live waves
-  const int lane = threadIdx.x;
-  if (lane < 49) {
-    int r = lane / 7, c = lane % 7;
-    int u = r < c ? r : c, v = r < c ? c : r;
-    int idx = u * 7 - (u * (u - 1)) / 2 + (v - u);
-    s.hth[lane] = sums[idx];
+  // frame error, part 1: stage the per-patch errors in LDS (the first VIS_ERR_STAGE of them; a larger sub-map reads the rest from HBM)
+  const int n_stage = min(VIS_ERR_STAGE, va.M);
+  {
+    float ev[VIS_ERR_STAGE / 512];                           // all loads of a thread in flight at once (a load-store loop costs one HBM round trip per turn)
+#pragma unroll
+    for (int u = 0; u < VIS_ERR_STAGE / 512; u++) { const int i = t + 512 * u; ev[u] = (i < n_stage) ? va.errors[i] : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < VIS_ERR_STAGE / 512; u++) { const int i = t + 512 * u; if (i < n_stage) errs[i] = ev[u]; }
   }
-  if (lane < 7) s.htz[lane] = sums[28 + lane];
+  VSPHASE(1);
+  __syncthreads();                                           // scratch, s.vec[0..2] (Log), s.P / s.cur / s.prop, errs visible
+  VSPHASE(2);
+  if (mode == 1 && iter > 0 && hdr_stop) return;            // block-uniform: the level has ended, the residual kernel did not run
+  if (t < VIS_PSTRIDE) {
+    double rr = scratch[t];
+#pragma unroll
+    for (int sl = 1; sl < 12; sl++) rr += scratch[sl * 41 + t];
+    sums[t] = rr;
+  }
   __syncthreads();
+  VSPHASE(3);
+  if (wave == 0) {                                           // the 19-dim algebra, speculative: LDS only
+    if (lane < 49) {
+      int rr = lane / 7, c = lane % 7;
+      int u = rr < c ? rr : c, v = rr < c ? c : rr;
+      int idx = u * 7 - (u * (u - 1)) / 2 + (v - u);
+      s.hth[lane] = sums[idx];
+    }
+    if (lane < 7) s.htz[lane] = sums[28 + lane];
+    wave_sync();
+    if (mode != 0) esikf_solve_wave<7>(s, -1, lane);
+  } else if (wave == 2) {                                    // frame error, part 2: lane c owns OpenMP thread c's static block of patches (libgomp: the first
+    const int T = va.error_threads < 1 ? 1 : (va.error_threads > LIVO2_WAVE ? LIVO2_WAVE : va.error_threads);   // M % T threads get one patch more)
+    const int q = va.M / T, r = va.M % T;
+    const int my_begin = lane < r ? lane * (q + 1) : lane * q + r, my_end = my_begin + (lane < r ? q + 1 : q);
+    float priv = 0.0f;
+    if (lane < T) {
+      const int mid = min(my_end, n_stage);
+      priv = float_chain(errs, my_begin, mid, priv);
+      for (int i = max(my_begin, n_stage); i < my_end; i++) priv += va.errors[i];
+      err_chunk[lane] = priv;
+    }
+    wave_sync();
+    if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += err_chunk[c]; err_total = e; }
+  }
+  VSPHASE(4);
+  __syncthreads();
+  VSPHASE(5);
+  if (wave != 0) return;                                     // the rest is one wave; only wave-local synchronisation below
   const double err_sum = sums[35];
   const int n_meas = (int)sums[36];
-  float error = (float)err_sum;
+  float error = err_total;
   error = error / n_meas;                                   // float / int (vio.cpp:1636); NaN when n_meas == 0
   if (mode == 0) {
     if (lane < 49) ctl->sums_v.HtH[lane] = s.hth[lane];
@@ -244,9 +498,9 @@ __global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, 
       double *dst = reinterpret_cast<double *>(&ctl->old);
       if (lane < 25) dst[lane] = s.cur[lane];
 #pragma unroll
-      for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; if (e < DS * DS) dst[25 + e] = craw[q]; }
+      for (int qq = 0; qq < 6; qq++) { const int e = lane + qq * LIVO2_WAVE; if (e < DS * DS) dst[25 + e] = craw[qq]; }
     }
-    esikf_update_wave<7>(ctl, s, -1, lane);
+    esikf_commit_wave(ctl, s, lane);
     const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
     const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
     if ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) stop = 1;   // vio.cpp:1675
@@ -273,9 +527,23 @@ __global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, 
     if (st) { st->level = level; st->iteration = iter; st->accepted = accepted ? 1 : 0; st->n_meas = n_meas; st->error = error; st->pad = 0; }
     ctl->hdr.n_steps = step + 1;
   }
+  VSPHASE(6);
+  VSPHASE(7);
 }
 
-__global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict__ ctl, VisualKernelArgs a, int update_cov) {
+__global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
+                                                             int iter, double img_point_cov, VisualSolveArgs va) {
+  visual_solve_body(ctl, partials, nblocks, mode, level, iter, img_point_cov, va);
+}
+// one block per frame of a batch
+__global__ void __launch_bounds__(512) k_visual_solve_batch(const VisualBatchEntry *__restrict__ entries, int mode, int level, int iter, double img_point_cov, int error_threads) {
+  const VisualBatchEntry &e = entries[blockIdx.x];
+  if (e.a.M == 0) return;                                    // total_points == 0 (vio.cpp:786): no step is taken, no step is recorded
+  VisualSolveArgs va = {e.a.errors, e.a.M, error_threads};
+  visual_solve_body(e.ctl, e.partials, e.nblocks, mode, level, iter, img_point_cov, va);
+}
+
+__device__ __forceinline__ void visual_finish_body(DevCtl *__restrict__ ctl, const VisualKernelArgs &a, int update_cov) {
   __shared__ double cov[DS * DS];
   const int lane = threadIdx.x;
   if (update_cov) {
@@ -303,3 +571,5 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict
   for (int e = lane; e < (int)(sizeof(livo2_state) / sizeof(double)); e += LIVO2_WAVE) dst[e] = src[e];
   for (int e = lane; e < DS * DS; e += LIVO2_WAVE) ctl->visual.G[e] = ctl->G[e];
 }
+
+__global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict__ ctl, VisualKernelArgs a, int update_cov) { visual_finish_body(ctl, a, update_cov); }

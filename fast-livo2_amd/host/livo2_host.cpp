@@ -299,6 +299,16 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   dev_.check(livo2_lidar_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, &pts));
   state_.from_abi(res.state);
   std::memcpy(position_last_.data(), res.position_last, 24);
+  {   // euler_cur = RotMtoEuler(state_.rot_end) (so3_math.h:68-87); geoQuat_ = tf::createQuaternionMsgFromRollPitchYaw(euler_cur) (voxel_map.cpp:493)
+    const double *R = res.state.rot;
+    const double sy = std::sqrt(R[0] * R[0] + R[3] * R[3]);
+    double ex, ey, ez;
+    if (!(sy < 1e-6)) { ex = std::atan2(R[7], R[8]); ey = std::atan2(-R[6], sy); ez = std::atan2(R[3], R[0]); }
+    else { ex = std::atan2(-R[5], R[4]); ey = std::atan2(-R[6], sy); ez = 0.0; }
+    const double hr = ex * 0.5, hp = ey * 0.5, hy = ez * 0.5;                       // tf::Quaternion::setRPY
+    const double cr = std::cos(hr), sr = std::sin(hr), cp = std::cos(hp), sp = std::sin(hp), cy = std::cos(hy), sn = std::sin(hy);
+    geoQuat_ = {{sr * cp * cy - cr * sp * sn, cr * sp * cy + sr * cp * sn, cr * cp * sn - sr * sp * cy, cr * cp * cy + sr * sp * sn}};
+  }
 
   // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811)
   pv_list_.assign(n, pointWithVar());
@@ -544,12 +554,20 @@ void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
   cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = 0; cfg.cam.width = width; cfg.cam.height = height;
   std::memcpy(cfg.Rcl, Rcl.data(), 72); std::memcpy(cfg.Pcl, Pcl.data(), 24); std::memcpy(cfg.extR, extR.data(), 72); std::memcpy(cfg.extT, extT.data(), 24);
   cfg.img_point_cov = img_point_cov; cfg.patch_pyrimid_level = L; cfg.max_iterations = max_iterations;
-  cfg.exposure_estimate_en = exposure_estimate_en; cfg.inverse_composition_en = inverse_composition_en;
+  cfg.exposure_estimate_en = exposure_estimate_en; cfg.inverse_composition_en = inverse_composition_en; cfg.mp_proc_num = mp_proc_num;
+  compute_jacobian_time = update_ekf_time = 0.0;                                            // vio.cpp:788
+  if (kernel_times_en) { dev_.check(livo2_ctx_kernel_timing(dev_.ctx(), 1)); livo2_ctx_kernel_timing_read(dev_.ctx(), 1, nullptr, nullptr, 1); livo2_ctx_kernel_timing_read(dev_.ctx(), 3, nullptr, nullptr, 1); }
   livo2_state s_in, s_prop;
   state->to_abi(s_in); state_propagat->to_abi(s_prop);
   static livo2_visual_result res;
   visual_submap->errors.resize(M);
   dev_.check(livo2_visual_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, visual_submap->errors.data()));
+  if (kernel_times_en) {
+    double ms = 0; int64_t nl = 0;
+    dev_.check(livo2_ctx_kernel_timing_read(dev_.ctx(), 1, &ms, &nl, 1)); compute_jacobian_time = ms * 1e-3;
+    dev_.check(livo2_ctx_kernel_timing_read(dev_.ctx(), 3, &ms, &nl, 1)); update_ekf_time = ms * 1e-3;
+    dev_.check(livo2_ctx_kernel_timing(dev_.ctx(), 0));
+  }
   state->from_abi(res.state);
   std::memcpy(G.data(), res.G, sizeof(res.G));
   std::memcpy(Rcw.data(), res.Rcw, 72); std::memcpy(Pcw.data(), res.Pcw, 24);     // new_frame_->T_f_w_ = SE3(Rcw, Pcw)

@@ -135,6 +135,7 @@ public:
   V3D extT_{};
   StatesGroup state_;
   V3D position_last_{};
+  std::array<double, 4> geoQuat_{{0, 0, 0, 1}};   // geometry_msgs::Quaternion x, y, z, w (reference include/voxel_map.h:212, src/voxel_map.cpp:493)
   std::vector<M3D> cross_mat_list_, body_cov_list_;
   std::vector<pointWithVar> pv_list_;
   std::vector<PointToPlane> ptpl_list_;
@@ -240,6 +241,9 @@ public:
   int patch_pyrimid_level = 4, patch_size = 8, max_iterations = 5, total_points = 0;
   double img_point_cov = 100;
   bool exposure_estimate_en = true, inverse_composition_en = false, normal_en = true, ncc_en = false;
+  int mp_proc_num = 4;                          // MP_PROC_NUM of the reference build (CMakeLists.txt:44-55): partition of the float error reduction (vio.cpp:1554)
+  double compute_jacobian_time = 0, update_ekf_time = 0;   // reference include/vio.h:114: seconds inside the residual / solve kernels of the last update when
+  bool kernel_times_en = false;                 // kernel_times_en (HIP event pair per launch, off by default: the events cost what they measure); else 0 (vio.cpp:788)
   double ncc_thre = 0, outlier_threshold = 1000;
   M3D R_f_w_new{{1, 0, 0, 0, 1, 0, 0, 0, 1}};   // new_frame_->T_f_w_ (reference include/frame.h:34)
   V3D t_f_w_new{};

@@ -123,6 +123,7 @@ int main(int argc, char **argv) {
       wr(dir, "out_pv_normal", normals.data(), normals.size()); wr(dir, "out_pv_var", pvvar.data(), pvvar.size());
       wr(dir, "out_ptpl_dis", dis.data(), dis.size()); wr(dir, "out_ptpl_pw", ptw.data(), ptw.size());
       int32_t eff = vm.effct_feat_num_; wr(dir, "out_effct", &eff, 1);
+      wr(dir, "out_geoquat", vm.geoQuat_.data(), 4);
       std::printf("lidar: effct_feat_num_=%d\n", vm.effct_feat_num_);
       // ---- UpdateVoxelMap's re-fits in bulk (src/voxel_map.cpp:55-135 via VoxelMapManager::FitPlanes), then the next frame's update ----
       auto fit_plane = rd<int32_t>(dir, "fit_plane");
@@ -285,8 +286,10 @@ int main(int argc, char **argv) {
       StatesGroup st = state_from(rd<double>(dir, "vis_state_in")), prop = state_from(rd<double>(dir, "vis_state_prop"));
       vio.state = &st; vio.state_propagat = &prop;
       GrayImage g{img.data(), vio.width, vio.height, vio.width};
+      vio.kernel_times_en = true;
       vio.computeJacobianAndUpdateEKF(g);                              // <- the reference call site (src/vio.cpp:1810)
       auto so = state_to(st);
+      { double tms[2] = {vio.compute_jacobian_time, vio.update_ekf_time}; wr(dir, "vis_out_times", tms, 2); }
       wr(dir, "vis_out_state", so.data(), so.size());
       wr(dir, "vis_out_errors", sm.errors.data(), sm.errors.size());
       wr(dir, "vis_out_G", vio.G.data(), vio.G.size());

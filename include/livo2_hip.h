@@ -262,6 +262,11 @@ typedef struct livo2_visual_cfg {
   int32_t max_iterations;       /* vio/max_iterations */
   int32_t exposure_estimate_en; /* vio/exposure_estimate_en */
   int32_t inverse_composition_en; /* vio/inverse_composition_en: 1 = updateStateInverse (needs livo2_visual_set_reference) */
+  int32_t mp_proc_num;          /* MP_PROC_NUM of the reference build (CMakeLists.txt:44-55; 4 on any host with more than 4 cores): the frame error of updateState
+                                 * is a FLOAT OpenMP reduction (vio.cpp:1546-1554, 1634) — thread t adds the per-patch errors of its static block of patches in
+                                 * index order, the per-thread sums are joined (here: in thread order; the reference: in completion order).  0 or 1 = the serial
+                                 * loop (a build without MP_EN, and always updateStateInverse, which has no OpenMP loop).  Decides `error <= last_error` at ties. */
+  int32_t pad;
 } livo2_visual_cfg;
 
 /* Upload the current gray image (CV_8UC1, row stride `stride` bytes) and the visual sub-map arrays the update reads
@@ -430,6 +435,23 @@ int livo2_visual_update_async(livo2_ctx *ctx, const livo2_state *state_in, const
 int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float *errors);
 int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_state *state_in, const livo2_state *prop,
                                   const livo2_visual_cfg *cfg, int32_t iters);
+
+/* ---- batch of frames, visual (offline / replay: BASELINE config "batched frames") ------------------------------------------------------
+ * n_frames independent VIOManager::computeJacobianAndUpdateEKF problems (src/vio.cpp:784-802; call site vio.cpp:1810) — each with its own gray image,
+ * visual sub-map (SubSparseMap arrays as in livo2_visual_set_frame), *state and *state_propagat — advanced in lockstep: every (level, iteration) is ONE residual
+ * grid over the patches of all frames plus one solve block per frame; a frame whose level has ended (EKF_end, vio.cpp:1675-1681) drops out of the level's later
+ * grids.  Every frame makes the same decisions and produces the same bits as its own livo2_visual_update call (same kernels, same per-frame reduction order).
+ * imgs: n_frames images of width x height with row stride `stride`, back to back; pos / warp_patch / search_levels / inv_expo_list: the frames' arrays
+ * concatenated; counts[f] = total_points of frame f (0 allowed).  The forward-compositional form only (inverse_composition_en must be 0). */
+int livo2_visual_batch_set_frames(livo2_ctx *ctx, int32_t n_frames, const uint8_t *imgs, int32_t width, int32_t height, int32_t stride, const double *pos,
+                                  const float *warp_patch, const int32_t *search_levels, const double *inv_expo_list, const int32_t *counts, int32_t L);
+int livo2_visual_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg,
+                              livo2_visual_result *results);
+int livo2_visual_batch_update_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg);
+int livo2_visual_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_visual_result *results);
+/* fixed iteration count at one level, always accepted, no stopping (bench.py) */
+int livo2_visual_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, int32_t level, const livo2_state *state_in, const livo2_state *prop,
+                                        const livo2_visual_cfg *cfg, int32_t iters);
 
 /* ---- one LiDAR-inertial frame on the device (N4 -> N3 -> the update) ------------------------------------------------------
  * What LIVMapper::handleLIO does with a synchronised (scan, IMU) package before the map update (src/LIVMapper.cpp:342-377):

@@ -386,10 +386,13 @@ def lidar_state_estimation(omap, cfg, xyz, state_in, prop, want_points=True):
     return dict(state=out, n_iters=nit.value, seconds=secs.value, trace=[trace[i] for i in range(nit.value)], **(b if want_points else {}))
 
 
-def visual_cfg(sc, num_threads=1, exposure=True, inverse=False, max_iterations=None):
+def visual_cfg(sc, num_threads=1, exposure=True, inverse=False, max_iterations=None, distortion=None):
     cfg = VisualCfg()
     cfg.fx, cfg.fy, cfg.cx, cfg.cy = sc.cam["fx"], sc.cam["fy"], sc.cam["cx"], sc.cam["cy"]
     cfg.distortion, cfg.width, cfg.height = 0, sc.cam["width"], sc.cam["height"]
+    if distortion is not None:                      # vk::PinholeCamera radial-tangential d0..d4
+        cfg.distortion = 1
+        cfg.d[:] = [float(x) for x in distortion]
     cfg.patch_pyrimid_level = int(sc.cfg["patch_pyrimid_level"])
     cfg.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
     cfg.exposure_estimate_en, cfg.inverse_composition_en, cfg.num_threads = int(exposure), int(inverse), num_threads

@@ -30,7 +30,7 @@ typedef Mat<3, 3> M3;
 // ---- summation-order model of the two long reductions of the path (voxel_map.cpp:464-466, vio.cpp:1660-1662) -------------------------
 // The reference evaluates them with Eigen (GEMM / GEMV), whose order of additions depends on the Eigen version, the SIMD width and the
 // cache-derived blocking of the build.  Mode 0 (the parity checker): strict left-to-right, one rounding per operation.  Mode 1
-// ("Eigen-like", tools/oracle_sensitivity.py only): GEMM = the depth is cut into panels of `kc` (Eigen's gebp blocking), a panel is a
+// ("Eigen-like", tests/sweeps/oracle_sensitivity.py only): GEMM = the depth is cut into panels of `kc` (Eigen's gebp blocking), a panel is a
 // sequential FMA chain, panels are added in order; column-major GEMV = one sequential FMA chain; row-major GEMV = `lanes` interleaved
 // FMA chains (a SIMD packet) reduced pairwise, the tail added sequentially.  Used to bound how far the reference's OWN build can move
 // the answer (profiles/r02_oracle_sensitivity.txt); never by the parity tests.

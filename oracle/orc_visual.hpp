@@ -120,11 +120,14 @@ public:
     Rcw = Rci * Rwi.T();
     Pcw = -Rci * Rwi.T() * Pwi + Pci;
     Jdp_dt = Rci * Rwi.T();
-    float error = 0.0;
     int n_meas = 0;
+    // `#pragma omp parallel for reduction(+:error, n_meas)` with MP_PROC_NUM threads (vio.cpp:1551-1555): libgomp's default static schedule gives thread t
+    // one contiguous block of patches, every thread adds its patches' float errors in index order into a private 0-initialised float, and the private sums
+    // are added to `error` in the order the threads finish — the one part the reference leaves to chance (Q9).  The oracle pins that order to thread 0, 1, 2, ...
+    // (reduce_error_static below), so the result does not depend on how many cores run the loop; num_threads_ = 1 is the serial loop.
 #ifdef _OPENMP
     omp_set_num_threads(num_threads_);
-#pragma omp parallel for reduction(+ : error, n_meas)
+#pragma omp parallel for reduction(+ : n_meas)
 #endif
     for (int i = 0; i < total_points; i++) {
       Mat<1, 2> Jimg; Mat<2, 3> Jdpi; Mat<1, 3> Jdphi, Jdp, JdR, Jdt;
@@ -179,10 +182,24 @@ public:
         }
       }
       visual_submap->errors[i] = patch_error;
-      error += patch_error;
     }
+    float error = reduce_error_static(visual_submap->errors.data(), total_points, num_threads_);
     error = error / n_meas;
     n_meas_out = n_meas;
+    return error;
+  }
+
+  // float sum of the per-patch errors in the order of an OpenMP static partition over `threads` threads, partial sums joined in thread order
+  static float reduce_error_static(const float *e, int n, int threads) {
+    const int T = threads > 0 ? threads : 1;
+    const int q = n / T, r = n % T;
+    float error = 0.0f;
+    for (int t = 0; t < T; t++) {
+      const int begin = t < r ? t * (q + 1) : t * q + r, cnt = t < r ? q + 1 : q;
+      float priv = 0.0f;
+      for (int i = begin; i < begin + cnt; i++) priv += e[i];
+      error += priv;
+    }
     return error;
   }
 

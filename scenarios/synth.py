@@ -426,7 +426,21 @@ class VisualScenario:
     cfg: dict
 
 
-def visual_scenario(seed=3, n_patches=2000, L=4, rot_sigma_deg=0.05, pos_sigma=0.004, noise_sigma=1.0, R_true=None, t_true=None):
+AVIA_RADTAN = (-0.076160, 0.123001, -0.00113, 0.000251, 0.0)      # config/camera_pinhole.yaml:9-12 cam_d0..cam_d3 (+ d4 = 0); the coefficients act on
+                                                                   # normalised coordinates, so the yaml's `scale: 0.5` leaves them unchanged
+
+
+def radtan_project(cam, d, pf):
+    """vk::PinholeCamera::world2cam with distortion (rpg_vikit): pf [.., 3] camera-frame points -> pixels [.., 2]"""
+    x, y = pf[..., 0] / pf[..., 2], pf[..., 1] / pf[..., 2]
+    r2 = x * x + y * y; r4 = r2 * r2; r6 = r4 * r2
+    a1, a2, a3 = 2 * x * y, r2 + 2 * x * x, r2 + 2 * y * y
+    cd = 1 + d[0] * r2 + d[1] * r4 + d[4] * r6
+    xd, yd = x * cd + d[2] * a1 + d[3] * a2, y * cd + d[2] * a3 + d[3] * a1
+    return np.stack([xd * cam["fx"] + cam["cx"], yd * cam["fy"] + cam["cy"]], -1)
+
+
+def visual_scenario(seed=3, n_patches=2000, L=4, rot_sigma_deg=0.05, pos_sigma=0.004, noise_sigma=1.0, R_true=None, t_true=None, distortion=None):
     rng = np.random.default_rng(seed)
     cam = dict(AVIA["cam"])
     cfg = dict(AVIA["vio"])
@@ -453,7 +467,7 @@ def visual_scenario(seed=3, n_patches=2000, L=4, rot_sigma_deg=0.05, pos_sigma=0
     warp = np.zeros((n_patches, L, 64), np.float32)
     for i in range(n_patches):
         pf = Rcw @ pos[i] + Pcw
-        pc = np.array([cam["fx"] * pf[0] / pf[2] + cam["cx"], cam["fy"] * pf[1] / pf[2] + cam["cy"]])
+        pc = np.array([cam["fx"] * pf[0] / pf[2] + cam["cx"], cam["fy"] * pf[1] / pf[2] + cam["cy"]]) if distortion is None else radtan_project(cam, distortion, pf)
         for lvl in range(L):
             cur = sample_patch(img, pc, 1 << (lvl + int(search[i]))).astype(np.float64)
             warp[i, lvl] = (cur * (tau_true / inv_ref[i]) + rng.normal(0, noise_sigma, (8, 8))).astype(np.float32).ravel()

@@ -28,7 +28,7 @@ def states(sc, cls, R=None, t=None, inv_expo=1.0):
     return cur, prior
 
 
-def visual_cfg_product(sc, exposure=True, max_iterations=None, inverse=False):
+def visual_cfg_product(sc, exposure=True, max_iterations=None, inverse=False, mp_proc_num=1, distortion=None):
     livo2 = product()
     c = livo2.VisualCfg()
     c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = sc.cam["fx"], sc.cam["fy"], sc.cam["cx"], sc.cam["cy"]
@@ -37,7 +37,10 @@ def visual_cfg_product(sc, exposure=True, max_iterations=None, inverse=False):
     c.img_point_cov = float(sc.cfg["img_point_cov"])
     c.patch_pyrimid_level = int(sc.cfg["patch_pyrimid_level"])
     c.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
-    c.exposure_estimate_en, c.inverse_composition_en = int(exposure), int(inverse)
+    c.exposure_estimate_en, c.inverse_composition_en, c.mp_proc_num = int(exposure), int(inverse), int(mp_proc_num)
+    if distortion is not None:                      # radial-tangential d0..d4 of vk::PinholeCamera
+        c.cam.distortion = 1
+        c.cam.d[:] = [float(x) for x in distortion]
     return c
 
 

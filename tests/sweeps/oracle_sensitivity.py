@@ -13,7 +13,7 @@ and Eigen's GEMM / GEMV order of additions for `Hsub_T_R_inv * Hsub`, `Hsub_T_R_
 
 and reports, against A: matched-plane flips of the LAST iteration's match list, iteration-count changes, spread of the accumulated update
 `x_final [-] x_prior` (relative) for the LiDAR update; accept/revert sequence changes, per-step float error differences and pose spread for the visual update.
-Usage: python tools/oracle_sensitivity.py [n_lidar] [n_visual] > profiles/r02_oracle_sensitivity.txt
+Usage: python tests/sweeps/oracle_sensitivity.py [n_lidar] [n_visual] > profiles/r02_oracle_sensitivity.txt
 """
 import os
 import sys
@@ -21,7 +21,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import orc  # noqa: E402
 from scenarios import synth  # noqa: E402

@@ -99,12 +99,18 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     assert np.array_equal(np.fromfile(os.path.join(d, "out_ptpl_dis.bin"), dtype=np.float32), ref["dis"][ref["match_plane"] >= 0])      # ptpl_list_ keeps point order
     assert np.array_equal(np.fromfile(os.path.join(d, "out_pv_normal.bin")).reshape(-1, 3), ref["normal"])
     assert H.relerr(np.fromfile(os.path.join(d, "out_pv_var.bin")).reshape(-1, 9), ref["var"]) < 1e-13
+    # geoQuat_ = createQuaternionMsgFromRollPitchYaw(RotMtoEuler(state_.rot_end)) (voxel_map.cpp:493): the quaternion of the posterior rotation, up to sign
+    from scipy.spatial.transform import Rotation
+    q, qr = np.fromfile(os.path.join(d, "out_geoquat.bin")), Rotation.from_matrix(out[:9].reshape(3, 3)).as_quat()
+    assert min(np.abs(q - qr).max(), np.abs(q + qr).max()) < 1e-12
 
-    vref = orc.visual_update(orc.visual_cfg(vs), vs, vcur, vprop)
+    vref = orc.visual_update(orc.visual_cfg(vs, num_threads=4), vs, vcur, vprop)           # the shim's default mp_proc_num = 4 (MP_PROC_NUM of the reference build)
+    tms = np.fromfile(os.path.join(d, "vis_out_times.bin"))
+    assert 0 < tms[0] < 1e-2 and 0 < tms[1] < 1e-2                                          # compute_jacobian_time / update_ekf_time in seconds (vio.h:114)
     vout = np.fromfile(os.path.join(d, "vis_out_state.bin"))
     vrefv = _state_vec(vref["state"])
     assert np.allclose(vout[:25], vrefv[:25], rtol=0, atol=1e-9) and H.relerr(vout[25:], vrefv[25:]) < 1e-8
-    assert np.allclose(np.fromfile(os.path.join(d, "vis_out_errors.bin"), dtype=np.float32), vref["errors"], rtol=1e-5)
+    assert np.array_equal(np.fromfile(os.path.join(d, "vis_out_errors.bin"), dtype=np.float32), vref["errors"])
     assert H.relerr(np.fromfile(os.path.join(d, "vis_out_G.bin")).reshape(19, 19), vref["G"]) < 1e-7
 
     # FitPlanes: fitted members vs the oracle's init_plane, and the second update vs the same refresh done through the Python ABI wrappers
@@ -134,7 +140,7 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     assert np.array_equal(np.fromfile(os.path.join(d, "retr_out_search.bin"), dtype=np.int32), wref["search_level"][keep])
     vs_r.img, vs_r.pos, vs_r.warp_patch, vs_r.search_levels, vs_r.inv_expo_list = rs.img, rs.pos[keep], wref["patch_wrap"][keep], wref["search_level"][keep], rs.ref_inv_expo[keep]
     rcur.inv_expo = rs.inv_expo_cur
-    vref2 = orc.visual_update(orc.visual_cfg(vs_r), vs_r, rcur, rprop)
+    vref2 = orc.visual_update(orc.visual_cfg(vs_r, num_threads=4), vs_r, rcur, rprop)
     vout2 = np.fromfile(os.path.join(d, "retr_out_state.bin"))
     vref2v = _state_vec(vref2["state"])
     assert np.allclose(vout2[:25], vref2v[:25], rtol=0, atol=1e-8) and H.relerr(vout2[25:], vref2v[25:]) < 1e-7
@@ -206,7 +212,7 @@ def test_shim_retrieve_from_visual_sparse_map(tmp_path, orc, normal_en):
     vs_c.img, vs_c.pos, vs_c.warp_patch = cs.img, cs.sel.pos[ref["sub_point"]], ref["tail"]["patch_wrap"][keep]
     vs_c.search_levels, vs_c.inv_expo_list = ref["tail"]["search_level"][keep], cs.obs_inv_expo[ref["sub_obs"]]
     ccur.inv_expo = cs.inv_expo_cur
-    vref = orc.visual_update(orc.visual_cfg(vs_c), vs_c, ccur, cprop)
+    vref = orc.visual_update(orc.visual_cfg(vs_c, num_threads=4), vs_c, ccur, cprop)
     vout = rd("state", np.float64)
     vrefv = _state_vec(vref["state"])
     assert np.allclose(vout[:25], vrefv[:25], rtol=0, atol=1e-8) and H.relerr(vout[25:], vrefv[25:]) < 1e-7

@@ -67,6 +67,39 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
         "visual_level0": {"patches": w.M, "evals_per_s": 64.0 * w.M * steps / dtv, "us_per_iteration": 1e6 * dtv / steps, "residual_kernel_us": vres_us, "solve_kernel_us": vsol_us,
                           "achieved_GBps": VISUAL_BYTES_PER_PATCH * w.M / (vres_us * 1e-6) / 1e9, "frac": VISUAL_BYTES_PER_PATCH * w.M / (vres_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
         "note": "fixed iteration count, no convergence stop (livo2_*_iterations_async): every launch executes"}
+    # The SAME step (w.F frame updates of the C4 frame from the same priors) executed in LOCKSTEP: one k_lidar_residual_batch grid over the F scans + F solve blocks
+    # per ESIKF iteration (livo2_lidar_batch_*), then one k_visual_residual_batch grid over the F x M patches + F solve blocks per (level, iteration)
+    # (livo2_visual_batch_*).  Per-frame decisions and results as in the frame-at-a-time headline; the latency-bound kernels are shared by F frames.
+    try:
+        ctx.batch_set_scans([w.sc.xyz] * w.F, w.cfg)
+        ctx.visual_batch_set_frames([(w.vs.img, w.vs.pos, w.vs.warp_patch, w.vs.search_levels, w.vs.inv_expo_list)] * w.F)
+        rb = ctx.batch_update(w.lid, w.lid, w.cfg)
+        vb = ctx.visual_batch_update(w.vis, w.vis, w.vcfg)
+        it_b, st_b = [int(r.n_iters) for r in rb], [int(v.n_steps) for v in vb]
+        evals_b = float(sum(it_b)) * w.N + float(sum(st_b)) * 64.0 * w.M
+        def lockstep(k):
+            for _ in range(k):
+                ctx.batch_update_async(w.lid, w.lid, w.cfg)
+                ctx.visual_batch_update_async(w.vis, w.vis, w.vcfg)
+        ksteps = 10
+        dtb, us_b = _timed_iters(ctx, lockstep, ksteps, (0, 1, 2, 3))
+        n_lid_b, n_vis_b = max(it_b) * ksteps, max(st_b) * ksteps         # launches in which at least one frame is still iterating
+        lres_us, vres_us = us_b[0] * (w.cfg.max_iterations * ksteps) / n_lid_b, us_b[1] * (4 * w.vcfg.max_iterations * ksteps) / n_vis_b
+        ach_b = LIDAR_BYTES_PER_EVAL * w.N * w.F / (lres_us * 1e-6) / 1e9
+        vach_b = VISUAL_BYTES_PER_PATCH * w.M * w.F / (vres_us * 1e-6) / 1e9
+        traffic_b, note_b = _load_traffic("r02_traffic_c4_lockstep.json", points=w.N * w.F)
+        extra["c4_lockstep"] = {"frames_per_launch": w.F, "evals_per_s": evals_b * ksteps / dtb, "ms_per_step": 1e3 * dtb / ksteps, "frame_updates_per_s": w.F * ksteps / dtb,
+                                "evals_per_step": evals_b, "lidar_iterations_per_frame": it_b, "visual_steps_per_frame": st_b,
+                                "same_iteration_counts_as_headline": it_b == list(w.iters) and st_b == list(w.vsteps),
+                                "roofline": {"bound": "hbm", "kernel": "k_lidar_residual_batch", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
+                                             "frac_of_copy_kernel": ach_b / copy_gbs, "kernel_us": lres_us, "bytes_per_launch": LIDAR_BYTES_PER_EVAL * w.N * w.F, "traffic": traffic_b,
+                                             "traffic_note": note_b,
+                                             "visual": {"kernel": "k_visual_residual_batch", "achieved": vach_b, "frac": vach_b / HBM_PEAK_GBS, "kernel_us": vres_us,
+                                                        "bytes_per_launch": VISUAL_BYTES_PER_PATCH * w.M * w.F}},
+                                "note": "kernel_us = total event time of all launches / launches in which a frame still iterates (upper bound, as in the headline roofline); the F frames "
+                                        "share one map snapshot and one image here, so their records are cache hits after the first frame — extra.out_of_cache is the leg that streams from HBM"}
+    except Exception as exc:
+        extra["c4_lockstep"] = {"error": repr(exc)}
     # whole frames per second with the PCIe legs: scan + image + sub-map H2D (pageable caller memory), Morton sort / body covariance, both updates, per-point outputs
     # (pv_list_ / ptpl_list_ members of SURVEY 8b) D2H, results D2H.  The map stays resident (map maintenance is its own leg).
     want = ("match_plane", "dis_to_plane", "point_w", "normal_plane", "var", "body_cov")
@@ -154,38 +187,6 @@ def _load_traffic(name, **match):
     except Exception:
         pass
     return None, "no PMC pass recorded for this workload; see profiles/"
-
-
-def cpu_widened_rows(lib):
-    """oracle timings of the widened rows on one host core (the figures the widened_rows notes refer to)"""
-    from oracle import orc
-    from scenarios import synth as _synth
-    from tests import imu_inputs as IMU
-    pw, var, off = plane_fit_groups()
-    orc.init_plane_batch(pw, var, off, 0.0025, lib)
-    _, fit_s = orc.init_plane_batch(pw, var, off, 0.0025, lib)
-    rs = _synth.retrieve_scenario(seed=21, n_cand=2000)
-    orc.warp_candidates(rs, lib)
-    warp_s = min(orc.warp_candidates(rs, lib)["seconds"] for _ in range(3))
-    ist = IMU.make_state(orc, orc.StatePOD, 0)
-    orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)
-    imu_us = 1e6 * min(orc.imu_propagate(ist, IMU.make_steps(0, n=20), IMU.CFG, lib)[2] for _ in range(5))
-    ss = _synth.select_scenario(seed=71, n_pg=10000, n_vis=100000)
-    orc.visual_select(ss, lib)
-    sel_s = min(orc.visual_select(ss, lib)["seconds"] for _ in range(3))
-    cs = _synth.retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=30000, grid_n_height=102, normal_en=True)
-    tch = []
-    for _ in range(3):
-        t0 = time.perf_counter(); orc.visual_retrieve(cs, lib); tch.append(time.perf_counter() - t0)
-    raw = _synth.raw_scan_scenario(seed=51, n_raw=240000)
-    tpre = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
-        orc.voxel_grid(u_, raw.leaf, lib)
-        tpre.append(time.perf_counter() - t0)
-    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
-            "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s}
 
 
 def widened_rows(ctx, livo2, synth, H, sc, cfg):
