@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per launch in the batched-frames legs (extra); 0 disables them")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational legs")
+    ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,live,c2,c3,batched,ooc); default all; the widened rows run only with all")
     ap.add_argument("--dist-selftest", action="store_true", help="run only the rank logic (gloo, no GPU)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.frames_per_step < 1:
@@ -371,10 +372,11 @@ def main():
                 extra.update(legs.headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs))
             except Exception as exc:                               # informational legs must never take the bench line down with them
                 extra["legs_error"] = repr(exc)
-            try:
-                extra.update(legs.widened_rows(ctx, livo2, synth, H, sc, w.cfg))
-            except Exception as exc:
-                extra["widened_rows_error"] = repr(exc)
+            if not args.legs:
+                try:
+                    extra.update(legs.widened_rows(ctx, livo2, synth, H, sc, w.cfg))
+                except Exception as exc:
+                    extra["widened_rows_error"] = repr(exc)
         if not args.no_cpu:
             try:
                 cpu, (orc_mod, lib) = cpu_baseline(sc, vs)

@@ -24,7 +24,8 @@
 #define LIDAR_NSUM 29       // 21 (sym HtH) + 6 (Htz) + n_eff + sum|r|
 #define LIDAR_LDS_BYTES_OF(B) (((B) / LIVO2_WAVE) * 32 * 65 * 8)
 #define LIDAR_LDS_BYTES LIDAR_LDS_BYTES_OF(LIDAR_BLOCK)
-#define LIDAR_LDS_DUMP 512          // landing area of the software-prefetch loads (touch_line), behind the tiles
+#define LIDAR_LDS_DUMP 512          // behind the tiles: [0,256) landing area of the software-prefetch loads (touch_line), [256,352) sym(P_rr), sym(P_tt)
+#define LIDAR_LDS_SP_OFF 256
 
 struct LidarKernelArgs {
   const float *x, *y, *z;          // [n]
@@ -65,7 +66,7 @@ struct LidarKernelArgs {
 #define CSTAMP(k)                                                                                                  \
   do {                                                                                                             \
     __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);           \
-    if (cprof && base <= LIDAR_BLOCK && (threadIdx.x & 63) == 0)                                                    \
+    if (cprof && base <= BLOCK && (threadIdx.x & 63) == 0)                                                    \
       cprof[((size_t)gridDim.x * 4 + 2) * 8 + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (base ? 6 : 0) + (k)] = __builtin_readcyclecounter(); \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   } while (0)
@@ -179,14 +180,24 @@ __device__ __forceinline__ double quad6_sym(const double *S, const double *J) {
   return acc;
 }
 
-// Per-point invariants of the candidate search and of the Jacobian row.
+// Per-point invariants of the candidate search and of the Jacobian row — kept small on purpose: the kernel's occupancy is set by its VGPR count, so whatever can be
+// re-derived in a few operations (the widened world point, the z-patched point, the prior-pose point q) is not held in registers across the visits.
 struct PointCtx {
-  double pw[3];                // float32-rounded world point, widened
-  double pc[3];                // z-patched IMU-frame point (cross matrix of the matching covariance, voxel_map.cpp:352-358)
+  float pwf[3];                // float32-rounded world point (voxel_map.cpp:524-526)
   double pi[3];                // un-patched IMU-frame point
-  double q[3];                 // PRIOR-pose world point R^ p_i + t^ (voxel_map.cpp:425)
   double Cb[6];                // body covariance, symmetric
+  float plx, ply;              // sensor-frame x, y: only to rebuild the z-patched point when plz == 0 (voxel_map.cpp:352-358)
+  bool zpatch;
 };
+// z-patched IMU-frame point (cross matrix of the matching covariance): p_i itself unless the sensor-frame z was exactly 0
+__device__ __forceinline__ void point_pc(const PointCtx &pt, const double *ER, const double *Et, double pc[3]) {
+  pc[0] = pt.pi[0]; pc[1] = pt.pi[1]; pc[2] = pt.pi[2];
+  if (pt.zpatch) {
+    const double plx = pt.plx, ply = pt.ply, pz = 0.001;
+#pragma unroll
+    for (int j = 0; j < 3; j++) pc[j] = ((ER[j * 3] * plx + ER[j * 3 + 1] * ply) + ER[j * 3 + 2] * pz) + Et[j];
+  }
+}
 
 // State of the running max-probability search of one point (build_single_residual's in/out arguments).
 // * The probability is evaluated LAZILY: the first accepted plane always wins against prob = 0 (exp(-0.5 d^2/sigma)/sqrt(sigma) > 0
@@ -217,16 +228,23 @@ __device__ __forceinline__ bool radius_gate(const double *n, const double *c, fl
 
 // 3-sigma gate, max-probability choice (voxel_map.cpp:732-755) and — when the plane becomes the point's current best — its
 // measurement row (voxel_map.cpp:425-457), for a plane that passed the radius gate.
+// StateRefs: the wave-uniform operands of a plane evaluation.  R / RE / Rp / tp point into the control block (scalar loads), sP at the block's LDS copy of
+// sym(P[0:3,0:3]) (6) and sym(P[3:6,3:6]) (6) — twelve broadcast LDS reads per evaluation instead of 24 VGPRs held for the whole kernel.
+struct StateRefs { const double *R, *RE, *Rp, *tp, *sP; };
 __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double *c, const double *S, const GateOut &g, int32_t pidx, double sigma_num,
-                                                   const PointCtx &pt, const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best) {
-  const double *pc = pt.pc;
+                                                   const double *pc, const double *pi, const double *Cb, const StateRefs &st, Best &best) {
   // sigma_l = J_nq plane_var J_nq^T + n^T Sigma_w n ,  J_nq = [p_w - c, -n]
   const double J[6] = {-g.e[0], -g.e[1], -g.e[2], -n[0], -n[1], -n[2]};
   double sigma_l = quad6_sym(S, J);
   // n^T Sigma_w n = m^T Cb m + q^T Prr q + n^T Ptt n  with m = R^T n, q = n x p_i  (Sigma_w = R Cb R^T + X Prr X^T + Ptt, X = [p_i]x)
-  double m[3]; mat3t_vec_fma(R, n, m);
+  double m[3]; mat3t_vec_fma(st.R, n, m);
   const double qx[3] = {n[1] * pc[2] - n[2] * pc[1], n[2] * pc[0] - n[0] * pc[2], n[0] * pc[1] - n[1] * pc[0]};
-  sigma_l += (quad3_sym(pt.Cb, m) + quad3_sym(sPrr, qx)) + quad3_sym(sPtt, n);
+  {
+    double sPrr[6], sPtt[6];
+#pragma unroll
+    for (int e = 0; e < 6; e++) { sPrr[e] = st.sP[e]; sPtt[e] = st.sP[6 + e]; }
+    sigma_l += (quad3_sym(Cb, m) + quad3_sym(sPrr, qx)) + quad3_sym(sPtt, n);
+  }
   const double sq = sqrt(sigma_l);
   if ((double)g.dis_to_plane < sigma_num * sq) {
     const double dis2 = (double)g.dis_to_plane * (double)g.dis_to_plane;
@@ -241,13 +259,16 @@ __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double
     if (take) {
       best.plane = pidx; best.r = (float)g.sd; best.dis2 = dis2; best.sigma = sigma_l;
       // H / R^-1 row (voxel_map.cpp:414-458): sigma_l' at the PRIOR-pose point, var with the PRIOR rotation, A with the CURRENT one
-      const double Jq[6] = {pt.q[0] - c[0], pt.q[1] - c[1], pt.q[2] - c[2], -n[0], -n[1], -n[2]};
+      double q[3];                                          // PRIOR-pose world point R^ p_i + t^, un-rounded (voxel_map.cpp:425)
+#pragma unroll
+      for (int j = 0; j < 3; j++) q[j] = ((st.Rp[j * 3] * pi[0] + st.Rp[j * 3 + 1] * pi[1]) + st.Rp[j * 3 + 2] * pi[2]) + st.tp[j];
+      const double Jq[6] = {q[0] - c[0], q[1] - c[1], q[2] - c[2], -n[0], -n[1], -n[2]};
       const double sig_q = quad6_sym(S, Jq);
-      double mp[3]; mat3t_vec_fma(RE, n, mp);               // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
-      best.w = 1.0 / (0.001 + sig_q + quad3_sym(pt.Cb, mp));
-      best.h[0] = pt.pi[1] * m[2] - pt.pi[2] * m[1];       // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
-      best.h[1] = pt.pi[2] * m[0] - pt.pi[0] * m[2];
-      best.h[2] = pt.pi[0] * m[1] - pt.pi[1] * m[0];
+      double mp[3]; mat3t_vec_fma(st.RE, n, mp);            // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
+      best.w = 1.0 / (0.001 + sig_q + quad3_sym(Cb, mp));
+      best.h[0] = pi[1] * m[2] - pi[2] * m[1];             // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
+      best.h[1] = pi[2] * m[0] - pi[0] * m[2];
+      best.h[2] = pi[0] * m[1] - pi[1] * m[0];
       best.h[3] = n[0]; best.h[4] = n[1]; best.h[5] = n[2];
     }
   }
@@ -266,6 +287,16 @@ __device__ __forceinline__ RootSlot load_slot(const RootSlot *__restrict__ slots
   return s;
 }
 
+// the part of a root slot a NEIGHBOUR lookup needs (its centre / quarter are never read): 24 B instead of the whole 64-B slot in registers
+struct SlotHead { int32_t kx, ky, kz, val, cand_begin, cand_count; };
+__device__ __forceinline__ SlotHead load_slot_head(const RootSlot *__restrict__ slots, uint32_t h) {
+  const int4 *p = reinterpret_cast<const int4 *>(slots + h);
+  const int4 a = p[0];
+  const int32_t *w = reinterpret_cast<const int32_t *>(slots + h);
+  return {a.x, a.y, a.z, a.w, w[11], w[12]};                 // cand_begin (word 11), cand_count (word 12)
+}
+__device__ __forceinline__ bool head_match(const SlotHead &s, const int32_t key[3]) { return s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]; }
+
 // Visit one root voxel (build_single_residual from layer 0).
 //  * plane root: the whole 256-B record in one batch, radius gate, 3-sigma gate (visit_plane_root).
 //  * non-plane root: the depth-first list of descendant planes (layers <= max_layer) was flattened at upload into contiguous copies
@@ -273,10 +304,14 @@ __device__ __forceinline__ RootSlot load_slot(const RootSlot *__restrict__ slots
 //    (coop_plan / coop_run below), in depth-first order so that ties keep the first.
 struct RootRef { int32_t val, cand_begin, cand_count; };   // what a visit needs from a RootSlot
 
-__device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *R, const double *RE,
-                                                 const double *sPrr, const double *sPtt, Best &best) {
+__device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *ER, const double *Et,
+                                                 const StateRefs &st, Best &best) {
   GateOut g;
-  if (radius_gate(p.n, p.c, p.d, p.radius, pt.pw, g)) sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pt, R, RE, sPrr, sPtt, best);
+  const double pw[3] = {(double)pt.pwf[0], (double)pt.pwf[1], (double)pt.pwf[2]};
+  if (radius_gate(p.n, p.c, p.d, p.radius, pw, g)) {
+    double pc[3]; point_pc(pt, ER, Et, pc);
+    sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pc, pt.pi, pt.Cb, st, best);
+  }
 }
 
 // Software prefetch (gfx950 has no prefetch instruction): a one-dword LDS-direct load (no destination VGPR) into a dump area
@@ -295,7 +330,7 @@ template <int BLOCK> __device__ __forceinline__ void touch_line(const void *p) {
 // probability and measurement row), and the owner folds the results of its pairs IN LIST ORDER with the reference's strict '>'
 // (ties keep the first), which reproduces the serial recursion of build_single_residual exactly.
 template <int BLOCK> struct __attribute__((aligned(16))) CoopLds {
-  double ctx[BLOCK][18];       // owner context: pw pc pi q (3 each) Cb (6)
+  double ctx[BLOCK][15];       // owner context: pw pc pi (3 each) Cb (6)
   double res[BLOCK][10];       // result rows of accepted pairs: prob, w, h[6], {float r, int32 plane}
   unsigned long long omax[BLOCK];                // per owner: largest accepted probability of the round (bit pattern)
   int32_t omin[BLOCK];                           // per owner: first slot holding it
@@ -328,19 +363,20 @@ template <int BLOCK> __device__ __forceinline__ CoopPlan coop_plan(CoopLds<BLOCK
 
 // Every thread parks its point context in LDS before the first plan: evaluators read the owners' rows, and the thread itself
 // re-reads its own row after the evaluation instead of holding 36 VGPRs across it (the evaluation is the register peak).
-template <int BLOCK> __device__ __forceinline__ void coop_park_ctx(CoopLds<BLOCK> &L, const PointCtx &pt) {
+template <int BLOCK> __device__ __forceinline__ void coop_park_ctx(CoopLds<BLOCK> &L, const PointCtx &pt, const double *ER, const double *Et) {
   double *c = L.ctx[threadIdx.x];
+  double pc[3]; point_pc(pt, ER, Et, pc);
 #pragma unroll
-  for (int k = 0; k < 3; k++) { c[k] = pt.pw[k]; c[3 + k] = pt.pc[k]; c[6 + k] = pt.pi[k]; c[9 + k] = pt.q[k]; }
+  for (int k = 0; k < 3; k++) { c[k] = (double)pt.pwf[k]; c[3 + k] = pc[k]; c[6 + k] = pt.pi[k]; }
 #pragma unroll
-  for (int k = 0; k < 6; k++) c[12 + k] = pt.Cb[k];
+  for (int k = 0; k < 6; k++) c[9 + k] = pt.Cb[k];
 }
 template <int BLOCK> __device__ __forceinline__ void coop_unpark_ctx(const CoopLds<BLOCK> &L, PointCtx &pt) {
   const double *c = L.ctx[threadIdx.x];
 #pragma unroll
-  for (int k = 0; k < 3; k++) { pt.pw[k] = c[k]; pt.pc[k] = c[3 + k]; pt.pi[k] = c[6 + k]; pt.q[k] = c[9 + k]; }
+  for (int k = 0; k < 3; k++) { pt.pwf[k] = (float)c[k]; pt.pi[k] = c[6 + k]; }      // (float)(double)f == f
 #pragma unroll
-  for (int k = 0; k < 6; k++) pt.Cb[k] = c[12 + k];
+  for (int k = 0; k < 6; k++) pt.Cb[k] = c[9 + k];
 }
 
 // One round of the evaluation half over the slots [base, base + PAIRS * 256) of the block's pair list; every thread evaluates PAIRS pairs.
@@ -356,7 +392,7 @@ template <int BLOCK> __device__ __forceinline__ void coop_unpark_ctx(const CoopL
 // values), then LDS min over the slots holding that maximum (ascending slot = list order -> the first one) — and the owner copies
 // one row (walking its accepted rows cost a dependent LDS round trip per accepted plane, ~1.8 us in cluttered blocks).
 template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int base, int max_layer, double sigma_num,
-                                                              const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
+                                                              const StateRefs &st, Best &best COOP_PROF_PARAM) {
   const int tid = threadIdx.x;
   const int cnt = pl.cnt, cand_begin = pl.cand_begin, excl = pl.excl, W = pl.W;
   constexpr int SPAN = PAIRS * BLOCK;
@@ -427,15 +463,15 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
     for (int w = 0; w < 10; w++) { S[2 * w] = sv[w].x; S[2 * w + 1] = sv[w].y; }
     S[20] = S20[q];
     const double *oc = L.ctx[owner[q]];
-    PointCtx pp;
+    double ppc[3], ppi[3], pCb[6];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { pp.pw[k] = oc[k]; pp.pc[k] = oc[3 + k]; pp.pi[k] = oc[6 + k]; pp.q[k] = oc[9 + k]; }
+    for (int k = 0; k < 3; k++) { ppc[k] = oc[3 + k]; ppi[k] = oc[6 + k]; }
 #pragma unroll
-    for (int k = 0; k < 6; k++) pp.Cb[k] = oc[12 + k];
+    for (int k = 0; k < 6; k++) pCb[k] = oc[9 + k];
     Best tb; tb.success = false; tb.prob_valid = false; tb.prob = 0.0; tb.dis2 = 0.0; tb.sigma = 1.0; tb.w = 0.0; tb.plane = -1; tb.r = 0.f;
 #pragma unroll
     for (int u = 0; u < 6; u++) tb.h[u] = 0.0;
-    sigma_gate_and_row(n[q], c[q], S, g[q], meta[q].x & CAND_PLANE_MASK, sigma_num, pp, R, RE, sPrr, sPtt, tb);
+    sigma_gate_and_row(n[q], c[q], S, g[q], meta[q].x & CAND_PLANE_MASK, sigma_num, ppc, ppi, pCb, st, tb);
     if (tb.success) {
       const double prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
       int row = tid;
@@ -480,15 +516,15 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
 
 // Evaluation half: every thread of the block calls it with its plan (W is block-uniform).
 template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int max_layer, double sigma_num,
-                                         const double *R, const double *RE, const double *sPrr, const double *sPtt, Best &best COOP_PROF_PARAM) {
+                                         const StateRefs &st, Best &best COOP_PROF_PARAM) {
 #ifdef LIVO2_PHASE_PROF
 #define COOP_PROF_FWD , cprof
 #else
 #define COOP_PROF_FWD
 #endif
   for (int base = 0; base < pl.W;) {
-    if (pl.W - base > BLOCK && coop_round<2, BLOCK>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD)) { base += 2 * BLOCK; continue; }
-    coop_round<1, BLOCK>(L, map, pl, base, max_layer, sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_FWD);
+    if (pl.W - base > BLOCK && coop_round<2, BLOCK>(L, map, pl, base, max_layer, sigma_num, st, best COOP_PROF_FWD)) { base += 2 * BLOCK; continue; }
+    coop_round<1, BLOCK>(L, map, pl, base, max_layer, sigma_num, st, best COOP_PROF_FWD);
     base += BLOCK;
   }
 }
@@ -518,21 +554,22 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
   const double plx = a.x[ic], ply = a.y[ic], plz = a.z[ic];
   const int o = a.perm[ic];                                     // per-point outputs go back to the caller's order
   PointCtx pt;
-  double *Cb = pt.Cb, *pi = pt.pi, *pw = pt.pw, *pc = pt.pc;
+  double *Cb = pt.Cb, *pi = pt.pi;
+  float *pwf = pt.pwf;
+  pt.plx = a.x[ic]; pt.ply = a.y[ic]; pt.zpatch = (plz == 0);
 #pragma unroll
   for (int e = 0; e < 6; e++) Cb[e] = a.cb[(size_t)e * a.n + ic];
   // p_i = extR * p_l + extT  (un-patched, voxel_map.cpp:522 / 418)
 #pragma unroll
   for (int j = 0; j < 3; j++) pi[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * plz) + a.Et[j];
   // p_w = float32( R * p_i + t )   (voxel_map.cpp:522-526)
-  float pwf[3];
 #pragma unroll
-  for (int j = 0; j < 3; j++) { pwf[j] = (float)(((R[j * 3] * pi[0] + R[j * 3 + 1] * pi[1]) + R[j * 3 + 2] * pi[2]) + t[j]); pw[j] = (double)pwf[j]; }
+  for (int j = 0; j < 3; j++) pwf[j] = (float)(((R[j * 3] * pi[0] + R[j * 3 + 1] * pi[1]) + R[j * 3 + 2] * pi[2]) + t[j]);
   // voxel key (voxel_map.cpp:665-671): double divide, narrow to float, -1 for negatives, truncate
   float loc[3]; int32_t key[3]; bool in_range = valid;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    float l = (float)(pw[j] / a.voxel_size);
+    float l = (float)((double)pwf[j] / a.voxel_size);
     if (l < 0) l = (float)((double)l - 1.0);
     loc[j] = l;
     in_range = in_range && (l > -2147483000.f) && (l < 2147483000.f);
@@ -546,24 +583,20 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     const uint32_t h2 = voxel_hash(key[0], key[1], key[2], a.map.seed2) & a.map.mask;
     s1 = load_slot(a.map.slots, h1); s2 = load_slot(a.map.slots, h2);
   }
-  // cross matrix uses the z-patched point (voxel_map.cpp:352-358)
-  pc[0] = pi[0]; pc[1] = pi[1]; pc[2] = pi[2];
-  if (plz == 0) {
-    const double pz = 0.001;
-#pragma unroll
-    for (int j = 0; j < 3; j++) pc[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * pz) + a.Et[j];
-  }
-  // symmetric parts of P[0:3,0:3] and P[3:6,3:6] (a quadratic form only sees the symmetric part)
-  double sPrr[6], sPtt[6];
-  {
+  // symmetric parts of P[0:3,0:3] and P[3:6,3:6] (a quadratic form only sees the symmetric part): block-uniform, kept in LDS behind the prefetch dump
+  // (published by the barrier of the first coop_plan, which every thread passes before any plane is evaluated)
+  double *sP = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_red) + LIDAR_LDS_BYTES_OF(BLOCK) + LIDAR_LDS_SP_OFF);
+  if (tid < 12) {
     const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+    const int e = tid % 6, o3 = tid < 6 ? 0 : 3;
+    int i_ = 0, j_ = 0;
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-      sPrr[e] = 0.5 * (cov[ii[e] * DS + jj[e]] + cov[jj[e] * DS + ii[e]]);
-      sPtt[e] = 0.5 * (cov[(3 + ii[e]) * DS + 3 + jj[e]] + cov[(3 + jj[e]) * DS + 3 + ii[e]]);
-    }
+    for (int k = 0; k < 6; k++) if (k == e) { i_ = ii[k]; j_ = jj[k]; }
+    sP[tid] = 0.5 * (cov[(o3 + i_) * DS + o3 + j_] + cov[(o3 + j_) * DS + o3 + i_]);
   }
+  const StateRefs st = {R, RE, Rp, tp, sP};
   if (a.var && valid) {       // pv.var = R Cb R^T + X Prr X^T + Ptt (voxel_map.cpp:387), only materialised when the caller asks for it
+    double pc[3]; point_pc(pt, a.ER, a.Et, pc);
     const double Cbf[9] = {Cb[0], Cb[1], Cb[2], Cb[1], Cb[3], Cb[4], Cb[2], Cb[4], Cb[5]};
     double T[9], RC[9], XP[9], XPX[9];
     mat3_mul(R, Cbf, T); mat3_mul_Bt(T, R, RC);
@@ -574,9 +607,6 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     for (int e = 0; e < 9; e++) { const int r = e / 3, c = e % 3, u = r < c ? r : c, v = r < c ? c : r; a.var[(size_t)o * 9 + e] = RC[u * 3 + v] + XPX[u * 3 + v] + cov[(3 + u) * DS + 3 + v]; }
   }
   if (a.pw && valid) { a.pw[(size_t)o * 3] = pwf[0]; a.pw[(size_t)o * 3 + 1] = pwf[1]; a.pw[(size_t)o * 3 + 2] = pwf[2]; }
-  // PRIOR-pose world point, un-rounded (voxel_map.cpp:425)
-#pragma unroll
-  for (int j = 0; j < 3; j++) pt.q[j] = ((Rp[j * 3] * pi[0] + Rp[j * 3 + 1] * pi[1]) + Rp[j * 3 + 2] * pi[2]) + tp[j];
   PHASE(2);
   Best best; best.prob = 0.0; best.plane = -1; best.r = 0.f; best.success = false; best.prob_valid = false; best.dis2 = 0.0; best.sigma = 1.0; best.w = 0.0;
 #pragma unroll
@@ -599,29 +629,29 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     // (when no axis triggers, the reference re-visits the same voxel with prob = 0 and fails again: nothing to do)
     const bool nbr = found && ((nk[0] != key[0]) || (nk[1] != key[1]) || (nk[2] != key[2]));
     PlaneRec p0;
-    RootSlot n1, n2;
+    SlotHead n1, n2;                                             // only the words a later visit needs: key, val, cand_begin, cand_count
     n1.val = -1; n2.val = -1;
     if (nbr) {
       const uint32_t g1 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed1) & a.map.mask;
       const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
-      n1 = load_slot(a.map.slots, g1); n2 = load_slot(a.map.slots, g2);
+      n1 = load_slot_head(a.map.slots, g1); n2 = load_slot_head(a.map.slots, g2);
     }
     if (s.val >= 0) load_plane(a.map.planes, s.val, p0);         // issued right behind the neighbour slots: same round trip
     // while that trip is in flight: plan the cooperative visit of the block's non-plane roots (LDS + one barrier only)
     const CoopPlan plan1 = coop_plan(coop, 0, (s.val == -2) ? s.cand_count : 0, s.cand_begin);
     // the neighbour slots return first (in order); keep only the three words a later visit needs
     if (nbr) {
-      if (slot_match(n1, nk)) nb = {n1.val, n1.cand_begin, n1.cand_count};
-      else if (slot_match(n2, nk)) nb = {n2.val, n2.cand_begin, n2.cand_count};
+      if (head_match(n1, nk)) nb = {n1.val, n1.cand_begin, n1.cand_count};
+      else if (head_match(n2, nk)) nb = {n2.val, n2.cand_begin, n2.cand_count};
     }
     // A plane-root neighbour is visited only if the first visit fails, one dependent trip later: start pulling its two cache
     // lines towards this CU now (a discarded dword per line), so that trip is an L2 hit instead of an HBM miss.
     if (nb.val >= 0) { const double *q = a.map.planes + (size_t)nb.val * PLANE_REC_DOUBLES; touch_line<BLOCK>(q); touch_line<BLOCK>(q + 16); }
-    if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+    if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, a.ER, a.Et, st, best);
     plan1W = plan1.W;
     if (plan1.W > 0) {              // block-uniform
-      coop_park_ctx(coop, pt);      // (the first barrier inside coop_run orders these rows before the evaluators' reads)
-      coop_run(coop, a.map, plan1, a.max_layer, a.sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_ARG1);
+      coop_park_ctx(coop, pt, a.ER, a.Et);      // (the first barrier inside coop_run orders these rows before the evaluators' reads)
+      coop_run(coop, a.map, plan1, a.max_layer, a.sigma_num, st, best COOP_PROF_ARG1);
       coop_unpark_ctx(coop, pt);
     }
 #ifdef LIVO2_PHASE_PROF
@@ -634,11 +664,11 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     const CoopPlan plan2 = coop_plan(coop, 1, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin);
     if (retry && nb.val >= 0) {
       PlaneRec p1; load_plane(a.map.planes, nb.val, p1);
-      visit_plane_root(p1, nb.val, a.sigma_num, pt, R, RE, sPrr, sPtt, best);
+      visit_plane_root(p1, nb.val, a.sigma_num, pt, a.ER, a.Et, st, best);
     }
     if (plan2.W > 0) {
-      if (plan1W == 0) coop_park_ctx(coop, pt);
-      coop_run(coop, a.map, plan2, a.max_layer, a.sigma_num, R, RE, sPrr, sPtt, best COOP_PROF_ARG2);
+      if (plan1W == 0) coop_park_ctx(coop, pt, a.ER, a.Et);
+      coop_run(coop, a.map, plan2, a.max_layer, a.sigma_num, st, best COOP_PROF_ARG2);
     }
   }
   PHASE(4);
@@ -702,9 +732,10 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
   PHASE(6);
 }
 
-__global__ void __launch_bounds__(LIDAR_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop) {
-  lidar_residual_body<LIDAR_BLOCK>(a, ctl, partials, check_stop, (int)blockIdx.x, (int)gridDim.x);
+  lidar_residual_body<BLOCK>(a, ctl, partials, check_stop, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Batched launch: several independent (scan, state) problems against the resident map in ONE grid.  A single 100k-point scan is
@@ -728,12 +759,20 @@ __global__ void __launch_bounds__(LIDAR_BLOCK_BATCH) __attribute__((amdgpu_waves
 __device__ inline void reduce_partials_block(const double *__restrict__ partials, int nblocks, double *scratch /*[16][33]*/, double *out /*[32]*/) {
   const int t = threadIdx.x, kidx = t & 31, slice = t >> 5;       // 16 slices
   double acc = 0.0;
-  for (int base = 0; base < nblocks; base += 512) {                  // 512 rows per pass: every pass issues its 32 loads before the first add
+  if (nblocks <= 512) {                                              // one pass of 32 loads per thread
     double v[32];
 #pragma unroll
-    for (int u = 0; u < 32; u++) { const int b = base + slice + 16 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
+    for (int u = 0; u < 32; u++) { const int b = slice + 16 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
 #pragma unroll
     for (int u = 0; u < 32; u++) acc += v[u];
+  } else {
+    for (int base = 0; base < nblocks; base += 1024) {               // 1024 rows per pass: 64 loads per thread in flight before the first add
+      double v[64];
+#pragma unroll
+      for (int u = 0; u < 64; u++) { const int b = base + slice + 16 * u; v[u] = (b < nblocks) ? partials[(size_t)b * 32 + kidx] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 64; u++) acc += v[u];
+    }
   }
   scratch[slice * 33 + kidx] = acc;
   __syncthreads();

@@ -17,6 +17,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -87,7 +88,7 @@ struct livo2_ctx {
   double imu_kernel_us = 0.0;
   // scan
   bool has_scan = false;
-  int n = 0, n_cap = 0;
+  int n = 0, n_cap = 0, lidar_block = 256;
   float *d_xyz_aos = nullptr, *d_x = nullptr, *d_y = nullptr, *d_z = nullptr; double *d_cb = nullptr;
   uint32_t *d_keys = nullptr, *d_keys2 = nullptr; int32_t *d_idx = nullptr, *d_perm = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_partials = nullptr; size_t partials_cap = 0;
@@ -219,7 +220,22 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_esikf_solve_only(DevCtl *__restr
 #else
 #define SOLVE_PROF_ARG
 #endif
-int lidar_grid(int n, int block = LIDAR_BLOCK) { int chunks = (n + block - 1) / block; int per_xcd = (chunks + 7) / 8; return std::max(8, per_xcd * 8); }
+int lidar_grid(int n, int block) { int chunks = (n + block - 1) / block; int per_xcd = (chunks + 7) / 8; return std::max(8, per_xcd * 8); }
+// Threads (= points) per block of a single-scan launch: 256.  128-point blocks are compiled in and selectable (LIVO2_LIDAR_BLOCK=128, tools/block_probe.py): at C4
+// (200 000 points = 782 blocks of 256 against the 512 the chip holds at once) they shorten the residual kernel (25.4 -> 23.0 us) by the amount the solve, which
+// then reads twice as many partial rows through ONE CU (~130 GB/s: 400 KB = 2.9 us), gets longer (10.3 -> 13.2 us) — no gain per iteration, so 256 stays the rule.
+int lidar_block_for(int n) {
+  static const int forced = [] { const char *e = std::getenv("LIVO2_LIDAR_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 128 || v == 256) ? v : 0; }();
+  (void)n;
+  return forced ? forced : 256;
+}
+void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop);
+
+void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop) {
+  const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
+  if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop);
+  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop);
+}
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   if (!cfg) return fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL");
@@ -272,7 +288,7 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   std::memcpy(a.ER, cfg->extR, 72); std::memcpy(a.Et, cfg->extT, 24);
 #ifdef LIVO2_PHASE_PROF
   {
-    size_t waves = (size_t)lidar_grid(std::max(ctx->n, 1)) * 4;
+    size_t waves = (size_t)lidar_grid(std::max(ctx->n, 1), 128) * 4;
     if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64 + 128 + waves * 16 + waves * 128); (void)e; ctx->prof_waves = waves; }
     hipError_t e = hipMemsetAsync(ctx->d_prof, 0, waves * 64, ctx->stream); (void)e;
     a.prof = ctx->d_prof;
@@ -741,7 +757,8 @@ int sort_reserve(livo2_ctx *ctx, size_t need) {
 // d_xyz_aos[0..n) holds feats_down_body: Morton order of the body-frame cells (cell = voxel_size), SoA gather, body covariance
 int scan_pipeline(livo2_ctx *ctx, int n, const livo2_lidar_cfg *cfg) {
   ctx->n = n;
-  const int grid = lidar_grid(std::max(n, 1));
+  ctx->lidar_block = lidar_block_for(n);
+  const int grid = lidar_grid(std::max(n, 1), ctx->lidar_block);
   int rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * 32, (size_t)64));
   if (rc) return rc;
   if (n > 0) {
@@ -886,8 +903,8 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   rc = upload_states(ctx, cur, prop, cfg->extR); if (rc) return rc;
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
-  const int grid = lidar_grid(std::max(ctx->n, 1));
-  { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, 0); t.done(); }
+  const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
+  { Timed t(ctx, 0); launch_lidar_residual(ctx, a, 0); t.done(); }
   { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations SOLVE_PROF_ARG); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
@@ -905,9 +922,9 @@ static int lidar_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo
 static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int iters, int mode) {
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
-  const int grid = lidar_grid(std::max(ctx->n, 1));
+  const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
   for (int it = 0; it < iters; it++) {
-    { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual, dim3(grid), dim3(LIDAR_BLOCK), LIDAR_LDS_BYTES + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode == 1 ? 1 : 0); t.done(); }
+    { Timed t(ctx, 0); launch_lidar_residual(ctx, a, mode == 1 ? 1 : 0); t.done(); }
     { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30) SOLVE_PROF_ARG); t.done(); }
   }
   hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Block-size experiment for the single-scan LiDAR residual kernel on a GPU box: the same C2 scan through liblivo2_hip.so (256-point blocks) and
-variant builds (hipcc ... -DLIDAR_BLOCK=128 / 64 -o fast-livo2_amd/lib/liblivo2_hip_b128.so / _b64.so): per-iteration wall time, HIP-event kernel
-time of residual and solve, full-update latency.  Usage: python tools/block_probe.py [lib suffixes, default '' b128 b64]"""
+"""Block-size experiment for the single-scan LiDAR residual kernel on a GPU box: the C2 scan (or, with `c4`, the bench's C4 frame) and a 17k-point scan with the
+block size forced through the environment (LIVO2_LIDAR_BLOCK=128|256; unset = the library's own choice by scan size) or through variant builds
+(fast-livo2_amd/lib/liblivo2_hip_<suffix>.so): per-iteration wall time, HIP-event kernel time of residual and solve, full-update latency.
+Usage: [LIVO2_LIDAR_BLOCK=128] python tools/block_probe.py [c4] [lib suffixes]"""
 import importlib
 import os
 import sys
@@ -25,13 +26,13 @@ else:
     sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12, downsample=synth.AVIA["filter_size_surf"])
 small = synth.lidar_scenario(seed=1, n_points=24000, downsample=0.1)
 ref_state = None
-for suffix in (args or ["", "b128", "b64"]):
+for suffix in (args or [""]):
     path = base if not suffix else base.replace(".so", "_" + suffix + ".so")
     if not os.path.exists(path):
         print(suffix, "missing", path); continue
     abi._lib, abi.LIB_PATH = None, path
     ctx = livo2.Context(0)
-    row = [suffix or "b256"]
+    row = [(suffix or "lib") + " block=" + os.environ.get("LIVO2_LIDAR_BLOCK", "auto")]
     for s in (sc, small):
         cfg = H.lidar_cfg_product(s)
         ctx.upload_map(s.fmap); ctx.set_scan(s.xyz, cfg)
