@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .abi import (Cam, ImuCfg, LidarCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveChainOut, RetrieveOut, SelectCfg, State, VisualCfg, VisualObs, VisualResult, VisualSums)  # noqa: F401
+from .abi import (Cam, ImuCfg, LidarCfg, MapTreeCfg, LidarPoints, LidarResult, LidarSums, MapView, PlaneFit, RetrieveCandidates, RetrieveCfg, RetrieveChainOut, RetrieveOut, SelectCfg, State, VisualCfg, VisualObs, VisualResult, VisualSums)  # noqa: F401
 
 
 class Livo2Error(RuntimeError):
@@ -102,6 +102,49 @@ class Context:
         self._chk(self.lib.livo2_map_update_planes(self.h, abi.as_ptr(idx, C.c_int32), len(idx), abi.as_ptr(normal, C.c_double),
                                                    abi.as_ptr(center, C.c_double), abi.as_ptr(plane_var, C.c_double), abi.as_ptr(d, C.c_float),
                                                    abi.as_ptr(radius, C.c_float)))
+
+    # ---- device-resident VoxelMap -----------------------------------------------------------------------------
+    def map_tree_create(self, lio_cfg, max_roots, **caps):
+        """lio_cfg: dict with voxel_size, min_eigen_value, max_layer, max_points_num, layer_init_num (config/avia.yaml lio/...)."""
+        c = MapTreeCfg()
+        c.voxel_size, c.planer_threshold = float(lio_cfg["voxel_size"]), float(lio_cfg["min_eigen_value"])
+        c.max_layer, c.max_points_num, c.max_roots = int(lio_cfg["max_layer"]), int(lio_cfg["max_points_num"]), int(max_roots)
+        c.layer_init_num[:] = [int(v) for v in list(lio_cfg["layer_init_num"])[:5]]
+        for k, v in caps.items():
+            setattr(c, k, int(v))
+        self._chk(self.lib.livo2_map_tree_create(self.h, C.byref(c)))
+
+    def map_tree_update(self, point_w, var, build=False):
+        pw, v = _f64(point_w).reshape(-1, 3), _f64(var).reshape(-1, 9)
+        self._chk(self.lib.livo2_map_tree_update(self.h, abi.as_ptr(pw, C.c_double), abi.as_ptr(v, C.c_double), len(pw), 1 if build else 0))
+
+    def map_tree_update_from_scan(self, state, cfg, build=False):
+        self._chk(self.lib.livo2_map_tree_update_from_scan(self.h, C.byref(state), C.byref(cfg), 1 if build else 0))
+
+    def map_tree_stats(self):
+        c = np.zeros(8, np.int32)
+        self._chk(self.lib.livo2_map_tree_stats(self.h, abi.as_ptr(c, C.c_int32)))
+        return dict(nodes=int(c[0]), points=int(c[1]), planes=int(c[2]), cand=int(c[3]), error=int(c[5]), touched=int(c[6]), roots=int(c[7]))
+
+    def map_tree_last_kernel_us(self):
+        return float(self.lib.livo2_map_tree_last_kernel_us(self.h))
+
+    def map_tree_export(self):
+        """The device tree as flat-map arrays (dict with the FlatMap field names + node_temp)."""
+        st = self.map_tree_stats()
+        R, N, P = st["roots"], max(st["nodes"], 1), max(st["planes"], 1)
+        o = dict(root_key=np.zeros((R, 3), np.int64), root_node=np.zeros(R, np.int32), root_center=np.zeros((R, 3)), root_quarter=np.zeros(R, np.float32),
+                 node_plane=np.zeros(N, np.int32), node_child=np.zeros((N, 8), np.int32), plane_normal=np.zeros((P, 3)), plane_center=np.zeros((P, 3)),
+                 plane_var=np.zeros((P, 36)), plane_d=np.zeros(P, np.float32), plane_radius=np.zeros(P, np.float32), node_temp=np.zeros(N, np.int32))
+        self._chk(self.lib.livo2_map_tree_export(self.h, abi.as_ptr(o["root_key"], C.c_int64), abi.as_ptr(o["root_node"], C.c_int32), abi.as_ptr(o["root_center"], C.c_double),
+                                                 abi.as_ptr(o["root_quarter"], C.c_float), abi.as_ptr(o["node_plane"], C.c_int32), abi.as_ptr(o["node_child"], C.c_int32),
+                                                 abi.as_ptr(o["plane_normal"], C.c_double), abi.as_ptr(o["plane_center"], C.c_double), abi.as_ptr(o["plane_var"], C.c_double),
+                                                 abi.as_ptr(o["plane_d"], C.c_float), abi.as_ptr(o["plane_radius"], C.c_float), abi.as_ptr(o["node_temp"], C.c_int32)))
+        for k in ("node_plane", "node_child", "node_temp"):
+            o[k] = o[k][: st["nodes"]]
+        for k in ("plane_normal", "plane_center", "plane_var", "plane_d", "plane_radius"):
+            o[k] = o[k][: st["planes"]]
+        return o
 
     # ---- LiDAR -----------------------------------------------------------------------------------------------
     def set_scan(self, xyz, cfg):

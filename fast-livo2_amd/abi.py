@@ -161,6 +161,12 @@ class VisualCfg(C.Structure):
                 ("exposure_estimate_en", C.c_int32), ("inverse_composition_en", C.c_int32), ("mp_proc_num", C.c_int32), ("pad", C.c_int32)]
 
 
+class MapTreeCfg(C.Structure):
+    _fields_ = [("voxel_size", C.c_double), ("planer_threshold", C.c_double), ("max_layer", C.c_int32), ("max_points_num", C.c_int32),
+                ("layer_init_num", C.c_int32 * 5), ("max_roots", C.c_int32), ("max_nodes", C.c_int32), ("max_planes", C.c_int32), ("max_points", C.c_int32),
+                ("max_cand", C.c_int32)]
+
+
 class VisualSums(C.Structure):
     _fields_ = [("HtH", C.c_double * 49), ("Htz", C.c_double * 7), ("err_sum", C.c_double), ("error", C.c_float), ("n_meas", C.c_int32)]
 
@@ -229,6 +235,13 @@ SIGNATURES = {
     "livo2_visual_update_async": (C.c_int, [_CTX, _P(State), _P(State), _P(VisualCfg)]),
     "livo2_visual_update_fetch": (C.c_int, [_CTX, _P(VisualResult), _P(C.c_float)]),
     "livo2_visual_iterations_async": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg), C.c_int32]),
+    "livo2_map_tree_create": (C.c_int, [_CTX, _P(MapTreeCfg)]),
+    "livo2_map_tree_update": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), C.c_int32, C.c_int32]),
+    "livo2_map_tree_update_from_scan": (C.c_int, [_CTX, _P(State), _P(LidarCfg), C.c_int32]),
+    "livo2_map_tree_stats": (C.c_int, [_CTX, _P(C.c_int32)]),
+    "livo2_map_tree_export": (C.c_int, [_CTX, _P(C.c_int64), _P(C.c_int32), _P(C.c_double), _P(C.c_float), _P(C.c_int32), _P(C.c_int32), _P(C.c_double), _P(C.c_double),
+                                        _P(C.c_double), _P(C.c_float), _P(C.c_float), _P(C.c_int32)]),
+    "livo2_map_tree_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_visual_batch_set_frames": (C.c_int, [_CTX, C.c_int32, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32), _P(C.c_double),
                                                 _P(C.c_int32), C.c_int32]),
     "livo2_visual_batch_update": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg), _P(VisualResult)]),

@@ -8,6 +8,7 @@
 #include "lidar_kernels.hpp"
 #include "visual_inverse_kernels.hpp"
 #include "map_kernels.hpp"
+#include "map_tree_kernels.hpp"
 #include "retrieve_kernels.hpp"
 #include "preprocess_kernels.hpp"
 #include "select_kernels.hpp"
@@ -124,6 +125,16 @@ struct livo2_ctx {
   size_t vb_pos_cap = 0, vb_invexpo_cap = 0, vb_partials_cap = 0, vb_warp_cap = 0, vb_errors_cap = 0, vb_search_cap = 0, vb_block_frame_cap = 0;
   VisualBatchEntry *vbd_entries = nullptr, *vbh_entries = nullptr;      // [LIVO2_MAX_BATCH], device / pinned
   livo2_visual_result *vbd_results = nullptr, *vbh_results = nullptr;   // [LIVO2_MAX_BATCH], device / pinned
+  // device-resident VoxelMap (map_tree_kernels.hpp)
+  bool tree_mode = false;
+  MapTreeArgs mt{};
+  livo2_map_tree_cfg mt_cfg{};
+  double *mt_in_pw = nullptr, *mt_in_var = nullptr; size_t mt_in_pw_cap = 0, mt_in_var_cap = 0;
+  unsigned long long *mt_keys = nullptr, *mt_keys2 = nullptr; size_t mt_keys_cap = 0, mt_keys2_cap = 0;
+  int32_t *mt_idx = nullptr, *mt_order = nullptr, *mt_head = nullptr, *mt_slot = nullptr, *mt_seg_begin = nullptr, *mt_seg_root = nullptr, *mt_nseg = nullptr;
+  size_t mt_idx_cap = 0, mt_order_cap = 0, mt_head_cap = 0, mt_slot_cap = 0, mt_seg_begin_cap = 0, mt_seg_root_cap = 0;
+  livo2_state *mt_state = nullptr;
+  double mt_kernel_us = 0.0;
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
 #endif
@@ -326,8 +337,10 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // device plane numbering (Morton order) -> the caller's
-  if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
-  if (p->normal_plane) for (size_t i = 0; i < n; i++) if (p->normal_plane[i] >= 0) p->normal_plane[i] = ctx->plane_orig[p->normal_plane[i]];
+  if (!ctx->tree_mode) {
+    if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
+    if (p->normal_plane) for (size_t i = 0; i < n; i++) if (p->normal_plane[i] >= 0) p->normal_plane[i] = ctx->plane_orig[p->normal_plane[i]];
+  }
   return LIVO2_OK;
 }
 
@@ -387,7 +400,7 @@ int32_t livo2_abi_sizeof(const char *name) {
   LIVO2_SZ(livo2_state) LIVO2_SZ(livo2_map_view) LIVO2_SZ(livo2_lidar_cfg) LIVO2_SZ(livo2_lidar_sums) LIVO2_SZ(livo2_lidar_points) LIVO2_SZ(livo2_lidar_result)
   LIVO2_SZ(livo2_cam) LIVO2_SZ(livo2_visual_cfg) LIVO2_SZ(livo2_visual_sums) LIVO2_SZ(livo2_visual_step) LIVO2_SZ(livo2_visual_result)
   LIVO2_SZ(livo2_plane_fit) LIVO2_SZ(livo2_imu_step) LIVO2_SZ(livo2_imu_cfg) LIVO2_SZ(livo2_imu_pose) LIVO2_SZ(livo2_select_cfg)
-  LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out)
+  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out)
 #undef LIVO2_SZ
   return 0;
 }
@@ -433,7 +446,9 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_ob_off, ctx->d_ob_id, ctx->d_ob_img, ctx->d_ob_lvl, ctx->d_vm_refpatch, ctx->d_ob_px, ctx->d_ob_f, ctx->d_ob_R, ctx->d_ob_t, ctx->d_ob_ie, ctx->d_vm_normal,
                  ctx->d_ob_patch, ctx->d_vm_ninit, ctx->d_ob_imgs, ctx->d_ch_obs, ctx->d_ch_flag, ctx->d_ch_slot, ctx->d_cand_cell, ctx->d_cand_point, ctx->d_cand_obs,
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
-                 ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results};
+                 ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
+                 ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -599,6 +614,10 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   ctx->map.seed1 = seed1; ctx->map.seed2 = seed2; ctx->map.n_planes = m->n_planes;
   ctx->has_map = true;
   ctx->plane_tabs_fresh = false;
+  if (ctx->tree_mode) {            // the snapshot replaces a device-resident tree
+    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); (void)e2;
+    ctx->mt = MapTreeArgs{}; ctx->tree_mode = false;
+  }
   return LIVO2_OK;
 }
 
@@ -778,6 +797,212 @@ int scan_pipeline(livo2_ctx *ctx, int n, const livo2_lidar_cfg *cfg) {
   return LIVO2_OK;
 }
 } // namespace
+
+// ---- device-resident VoxelMap ------------------------------------------------------------------------------------------------------------
+int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!cfg || !(cfg->voxel_size > 0) || cfg->max_layer < 0 || cfg->max_layer > LIVO2_MAX_LAYER || cfg->max_points_num < 1 || cfg->max_points_num > MT_SLAB - 2 || cfg->max_roots < 1)
+    return fail(ctx, LIVO2_ERR_INVALID, "bad map tree cfg (max_layer in [0,LIVO2_MAX_LAYER], max_points_num in [1,50], max_roots >= 1)");
+  for (int k = 0; k < 5; k++) if (cfg->layer_init_num[k] < 1 || cfg->layer_init_num[k] > MT_SLAB - 2) return fail(ctx, LIVO2_ERR_INVALID, "layer_init_num out of [1,50]");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipError_t e;
+  if (ctx->d_slots) { e = hipFree(ctx->d_slots); e = hipFree(ctx->d_cand); e = hipFree(ctx->d_planes); ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; }
+  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); }
+  (void)e;
+  ctx->has_map = false; ctx->tree_mode = false; ctx->mt = MapTreeArgs{};
+  MapTreeArgs &m = ctx->mt;
+  const long long R = cfg->max_roots;
+  m.cap_nodes = (int32_t)std::min<long long>(cfg->max_nodes > 0 ? cfg->max_nodes : 3 * R, INT32_MAX / 2);
+  m.cap_planes = (int32_t)std::min<long long>(cfg->max_planes > 0 ? cfg->max_planes : 2 * R, (1 << CAND_LAYER_SHIFT) - 1);
+  m.cap_points = (int32_t)std::min<long long>(cfg->max_points > 0 ? cfg->max_points : 80 * R, INT32_MAX / 16);
+  m.cap_cand = (int32_t)std::min<long long>(cfg->max_cand > 0 ? cfg->max_cand : R, INT32_MAX / 64);
+  m.cap_overflow = (int32_t)std::max<long long>(1024, R / 4);
+  uint32_t cap = 64;
+  while ((long long)cap < 8 * R) cap <<= 1;
+  HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
+  HIPCHK(hipMalloc((void **)&ctx->d_planes, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand, (size_t)m.cap_cand * PLANE_REC_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&m.nodes, (size_t)m.cap_nodes * sizeof(DevNode)));
+  HIPCHK(hipMalloc((void **)&m.pool_pw, (size_t)m.cap_points * 24));
+  HIPCHK(hipMalloc((void **)&m.pool_var, (size_t)m.cap_points * 72));
+  HIPCHK(hipMalloc((void **)&m.counters, MTC_COUNT * 4));
+  HIPCHK(hipMalloc((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
+  HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
+  {
+    std::vector<RootSlot> empty(cap);
+    for (auto &sl : empty) sl.val = -1;
+    HIPCHK(hipMemcpy(ctx->d_slots, empty.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemset(m.counters, 0, MTC_COUNT * 4));
+  HIPCHK(hipMemset(ctx->d_planes, 0, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
+  HIPCHK(hipMemset(ctx->d_cand, 0, (size_t)m.cap_cand * PLANE_REC_DOUBLES * 8));
+  m.planes = ctx->d_planes; m.cand = ctx->d_cand; m.slots = ctx->d_slots;
+  m.mask = cap - 1; m.seed1 = 0x243f6a88u; m.seed2 = 0x85a308d3u;
+  m.voxel_size_d = cfg->voxel_size; m.voxel_size_f = (float)cfg->voxel_size; m.planer_threshold = (float)cfg->planer_threshold;
+  m.max_layer = cfg->max_layer; m.max_points_num = cfg->max_points_num; m.update_size_threshold = 5;      // VoxelOctoTree ctor (voxel_map.h:159)
+  for (int k = 0; k <= LIVO2_MAX_LAYER; k++) m.layer_init_num[k] = cfg->layer_init_num[k < 5 ? k : 4];
+  ctx->map.slots = ctx->d_slots; ctx->map.cand_rec = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = m.mask; ctx->map.seed1 = m.seed1; ctx->map.seed2 = m.seed2;
+  ctx->map.n_planes = m.cap_planes;
+  ctx->mt_cfg = *cfg;
+  ctx->plane_internal.clear(); ctx->plane_orig.clear(); ctx->plane_cand_pos.clear();
+  if (!ctx->mt_nseg) HIPCHK(hipMalloc((void **)&ctx->mt_nseg, 64));
+  if (!ctx->mt_state) HIPCHK(hipMalloc((void **)&ctx->mt_state, sizeof(livo2_state)));
+  ctx->has_map = true; ctx->tree_mode = true;
+  return LIVO2_OK;
+}
+
+namespace {
+// sort by root voxel, segment, roots, octree update, emit — on points already in mt_in_pw / mt_in_var
+int map_tree_run(livo2_ctx *ctx, int n, int build) {
+  MapTreeArgs &m = ctx->mt;
+  int rc;
+  if ((rc = ensure(ctx, ctx->mt_keys, ctx->mt_keys_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_keys2, ctx->mt_keys2_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_idx, ctx->mt_idx_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_order, ctx->mt_order_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_head, ctx->mt_head_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_slot, ctx->mt_slot_cap, (size_t)std::max(n, 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_seg_begin, ctx->mt_seg_begin_cap, (size_t)n + 2))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_seg_root, ctx->mt_seg_root_cap, (size_t)n + 1))) return rc;
+  HIPCHK(hipMemsetAsync(m.counters + MTC_OVERFLOW, 0, 3 * 4, ctx->stream));          // overflow, error, dirty
+  HIPCHK(hipMemsetAsync(ctx->mt_nseg, 0, 4, ctx->stream));
+  if (n == 0) return LIVO2_OK;
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_mt_keys, dim3(nb), dim3(256), 0, ctx->stream, ctx->mt_in_pw, n, m.voxel_size_f, ctx->mt_keys, ctx->mt_idx, m.counters);
+  size_t need = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, (size_t)n, 0, 63, ctx->stream));
+  rc = sort_reserve(ctx, need); if (rc) return rc;
+  size_t tmp_bytes = ctx->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, (size_t)n, 0, 63, ctx->stream));
+  hipLaunchKernelGGL(k_mt_heads, dim3(nb), dim3(256), 0, ctx->stream, ctx->mt_keys2, n, ctx->mt_head);
+  {
+    size_t scan_need = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, scan_need, ctx->mt_head, ctx->mt_slot, 0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
+    rc = sort_reserve(ctx, scan_need); if (rc) return rc;
+    size_t scan_bytes = ctx->sort_tmp_bytes;
+    HIPCHK(rocprim::exclusive_scan(ctx->d_sort_tmp, scan_bytes, ctx->mt_head, ctx->mt_slot, 0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
+  }
+  hipLaunchKernelGGL(k_mt_segments, dim3(nb), dim3(256), 0, ctx->stream, ctx->mt_head, ctx->mt_slot, n, ctx->mt_seg_begin, ctx->mt_nseg);
+  MapTreeArgs a = m;
+  a.in_pw = ctx->mt_in_pw; a.in_var = ctx->mt_in_var; a.order = ctx->mt_order; a.skeys = ctx->mt_keys2; a.seg_head = ctx->mt_head; a.seg_slot = ctx->mt_slot;
+  a.seg_begin = ctx->mt_seg_begin; a.seg_root = ctx->mt_seg_root; a.n = n; a.build = build ? 1 : 0;
+  // the segment count stays on the device: grids are sized for the worst case (one segment per point), surplus threads leave at once
+  hipLaunchKernelGGL(k_mt_roots, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  hipLaunchKernelGGL(k_mt_overflow, dim3(1), dim3(64), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_mt_update, dim3((n * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  hipLaunchKernelGGL(k_mt_emit, dim3((n * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  return LIVO2_OK;
+}
+int map_tree_finish(livo2_ctx *ctx) {
+  int32_t c[MTC_COUNT];
+  HIPCHK(hipMemcpyAsync(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
+  ctx->mt_kernel_us = 1e3 * ms;
+  if (c[MTC_ERROR]) {
+    static char msg[160];
+    std::snprintf(msg, sizeof(msg), "device map tree: capacity / range error bits 0x%x (1 nodes, 2 points, 4 planes, 8 candidate lists, 16 hash table, 32 voxel key range, 64 node region)", c[MTC_ERROR]);
+    return fail(ctx, LIVO2_ERR_RANGE, msg);
+  }
+  return LIVO2_OK;
+}
+} // namespace
+
+int livo2_map_tree_update(livo2_ctx *ctx, const double *point_w, const double *var, int32_t n, int32_t build) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_map_tree_create has not been called");
+  if (n < 0 || (n > 0 && (!point_w || !var))) return fail(ctx, LIVO2_ERR_INVALID, "bad input_points");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = ensure(ctx, ctx->mt_in_pw, ctx->mt_in_pw_cap, (size_t)std::max(n, 1) * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_in_var, ctx->mt_in_var_cap, (size_t)std::max(n, 1) * 9))) return rc;
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->mt_in_pw, point_w, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->mt_in_var, var, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
+  rc = map_tree_run(ctx, n, build); if (rc) return rc;
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
+  return map_tree_finish(ctx);
+}
+
+int livo2_map_tree_update_from_scan(livo2_ctx *ctx, const livo2_state *state, const livo2_lidar_cfg *cfg, int32_t build) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_map_tree_create has not been called");
+  if (!state) return fail(ctx, LIVO2_ERR_INVALID, "state is NULL");
+  int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
+  if (!ctx->has_scan) return fail(ctx, LIVO2_ERR_NO_SCAN, "livo2_lidar_set_scan has not been called");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int n = ctx->n;
+  if ((rc = ensure(ctx, ctx->mt_in_pw, ctx->mt_in_pw_cap, (size_t)std::max(n, 1) * 3))) return rc;
+  if ((rc = ensure(ctx, ctx->mt_in_var, ctx->mt_in_var_cap, (size_t)std::max(n, 1) * 9))) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->mt_state, state, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
+  if (n > 0) {
+    MapPvArgs p{};
+    p.x = ctx->d_x; p.y = ctx->d_y; p.z = ctx->d_z; p.cb = ctx->d_cb; p.perm = ctx->d_perm; p.n = n;
+    std::memcpy(p.ER, cfg->extR, 72); std::memcpy(p.Et, cfg->extT, 24);
+    p.out_pw = ctx->mt_in_pw; p.out_var = ctx->mt_in_var;
+    hipLaunchKernelGGL(k_mt_pv_from_scan, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p, ctx->mt_state);
+  }
+  rc = map_tree_run(ctx, n, build); if (rc) return rc;
+  HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
+  return map_tree_finish(ctx);
+}
+
+int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->tree_mode || !counts) return fail(ctx, LIVO2_ERR_INVALID, "no device map tree / counts is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(counts, ctx->mt.counters, MTC_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LIVO2_OK;
+}
+double livo2_map_tree_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->mt_kernel_us : 0.0; }
+
+int livo2_map_tree_export(livo2_ctx *ctx, int64_t *root_key, int32_t *root_node, double *root_center, float *root_quarter, int32_t *node_plane, int32_t *node_child,
+                          double *plane_normal, double *plane_center, double *plane_var, float *plane_d, float *plane_radius, int32_t *node_temp) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "no device map tree");
+  HIPCHK(hipSetDevice(ctx->device));
+  int32_t c[MTC_COUNT];
+  HIPCHK(hipMemcpy(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost));
+  const int nn = std::min(c[MTC_NODES], ctx->mt.cap_nodes), np = std::min(c[MTC_PLANES], ctx->mt.cap_planes);
+  std::vector<DevNode> nodes((size_t)std::max(nn, 1));
+  std::vector<double> recs((size_t)std::max(np, 1) * PLANE_REC_DOUBLES);
+  if (nn) HIPCHK(hipMemcpy(nodes.data(), ctx->mt.nodes, (size_t)nn * sizeof(DevNode), hipMemcpyDeviceToHost));
+  if (np) HIPCHK(hipMemcpy(recs.data(), ctx->d_planes, (size_t)np * PLANE_REC_DOUBLES * 8, hipMemcpyDeviceToHost));
+  int r = 0;
+  for (int i = 0; i < nn; i++) {
+    const DevNode &nd = nodes[i];
+    if (node_plane) node_plane[i] = nd.is_plane ? nd.plane : -1;
+    if (node_child) for (int k = 0; k < 8; k++) node_child[(size_t)i * 8 + k] = nd.child[k];
+    if (node_temp) node_temp[i] = nd.n_temp;
+    if (nd.layer == 0 && nd.root == i) {
+      if (root_key) for (int k = 0; k < 3; k++) root_key[(size_t)r * 3 + k] = nd.key[k];
+      if (root_node) root_node[r] = i;
+      if (root_center) for (int k = 0; k < 3; k++) root_center[(size_t)r * 3 + k] = nd.center[k];
+      if (root_quarter) root_quarter[r] = nd.quarter;
+      r++;
+    }
+  }
+  for (int p = 0; p < np; p++) {
+    const double *rec = &recs[(size_t)p * PLANE_REC_DOUBLES];
+    if (plane_normal) for (int k = 0; k < 3; k++) plane_normal[(size_t)p * 3 + k] = rec[k];
+    if (plane_center) for (int k = 0; k < 3; k++) plane_center[(size_t)p * 3 + k] = rec[3 + k];
+    if (plane_var) { int q = 6; for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { plane_var[(size_t)p * 36 + a * 6 + b] = rec[q]; plane_var[(size_t)p * 36 + b * 6 + a] = rec[q]; q++; } }
+    float dr[2]; std::memcpy(dr, &rec[27], 8);
+    if (plane_d) plane_d[p] = dr[0];
+    if (plane_radius) plane_radius[p] = dr[1];
+  }
+  return LIVO2_OK;
+}
+
 
 int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg) {
   if (!ctx) return LIVO2_ERR_INVALID;

@@ -64,32 +64,26 @@ template <int LPG> __device__ __forceinline__ double group_sum(double v) {      
   return v;
 }
 
-template <int LPG> __global__ void __launch_bounds__(FIT_WAVES *LIVO2_WAVE) __attribute__((amdgpu_waves_per_eu(2))) k_plane_fit(PlaneFitArgs a) {
-  const int lane = threadIdx.x & (LPG - 1);                      // lane within the group
-  const int slot = (blockIdx.x * (FIT_WAVES * LIVO2_WAVE) + threadIdx.x) / LPG;
-  if (slot >= a.n_list) return;                                  // (a whole group's lanes leave together)
-  const int g = a.list[slot];
-  const int lo = a.offsets[g], hi = a.offsets[g + 1];
+// VoxelOctoTree::init_plane for the points [lo, hi) of (pw, var), evaluated by the LPG lanes of one group (every lane ends up with the same values).
+struct FitRes {
+  double c[3], cov[9], ev_min, ev_mid, ev_max, vmin[3], vmid[3], vmax[3], pv[36];
+  bool is_plane;
+};
+template <int LPG> __device__ __forceinline__ void plane_fit_core(const double *__restrict__ pw, const double *__restrict__ var_, int lo, int hi, int lane, float planer_threshold, FitRes &R) {
   const int n = hi - lo;
-  livo2_plane_fit *o = a.out + g;
-  if (n <= 0) {                                   // the reference never fits an empty voxel; report "no plane"
-    double *z = reinterpret_cast<double *>(o);
-    for (int k = lane; k < (int)(sizeof(livo2_plane_fit) / 8); k += LPG) z[k] = 0.0;
-    return;
-  }
   // pass 1: covariance_ += p p^T, center_ += p  (voxel_map.cpp:63-67)
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // sum p (3), then xx xy xz yy yz zz
   for (int i = lo + lane; i < hi; i += LPG) {
-    const double x = a.pw[(size_t)i * 3], y = a.pw[(size_t)i * 3 + 1], z = a.pw[(size_t)i * 3 + 2];
+    const double x = pw[(size_t)i * 3], y = pw[(size_t)i * 3 + 1], z = pw[(size_t)i * 3 + 2];
     s[0] += x; s[1] += y; s[2] += z;
     s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
   }
 #pragma unroll
   for (int k = 0; k < 9; k++) s[k] = group_sum<LPG>(s[k]);
   const double nn = (double)n;
-  const double c[3] = {s[0] / nn, s[1] / nn, s[2] / nn};                       // voxel_map.cpp:68
-  double cov[9];                                                              // voxel_map.cpp:69
-  cov[0] = s[3] / nn - c[0] * c[0]; cov[1] = s[4] / nn - c[0] * c[1]; cov[2] = s[5] / nn - c[0] * c[2];
+  double *c = R.c, *cov = R.cov;
+  c[0] = s[0] / nn; c[1] = s[1] / nn; c[2] = s[2] / nn;                       // voxel_map.cpp:68
+  cov[0] = s[3] / nn - c[0] * c[0]; cov[1] = s[4] / nn - c[0] * c[1]; cov[2] = s[5] / nn - c[0] * c[2];      // voxel_map.cpp:69
   cov[3] = s[4] / nn - c[1] * c[0]; cov[4] = s[6] / nn - c[1] * c[1]; cov[5] = s[7] / nn - c[1] * c[2];
   cov[6] = s[5] / nn - c[2] * c[0]; cov[7] = s[7] / nn - c[2] * c[1]; cov[8] = s[8] / nn - c[2] * c[2];
   double ev[3], V[9];
@@ -102,12 +96,14 @@ template <int LPG> __global__ void __launch_bounds__(FIT_WAVES *LIVO2_WAVE) __at
   // (register arrays are only indexed with compile-time constants: a lane-dependent index would move them to scratch memory)
   auto sel3 = [](double x0, double x1, double x2, int i) { return i == 0 ? x0 : (i == 1 ? x1 : x2); };
   const double ev_min = sel3(ev[0], ev[1], ev[2], imin), ev_mid = sel3(ev[0], ev[1], ev[2], imid), ev_max = sel3(ev[0], ev[1], ev[2], imax);
-  const bool is_plane = ev_min < (double)a.planer_threshold;                   // voxel_map.cpp:85
+  const bool is_plane = ev_min < (double)planer_threshold;                     // voxel_map.cpp:85
   const double vmin[3] = {sel3(V[0], V[1], V[2], imin), sel3(V[3], V[4], V[5], imin), sel3(V[6], V[7], V[8], imin)};
   const double vmid[3] = {sel3(V[0], V[1], V[2], imid), sel3(V[3], V[4], V[5], imid), sel3(V[6], V[7], V[8], imid)};
   const double vmax[3] = {sel3(V[0], V[1], V[2], imax), sel3(V[3], V[4], V[5], imax), sel3(V[6], V[7], V[8], imax)};
-
-  double pv[36];
+  R.ev_min = ev_min; R.ev_mid = ev_mid; R.ev_max = ev_max; R.is_plane = is_plane;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { R.vmin[k] = vmin[k]; R.vmid[k] = vmid[k]; R.vmax[k] = vmax[k]; }
+  double *pv = R.pv;
 #pragma unroll
   for (int k = 0; k < 36; k++) pv[k] = 0.0;
   if (is_plane) {
@@ -123,10 +119,10 @@ template <int LPG> __global__ void __launch_bounds__(FIT_WAVES *LIVO2_WAVE) __at
     }
     const double jq = 1.0 / nn;                                                // J_Q (voxel_map.cpp:82)
     for (int i = lo + lane; i < hi; i += LPG) {
-      const double d[3] = {a.pw[(size_t)i * 3] - c[0], a.pw[(size_t)i * 3 + 1] - c[1], a.pw[(size_t)i * 3 + 2] - c[2]};
+      const double d[3] = {pw[(size_t)i * 3] - c[0], pw[(size_t)i * 3 + 1] - c[1], pw[(size_t)i * 3 + 2] - c[2]};
       double var[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) var[k] = a.var[(size_t)i * 9 + k];
+      for (int k = 0; k < 9; k++) var[k] = var_[(size_t)i * 9 + k];
       double F[9];
 #pragma unroll
       for (int m = 0; m < 3; m++) {
@@ -158,6 +154,26 @@ template <int LPG> __global__ void __launch_bounds__(FIT_WAVES *LIVO2_WAVE) __at
 #pragma unroll
     for (int k = 0; k < 36; k++) pv[k] = group_sum<LPG>(pv[k]);
   }
+}
+
+template <int LPG> __global__ void __launch_bounds__(FIT_WAVES *LIVO2_WAVE) __attribute__((amdgpu_waves_per_eu(2))) k_plane_fit(PlaneFitArgs a) {
+  const int lane = threadIdx.x & (LPG - 1);                      // lane within the group
+  const int slot = (blockIdx.x * (FIT_WAVES * LIVO2_WAVE) + threadIdx.x) / LPG;
+  if (slot >= a.n_list) return;                                  // (a whole group's lanes leave together)
+  const int g = a.list[slot];
+  const int lo = a.offsets[g], hi = a.offsets[g + 1];
+  const int n = hi - lo;
+  livo2_plane_fit *o = a.out + g;
+  if (n <= 0) {                                   // the reference never fits an empty voxel; report "no plane"
+    double *z = reinterpret_cast<double *>(o);
+    for (int k = lane; k < (int)(sizeof(livo2_plane_fit) / 8); k += LPG) z[k] = 0.0;
+    return;
+  }
+  FitRes R;
+  plane_fit_core<LPG>(a.pw, a.var, lo, hi, lane, a.planer_threshold, R);
+  const bool is_plane = R.is_plane;
+  const double *c = R.c, *cov = R.cov, *pv = R.pv, *vmin = R.vmin, *vmid = R.vmid, *vmax = R.vmax;
+  const double ev_min = R.ev_min, ev_mid = R.ev_mid, ev_max = R.ev_max;
   const double nrm[3] = {is_plane ? vmin[0] : 0.0, is_plane ? vmin[1] : 0.0, is_plane ? vmin[2] : 0.0};
   const float radius = is_plane ? (float)sqrt(ev_max) : 0.f;                 // radius_ is a float member (voxel_map.h:77)
   const float dd = is_plane ? (float)(-((nrm[0] * c[0] + nrm[1] * c[1]) + nrm[2] * c[2])) : 0.f;

@@ -1,0 +1,501 @@
+// Device-resident VoxelMap (second half): the octree bookkeeping of map maintenance on the GPU.
+//   VoxelMapManager::BuildVoxelMap / UpdateVoxelMap        reference src/voxel_map.cpp:532-591, 609-641
+//   VoxelOctoTree::init_octo_tree / cut_octo_tree / UpdateOctoTree   reference src/voxel_map.cpp:137-290
+//   VoxelOctoTree::init_plane                               reference src/voxel_map.cpp:55-135 (plane_fit_core, map_kernels.hpp)
+//   pv_list_ of the posterior (point_w, var)                reference src/LIVMapper.cpp:413-423
+// The map lives in five pools in HBM — octree nodes, the temp_points_ of every node, the 256-B plane records, the candidate lists of
+// the non-plane roots, the 2-choice cuckoo table of root voxels — and k_lidar_residual reads the last three directly: no host octree, no
+// re-flatten, no snapshot upload between frames.
+//
+// Schedule: the reference feeds the points of a scan ONE BY ONE, in input order, through UpdateOctoTree; what a point does depends on what
+// the earlier points of the same root voxel did (counters, re-fit every 5 points, subdivision, freezing at max_points_num_).  Root voxels
+// are independent of each other, so the scan is sorted by root voxel (stable: input order inside a voxel) and every touched root is
+// walked serially by ONE group of 8 lanes — the reference's state machine, statement by statement — while the init_plane calls inside
+// are evaluated by the 8 lanes together.  Tree shape and decisions are those of the serial loop; the fitted planes agree with the CPU
+// evaluation to the tolerance of plane_fit_core (summation order).
+#pragma once
+#include "map_kernels.hpp"
+
+#define MT_LPG 8                 // lanes per root voxel
+#define MT_SLAB 52               // points a node's temp_points_ region holds by default (max_points_num_ 50 + the point that trips the limit + 1)
+#define MT_STACK (LIVO2_MAX_LAYER + 2)
+enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8 };
+enum { MTE_NODES = 1, MTE_POINTS = 2, MTE_PLANES = 4, MTE_CAND = 8, MTE_TABLE = 16, MTE_RANGE = 32, MTE_REGION = 64 };
+
+struct __attribute__((aligned(128))) DevNode {      // VoxelOctoTree (reference include/voxel_map.h:129-183), 128 B
+  double center[3];              // voxel_center_
+  float quarter;                 // quater_length_
+  int32_t layer;                 // layer_
+  int32_t init_octo, is_plane, update_enable, octo_state;     // init_octo_, plane_ptr_->is_plane_, update_enable_, octo_state_
+  int32_t new_points, n_temp, pts_off, pts_cap;                // new_points_, temp_points_.size(), its region in the point pool
+  int32_t plane, root, cand_begin, cand_cap;                   // row of its plane record (-1: never was a plane); root node; (roots) candidate-list region
+  int32_t child[8];              // leaves_
+  int32_t key[3];                // (roots) VOXEL_LOCATION
+  int32_t dirty;                 // (roots) queued for k_mt_emit in this update
+};
+static_assert(sizeof(DevNode) == 128, "DevNode is two cache lines of 64 B");
+
+struct MapTreeArgs {
+  DevNode *nodes; double *pool_pw, *pool_var;        // point pool: [cap][3], [cap][9]
+  double *planes, *cand; RootSlot *slots;
+  int32_t *counters;                                 // [MTC_COUNT]
+  int32_t *dirty_list, *overflow_list;
+  int32_t cap_nodes, cap_points, cap_planes, cap_cand, cap_overflow;
+  uint32_t mask, seed1, seed2;
+  double voxel_size_d; float voxel_size_f, planer_threshold;
+  int32_t max_layer, max_points_num, update_size_threshold;
+  int32_t layer_init_num[LIVO2_MAX_LAYER + 1];
+  // the frame being fed
+  const double *in_pw, *in_var;                      // [n][3], [n][9] in input order
+  const int32_t *order;                              // [n] input index of the k-th point in (root voxel, input order) order
+  const unsigned long long *skeys;                   // [n] sorted packed keys
+  const int32_t *seg_head, *seg_slot;                // [n] head flags / exclusive scan (segment number at heads)
+  int32_t *seg_begin, *seg_root;                     // [n_seg + 1], [n_seg]
+  int32_t n, build;
+};
+
+__device__ __forceinline__ int grp_first(int v) { return __shfl(v, (threadIdx.x & 63) & ~(MT_LPG - 1), 64); }
+__device__ __forceinline__ void mt_error(const MapTreeArgs &a, int bit) { atomicOr(&a.counters[MTC_ERROR], bit); }
+
+// packed 3 x 21-bit voxel key (offset 2^20) <-> VOXEL_LOCATION
+__device__ __forceinline__ void mt_unpack(unsigned long long k, int32_t key[3]) {
+  key[0] = (int32_t)((k >> 42) & 0x1fffff) - (1 << 20); key[1] = (int32_t)((k >> 21) & 0x1fffff) - (1 << 20); key[2] = (int32_t)(k & 0x1fffff) - (1 << 20);
+}
+
+// ---- pv_list_ of the posterior, root-voxel key of every point -----------------------------------------------------------------------------
+// LIVMapper.cpp:413-423: point_w = float32(R p_i + t) widened; var = (R extR) C_b (R extR)^T + (-X) P_rr (-X)^T + P_tt, X = cross_mat_list_[i]
+// (the z-patched IMU-frame point's skew matrix, voxel_map.cpp:352-358).  The scan is resident in Morton order; outputs go to INPUT order.
+struct MapPvArgs {
+  const float *x, *y, *z; const double *cb; const int32_t *perm; int32_t n;
+  double ER[9], Et[3];
+  double *out_pw, *out_var;
+};
+__global__ void __launch_bounds__(256) k_mt_pv_from_scan(MapPvArgs a, const livo2_state *__restrict__ st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const double *R = st->rot, *t = st->pos, *cov = st->cov;
+  const double plx = a.x[i], ply = a.y[i], plz = a.z[i];
+  const int o = a.perm[i];
+  double pi[3], pc[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) pi[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * plz) + a.Et[j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) pc[j] = pi[j];
+  if (plz == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) pc[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * 0.001) + a.Et[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) a.out_pw[(size_t)o * 3 + j] = (double)(float)(((R[j * 3] * pi[0] + R[j * 3 + 1] * pi[1]) + R[j * 3 + 2] * pi[2]) + t[j]);
+  double RE[9];
+  mat3_mul(R, a.ER, RE);
+  const double Cbf[9] = {a.cb[i], a.cb[(size_t)a.n + i], a.cb[(size_t)2 * a.n + i], a.cb[(size_t)a.n + i], a.cb[(size_t)3 * a.n + i], a.cb[(size_t)4 * a.n + i],
+                         a.cb[(size_t)2 * a.n + i], a.cb[(size_t)4 * a.n + i], a.cb[(size_t)5 * a.n + i]};
+  double T[9], RC[9], XP[9], XPX[9];
+  mat3_mul(RE, Cbf, T); mat3_mul_Bt(T, RE, RC);
+  const double nX[9] = {-0.0, pc[2], -pc[1], -pc[2], -0.0, pc[0], pc[1], -pc[0], -0.0};          // -point_crossmat
+  const double Prr[9] = {cov[0], cov[1], cov[2], cov[DS], cov[DS + 1], cov[DS + 2], cov[2 * DS], cov[2 * DS + 1], cov[2 * DS + 2]};
+  mat3_mul(nX, Prr, XP); mat3_mul_Bt(XP, nX, XPX);
+#pragma unroll
+  for (int e = 0; e < 9; e++) { const int r = e / 3, c = e % 3; a.out_var[(size_t)o * 9 + e] = (RC[e] + XPX[e]) + cov[(3 + r) * DS + 3 + c]; }
+}
+
+// root voxel of every point (voxel_map.cpp:559-567 / 617-625: float division, -1 for negatives, truncation), packed for the sort
+__global__ void __launch_bounds__(256) k_mt_keys(const double *__restrict__ pw, int n, float voxel_size, unsigned long long *__restrict__ keys, int32_t *__restrict__ idx, int32_t *__restrict__ counters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long k = 0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float l = (float)(pw[(size_t)i * 3 + j] / (double)voxel_size);      // double / float -> double, narrowed to the float loc_xyz
+    if (l < 0) l = (float)((double)l - 1.0);
+    if (!(l > -1048000.f && l < 1048000.f)) { bad = true; l = 0.f; }
+    const long long v = (long long)l + (1 << 20);
+    k = (k << 21) | (unsigned long long)(v & 0x1fffff);
+  }
+  if (bad) atomicOr(&counters[MTC_ERROR], MTE_RANGE);
+  keys[i] = k; idx[i] = i;
+}
+__global__ void __launch_bounds__(256) k_mt_heads(const unsigned long long *__restrict__ skeys, int n, int32_t *__restrict__ head) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_mt_segments(const int32_t *__restrict__ head, const int32_t *__restrict__ slot, int n, int32_t *__restrict__ seg_begin, int32_t *__restrict__ n_seg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (head[i]) seg_begin[slot[i]] = i;
+  if (i == n - 1) { const int ns = slot[i] + (head[i] ? 1 : 0); seg_begin[ns] = n; *n_seg = ns; }
+}
+
+// ---- allocation ----------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mt_alloc(const MapTreeArgs &a, int which, int count, int cap, int errbit) {      // one lane calls; -1 when the pool is exhausted
+  const int at = atomicAdd(&a.counters[which], count);
+  if (at + count > cap) { mt_error(a, errbit); return -1; }
+  return at;
+}
+__device__ __forceinline__ void mt_init_node(DevNode &nd, const double c[3], float quarter, int layer, int root, int pts_off, int pts_cap) {
+  nd.center[0] = c[0]; nd.center[1] = c[1]; nd.center[2] = c[2]; nd.quarter = quarter; nd.layer = layer;
+  nd.init_octo = 0; nd.is_plane = 0; nd.update_enable = 1; nd.octo_state = 0;
+  nd.new_points = 0; nd.n_temp = 0; nd.pts_off = pts_off; nd.pts_cap = pts_cap;
+  nd.plane = -1; nd.root = root; nd.cand_begin = 0; nd.cand_cap = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) nd.child[k] = -1;
+  nd.key[0] = nd.key[1] = nd.key[2] = 0; nd.dirty = 0;
+}
+
+// ---- roots: lookup or creation --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mt_roots(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= *n_seg_p) return;
+  const int b = a.seg_begin[g], e = a.seg_begin[g + 1];
+  int32_t key[3];
+  mt_unpack(a.skeys[b], key);
+  const uint32_t h1 = voxel_hash(key[0], key[1], key[2], a.seed1) & a.mask, h2 = voxel_hash(key[0], key[1], key[2], a.seed2) & a.mask;
+  const uint32_t hh[2] = {h1, h2};
+  for (int t = 0; t < 2; t++) {
+    const RootSlot &s = a.slots[hh[t]];
+    if (s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]) { a.seg_root[g] = s.pad; return; }
+  }
+  // new root voxel (voxel_map.cpp:574-583 / 630-637)
+  const int cap = a.build ? max(MT_SLAB, e - b + 1) : MT_SLAB;
+  const int id = mt_alloc(a, MTC_NODES, 1, a.cap_nodes, MTE_NODES);
+  const int off = mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS);
+  if (id < 0 || off < 0) { a.seg_root[g] = -1; return; }
+  atomicAdd(&a.counters[MTC_ROOTS], 1);
+  DevNode nd;
+  const double c[3] = {(0.5 + (double)key[0]) * (double)a.voxel_size_f, (0.5 + (double)key[1]) * (double)a.voxel_size_f, (0.5 + (double)key[2]) * (double)a.voxel_size_f};
+  mt_init_node(nd, c, a.voxel_size_f / 4, 0, id, off, cap);
+  nd.key[0] = key[0]; nd.key[1] = key[1]; nd.key[2] = key[2];
+  a.nodes[id] = nd;
+  a.seg_root[g] = id;
+  RootSlot ns{};
+  ns.kx = key[0]; ns.ky = key[1]; ns.kz = key[2]; ns.val = -2; ns.center[0] = c[0]; ns.center[1] = c[1]; ns.center[2] = c[2]; ns.quarter = nd.quarter;
+  ns.cand_begin = 0; ns.cand_count = 0; ns.pad = id;
+  for (int t = 0; t < 2; t++) {
+    const uint32_t h = hh[t];
+    if (atomicCAS(&a.slots[h].val, -1, -3) == -1) {            // claimed (no lookup runs concurrently with an update)
+      RootSlot *d = &a.slots[h];
+      d->kx = ns.kx; d->ky = ns.ky; d->kz = ns.kz; d->center[0] = c[0]; d->center[1] = c[1]; d->center[2] = c[2]; d->quarter = ns.quarter;
+      d->cand_begin = 0; d->cand_count = 0; d->pad = id;
+      __threadfence();
+      d->val = -2;
+      return;
+    }
+  }
+  const int at = atomicAdd(&a.counters[MTC_OVERFLOW], 1);       // both buckets taken: the serial cuckoo pass places it
+  if (at < a.cap_overflow) a.overflow_list[at] = id; else mt_error(a, MTE_TABLE);
+}
+// both buckets of a new root were occupied: standard cuckoo eviction, one thread (a few per cent of the new roots at load factor <= 1/8)
+__global__ void __launch_bounds__(64) k_mt_overflow(MapTreeArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = min(a.counters[MTC_OVERFLOW], a.cap_overflow);
+  for (int k = 0; k < n; k++) {
+    const DevNode &nd = a.nodes[a.overflow_list[k]];
+    RootSlot cur{};
+    cur.kx = nd.key[0]; cur.ky = nd.key[1]; cur.kz = nd.key[2]; cur.val = -2; cur.center[0] = nd.center[0]; cur.center[1] = nd.center[1]; cur.center[2] = nd.center[2];
+    cur.quarter = nd.quarter; cur.cand_begin = 0; cur.cand_count = 0; cur.pad = a.overflow_list[k];
+    uint32_t h = voxel_hash(cur.kx, cur.ky, cur.kz, a.seed1) & a.mask;
+    bool placed = false;
+    for (int kick = 0; kick < 512; kick++) {
+      if (a.slots[h].val == -1) { a.slots[h] = cur; placed = true; break; }
+      const RootSlot t = a.slots[h]; a.slots[h] = cur; cur = t;      // evict the resident, move it to its other bucket
+      const uint32_t ha = voxel_hash(cur.kx, cur.ky, cur.kz, a.seed1) & a.mask, hb = voxel_hash(cur.kx, cur.ky, cur.kz, a.seed2) & a.mask;
+      h = (h == ha) ? hb : ha;
+    }
+    if (!placed) mt_error(a, MTE_TABLE);
+  }
+  a.counters[MTC_OVERFLOW] = 0;
+}
+
+// ---- the octree state machine, one group of MT_LPG lanes per touched root --------------------------------------------------------------
+struct MtGroup {
+  const MapTreeArgs &a; int lane;
+  __device__ MtGroup(const MapTreeArgs &a_, int l) : a(a_), lane(l) {}
+
+  __device__ int thr(int layer) const { return a.layer_init_num[layer <= LIVO2_MAX_LAYER ? layer : LIVO2_MAX_LAYER]; }
+  // temp_points_.push_back(pv)
+  __device__ bool push(DevNode &n, const double *pw, const double *var) {
+    if (n.n_temp >= n.pts_cap) { mt_error(a, MTE_REGION); return false; }
+    const size_t at = (size_t)n.pts_off + n.n_temp;
+    for (int q = lane; q < 12; q += MT_LPG) { if (q < 3) a.pool_pw[at * 3 + q] = pw[q]; else a.pool_var[at * 9 + q - 3] = var[q - 3]; }
+    n.n_temp++;
+    return true;
+  }
+  // std::vector<pointWithVar>().swap(temp_points_); update_enable_ = false
+  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; }
+  // init_plane(temp_points_, plane_ptr_): fit + the packed record the residual kernel reads
+  __device__ void fit(DevNode &n) {
+    wave_sync();                                              // the pushes of this group are visible to its 8 lanes
+    FitRes R;
+    plane_fit_core<MT_LPG>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);
+    n.is_plane = R.is_plane ? 1 : 0;
+    if (!R.is_plane) return;
+    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc(a, MTC_PLANES, 1, a.cap_planes, MTE_PLANES); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
+    double *rec = a.planes + (size_t)n.plane * PLANE_REC_DOUBLES;
+    const double nrm[3] = {R.vmin[0], R.vmin[1], R.vmin[2]};
+    const float radius = (float)sqrt(R.ev_max);
+    const float dd = (float)(-((nrm[0] * R.c[0] + nrm[1] * R.c[1]) + nrm[2] * R.c[2]));
+    auto put = [&](int k, double v) { if (lane == k % MT_LPG) rec[k] = v; };
+#pragma unroll
+    for (int k = 0; k < 3; k++) { put(k, nrm[k]); put(3 + k, R.c[k]); }
+    {
+      int q = 6;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int u = r; u < 6; u++) { put(q, 0.5 * (R.pv[r * 6 + u] + R.pv[u * 6 + r])); q++; }
+    }
+    put(27, __builtin_bit_cast(double, make_float2(dd, radius)));
+#pragma unroll
+    for (int k = 28; k < 32; k++) put(k, 0.0);
+  }
+  __device__ int octant(const DevNode &n, const double *pw) const { return 4 * (pw[0] > n.center[0] ? 1 : 0) + 2 * (pw[1] > n.center[1] ? 1 : 0) + (pw[2] > n.center[2] ? 1 : 0); }
+  // leaves_[leafnum] = new VoxelOctoTree(...) (voxel_map.cpp:179-186 / 255-262); returns its id (-1: pool exhausted)
+  __device__ int new_leaf(const DevNode &n, int leafnum, int cap) {
+    int id = -1, off = -1;
+    if (lane == 0) { id = mt_alloc(a, MTC_NODES, 1, a.cap_nodes, MTE_NODES); off = mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS); }
+    id = grp_first(id); off = grp_first(off);
+    if (id < 0 || off < 0) return -1;
+    DevNode l;
+    const int xyz[3] = {(leafnum >> 2) & 1, (leafnum >> 1) & 1, leafnum & 1};
+    double c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = n.center[k] + (double)((2 * xyz[k] - 1) * n.quarter);       // int * float -> float, widened for the add
+    mt_init_node(l, c, n.quarter / 2, n.layer + 1, n.root, off, cap);
+    if (lane == 0) a.nodes[id] = l;
+    return id;
+  }
+
+  // init_octo_tree body after the size test / the per-leaf body of cut_octo_tree (voxel_map.cpp:141-159, 194-214): fit, then plane bookkeeping or subdivision.
+  // `parent_new_points` is the counter the reference zeroes when it freezes a LEAF inside cut_octo_tree (it writes the PARENT's new_points_, voxel_map.cpp:204).
+  __device__ void init_node(int id, DevNode &n, int *parent_new_points) {
+    // explicit stack instead of the recursion init -> cut -> (leaf) init -> cut ...
+    struct Frame { int id; DevNode n; int next; int *parent_np; };
+    // depth <= max_layer + 1; frames live in scratch memory (rare path)
+    Frame st[MT_STACK];
+    int sp = 0;
+    st[0].id = id; st[0].n = n; st[0].next = -1; st[0].parent_np = parent_new_points;
+    while (sp >= 0) {
+      Frame &f = st[sp];
+      if (f.next < 0) {                                       // entering: init_plane + decision
+        fit(f.n);
+        if (f.n.is_plane) {
+          f.n.octo_state = 0;
+          if (f.n.n_temp > a.max_points_num) { freeze(f.n); if (f.parent_np) *f.parent_np = 0; else f.n.new_points = 0; }
+          f.n.init_octo = 1; f.n.new_points = 0;
+          if (lane == 0) a.nodes[f.id] = f.n;
+          if (sp == 0) n = f.n;
+          sp--;
+          continue;
+        }
+        f.n.octo_state = 1;
+        // cut_octo_tree (voxel_map.cpp:163-217)
+        if (f.n.layer >= a.max_layer) { f.n.octo_state = 0; f.n.init_octo = 1; f.n.new_points = 0; if (lane == 0) a.nodes[f.id] = f.n; if (sp == 0) n = f.n; sp--; continue; }
+        wave_sync();
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < f.n.n_temp; i++) {
+          const double *pw = a.pool_pw + ((size_t)f.n.pts_off + i) * 3;
+          const double p[3] = {pw[0], pw[1], pw[2]};
+          const int o = octant(f.n, p);
+#pragma unroll
+          for (int k = 0; k < 8; k++) cnt[k] += (o == k) ? 1 : 0;
+        }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (cnt[k] > 0 && f.n.child[k] < 0) { f.n.child[k] = new_leaf(f.n, k, max(MT_SLAB, cnt[k] + 1)); if (f.n.child[k] < 0) ok = false; }
+        if (!ok) { if (lane == 0) a.nodes[f.id] = f.n; if (sp == 0) n = f.n; return; }
+        wave_sync();                                          // the new leaves are in memory for every lane
+        // copy the points to the leaves in list order (temp_points_.push_back, new_points_++)
+        int cur[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = (f.n.child[k] >= 0) ? a.nodes[f.n.child[k]].n_temp : 0;
+        for (int i = 0; i < f.n.n_temp; i++) {
+          const size_t src = (size_t)f.n.pts_off + i;
+          const double p[3] = {a.pool_pw[src * 3], a.pool_pw[src * 3 + 1], a.pool_pw[src * 3 + 2]};
+          const int o = octant(f.n, p);
+          int at = 0, cid = 0;
+#pragma unroll
+          for (int k = 0; k < 8; k++) if (o == k) { at = cur[k]; cur[k]++; cid = f.n.child[k]; }
+          const DevNode &cn = a.nodes[cid];
+          if (at >= cn.pts_cap) { mt_error(a, MTE_REGION); continue; }
+          const size_t dst = (size_t)cn.pts_off + at;
+          for (int q = lane; q < 12; q += MT_LPG) { if (q < 3) a.pool_pw[dst * 3 + q] = a.pool_pw[src * 3 + q]; else a.pool_var[dst * 9 + q - 3] = a.pool_var[src * 9 + q - 3]; }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) if (f.n.child[k] >= 0 && cnt[k] > 0) { DevNode *cn = &a.nodes[f.n.child[k]]; cn->n_temp = cur[k]; cn->new_points += cnt[k]; }
+        }
+        wave_sync();
+        f.next = 0;
+      }
+      // the loop over the eight leaves (voxel_map.cpp:190-216)
+      bool descended = false;
+      while (f.next < 8) {
+        const int k = f.next++;
+        int cid = -1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q == k) cid = f.n.child[q];
+        if (cid < 0) continue;
+        DevNode cn = a.nodes[cid];
+        if (cn.n_temp > thr(cn.layer)) {
+          st[sp + 1].id = cid; st[sp + 1].n = cn; st[sp + 1].next = -1; st[sp + 1].parent_np = &f.n.new_points;
+          sp++; descended = true;
+          break;
+        }
+      }
+      if (descended) continue;
+      f.n.init_octo = 1; f.n.new_points = 0;
+      if (lane == 0) a.nodes[f.id] = f.n;
+      if (sp == 0) n = f.n;
+      sp--;
+    }
+  }
+
+  // init_octo_tree (voxel_map.cpp:137-161)
+  __device__ void init_octo_tree(int id, DevNode &n) {
+    if (n.n_temp > thr(n.layer)) init_node(id, n, nullptr);
+  }
+
+  // UpdateOctoTree(pv) from the root (voxel_map.cpp:219-290); the recursion only ever descends, so it is a loop
+  __device__ void update(int root, const double *pw, const double *var) {
+    int id = root;
+    for (int depth = 0; depth <= LIVO2_MAX_LAYER + 1; depth++) {
+      DevNode n = a.nodes[id];
+      if (!n.init_octo) {
+        n.new_points++;
+        if (!push(n, pw, var)) { if (lane == 0) a.nodes[id] = n; return; }
+        if (n.n_temp > thr(n.layer)) init_octo_tree(id, n);
+        else if (lane == 0) a.nodes[id] = n;
+        if (lane == 0) a.nodes[id] = n;
+        return;
+      }
+      if (n.is_plane) {
+        if (n.update_enable) {
+          n.new_points++;
+          push(n, pw, var);
+          if (n.new_points > a.update_size_threshold) { fit(n); n.new_points = 0; }
+          if (n.n_temp >= a.max_points_num) { freeze(n); n.new_points = 0; }
+          if (lane == 0) a.nodes[id] = n;
+        }
+        return;
+      }
+      if (n.layer < a.max_layer) {
+        const int leafnum = octant(n, pw);
+        int cid = -1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q == leafnum) cid = n.child[q];
+        if (cid < 0) {
+          cid = new_leaf(n, leafnum, MT_SLAB);
+          if (cid < 0) return;
+#pragma unroll
+          for (int q = 0; q < 8; q++) if (q == leafnum) n.child[q] = cid;
+          if (lane == 0) a.nodes[id] = n;
+          wave_sync();
+        }
+        id = cid;
+        continue;
+      }
+      if (n.update_enable) {                                  // a non-plane node at max_layer_ keeps collecting
+        n.new_points++;
+        push(n, pw, var);
+        if (n.new_points > a.update_size_threshold) { fit(n); n.new_points = 0; }
+        if (n.n_temp > a.max_points_num) { freeze(n); n.new_points = 0; }
+        if (lane == 0) a.nodes[id] = n;
+      }
+      return;
+    }
+  }
+};
+
+__global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / MT_LPG, lane = threadIdx.x & (MT_LPG - 1);
+  if (g >= *n_seg_p) return;
+  const int root = a.seg_root[g];
+  if (root < 0) return;
+  const int b = a.seg_begin[g], e = a.seg_begin[g + 1];
+  MtGroup G(a, lane);
+  if (a.build) {                                              // BuildVoxelMap: every point of the voxel first, then init_octo_tree (voxel_map.cpp:568-590)
+    DevNode n = a.nodes[root];
+    for (int k = b; k < e; k++) {
+      const int i = a.order[k];
+      const double pw[3] = {a.in_pw[(size_t)i * 3], a.in_pw[(size_t)i * 3 + 1], a.in_pw[(size_t)i * 3 + 2]};
+      double var[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) var[q] = a.in_var[(size_t)i * 9 + q];
+      G.push(n, pw, var); n.new_points++;
+    }
+    if (lane == 0) a.nodes[root] = n;
+    wave_sync();
+    G.init_octo_tree(root, n);
+    if (lane == 0) a.nodes[root] = n;
+  } else {
+    for (int k = b; k < e; k++) {
+      const int i = a.order[k];
+      const double pw[3] = {a.in_pw[(size_t)i * 3], a.in_pw[(size_t)i * 3 + 1], a.in_pw[(size_t)i * 3 + 2]};
+      double var[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) var[q] = a.in_var[(size_t)i * 9 + q];
+      G.update(root, pw, var);
+      wave_sync();
+    }
+  }
+  if (lane == 0) { const int at = atomicAdd(&a.counters[MTC_DIRTY], 1); a.dirty_list[at] = root; }      // (one segment per root: no duplicates)
+}
+
+// ---- what k_lidar_residual reads: the root's slot and, for a non-plane root, the depth-first list of its descendant planes (record copies) -----------
+// build_single_residual (voxel_map.cpp:713-786) evaluates a node's plane if is_plane_, otherwise recurses into all eight leaves while layer < max_layer.
+__global__ void __launch_bounds__(256) k_mt_emit(MapTreeArgs a) {
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / MT_LPG, lane = threadIdx.x & (MT_LPG - 1);
+  if (g >= a.counters[MTC_DIRTY]) return;
+  const int rid = a.dirty_list[g];
+  DevNode r = a.nodes[rid];
+  int val = -2, count = 0;
+  if (r.is_plane) val = r.plane;
+  else {
+    for (int pass = 0; pass < 2; pass++) {                    // pass 0 counts, pass 1 writes
+      int n_out = 0;
+      int st_id[MT_STACK], st_next[MT_STACK];
+      int sp = 0; st_id[0] = rid; st_next[0] = 0;
+      while (sp >= 0) {
+        const DevNode &nd = a.nodes[st_id[sp]];
+        if (st_next[sp] >= 8 || nd.layer >= LIVO2_MAX_LAYER) { sp--; continue; }
+        const int cid = nd.child[st_next[sp]++];
+        if (cid < 0) continue;
+        const DevNode &c = a.nodes[cid];
+        if (c.is_plane) {
+          if (pass == 1) {
+            double *dst = a.cand + (size_t)(r.cand_begin + n_out) * PLANE_REC_DOUBLES;
+            const double *src = a.planes + (size_t)c.plane * PLANE_REC_DOUBLES;
+            for (int q = lane; q < 28; q += MT_LPG) dst[q] = src[q];
+            if (lane == 0) { const int32_t meta[2] = {c.plane | (c.layer << CAND_LAYER_SHIFT), 0}; dst[28] = __builtin_bit_cast(double, make_int2(meta[0], meta[1])); }
+          }
+          n_out++;
+        } else if (sp + 1 < MT_STACK) { sp++; st_id[sp] = cid; st_next[sp] = 0; }
+      }
+      if (pass == 0) {
+        count = n_out;
+        if (count > r.cand_cap) {
+          const int cap = max(16, 2 * count);
+          int at = 0;
+          if (lane == 0) at = mt_alloc(a, MTC_CAND, cap, a.cap_cand, MTE_CAND);
+          at = grp_first(at);
+          if (at < 0) { count = 0; break; }
+          r.cand_begin = at; r.cand_cap = cap;
+        }
+        if (count == 0) break;
+      }
+    }
+  }
+  if (lane == 0) {
+    r.dirty = 0;
+    a.nodes[rid] = r;
+    const uint32_t h1 = voxel_hash(r.key[0], r.key[1], r.key[2], a.seed1) & a.mask, h2 = voxel_hash(r.key[0], r.key[1], r.key[2], a.seed2) & a.mask;
+    const uint32_t hh[2] = {h1, h2};
+    for (int t = 0; t < 2; t++) {
+      RootSlot *s = &a.slots[hh[t]];
+      if (s->val != -1 && s->kx == r.key[0] && s->ky == r.key[1] && s->kz == r.key[2]) { s->val = val; s->cand_begin = r.cand_begin; s->cand_count = count; break; }
+    }
+  }
+}

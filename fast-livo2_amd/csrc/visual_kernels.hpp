@@ -543,33 +543,47 @@ __global__ void __launch_bounds__(512) k_visual_solve_batch(const VisualBatchEnt
   visual_solve_body(e.ctl, e.partials, e.nblocks, mode, level, iter, img_point_cov, va);
 }
 
+// One wave.  Every global read (covariance, G, the 25 pose / bias scalars) is issued in one batch and everything is written from registers / LDS: the first
+// version re-read what it had just stored and walked G through HBM inside the 19-term loop (8.4 us for a 64-thread kernel).
 __device__ __forceinline__ void visual_finish_body(DevCtl *__restrict__ ctl, const VisualKernelArgs &a, int update_cov) {
   __shared__ double cov[DS * DS];
+  __shared__ double G[DS * DS];
+  __shared__ double sc[25];
   const int lane = threadIdx.x;
-  if (update_cov) {
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) cov[e] = ctl->cur.cov[e];
-    __syncthreads();
-    for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {      // state->cov -= G * state->cov (vio.cpp:800)
-      int r = e / DS, c = e % DS;
-      double g = ctl->G[r * DS] * cov[c];
-      for (int k = 1; k < DS; k++) g = g + ctl->G[r * DS + k] * cov[k * DS + c];
-      ctl->cur.cov[e] = cov[e] - g;
+  double c6[6], g6[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; c6[q] = (e < DS * DS) ? ctl->cur.cov[e] : 0.0; g6[q] = (e < DS * DS) ? ctl->G[e] : 0.0; }
+  const double sv = (lane < 25) ? reinterpret_cast<const double *>(&ctl->cur)[lane] : 0.0;
+  const int n_steps = ctl->hdr.n_steps;
+#pragma unroll
+  for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; if (e < DS * DS) { cov[e] = c6[q]; G[e] = g6[q]; } }
+  if (lane < 25) sc[lane] = sv;
+  wave_sync();
+  double *dst = reinterpret_cast<double *>(&ctl->visual.state);
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int e = lane + q * LIVO2_WAVE;
+    if (e < DS * DS) {
+      double v = c6[q];
+      if (update_cov) {                                       // state->cov -= G * state->cov (vio.cpp:800)
+        const int r = e / DS, c = e % DS;
+        double g = G[r * DS] * cov[c];
+        for (int k = 1; k < DS; k++) g = g + G[r * DS + k] * cov[k * DS + c];
+        v = c6[q] - g;
+        ctl->cur.cov[e] = v;
+      }
+      dst[25 + e] = v;
+      ctl->visual.G[e] = g6[q];
     }
-    __syncthreads();
   }
+  if (lane < 25) dst[lane] = sv;
   if (lane == 0) {                                          // updateFrameState (vio.cpp:1690-1697)
     double Rcw[9];
-    mat3_mul_Bt(a.Rci, ctl->cur.rot, Rcw);
+    mat3_mul_Bt(a.Rci, sc, Rcw);
     for (int j = 0; j < 9; j++) ctl->visual.Rcw[j] = Rcw[j];
-    for (int j = 0; j < 3; j++)
-      ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * ctl->cur.pos[0] + Rcw[j * 3 + 1] * ctl->cur.pos[1]) + Rcw[j * 3 + 2] * ctl->cur.pos[2]);
-    ctl->visual.n_steps = ctl->hdr.n_steps;
+    for (int j = 0; j < 3; j++) ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * sc[9] + Rcw[j * 3 + 1] * sc[10]) + Rcw[j * 3 + 2] * sc[11]);
+    ctl->visual.n_steps = n_steps;
   }
-  __syncthreads();
-  const double *src = reinterpret_cast<const double *>(&ctl->cur);
-  double *dst = reinterpret_cast<double *>(&ctl->visual.state);
-  for (int e = lane; e < (int)(sizeof(livo2_state) / sizeof(double)); e += LIVO2_WAVE) dst[e] = src[e];
-  for (int e = lane; e < DS * DS; e += LIVO2_WAVE) ctl->visual.G[e] = ctl->G[e];
 }
 
 __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict__ ctl, VisualKernelArgs a, int update_cov) { visual_finish_body(ctl, a, update_cov); }

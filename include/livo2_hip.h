@@ -155,6 +155,41 @@ typedef struct livo2_lidar_cfg {
  * (calcBodyCov per point, voxel_map.cpp:349-360).  The scan stays resident until the next set_scan. */
 int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo2_lidar_cfg *cfg);
 
+/* ---- device-resident VoxelMap (second half) ------------------------------------------------------------------------------
+ * VoxelMapManager::BuildVoxelMap / UpdateVoxelMap (src/voxel_map.cpp:532-591, 609-641) with the octree itself — VoxelOctoTree::UpdateOctoTree /
+ * init_octo_tree / cut_octo_tree (137-290), the temp_points_ of every node, the re-fit every update_size_threshold_ points, subdivision, freezing at
+ * max_points_num_ — kept in device memory: the residual kernel reads the structure these calls maintain, so no snapshot is flattened or uploaded
+ * between frames.  Points of one root voxel are processed in input order like the reference's loop; root voxels are independent and run in
+ * parallel.  livo2_map_tree_create makes the (empty) tree the resident map of the ctx, replacing any snapshot of livo2_map_upload (and vice versa);
+ * with a tree resident, the plane indices of livo2_lidar_points (match_plane / normal_plane) are rows of the device plane table — livo2_map_tree_export
+ * returns the planes in that numbering.  Capacities are fixed at creation (0 = defaults derived from max_roots); exhausting one fails the update
+ * with LIVO2_ERR_RANGE and leaves the tree unusable. */
+typedef struct livo2_map_tree_cfg {
+  double voxel_size;            /* lio/voxel_size (narrowed to float like BuildVoxelMap's local, voxel_map.cpp:534) */
+  double planer_threshold;      /* lio/min_eigen_value (narrowed to float: VoxelOctoTree::planer_threshold_) */
+  int32_t max_layer;            /* lio/max_layer */
+  int32_t max_points_num;       /* lio/max_points_num */
+  int32_t layer_init_num[5];    /* lio/layer_init_num */
+  int32_t max_roots;            /* root voxels the cuckoo table is sized for (load factor <= 1/8) */
+  int32_t max_nodes, max_planes, max_points, max_cand;   /* pool capacities; 0 = 3 x / 2 x / 80 x / 1 x max_roots */
+} livo2_map_tree_cfg;
+int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg);
+/* input_points as the reference passes them: pointWithVar::point_w ([n][3]) and ::var ([n][9] row-major), in pv_list_ order.  build != 0:
+ * BuildVoxelMap (all points of a voxel first, then init_octo_tree); else UpdateVoxelMap. */
+int livo2_map_tree_update(livo2_ctx *ctx, const double *point_w, const double *var, int32_t n, int32_t build);
+/* The same with pv_list_ formed on the device from the resident scan and the given (posterior) state — what LIVMapper::handleLIO does between
+ * StateEstimation and UpdateVoxelMap (src/LIVMapper.cpp:413-423): point_w = float32(R (extR p + extT) + t), var = (R extR) body_cov (R extR)^T +
+ * [p_i]x P_rr [p_i]x^T + P_tt.  Nothing crosses PCIe but the state. */
+int livo2_map_tree_update_from_scan(livo2_ctx *ctx, const livo2_state *state, const livo2_lidar_cfg *cfg, int32_t build);
+/* counts[8]: nodes, temp points reserved, plane rows, candidate records reserved, (0), error bits of the last update, roots touched by it, root voxels */
+int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts);
+/* Export as a flat map (same arrays as livo2_map_view; caller buffers sized from livo2_map_tree_stats: roots = counts[7], nodes = counts[0],
+ * planes = counts[2]); node_plane[i] = row of the node's plane if is_plane_, else -1.  node_temp (may be NULL) = temp_points_.size() per node. */
+int livo2_map_tree_export(livo2_ctx *ctx, int64_t *root_key, int32_t *root_node, double *root_center, float *root_quarter, int32_t *node_plane, int32_t *node_child,
+                          double *plane_normal, double *plane_center, double *plane_var, float *plane_d, float *plane_radius, int32_t *node_temp);
+/* kernel time of the last livo2_map_tree_update* call in microseconds (HIP events on the ctx stream; sort + segmentation + octree + emit) */
+double livo2_map_tree_last_kernel_us(const livo2_ctx *ctx);
+
 /* Raw scan -> feats_down_body on the device: ImuProcess::UndistortPcl's backward propagation of every point to the
  * scan-end pose (src/IMU_Processing.cpp:494-539: xyz [n][3] and curvature [n] = PointType x,y,z,curvature of pcl_wait_proc, sorted by
  * curvature like the reference sorts it, IMU_Processing.cpp:154-156; poses = IMUpose, rot_end / pos_end = state_inout after the forward

@@ -1,0 +1,116 @@
+"""Device-resident VoxelMap (livo2_map_tree_*): BuildVoxelMap / UpdateVoxelMap with the octree itself on the GPU (reference src/voxel_map.cpp:137-290, 532-591,
+609-641) against the oracle's serial restatement (oracle/orc_voxel_map.hpp): identical tree shape after the build and after every update of a sequence (which root
+voxels exist, which nodes are planes, which children exist — i.e. every counter-driven decision of UpdateOctoTree was taken at the same point), plane
+parameters within the plane-fit tolerances; then the LiDAR update reads the structure those calls maintain, with no snapshot upload in between."""
+import numpy as np
+import pytest
+
+from scenarios import synth
+from tests import helpers as H
+from tests.test_map_update_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat(d, c):
+    return synth.FlatMap(c["voxel_size"], c["max_layer"], d["root_key"], d["root_node"], d["root_center"], d["root_quarter"], d["node_plane"], d["node_child"],
+                         d["plane_normal"], d["plane_center"], d["plane_var"], d["plane_d"], d["plane_radius"])
+
+
+def _scene(seed):
+    rng = np.random.default_rng(seed)
+    c = dict(synth.AVIA["lio"])
+    scene = synth.make_room(rng, (20.0, 20.0, 6.0), 8)
+    extR, extT = synth.AVIA["extrinsic_R"], synth.AVIA["extrinsic_T"]
+    R0, t0 = scene.R_ws @ synth.rot_from_rpy(0.01, -0.015, 0.4), scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    P0 = synth.default_cov() * 1e-3
+    def cloud(n, R, t):
+        xyz = synth.lidar_scan(rng, scene, R, t, extR, extT, n, c["dept_err"], c["beam_err"], synth.AVIA["blind"], False)
+        return xyz, synth.world_points_and_var(xyz, R, t, extR, extT, P0, c["dept_err"], c["beam_err"])
+    return c, cloud, R0, t0, P0, extR, extT
+
+
+def test_build_and_update_sequence_match_oracle(ctx, orc):
+    c, cloud, R0, t0, P0, extR, extT = _scene(81)
+    _, (pw0, var0) = cloud(40000, R0, t0)
+    ctx.map_tree_create(c, max_roots=60000)
+    ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+    om = orc.OracleMap.build(pw0, var0.reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    n_prev = _compare(_flat(ctx.map_tree_export(), c), om.export(c["voxel_size"], c["max_layer"]))
+    assert n_prev > 1000
+    # a sequence of scans: each overlaps the map (re-fits every 5 points, freezing at 50) and extends it (new roots, subdivision)
+    for k in range(4):
+        Rk, tk = R0 @ synth.rot_from_rpy(0.0, 0.0, 0.12 * (k + 1)), t0 + np.array([0.3 * (k + 1), 0.1 * k, 0.0])
+        _, (pw, var) = cloud(12000, Rk, tk)
+        ctx.map_tree_update(pw, var.reshape(-1, 9))
+        om.update(pw, var.reshape(-1, 9))
+        dev = ctx.map_tree_export()
+        n = _compare(_flat(dev, c), om.export(c["voxel_size"], c["max_layer"]))
+        st = ctx.map_tree_stats()
+        assert n >= n_prev and st["error"] == 0 and st["touched"] > 500
+        n_prev = n
+
+
+def test_tiny_inputs_and_thresholds(ctx, orc):
+    """voxels below the init threshold, exactly at it, one point per call (the counters live across calls), an empty call"""
+    c = dict(synth.AVIA["lio"])
+    rng = np.random.default_rng(5)
+    ctx.map_tree_create(c, max_roots=1000)
+    om = None
+    base = np.array([3.02, -1.98, 0.3])                      # x in [3.02, 3.47], y in [-1.98, -1.53], z ~ 0.4: one root voxel
+    pts = base + np.stack([rng.uniform(0, 0.45, 80), rng.uniform(0, 0.45, 80), 0.1 + 0.002 * rng.normal(size=80)], 1)     # one voxel, a thin slab: becomes a plane, then freezes at 50
+    pts = pts.astype(np.float32).astype(np.float64)
+    A = rng.normal(size=(80, 3, 3)); var = 1e-4 * (A @ A.transpose(0, 2, 1) + 0.1 * np.eye(3))
+    ctx.map_tree_update(np.zeros((0, 3)), np.zeros((0, 9)))
+    for lo, hi in ((0, 3), (3, 5), (5, 6), (6, 7), (7, 30), (30, 49), (49, 50), (50, 51), (51, 80)):
+        ctx.map_tree_update(pts[lo:hi], var[lo:hi].reshape(-1, 9))
+        if om is None:
+            om = orc.OracleMap.build(np.zeros((0, 3)), np.zeros((0, 9)), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+        om.update(pts[lo:hi], var[lo:hi].reshape(-1, 9))
+        _compare(_flat(ctx.map_tree_export(), c), om.export(c["voxel_size"], c["max_layer"]))
+    dev = ctx.map_tree_export()
+    assert len(dev["root_node"]) == 1
+    assert dev["node_plane"][dev["root_node"][0]] >= 0 and dev["node_temp"][dev["root_node"][0]] == 0          # a plane, frozen: temp_points_ released
+
+
+def test_lidar_update_reads_the_device_tree(ctx, livo2, orc):
+    sc = synth.lidar_scenario(seed=31, n_points=12000, downsample=0.1)
+    c = sc.cfg
+    # the map: built on the device from the same world points the scenario's numpy BuildVoxelMap used is not available here, so build from a fresh dense sweep
+    cs, cloud, R0, t0, P0, extR, extT = _scene(31)
+    _, (pw0, var0) = cloud(60000, R0, t0)
+    ctx.map_tree_create(cs, max_roots=60000)
+    ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+    fm = _flat(ctx.map_tree_export(), cs)
+    xyz, _ = cloud(9000, R0, t0)
+    sc2 = synth.LidarScenario(fm, np.ascontiguousarray(xyz, np.float32), R0, t0, R0 @ synth.so3_exp(np.array([0.004, -0.003, 0.005])), t0 + np.array([0.02, -0.015, 0.01]),
+                              synth.prior_cov(np.random.default_rng(1)), extR, extT, cs)
+    pcfg = H.lidar_cfg_product(sc2)
+    pcur, pprop = H.states(sc2, livo2.State)
+    ctx.set_scan(sc2.xyz, pcfg)
+    res_tree, pts_tree = ctx.lidar_update(pcur, pprop, pcfg, want=("match_plane", "dis_to_plane"))
+    # the same planes as a snapshot (livo2_map_upload of the exported tree) and in the oracle: same matches, same residual bits
+    om = orc.OracleMap.from_flat(fm)
+    ocur, oprop = H.states(sc2, orc.StatePOD)
+    ref = orc.lidar_state_estimation(om, orc.lidar_cfg(cs, extR, extT), sc2.xyz, ocur, oprop)
+    assert res_tree.n_iters == ref["n_iters"]
+    assert np.array_equal(pts_tree["match_plane"], ref["match_plane"]) and np.array_equal(pts_tree["dis_to_plane"], ref["dis"])
+    d = H.state_diff(res_tree.state, ref["state"])
+    assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-7, d
+    # map maintenance from the posterior, formed on the device from the resident scan (LIVMapper.cpp:413-423), against the same points fed from the host
+    Rp, tp, P = np.array(res_tree.state.rot).reshape(3, 3), np.array(res_tree.state.pos), np.array(res_tree.state.cov).reshape(19, 19)
+    pl = sc2.xyz.astype(np.float64)
+    pi = pl @ extR.T + extT
+    pw = (pi @ Rp.T + tp).astype(np.float32).astype(np.float64)
+    cb = synth.body_cov(pl, cs["dept_err"], cs["beam_err"])
+    RE, X = Rp @ extR, synth.skew(pi)
+    var = RE @ cb @ RE.T + X @ P[0:3, 0:3] @ X.transpose(0, 2, 1) + P[3:6, 3:6]
+    om_seq = orc.OracleMap.build(pw0, var0.reshape(-1, 9), cs["voxel_size"], cs["max_layer"], cs["layer_init_num"], cs["max_points_num"], cs["min_eigen_value"])   # (from_flat carries no temp_points_)
+    om_seq.update(pw, var.reshape(-1, 9))
+    ctx.map_tree_update_from_scan(res_tree.state, pcfg)
+    n = _compare(_flat(ctx.map_tree_export(), cs), om_seq.export(cs["voxel_size"], cs["max_layer"]), loose=True)
+    assert n > 1000 and ctx.map_tree_last_kernel_us() > 0
+    # and the next frame's update runs on the refreshed structure
+    res2, _ = ctx.lidar_update(pcur, pprop, pcfg)
+    assert res2.n_iters >= 1 and abs(res2.iter_sums[0].n_eff - res_tree.iter_sums[0].n_eff) < 0.05 * res_tree.iter_sums[0].n_eff
+    ctx.upload_map(fm)                                        # leave a snapshot resident for whatever test comes next on this ctx
