@@ -273,7 +273,19 @@ def cpu_widened_rows(orc, lib):
         u_ = orc.undistort(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.extR, raw.extT, lib)
         orc.voxel_grid(u_, raw.leaf, lib)
         tpre.append(time.perf_counter() - t0)
-    return {"imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
+    from tools.bench_legs import MAP_UPDATE_CASES, map_update_case
+    mu = {}
+    for case in MAP_UPDATE_CASES:
+        c, pw0, var0, frames, extR, extT, P0 = map_update_case(_synth, case)
+        t0 = time.perf_counter()
+        om = orc.OracleMap.build(pw0, var0, c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"], lib)
+        tb = time.perf_counter() - t0
+        ts = []
+        for xyz, Rk, tk in frames:
+            pw, var = _synth.world_points_and_var(xyz, Rk, tk, extR, extT, P0, c["dept_err"], c["beam_err"])
+            t0 = time.perf_counter(); om.update(pw, var.reshape(-1, 9)); ts.append(time.perf_counter() - t0)
+        mu[case[0]] = {"build_ms": 1e3 * tb, "update_ms_median": 1e3 * float(np.median(ts)), "points_per_frame": int(np.mean([len(f[0]) for f in frames]))}
+    return {"map_update_ms": mu, "imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
             "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s}
 
 
@@ -288,7 +300,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per launch in the batched-frames legs (extra); 0 disables them")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational legs")
-    ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,live,c2,c3,batched,ooc); default all; the widened rows run only with all")
+    ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,live,c2,c3,batched,ooc,map); default all; the widened rows run only with all")
     ap.add_argument("--dist-selftest", action="store_true", help="run only the rank logic (gloo, no GPU)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.frames_per_step < 1:

@@ -147,7 +147,7 @@ class RetrieveChainOut(C.Structure):
 class ImuCfg(C.Structure):
     _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3), ("cov_bias_acc", C.c_double * 3), ("cov_inv_expo", C.c_double),
                 ("G_m_s2", C.c_double), ("mean_acc_norm", C.c_double), ("ba_bg_est_en", C.c_int32), ("gravity_est_en", C.c_int32), ("exposure_estimate_en", C.c_int32),
-                ("pad", C.c_int32)]
+                ("first_call", C.c_int32)]
 
 
 class SelectCfg(C.Structure):

@@ -11,7 +11,7 @@
 
 struct ImuKernelArgs {
   const double *steps;          // [n][8] gyr3 acc3 dt offs_t
-  int32_t n, ba_bg_est_en, gravity_est_en, exposure_estimate_en;
+  int32_t n, ba_bg_est_en, gravity_est_en, exposure_estimate_en, first_call;
   double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm;
   const livo2_state *in;
   livo2_state *out;
@@ -122,5 +122,5 @@ __global__ void __launch_bounds__(IMU_THREADS) k_imu_propagate(ImuKernelArgs a) 
   if (cell) a.out->cov[tid] = P[tid];
   if (tid < 9) a.out->rot[tid] = R[tid];
   if (tid < 3) { a.out->pos[tid] = pos[tid]; a.out->vel[tid] = vel[tid]; a.out->bg[tid] = bg[tid]; a.out->ba[tid] = ba[tid]; a.out->grav[tid] = grav[tid]; }
-  if (tid == 0) a.out->inv_expo = a.in->inv_expo;
+  if (tid == 0) a.out->inv_expo = a.first_call ? 1.0 : a.in->inv_expo;      // tau (IMU_Processing.cpp:305-317, 444)
 }

@@ -650,7 +650,7 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
 // ---- IMU forward propagation -----------------------------------------------------------------------------------------------------
 static ImuKernelArgs make_imu_args(livo2_ctx *ctx, const livo2_imu_cfg *cfg, int n, double *poses) {
   ImuKernelArgs a{};
-  a.steps = ctx->d_imu_steps; a.n = n; a.ba_bg_est_en = cfg->ba_bg_est_en; a.gravity_est_en = cfg->gravity_est_en; a.exposure_estimate_en = cfg->exposure_estimate_en;
+  a.steps = ctx->d_imu_steps; a.n = n; a.ba_bg_est_en = cfg->ba_bg_est_en; a.gravity_est_en = cfg->gravity_est_en; a.exposure_estimate_en = cfg->exposure_estimate_en; a.first_call = cfg->first_call ? 1 : 0;
   std::memcpy(a.cov_gyr, cfg->cov_gyr, 24); std::memcpy(a.cov_acc, cfg->cov_acc, 24); std::memcpy(a.cov_bias_gyr, cfg->cov_bias_gyr, 24); std::memcpy(a.cov_bias_acc, cfg->cov_bias_acc, 24);
   a.cov_inv_expo = cfg->cov_inv_expo; a.G_m_s2 = cfg->G_m_s2; a.mean_acc_norm = cfg->mean_acc_norm;
   a.in = ctx->d_imu_state; a.out = ctx->d_imu_state + 1; a.poses = poses;

@@ -360,6 +360,7 @@ void ImuProcess::ForwardPropagate(StatesGroup &state_inout, const std::vector<li
   c.cov_inv_expo = cov_inv_expo; c.G_m_s2 = 9.81;                                  // reference include/common_lib.h:29
   c.mean_acc_norm = std::sqrt(mean_acc[0] * mean_acc[0] + mean_acc[1] * mean_acc[1] + mean_acc[2] * mean_acc[2]);
   c.ba_bg_est_en = ba_bg_est_en; c.gravity_est_en = gravity_est_en; c.exposure_estimate_en = exposure_estimate_en;
+  c.first_call = imu_time_init ? 0 : 1; imu_time_init = true;                      // IMU_Processing.cpp:305-317: tau = 1.0 on the first call
   livo2_state s_in, s_out;
   state_inout.to_abi(s_in);
   std::vector<livo2_imu_pose> pushed(std::max<size_t>(steps.size(), 1));

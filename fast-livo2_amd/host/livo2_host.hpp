@@ -187,6 +187,7 @@ public:
   V3D cov_acc{{0.1, 0.1, 0.1}}, cov_gyr{{0.1, 0.1, 0.1}}, cov_bias_gyr{{0.1, 0.1, 0.1}}, cov_bias_acc{{0.1, 0.1, 0.1}}, mean_acc{{0, 0, -1.0}};   // IMU_Processing.cpp:19-24
   double cov_inv_expo = 0.2;
   bool ba_bg_est_en = true, gravity_est_en = true, exposure_estimate_en = true;
+  bool imu_time_init = false;               // IMU_Processing.cpp:28, 305-310
   std::vector<livo2_imu_pose> IMUpose;      // Pose6D list (msg/Pose6D.msg)
   explicit ImuProcess(Device &dev) : dev_(dev) {}
   // The forward loop of UndistortPcl (reference src/IMU_Processing.cpp:322-445) for the steps its time-stamp logic produced: one step per

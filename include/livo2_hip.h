@@ -108,7 +108,9 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
 typedef struct livo2_imu_step { double gyr[3], acc[3], dt, offs_t; } livo2_imu_step;
 typedef struct livo2_imu_cfg {
   double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm;
-  int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en, pad;
+  int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en;
+  int32_t first_call;           /* !imu_time_init: the first UndistortPcl call forces state_inout.inv_expo_time = tau = 1.0 (IMU_Processing.cpp:305-317, 444);
+                                 * every later call passes the state's own inv_expo_time through */
 } livo2_imu_cfg;
 struct livo2_imu_pose;
 int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu_step *steps, int32_t n_steps, const livo2_imu_cfg *cfg,

@@ -318,7 +318,7 @@ def feat_map_keys(pos, lib=None):
 class ImuCfg(C.Structure):
     _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3), ("cov_bias_acc", C.c_double * 3), ("cov_inv_expo", C.c_double),
                 ("G_m_s2", C.c_double), ("mean_acc_norm", C.c_double), ("ba_bg_est_en", C.c_int32), ("gravity_est_en", C.c_int32), ("exposure_estimate_en", C.c_int32),
-                ("pad", C.c_int32)]
+                ("first_call", C.c_int32)]
 
 
 def imu_cfg(d, cls=ImuCfg):
@@ -327,6 +327,7 @@ def imu_cfg(d, cls=ImuCfg):
         getattr(c, k)[:] = [float(x) for x in d[k]]
     c.cov_inv_expo, c.G_m_s2, c.mean_acc_norm = float(d["cov_inv_expo"]), float(d["G_m_s2"]), float(d["mean_acc_norm"])
     c.ba_bg_est_en, c.gravity_est_en, c.exposure_estimate_en = int(d["ba_bg_est_en"]), int(d["gravity_est_en"]), int(d["exposure_estimate_en"])
+    c.first_call = int(d.get("first_call", 0))
     return c
 
 

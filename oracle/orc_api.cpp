@@ -476,13 +476,13 @@ void orc_choose_ref(int normal_en, const double *R_cur9, const double *t_cur3, i
 }
 
 // IMU forward propagation (orc_imu.hpp).  steps: n x 8 doubles (gyr3, acc3, dt, offs_t); cfg: 13 doubles + 3 flags; poses out: n x 22 doubles.
-struct orc_imu_cfg { double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm; int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en, pad; };
+struct orc_imu_cfg { double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo, G_m_s2, mean_acc_norm; int32_t ba_bg_est_en, gravity_est_en, exposure_estimate_en, first_call; };
 double orc_imu_propagate(const StatePOD *in, const double *steps8, int n, const orc_imu_cfg *c, StatePOD *out, double *poses22) {
   StatesGroup st; st.from_pod(*in);
   ImuCfg cfg;
   std::memcpy(cfg.cov_gyr, c->cov_gyr, 24); std::memcpy(cfg.cov_acc, c->cov_acc, 24); std::memcpy(cfg.cov_bias_gyr, c->cov_bias_gyr, 24); std::memcpy(cfg.cov_bias_acc, c->cov_bias_acc, 24);
   cfg.cov_inv_expo = c->cov_inv_expo; cfg.G_m_s2 = c->G_m_s2; cfg.mean_acc_norm = c->mean_acc_norm;
-  cfg.ba_bg_est_en = c->ba_bg_est_en; cfg.gravity_est_en = c->gravity_est_en; cfg.exposure_estimate_en = c->exposure_estimate_en;
+  cfg.ba_bg_est_en = c->ba_bg_est_en; cfg.gravity_est_en = c->gravity_est_en; cfg.exposure_estimate_en = c->exposure_estimate_en; cfg.first_call = c->first_call;
   std::vector<ImuStep> S((size_t)n); std::vector<Pose6D> P((size_t)n);
   static_assert(sizeof(ImuStep) == 64, "ImuStep is 8 doubles");
   if (n) std::memcpy(S.data(), steps8, (size_t)n * 64);

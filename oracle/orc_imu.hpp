@@ -20,6 +20,7 @@ struct ImuCfg {
   double cov_gyr[3], cov_acc[3], cov_bias_gyr[3], cov_bias_acc[3], cov_inv_expo;
   double G_m_s2, mean_acc_norm;                     // acc_avr * G_m_s2 / mean_acc.norm()
   int ba_bg_est_en, gravity_est_en, exposure_estimate_en;
+  int first_call = 0;          // !imu_time_init (IMU_Processing.cpp:305-310): tau = 1.0
 };
 
 // state_inout: in = state at prop_beg_time, out = state_propagat.  poses[n_steps] receives the Pose6D pushed per step (the entry at offset 0,
@@ -27,7 +28,7 @@ struct ImuCfg {
 inline void imu_propagate(StatesGroup &state_inout, const ImuStep *steps, int n_steps, const ImuCfg &cfg, Pose6D *poses) {
   V3 vel_imu = state_inout.vel_end, pos_imu = state_inout.pos_end;
   M3 R_imu = state_inout.rot_end;
-  const double tau = state_inout.inv_expo_time;
+  const double tau = cfg.first_call ? 1.0 : state_inout.inv_expo_time;      // IMU_Processing.cpp:305-317
   for (int i = 0; i < n_steps; i++) {
     V3 angvel_avr = vec3(steps[i].gyr[0], steps[i].gyr[1], steps[i].gyr[2]);
     V3 acc_avr = vec3(steps[i].acc[0], steps[i].acc[1], steps[i].acc[2]);

@@ -146,7 +146,7 @@ def test_shim_matches_oracle(tmp_path, orc, livo2):
     assert np.allclose(vout2[:25], vref2v[:25], rtol=0, atol=1e-8) and H.relerr(vout2[25:], vref2v[25:]) < 1e-7
 
     # IMU propagation and the pre-stage through the shim
-    iref, iposes, _ = orc.imu_propagate(ist, isteps, IMU.CFG)
+    iref, iposes, _ = orc.imu_propagate(ist, isteps, dict(IMU.CFG, first_call=1))          # the shim's first ForwardPropagate: imu_time_init is false, tau = 1.0
     iout = np.fromfile(os.path.join(d, "imu_out_state.bin"))
     irefv = _state_vec(iref)
     assert np.allclose(iout[:25], irefv[:25], rtol=0, atol=1e-12) and H.relerr(iout[25:], irefv[25:]) < 1e-12

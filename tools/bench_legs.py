@@ -56,7 +56,7 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
     launch (configs[4] shape on one GPU), whole frames per second including the PCIe legs.  `w` is bench.C4 (resident on ctx); the C4 map / scan are
     NOT resident any more on return (widened_rows re-uploads what it needs)."""
     extra = {}
-    legs = set((args.legs or "single,lockstep,live,c2,c3,batched,ooc").split(","))
+    legs = set((args.legs or "single,lockstep,live,c2,c3,batched,ooc,map").split(","))
     steps = 100
     cur, vcur = w.lid[0], w.vis[0]
     if "single" in legs:
@@ -67,6 +67,11 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
         _live_leg(ctx, w, extra)
     if legs & {"c2", "c3", "batched", "ooc"}:
         _c2_legs(ctx, livo2, synth, H, args, extra, copy_gbs, legs)
+    if "map" in legs:
+        try:
+            _map_update_leg(ctx, livo2, synth, H, extra)
+        except Exception as exc:
+            extra["map_update"] = {"error": repr(exc)}
     return extra
 
 
@@ -210,6 +215,63 @@ def _batched_leg(ctx, livo2, synth, args, extra, copy_gbs, sc2, cfg2, n2):
                             "frames_per_s": B * reps_b / tfb, "full_update_iters": [int(r.n_iters) for r in rb],
                             "note": "same device code as the single-scan path with 64-point blocks, B independent (scan, state) problems per grid; the frames share ONE map snapshot, so most "
                                     "plane-record reads are cache hits (see extra.out_of_cache for the leg whose working set exceeds the 256 MiB Infinity Cache)"}
+
+
+MAP_UPDATE_CASES = (("avia_15k", (20.0, 20.0, 6.0), 8, 200000, 24000, False, 91), ("c2_94k", (60.0, 60.0, 10.0), 24, 1200000, 160000, True, 92))
+
+
+def map_update_case(synth, case):
+    """(lio cfg, map sweep world points + covariances, [down-sampled scans of a short trajectory with their true poses], extrinsics) of one map-maintenance case"""
+    name, room, boxes, n_map, n_rays, full, seed = case
+    rng = np.random.default_rng(seed)
+    c = dict(synth.AVIA["lio"])
+    scene = synth.make_room(rng, room, boxes)
+    extR, extT = synth.AVIA["extrinsic_R"], synth.AVIA["extrinsic_T"]
+    R0, t0 = scene.R_ws @ synth.rot_from_rpy(0.01, -0.015, 0.4), scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    P0 = synth.default_cov() * 1e-3
+    chunks = []
+    while sum(len(x) for x in chunks) < n_map:
+        chunks.append(synth.lidar_scan(rng, scene, R0, t0, extR, extT, min(400000, n_map), c["dept_err"], c["beam_err"], synth.AVIA["blind"], full))
+    xyz_map = np.concatenate(chunks)[:n_map]
+    pw0, var0 = synth.world_points_and_var(xyz_map, R0, t0, extR, extT, P0, c["dept_err"], c["beam_err"])
+    frames = []
+    for k in range(4):
+        Rk, tk = R0 @ synth.rot_from_rpy(0.0, 0.0, 0.05 * (k + 1)), t0 + np.array([0.25 * (k + 1), 0.1 * k, 0.0])
+        xyz = synth.voxel_grid_downsample(synth.lidar_scan(rng, scene, Rk, tk, extR, extT, n_rays, c["dept_err"], c["beam_err"], synth.AVIA["blind"], full), synth.AVIA["filter_size_surf"])
+        frames.append((np.ascontiguousarray(xyz, np.float32), Rk, tk))
+    return c, pw0, var0.reshape(-1, 9), frames, extR, extT, P0
+
+
+def _map_update_leg(ctx, livo2, synth, H, extra):
+    """map maintenance with the octree resident on the device — per frame: StateEstimation on the resident tree, then UpdateVoxelMap from the posterior
+    (pv_list_ formed on the device, LIVMapper.cpp:413-423); nothing but the scan and the states crosses PCIe, no snapshot is flattened or uploaded."""
+    out = {}
+    for case in MAP_UPDATE_CASES:
+        c, pw0, var0, frames, extR, extT, P0 = map_update_case(synth, case)
+        ctx.map_tree_create(c, max_roots=max(20000, len(pw0) // 8))
+        t0 = time.perf_counter(); ctx.map_tree_update(pw0, var0, build=True); t_build = time.perf_counter() - t0
+        build_us = ctx.map_tree_last_kernel_us()
+        st0 = ctx.map_tree_stats()
+        rows = []
+        for xyz, Rk, tk in frames:
+            sc = synth.LidarScenario(None, xyz, Rk, tk, Rk @ synth.so3_exp(np.array([0.003, -0.002, 0.004])), tk + np.array([0.015, -0.01, 0.008]), synth.prior_cov(np.random.default_rng(3)), extR, extT, c)
+            cfg = H.lidar_cfg_product(sc)
+            cur, prop = make_states(livo2, sc)
+            t1 = time.perf_counter(); ctx.set_scan(xyz, cfg); t2 = time.perf_counter()
+            res, _ = ctx.lidar_update(cur, prop, cfg); t3 = time.perf_counter()
+            ctx.map_tree_update_from_scan(res.state, cfg); t4 = time.perf_counter()
+            st = ctx.map_tree_stats()
+            rows.append(dict(points=len(xyz), set_scan_ms=1e3 * (t2 - t1), lidar_update_ms=1e3 * (t3 - t2), map_update_ms=1e3 * (t4 - t3), map_update_kernel_us=ctx.map_tree_last_kernel_us(),
+                             roots_touched=st["touched"], n_eff=int(res.iter_sums[res.n_iters - 1].n_eff), iterations=int(res.n_iters)))
+        st1 = ctx.map_tree_stats()
+        out[case[0]] = {"map_points": len(pw0), "build_ms_with_h2d": 1e3 * t_build, "build_kernel_us": build_us, "roots_after_build": st0["roots"], "nodes_after_build": st0["nodes"],
+                        "planes_after_build": st0["planes"], "frames": rows, "map_update_ms_median": float(np.median([r["map_update_ms"] for r in rows])),
+                        "map_update_kernel_us_median": float(np.median([r["map_update_kernel_us"] for r in rows])),
+                        "roots_after": st1["roots"], "nodes_after": st1["nodes"], "planes_after": st1["planes"], "temp_points_reserved": st1["points"]}
+    out["note"] = ("livo2_map_tree_update_from_scan: pv_list_ from the posterior + sort by root voxel + segments + root lookup / creation + the per-point octree state machine "
+                   "(8 lanes per touched root voxel, init_plane inside) + slot / candidate-list refresh; host part = one 3 KB state H2D and one 32-B counter D2H; "
+                   "CPU figure (oracle's serial UpdateVoxelMap on the same frames): cpu_baseline.map_update_ms")
+    extra["map_update"] = out
 
 
 def tiled_map(fm, offsets):
