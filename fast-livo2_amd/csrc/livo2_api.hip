@@ -965,6 +965,36 @@ int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts) {
 }
 double livo2_map_tree_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->mt_kernel_us : 0.0; }
 
+int livo2_map_tree_read_planes(livo2_ctx *ctx, const int32_t *rows, int32_t n, double *normal, double *center, double *plane_var, float *d, float *radius, int32_t *layer) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "no device map tree");
+  if (n < 0 || (n > 0 && !rows)) return fail(ctx, LIVO2_ERR_INVALID, "bad rows");
+  if (n == 0) return LIVO2_OK;
+  for (int i = 0; i < n; i++) if (rows[i] < 0 || rows[i] >= ctx->mt.cap_planes) return fail(ctx, LIVO2_ERR_INVALID, "plane row out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  int32_t *d_rows = nullptr; double *d_out = nullptr;
+  HIPCHK(hipMalloc((void **)&d_rows, (size_t)n * 4));
+  HIPCHK(hipMalloc((void **)&d_out, (size_t)n * PLANE_REC_DOUBLES * 8));
+  HIPCHK(hipMemcpyAsync(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_mt_gather_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_planes, d_rows, n, d_out);
+  std::vector<double> recs((size_t)n * PLANE_REC_DOUBLES);
+  HIPCHK(hipMemcpyAsync(recs.data(), d_out, recs.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(d_rows)); HIPCHK(hipFree(d_out));
+  for (int p = 0; p < n; p++) {
+    const double *rec = &recs[(size_t)p * PLANE_REC_DOUBLES];
+    if (normal) for (int k = 0; k < 3; k++) normal[(size_t)p * 3 + k] = rec[k];
+    if (center) for (int k = 0; k < 3; k++) center[(size_t)p * 3 + k] = rec[3 + k];
+    if (plane_var) { int q = 6; for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { plane_var[(size_t)p * 36 + a * 6 + b] = rec[q]; plane_var[(size_t)p * 36 + b * 6 + a] = rec[q]; q++; } }
+    float dr[2]; std::memcpy(dr, &rec[27], 8);
+    int32_t meta[2]; std::memcpy(meta, &rec[28], 8);
+    if (d) d[p] = dr[0];
+    if (radius) radius[p] = dr[1];
+    if (layer) layer[p] = meta[0];
+  }
+  return LIVO2_OK;
+}
+
 int livo2_map_tree_export(livo2_ctx *ctx, int64_t *root_key, int32_t *root_node, double *root_center, float *root_quarter, int32_t *node_plane, int32_t *node_child,
                           double *plane_normal, double *plane_center, double *plane_var, float *plane_d, float *plane_radius, int32_t *node_temp) {
   if (!ctx) return LIVO2_ERR_INVALID;

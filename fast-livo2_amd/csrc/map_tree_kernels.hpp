@@ -247,8 +247,9 @@ struct MtGroup {
         for (int u = r; u < 6; u++) { put(q, 0.5 * (R.pv[r * 6 + u] + R.pv[u * 6 + r])); q++; }
     }
     put(27, __builtin_bit_cast(double, make_float2(dd, radius)));
+    put(28, __builtin_bit_cast(double, make_int2(n.layer, 0)));       // PointToPlane::layer_ of a match (livo2_map_tree_read_planes); the residual kernel reads words 0..27
 #pragma unroll
-    for (int k = 28; k < 32; k++) put(k, 0.0);
+    for (int k = 29; k < 32; k++) put(k, 0.0);
   }
   __device__ int octant(const DevNode &n, const double *pw) const { return 4 * (pw[0] > n.center[0] ? 1 : 0) + 2 * (pw[1] > n.center[1] ? 1 : 0) + (pw[2] > n.center[2] ? 1 : 0); }
   // leaves_[leafnum] = new VoxelOctoTree(...) (voxel_map.cpp:179-186 / 255-262); returns its id (-1: pool exhausted)
@@ -442,6 +443,12 @@ __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t 
     }
   }
   if (lane == 0) { const int at = atomicAdd(&a.counters[MTC_DIRTY], 1); a.dirty_list[at] = root; }      // (one segment per root: no duplicates)
+}
+
+// rows of the plane table -> a packed array (livo2_map_tree_read_planes)
+__global__ void __launch_bounds__(256) k_mt_gather_planes(const double *__restrict__ planes, const int32_t *__restrict__ rows, int n, double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, p = t >> 5, k = t & 31;
+  if (p < n) out[(size_t)p * PLANE_REC_DOUBLES + k] = planes[(size_t)rows[p] * PLANE_REC_DOUBLES + k];
 }
 
 // ---- what k_lidar_residual reads: the root's slot and, for a non-plane root, the depth-first list of its descendant planes (record copies) -----------

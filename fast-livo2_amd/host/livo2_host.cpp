@@ -245,8 +245,37 @@ void VoxelMapManager::maintain(const std::vector<pointWithVar> &input_points, bo
   map_dirty_ = true;                                                      // the snapshot is re-flattened before the next StateEstimation
 }
 
-void VoxelMapManager::BuildVoxelMap(const std::vector<pointWithVar> &input_points) { maintain(input_points, true); }
-void VoxelMapManager::UpdateVoxelMap(const std::vector<pointWithVar> &input_points) { maintain(input_points, false); }
+static void device_tree_feed(Device &dev, const std::vector<pointWithVar> &pts, bool build) {
+  std::vector<double> pw(pts.size() * 3), var(pts.size() * 9);
+  for (size_t i = 0; i < pts.size(); i++) { std::memcpy(&pw[i * 3], pts[i].point_w.data(), 24); std::memcpy(&var[i * 9], pts[i].var.data(), 72); }
+  dev.check(livo2_map_tree_update(dev.ctx(), pw.data(), var.data(), (int32_t)pts.size(), build ? 1 : 0));
+}
+void VoxelMapManager::BuildVoxelMap(const std::vector<pointWithVar> &input_points) {
+  if (!device_map_) { maintain(input_points, true); return; }
+  livo2_map_tree_cfg tc{};
+  tc.voxel_size = config_setting_.max_voxel_size_; tc.planer_threshold = config_setting_.planner_threshold_; tc.max_layer = config_setting_.max_layer_;
+  tc.max_points_num = config_setting_.max_points_num_; tc.max_roots = device_map_max_roots_;
+  for (int k = 0; k < 5; k++) tc.layer_init_num[k] = config_setting_.layer_init_num_[std::min<size_t>(k, config_setting_.layer_init_num_.size() - 1)];
+  dev_.check(livo2_map_tree_create(dev_.ctx(), &tc));
+  device_tree_feed(dev_, input_points, true);
+  last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
+  map_dirty_ = false;
+}
+void VoxelMapManager::UpdateVoxelMap(const std::vector<pointWithVar> &input_points) {
+  if (!device_map_) { maintain(input_points, false); return; }
+  device_tree_feed(dev_, input_points, false);
+  last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
+}
+void VoxelMapManager::UpdateVoxelMapFromPosterior() {
+  if (!device_map_) throw std::runtime_error("UpdateVoxelMapFromPosterior needs device_map_");
+  livo2_lidar_cfg cfg{};
+  cfg.max_iterations = config_setting_.max_iterations_; cfg.max_layer = config_setting_.max_layer_; cfg.sigma_num = config_setting_.sigma_num_;
+  cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
+  std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
+  livo2_state s; state_.to_abi(s);
+  dev_.check(livo2_map_tree_update_from_scan(dev_.ctx(), &s, &cfg, 0));
+  last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
+}
 
 void VoxelMapManager::FitPlanes(const std::vector<VoxelOctoTree *> &voxels) {
   const int G = (int)voxels.size();
@@ -276,7 +305,7 @@ void VoxelMapManager::FitPlanes(const std::vector<VoxelOctoTree *> &voxels) {
 }
 
 void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
-  if (map_dirty_) FlattenAndUpload();
+  if (!device_map_ && map_dirty_) FlattenAndUpload();
   const int n = (int)feats_down_body_.size();
   feats_down_size_ = n;
   livo2_lidar_cfg cfg{};
@@ -311,6 +340,15 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   }
 
   // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811)
+  // device-resident map: the VoxelPlane members of the matched rows come from the device plane table
+  std::vector<int32_t> rows; std::vector<double> r_normal, r_center, r_pvar; std::vector<float> r_d; std::vector<int32_t> r_layer;
+  std::unordered_map<int32_t, int32_t> row_at;
+  if (device_map_) {
+    for (int i = 0; i < n; i++)
+      for (int32_t r : {match[i], normal_plane[i]}) if (r >= 0 && row_at.emplace(r, (int32_t)rows.size()).second) rows.push_back(r);
+    r_normal.resize(rows.size() * 3); r_center.resize(rows.size() * 3); r_pvar.resize(rows.size() * 36); r_d.resize(rows.size()); r_layer.resize(rows.size());
+    dev_.check(livo2_map_tree_read_planes(dev_.ctx(), rows.data(), (int32_t)rows.size(), r_normal.data(), r_center.data(), r_pvar.data(), r_d.data(), nullptr, r_layer.data()));
+  }
   pv_list_.assign(n, pointWithVar());
   cross_mat_list_.resize(n); body_cov_list_.resize(n);
   ptpl_list_.clear();
@@ -326,6 +364,18 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     double q[3];
     for (int j = 0; j < 3; j++) q[j] = extR_[j * 3] * p.x + extR_[j * 3 + 1] * p.y + extR_[j * 3 + 2] * pz + extT_[j];
     cross_mat_list_[i] = {0.0, -q[2], q[1], q[2], 0.0, -q[0], -q[1], q[0], 0.0};
+    if (device_map_) {
+      if (normal_plane[i] >= 0) std::memcpy(pv.normal.data(), &r_normal[(size_t)row_at[normal_plane[i]] * 3], 24);
+      if (match[i] >= 0) {
+        const size_t k = (size_t)row_at[match[i]];
+        PointToPlane pp;
+        pp.point_b_ = pv.point_b; pp.point_w_ = pv.point_w; std::memcpy(pp.normal_.data(), &r_normal[k * 3], 24); std::memcpy(pp.center_.data(), &r_center[k * 3], 24);
+        std::memcpy(pp.plane_var_.data(), &r_pvar[k * 36], 288);
+        pp.body_cov_ = pv.body_var; pp.layer_ = r_layer[k]; pp.d_ = r_d[k]; pp.is_valid_ = true; pp.dis_to_plane_ = dis[i];
+        ptpl_list_.push_back(pp);
+      }
+      continue;
+    }
     if (normal_plane[i] >= 0) pv.normal = plane_by_index_[normal_plane[i]]->normal_;
     if (match[i] >= 0) {
       const VoxelPlane *pl = plane_by_index_[match[i]];

@@ -169,6 +169,14 @@ public:
   void BuildVoxelMap(const std::vector<pointWithVar> &input_points);
   void UpdateVoxelMap(const std::vector<pointWithVar> &input_points);
   int last_fit_rounds_ = 0, last_fit_count_ = 0;      // device batches / plane fits of the last Build / Update call
+  // Device-resident map (livo2_map_tree_*): with device_map_ set BEFORE BuildVoxelMap, voxel_map_ stays empty on the host — the octree, its temp_points_ and the
+  // plane table live on the GPU, BuildVoxelMap / UpdateVoxelMap feed them, StateEstimation reads them, and ptpl_list_ / pv.normal are filled from the device
+  // plane rows of the matches.  UpdateVoxelMapFromPosterior() is LIVMapper.cpp:413-424 in one call: pv_list_[i].point_w / .var of the posterior state_ are
+  // formed on the device from the scan that StateEstimation left resident, and fed to UpdateVoxelMap there (nothing crosses PCIe but the state).
+  bool device_map_ = false;
+  int device_map_max_roots_ = 300000;
+  void UpdateVoxelMapFromPosterior();
+  double last_map_kernel_us_ = 0;
 
 private:
   void FlattenAndUpload();

@@ -80,6 +80,21 @@ static void dump_map(const VoxelMapManager &vm, const std::string &dir, const st
   wr(dir, (prefix + "plane_normal").c_str(), f.pn.data(), f.pn.size()); wr(dir, (prefix + "plane_center").c_str(), f.pc.data(), f.pc.size());
   wr(dir, (prefix + "plane_var").c_str(), f.pv.data(), f.pv.size()); wr(dir, (prefix + "plane_d").c_str(), f.pd.data(), f.pd.size()); wr(dir, (prefix + "plane_radius").c_str(), f.pr.data(), f.pr.size());
 }
+// the device-resident map (livo2_map_tree_export) in the same files
+static void dump_device_map(Device &dev, const std::string &dir, const std::string &prefix) {
+  int32_t c[8];
+  dev.check(livo2_map_tree_stats(dev.ctx(), c));
+  const size_t R = (size_t)c[7], N = (size_t)std::max(c[0], 1), P = (size_t)std::max(c[2], 1);
+  std::vector<int64_t> root_key(R * 3); std::vector<int32_t> root_node(R), node_plane(N), node_child(N * 8);
+  std::vector<double> root_center(R * 3), pn(P * 3), pc(P * 3), pv(P * 36); std::vector<float> root_quarter(R), pd(P), pr(P);
+  dev.check(livo2_map_tree_export(dev.ctx(), root_key.data(), root_node.data(), root_center.data(), root_quarter.data(), node_plane.data(), node_child.data(), pn.data(), pc.data(),
+                                  pv.data(), pd.data(), pr.data(), nullptr));
+  wr(dir, (prefix + "root_key").c_str(), root_key.data(), root_key.size()); wr(dir, (prefix + "root_node").c_str(), root_node.data(), root_node.size());
+  wr(dir, (prefix + "root_center").c_str(), root_center.data(), root_center.size()); wr(dir, (prefix + "root_quarter").c_str(), root_quarter.data(), root_quarter.size());
+  wr(dir, (prefix + "node_plane").c_str(), node_plane.data(), (size_t)c[0]); wr(dir, (prefix + "node_child").c_str(), node_child.data(), (size_t)c[0] * 8);
+  wr(dir, (prefix + "plane_normal").c_str(), pn.data(), (size_t)c[2] * 3); wr(dir, (prefix + "plane_center").c_str(), pc.data(), (size_t)c[2] * 3);
+  wr(dir, (prefix + "plane_var").c_str(), pv.data(), (size_t)c[2] * 36); wr(dir, (prefix + "plane_d").c_str(), pd.data(), (size_t)c[2]); wr(dir, (prefix + "plane_radius").c_str(), pr.data(), (size_t)c[2]);
+}
 static std::vector<pointWithVar> points_from(const std::vector<double> &pw, const std::vector<double> &var) {
   std::vector<pointWithVar> v(pw.size() / 3);
   for (size_t i = 0; i < v.size(); i++) { for (int k = 0; k < 3; k++) v[i].point_w[k] = pw[i * 3 + k]; for (int k = 0; k < 9; k++) v[i].var[k] = var[i * 9 + k]; }
@@ -212,6 +227,7 @@ int main(int argc, char **argv) {
       auto mc = rd<double>(dir, "seq_map_cfg"); auto lc = rd<double>(dir, "seq_lidar_cfg");
       auto scans = rd<float>(dir, "seq_scans"); auto motion = rd<double>(dir, "seq_motion"); auto qd = rd<double>(dir, "seq_q");
       VoxelMapManager vm(dev);
+      vm.device_map_ = !rd<int32_t>(dir, "seq_device_map").empty();      // the octree on the GPU (livo2_map_tree_*) instead of on the host
       vm.config_setting_.max_voxel_size_ = mc[0]; vm.config_setting_.max_layer_ = (int)mc[1]; vm.config_setting_.max_points_num_ = (int)mc[2]; vm.config_setting_.planner_threshold_ = mc[3];
       vm.config_setting_.layer_init_num_.assign(5, 5);
       for (int k = 0; k < 5; k++) vm.config_setting_.layer_init_num_[k] = (int)mc[4 + k];
@@ -236,6 +252,13 @@ int main(int argc, char **argv) {
         vm.state_ = prop;
         vm.StateEstimation(prop);
         post = vm.state_;
+        if (vm.device_map_) {                                           // LIVMapper.cpp:413-424 in one device call
+          vm.UpdateVoxelMapFromPosterior();
+          auto so = state_to(post);
+          traj.insert(traj.end(), so.begin(), so.begin() + 12);
+          std::printf("seq frame %zu: effct_feat_num_=%d, device map update %.0f us\n", f, vm.effct_feat_num_, vm.last_map_kernel_us_);
+          continue;
+        }
         // LIVMapper.cpp:413-423: world points (float cloud) and their covariance from the posterior
         M3D RE;
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RE[r * 3 + c] = post.rot_end[r * 3] * vm.extR_[c] + post.rot_end[r * 3 + 1] * vm.extR_[3 + c] + post.rot_end[r * 3 + 2] * vm.extR_[6 + c];
@@ -259,7 +282,7 @@ int main(int argc, char **argv) {
         std::printf("seq frame %zu: effct_feat_num_=%d, %d plane fits in %d batches\n", f, vm.effct_feat_num_, vm.last_fit_count_, vm.last_fit_rounds_);
       }
       wr(dir, "seq_out_traj", traj.data(), traj.size());
-      dump_map(vm, dir, "seq_out_");
+      if (vm.device_map_) dump_device_map(dev, dir, "seq_out_"); else dump_map(vm, dir, "seq_out_");
     }
     // ---- visual -----------------------------------------------------------------------------------------------------------
     auto img = rd<uint8_t>(dir, "img");

@@ -189,6 +189,9 @@ int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts);
  * planes = counts[2]); node_plane[i] = row of the node's plane if is_plane_, else -1.  node_temp (may be NULL) = temp_points_.size() per node. */
 int livo2_map_tree_export(livo2_ctx *ctx, int64_t *root_key, int32_t *root_node, double *root_center, float *root_quarter, int32_t *node_plane, int32_t *node_child,
                           double *plane_normal, double *plane_center, double *plane_var, float *plane_d, float *plane_radius, int32_t *node_temp);
+/* The VoxelPlane members a match carries into ptpl_list_ (PointToPlane: normal_, center_, plane_var_, d_, layer_; src/voxel_map.cpp:744-755) for `n` rows of the
+ * device plane table (the values of livo2_lidar_points::match_plane / normal_plane while a tree is resident).  Any output may be NULL. */
+int livo2_map_tree_read_planes(livo2_ctx *ctx, const int32_t *rows, int32_t n, double *normal, double *center, double *plane_var, float *d, float *radius, int32_t *layer);
 /* kernel time of the last livo2_map_tree_update* call in microseconds (HIP events on the ctx stream; sort + segmentation + octree + emit) */
 double livo2_map_tree_last_kernel_us(const livo2_ctx *ctx);
 

@@ -29,8 +29,13 @@ def _glue(xyz, R, t, P, extR, extT, c):
     return pw, RE @ cb @ RE.T + X @ P[0:3, 0:3] @ X.transpose(0, 2, 1) + P[3:6, 3:6]
 
 
-def test_lio_sequence_matches_oracle(tmp_path, orc):
+@pytest.mark.parametrize("device_map", [False, True])
+def test_lio_sequence_matches_oracle(tmp_path, orc, device_map):
+    """device_map: the shim keeps the octree on the GPU (VoxelMapManager::device_map_, livo2_map_tree_*): BuildVoxelMap from the host points once, then per frame
+    StateEstimation on the resident tree and UpdateVoxelMapFromPosterior — no host octree, no snapshot upload"""
     d = str(tmp_path)
+    if device_map:
+        np.array([1], np.int32).tofile(os.path.join(d, "seq_device_map.bin"))
     rng = np.random.default_rng(91)
     c = dict(synth.AVIA["lio"])
     extR, extT = synth.AVIA["extrinsic_R"], synth.AVIA["extrinsic_T"]
