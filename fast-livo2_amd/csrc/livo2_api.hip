@@ -45,6 +45,8 @@ struct livo2_ctx {
   bool in_used[16] = {};
   int in_next = 0;
   void *h_out = nullptr;                    // pinned, sizeof(livo2_visual_result) (largest result)
+  void *h_pts = nullptr; size_t h_pts_cap = 0;   // pinned staging of the per-point outputs
+  void *scan_stage[2] = {nullptr, nullptr}; size_t scan_stage_cap[2] = {0, 0}; hipEvent_t scan_stage_ev[2] = {nullptr, nullptr}; bool scan_stage_used[2] = {false, false}; int scan_stage_next = 0;
   // map
   bool has_map = false;
   DevMap map{};
@@ -312,6 +314,9 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   return a;
 }
 
+// Per-point outputs (pv_list_ / ptpl_list_ / body_cov_list_ members) come back through ONE pinned staging block owned by the ctx: every selected
+// array is copied D2H into it asynchronously (pinned memory: DMA at link rate, no hidden pageable bounce buffer per call), one synchronisation, then a host copy
+// into the caller's arrays.
 int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   if (!p) return LIVO2_OK;
   const livo2_lidar_points &w = ctx->want_l;
@@ -319,23 +324,35 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   if ((p->match_plane && !w.match_plane) || (p->dis_to_plane && !w.dis_to_plane) || (p->point_w && !w.point_w) || (p->normal_plane && !w.normal_plane) ||
       (p->var && !w.var) || (p->r_inv && !w.r_inv) || (p->h_row && !w.h_row))
     return fail(ctx, LIVO2_ERR_INVALID, "per-point array requested at fetch was not selected at enqueue");
-  if (p->match_plane) HIPCHK(hipMemcpyAsync(p->match_plane, ctx->d_match, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->dis_to_plane) HIPCHK(hipMemcpyAsync(p->dis_to_plane, ctx->d_dis, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->point_w) HIPCHK(hipMemcpyAsync(p->point_w, ctx->d_pw, n * 12, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->normal_plane) HIPCHK(hipMemcpyAsync(p->normal_plane, ctx->d_normal_plane, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->var) HIPCHK(hipMemcpyAsync(p->var, ctx->d_var, n * 72, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->r_inv) HIPCHK(hipMemcpyAsync(p->r_inv, ctx->d_rinv, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (p->h_row) HIPCHK(hipMemcpyAsync(p->h_row, ctx->d_hrow, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+  struct Item { void *dst; const void *src; size_t bytes; };
+  const Item items[] = {{p->match_plane, ctx->d_match, n * 4}, {p->dis_to_plane, ctx->d_dis, n * 4}, {p->point_w, ctx->d_pw, n * 12}, {p->normal_plane, ctx->d_normal_plane, n * 4},
+                        {p->var, ctx->d_var, n * 72}, {p->r_inv, ctx->d_rinv, n * 8}, {p->h_row, ctx->d_hrow, n * 48},
+                        {p->body_cov ? (void *)p->body_cov : nullptr, ctx->d_cb, 6 * n * 8}, {p->body_cov ? (void *)p->body_cov : nullptr, ctx->d_perm, n * 4}};
+  size_t total = 0;
+  for (const Item &it : items) if (it.dst) total += (it.bytes + 63) & ~(size_t)63;
+  if (total == 0) return LIVO2_OK;
+  if (total > ctx->h_pts_cap) {
+    if (ctx->h_pts) HIPCHK(hipHostFree(ctx->h_pts));
+    ctx->h_pts = nullptr; ctx->h_pts_cap = 0;
+    HIPCHK(hipHostMalloc(&ctx->h_pts, total + total / 4));
+    ctx->h_pts_cap = total + total / 4;
+  }
+  char *base = static_cast<char *>(ctx->h_pts);
+  size_t off = 0, offs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 9; k++) {
+    if (!items[k].dst) continue;
+    offs[k] = off;
+    if (items[k].bytes) HIPCHK(hipMemcpyAsync(base + off, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
+    off += (items[k].bytes + 63) & ~(size_t)63;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 7; k++) if (items[k].dst && items[k].bytes) std::memcpy(items[k].dst, base + offs[k], items[k].bytes);
   if (p->body_cov) {          // body_cov_list_: the device keeps the symmetric 6 in sorted order; expand to 3x3 in caller order
-    std::vector<double> cb(6 * n);
-    std::vector<int32_t> perm(n);
-    HIPCHK(hipMemcpyAsync(cb.data(), ctx->d_cb, 6 * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(perm.data(), ctx->d_perm, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const double *cb = reinterpret_cast<const double *>(base + offs[7]);
+    const int32_t *perm = reinterpret_cast<const int32_t *>(base + offs[8]);
     const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
     for (size_t j = 0; j < n; j++) for (int e = 0; e < 9; e++) p->body_cov[(size_t)perm[j] * 9 + e] = cb[(size_t)map9[e] * n + j];
   }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   // device plane numbering (Morton order) -> the caller's
   if (!ctx->tree_mode) {
     if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
@@ -452,6 +469,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
+  if (ctx->h_pts) e = hipHostFree(ctx->h_pts);
+  for (int k = 0; k < 2; k++) { if (ctx->scan_stage[k]) e = hipHostFree(ctx->scan_stage[k]); if (ctx->scan_stage_ev[k]) e = hipEventDestroy(ctx->scan_stage_ev[k]); }
   if (ctx->bh_in) e = hipHostFree(ctx->bh_in);
   if (ctx->bh_results) e = hipHostFree(ctx->bh_results);
   if (ctx->bh_entries) e = hipHostFree(ctx->bh_entries);
@@ -1039,11 +1058,27 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
   if (n < 0 || (n > 0 && !xyz)) return fail(ctx, LIVO2_ERR_INVALID, "bad scan");
   int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n > ctx->n_cap) HIPCHK(hipStreamSynchronize(ctx->stream));      // the scan buffers are about to be re-allocated
   rc = scan_reserve(ctx, n); if (rc) return rc;
-  if (n > 0) HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) {
+    // the caller's (pageable) array goes through one of two pinned staging blocks: no stream synchronisation at entry or exit, the H2D of this scan
+    // overlaps whatever the stream is still doing; a block is rewritten only after the copy that read it last has completed
+    const int k = ctx->scan_stage_next; ctx->scan_stage_next ^= 1;
+    const size_t bytes = (size_t)n * 12;
+    if (ctx->scan_stage_used[k]) HIPCHK(hipEventSynchronize(ctx->scan_stage_ev[k]));
+    if (bytes > ctx->scan_stage_cap[k]) {
+      if (ctx->scan_stage[k]) HIPCHK(hipHostFree(ctx->scan_stage[k]));
+      ctx->scan_stage[k] = nullptr; ctx->scan_stage_cap[k] = 0;
+      HIPCHK(hipHostMalloc(&ctx->scan_stage[k], bytes + bytes / 4));
+      ctx->scan_stage_cap[k] = bytes + bytes / 4;
+    }
+    if (!ctx->scan_stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->scan_stage_ev[k], hipEventDisableTiming));
+    std::memcpy(ctx->scan_stage[k], xyz, bytes);
+    HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, ctx->scan_stage[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->scan_stage_ev[k], ctx->stream));
+    ctx->scan_stage_used[k] = true;
+  }
   rc = scan_pipeline(ctx, n, cfg); if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(ctx->stream));      // xyz is caller memory: do not return before the copy has consumed it
   ctx->has_scan = true;
   return LIVO2_OK;
 }
