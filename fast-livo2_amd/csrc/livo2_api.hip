@@ -331,6 +331,27 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   size_t total = 0;
   for (const Item &it : items) if (it.dst) total += (it.bytes + 63) & ~(size_t)63;
   if (total == 0) return LIVO2_OK;
+  if (total > ((size_t)8 << 20)) {
+    // large outputs (C4: 168 B x 200 000 points = 34 MB): copy straight into the caller's arrays — the runtime pipelines a pageable D2H through its own pinned
+    // chunks while it copies the previous chunk out, which a stage-everything-then-memcpy scheme does not (measured: 3.0 ms against 3.8 ms per C4 frame)
+    std::vector<double> cb; std::vector<int32_t> perm;
+    for (int k = 0; k < 7; k++) if (items[k].dst && items[k].bytes) HIPCHK(hipMemcpyAsync(items[k].dst, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (p->body_cov) {
+      cb.resize(6 * n); perm.resize(n);
+      HIPCHK(hipMemcpyAsync(cb.data(), ctx->d_cb, 6 * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(perm.data(), ctx->d_perm, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (p->body_cov) {
+      const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+      for (size_t j = 0; j < n; j++) for (int e = 0; e < 9; e++) p->body_cov[(size_t)perm[j] * 9 + e] = cb[(size_t)map9[e] * n + j];
+    }
+    if (!ctx->tree_mode) {
+      if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
+      if (p->normal_plane) for (size_t i = 0; i < n; i++) if (p->normal_plane[i] >= 0) p->normal_plane[i] = ctx->plane_orig[p->normal_plane[i]];
+    }
+    return LIVO2_OK;
+  }
   if (total > ctx->h_pts_cap) {
     if (ctx->h_pts) HIPCHK(hipHostFree(ctx->h_pts));
     ctx->h_pts = nullptr; ctx->h_pts_cap = 0;
