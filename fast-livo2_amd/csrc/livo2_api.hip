@@ -128,6 +128,7 @@ struct livo2_ctx {
   VisualBatchEntry *vbd_entries = nullptr, *vbh_entries = nullptr;      // [LIVO2_MAX_BATCH], device / pinned
   livo2_visual_result *vbd_results = nullptr, *vbh_results = nullptr;   // [LIVO2_MAX_BATCH], device / pinned
   // device-resident VoxelMap (map_tree_kernels.hpp)
+  bool visual_fused = [] { const char *e = std::getenv("LIVO2_VISUAL_FUSED"); return e ? std::atoi(e) != 0 : false; }();   // LIVO2_VISUAL_FUSED=1: one k_visual_step launch per (level, iteration) instead of residual + solve (tools/vis_probe.py)
   bool tree_mode = false;
   MapTreeArgs mt{};
   livo2_map_tree_cfg mt_cfg{};
@@ -2025,6 +2026,13 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       hipLaunchKernelGGL(k_visual_ref_precompute, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r);
     }
     for (int it = 0; it < iters; it++) {
+      if (!inverse && ctx->visual_fused) {        // one launch per step: residual grid + last-block solve
+        Timed t(ctx, 1);
+        hipLaunchKernelGGL(k_visual_step, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov,
+                           cfg->mp_proc_num);
+        t.done();
+        continue;
+      }
       {
         Timed t(ctx, 1);
         if (inverse) hipLaunchKernelGGL(k_visual_inverse_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0);

@@ -113,6 +113,15 @@ struct __attribute__((aligned(16))) VisWaveLds {
   float pe[VIS_PPW]; float nm[VIS_PPW];
 };
 
+// Stores / loads of data that another workgroup of the SAME launch consumes (k_visual_step): relaxed atomics at agent scope = write-through stores and
+// cache-bypassing loads (sc1), so the hand-off needs no L2 write-back / invalidate fence (HIP guide section 6, guideline 16, second recipe).
+template <bool XB, typename T> __device__ __forceinline__ void xb_store(T *p, T v) {
+  if (XB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool XB, typename T> __device__ __forceinline__ T xb_load(const T *p) {
+  return XB ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
 // value q of a patch's 37-vector from its moment sums S and its M:  q<28: upper-tri (r<=c) of the 7x7 ; 28..34: Htz ; 35: err ; 36: n_meas.
 // (r, c) of lane q are found once, before the first memory wait (vis_rc); the four M entries a lane needs are then four independent LDS reads per patch.
 struct VisRC { int r, c; };
@@ -144,7 +153,7 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
 
 // Four patches per wave (the body shared by the single-frame and the batched kernel).  patch0 = first patch of this wave.  Returns lane q's value q (q < 37) of the
 // SUM of the wave's patch vectors (slot order).
-template <bool DEBUG_ROWS>
+template <bool DEBUG_ROWS, bool XB = false>
 __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const DevCtl *__restrict__ ctl, VisWaveLds &L, int patch0, int lane) {
   const int slot = lane / VIS_LPP, j = lane % VIS_LPP;
   const VisRC rc = vis_rc(lane);
@@ -284,7 +293,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
 #endif
   if (!ok) pe = 0.0f;
   if (j == 0) {
-    if (valid) a.errors[patch] = pe;
+    if (valid) xb_store<XB>(&a.errors[patch], pe);
     L.pe[slot] = pe; L.nm[slot] = ok ? 64.0f : 0.0f;
   }
   wave_sync();
@@ -298,6 +307,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
 }
 
 // the block's 8 wave vectors -> one partial row (fixed order: deterministic)
+template <bool XB = false>
 __device__ __forceinline__ void vis_block_store(double (*red)[VIS_PSTRIDE], double out_val, double *__restrict__ partial_row) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (lane < VIS_PSTRIDE) red[wave][lane] = out_val;
@@ -306,7 +316,7 @@ __device__ __forceinline__ void vis_block_store(double (*red)[VIS_PSTRIDE], doub
     double v = red[0][tid];
 #pragma unroll
     for (int w = 1; w < VIS_WAVES; w++) v = v + red[w][tid];
-    partial_row[tid] = v;
+    xb_store<XB>(&partial_row[tid], v);
   }
 }
 
@@ -396,21 +406,31 @@ __device__ __forceinline__ float float_chain(const float *e, int lo, int hi, flo
   return acc;
 }
 
-__device__ __forceinline__ void visual_solve_body(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level, int iter,
-                                                  double img_point_cov, VisualSolveArgs va) {
-  __shared__ SolveLds s;
-  __shared__ double sums[64];
-  __shared__ double scratch[12 * 41];
-  __shared__ __attribute__((aligned(16))) float errs[VIS_ERR_STAGE];
-  __shared__ float err_chunk[LIVO2_WAVE];
-  __shared__ float err_total;
+struct __attribute__((aligned(16))) VisSolveLds {
+  float errs[VIS_ERR_STAGE];
+  SolveLds s;
+  double sums[64];
+  double scratch[12 * 41];
+  float err_chunk[LIVO2_WAVE];
+  float err_total;
+};
+template <bool XB = false>
+__device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level, int iter,
+                                                  double img_point_cov, VisualSolveArgs va, const double *craw_in = nullptr) {
+  SolveLds &s = SL.s;
+  double *sums = SL.sums, *scratch = SL.scratch;
+  float *errs = SL.errs, *err_chunk = SL.err_chunk;
+  float &err_total = SL.err_total;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   VSPHASE(0);
   // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
   const int hdr_stop = ctl->hdr.stop, hdr_steps = ctl->hdr.n_steps;
   const float hdr_last_error = ctl->hdr.last_error;
   double craw[6];
-  if (mode != 0 && wave == 0) esikf_prefetch_wave(ctl, s, img_point_cov, lane, craw);
+  if (craw_in) {                                             // k_visual_step: P / states were fetched before the ticket
+#pragma unroll
+    for (int qq = 0; qq < 6; qq++) craw[qq] = craw_in[qq];
+  } else if (mode != 0 && wave == 0) esikf_prefetch_wave(ctl, s, img_point_cov, lane, craw);
   if (mode != 0 && t == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
   {
     const int kidx = t % VIS_PSTRIDE, slice = t / VIS_PSTRIDE;     // 12 slices (threads >= 480 idle here)
@@ -419,7 +439,7 @@ __device__ __forceinline__ void visual_solve_body(DevCtl *__restrict__ ctl, cons
       for (int base = 0; base < nblocks; base += 12 * 48) {
         double v[48];
 #pragma unroll
-        for (int u = 0; u < 48; u++) { const int b = base + slice + 12 * u; v[u] = (b < nblocks) ? partials[(size_t)b * VIS_PSTRIDE + kidx] : 0.0; }
+        for (int u = 0; u < 48; u++) { const int b = base + slice + 12 * u; v[u] = (b < nblocks) ? xb_load<XB>(&partials[(size_t)b * VIS_PSTRIDE + kidx]) : 0.0; }
 #pragma unroll
         for (int u = 0; u < 48; u++) acc += v[u];
       }
@@ -431,7 +451,7 @@ __device__ __forceinline__ void visual_solve_body(DevCtl *__restrict__ ctl, cons
   {
     float ev[VIS_ERR_STAGE / 512];                           // all loads of a thread in flight at once (a load-store loop costs one HBM round trip per turn)
 #pragma unroll
-    for (int u = 0; u < VIS_ERR_STAGE / 512; u++) { const int i = t + 512 * u; ev[u] = (i < n_stage) ? va.errors[i] : 0.0f; }
+    for (int u = 0; u < VIS_ERR_STAGE / 512; u++) { const int i = t + 512 * u; ev[u] = (i < n_stage) ? xb_load<XB>(&va.errors[i]) : 0.0f; }
 #pragma unroll
     for (int u = 0; u < VIS_ERR_STAGE / 512; u++) { const int i = t + 512 * u; if (i < n_stage) errs[i] = ev[u]; }
   }
@@ -465,7 +485,7 @@ __device__ __forceinline__ void visual_solve_body(DevCtl *__restrict__ ctl, cons
     if (lane < T) {
       const int mid = min(my_end, n_stage);
       priv = float_chain(errs, my_begin, mid, priv);
-      for (int i = max(my_begin, n_stage); i < my_end; i++) priv += va.errors[i];
+      for (int i = max(my_begin, n_stage); i < my_end; i++) priv += xb_load<XB>(&va.errors[i]);
       err_chunk[lane] = priv;
     }
     wave_sync();
@@ -533,14 +553,51 @@ __device__ __forceinline__ void visual_solve_body(DevCtl *__restrict__ ctl, cons
 
 __global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level,
                                                              int iter, double img_point_cov, VisualSolveArgs va) {
-  visual_solve_body(ctl, partials, nblocks, mode, level, iter, img_point_cov, va);
+  __shared__ VisSolveLds SL;
+  visual_solve_body(SL, ctl, partials, nblocks, mode, level, iter, img_point_cov, va);
+}
+
+// One launch per (level, iteration): the residual grid, and the LAST block to finish runs the reduction + accept / revert + solve (the body of k_visual_solve)
+// — a dependent launch costs ~4 us on this stack before its first useful instruction, a frame's visual update issues 40 of them as two kernels per step.
+// Hand-off (HIP guide section 6, guideline 16: placement-independent): the partial row and the per-patch errors are written with agent-scope (write-through) stores, every wave drains them, block barrier,
+// ONE lane takes a ticket (hdr.reserved, zeroed with the header at every update and by the last block); the block that draws the last ticket reads the other
+// blocks' rows and errors with agent-scope (cache-bypassing) loads — no L2 write-back / invalidate fence (the fenced variant measured +5 us per step).  The LDS of the two phases is a union.
+union VisStepLds { struct { VisWaveLds lds[VIS_WAVES]; double red[VIS_WAVES][VIS_PSTRIDE]; } r; VisSolveLds s; };
+__global__ void __launch_bounds__(VIS_BLOCK) k_visual_step(VisualKernelArgs a, DevCtl *ctl, double *partials, int mode, int iter, double img_point_cov, int error_threads) {
+  VPHASE(0);
+  if (mode == 1 && iter > 0 && ctl->hdr.stop) return;        // the level has ended: nothing to evaluate, nothing to solve
+  __shared__ VisStepLds U;
+  __shared__ int last_block;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int patch0 = (blockIdx.x * VIS_WAVES + wave) * VIS_PPW;
+  double out_val = 0.0;
+  if (patch0 < a.M) out_val = visual_wave_body<false, true>(a, ctl, U.r.lds[wave], patch0, lane);
+  VPHASE(6);
+  vis_block_store<true>(U.r.red, out_val, partials + (size_t)blockIdx.x * VIS_PSTRIDE);
+  // every block fetches what the solve needs besides the rows (P, both states) while its stores drain: the block that turns out to be last starts the
+  // solve with them in LDS / registers (U.s.s does not overlap `red`, and the barrier inside vis_block_store ended all use of the wave tiles)
+  double craw[6] = {0, 0, 0, 0, 0, 0};
+  if (mode != 0 && wave == 0) esikf_prefetch_wave(ctl, U.s.s, img_point_cov, lane, craw);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores (errors, partial row) are acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    const int ticket = atomicAdd(&ctl->hdr.reserved, 1);
+    last_block = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+    if (last_block) ctl->hdr.reserved = 0;
+  }
+  __syncthreads();
+  VPHASE(7);
+  if (!last_block) return;
+  const VisualSolveArgs va = {a.errors, a.M, error_threads};
+  visual_solve_body<true>(U.s, ctl, partials, (int)gridDim.x, mode, a.level, iter, img_point_cov, va, mode != 0 ? craw : nullptr);
 }
 // one block per frame of a batch
 __global__ void __launch_bounds__(512) k_visual_solve_batch(const VisualBatchEntry *__restrict__ entries, int mode, int level, int iter, double img_point_cov, int error_threads) {
   const VisualBatchEntry &e = entries[blockIdx.x];
   if (e.a.M == 0) return;                                    // total_points == 0 (vio.cpp:786): no step is taken, no step is recorded
   VisualSolveArgs va = {e.a.errors, e.a.M, error_threads};
-  visual_solve_body(e.ctl, e.partials, e.nblocks, mode, level, iter, img_point_cov, va);
+  __shared__ VisSolveLds SL;
+  visual_solve_body(SL, e.ctl, e.partials, e.nblocks, mode, level, iter, img_point_cov, va);
 }
 
 // One wave.  Every global read (covariance, G, the 25 pose / bias scalars) is issued in one batch and everything is written from registers / LDS: the first

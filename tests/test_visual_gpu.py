@@ -132,3 +132,25 @@ def test_batched_frames_equal_single_updates(ctx, livo2, orc):
         ocur, oprop = H.states(frames[k], orc.StatePOD)
         ref = orc.visual_update(orc.visual_cfg(frames[k], num_threads=4), frames[k], ocur, oprop)
         assert [(res[k].steps[j].level, res[k].steps[j].accepted, res[k].steps[j].error) for j in range(res[k].n_steps)] == [(t.level, t.accepted, t.error) for t in ref["trace"]]
+
+
+def test_fused_step_kernel_gives_the_same_bits(livo2, ctx):
+    """LIVO2_VISUAL_FUSED=1: residual grid + last-block solve in ONE launch per (level, iteration) (k_visual_step: write-through stores, ticket, cache-bypassing
+    loads between workgroups of the same launch) — same bits as the two-launch form, repeatedly (a stale read across workgroups would show up as a flaky diff)."""
+    import os
+    vs = synth.visual_scenario(seed=77, n_patches=3000)
+    cfg = H.visual_cfg_product(vs, mp_proc_num=4)
+    cur, prop = H.states(vs, livo2.State)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    ref, ref_err = ctx.visual_update(cur, prop, cfg)
+    os.environ["LIVO2_VISUAL_FUSED"] = "1"
+    try:
+        c2 = livo2.Context(0)
+    finally:
+        del os.environ["LIVO2_VISUAL_FUSED"]
+    c2.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    for _ in range(20):
+        res, err = c2.visual_update(cur, prop, cfg)
+        assert res.n_steps == ref.n_steps and bytes(res.state) == bytes(ref.state) and np.array_equal(err, ref_err)
+        assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
+    c2.close()

@@ -35,7 +35,7 @@ for suffix in (sys.argv[1:] or [""]):
         ctx.visual_iterations_async(level, cur, prop, cfg, 200)
         ms_res, n_res = ctx.kernel_timing_read(1); ms_sol, n_sol = ctx.kernel_timing_read(3)
         ctx.kernel_timing(False)
-        row += [f"L{level}: step_us={best * 1e6:.2f} res_us={1e3 * ms_res / n_res:.2f} sol_us={1e3 * ms_sol / n_sol:.2f}"]
+        row += [f"L{level}: step_us={best * 1e6:.2f} res_us={1e3 * ms_res / n_res:.2f} sol_us={1e3 * ms_sol / max(n_sol, 1):.2f}"]
     tf = 1e9
     for _ in range(10):
         t0 = time.perf_counter(); res, _ = ctx.visual_update(cur, prop, cfg); tf = min(tf, time.perf_counter() - t0)
