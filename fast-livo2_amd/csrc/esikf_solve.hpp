@@ -26,6 +26,7 @@ struct SolveLds {
   double vec[DS + 1];
   double sol[DS + 1];
   double cur[25], prop[25];     // the 25 non-covariance scalars of state_ / state_propagat (rot 9, pos 3, inv_expo, vel, bg, ba, grav)
+  double newR[9];               // rot_end * Exp(solution[0:3]), prepared by esikf_solve_wave so that the commit only stores
 };
 
 // One Kalman update of ctl->cur given the reduced sums (s.hth: k x k row-major with stride k, s.htz).
@@ -131,6 +132,13 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
   }
   wave_sync();
+  if (lane == 0) {                                           // state.rot_end * Exp(delta theta)  (common_lib.h:184), ~1 us of sin / cos / sqrt on one lane
+    double E[9], Rn[9];
+    so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
+    mat3_mul(s.cur, E, Rn);
+    for (int i = 0; i < 9; i++) s.newR[i] = Rn[i];
+  }
+  wave_sync();
 }
 
 // Part 3: publish G (zero-padded 19x19 in ctl->G) and apply  state += solution  (common_lib.h:182-192) to ctl->cur, from the LDS copies.
@@ -139,11 +147,8 @@ __device__ inline void esikf_commit_wave(DevCtl *ctl, SolveLds &s, const int lan
 #pragma unroll
     for (int c = 0; c < KMAX; c++) ctl->G[lane * DS + c] = s.G[lane * KMAX + c];      // columns >= KMAX of ctl->G stay zero
   }
-  if (lane == 0) {
-    double E[9], Rn[9];
-    so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
-    mat3_mul(s.cur, E, Rn);
-    for (int i = 0; i < 9; i++) ctl->cur.rot[i] = Rn[i];
+  if (lane < 9) {
+    ctl->cur.rot[lane] = s.newR[lane];
   } else if (lane >= 9 && lane < 25) {
     reinterpret_cast<double *>(&ctl->cur)[lane] = s.cur[lane] + s.sol[lane - 6];
   }

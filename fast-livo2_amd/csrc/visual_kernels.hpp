@@ -110,7 +110,7 @@ struct __attribute__((aligned(16))) VisWaveLds {
   double Rr[VIS_PPW][64];      // res^2 per pixel, pixel order
   double S[VIS_PPW][9];        // the 9 moment sums of each patch
   double Mx[VIS_PPW][12];      // patch-constant 2x6 M
-  float pe[VIS_PPW]; float nm[VIS_PPW];
+  float nm[VIS_PPW];
 };
 
 // Stores / loads of data that another workgroup of the SAME launch consumes (k_visual_step): relaxed atomics at agent scope = write-through stores and
@@ -135,7 +135,7 @@ __device__ __forceinline__ VisRC vis_rc(int q) {
   } else if (q < 35) { o.r = q - 28; o.c = 7; }
   return o;
 }
-__device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, const double *Mx, float pe, float nm) {
+__device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, const double *Mx, float nm) {
   const int r = rc.r < 6 ? rc.r : 0, c = rc.c < 6 ? rc.c : 0;                 // clamped: the loads below are unconditional
   const double m0r = Mx[r], m1r = Mx[6 + r], m0c = Mx[c], m1c = Mx[6 + c];
   const double Sg00 = S[0], Sg01 = S[1], Sg11 = S[2], Sgc0 = S[3], Sgc1 = S[4], Scc = S[5], Sgr0 = S[6], Sgr1 = S[7], Scr = S[8];
@@ -145,8 +145,7 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
     else if (rc.r < 6) v = m0r * Sgc0 + m1r * Sgc1;
     else v = Scc;
   } else if (q < 35) v = (rc.r < 6) ? (m0r * Sgr0 + m1r * Sgr1) : Scr;
-  else if (q == 35) v = (double)pe;
-  else if (q == 36) v = (double)nm;
+  else if (q == 36) v = (double)nm;            // (q == 35, the error sum, is formed by the solve kernel from errors[]: 0 here)
   else v = 0.0;
   return v;
 }
@@ -265,10 +264,22 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
     acc[6] += g0 * res; acc[7] += g1 * res; acc[8] += cexp * res;
     L.Rr[slot][p] = res * res;
   }
-  wave_sync();                                              // the staging buffers alias the tile written next
+  wave_sync();                                              // the staging buffers alias the tile written next; Rr is complete
   VPHASE(4);
+  // patch error: the reference's accumulator is a FLOAT updated in pixel order, `patch_error += res * res` = float(double(patch_error) + res*res)
+  // (vio.cpp:1563,1624); the 16 lanes of a slot run that 64-step chain from broadcast LDS reads, so errors[] equals the CPU loop bit for bit.  The chain is
+  // 192 dependent operations (~1.2 us) that nothing else in the wave needs: it is cut into three pieces placed inside the three synchronisation regions
+  // below, so that the scheduler fills its stalls with the reduction's LDS traffic and the expansion's arithmetic.
+  float pe = 0.0f;
+  const double *rr = L.Rr[slot];
+#ifndef VIS_EXP_NOCHAIN
+#define VIS_CHAIN(lo, hi) _Pragma("unroll") for (int i = (lo); i < (hi); i++) pe = (float)((double)pe + rr[i]);
+#else
+#define VIS_CHAIN(lo, hi)
+#endif
 #pragma unroll
   for (int v = 0; v < 9; v++) L.T[v * VIS_TPITCH + lane] = ok ? acc[v] : 0.0;
+  VIS_CHAIN(0, 16)
   wave_sync();
   {
     // lane 4v+q adds columns [16q, 16q+16) of row v = the 16 lanes of patch slot q (16 independent LDS reads)
@@ -281,28 +292,19 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
       L.S[q][v] = (s0 + s1) + (s2 + s3);
     }
   }
-  // patch error: the reference's accumulator is a FLOAT updated in pixel order, `patch_error += res * res` = float(double(patch_error) + res*res)
-  // (vio.cpp:1563,1624); the 16 lanes of a slot run that 64-step chain from broadcast LDS reads, so errors[] equals the CPU loop bit for bit
-  float pe = 0.0f;
-#ifndef VIS_EXP_NOCHAIN
-  {
-    const double *rr = L.Rr[slot];
-#pragma unroll
-    for (int i = 0; i < 64; i++) pe = (float)((double)pe + rr[i]);
-  }
-#endif
-  if (!ok) pe = 0.0f;
-  if (j == 0) {
-    if (valid) xb_store<XB>(&a.errors[patch], pe);
-    L.pe[slot] = pe; L.nm[slot] = ok ? 64.0f : 0.0f;
-  }
+  VIS_CHAIN(16, 40)
+  if (j == 0) L.nm[slot] = ok ? 64.0f : 0.0f;
   wave_sync();
   VPHASE(5);
   double out_val = 0.0;
   if (lane < VIS_NSUM) {
 #pragma unroll
-    for (int sl = 0; sl < VIS_PPW; sl++) out_val += vis_expand(lane, rc, L.S[sl], L.Mx[sl], L.pe[sl], L.nm[sl]);
+    for (int sl = 0; sl < VIS_PPW; sl++) out_val += vis_expand(lane, rc, L.S[sl], L.Mx[sl], L.nm[sl]);
   }
+  VIS_CHAIN(40, 64)
+#undef VIS_CHAIN
+  if (!ok) pe = 0.0f;
+  if (j == 0 && valid) xb_store<XB>(&a.errors[patch], pe);
   return out_val;
 }
 
@@ -413,6 +415,7 @@ struct __attribute__((aligned(16))) VisSolveLds {
   double scratch[12 * 41];
   float err_chunk[LIVO2_WAVE];
   float err_total;
+  double err_sum_d;
 };
 template <bool XB = false>
 __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int level, int iter,
@@ -491,11 +494,18 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
     wave_sync();
     if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += err_chunk[c]; err_total = e; }
   }
+  else if (wave == 3) {                                      // diagnostic double-precision sum of the patch errors (livo2_visual_sums.err_sum): a tree, off the chain
+    double e = 0.0;
+    for (int i = lane; i < n_stage; i += LIVO2_WAVE) e += (double)errs[i];
+    for (int i = n_stage + lane; i < va.M; i += LIVO2_WAVE) e += (double)xb_load<XB>(&va.errors[i]);
+    e = wave_sum(e);
+    if (lane == 0) SL.err_sum_d = e;
+  }
   VSPHASE(4);
   __syncthreads();
   VSPHASE(5);
   if (wave != 0) return;                                     // the rest is one wave; only wave-local synchronisation below
-  const double err_sum = sums[35];
+  const double err_sum = SL.err_sum_d;                       // (the partial rows do not carry the error: both sums are formed from errors[])
   const int n_meas = (int)sums[36];
   float error = err_total;
   error = error / n_meas;                                   // float / int (vio.cpp:1636); NaN when n_meas == 0
