@@ -149,35 +149,27 @@ __global__ void __launch_bounds__(256) k_body_cov(const float *__restrict__ x, c
 
 // ---- plane record in registers ------------------------------------------------------------------------------------------
 struct PlaneRec {
-  double n[3], c[3], S[21];
+  double n[3], c[3], See[6], v[3], k;
   float d, radius;
 };
 
-__device__ __forceinline__ void load_plane(const double *__restrict__ planes, int32_t pidx, PlaneRec &r) {
-  const double2 *P2 = reinterpret_cast<const double2 *>(planes + (size_t)pidx * PLANE_REC_DOUBLES);
-  double2 v[14];
+__device__ __forceinline__ void load_plane(const DevMap &map, int32_t pidx, PlaneRec &r) {
+  const double2 *P2 = reinterpret_cast<const double2 *>(map.planes + (size_t)pidx * PLANE_HOT_DOUBLES);
+  double2 v[8];
 #pragma unroll
-  for (int q = 0; q < 14; q++) v[q] = P2[q];                    // one batch of 16-B loads: a single round trip
+  for (int q = 0; q < 8; q++) v[q] = P2[q];                     // one batch of 16-B loads (one 128-B line) + the side word: a single round trip
+  const float2 dr = *reinterpret_cast<const float2 *>(map.plane_aux + pidx);
   r.n[0] = v[0].x; r.n[1] = v[0].y; r.n[2] = v[1].x; r.c[0] = v[1].y; r.c[1] = v[2].x; r.c[2] = v[2].y;
 #pragma unroll
-  for (int q = 0; q < 10; q++) { r.S[2 * q] = v[3 + q].x; r.S[2 * q + 1] = v[3 + q].y; }
-  r.S[20] = v[13].x;
-  const float2 dr = __builtin_bit_cast(float2, v[13].y);
+  for (int q = 0; q < 3; q++) { r.See[2 * q] = v[3 + q].x; r.See[2 * q + 1] = v[3 + q].y; }
+  r.v[0] = v[6].x; r.v[1] = v[6].y; r.v[2] = v[7].x; r.k = v[7].y;
   r.d = dr.x; r.radius = dr.y;
 }
 
-// J S J^T for the symmetric 6x6 S (upper triangle, row-major) and J = [a, -n]
-__device__ __forceinline__ double quad6_sym(const double *S, const double *J) {
-  double acc = 0.0;
-  int q = 0;
-#pragma unroll
-  for (int a = 0; a < 6; a++) {
-    double rowacc = S[q] * J[a]; q++;                           // diagonal term once
-#pragma unroll
-    for (int b = a + 1; b < 6; b++) { rowacc = fma(2.0 * S[q], J[b], rowacc); q++; }
-    acc = fma(J[a], rowacc, acc);
-  }
-  return acc;
+// J plane_var_ J^T for J = [a, -n]: a^T See a - 2 a^T v + k (livo2_device.hpp, PLANE_HOT_DOUBLES)
+__device__ __forceinline__ double quad_plane(const double *See, const double *v, double k, const double *a) {
+  const double av = fma(a[2], v[2], fma(a[1], v[1], a[0] * v[0]));
+  return fma(-2.0, av, quad3_sym(See, a)) + k;
 }
 
 // Per-point invariants of the candidate search and of the Jacobian row — kept small on purpose: the kernel's occupancy is set by its VGPR count, so whatever can be
@@ -231,11 +223,11 @@ __device__ __forceinline__ bool radius_gate(const double *n, const double *c, fl
 // StateRefs: the wave-uniform operands of a plane evaluation.  R / RE / Rp / tp point into the control block (scalar loads), sP at the block's LDS copy of
 // sym(P[0:3,0:3]) (6) and sym(P[3:6,3:6]) (6) — twelve broadcast LDS reads per evaluation instead of 24 VGPRs held for the whole kernel.
 struct StateRefs { const double *R, *RE, *Rp, *tp, *sP; };
-__device__ __forceinline__ void sigma_gate_and_row(const double *n, const double *c, const double *S, const GateOut &g, int32_t pidx, double sigma_num,
-                                                   const double *pc, const double *pi, const double *Cb, const StateRefs &st, Best &best) {
+__device__ __forceinline__ void sigma_gate_and_row(const double *n, const double *c, const double *See, const double *pv, double pk, const GateOut &g, int32_t pidx,
+                                                   double sigma_num, const double *pc, const double *pi, const double *Cb, const StateRefs &st, Best &best) {
   // sigma_l = J_nq plane_var J_nq^T + n^T Sigma_w n ,  J_nq = [p_w - c, -n]
-  const double J[6] = {-g.e[0], -g.e[1], -g.e[2], -n[0], -n[1], -n[2]};
-  double sigma_l = quad6_sym(S, J);
+  const double aw[3] = {-g.e[0], -g.e[1], -g.e[2]};
+  double sigma_l = quad_plane(See, pv, pk, aw);
   // n^T Sigma_w n = m^T Cb m + q^T Prr q + n^T Ptt n  with m = R^T n, q = n x p_i  (Sigma_w = R Cb R^T + X Prr X^T + Ptt, X = [p_i]x)
   double m[3]; mat3t_vec_fma(st.R, n, m);
   const double qx[3] = {n[1] * pc[2] - n[2] * pc[1], n[2] * pc[0] - n[0] * pc[2], n[0] * pc[1] - n[1] * pc[0]};
@@ -262,8 +254,8 @@ __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double
       double q[3];                                          // PRIOR-pose world point R^ p_i + t^, un-rounded (voxel_map.cpp:425)
 #pragma unroll
       for (int j = 0; j < 3; j++) q[j] = ((st.Rp[j * 3] * pi[0] + st.Rp[j * 3 + 1] * pi[1]) + st.Rp[j * 3 + 2] * pi[2]) + st.tp[j];
-      const double Jq[6] = {q[0] - c[0], q[1] - c[1], q[2] - c[2], -n[0], -n[1], -n[2]};
-      const double sig_q = quad6_sym(S, Jq);
+      const double aq[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+      const double sig_q = quad_plane(See, pv, pk, aq);
       double mp[3]; mat3t_vec_fma(st.RE, n, mp);            // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
       best.w = 1.0 / (0.001 + sig_q + quad3_sym(Cb, mp));
       best.h[0] = pi[1] * m[2] - pi[2] * m[1];             // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
@@ -310,7 +302,7 @@ __device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx
   const double pw[3] = {(double)pt.pwf[0], (double)pt.pwf[1], (double)pt.pwf[2]};
   if (radius_gate(p.n, p.c, p.d, p.radius, pw, g)) {
     double pc[3]; point_pc(pt, ER, Et, pc);
-    sigma_gate_and_row(p.n, p.c, p.S, g, pidx, sigma_num, pc, pt.pi, pt.Cb, st, best);
+    sigma_gate_and_row(p.n, p.c, p.See, p.v, p.k, g, pidx, sigma_num, pc, pt.pi, pt.Cb, st, best);
   }
 }
 
@@ -407,30 +399,34 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
   bool act[PAIRS], acc[PAIRS];
   int owner[PAIRS];
   unsigned long long pbits[PAIRS];
-  double n[PAIRS][3], c[PAIRS][3], S20[PAIRS];
+  double n[PAIRS][3], c[PAIRS][3];
   float d[PAIRS], radius[PAIRS];
-  int2 meta[PAIRS];
+  int meta[PAIRS];
   const double2 *P2[PAIRS];
+  const PlaneAux *PA[PAIRS];
 #pragma unroll
   for (int q = 0; q < PAIRS; q++) {
     const int s = tid + q * BLOCK;
     act[q] = base + s < W; acc[q] = false; owner[q] = 0; pbits[q] = 0ull;
-    P2[q] = reinterpret_cast<const double2 *>(map.cand_rec + (size_t)(act[q] ? L.pair_cand[s] : 0) * PLANE_REC_DOUBLES);
+    const size_t ci = (size_t)(act[q] ? L.pair_cand[s] : 0);
+    P2[q] = reinterpret_cast<const double2 *>(map.cand_rec + ci * PLANE_HOT_DOUBLES);
+    PA[q] = map.cand_aux + ci;
     if (act[q]) owner[q] = L.pair_owner[s];
   }
-  double2 g0[PAIRS], g1[PAIRS], g2[PAIRS], g13[PAIRS], g14[PAIRS];
-  double2 sv[10];                                                   // covariance words 3..12 of ONE record at a time
+  double2 g0[PAIRS], g1[PAIRS], g2[PAIRS];
+  int4 ga[PAIRS];
+  double2 sv[5];                                                    // covariance words 6..15 of ONE record at a time
   if (PAIRS == 1) {
     if (act[0]) {
       g0[0] = P2[0][0]; g1[0] = P2[0][1]; g2[0] = P2[0][2];
 #pragma unroll
-      for (int w = 0; w < 10; w++) sv[w] = P2[0][3 + w];
-      g13[0] = P2[0][13]; g14[0] = P2[0][14];
+      for (int w = 0; w < 5; w++) sv[w] = P2[0][3 + w];
+      ga[0] = *reinterpret_cast<const int4 *>(PA[0]);
     }
   } else {
 #pragma unroll
     for (int q = 0; q < PAIRS; q++)
-      if (act[q]) { g0[q] = P2[q][0]; g1[q] = P2[q][1]; g2[q] = P2[q][2]; g13[q] = P2[q][13]; g14[q] = P2[q][14]; }
+      if (act[q]) { g0[q] = P2[q][0]; g1[q] = P2[q][1]; g2[q] = P2[q][2]; ga[q] = *reinterpret_cast<const int4 *>(PA[q]); }
   }
   CSTAMP(2);
   GateOut g[PAIRS];
@@ -440,11 +436,9 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
     pass[q] = false;
     if (act[q]) {
       n[q][0] = g0[q].x; n[q][1] = g0[q].y; n[q][2] = g1[q].x; c[q][0] = g1[q].y; c[q][1] = g2[q].x; c[q][2] = g2[q].y;
-      S20[q] = g13[q].x;
-      const float2 dr = __builtin_bit_cast(float2, g13[q].y);
-      d[q] = dr.x; radius[q] = dr.y;
-      meta[q] = __builtin_bit_cast(int2, g14[q].x);
-      if ((meta[q].x >> CAND_LAYER_SHIFT) <= max_layer) {
+      d[q] = __builtin_bit_cast(float, ga[q].x); radius[q] = __builtin_bit_cast(float, ga[q].y);
+      meta[q] = ga[q].z;
+      if ((meta[q] >> CAND_LAYER_SHIFT) <= max_layer) {
         const double *oc = L.ctx[owner[q]];
         const double pw[3] = {oc[0], oc[1], oc[2]};
         pass[q] = radius_gate(n[q], c[q], d[q], radius[q], pw, g[q]);
@@ -456,12 +450,11 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
     if (!pass[q]) continue;
     if (PAIRS > 1) {
 #pragma unroll
-      for (int w = 0; w < 10; w++) sv[w] = P2[q][3 + w];
+      for (int w = 0; w < 5; w++) sv[w] = P2[q][3 + w];
     }
-    double S[21];
-#pragma unroll
-    for (int w = 0; w < 10; w++) { S[2 * w] = sv[w].x; S[2 * w + 1] = sv[w].y; }
-    S[20] = S20[q];
+    const double See[6] = {sv[0].x, sv[0].y, sv[1].x, sv[1].y, sv[2].x, sv[2].y};
+    const double pv[3] = {sv[3].x, sv[3].y, sv[4].x};
+    const double pk = sv[4].y;
     const double *oc = L.ctx[owner[q]];
     double ppc[3], ppi[3], pCb[6];
 #pragma unroll
@@ -471,7 +464,7 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
     Best tb; tb.success = false; tb.prob_valid = false; tb.prob = 0.0; tb.dis2 = 0.0; tb.sigma = 1.0; tb.w = 0.0; tb.plane = -1; tb.r = 0.f;
 #pragma unroll
     for (int u = 0; u < 6; u++) tb.h[u] = 0.0;
-    sigma_gate_and_row(n[q], c[q], S, g[q], meta[q].x & CAND_PLANE_MASK, sigma_num, ppc, ppi, pCb, st, tb);
+    sigma_gate_and_row(n[q], c[q], See, pv, pk, g[q], meta[q] & CAND_PLANE_MASK, sigma_num, ppc, ppi, pCb, st, tb);
     if (tb.success) {
       const double prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
       int row = tid;
@@ -636,7 +629,7 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
       const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
       n1 = load_slot_head(a.map.slots, g1); n2 = load_slot_head(a.map.slots, g2);
     }
-    if (s.val >= 0) load_plane(a.map.planes, s.val, p0);         // issued right behind the neighbour slots: same round trip
+    if (s.val >= 0) load_plane(a.map, s.val, p0);         // issued right behind the neighbour slots: same round trip
     // while that trip is in flight: plan the cooperative visit of the block's non-plane roots (LDS + one barrier only)
     const CoopPlan plan1 = coop_plan(coop, 0, (s.val == -2) ? s.cand_count : 0, s.cand_begin);
     // the neighbour slots return first (in order); keep only the three words a later visit needs
@@ -646,7 +639,7 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     }
     // A plane-root neighbour is visited only if the first visit fails, one dependent trip later: start pulling its two cache
     // lines towards this CU now (a discarded dword per line), so that trip is an L2 hit instead of an HBM miss.
-    if (nb.val >= 0) { const double *q = a.map.planes + (size_t)nb.val * PLANE_REC_DOUBLES; touch_line<BLOCK>(q); touch_line<BLOCK>(q + 16); }
+    if (nb.val >= 0) { touch_line<BLOCK>(a.map.planes + (size_t)nb.val * PLANE_HOT_DOUBLES); touch_line<BLOCK>(a.map.plane_aux + nb.val); }
     if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, a.ER, a.Et, st, best);
     plan1W = plan1.W;
     if (plan1.W > 0) {              // block-uniform
@@ -663,7 +656,7 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     const bool retry = found && !best.success && nb.val != -1;
     const CoopPlan plan2 = coop_plan(coop, 1, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin);
     if (retry && nb.val >= 0) {
-      PlaneRec p1; load_plane(a.map.planes, nb.val, p1);
+      PlaneRec p1; load_plane(a.map, nb.val, p1);
       visit_plane_root(p1, nb.val, a.sigma_num, pt, a.ER, a.Et, st, best);
     }
     if (plan2.W > 0) {

@@ -50,7 +50,8 @@ struct livo2_ctx {
   // map
   bool has_map = false;
   DevMap map{};
-  RootSlot *d_slots = nullptr; double *d_cand = nullptr; double *d_planes = nullptr;
+  RootSlot *d_slots = nullptr; double *d_cand = nullptr; double *d_planes = nullptr;      // slots; candidate hot words [.][16]; master plane records [.][32]
+  double *d_planes_hot = nullptr; PlaneAux *d_plane_aux = nullptr, *d_cand_aux = nullptr;  // the residual kernel's view of the plane table (livo2_device.hpp)
   std::vector<int32_t> plane_cand_pos;      // host: position of each (caller-indexed) plane in the candidate array, or -1
   std::vector<int32_t> plane_internal, plane_orig;   // caller plane index <-> device (Morton-ordered) plane index
   int32_t *d_plane_internal = nullptr, *d_plane_cand_pos = nullptr; size_t plane_tab_cap = 0, plane_tab_cap2 = 0;   // device copies for k_plane_fit
@@ -183,6 +184,16 @@ struct Timed {                 // RAII-free helper: brackets one launch with an 
   void done() { if (!on) return; hipError_t e = hipEventRecord(ev.b, ctx->stream); (void)e; ctx->bins[bin].used.push_back(ev); }
 };
 
+// (re)point the residual kernel's map view at the ctx's arrays
+void set_map_view(livo2_ctx *ctx) {
+  ctx->map.slots = ctx->d_slots; ctx->map.cand_rec = ctx->d_cand; ctx->map.cand_aux = ctx->d_cand_aux; ctx->map.planes = ctx->d_planes_hot; ctx->map.plane_aux = ctx->d_plane_aux;
+}
+void free_map_arrays(livo2_ctx *ctx) {
+  void *p[] = {ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand_aux};
+  for (void *q : p) if (q) { hipError_t e = hipFree(q); (void)e; }
+  ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; ctx->d_planes_hot = nullptr; ctx->d_plane_aux = nullptr; ctx->d_cand_aux = nullptr;
+}
+
 void pack_plane(double *rec, const double *normal, const double *center, const double *pv36, float d, float radius) {
   for (int k = 0; k < 3; k++) { rec[k] = normal[k]; rec[3 + k] = center[k]; }
   int q = 6;
@@ -192,15 +203,46 @@ void pack_plane(double *rec, const double *normal, const double *center, const d
   for (int k = 28; k < 32; k++) rec[k] = 0.0;
 }
 
-__global__ void k_scatter_planes(const double *__restrict__ recs, const int32_t *__restrict__ idx, const int32_t *__restrict__ gate_pos, int n,
-                                 double *__restrict__ planes, double *__restrict__ gates) {
+__global__ void k_scatter_planes(const double *__restrict__ recs, const int32_t *__restrict__ idx, int n, double *__restrict__ planes) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int p = t >> 5, k = t & 31;
   if (p >= n) return;
-  const double v = recs[(size_t)p * PLANE_REC_DOUBLES + k];
-  planes[(size_t)idx[p] * PLANE_REC_DOUBLES + k] = v;
-  const int gp = gate_pos[p];                      // the plane's copy inside a candidate list (meta word [7] is left untouched)
-  if (gp >= 0 && k < 28) gates[(size_t)gp * PLANE_REC_DOUBLES + k] = v;
+  planes[(size_t)idx[p] * PLANE_REC_DOUBLES + k] = recs[(size_t)p * PLANE_REC_DOUBLES + k];
+}
+// master records -> the residual kernel's view (hot words + side word), for the rows listed (rows == null: rows 0..n-1); gate_pos (optional): the
+// plane's copy inside a candidate list is refreshed as well (its meta stays)
+__global__ void k_planes_hot(const double *__restrict__ planes, const int32_t *__restrict__ rows, const int32_t *__restrict__ gate_pos, int n, double *__restrict__ hot_out,
+                             PlaneAux *__restrict__ aux, double *__restrict__ cand, PlaneAux *__restrict__ cand_aux) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int row = rows ? rows[p] : p;
+  const double *rec = planes + (size_t)row * PLANE_REC_DOUBLES;
+  double f[28];
+#pragma unroll
+  for (int k = 0; k < 28; k++) f[k] = rec[k];
+  double hot[PLANE_HOT_DOUBLES];
+  plane_hot_words(f, f + 3, f + 6, hot);
+  const float2 dr = __builtin_bit_cast(float2, f[27]);
+  double2 *dst = reinterpret_cast<double2 *>(hot_out + (size_t)row * PLANE_HOT_DOUBLES);
+#pragma unroll
+  for (int k = 0; k < PLANE_HOT_DOUBLES / 2; k++) dst[k] = make_double2(hot[2 * k], hot[2 * k + 1]);
+  PlaneAux x; x.d = dr.x; x.radius = dr.y; x.meta = row; x.pad = 0;
+  aux[row] = x;
+  const int gp = gate_pos ? gate_pos[p] : -1;
+  if (gp >= 0) {
+    double2 *cd = reinterpret_cast<double2 *>(cand + (size_t)gp * PLANE_HOT_DOUBLES);
+#pragma unroll
+    for (int k = 0; k < PLANE_HOT_DOUBLES / 2; k++) cd[k] = make_double2(hot[2 * k], hot[2 * k + 1]);
+    cand_aux[gp].d = dr.x; cand_aux[gp].radius = dr.y;
+  }
+}
+// candidate lists: hot words of plane (meta & mask), side word with the list's meta (plane | layer << 28)
+__global__ void k_cand_fill(const double *__restrict__ hot, const PlaneAux *__restrict__ aux, const int32_t *__restrict__ meta, int n, double *__restrict__ cand, PlaneAux *__restrict__ cand_aux) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = t >> 3, k = t & 7;
+  if (c >= n) return;
+  const int pl = meta[c] & CAND_PLANE_MASK;
+  reinterpret_cast<double2 *>(cand + (size_t)c * PLANE_HOT_DOUBLES)[k] = reinterpret_cast<const double2 *>(hot + (size_t)pl * PLANE_HOT_DOUBLES)[k];
+  if (k == 0) { PlaneAux x = aux[pl]; x.meta = meta[c]; cand_aux[c] = x; }
 }
 
 // head of DevCtl from a state that is already on the device (livo2_lio_frame: state_ = state_propagat = the IMU propagation's result): what
@@ -472,7 +514,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (!ctx) return;
   hipError_t e = hipSetDevice(ctx->device);
   if (ctx->stream) e = hipStreamSynchronize(ctx->stream);
-  void *dev[] = {ctx->d_ctl, ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
+  void *dev[] = {ctx->d_ctl, ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand_aux, ctx->d_xyz_aos, ctx->d_x, ctx->d_y, ctx->d_z,
                  ctx->d_cb, ctx->d_keys, ctx->d_keys2, ctx->d_idx, ctx->d_perm, ctx->d_sort_tmp, ctx->d_partials, ctx->d_match, ctx->d_normal_plane, ctx->d_dis, ctx->d_pw, ctx->d_var, ctx->d_rinv, ctx->d_hrow, ctx->d_img,
                  ctx->d_pos, ctx->d_invexpo, ctx->d_warp, ctx->d_search, ctx->d_errors, ctx->d_zdbg, ctx->d_Hdbg, ctx->d_ref_imgs, ctx->d_ref_idx, ctx->d_ref_px, ctx->d_ref_f, ctx->d_ref_R, ctx->d_ref_pos,
                  ctx->d_gref, ctx->d_mref, ctx->bd_xyz_aos, ctx->bd_x, ctx->bd_y, ctx->bd_z, ctx->bd_cb, ctx->bd_keys, ctx->bd_keys2, ctx->bd_idx, ctx->bd_perm, ctx->bd_partials,
@@ -631,27 +673,38 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   // candidate lists hold whole record copies (one round trip per evaluated pair); remember where each plane sits for
   // livo2_map_update_planes
   ctx->plane_cand_pos.assign((size_t)std::max(1, m->n_planes), -1);
-  std::vector<double> gates((size_t)std::max<size_t>(1, cand.size()) * PLANE_REC_DOUBLES, 0.0);
-  for (size_t k = 0; k < cand.size(); k++) {
-    const int pl = cand[k] & CAND_PLANE_MASK;
-    double *g = &gates[k * PLANE_REC_DOUBLES];
-    std::memcpy(g, &recs[(size_t)pl * PLANE_REC_DOUBLES], 28 * sizeof(double));
-    int32_t meta[2] = {cand[k], 0};
-    std::memcpy(&g[28], meta, 8);
-    ctx->plane_cand_pos[ctx->plane_orig[pl]] = (int32_t)k;
-  }
+  for (size_t k = 0; k < cand.size(); k++) ctx->plane_cand_pos[ctx->plane_orig[cand[k] & CAND_PLANE_MASK]] = (int32_t)k;
 
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hipError_t e;
-  if (ctx->d_slots) { e = hipFree(ctx->d_slots); e = hipFree(ctx->d_cand); e = hipFree(ctx->d_planes); (void)e; ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; }
+  free_map_arrays(ctx);
   ctx->has_map = false;
+  const size_t n_rows = (size_t)std::max(1, m->n_planes), n_cand = std::max<size_t>(1, cand.size());
   HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand, gates.size() * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand, n_cand * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand_aux, n_cand * sizeof(PlaneAux)));
   HIPCHK(hipMalloc((void **)&ctx->d_planes, recs.size() * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_planes_hot, n_rows * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_plane_aux, n_rows * sizeof(PlaneAux)));
   HIPCHK(hipMemcpy(ctx->d_slots, slots.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->d_cand, gates.data(), gates.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_planes, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
-  ctx->map.slots = ctx->d_slots; ctx->map.cand_rec = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = cap - 1;
+  HIPCHK(hipMemsetAsync(ctx->d_cand, 0, n_cand * PLANE_HOT_DOUBLES * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_cand_aux, 0, n_cand * sizeof(PlaneAux), ctx->stream));
+  // the residual kernel's view of the table is derived on the device from the master records
+  hipLaunchKernelGGL(k_planes_hot, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_planes, (const int32_t *)nullptr, (const int32_t *)nullptr, (int)n_rows,
+                     ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand, ctx->d_cand_aux);
+  if (!cand.empty()) {
+    int32_t *d_meta = nullptr;
+    HIPCHK(hipMalloc((void **)&d_meta, cand.size() * 4));
+    HIPCHK(hipMemcpyAsync(d_meta, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_cand_fill, dim3((unsigned)((cand.size() * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_planes_hot, ctx->d_plane_aux, d_meta, (int)cand.size(), ctx->d_cand, ctx->d_cand_aux);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_meta));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  set_map_view(ctx);
+  ctx->map.mask = cap - 1;
   ctx->map.seed1 = seed1; ctx->map.seed2 = seed2; ctx->map.n_planes = m->n_planes;
   ctx->has_map = true;
   ctx->plane_tabs_fresh = false;
@@ -681,7 +734,8 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_idx, didx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, d_gpos, n, ctx->d_planes, ctx->d_cand);
+  hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, n, ctx->d_planes);
+  hipLaunchKernelGGL(k_planes_hot, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_planes, d_idx, d_gpos, n, ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand, ctx->d_cand_aux);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_gpos));
@@ -771,7 +825,7 @@ int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *v
   PlaneFitArgs a{};
   a.pw = ctx->d_fit_pw; a.var = ctx->d_fit_var; a.offsets = ctx->d_fit_off; a.planer_threshold = planer_threshold; a.out = ctx->d_fit_out;
   a.plane_idx = plane_idx ? ctx->d_fit_idx : nullptr; a.plane_internal = ctx->d_plane_internal; a.plane_cand_pos = ctx->d_plane_cand_pos;
-  a.planes = ctx->d_planes; a.cand = ctx->d_cand;
+  a.planes = ctx->d_planes; a.planes_hot = ctx->d_planes_hot; a.cand = ctx->d_cand; a.plane_aux = ctx->d_plane_aux; a.cand_aux = ctx->d_cand_aux;
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   const int tpb = FIT_WAVES * LIVO2_WAVE;
   if (n_small) { a.list = ctx->d_fit_list; a.n_list = n_small; hipLaunchKernelGGL(k_plane_fit<8>, dim3((n_small * 8 + tpb - 1) / tpb), dim3(tpb), 0, ctx->stream, a); }
@@ -848,7 +902,8 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hipError_t e;
-  if (ctx->d_slots) { e = hipFree(ctx->d_slots); e = hipFree(ctx->d_cand); e = hipFree(ctx->d_planes); ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; }
+  e = hipSuccess;
+  free_map_arrays(ctx);
   if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); }
   (void)e;
   ctx->has_map = false; ctx->tree_mode = false; ctx->mt = MapTreeArgs{};
@@ -863,7 +918,10 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   while ((long long)cap < 8 * R) cap <<= 1;
   HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
   HIPCHK(hipMalloc((void **)&ctx->d_planes, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand, (size_t)m.cap_cand * PLANE_REC_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand, (size_t)m.cap_cand * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_cand_aux, (size_t)m.cap_cand * sizeof(PlaneAux)));
+  HIPCHK(hipMalloc((void **)&ctx->d_planes_hot, (size_t)m.cap_planes * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(hipMalloc((void **)&ctx->d_plane_aux, (size_t)m.cap_planes * sizeof(PlaneAux)));
   HIPCHK(hipMalloc((void **)&m.nodes, (size_t)m.cap_nodes * sizeof(DevNode)));
   HIPCHK(hipMalloc((void **)&m.pool_pw, (size_t)m.cap_points * 24));
   HIPCHK(hipMalloc((void **)&m.pool_var, (size_t)m.cap_points * 72));
@@ -877,13 +935,17 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   }
   HIPCHK(hipMemset(m.counters, 0, MTC_COUNT * 4));
   HIPCHK(hipMemset(ctx->d_planes, 0, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
-  HIPCHK(hipMemset(ctx->d_cand, 0, (size_t)m.cap_cand * PLANE_REC_DOUBLES * 8));
-  m.planes = ctx->d_planes; m.cand = ctx->d_cand; m.slots = ctx->d_slots;
+  HIPCHK(hipMemset(ctx->d_cand, 0, (size_t)m.cap_cand * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(hipMemset(ctx->d_cand_aux, 0, (size_t)m.cap_cand * sizeof(PlaneAux)));
+  HIPCHK(hipMemset(ctx->d_planes_hot, 0, (size_t)m.cap_planes * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(hipMemset(ctx->d_plane_aux, 0, (size_t)m.cap_planes * sizeof(PlaneAux)));
+  m.planes = ctx->d_planes; m.planes_hot = ctx->d_planes_hot; m.cand = ctx->d_cand; m.plane_aux = ctx->d_plane_aux; m.cand_aux = ctx->d_cand_aux; m.slots = ctx->d_slots;
   m.mask = cap - 1; m.seed1 = 0x243f6a88u; m.seed2 = 0x85a308d3u;
   m.voxel_size_d = cfg->voxel_size; m.voxel_size_f = (float)cfg->voxel_size; m.planer_threshold = (float)cfg->planer_threshold;
   m.max_layer = cfg->max_layer; m.max_points_num = cfg->max_points_num; m.update_size_threshold = 5;      // VoxelOctoTree ctor (voxel_map.h:159)
   for (int k = 0; k <= LIVO2_MAX_LAYER; k++) m.layer_init_num[k] = cfg->layer_init_num[k < 5 ? k : 4];
-  ctx->map.slots = ctx->d_slots; ctx->map.cand_rec = ctx->d_cand; ctx->map.planes = ctx->d_planes; ctx->map.mask = m.mask; ctx->map.seed1 = m.seed1; ctx->map.seed2 = m.seed2;
+  set_map_view(ctx);
+  ctx->map.mask = m.mask; ctx->map.seed1 = m.seed1; ctx->map.seed2 = m.seed2;
   ctx->map.n_planes = m.cap_planes;
   ctx->mt_cfg = *cfg;
   ctx->plane_internal.clear(); ctx->plane_orig.clear(); ctx->plane_cand_pos.clear();

@@ -36,15 +36,35 @@ struct __attribute__((aligned(64))) RootSlot {
 #define CAND_LAYER_SHIFT 28
 #define CAND_PLANE_MASK 0x0fffffff
 
-// Plane record: 256 B, 256-B aligned => exactly two 128-B L2 lines, fetched by a lane as 16-B vector loads in ONE batch.
+// Plane table, master copy: 256 B per plane — what the map kernels (fit, octree maintenance, export) write and read.
 //   [0..2] normal_  [3..5] center_  [6..26] sym(plane_var_) upper triangle row-major (21)  [27] {float d_, float radius_}
-//   [28..31] pad
+//   [28] {int32 layer, 0} (device-built trees)  [29..31] pad
 #define PLANE_REC_DOUBLES 32
+// What the residual kernel reads per (point, plane) pair: ONE 128-B line + one 16-B word of a side array.
+//   With J = [a, -n] (a = p - center_, voxel_map.cpp:733-735 / 437-440) the quadratic form J plane_var_ J^T is
+//       a^T See a - 2 a^T v + k,   See = plane_var_[0:3,0:3] (sym),  v = plane_var_[0:3,3:6] n,  k = n^T plane_var_[3:6,3:6] n
+//   — v and k depend on the plane only, so they are formed once when the plane is (re)fitted instead of once per pair: 10 doubles instead of 21 travel
+//   and stay in registers, and the form costs 15 operations instead of 48.
+//   hot[0..2] normal_  [3..5] center_  [6..11] See (00 01 02 11 12 22)  [12..14] v  [15] k ;  aux = {d_, radius_, plane | layer << 28 (candidate copies), 0}
+#define PLANE_HOT_DOUBLES 16
+struct __attribute__((aligned(16))) PlaneAux { float d, radius; int32_t meta, pad; };
+// S = the 21-entry upper triangle at words [6..26] of the master record (row r starts at {0, 6, 11, 15, 18, 20})
+__host__ __device__ inline void plane_hot_words(const double *n, const double *c, const double *S, double *hot) {
+  hot[0] = n[0]; hot[1] = n[1]; hot[2] = n[2]; hot[3] = c[0]; hot[4] = c[1]; hot[5] = c[2];
+  hot[6] = S[0]; hot[7] = S[1]; hot[8] = S[2]; hot[9] = S[6]; hot[10] = S[7]; hot[11] = S[11];
+  hot[12] = (S[3] * n[0] + S[4] * n[1]) + S[5] * n[2];
+  hot[13] = (S[8] * n[0] + S[9] * n[1]) + S[10] * n[2];
+  hot[14] = (S[12] * n[0] + S[13] * n[1]) + S[14] * n[2];
+  hot[15] = (n[0] * ((S[15] * n[0] + S[16] * n[1]) + S[17] * n[2]) + n[1] * ((S[16] * n[0] + S[18] * n[1]) + S[19] * n[2])) +
+            n[2] * ((S[17] * n[0] + S[19] * n[1]) + S[20] * n[2]);
+}
 
 struct DevMap {
   const RootSlot *slots;
-  const double *cand_rec;      // [n_cand][32]: COPY of the plane record in candidate (depth-first) order, [28] = {int32 plane|layer<<28, 0}
-  const double *planes;        // [n_planes][32]
+  const double *cand_rec;      // [n_cand][16]: hot words of the candidate's plane, in candidate (depth-first) order
+  const PlaneAux *cand_aux;    // [n_cand]: d_, radius_, plane | layer << 28
+  const double *planes;        // [n_planes][16]: hot words
+  const PlaneAux *plane_aux;   // [n_planes]
   uint32_t mask;               // capacity - 1 (power of two)
   uint32_t seed1, seed2;
   int32_t n_planes;

@@ -28,7 +28,9 @@ struct PlaneFitArgs {
   const int32_t *plane_idx;       // [n_groups] caller's plane index, -1 = do not write ; or null
   const int32_t *plane_internal;  // caller plane index -> row of the device plane table
   const int32_t *plane_cand_pos;  // caller plane index -> position of its copy in the candidate records, or -1
-  double *planes, *cand;
+  double *planes;                 // master records [.][32]
+  double *planes_hot, *cand;      // what the residual kernel reads: [.][16] by plane row / by candidate position
+  PlaneAux *plane_aux, *cand_aux;
 };
 
 // symmetric 3x3 eigen-decomposition, cyclic Jacobi; columns of V are unit eigenvectors
@@ -198,20 +200,31 @@ template <int LPG> __global__ void __launch_bounds__(FIT_WAVES *LIVO2_WAVE) __at
   if (a.plane_idx && is_plane) {
     const int32_t pi = a.plane_idx[g];
     if (pi >= 0) {
-      double *rec = a.planes + (size_t)a.plane_internal[pi] * PLANE_REC_DOUBLES;
-      const int32_t gp = a.plane_cand_pos[pi];
-      double *cpy = gp >= 0 ? a.cand + (size_t)gp * PLANE_REC_DOUBLES : nullptr;      // copy inside a candidate list (its meta word [28] stays)
-      auto put = [&](int k, double v) { if (lane == k % LPG) { rec[k] = v; if (cpy && k < 28) cpy[k] = v; } };
+      const int32_t row = a.plane_internal[pi];
+      double *rec = a.planes + (size_t)row * PLANE_REC_DOUBLES;
+      auto put = [&](int k, double v) { if (lane == k % LPG) rec[k] = v; };
 #pragma unroll
       for (int k = 0; k < 3; k++) { put(k, nrm[k]); put(3 + k, c[k]); }
+      double S[21];
       {
-        int q = 6;
+        int q = 0;
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
-          for (int u = r; u < 6; u++) { put(q, 0.5 * (pv[r * 6 + u] + pv[u * 6 + r])); q++; }
+          for (int u = r; u < 6; u++) { S[q] = 0.5 * (pv[r * 6 + u] + pv[u * 6 + r]); put(6 + q, S[q]); q++; }
       }
       put(27, __builtin_bit_cast(double, make_float2(dd, radius)));
+      // the residual kernel's view: hot words + side word, in the plane table and in the plane's copy inside a candidate list (whose meta stays)
+      double hot[PLANE_HOT_DOUBLES];
+      plane_hot_words(nrm, c, S, hot);
+      const int32_t gp = a.plane_cand_pos[pi];
+#pragma unroll
+      for (int k = 0; k < PLANE_HOT_DOUBLES; k++)
+        if (lane == k % LPG) { a.planes_hot[(size_t)row * PLANE_HOT_DOUBLES + k] = hot[k]; if (gp >= 0) a.cand[(size_t)gp * PLANE_HOT_DOUBLES + k] = hot[k]; }
+      if (lane == 0) {
+        a.plane_aux[row].d = dd; a.plane_aux[row].radius = radius;
+        if (gp >= 0) { a.cand_aux[gp].d = dd; a.cand_aux[gp].radius = radius; }
+      }
 #pragma unroll
       for (int k = 28; k < 32; k++) put(k, 0.0);
     }

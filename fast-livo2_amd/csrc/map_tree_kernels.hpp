@@ -37,7 +37,7 @@ static_assert(sizeof(DevNode) == 128, "DevNode is two cache lines of 64 B");
 
 struct MapTreeArgs {
   DevNode *nodes; double *pool_pw, *pool_var;        // point pool: [cap][3], [cap][9]
-  double *planes, *cand; RootSlot *slots;
+  double *planes, *planes_hot, *cand; PlaneAux *plane_aux, *cand_aux; RootSlot *slots;     // master records [.][32]; hot words [.][16] by plane row / candidate position
   int32_t *counters;                                 // [MTC_COUNT]
   int32_t *dirty_list, *overflow_list;
   int32_t cap_nodes, cap_points, cap_planes, cap_cand, cap_overflow;
@@ -239,15 +239,21 @@ struct MtGroup {
     auto put = [&](int k, double v) { if (lane == k % MT_LPG) rec[k] = v; };
 #pragma unroll
     for (int k = 0; k < 3; k++) { put(k, nrm[k]); put(3 + k, R.c[k]); }
+    double S[21];
     {
-      int q = 6;
+      int q = 0;
 #pragma unroll
       for (int r = 0; r < 6; r++)
 #pragma unroll
-        for (int u = r; u < 6; u++) { put(q, 0.5 * (R.pv[r * 6 + u] + R.pv[u * 6 + r])); q++; }
+        for (int u = r; u < 6; u++) { S[q] = 0.5 * (R.pv[r * 6 + u] + R.pv[u * 6 + r]); put(6 + q, S[q]); q++; }
     }
     put(27, __builtin_bit_cast(double, make_float2(dd, radius)));
-    put(28, __builtin_bit_cast(double, make_int2(n.layer, 0)));       // PointToPlane::layer_ of a match (livo2_map_tree_read_planes); the residual kernel reads words 0..27
+    double hot[PLANE_HOT_DOUBLES];
+    plane_hot_words(nrm, R.c, S, hot);
+#pragma unroll
+    for (int k = 0; k < PLANE_HOT_DOUBLES; k++) if (lane == k % MT_LPG) a.planes_hot[(size_t)n.plane * PLANE_HOT_DOUBLES + k] = hot[k];
+    if (lane == 0) { PlaneAux x; x.d = dd; x.radius = radius; x.meta = n.plane | (n.layer << CAND_LAYER_SHIFT); x.pad = 0; a.plane_aux[n.plane] = x; }
+    put(28, __builtin_bit_cast(double, make_int2(n.layer, 0)));       // PointToPlane::layer_ of a match (livo2_map_tree_read_planes)
 #pragma unroll
     for (int k = 29; k < 32; k++) put(k, 0.0);
   }
@@ -473,10 +479,11 @@ __global__ void __launch_bounds__(256) k_mt_emit(MapTreeArgs a) {
         const DevNode &c = a.nodes[cid];
         if (c.is_plane) {
           if (pass == 1) {
-            double *dst = a.cand + (size_t)(r.cand_begin + n_out) * PLANE_REC_DOUBLES;
-            const double *src = a.planes + (size_t)c.plane * PLANE_REC_DOUBLES;
-            for (int q = lane; q < 28; q += MT_LPG) dst[q] = src[q];
-            if (lane == 0) { const int32_t meta[2] = {c.plane | (c.layer << CAND_LAYER_SHIFT), 0}; dst[28] = __builtin_bit_cast(double, make_int2(meta[0], meta[1])); }
+            const size_t at = (size_t)(r.cand_begin + n_out);
+            double *dst = a.cand + at * PLANE_HOT_DOUBLES;
+            const double *src = a.planes_hot + (size_t)c.plane * PLANE_HOT_DOUBLES;
+            for (int q = lane; q < PLANE_HOT_DOUBLES; q += MT_LPG) dst[q] = src[q];
+            if (lane == 0) { PlaneAux x = a.plane_aux[c.plane]; x.meta = c.plane | (c.layer << CAND_LAYER_SHIFT); a.cand_aux[at] = x; }
           }
           n_out++;
         } else if (sp + 1 < MT_STACK) { sp++; st_id[sp] = cid; st_next[sp] = 0; }
