@@ -38,7 +38,7 @@ def main():
     buf = np.zeros((W, 8), np.uint64)
     nw = C.c_size_t()
     assert fn(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), W, C.byref(nw)) == 0
-    waves = (nw.value - 2) * 4 // 13
+    waves = ((len(sc.xyz) + 255) // 256 + 7) // 8 * 8 * 4        # the launch's own grid (256-point blocks, a multiple of 8): the stamp regions are laid out by gridDim
     cst = buf[waves + 2 + waves // 4:waves + 2 + waves // 4 + 2 * waves].reshape(waves, 16).astype(np.int64)   # stamps inside the first cooperative round
     rt = buf[waves + 2:waves + 2 + waves // 4].reshape(-1)[:2 * waves].reshape(waves, 2).astype(np.int64)   # chip-wide 100 MHz stamps
     sol = buf[waves].astype(np.int64)
