@@ -298,6 +298,10 @@ int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   if (cfg->max_iterations < 1 || cfg->max_iterations > LIVO2_MAX_ITERS) return fail(ctx, LIVO2_ERR_INVALID, "max_iterations out of [1,LIVO2_MAX_ITERS]");
   if (cfg->max_layer < 0 || cfg->max_layer > LIVO2_MAX_LAYER) return fail(ctx, LIVO2_ERR_INVALID, "max_layer out of [0,LIVO2_MAX_LAYER]");
   if (!(cfg->voxel_size > 0)) return fail(ctx, LIVO2_ERR_INVALID, "voxel_size must be > 0");
+  // The first plane that passes the 3-sigma gate is taken without evaluating its probability (lidar_kernels.hpp, struct Best): exp(-d^2 / 2 sigma) / sqrt(sigma) > 0
+  // whenever d < sigma_num sqrt(sigma) and sigma_num is moderate.  Beyond ~38 the exponential underflows, `this_prob > prob` (voxel_map.cpp:741) fails and the
+  // reference pushes a default-constructed PointToPlane — a case nobody can mean; it is refused instead of reproduced.
+  if (!(cfg->sigma_num > 0) || cfg->sigma_num > 30.0) return fail(ctx, LIVO2_ERR_INVALID, "sigma_num out of (0, 30]");
   return LIVO2_OK;
 }
 

@@ -144,7 +144,8 @@ double livo2_plane_fit_last_kernel_us(const livo2_ctx *ctx);
 typedef struct livo2_lidar_cfg {
   int32_t max_iterations;       /* lio/max_iterations */
   int32_t max_layer;            /* lio/max_layer */
-  double sigma_num;             /* lio/sigma_num */
+  double sigma_num;             /* lio/sigma_num, in (0, 30]: above ~38 the reference's first-plane probability underflows to 0 and it records an
+                                   uninitialised match (voxel_map.cpp:739-753); such values are refused with LIVO2_ERR_INVALID */
   double dept_err;              /* lio/dept_err  (narrowed to float like calcBodyCov's parameter) */
   double beam_err;              /* lio/beam_err  (narrowed to float) */
   double voxel_size;            /* lio/voxel_size */

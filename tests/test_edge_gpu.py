@@ -190,6 +190,10 @@ def test_error_codes_and_determinism(livo2):
     with pytest.raises(livo2.Livo2Error) as e:
         c.set_scan(sc.xyz, bad)
     assert e.value.code == livo2.abi.ERR_INVALID
+    bad = H.lidar_cfg_product(sc); bad.sigma_num = 64.0        # first-plane probability could underflow: refused, not reproduced (include/livo2_hip.h)
+    with pytest.raises(livo2.Livo2Error) as e:
+        c.set_scan(sc.xyz, bad)
+    assert e.value.code == livo2.abi.ERR_INVALID
     c.set_scan(sc.xyz, cfg)
     a, _ = c.lidar_update(cur, prop, cfg)
     b, _ = c.lidar_update(cur, prop, cfg)
