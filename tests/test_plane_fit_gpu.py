@@ -57,6 +57,39 @@ def test_fit_batch_matches_oracle(ctx, orc):
     assert planes > 150
 
 
+def test_fit_batch_matches_numpy_second_opinion(ctx):
+    """The device fit against an evaluation that shares NO code with it or with the oracle (scenarios/synth._fit_planes: batched numpy eigh, Eigen's role in
+    voxel_map.cpp:70) — the Jacobi sweeps of oracle and kernel are the same algorithm, so the oracle comparison alone would check an algorithm against its twin."""
+    pw, var, off, kinds = PG.make_groups(seed=11, n_groups=300, big=(700,))
+    G = len(off) - 1
+    gid = np.repeat(np.arange(G), np.diff(off))
+    cnt, ctr, ev, evec, pv = synth._fit_planes(pw, var.reshape(-1, 3, 3), gid, G)
+    out = ctx.plane_fit_batch(pw, var, off.astype(np.int32), THR)
+    n_planes = 0
+    for g in range(G):
+        o = out[g]
+        assert o.points_size == off[g + 1] - off[g]
+        np.testing.assert_allclose(np.array(o.center), ctr[g], rtol=1e-13)
+        if abs(ev[g, 0] - THR) < 1e-9:
+            continue                                           # the plane / no-plane decision at the threshold is a rounding matter
+        assert o.is_plane == int(ev[g, 0] < THR), (g, kinds[g], ev[g])
+        if not o.is_plane:
+            continue
+        n_planes += 1
+        assert abs(o.min_eigen_value - ev[g, 0]) < 1e-6 * ev[g, 2] + 1e-7 * abs(ev[g, 0])
+        assert abs(o.max_eigen_value - ev[g, 2]) < 1e-6 * ev[g, 2]
+        n = np.array(o.normal)
+        sgn = np.sign(n @ evec[g][:, 0])
+        gap = ev[g, 1] - ev[g, 0]
+        assert np.linalg.norm(sgn * n - evec[g][:, 0]) < 1e-7 * ev[g, 2] / gap + 1e-12
+        assert abs(o.radius - np.sqrt(ev[g, 2])) < 1e-6
+        assert abs(o.d + sgn * float(evec[g][:, 0] @ ctr[g])) < 1e-4
+        D = np.diag([sgn, sgn, sgn, 1.0, 1.0, 1.0])            # the normal / centre cross blocks carry the solver-dependent sign of the normal
+        P, Q = np.array(o.plane_var).reshape(6, 6), D @ pv[g].reshape(6, 6) @ D
+        assert np.linalg.norm(P - Q) < 1e-5 * np.linalg.norm(Q) * max(1.0, ev[g, 2] / gap), (g, kinds[g])
+    assert n_planes > 100
+
+
 def test_fit_refreshes_resident_map(ctx, livo2, orc):
     """Fitted records written in place by the kernel == records sent through livo2_map_update_planes from the oracle's fit,
     as seen by the LiDAR update that reads them."""
