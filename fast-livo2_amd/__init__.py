@@ -23,6 +23,13 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def _cam_distortion(c, cam):
+    """cam["d"] (optional): the five radial-tangential coefficients d0..d4 of vk::PinholeCamera"""
+    d = cam.get("d")
+    c.distortion = 0 if d is None else 1
+    c.d[:] = [0.0] * 5 if d is None else [float(x) for x in d]
+
+
 class Context:
     """One GPU + one HIP stream (livo2_ctx)."""
 
@@ -310,6 +317,7 @@ class Context:
         c = SelectCfg()
         c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"]
         c.cam.distortion, c.cam.width, c.cam.height = 0, ss.cam["width"], ss.cam["height"]
+        _cam_distortion(c.cam, ss.cam)
         c.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); c.t_cur[:] = np.asarray(ss.t_cur, float).tolist()
         c.border, c.grid_size, c.grid_n_width, c.grid_n_height, c.patch_size_half = int(ss.border), int(ss.grid_size), int(ss.grid_n_width), int(ss.grid_n_height), 4
         length = int(ss.grid_n_width) * int(ss.grid_n_height)
@@ -330,6 +338,7 @@ class Context:
         c = RetrieveCfg()
         c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = rs.cam["fx"], rs.cam["fy"], rs.cam["cx"], rs.cam["cy"]
         c.cam.distortion, c.cam.width, c.cam.height = 0, rs.cam["width"], rs.cam["height"]
+        _cam_distortion(c.cam, rs.cam)
         c.R_cur[:] = np.asarray(rs.R_cur, float).ravel().tolist(); c.t_cur[:] = np.asarray(rs.t_cur, float).tolist(); c.inv_expo_cur = float(rs.inv_expo_cur)
         c.patch_pyrimid_level, c.normal_en, c.ncc_en = L, int(rs.cfg["normal_en"]), int(rs.cfg["ncc_en"])
         c.ncc_thre, c.outlier_threshold = float(rs.cfg["ncc_thre"]), float(rs.cfg["outlier_threshold"])
@@ -382,6 +391,7 @@ class Context:
         sc = SelectCfg()
         sc.cam.fx, sc.cam.fy, sc.cam.cx, sc.cam.cy = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"]
         sc.cam.distortion, sc.cam.width, sc.cam.height = 0, ss.cam["width"], ss.cam["height"]
+        _cam_distortion(sc.cam, ss.cam)
         sc.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); sc.t_cur[:] = np.asarray(ss.t_cur, float).tolist()
         sc.border, sc.grid_size, sc.grid_n_width, sc.grid_n_height, sc.patch_size_half = int(ss.border), int(ss.grid_size), int(ss.grid_n_width), int(ss.grid_n_height), 4
         c = RetrieveCfg()

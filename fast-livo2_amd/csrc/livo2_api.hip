@@ -1670,7 +1670,6 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
 // selection stage: buffers for n_pg scan points and `length` grid cells; *cap_out = capacity of the scan-voxel hash set
 static int select_reserve(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n_pg, size_t *cap_out) {
   if (!ctx->has_vmap) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_map_upload has not been called");
-  if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "selection needs a zero-distortion camera");
   const int length = cfg->grid_n_width * cfg->grid_n_height;
   if (cfg->grid_size < 1 || cfg->grid_n_width < 1 || cfg->grid_n_height < 1 || length > (1 << 20) || cfg->cam.width < 1 || cfg->cam.height < 1 || cfg->patch_size_half < 0 ||
       cfg->border < cfg->patch_size_half) return fail(ctx, LIVO2_ERR_INVALID, "bad grid / border (the 9x9 depth window must stay inside the image: border >= patch_size_half)");
@@ -1697,7 +1696,7 @@ static int select_enqueue(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n
   const int length = cfg->grid_n_width * cfg->grid_n_height;
   const size_t px = (size_t)cfg->cam.width * cfg->cam.height;
   SelectArgs a{};
-  a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
+  a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy; std::memcpy(a.d, cfg->cam.d, 40); a.distortion = cfg->cam.distortion;
   std::memcpy(a.R, cfg->R_cur, 72); std::memcpy(a.t, cfg->t_cur, 24);
   frame_pos(cfg->R_cur, cfg->t_cur, a.cam_pos);
   a.width = cfg->cam.width; a.height = cfg->cam.height; a.border = cfg->border; a.grid_size = cfg->grid_size; a.grid_n_width = cfg->grid_n_width; a.length = length;
@@ -1797,6 +1796,7 @@ static int tail_enqueue(livo2_ctx *ctx, const livo2_retrieve_cfg *cfg, int width
   WarpKernelArgs a{};
   a.img = ctx->d_img; a.ref_imgs = d_ref_imgs; a.width = width; a.height = height; a.stride = stride; a.n = n; a.L = L;
   a.normal_en = cfg->normal_en; a.ncc_en = cfg->ncc_en; a.fx = cfg->cam.fx; a.fy = cfg->cam.fy; a.cx = cfg->cam.cx; a.cy = cfg->cam.cy;
+  std::memcpy(a.d, cfg->cam.d, 40); a.distortion = cfg->cam.distortion;
   a.inv_expo_cur = cfg->inv_expo_cur; a.ncc_thre = cfg->ncc_thre; a.outlier_threshold = cfg->outlier_threshold;
   std::memcpy(a.R_cur, cfg->R_cur, 72); std::memcpy(a.t_cur, cfg->t_cur, 24);
   a.pos = ctx->d_c_pos; a.normal = ctx->d_c_normal; a.ref_px = ctx->d_c_px; a.ref_f = ctx->d_c_f; a.ref_R = ctx->d_c_R; a.ref_t = ctx->d_c_t; a.ref_inv_expo = ctx->d_c_ie;
@@ -1831,7 +1831,6 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
   if (!cand || !cfg || !n_accepted) return fail(ctx, LIVO2_ERR_INVALID, "cand / cfg / n_accepted is NULL");
   const int n = cand->n, L = cfg->patch_pyrimid_level;
   if (n < 0 || L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad candidate count or patch_pyrimid_level");
-  if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "retrieval needs a zero-distortion camera");
   if (cfg->cam.width != width || cfg->cam.height != height) return fail(ctx, LIVO2_ERR_INVALID, "camera size differs from the image");
   if (n > 0 && (!ref_imgs || n_ref < 1 || !cand->pos || !cand->normal || !cand->ref_img_idx || !cand->ref_px || !cand->ref_f || !cand->ref_R || !cand->ref_t ||
                 !cand->ref_level || !cand->ref_inv_expo)) return fail(ctx, LIVO2_ERR_INVALID, "bad candidate arrays");
@@ -1951,7 +1950,6 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if (!ctx->has_obs) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_obs_upload has not been called (after livo2_visual_map_upload)");
   const int L = cfg->patch_pyrimid_level;
   if (L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad patch_pyrimid_level");
-  if (cfg->cam.distortion != 0) return fail(ctx, LIVO2_ERR_INVALID, "retrieval needs a zero-distortion camera");
   if (cfg->cam.width != width || cfg->cam.height != height || sel->cam.width != width || sel->cam.height != height) return fail(ctx, LIVO2_ERR_INVALID, "camera size differs from the image");
   if (ctx->n_obs > 0 && (ctx->ob_w != width || ctx->ob_h != height || ctx->ob_stride != stride)) return fail(ctx, LIVO2_ERR_INVALID, "reference images differ in size from the image");
   if (sel->border < 4) return fail(ctx, LIVO2_ERR_INVALID, "border must keep the 8x8 patch of a selected point inside the image (>= 4)");

@@ -8,7 +8,7 @@
 //   C  k_sel_cells   per grid cell (one wave): the depth-continuity test of the selected point against the 9x9 depth-image window.
 // The visual map lives on the device as flat arrays (position, the voxel it is filed under, active flag), uploaded by
 // livo2_visual_map_upload.  Both voxel-key formulas are the reference's own, mismatch for negative coordinates included
-// (vio.cpp:392-396 vs 232-236).  vikit's world2cam / isInFrame restated (zero-distortion pinhole): parity unpinned at that boundary.
+// (vio.cpp:392-396 vs 232-236).  vikit's world2cam (pinhole, optional radial-tangential distortion) / isInFrame restated: parity unpinned at that boundary.
 #pragma once
 #include "livo2_device.hpp"
 
@@ -16,6 +16,8 @@
 
 struct SelectArgs {
   double fx, fy, cx, cy, R[9], t[3], cam_pos[3];
+  double d[5];                             // vk::PinholeCamera radial-tangential coefficients, used when distortion != 0
+  int32_t distortion, pad2;
   int32_t width, height, border, grid_size, grid_n_width, length, patch_size_half, n_pg, n_pts, pad;
   const double *pg;                        // [n_pg][3]
   const double *pos;                       // [n_pts][3]
@@ -43,7 +45,13 @@ __device__ __forceinline__ bool sel_project(const SelectArgs &a, const double *p
 #pragma unroll
   for (int r = 0; r < 3; r++) pc3[r] = ((a.R[r * 3] * p[0] + a.R[r * 3 + 1] * p[1]) + a.R[r * 3 + 2] * p[2]) + a.t[r];
   const double u = pc3[0] / pc3[2], v = pc3[1] / pc3[2];
-  px[0] = a.fx * u + a.cx; px[1] = a.fy * v + a.cy;
+  if (!a.distortion) { px[0] = a.fx * u + a.cx; px[1] = a.fy * v + a.cy; return true; }
+  const double x = u, y = v, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;      // rpg_vikit's radtan model, order of oracle/orc_visual.hpp
+  const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+  const double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
+  const double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2;
+  const double yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
+  px[0] = xd * a.fx + a.cx; px[1] = yd * a.fy + a.cy;
   return true;
 }
 __device__ __forceinline__ bool sel_in_frame(const SelectArgs &a, int x, int y) { return x >= a.border && x < a.width - a.border && y >= a.border && y < a.height - a.border; }

@@ -480,7 +480,7 @@ void VIOManager::gridSetup() {                                                  
 
 livo2_select_cfg VIOManager::selectCfg() const {
   livo2_select_cfg sc{};
-  sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = 0; sc.cam.width = width; sc.cam.height = height;
+  sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = distortion_en ? 1 : 0; std::memcpy(sc.cam.d, cam_d, sizeof(cam_d)); sc.cam.width = width; sc.cam.height = height;
   std::memcpy(sc.R_cur, R_f_w_new.data(), 72); std::memcpy(sc.t_cur, t_f_w_new.data(), 24);
   sc.border = border; sc.grid_size = grid_size; sc.grid_n_width = grid_n_width; sc.grid_n_height = grid_n_height; sc.patch_size_half = patch_size / 2;
   return sc;
@@ -555,7 +555,7 @@ void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<C
   for (size_t k = 0; k < imgs.size(); k++) std::memcpy(&pool[k * bytes], imgs[k], bytes);
   livo2_retrieve_candidates cd{n, 0, pos.data(), nrm.data(), idx.data(), px.data(), f.data(), R.data(), t.data(), lvl.data(), ie.data()};
   livo2_retrieve_cfg rc{};
-  rc.cam.fx = fx; rc.cam.fy = fy; rc.cam.cx = cx; rc.cam.cy = cy; rc.cam.distortion = 0; rc.cam.width = width; rc.cam.height = height;
+  rc.cam.fx = fx; rc.cam.fy = fy; rc.cam.cx = cx; rc.cam.cy = cy; rc.cam.distortion = distortion_en ? 1 : 0; std::memcpy(rc.cam.d, cam_d, sizeof(cam_d)); rc.cam.width = width; rc.cam.height = height;
   std::memcpy(rc.R_cur, R_f_w_new.data(), 72); std::memcpy(rc.t_cur, t_f_w_new.data(), 24);
   rc.inv_expo_cur = state->inv_expo_time; rc.patch_pyrimid_level = L; rc.normal_en = normal_en; rc.ncc_en = ncc_en; rc.ncc_thre = ncc_thre; rc.outlier_threshold = outlier_threshold;
   std::vector<int32_t> acc(n), sl(n); std::vector<float> err(n);
@@ -602,7 +602,7 @@ void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
     dev_.check(livo2_visual_set_reference(dev_.ctx(), stack.data(), (int32_t)imgs.size(), idx.data(), px.data(), f.data(), R.data(), rp.data()));
   }
   livo2_visual_cfg cfg{};
-  cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = 0; cfg.cam.width = width; cfg.cam.height = height;
+  cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = distortion_en ? 1 : 0; std::memcpy(cfg.cam.d, cam_d, sizeof(cam_d)); cfg.cam.width = width; cfg.cam.height = height;
   std::memcpy(cfg.Rcl, Rcl.data(), 72); std::memcpy(cfg.Pcl, Pcl.data(), 24); std::memcpy(cfg.extR, extR.data(), 72); std::memcpy(cfg.extT, extT.data(), 24);
   cfg.img_point_cov = img_point_cov; cfg.patch_pyrimid_level = L; cfg.max_iterations = max_iterations;
   cfg.exposure_estimate_en = exposure_estimate_en; cfg.inverse_composition_en = inverse_composition_en; cfg.mp_proc_num = mp_proc_num;

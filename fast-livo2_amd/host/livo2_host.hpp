@@ -246,6 +246,9 @@ public:
   M3D Rcl{{1, 0, 0, 0, 1, 0, 0, 0, 1}}, extR{{1, 0, 0, 0, 1, 0, 0, 0, 1}}, Rcw{};
   V3D Pcl{}, extT{}, Pcw{};
   double fx = 0, fy = 0, cx = 0, cy = 0;
+  // cam_d0..cam_d4 of config/camera_pinhole.yaml (vk::PinholeCamera's radial-tangential model); distortion_en = vikit's `distortion_` (any coefficient non-zero)
+  double cam_d[5] = {0, 0, 0, 0, 0};
+  bool distortion_en = false;
   int width = 0, height = 0;
   int patch_pyrimid_level = 4, patch_size = 8, max_iterations = 5, total_points = 0;
   double img_point_cov = 100;

@@ -363,7 +363,8 @@ double livo2_visual_select_last_kernel_us(const livo2_ctx *ctx);
  * whose ref_ftr has the same id_; with ref_id given that is reproduced, with NULL every candidate computes its own.
  * Outputs (each may be NULL): accepted[n] (1 = appended to visual_submap), search_level[n], error[n] (the float photometric error),
  * ncc[n], A_cur_ref[n][4] row-major, patch_wrap[n][L][64] (all candidates, for inspection).  *n_accepted = survivors.
- * cam.distortion must be 0 (cam2world of a distorted vikit camera is not restated).  A candidate whose 9x9 current-image window
+ * cam.distortion = 1: rpg_vikit's radial-tangential model; its cam2world is OpenCV's undistortPoints (float32 point in, five fixed-point iterations in double,
+ * float32 point out), restated from the published source (third party, parity unpinned).  A candidate whose 9x9 current-image window
  * leaves the image is rejected with error = +inf (the reference reads out of bounds there). */
 typedef struct livo2_retrieve_cfg {
   livo2_cam cam;

@@ -177,7 +177,31 @@ def init_plane_batch(point_w, var, offsets, planer_threshold, lib=None):
 class WarpCfg(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("width", C.c_int32), ("height", C.c_int32),
                 ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("inv_expo_cur", C.c_double), ("patch_pyrimid_level", C.c_int32),
-                ("normal_en", C.c_int32), ("ncc_en", C.c_int32), ("pad", C.c_int32), ("ncc_thre", C.c_double), ("outlier_threshold", C.c_double)]
+                ("normal_en", C.c_int32), ("ncc_en", C.c_int32), ("pad", C.c_int32), ("ncc_thre", C.c_double), ("outlier_threshold", C.c_double),
+                ("d", C.c_double * 5), ("distortion", C.c_int32), ("pad2", C.c_int32)]
+
+
+def _cam_distortion(c, cam):
+    """cam["d"] (optional): the five radial-tangential coefficients d0..d4 of vk::PinholeCamera"""
+    d = cam.get("d")
+    c.distortion = 0 if d is None else 1
+    c.d[:] = [0.0] * 5 if d is None else [float(x) for x in d]
+
+
+def cam_roundtrip(cam, uv, lib=None):
+    """vk::PinholeCamera::cam2world then world2cam for pixels uv [n,2] of the camera dict `cam` (optional key "d": radial-tangential coefficients).
+    Returns (bearing vectors [n,3], re-projected pixels [n,2])."""
+    lib = lib or load()
+    c = WarpCfg()
+    c.fx, c.fy, c.cx, c.cy, c.width, c.height = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["width"], cam["height"]
+    _cam_distortion(c, cam)
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    f, px = np.zeros((len(uv), 3)), np.zeros((len(uv), 2))
+    lib.orc_cam2world.restype = None; lib.orc_world2cam.restype = None
+    for i in range(len(uv)):
+        lib.orc_cam2world(C.byref(c), C.c_double(uv[i, 0]), C.c_double(uv[i, 1]), f[i].ctypes.data_as(C.POINTER(C.c_double)))
+        lib.orc_world2cam(C.byref(c), f[i].ctypes.data_as(C.POINTER(C.c_double)), px[i].ctypes.data_as(C.POINTER(C.c_double)))
+    return f, px
 
 
 def warp_candidates(rs, lib=None):
@@ -186,6 +210,7 @@ def warp_candidates(rs, lib=None):
     lib = lib or load()
     c = WarpCfg()
     c.fx, c.fy, c.cx, c.cy, c.width, c.height = rs.cam["fx"], rs.cam["fy"], rs.cam["cx"], rs.cam["cy"], rs.cam["width"], rs.cam["height"]
+    _cam_distortion(c, rs.cam)
     c.R_cur[:] = rs.R_cur.ravel().tolist(); c.t_cur[:] = rs.t_cur.tolist(); c.inv_expo_cur = rs.inv_expo_cur
     c.patch_pyrimid_level, c.normal_en, c.ncc_en = int(rs.cfg["patch_pyrimid_level"]), int(rs.cfg["normal_en"]), int(rs.cfg["ncc_en"])
     c.ncc_thre, c.outlier_threshold = float(rs.cfg["ncc_thre"]), float(rs.cfg["outlier_threshold"])
@@ -238,7 +263,7 @@ def voxel_grid(xyz, leaf, lib=None):
 class SelectCfg(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("width", C.c_int32), ("height", C.c_int32),
                 ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_width", C.c_int32),
-                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32)]
+                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32), ("d", C.c_double * 5), ("distortion", C.c_int32), ("pad2", C.c_int32)]
 
 
 def visual_select(ss, lib=None):
@@ -246,6 +271,7 @@ def visual_select(ss, lib=None):
     lib = lib or load()
     c = SelectCfg()
     c.fx, c.fy, c.cx, c.cy, c.width, c.height = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"], ss.cam["width"], ss.cam["height"]
+    _cam_distortion(c, ss.cam)
     c.R_cur[:] = ss.R_cur.ravel().tolist(); c.t_cur[:] = ss.t_cur.tolist()
     c.border, c.grid_size, c.grid_n_width, c.grid_n_height, c.patch_size_half = ss.border, ss.grid_size, ss.grid_n_width, ss.grid_n_height, 4
     length = ss.grid_n_width * ss.grid_n_height

@@ -370,14 +370,15 @@ struct orc_warp_cfg {
   double R_cur[9], t_cur[3], inv_expo_cur;
   int32_t patch_pyrimid_level, normal_en, ncc_en, pad;
   double ncc_thre, outlier_threshold;
+  double d[5]; int32_t distortion, pad2;          // vk::PinholeCamera radial-tangential coefficients (distortion = 0: pure pinhole)
 };
 double orc_warp_candidates(const orc_warp_cfg *c, const uint8_t *img, const uint8_t *ref_imgs, int n, const double *pos, const double *normal,
                            const int32_t *ref_img_idx, const double *ref_px, const double *ref_f, const double *ref_R, const double *ref_t,
                            const int32_t *ref_level, const double *ref_inv_expo, const int32_t *ref_id, int32_t *accepted, int32_t *search_level, float *error,
                            double *ncc, double *A4, float *patch_wrap) {
   WarpCfg cfg;
-  cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = 0; cfg.cam.width = c->width; cfg.cam.height = c->height;
-  for (int k = 0; k < 5; k++) cfg.cam.d[k] = 0;
+  cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = c->distortion; cfg.cam.width = c->width; cfg.cam.height = c->height;
+  for (int k = 0; k < 5; k++) cfg.cam.d[k] = c->d[k];
   std::memcpy(cfg.R_cur.a, c->R_cur, 72); std::memcpy(cfg.t_cur.a, c->t_cur, 24);
   cfg.inv_expo_cur = c->inv_expo_cur; cfg.patch_pyrimid_level = c->patch_pyrimid_level; cfg.normal_en = c->normal_en; cfg.ncc_en = c->ncc_en;
   cfg.ncc_thre = c->ncc_thre; cfg.outlier_threshold = c->outlier_threshold;
@@ -423,14 +424,27 @@ int orc_voxel_grid(const float *xyz, int n, float leaf, float *out_xyz /*capacit
   return m;
 }
 
+// vk::PinholeCamera::cam2world / world2cam of the camera in a warp cfg (tests: round trip, second opinion)
+void orc_cam2world(const orc_warp_cfg *c, double u, double v, double *xyz) {
+  PinholeCam cam; cam.fx = c->fx; cam.fy = c->fy; cam.cx = c->cx; cam.cy = c->cy; cam.distortion = c->distortion; cam.width = c->width; cam.height = c->height;
+  for (int k = 0; k < 5; k++) cam.d[k] = c->d[k];
+  const V3 f = cam2world(cam, u, v);
+  xyz[0] = f[0]; xyz[1] = f[1]; xyz[2] = f[2];
+}
+void orc_world2cam(const orc_warp_cfg *c, const double *xyz, double *px) {
+  PinholeCam cam; cam.fx = c->fx; cam.fy = c->fy; cam.cx = c->cx; cam.cy = c->cy; cam.distortion = c->distortion; cam.width = c->width; cam.height = c->height;
+  for (int k = 0; k < 5; k++) cam.d[k] = c->d[k];
+  cam.world2cam(vec3(xyz[0], xyz[1], xyz[2]), px);
+}
+
 // Selection half of retrieveFromVisualSparseMap (orc_select.hpp).  keys: [n_pts][3] int64 feat_map keys (NULL: computed from pos with
 // insertPointIntoVoxelMap's formula).  Returns seconds.
-struct orc_select_cfg { double fx, fy, cx, cy; int32_t width, height; double R_cur[9], t_cur[3]; int32_t border, grid_size, grid_n_width, grid_n_height, patch_size_half, pad; };
+struct orc_select_cfg { double fx, fy, cx, cy; int32_t width, height; double R_cur[9], t_cur[3]; int32_t border, grid_size, grid_n_width, grid_n_height, patch_size_half, pad; double d[5]; int32_t distortion, pad2; };
 double orc_visual_select(const orc_select_cfg *c, const double *pg, int n_pg, const double *pos, const int64_t *keys, const uint8_t *active, int n_pts,
                          int32_t *cell_point, float *cell_dist, int32_t *cell_type, int32_t *discont, int32_t *in_fov, float *depth_img) {
   SelectCfg cfg;
-  cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = 0; cfg.cam.width = c->width; cfg.cam.height = c->height;
-  for (int k = 0; k < 5; k++) cfg.cam.d[k] = 0;
+  cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = c->distortion; cfg.cam.width = c->width; cfg.cam.height = c->height;
+  for (int k = 0; k < 5; k++) cfg.cam.d[k] = c->d[k];
   std::memcpy(cfg.R_cur.a, c->R_cur, 72); std::memcpy(cfg.t_cur.a, c->t_cur, 24);
   cfg.border = c->border; cfg.grid_size = c->grid_size; cfg.grid_n_width = c->grid_n_width; cfg.grid_n_height = c->grid_n_height; cfg.patch_size_half = c->patch_size_half;
   std::vector<VisualMapPoint> pts((size_t)n_pts);

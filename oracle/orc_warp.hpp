@@ -15,7 +15,7 @@
 //
 // Third-party arithmetic NOT under /root/reference (rpg_vikit, xuankuzcr fork, unpinned — README.md:76-84), restated from its
 // published sources, PARITY UNPINNED:
-//   vk::PinholeCamera::cam2world(px)  = normalize((u-cx)/fx, (v-cy)/fy, 1)          (zero distortion, as in the benchmark configs)
+//   vk::PinholeCamera::cam2world(px)  = normalize((u-cx)/fx, (v-cy)/fy, 1); with distortion: OpenCV's undistortPoints iteration first (see cam2world below)
 //   vk::interpolateMat_8u(mat, u, v)  = float bilinear: w00=(1-sx)(1-sy), w01=(1-sx)sy, w10=sx(1-sy), w11=1-w00-w01-w10;
 //                                       w00*p[0] + w01*p[stride] + w10*p[1] + w11*p[stride+1]
 //   Sophus SE3 composition / inverse  = rigid-transform algebra
@@ -42,8 +42,29 @@ struct WarpCand {                   // what the loop body reads of `pt` and `ref
   double inv_expo_ref;              // ref_ftr->inv_expo_time_
 };
 
+// vk::PinholeCamera::cam2world.  Without distortion: normalize((u-cx)/fx, (v-cy)/fy, 1).  With distortion rpg_vikit calls
+//   cv::undistortPoints(CV_32FC2 point, CV_32FC2 result, cvK_, cvD_)          (OpenCV >= 4.2, unpinned: README.md:57-61)
+// whose published algorithm (cvUndistortPointsInternal, default TermCriteria(MAX_ITER, 5, 0.01): exactly five fixed-point iterations, no R / P, no tilt,
+// k = (k1, k2, p1, p2, k3) = d[0..4]) is restated here: the pixel enters as float32, the iteration runs in double, the undistorted normalised point leaves
+// as float32, and vikit normalises (x, y, 1) in double.  PARITY UNPINNED (third-party, from its published source).
 inline V3 cam2world(const PinholeCam &c, double u, double v) {
-  V3 xyz = vec3((u - c.cx) / c.fx, (v - c.cy) / c.fy, 1.0);
+  if (!c.distortion) {
+    V3 xyz = vec3((u - c.cx) / c.fx, (v - c.cy) / c.fy, 1.0);
+    return xyz / norm(xyz);
+  }
+  const double uf = (double)(float)u, vf = (double)(float)v;           // cv::Point2f uv(u, v)
+  const double ifx = 1.0 / c.fx, ify = 1.0 / c.fy;
+  const double x0 = (uf - c.cx) * ifx, y0 = (vf - c.cy) * ify;
+  double x = x0, y = y0;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1.0 / (1.0 + ((c.d[4] * r2 + c.d[1]) * r2 + c.d[0]) * r2);
+    if (icdist < 0) { x = x0; y = y0; break; }
+    const double deltaX = 2.0 * c.d[2] * x * y + c.d[3] * (r2 + 2.0 * x * x);
+    const double deltaY = c.d[2] * (r2 + 2.0 * y * y) + 2.0 * c.d[3] * x * y;
+    x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
+  }
+  V3 xyz = vec3((double)(float)x, (double)(float)y, 1.0);               // dst point is CV_32FC2
   return xyz / norm(xyz);
 }
 

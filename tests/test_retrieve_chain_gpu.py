@@ -54,6 +54,14 @@ def test_chain_matches_oracle(ctx, orc, normal_en):
         assert len(np.unique(ids)) < len(ids) / 10                     # warp_map: a handful of frames lead all candidates
 
 
+def test_chain_with_radtan_camera(ctx, orc):
+    """The whole retrieveFromVisualSparseMap with the avia camera's distortion (world2cam in selection and warp, cam2world in the warp)."""
+    cs = synth.retrieve_chain_scenario(seed=83, n_pg=8000, n_vis=12000, grid_n_height=51, normal_en=True)
+    cs.sel.cam = dict(cs.sel.cam); cs.sel.cam["d"] = synth.AVIA_RADTAN
+    ref, out = _compare(ctx, orc, cs)
+    assert len(ref["cand_cell"]) > 200 and len(ref["sub_point"]) > 50
+
+
 def test_remembered_choice_is_reused(ctx, orc):
     """A second call on the same map sees the ref_patch the first one remembered on the device (pt->ref_patch / has_ref_patch_)."""
     cs = synth.retrieve_chain_scenario(seed=82, n_pg=6000, n_vis=9000, normal_en=True)

@@ -77,3 +77,39 @@ def test_affine_variant_with_ncc_gate():
     rs = synth.retrieve_scenario(seed=32, n_cand=200, normal_en=False, ncc_en=True, ncc_thre=0.9)
     ref = orc.warp_candidates(rs)
     _check(rs, ref, range(0, 200, 3))
+
+
+def test_radtan_cam2world_inverts_world2cam_and_matches_numpy():
+    """The distorted vk::PinholeCamera::cam2world (OpenCV's undistortPoints restated: float32 pixel in, five fixed-point iterations in double, float32
+    normalised point out) against a plain numpy evaluation of the same published iteration, and as the inverse of world2cam on the avia camera."""
+    from oracle import orc
+    cam = dict(synth.AVIA["cam"]); cam["d"] = synth.AVIA_RADTAN
+    rng = np.random.default_rng(5)
+    uv = np.stack([rng.uniform(0, cam["width"] - 1, 400), rng.uniform(0, cam["height"] - 1, 400)], 1)
+    f, px = orc.cam_roundtrip(cam, uv)
+    assert np.allclose(np.linalg.norm(f, axis=1), 1.0, atol=1e-15)
+    assert np.abs(px - uv).max() < 2e-3                       # float32 pixel / float32 normalised point: ~1e-4 px; the iteration itself converges to 1e-9
+    d = np.array(cam["d"])
+    u32, v32 = uv[:, 0].astype(np.float32).astype(np.float64), uv[:, 1].astype(np.float32).astype(np.float64)
+    x0, y0 = (u32 - cam["cx"]) * (1.0 / cam["fx"]), (v32 - cam["cy"]) * (1.0 / cam["fy"])
+    x, y = x0.copy(), y0.copy()
+    for _ in range(5):
+        r2 = x * x + y * y
+        ic = 1.0 / (1.0 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2)
+        dx = 2.0 * d[2] * x * y + d[3] * (r2 + 2.0 * x * x)
+        dy = d[2] * (r2 + 2.0 * y * y) + 2.0 * d[3] * x * y
+        x, y = (x0 - dx) * ic, (y0 - dy) * ic
+    g = np.stack([x.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64), np.ones_like(x)], 1)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    assert np.abs(f - g).max() < 1e-15
+    f0, _ = orc.cam_roundtrip(dict(synth.AVIA["cam"]), uv)     # the pinhole bearing differs by the distortion: up to a few pixels' worth near the corners
+    assert 1e-4 < np.abs(f - f0).max() < 2e-2
+
+
+def test_radtan_camera_changes_the_warps():
+    rs = synth.retrieve_scenario(seed=24, n_cand=300, normal_en=True)
+    a = orc.warp_candidates(rs)
+    rs.cam = dict(rs.cam); rs.cam["d"] = synth.AVIA_RADTAN
+    b = orc.warp_candidates(rs)
+    assert np.abs(a["A"] - b["A"]).max() > 1e-4 and not np.array_equal(a["patch_wrap"], b["patch_wrap"])
+    assert 0.3 < b["accepted"].mean() <= 1.0

@@ -42,6 +42,18 @@ def test_affine_warp_and_ncc_gate_match_oracle(ctx, orc):
     assert ((ref["ncc"] < 0.9) & (ref["error"] <= 1000.0 * 64)).sum() > 0       # some candidates fall to the NCC gate alone
 
 
+@pytest.mark.parametrize("normal_en", [True, False])
+def test_radtan_camera_matches_oracle(ctx, orc, normal_en):
+    """The avia camera's radial-tangential coefficients (config/camera_pinhole.yaml:9-12) through world2cam AND cam2world (OpenCV's undistortPoints
+    iteration inside vk::PinholeCamera::cam2world): same bit-level bars as the pinhole camera."""
+    rs = synth.retrieve_scenario(seed=25, n_cand=900, normal_en=normal_en, ncc_en=not normal_en, ncc_thre=0.85)
+    pin = orc.warp_candidates(rs)
+    rs.cam = dict(rs.cam); rs.cam["d"] = synth.AVIA_RADTAN
+    ref, out = _compare(ctx, orc, rs)
+    assert np.abs(ref["A"] - pin["A"]).max() > 1e-4           # the distortion is felt
+    assert 0.3 < ref["accepted"].mean() < 0.98
+
+
 def test_survivors_become_the_resident_frame(ctx, livo2, orc):
     """After the call the frame of the next visual update is the compacted survivor list: the update gives byte-identical results to
     livo2_visual_set_frame with the survivors' arrays taken from the oracle."""
