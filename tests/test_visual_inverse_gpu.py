@@ -40,6 +40,24 @@ def test_inverse_iterate_matches_oracle(ctx, livo2, orc, vs_inv, level):
     assert np.array_equal(np.array(sums2.HtH), np.array(sums.HtH)) and np.array_equal(errors2, errors)
 
 
+def test_inverse_iterate_with_radtan_camera(ctx, livo2, orc, vs_inv):
+    """cam->world2cam with the avia camera's distortion coefficients inside updateStateInverse (vio.cpp:1447): the kernel's radtan branch."""
+    vs = vs_inv
+    ocfg = orc.visual_cfg(vs, inverse=True, distortion=synth.AVIA_RADTAN)
+    pcfg = H.visual_cfg_product(vs, inverse=True, distortion=synth.AVIA_RADTAN)
+    ocur, _ = H.states(vs, orc.StatePOD)
+    pcur, _ = H.states(vs, livo2.State)
+    pin = orc.visual_iterate_inverse(orc.visual_cfg(vs, inverse=True), vs, 0, ocur)
+    ref = orc.visual_iterate_inverse(ocfg, vs, 0, ocur)
+    assert not np.array_equal(ref["z"], pin["z"])                            # the distortion moves the sampling positions
+    _upload(ctx, vs)
+    sums, errors, z, Hs = ctx.visual_iterate(0, pcur, pcfg, rows=True)
+    assert sums.n_meas == ref["n_meas"]
+    assert np.array_equal(z, ref["z"]), np.abs(z - ref["z"]).max()
+    assert H.relerr(Hs[:, :6], ref["H"]) < 1e-13
+    assert np.allclose(errors, ref["errors"], rtol=2e-6)
+
+
 def test_inverse_full_update_matches_oracle(ctx, livo2, orc, vs_inv):
     vs = vs_inv
     ocfg = orc.visual_cfg(vs, inverse=True)
