@@ -78,7 +78,7 @@ struct LidarKernelArgs {
 #endif
 
 // ---- once per scan: spatial ordering --------------------------------------------------------------------------------------
-// The residual pass gathers one 256-B plane record per point; with points in arbitrary order every lane of a wave touches
+// The residual pass gathers one plane record (a 128-B hot record + a 16-B side word) per point; with points in arbitrary order every lane of a wave touches
 // different L2 lines (measured: 12 of 24 us).  Points are therefore re-ordered once per scan along a 30-bit Morton curve of their
 // body-frame cell (cell = voxel_size): a rigid transform keeps neighbours neighbours, so a wave's lanes share planes and each
 // XCD (consecutive chunks, see k_lidar_residual) keeps one spatial slab in its private L2.  Only the summation order changes.
@@ -290,9 +290,9 @@ __device__ __forceinline__ SlotHead load_slot_head(const RootSlot *__restrict__ 
 __device__ __forceinline__ bool head_match(const SlotHead &s, const int32_t key[3]) { return s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]; }
 
 // Visit one root voxel (build_single_residual from layer 0).
-//  * plane root: the whole 256-B record in one batch, radius gate, 3-sigma gate (visit_plane_root).
+//  * plane root: the whole hot record + side word in one batch, radius gate, 3-sigma gate (visit_plane_root).
 //  * non-plane root: the depth-first list of descendant planes (layers <= max_layer) was flattened at upload into contiguous copies
-//    of their 256-B records (word [28] = plane index | layer); the block evaluates all such (point, candidate) pairs cooperatively
+//    of their hot records (side word: d_, radius_, plane index | layer); the block evaluates all such (point, candidate) pairs cooperatively
 //    (coop_plan / coop_run below), in depth-first order so that ties keep the first.
 struct RootRef { int32_t val, cand_begin, cand_count; };   // what a visit needs from a RootSlot
 
@@ -318,7 +318,7 @@ template <int BLOCK> __device__ __forceinline__ void touch_line(const void *p) {
 // plane evaluations while the other lanes idle, and the kernel ends with its slowest wave (measured tail: 14 us against a 2.6 us
 // median; the Morton order concentrates cluttered voxels in the same wave).  Instead every (point, candidate) pair of the BLOCK
 // becomes one work item: owners publish their point context and their pair range in LDS, each of the 256 threads evaluates one
-// pair per round (whole 256-B record copy from the candidate-ordered array: one round trip -> radius gate -> 3-sigma gate ->
+// pair per round (hot record + side word from the candidate-ordered arrays: one round trip -> radius gate -> 3-sigma gate ->
 // probability and measurement row), and the owner folds the results of its pairs IN LIST ORDER with the reference's strict '>'
 // (ties keep the first), which reproduces the serial recursion of build_single_residual exactly.
 template <int BLOCK> struct __attribute__((aligned(16))) CoopLds {
@@ -372,10 +372,10 @@ template <int BLOCK> __device__ __forceinline__ void coop_unpark_ctx(const CoopL
 }
 
 // One round of the evaluation half over the slots [base, base + PAIRS * 256) of the block's pair list; every thread evaluates PAIRS pairs.
-//  PAIRS == 1: the whole 256-B record in one batch of loads (one round trip), as everywhere else in this kernel.
+//  PAIRS == 1: hot record + side word in one batch of loads (one round trip), as everywhere else in this kernel.
 //  PAIRS == 2 (blocks with more than 256 pairs left — the slowest blocks of a launch): gate first.  Both pairs' gate words
-//    {normal_, center_, d_, radius_, meta} are fetched together (they sit in both 128-B lines of the record, so the whole record is
-//    on its way to this CU), the radius gate runs on both, and the covariance part is read — now an L1/L2 hit — only for a pair
+//    {normal_, center_} (the first 48 B of the hot record's line, so the whole record is on its way to this CU) and {d_, radius_, meta} (the side word) are
+//    fetched together, the radius gate runs on both, and the covariance part is read — now an L1/L2 hit — only for a pair
 //    that passed: one cold round trip and one set of barriers for up to 512 pairs instead of two of each.  Accepted pairs take
 //    result rows from an LDS counter; should more than 256 of them turn up the round reports failure and the caller repeats the
 //    slots with PAIRS == 1.

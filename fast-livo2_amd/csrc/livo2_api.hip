@@ -585,7 +585,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   }
   if (m->n_planes >= (1 << CAND_LAYER_SHIFT)) return fail(ctx, LIVO2_ERR_RANGE, "too many planes");
   // Device plane order: roots along a Morton curve of their voxel key, each root's planes in depth-first order.  The scan is
-  // Morton-sorted too, so neighbouring lanes gather neighbouring (often contiguous) 256-B records: measured on the C2 scene the
+  // Morton-sorted too, so neighbouring lanes gather neighbouring (often contiguous) records: measured on the C2 scene the
   // plane gather drops from ~random-access cost to within a few % of the fully contiguous floor.  The caller's plane numbering is
   // kept at the boundary through plane_internal / plane_orig.
   std::vector<int32_t> order(m->n_roots);
