@@ -133,6 +133,14 @@ class Context:
         self._chk(self.lib.livo2_map_tree_stats(self.h, abi.as_ptr(c, C.c_int32)))
         return dict(nodes=int(c[0]), points=int(c[1]), planes=int(c[2]), cand=int(c[3]), error=int(c[5]), touched=int(c[6]), roots=int(c[7]))
 
+    def map_tree_slide(self, position_last, sliding_thresh, half_map_size):
+        """VoxelMapManager::mapSliding on the device tree.  Returns (root voxels removed or -1 below the threshold, dict of what the free stacks hold)."""
+        pos = _f64(position_last).reshape(3)
+        removed = C.c_int32(0)
+        fc = np.zeros(3, np.int32)
+        self._chk(self.lib.livo2_map_tree_slide(self.h, abi.as_ptr(pos, C.c_double), float(sliding_thresh), int(half_map_size), C.byref(removed), abi.as_ptr(fc, C.c_int32)))
+        return int(removed.value), dict(nodes=int(fc[0]), planes=int(fc[1]), slabs=int(fc[2]))
+
     def map_tree_last_kernel_us(self):
         return float(self.lib.livo2_map_tree_last_kernel_us(self.h))
 

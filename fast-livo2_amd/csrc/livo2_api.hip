@@ -132,6 +132,7 @@ struct livo2_ctx {
   bool visual_fused = [] { const char *e = std::getenv("LIVO2_VISUAL_FUSED"); return e ? std::atoi(e) != 0 : false; }();   // LIVO2_VISUAL_FUSED=1: one k_visual_step launch per (level, iteration) instead of residual + solve (tools/vis_probe.py)
   bool tree_mode = false;
   MapTreeArgs mt{};
+  double mt_last_slide[3] = {0, 0, 0};      // VoxelMapManager::last_slide_position
   livo2_map_tree_cfg mt_cfg{};
   double *mt_in_pw = nullptr, *mt_in_var = nullptr; size_t mt_in_pw_cap = 0, mt_in_var_cap = 0;
   unsigned long long *mt_keys = nullptr, *mt_keys2 = nullptr; size_t mt_keys_cap = 0, mt_keys2_cap = 0;
@@ -713,7 +714,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   ctx->has_map = true;
   ctx->plane_tabs_fresh = false;
   if (ctx->tree_mode) {            // the snapshot replaces a device-resident tree
-    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); (void)e2;
+    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); e2 = hipFree(ctx->mt.free_nodes); e2 = hipFree(ctx->mt.free_planes); e2 = hipFree(ctx->mt.free_slabs); (void)e2;
     ctx->mt = MapTreeArgs{}; ctx->tree_mode = false;
   }
   return LIVO2_OK;
@@ -908,7 +909,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   hipError_t e;
   e = hipSuccess;
   free_map_arrays(ctx);
-  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); }
+  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); e = hipFree(ctx->mt.free_nodes); e = hipFree(ctx->mt.free_planes); e = hipFree(ctx->mt.free_slabs); }
   (void)e;
   ctx->has_map = false; ctx->tree_mode = false; ctx->mt = MapTreeArgs{};
   MapTreeArgs &m = ctx->mt;
@@ -929,7 +930,10 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   HIPCHK(hipMalloc((void **)&m.nodes, (size_t)m.cap_nodes * sizeof(DevNode)));
   HIPCHK(hipMalloc((void **)&m.pool_pw, (size_t)m.cap_points * 24));
   HIPCHK(hipMalloc((void **)&m.pool_var, (size_t)m.cap_points * 72));
-  HIPCHK(hipMalloc((void **)&m.counters, MTC_COUNT * 4));
+  HIPCHK(hipMalloc((void **)&m.counters, MTC_TOTAL * 4));
+  HIPCHK(hipMalloc((void **)&m.free_nodes, (size_t)m.cap_nodes * 4));
+  HIPCHK(hipMalloc((void **)&m.free_planes, (size_t)m.cap_planes * 4));
+  HIPCHK(hipMalloc((void **)&m.free_slabs, ((size_t)m.cap_points / MT_SLAB + 1) * 4));
   HIPCHK(hipMalloc((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
   HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
   {
@@ -937,7 +941,8 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
     for (auto &sl : empty) sl.val = -1;
     HIPCHK(hipMemcpy(ctx->d_slots, empty.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
   }
-  HIPCHK(hipMemset(m.counters, 0, MTC_COUNT * 4));
+  HIPCHK(hipMemset(m.counters, 0, MTC_TOTAL * 4));
+  ctx->mt_last_slide[0] = ctx->mt_last_slide[1] = ctx->mt_last_slide[2] = 0.0;          // VoxelMapManager::last_slide_position (voxel_map.h:209)
   HIPCHK(hipMemset(ctx->d_planes, 0, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
   HIPCHK(hipMemset(ctx->d_cand, 0, (size_t)m.cap_cand * PLANE_HOT_DOUBLES * 8));
   HIPCHK(hipMemset(ctx->d_cand_aux, 0, (size_t)m.cap_cand * sizeof(PlaneAux)));
@@ -1071,6 +1076,39 @@ int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts) {
   return LIVO2_OK;
 }
 double livo2_map_tree_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->mt_kernel_us : 0.0; }
+
+// VoxelMapManager::mapSliding (voxel_map.cpp:924-948) + clearMemOutOfMap (950-972) on the device tree
+int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sliding_thresh, int32_t half_map_size, int32_t *removed, int32_t *free_counts) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "no device map tree");
+  if (!position_last) return fail(ctx, LIVO2_ERR_INVALID, "position_last is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  const double dx = position_last[0] - ctx->mt_last_slide[0], dy = position_last[1] - ctx->mt_last_slide[1], dz = position_last[2] - ctx->mt_last_slide[2];
+  int32_t c[MTC_TOTAL];
+  bool slid = false;
+  if (std::sqrt((dx * dx + dy * dy) + dz * dz) < sliding_thresh) {          // (position_last_ - last_slide_position).norm() < sliding_thresh: nothing happens
+  } else {
+    slid = true;
+    for (int k = 0; k < 3; k++) ctx->mt_last_slide[k] = position_last[k];
+    int64_t loc[3];
+    for (int j = 0; j < 3; j++) {                               // float loc = position_last_[j] / max_voxel_size_; negatives one lower; truncation
+      float l = (float)(position_last[j] / ctx->mt_cfg.voxel_size);
+      if (l < 0) l = (float)((double)l - 1.0);
+      loc[j] = (int64_t)l;
+    }
+    // clearMemOutOfMap takes `const int &`: the int64 sums are narrowed at the call
+    SlideBox b = {(int)(loc[0] + half_map_size), (int)(loc[0] - half_map_size), (int)(loc[1] + half_map_size), (int)(loc[1] - half_map_size),
+                  (int)(loc[2] + half_map_size), (int)(loc[2] - half_map_size)};
+    HIPCHK(hipMemsetAsync(ctx->mt.counters + MTC_REMOVED, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_mt_slide, dim3((ctx->mt.mask + 256) / 256), dim3(256), 0, ctx->stream, ctx->mt, b);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (removed) *removed = slid ? c[MTC_REMOVED] : -1;
+  if (free_counts) { free_counts[0] = c[MTC_FREE_NODES]; free_counts[1] = c[MTC_FREE_PLANES]; free_counts[2] = c[MTC_FREE_SLABS]; }
+  return LIVO2_OK;
+}
 
 int livo2_map_tree_read_planes(livo2_ctx *ctx, const int32_t *rows, int32_t n, double *normal, double *center, double *plane_var, float *d, float *radius, int32_t *layer) {
   if (!ctx) return LIVO2_ERR_INVALID;

@@ -19,7 +19,9 @@
 #define MT_LPG 8                 // lanes per root voxel
 #define MT_SLAB 52               // points a node's temp_points_ region holds by default (max_points_num_ 50 + the point that trips the limit + 1)
 #define MT_STACK (LIVO2_MAX_LAYER + 2)
-enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8 };
+enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8,
+       // beyond what livo2_map_tree_stats reports: tops of the free stacks that mapSliding fills (k_mt_slide) and the allocators drain, root voxels it removed
+       MTC_FREE_NODES = 8, MTC_FREE_PLANES = 9, MTC_FREE_SLABS = 10, MTC_REMOVED = 11, MTC_TOTAL = 12 };
 enum { MTE_NODES = 1, MTE_POINTS = 2, MTE_PLANES = 4, MTE_CAND = 8, MTE_TABLE = 16, MTE_RANGE = 32, MTE_REGION = 64 };
 
 struct __attribute__((aligned(128))) DevNode {      // VoxelOctoTree (reference include/voxel_map.h:129-183), 128 B
@@ -40,6 +42,7 @@ struct MapTreeArgs {
   double *planes, *planes_hot, *cand; PlaneAux *plane_aux, *cand_aux; RootSlot *slots;     // master records [.][32]; hot words [.][16] by plane row / candidate position
   int32_t *counters;                                 // [MTC_COUNT]
   int32_t *dirty_list, *overflow_list;
+  int32_t *free_nodes, *free_planes, *free_slabs;    // stacks of node ids / plane rows / offsets of MT_SLAB-point regions released by mapSliding
   int32_t cap_nodes, cap_points, cap_planes, cap_cand, cap_overflow;
   uint32_t mask, seed1, seed2;
   double voxel_size_d; float voxel_size_f, planer_threshold;
@@ -134,6 +137,20 @@ __device__ __forceinline__ int mt_alloc(const MapTreeArgs &a, int which, int cou
   if (at + count > cap) { mt_error(a, errbit); return -1; }
   return at;
 }
+// what mapSliding released comes back first (the stacks are only pushed by k_mt_slide, never while an update runs: a pop is one atomic)
+__device__ __forceinline__ int mt_pop(const MapTreeArgs &a, int which, const int32_t *stack) {
+  if (a.counters[which] <= 0) return -1;
+  const int top = atomicSub(&a.counters[which], 1);
+  if (top > 0) return stack[top - 1];
+  atomicAdd(&a.counters[which], 1);
+  return -1;
+}
+__device__ __forceinline__ int mt_alloc_node(const MapTreeArgs &a) { const int id = mt_pop(a, MTC_FREE_NODES, a.free_nodes); return id >= 0 ? id : mt_alloc(a, MTC_NODES, 1, a.cap_nodes, MTE_NODES); }
+__device__ __forceinline__ int mt_alloc_plane(const MapTreeArgs &a) { const int r = mt_pop(a, MTC_FREE_PLANES, a.free_planes); return r >= 0 ? r : mt_alloc(a, MTC_PLANES, 1, a.cap_planes, MTE_PLANES); }
+__device__ __forceinline__ int mt_alloc_region(const MapTreeArgs &a, int cap) {
+  if (cap == MT_SLAB) { const int off = mt_pop(a, MTC_FREE_SLABS, a.free_slabs); if (off >= 0) return off; }
+  return mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS);
+}
 __device__ __forceinline__ void mt_init_node(DevNode &nd, const double c[3], float quarter, int layer, int root, int pts_off, int pts_cap) {
   nd.center[0] = c[0]; nd.center[1] = c[1]; nd.center[2] = c[2]; nd.quarter = quarter; nd.layer = layer;
   nd.init_octo = 0; nd.is_plane = 0; nd.update_enable = 1; nd.octo_state = 0;
@@ -159,8 +176,8 @@ __global__ void __launch_bounds__(256) k_mt_roots(MapTreeArgs a, const int32_t *
   }
   // new root voxel (voxel_map.cpp:574-583 / 630-637)
   const int cap = a.build ? max(MT_SLAB, e - b + 1) : MT_SLAB;
-  const int id = mt_alloc(a, MTC_NODES, 1, a.cap_nodes, MTE_NODES);
-  const int off = mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS);
+  const int id = mt_alloc_node(a);
+  const int off = mt_alloc_region(a, cap);
   if (id < 0 || off < 0) { a.seg_root[g] = -1; return; }
   atomicAdd(&a.counters[MTC_ROOTS], 1);
   DevNode nd;
@@ -231,7 +248,7 @@ struct MtGroup {
     plane_fit_core<MT_LPG>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);
     n.is_plane = R.is_plane ? 1 : 0;
     if (!R.is_plane) return;
-    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc(a, MTC_PLANES, 1, a.cap_planes, MTE_PLANES); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
+    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc_plane(a); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
     double *rec = a.planes + (size_t)n.plane * PLANE_REC_DOUBLES;
     const double nrm[3] = {R.vmin[0], R.vmin[1], R.vmin[2]};
     const float radius = (float)sqrt(R.ev_max);
@@ -261,7 +278,7 @@ struct MtGroup {
   // leaves_[leafnum] = new VoxelOctoTree(...) (voxel_map.cpp:179-186 / 255-262); returns its id (-1: pool exhausted)
   __device__ int new_leaf(const DevNode &n, int leafnum, int cap) {
     int id = -1, off = -1;
-    if (lane == 0) { id = mt_alloc(a, MTC_NODES, 1, a.cap_nodes, MTE_NODES); off = mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS); }
+    if (lane == 0) { id = mt_alloc_node(a); off = mt_alloc_region(a, cap); }
     id = grp_first(id); off = grp_first(off);
     if (id < 0 || off < 0) return -1;
     DevNode l;
@@ -449,6 +466,36 @@ __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t 
     }
   }
   if (lane == 0) { const int at = atomicAdd(&a.counters[MTC_DIRTY], 1); a.dirty_list[at] = root; }      // (one segment per root: no duplicates)
+}
+
+// ---- VoxelMapManager::mapSliding / clearMemOutOfMap (voxel_map.cpp:924-972): every root voxel whose key lies outside the box is deleted with its subtree ----------
+// One thread per bucket.  The bucket becomes empty (a 2-choice table needs no tombstone: a lookup reads both buckets of a key whatever else they hold); the
+// subtree's node ids, plane rows and MT_SLAB-point regions go onto the free stacks, from where the next updates take them before they touch fresh pool memory
+// (regions of another size — the build sizes them by count — and candidate ranges are not recycled).
+struct SlideBox { int32_t x_max, x_min, y_max, y_min, z_max, z_min; };
+__global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h > a.mask) return;
+  RootSlot *s = &a.slots[h];
+  if (s->val == -1) return;
+  const long long x = s->kx, y = s->ky, z = s->kz;
+  const bool should_remove = x > b.x_max || x < b.x_min || y > b.y_max || y < b.y_min || z > b.z_max || z < b.z_min;
+  if (!should_remove) return;
+  int st[8 * (LIVO2_MAX_LAYER + 1) + 1];
+  int sp = 0;
+  st[0] = s->pad;                                               // the root's node id
+  while (sp >= 0) {
+    const int id = st[sp--];
+    DevNode &nd = a.nodes[id];
+    for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
+    if (nd.plane >= 0) a.free_planes[atomicAdd(&a.counters[MTC_FREE_PLANES], 1)] = nd.plane;
+    if (nd.pts_cap == MT_SLAB) a.free_slabs[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off;
+    nd.root = -1; nd.layer = -1; nd.plane = -1; nd.is_plane = 0;          // (livo2_map_tree_export recognises roots by layer == 0 && root == id)
+    a.free_nodes[atomicAdd(&a.counters[MTC_FREE_NODES], 1)] = id;
+  }
+  s->val = -1;
+  atomicSub(&a.counters[MTC_ROOTS], 1);
+  atomicAdd(&a.counters[MTC_REMOVED], 1);
 }
 
 // rows of the plane table -> a packed array (livo2_map_tree_read_planes)

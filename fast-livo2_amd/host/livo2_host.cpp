@@ -277,6 +277,33 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
   last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
 }
 
+int VoxelMapManager::mapSliding() {
+  if (device_map_) {
+    int32_t removed = 0;
+    dev_.check(livo2_map_tree_slide(dev_.ctx(), position_last_.data(), config_setting_.sliding_thresh, config_setting_.half_map_size, &removed, nullptr));
+    return removed;
+  }
+  const double dx = position_last_[0] - last_slide_position[0], dy = position_last_[1] - last_slide_position[1], dz = position_last_[2] - last_slide_position[2];
+  if (std::sqrt((dx * dx + dy * dy) + dz * dz) < config_setting_.sliding_thresh) return -1;
+  last_slide_position = position_last_;
+  float loc_xyz[3];
+  for (int j = 0; j < 3; j++) {
+    loc_xyz[j] = position_last_[j] / config_setting_.max_voxel_size_;
+    if (loc_xyz[j] < 0) loc_xyz[j] -= 1.0;
+  }
+  const int h = config_setting_.half_map_size;
+  const int x_max = (int)((int64_t)loc_xyz[0] + h), x_min = (int)((int64_t)loc_xyz[0] - h), y_max = (int)((int64_t)loc_xyz[1] + h), y_min = (int)((int64_t)loc_xyz[1] - h);
+  const int z_max = (int)((int64_t)loc_xyz[2] + h), z_min = (int)((int64_t)loc_xyz[2] - h);
+  int n = 0;
+  for (auto it = voxel_map_.begin(); it != voxel_map_.end();) {
+    const VOXEL_LOCATION &loc = it->first;
+    if (loc.x > x_max || loc.x < x_min || loc.y > y_max || loc.y < y_min || loc.z > z_max || loc.z < z_min) { delete it->second; it = voxel_map_.erase(it); n++; }
+    else ++it;
+  }
+  if (n) map_dirty_ = true;                                    // the resident snapshot no longer matches voxel_map_
+  return n;
+}
+
 void VoxelMapManager::FitPlanes(const std::vector<VoxelOctoTree *> &voxels) {
   const int G = (int)voxels.size();
   if (G == 0) return;

@@ -111,6 +111,9 @@ struct VoxelMapConfig {                     // reference include/voxel_map.h:35-
   std::vector<int> layer_init_num_{5, 5, 5, 5, 5};
   int max_points_num_ = 50;
   double planner_threshold_ = 0.0025;       // local_map / min_eigen_value
+  bool map_sliding_en = false;              // local_map/map_sliding_en, half_map_size, sliding_thresh (reference src/voxel_map.cpp:50-52)
+  int half_map_size = 100;
+  double sliding_thresh = 8;
 };
 
 class Device {                              // one GPU + stream, shared by the two managers of a LIVMapper
@@ -135,6 +138,7 @@ public:
   V3D extT_{};
   StatesGroup state_;
   V3D position_last_{};
+  V3D last_slide_position{};                // reference include/voxel_map.h:209
   std::array<double, 4> geoQuat_{{0, 0, 0, 1}};   // geometry_msgs::Quaternion x, y, z, w (reference include/voxel_map.h:212, src/voxel_map.cpp:493)
   std::vector<M3D> cross_mat_list_, body_cov_list_;
   std::vector<pointWithVar> pv_list_;
@@ -176,6 +180,9 @@ public:
   bool device_map_ = false;
   int device_map_max_roots_ = 300000;
   void UpdateVoxelMapFromPosterior();
+  // reference src/voxel_map.cpp:924-972 (LIVMapper.cpp:430-433 calls it when config_setting_.map_sliding_en): root voxels outside the box around
+  // position_last_ are deleted — on the device tree with device_map_ (livo2_map_tree_slide), in voxel_map_ otherwise.  Returns the count, -1 below sliding_thresh.
+  int mapSliding();
   double last_map_kernel_us_ = 0;
 
 private:

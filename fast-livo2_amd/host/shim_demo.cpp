@@ -234,6 +234,8 @@ int main(int argc, char **argv) {
       vm.config_setting_.max_iterations_ = (int)lc[0]; vm.config_setting_.sigma_num_ = lc[2]; vm.config_setting_.dept_err_ = lc[3]; vm.config_setting_.beam_err_ = lc[4];
       for (int k = 0; k < 9; k++) vm.extR_[k] = lc[6 + k];
       for (int k = 0; k < 3; k++) vm.extT_[k] = lc[15 + k];
+      auto slide = rd<double>(dir, "seq_slide");                        // {sliding_thresh, half_map_size}: mapSliding after every UpdateVoxelMap (LIVMapper.cpp:430-433)
+      if (slide.size() >= 2) { vm.config_setting_.map_sliding_en = true; vm.config_setting_.sliding_thresh = slide[0]; vm.config_setting_.half_map_size = (int)slide[1]; }
       vm.BuildVoxelMap(points_from(rd<double>(dir, "seq_bld_pw"), rd<double>(dir, "seq_bld_var")));
       StatesGroup post = state_from(rd<double>(dir, "seq_state0"));
       std::vector<double> traj;
@@ -254,6 +256,7 @@ int main(int argc, char **argv) {
         post = vm.state_;
         if (vm.device_map_) {                                           // LIVMapper.cpp:413-424 in one device call
           vm.UpdateVoxelMapFromPosterior();
+          if (vm.config_setting_.map_sliding_en) { const int nrm = vm.mapSliding(); std::printf("seq frame %zu: mapSliding removed %d root voxels\n", f, nrm); }
           auto so = state_to(post);
           traj.insert(traj.end(), so.begin(), so.begin() + 12);
           std::printf("seq frame %zu: effct_feat_num_=%d, device map update %.0f us\n", f, vm.effct_feat_num_, vm.last_map_kernel_us_);
@@ -277,6 +280,7 @@ int main(int argc, char **argv) {
                                 post.cov[(3 + r) * 19 + 3 + c];
         }
         vm.UpdateVoxelMap(vm.pv_list_);
+        if (vm.config_setting_.map_sliding_en) { const int nrm = vm.mapSliding(); std::printf("seq frame %zu: mapSliding removed %d root voxels\n", f, nrm); }
         auto so = state_to(post);
         traj.insert(traj.end(), so.begin(), so.begin() + 12);            // rot9 pos3
         std::printf("seq frame %zu: effct_feat_num_=%d, %d plane fits in %d batches\n", f, vm.effct_feat_num_, vm.last_fit_count_, vm.last_fit_rounds_);

@@ -193,6 +193,13 @@ int livo2_map_tree_export(livo2_ctx *ctx, int64_t *root_key, int32_t *root_node,
 /* The VoxelPlane members a match carries into ptpl_list_ (PointToPlane: normal_, center_, plane_var_, d_, layer_; src/voxel_map.cpp:744-755) for `n` rows of the
  * device plane table (the values of livo2_lidar_points::match_plane / normal_plane while a tree is resident).  Any output may be NULL. */
 int livo2_map_tree_read_planes(livo2_ctx *ctx, const int32_t *rows, int32_t n, double *normal, double *center, double *plane_var, float *d, float *radius, int32_t *layer);
+/* VoxelMapManager::mapSliding + clearMemOutOfMap (src/voxel_map.cpp:924-972; local_map/map_sliding_en, sliding_thresh, half_map_size): when position_last
+ * (voxel_map.cpp:492: the posterior position) has moved at least sliding_thresh from the position of the last slide (initially the origin, voxel_map.h:209),
+ * every root voxel whose key lies outside [loc - half_map_size, loc + half_map_size] on some axis (loc = the float voxel index of position_last, one lower for
+ * negatives, truncated: voxel_map.cpp:936-940) is deleted with its subtree.  *removed = root voxels deleted, -1 when the threshold was not reached (nothing
+ * changes).  The node ids, plane rows and 52-point regions of the deleted subtrees are handed out again by later updates before fresh pool memory is
+ * (free_counts[3], may be NULL: what the three free stacks hold after the call); regions of other sizes and candidate ranges are not recycled. */
+int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sliding_thresh, int32_t half_map_size, int32_t *removed, int32_t *free_counts);
 /* kernel time of the last livo2_map_tree_update* call in microseconds (HIP events on the ctx stream; sort + segmentation + octree + emit) */
 double livo2_map_tree_last_kernel_us(const livo2_ctx *ctx);
 

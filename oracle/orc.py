@@ -120,6 +120,12 @@ class OracleMap:
         pw = np.ascontiguousarray(pw, np.float64); var = np.ascontiguousarray(var, np.float64)
         self.lib.orc_map_update(self.h, _p(pw, C.c_double), _p(var, C.c_double), C.c_int(len(pw)))
 
+    def slide(self, position_last, sliding_thresh, half_map_size):
+        """Restated mapSliding / clearMemOutOfMap (reference src/voxel_map.cpp:924-972): root voxels deleted, -1 below the threshold."""
+        pos = np.ascontiguousarray(position_last, np.float64).reshape(3)
+        self.lib.orc_map_slide.restype = C.c_int
+        return int(self.lib.orc_map_slide(self.h, _p(pos, C.c_double), C.c_double(sliding_thresh), C.c_int(half_map_size)))
+
     def export(self, voxel_size, max_layer):
         from scenarios.synth import FlatMap
         nr, nn, npl = C.c_int(), C.c_int(), C.c_int()

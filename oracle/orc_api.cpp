@@ -93,6 +93,9 @@ static void to_points(const double *pw, const double *var9, int n, std::vector<M
 void orc_map_build(void *m, const double *pw, const double *var9, int n) { std::vector<MapPoint> pts; to_points(pw, var9, n, pts); ((MapHandle *)m)->map.BuildVoxelMap(pts); }
 void orc_map_update(void *m, const double *pw, const double *var9, int n) { std::vector<MapPoint> pts; to_points(pw, var9, n, pts); ((MapHandle *)m)->map.UpdateVoxelMap(pts); }
 
+int orc_map_slide(void *m, const double *position_last, double sliding_thresh, int half_map_size) {
+  return ((MapHandle *)m)->map.mapSliding(vec3(position_last[0], position_last[1], position_last[2]), sliding_thresh, half_map_size);
+}
 void orc_map_counts(void *m, int *n_roots, int *n_nodes, int *n_planes) {
   MapHandle *h = (MapHandle *)m; int nn = 0, np = 0;
   for (auto &kv : h->map.voxel_map_) count_nodes(kv.second, nn, np);

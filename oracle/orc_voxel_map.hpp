@@ -274,6 +274,29 @@ struct VoxelMap {
     }
     for (auto iter = voxel_map_.begin(); iter != voxel_map_.end(); ++iter) iter->second->init_octo_tree();
   }
+  // src/voxel_map.cpp:924-948 (mapSliding) + 950-972 (clearMemOutOfMap).  Returns the number of root voxels deleted, -1 when the threshold is not reached.
+  V3 last_slide_position = vec3(0.0, 0.0, 0.0);                 // include/voxel_map.h:209
+  int mapSliding(const V3 &position_last_, double sliding_thresh, int half_map_size) {
+    if (norm(position_last_ - last_slide_position) < sliding_thresh) return -1;
+    last_slide_position = position_last_;
+    float loc_xyz[3];
+    for (int j = 0; j < 3; j++) {
+      loc_xyz[j] = position_last_[j] / config_setting_.max_voxel_size_;
+      if (loc_xyz[j] < 0) loc_xyz[j] -= 1.0;
+    }
+    // clearMemOutOfMap(const int &x_max, ...): the int64 sums are narrowed to int at the call
+    const int x_max = (int)((int64_t)loc_xyz[0] + half_map_size), x_min = (int)((int64_t)loc_xyz[0] - half_map_size);
+    const int y_max = (int)((int64_t)loc_xyz[1] + half_map_size), y_min = (int)((int64_t)loc_xyz[1] - half_map_size);
+    const int z_max = (int)((int64_t)loc_xyz[2] + half_map_size), z_min = (int)((int64_t)loc_xyz[2] - half_map_size);
+    int delete_voxel_cout = 0;
+    for (auto it = voxel_map_.begin(); it != voxel_map_.end();) {
+      const VOXEL_LOCATION &loc = it->first;
+      const bool should_remove = loc.x > x_max || loc.x < x_min || loc.y > y_max || loc.y < y_min || loc.z > z_max || loc.z < z_min;
+      if (should_remove) { delete it->second; it = voxel_map_.erase(it); delete_voxel_cout++; }
+      else ++it;
+    }
+    return delete_voxel_cout;
+  }
   // src/voxel_map.cpp:609-641
   void UpdateVoxelMap(const std::vector<MapPoint> &input_points) {
     float voxel_size = config_setting_.max_voxel_size_;

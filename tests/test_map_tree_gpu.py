@@ -51,6 +51,46 @@ def test_build_and_update_sequence_match_oracle(ctx, orc):
         n_prev = n
 
 
+def test_map_sliding_matches_oracle_and_recycles(ctx, orc):
+    """VoxelMapManager::mapSliding / clearMemOutOfMap (reference src/voxel_map.cpp:924-972) on the device tree: the same root voxels disappear as in the oracle,
+    a call below sliding_thresh changes nothing, and the next updates take the released nodes / plane rows / point regions before fresh pool memory while the
+    tree keeps matching the oracle's."""
+    c, cloud, R0, t0, P0, extR, extT = _scene(83)
+    _, (pw0, var0) = cloud(40000, R0, t0)
+    ctx.map_tree_create(c, max_roots=60000)
+    ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+    om = orc.OracleMap.build(pw0, var0.reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    st0 = ctx.map_tree_stats()
+    # below the threshold (last_slide_position starts at the origin): nothing happens on either side
+    assert ctx.map_tree_slide(t0 * 0.0 + 0.5, 8.0, 8)[0] == -1 and om.slide(t0 * 0.0 + 0.5, 8.0, 8) == -1
+    assert ctx.map_tree_stats() == st0
+    # a slide that keeps a box of +-8 voxels (4 m) around the sensor, far from the origin of last_slide_position: most of the map goes
+    pos = np.asarray(t0, float) + 40.0 * 0.0
+    thr = 0.5 * float(np.linalg.norm(pos))
+    assert thr > 0.1
+    removed, free = ctx.map_tree_slide(pos, thr, 8)
+    assert removed == om.slide(pos, thr, 8) and removed > 300
+    st1 = ctx.map_tree_stats()
+    assert st1["roots"] == st0["roots"] - removed and st1["nodes"] == st0["nodes"]            # the pools keep their high-water marks
+    assert free["nodes"] >= removed and free["planes"] > 100 and free["slabs"] >= 0
+    n_kept = _compare(_flat(ctx.map_tree_export(), c), om.export(c["voxel_size"], c["max_layer"]))
+    assert 0 < n_kept < st0["planes"]
+    # a second call from (almost) the same place: below the threshold again
+    assert ctx.map_tree_slide(pos + 0.01, thr, 8)[0] == -1 and om.slide(pos + 0.01, thr, 8) == -1
+    # new scans re-create voxels in the emptied space out of the released resources
+    for k in range(3):
+        Rk, tk = R0 @ synth.rot_from_rpy(0.0, 0.0, 0.15 * (k + 1)), t0 + np.array([0.2 * (k + 1), 0.1 * k, 0.0])
+        _, (pw, var) = cloud(12000, Rk, tk)
+        ctx.map_tree_update(pw, var.reshape(-1, 9))
+        om.update(pw, var.reshape(-1, 9))
+        _compare(_flat(ctx.map_tree_export(), c), om.export(c["voxel_size"], c["max_layer"]))
+    st2 = ctx.map_tree_stats()
+    _, free2 = ctx.map_tree_slide(pos + 0.02, thr, 8)                                          # (below the threshold: only reports the stacks)
+    assert st2["error"] == 0 and st2["roots"] > st1["roots"]
+    assert free2["nodes"] < free["nodes"] and free2["planes"] < free["planes"]                # recycled ...
+    assert st2["nodes"] - st1["nodes"] < (free["nodes"] - free2["nodes"])                      # ... so the pools grew by less than what the scans needed
+
+
 def test_tiny_inputs_and_thresholds(ctx, orc):
     """voxels below the init threshold, exactly at it, one point per call (the counters live across calls), an empty call"""
     c = dict(synth.AVIA["lio"])

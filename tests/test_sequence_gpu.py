@@ -29,13 +29,16 @@ def _glue(xyz, R, t, P, extR, extT, c):
     return pw, RE @ cb @ RE.T + X @ P[0:3, 0:3] @ X.transpose(0, 2, 1) + P[3:6, 3:6]
 
 
-@pytest.mark.parametrize("device_map", [False, True])
-def test_lio_sequence_matches_oracle(tmp_path, orc, device_map):
+@pytest.mark.parametrize("device_map,slide", [(False, False), (True, False), (True, True), (False, True)])
+def test_lio_sequence_matches_oracle(tmp_path, orc, device_map, slide):
     """device_map: the shim keeps the octree on the GPU (VoxelMapManager::device_map_, livo2_map_tree_*): BuildVoxelMap from the host points once, then per frame
     StateEstimation on the resident tree and UpdateVoxelMapFromPosterior — no host octree, no snapshot upload"""
     d = str(tmp_path)
     if device_map:
         np.array([1], np.int32).tofile(os.path.join(d, "seq_device_map.bin"))
+    SLIDE = (0.3, 14)                       # sliding_thresh [m], half_map_size [voxels]: a 7 m box that follows the sensor (mapSliding, LIVMapper.cpp:430-433)
+    if slide:
+        np.array(SLIDE, np.float64).tofile(os.path.join(d, "seq_slide.bin"))
     rng = np.random.default_rng(91)
     c = dict(synth.AVIA["lio"])
     extR, extT = synth.AVIA["extrinsic_R"], synth.AVIA["extrinsic_T"]
@@ -79,11 +82,14 @@ def test_lio_sequence_matches_oracle(tmp_path, orc, device_map):
         assert ref["n_iters"] >= 2
         pw, var = _glue(scans[k], post["R"], post["t"], post["P"], extR, extT, c)
         om.update(pw, var.reshape(-1, 9))
+        if slide:
+            removed = om.slide(post["t"], SLIDE[0], SLIDE[1])          # position_last_ = the posterior position (voxel_map.cpp:492)
+            assert removed != 0 or k > 0
         traj.append(np.concatenate([post["R"].ravel(), post["t"]]))
         assert np.linalg.norm(post["t"] - tt[k + 1]) < 0.02            # the filter tracks the true path
     got = np.fromfile(os.path.join(d, "seq_out_traj.bin")).reshape(K, 12)
     err = np.abs(got - np.array(traj)).max(axis=1)
     assert err[0] < 1e-8 and err.max() < 1e-7, err
     n_planes = _compare(_load(d, "seq_out_"), om.export(c["voxel_size"], c["max_layer"]), loose=True)
-    assert n_planes > 1000
+    assert n_planes > (300 if slide else 1000)
     print(r.stdout)
