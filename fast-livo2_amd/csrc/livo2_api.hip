@@ -714,7 +714,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   ctx->has_map = true;
   ctx->plane_tabs_fresh = false;
   if (ctx->tree_mode) {            // the snapshot replaces a device-resident tree
-    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); e2 = hipFree(ctx->mt.free_nodes); e2 = hipFree(ctx->mt.free_planes); e2 = hipFree(ctx->mt.free_slabs); (void)e2;
+    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); e2 = hipFree(ctx->mt.free_nodes); e2 = hipFree(ctx->mt.free_planes); e2 = hipFree(ctx->mt.free_slabs); e2 = hipFree(ctx->mt.pending_slabs); (void)e2;
     ctx->mt = MapTreeArgs{}; ctx->tree_mode = false;
   }
   return LIVO2_OK;
@@ -909,7 +909,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   hipError_t e;
   e = hipSuccess;
   free_map_arrays(ctx);
-  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); e = hipFree(ctx->mt.free_nodes); e = hipFree(ctx->mt.free_planes); e = hipFree(ctx->mt.free_slabs); }
+  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); e = hipFree(ctx->mt.free_nodes); e = hipFree(ctx->mt.free_planes); e = hipFree(ctx->mt.free_slabs); e = hipFree(ctx->mt.pending_slabs); }
   (void)e;
   ctx->has_map = false; ctx->tree_mode = false; ctx->mt = MapTreeArgs{};
   MapTreeArgs &m = ctx->mt;
@@ -934,6 +934,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   HIPCHK(hipMalloc((void **)&m.free_nodes, (size_t)m.cap_nodes * 4));
   HIPCHK(hipMalloc((void **)&m.free_planes, (size_t)m.cap_planes * 4));
   HIPCHK(hipMalloc((void **)&m.free_slabs, ((size_t)m.cap_points / MT_SLAB + 1) * 4));
+  HIPCHK(hipMalloc((void **)&m.pending_slabs, ((size_t)m.cap_points / MT_SLAB + 1) * 4));
   HIPCHK(hipMalloc((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
   HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
   {
@@ -978,6 +979,7 @@ int map_tree_run(livo2_ctx *ctx, int n, int build) {
   if ((rc = ensure(ctx, ctx->mt_seg_begin, ctx->mt_seg_begin_cap, (size_t)n + 2))) return rc;
   if ((rc = ensure(ctx, ctx->mt_seg_root, ctx->mt_seg_root_cap, (size_t)n + 1))) return rc;
   HIPCHK(hipMemsetAsync(m.counters + MTC_OVERFLOW, 0, 3 * 4, ctx->stream));          // overflow, error, dirty
+  hipLaunchKernelGGL(k_mt_merge_free, dim3(1), dim3(256), 0, ctx->stream, m);          // what the previous update's frozen nodes released
   HIPCHK(hipMemsetAsync(ctx->mt_nseg, 0, 4, ctx->stream));
   if (n == 0) return LIVO2_OK;
   const int nb = (n + 255) / 256;
@@ -1100,6 +1102,7 @@ int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sli
     SlideBox b = {(int)(loc[0] + half_map_size), (int)(loc[0] - half_map_size), (int)(loc[1] + half_map_size), (int)(loc[1] - half_map_size),
                   (int)(loc[2] + half_map_size), (int)(loc[2] - half_map_size)};
     HIPCHK(hipMemsetAsync(ctx->mt.counters + MTC_REMOVED, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_mt_merge_free, dim3(1), dim3(256), 0, ctx->stream, ctx->mt);
     hipLaunchKernelGGL(k_mt_slide, dim3((ctx->mt.mask + 256) / 256), dim3(256), 0, ctx->stream, ctx->mt, b);
     HIPCHK(hipGetLastError());
   }

@@ -21,7 +21,7 @@
 #define MT_STACK (LIVO2_MAX_LAYER + 2)
 enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8,
        // beyond what livo2_map_tree_stats reports: tops of the free stacks that mapSliding fills (k_mt_slide) and the allocators drain, root voxels it removed
-       MTC_FREE_NODES = 8, MTC_FREE_PLANES = 9, MTC_FREE_SLABS = 10, MTC_REMOVED = 11, MTC_TOTAL = 12 };
+       MTC_FREE_NODES = 8, MTC_FREE_PLANES = 9, MTC_FREE_SLABS = 10, MTC_REMOVED = 11, MTC_PENDING_SLABS = 12, MTC_TOTAL = 13 };
 enum { MTE_NODES = 1, MTE_POINTS = 2, MTE_PLANES = 4, MTE_CAND = 8, MTE_TABLE = 16, MTE_RANGE = 32, MTE_REGION = 64 };
 
 struct __attribute__((aligned(128))) DevNode {      // VoxelOctoTree (reference include/voxel_map.h:129-183), 128 B
@@ -43,6 +43,7 @@ struct MapTreeArgs {
   int32_t *counters;                                 // [MTC_COUNT]
   int32_t *dirty_list, *overflow_list;
   int32_t *free_nodes, *free_planes, *free_slabs;    // stacks of node ids / plane rows / offsets of MT_SLAB-point regions released by mapSliding
+  int32_t *pending_slabs;                            // regions released DURING an update (frozen nodes): joined to free_slabs before the next update starts
   int32_t cap_nodes, cap_points, cap_planes, cap_cand, cap_overflow;
   uint32_t mask, seed1, seed2;
   double voxel_size_d; float voxel_size_f, planer_threshold;
@@ -240,7 +241,15 @@ struct MtGroup {
     return true;
   }
   // std::vector<pointWithVar>().swap(temp_points_); update_enable_ = false
-  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; }
+  // (a frozen node never stores a point again: its MT_SLAB region goes back to the pool — through the pending list, because the free stack is being
+  //  popped while this update runs)
+  __device__ void freeze(DevNode &n) {
+    n.update_enable = 0; n.n_temp = 0;
+    if (n.pts_cap == MT_SLAB) {
+      if (lane == 0) a.pending_slabs[atomicAdd(&a.counters[MTC_PENDING_SLABS], 1)] = n.pts_off;
+      n.pts_cap = 0; n.pts_off = 0;
+    }
+  }
   // init_plane(temp_points_, plane_ptr_): fit + the packed record the residual kernel reads
   __device__ void fit(DevNode &n) {
     wave_sync();                                              // the pushes of this group are visible to its 8 lanes
@@ -466,6 +475,14 @@ __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t 
     }
   }
   if (lane == 0) { const int at = atomicAdd(&a.counters[MTC_DIRTY], 1); a.dirty_list[at] = root; }      // (one segment per root: no duplicates)
+}
+
+// regions released by the previous update (frozen nodes) become allocatable: runs alone, before anything pops
+__global__ void __launch_bounds__(256) k_mt_merge_free(MapTreeArgs a) {
+  const int n = a.counters[MTC_PENDING_SLABS], base = a.counters[MTC_FREE_SLABS];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) a.free_slabs[base + i] = a.pending_slabs[i];
+  __syncthreads();
+  if (threadIdx.x == 0) { a.counters[MTC_FREE_SLABS] = base + n; a.counters[MTC_PENDING_SLABS] = 0; }
 }
 
 // ---- VoxelMapManager::mapSliding / clearMemOutOfMap (voxel_map.cpp:924-972): every root voxel whose key lies outside the box is deleted with its subtree ----------

@@ -111,6 +111,8 @@ def test_tiny_inputs_and_thresholds(ctx, orc):
     dev = ctx.map_tree_export()
     assert len(dev["root_node"]) == 1
     assert dev["node_plane"][dev["root_node"][0]] >= 0 and dev["node_temp"][dev["root_node"][0]] == 0          # a plane, frozen: temp_points_ released
+    _, free = ctx.map_tree_slide(np.zeros(3), 1e9, 1)                                      # (below the threshold: only reports the free stacks)
+    assert free["slabs"] == 1                                                             # ... and its 52-point region is back in the pool
 
 
 def test_lidar_update_reads_the_device_tree(ctx, livo2, orc):
