@@ -133,6 +133,7 @@ struct livo2_ctx {
   bool tree_mode = false;
   MapTreeArgs mt{};
   double mt_last_slide[3] = {0, 0, 0};      // VoxelMapManager::last_slide_position
+  bool mt_pool_pressure = false;            // some pool of the device tree is more than half used (or LIVO2_MAP_RECYCLE=1): updates run the recycling kernels
   livo2_map_tree_cfg mt_cfg{};
   double *mt_in_pw = nullptr, *mt_in_var = nullptr; size_t mt_in_pw_cap = 0, mt_in_var_cap = 0;
   unsigned long long *mt_keys = nullptr, *mt_keys2 = nullptr; size_t mt_keys_cap = 0, mt_keys2_cap = 0;
@@ -714,7 +715,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   ctx->has_map = true;
   ctx->plane_tabs_fresh = false;
   if (ctx->tree_mode) {            // the snapshot replaces a device-resident tree
-    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); e2 = hipFree(ctx->mt.free_nodes); e2 = hipFree(ctx->mt.free_planes); e2 = hipFree(ctx->mt.free_slabs); e2 = hipFree(ctx->mt.pending_slabs); (void)e2;
+    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); (void)e2;
     ctx->mt = MapTreeArgs{}; ctx->tree_mode = false;
   }
   return LIVO2_OK;
@@ -909,7 +910,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   hipError_t e;
   e = hipSuccess;
   free_map_arrays(ctx);
-  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); e = hipFree(ctx->mt.free_nodes); e = hipFree(ctx->mt.free_planes); e = hipFree(ctx->mt.free_slabs); e = hipFree(ctx->mt.pending_slabs); }
+  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); }
   (void)e;
   ctx->has_map = false; ctx->tree_mode = false; ctx->mt = MapTreeArgs{};
   MapTreeArgs &m = ctx->mt;
@@ -930,11 +931,8 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   HIPCHK(hipMalloc((void **)&m.nodes, (size_t)m.cap_nodes * sizeof(DevNode)));
   HIPCHK(hipMalloc((void **)&m.pool_pw, (size_t)m.cap_points * 24));
   HIPCHK(hipMalloc((void **)&m.pool_var, (size_t)m.cap_points * 72));
-  HIPCHK(hipMalloc((void **)&m.counters, MTC_TOTAL * 4));
-  HIPCHK(hipMalloc((void **)&m.free_nodes, (size_t)m.cap_nodes * 4));
-  HIPCHK(hipMalloc((void **)&m.free_planes, (size_t)m.cap_planes * 4));
-  HIPCHK(hipMalloc((void **)&m.free_slabs, ((size_t)m.cap_points / MT_SLAB + 1) * 4));
-  HIPCHK(hipMalloc((void **)&m.pending_slabs, ((size_t)m.cap_points / MT_SLAB + 1) * 4));
+  // counters + the free stacks behind them (map_tree_kernels.hpp: mt_free_nodes ... mt_pending_slabs)
+  HIPCHK(hipMalloc((void **)&m.counters, ((size_t)MTC_TOTAL + m.cap_nodes + m.cap_planes + ((size_t)m.cap_points / MT_SLAB + 1)) * 4));
   HIPCHK(hipMalloc((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
   HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
   {
@@ -979,7 +977,6 @@ int map_tree_run(livo2_ctx *ctx, int n, int build) {
   if ((rc = ensure(ctx, ctx->mt_seg_begin, ctx->mt_seg_begin_cap, (size_t)n + 2))) return rc;
   if ((rc = ensure(ctx, ctx->mt_seg_root, ctx->mt_seg_root_cap, (size_t)n + 1))) return rc;
   HIPCHK(hipMemsetAsync(m.counters + MTC_OVERFLOW, 0, 3 * 4, ctx->stream));          // overflow, error, dirty
-  hipLaunchKernelGGL(k_mt_merge_free, dim3(1), dim3(256), 0, ctx->stream, m);          // what the previous update's frozen nodes released
   HIPCHK(hipMemsetAsync(ctx->mt_nseg, 0, 4, ctx->stream));
   if (n == 0) return LIVO2_OK;
   const int nb = (n + 255) / 256;
@@ -1002,17 +999,29 @@ int map_tree_run(livo2_ctx *ctx, int n, int build) {
   a.in_pw = ctx->mt_in_pw; a.in_var = ctx->mt_in_var; a.order = ctx->mt_order; a.skeys = ctx->mt_keys2; a.seg_head = ctx->mt_head; a.seg_slot = ctx->mt_slot;
   a.seg_begin = ctx->mt_seg_begin; a.seg_root = ctx->mt_seg_root; a.n = n; a.build = build ? 1 : 0;
   // the segment count stays on the device: grids are sized for the worst case (one segment per point), surplus threads leave at once
-  hipLaunchKernelGGL(k_mt_roots, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  // recycling variants only when there is something to recycle and a pool is more than half used (the plain kernels are ~40 % faster: map_tree_kernels.hpp)
+  const bool recycle = m.may_pop != 0 && ctx->mt_pool_pressure;
+  if (recycle) hipLaunchKernelGGL(k_mt_roots<true>, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  else hipLaunchKernelGGL(k_mt_roots<false>, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
   hipLaunchKernelGGL(k_mt_overflow, dim3(1), dim3(64), 0, ctx->stream, a);
-  hipLaunchKernelGGL(k_mt_update, dim3((n * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  if (recycle) hipLaunchKernelGGL(k_mt_update<true>, dim3((n * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  else hipLaunchKernelGGL(k_mt_update<false>, dim3((n * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a, ctx->mt_nseg);
+  hipLaunchKernelGGL(k_mt_collect, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);        // regions of the nodes that froze in this update -> free stack (at most n roots are dirty)
   hipLaunchKernelGGL(k_mt_emit, dim3((n * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a);
   HIPCHK(hipGetLastError());
   return LIVO2_OK;
 }
 int map_tree_finish(livo2_ctx *ctx) {
-  int32_t c[MTC_COUNT];
+  int32_t c[MTC_COUNT], fr[5];
   HIPCHK(hipMemcpyAsync(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(fr, ctx->mt.counters + MTC_FREE_NODES, sizeof(fr), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  // what the next update may pop: the stacks as they are + the regions this update's frozen nodes released (joined to the stack before that update starts)
+  ctx->mt.may_pop = (fr[0] > 0 ? 1 : 0) | (fr[1] > 0 ? 2 : 0) | (fr[2] > 0 ? 4 : 0);
+  {
+    static const bool always = [] { const char *e = std::getenv("LIVO2_MAP_RECYCLE"); return e && std::atoi(e) != 0; }();
+    ctx->mt_pool_pressure = always || 2 * (long long)c[MTC_NODES] > ctx->mt.cap_nodes || 2 * (long long)c[MTC_POINTS] > ctx->mt.cap_points || 2 * (long long)c[MTC_PLANES] > ctx->mt.cap_planes;
+  }
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->mt_kernel_us = 1e3 * ms;
@@ -1086,7 +1095,7 @@ int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sli
   if (!position_last) return fail(ctx, LIVO2_ERR_INVALID, "position_last is NULL");
   HIPCHK(hipSetDevice(ctx->device));
   const double dx = position_last[0] - ctx->mt_last_slide[0], dy = position_last[1] - ctx->mt_last_slide[1], dz = position_last[2] - ctx->mt_last_slide[2];
-  int32_t c[MTC_TOTAL];
+  int32_t c[5];                                                  // free nodes / planes / slabs, removed, pending
   bool slid = false;
   if (std::sqrt((dx * dx + dy * dy) + dz * dz) < sliding_thresh) {          // (position_last_ - last_slide_position).norm() < sliding_thresh: nothing happens
   } else {
@@ -1102,14 +1111,14 @@ int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sli
     SlideBox b = {(int)(loc[0] + half_map_size), (int)(loc[0] - half_map_size), (int)(loc[1] + half_map_size), (int)(loc[1] - half_map_size),
                   (int)(loc[2] + half_map_size), (int)(loc[2] - half_map_size)};
     HIPCHK(hipMemsetAsync(ctx->mt.counters + MTC_REMOVED, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_mt_merge_free, dim3(1), dim3(256), 0, ctx->stream, ctx->mt);
     hipLaunchKernelGGL(k_mt_slide, dim3((ctx->mt.mask + 256) / 256), dim3(256), 0, ctx->stream, ctx->mt, b);
     HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipMemcpyAsync(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(c, ctx->mt.counters + MTC_FREE_NODES, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (removed) *removed = slid ? c[MTC_REMOVED] : -1;
-  if (free_counts) { free_counts[0] = c[MTC_FREE_NODES]; free_counts[1] = c[MTC_FREE_PLANES]; free_counts[2] = c[MTC_FREE_SLABS]; }
+  ctx->mt.may_pop = (c[0] > 0 ? 1 : 0) | (c[1] > 0 ? 2 : 0) | (c[2] > 0 ? 4 : 0);
+  if (removed) *removed = slid ? c[3] : -1;
+  if (free_counts) { free_counts[0] = c[0]; free_counts[1] = c[1]; free_counts[2] = c[2]; }
   return LIVO2_OK;
 }
 

@@ -21,7 +21,9 @@
 #define MT_STACK (LIVO2_MAX_LAYER + 2)
 enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8,
        // beyond what livo2_map_tree_stats reports: tops of the free stacks that mapSliding fills (k_mt_slide) and the allocators drain, root voxels it removed
-       MTC_FREE_NODES = 8, MTC_FREE_PLANES = 9, MTC_FREE_SLABS = 10, MTC_REMOVED = 11, MTC_PENDING_SLABS = 12, MTC_TOTAL = 13 };
+       // (4 KB away from the bump counters: those take an atomic per allocation from thousands of groups, and any access that shares their memory channel queues
+       //  behind them — three loads of a NEIGHBOURING line per new root made k_mt_roots 25x slower)
+       MTC_FREE_NODES = 1024, MTC_FREE_PLANES = 1025, MTC_FREE_SLABS = 1026, MTC_REMOVED = 1027, MTC_PENDING_SLABS = 1028, MTC_TOTAL = 1056 };
 enum { MTE_NODES = 1, MTE_POINTS = 2, MTE_PLANES = 4, MTE_CAND = 8, MTE_TABLE = 16, MTE_RANGE = 32, MTE_REGION = 64 };
 
 struct __attribute__((aligned(128))) DevNode {      // VoxelOctoTree (reference include/voxel_map.h:129-183), 128 B
@@ -42,8 +44,6 @@ struct MapTreeArgs {
   double *planes, *planes_hot, *cand; PlaneAux *plane_aux, *cand_aux; RootSlot *slots;     // master records [.][32]; hot words [.][16] by plane row / candidate position
   int32_t *counters;                                 // [MTC_COUNT]
   int32_t *dirty_list, *overflow_list;
-  int32_t *free_nodes, *free_planes, *free_slabs;    // stacks of node ids / plane rows / offsets of MT_SLAB-point regions released by mapSliding
-  int32_t *pending_slabs;                            // regions released DURING an update (frozen nodes): joined to free_slabs before the next update starts
   int32_t cap_nodes, cap_points, cap_planes, cap_cand, cap_overflow;
   uint32_t mask, seed1, seed2;
   double voxel_size_d; float voxel_size_f, planer_threshold;
@@ -56,7 +56,15 @@ struct MapTreeArgs {
   const int32_t *seg_head, *seg_slot;                // [n] head flags / exclusive scan (segment number at heads)
   int32_t *seg_begin, *seg_root;                     // [n_seg + 1], [n_seg]
   int32_t n, build;
+  int32_t may_pop;                                   // host-side note: bit 0 / 1 / 2 = the free stack of node ids / plane rows / 52-point regions is non-empty
 };
+
+// The free stacks live behind the counters in the SAME allocation — [MTC_TOTAL counters][node ids: cap_nodes][plane rows: cap_planes][regions: cap_points /
+// MT_SLAB + 1] — so that they need no kernel arguments of their own: k_mt_update sits at the register limit, and four more pointers
+// in its argument block cost a 70 % longer build (measured).
+__device__ __forceinline__ int32_t *mt_free_nodes(const MapTreeArgs &a) { return a.counters + MTC_TOTAL; }
+__device__ __forceinline__ int32_t *mt_free_planes(const MapTreeArgs &a) { return a.counters + MTC_TOTAL + a.cap_nodes; }
+__device__ __forceinline__ int32_t *mt_free_slabs(const MapTreeArgs &a) { return a.counters + MTC_TOTAL + a.cap_nodes + a.cap_planes; }
 
 __device__ __forceinline__ int grp_first(int v) { return __shfl(v, (threadIdx.x & 63) & ~(MT_LPG - 1), 64); }
 __device__ __forceinline__ void mt_error(const MapTreeArgs &a, int bit) { atomicOr(&a.counters[MTC_ERROR], bit); }
@@ -146,10 +154,17 @@ __device__ __forceinline__ int mt_pop(const MapTreeArgs &a, int which, const int
   atomicAdd(&a.counters[which], 1);
   return -1;
 }
-__device__ __forceinline__ int mt_alloc_node(const MapTreeArgs &a) { const int id = mt_pop(a, MTC_FREE_NODES, a.free_nodes); return id >= 0 ? id : mt_alloc(a, MTC_NODES, 1, a.cap_nodes, MTE_NODES); }
-__device__ __forceinline__ int mt_alloc_plane(const MapTreeArgs &a) { const int r = mt_pop(a, MTC_FREE_PLANES, a.free_planes); return r >= 0 ? r : mt_alloc(a, MTC_PLANES, 1, a.cap_planes, MTE_PLANES); }
-__device__ __forceinline__ int mt_alloc_region(const MapTreeArgs &a, int cap) {
-  if (cap == MT_SLAB) { const int off = mt_pop(a, MTC_FREE_SLABS, a.free_slabs); if (off >= 0) return off; }
+// Recycling is a property of the LAUNCH (template parameter): k_mt_update sits at the register limit and any code on its allocation paths — a flag test, a call,
+// an inlined pop — costs it ~60 % (measured: 14.5 -> 23-27 ms for a 1.2 M-point build), so the plain kernels allocate by bumping only and the host starts the
+// <true> variants when the free stacks hold something AND a pool is more than half used (livo2_api.hip, map_tree_run).
+template <bool RECYCLE> __device__ __forceinline__ int mt_take(const MapTreeArgs &a, int which_free, const int32_t *stack, int which, int count, int cap, int errbit) {
+  if (RECYCLE) { const int id = mt_pop(a, which_free, stack); if (id >= 0) return id; }
+  return mt_alloc(a, which, count, cap, errbit);
+}
+template <bool RECYCLE> __device__ __forceinline__ int mt_alloc_node(const MapTreeArgs &a) { return mt_take<RECYCLE>(a, MTC_FREE_NODES, mt_free_nodes(a), MTC_NODES, 1, a.cap_nodes, MTE_NODES); }
+template <bool RECYCLE> __device__ __forceinline__ int mt_alloc_plane(const MapTreeArgs &a) { return mt_take<RECYCLE>(a, MTC_FREE_PLANES, mt_free_planes(a), MTC_PLANES, 1, a.cap_planes, MTE_PLANES); }
+template <bool RECYCLE> __device__ __forceinline__ int mt_alloc_region(const MapTreeArgs &a, int cap) {
+  if (RECYCLE && cap == MT_SLAB) { const int off = mt_pop(a, MTC_FREE_SLABS, mt_free_slabs(a)); if (off >= 0) return off; }
   return mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS);
 }
 __device__ __forceinline__ void mt_init_node(DevNode &nd, const double c[3], float quarter, int layer, int root, int pts_off, int pts_cap) {
@@ -163,7 +178,7 @@ __device__ __forceinline__ void mt_init_node(DevNode &nd, const double c[3], flo
 }
 
 // ---- roots: lookup or creation --------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_mt_roots(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
+template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_roots(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= *n_seg_p) return;
   const int b = a.seg_begin[g], e = a.seg_begin[g + 1];
@@ -177,8 +192,8 @@ __global__ void __launch_bounds__(256) k_mt_roots(MapTreeArgs a, const int32_t *
   }
   // new root voxel (voxel_map.cpp:574-583 / 630-637)
   const int cap = a.build ? max(MT_SLAB, e - b + 1) : MT_SLAB;
-  const int id = mt_alloc_node(a);
-  const int off = mt_alloc_region(a, cap);
+  const int id = mt_alloc_node<RECYCLE>(a);
+  const int off = mt_alloc_region<RECYCLE>(a, cap);
   if (id < 0 || off < 0) { a.seg_root[g] = -1; return; }
   atomicAdd(&a.counters[MTC_ROOTS], 1);
   DevNode nd;
@@ -227,7 +242,7 @@ __global__ void __launch_bounds__(64) k_mt_overflow(MapTreeArgs a) {
 }
 
 // ---- the octree state machine, one group of MT_LPG lanes per touched root --------------------------------------------------------------
-struct MtGroup {
+template <bool RECYCLE> struct MtGroup {
   const MapTreeArgs &a; int lane;
   __device__ MtGroup(const MapTreeArgs &a_, int l) : a(a_), lane(l) {}
 
@@ -241,15 +256,9 @@ struct MtGroup {
     return true;
   }
   // std::vector<pointWithVar>().swap(temp_points_); update_enable_ = false
-  // (a frozen node never stores a point again: its MT_SLAB region goes back to the pool — through the pending list, because the free stack is being
-  //  popped while this update runs)
-  __device__ void freeze(DevNode &n) {
-    n.update_enable = 0; n.n_temp = 0;
-    if (n.pts_cap == MT_SLAB) {
-      if (lane == 0) a.pending_slabs[atomicAdd(&a.counters[MTC_PENDING_SLABS], 1)] = n.pts_off;
-      n.pts_cap = 0; n.pts_off = 0;
-    }
-  }
+  // A frozen node never stores a point again: its MT_SLAB region goes back to the pool.  Here it is only MARKED (pts_cap = -MT_SLAB): an atomic per freeze on one
+  // counter would serialise behind the allocators' (a build freezes most of its planes); k_mt_collect gathers the marks of the touched roots after the update.
+  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; if (n.pts_cap == MT_SLAB) n.pts_cap = -MT_SLAB; }
   // init_plane(temp_points_, plane_ptr_): fit + the packed record the residual kernel reads
   __device__ void fit(DevNode &n) {
     wave_sync();                                              // the pushes of this group are visible to its 8 lanes
@@ -257,7 +266,7 @@ struct MtGroup {
     plane_fit_core<MT_LPG>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);
     n.is_plane = R.is_plane ? 1 : 0;
     if (!R.is_plane) return;
-    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc_plane(a); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
+    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc_plane<RECYCLE>(a); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
     double *rec = a.planes + (size_t)n.plane * PLANE_REC_DOUBLES;
     const double nrm[3] = {R.vmin[0], R.vmin[1], R.vmin[2]};
     const float radius = (float)sqrt(R.ev_max);
@@ -287,7 +296,7 @@ struct MtGroup {
   // leaves_[leafnum] = new VoxelOctoTree(...) (voxel_map.cpp:179-186 / 255-262); returns its id (-1: pool exhausted)
   __device__ int new_leaf(const DevNode &n, int leafnum, int cap) {
     int id = -1, off = -1;
-    if (lane == 0) { id = mt_alloc_node(a); off = mt_alloc_region(a, cap); }
+    if (lane == 0) { id = mt_alloc_node<RECYCLE>(a); off = mt_alloc_region<RECYCLE>(a, cap); }
     id = grp_first(id); off = grp_first(off);
     if (id < 0 || off < 0) return -1;
     DevNode l;
@@ -442,13 +451,13 @@ struct MtGroup {
   }
 };
 
-__global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
+template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) / MT_LPG, lane = threadIdx.x & (MT_LPG - 1);
   if (g >= *n_seg_p) return;
   const int root = a.seg_root[g];
   if (root < 0) return;
   const int b = a.seg_begin[g], e = a.seg_begin[g + 1];
-  MtGroup G(a, lane);
+  MtGroup<RECYCLE> G(a, lane);
   if (a.build) {                                              // BuildVoxelMap: every point of the voxel first, then init_octo_tree (voxel_map.cpp:568-590)
     DevNode n = a.nodes[root];
     for (int k = b; k < e; k++) {
@@ -477,12 +486,31 @@ __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t 
   if (lane == 0) { const int at = atomicAdd(&a.counters[MTC_DIRTY], 1); a.dirty_list[at] = root; }      // (one segment per root: no duplicates)
 }
 
-// regions released by the previous update (frozen nodes) become allocatable: runs alone, before anything pops
-__global__ void __launch_bounds__(256) k_mt_merge_free(MapTreeArgs a) {
-  const int n = a.counters[MTC_PENDING_SLABS], base = a.counters[MTC_FREE_SLABS];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) a.free_slabs[base + i] = a.pending_slabs[i];
-  __syncthreads();
-  if (threadIdx.x == 0) { a.counters[MTC_FREE_SLABS] = base + n; a.counters[MTC_PENDING_SLABS] = 0; }
+// The regions of the nodes that froze during the update just finished (marked pts_cap = -MT_SLAB) go onto the free stack: one thread per touched root walks its
+// subtree; the pushes of a wave share one atomic.  Runs after k_mt_update / before anything pops.
+__global__ void __launch_bounds__(256) k_mt_collect(MapTreeArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_dirty = a.counters[MTC_DIRTY];
+  int st[8 * (LIVO2_MAX_LAYER + 1) + 1];
+  int sp = -1;
+  if (t < n_dirty) { sp = 0; st[0] = a.dirty_list[t]; }
+  while (__any(sp >= 0)) {
+    int off = -1;
+    if (sp >= 0) {
+      const int id = st[sp--];
+      DevNode &nd = a.nodes[id];
+      for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
+      if (nd.pts_cap == -MT_SLAB) { off = nd.pts_off; nd.pts_cap = 0; nd.pts_off = 0; }
+    }
+    const unsigned long long m = __ballot(off >= 0);
+    if (m) {
+      const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&a.counters[MTC_FREE_SLABS], __popcll(m));
+      base = __shfl(base, leader, 64);
+      if (off >= 0) mt_free_slabs(a)[base + __popcll(m & ((1ull << lane) - 1))] = off;
+    }
+  }
 }
 
 // ---- VoxelMapManager::mapSliding / clearMemOutOfMap (voxel_map.cpp:924-972): every root voxel whose key lies outside the box is deleted with its subtree ----------
@@ -505,10 +533,10 @@ __global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
     const int id = st[sp--];
     DevNode &nd = a.nodes[id];
     for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
-    if (nd.plane >= 0) a.free_planes[atomicAdd(&a.counters[MTC_FREE_PLANES], 1)] = nd.plane;
-    if (nd.pts_cap == MT_SLAB) a.free_slabs[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off;
+    if (nd.plane >= 0) mt_free_planes(a)[atomicAdd(&a.counters[MTC_FREE_PLANES], 1)] = nd.plane;
+    if (nd.pts_cap == MT_SLAB) mt_free_slabs(a)[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off;
     nd.root = -1; nd.layer = -1; nd.plane = -1; nd.is_plane = 0;          // (livo2_map_tree_export recognises roots by layer == 0 && root == id)
-    a.free_nodes[atomicAdd(&a.counters[MTC_FREE_NODES], 1)] = id;
+    mt_free_nodes(a)[atomicAdd(&a.counters[MTC_FREE_NODES], 1)] = id;
   }
   s->val = -1;
   atomicSub(&a.counters[MTC_ROOTS], 1);

@@ -59,6 +59,10 @@ def test_map_sliding_matches_oracle_and_recycles(ctx, orc):
     _, (pw0, var0) = cloud(40000, R0, t0)
     ctx.map_tree_create(c, max_roots=60000)
     ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+    st = ctx.map_tree_stats()
+    # pools sized so that the build leaves them more than half used: from then on the updates run the recycling kernels (the plain ones only bump)
+    ctx.map_tree_create(c, max_roots=60000, max_nodes=int(1.6 * st["nodes"]), max_planes=int(1.6 * st["planes"]), max_points=int(1.6 * st["points"]))
+    ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
     om = orc.OracleMap.build(pw0, var0.reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
     st0 = ctx.map_tree_stats()
     # below the threshold (last_slide_position starts at the origin): nothing happens on either side
@@ -112,7 +116,7 @@ def test_tiny_inputs_and_thresholds(ctx, orc):
     assert len(dev["root_node"]) == 1
     assert dev["node_plane"][dev["root_node"][0]] >= 0 and dev["node_temp"][dev["root_node"][0]] == 0          # a plane, frozen: temp_points_ released
     _, free = ctx.map_tree_slide(np.zeros(3), 1e9, 1)                                      # (below the threshold: only reports the free stacks)
-    assert free["slabs"] == 1                                                             # ... and its 52-point region is back in the pool
+    assert free["slabs"] == 1                                                             # ... and its 52-point region is back in the pool (k_mt_collect)
 
 
 def test_lidar_update_reads_the_device_tree(ctx, livo2, orc):
