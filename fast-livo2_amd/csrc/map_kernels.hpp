@@ -71,7 +71,10 @@ struct FitRes {
   double c[3], cov[9], ev_min, ev_mid, ev_max, vmin[3], vmid[3], vmax[3], pv[36];
   bool is_plane;
 };
-template <int LPG> __device__ __forceinline__ void plane_fit_core(const double *__restrict__ pw, const double *__restrict__ var_, int lo, int hi, int lane, float planer_threshold, FitRes &R) {
+// SYM: only the upper triangle of plane_var_ is accumulated (pv[r * 6 + u], r <= u; the rest stays 0) — for callers that keep sym(plane_var_) anyway (the
+// device octree: 15 accumulators, their products and their group sums less in a kernel that sits at the register limit).  Equal to the symmetrised full sum
+// when the point covariances are symmetric, to rounding otherwise.
+template <int LPG, bool SYM = false> __device__ __forceinline__ void plane_fit_core(const double *__restrict__ pw, const double *__restrict__ var_, int lo, int hi, int lane, float planer_threshold, FitRes &R) {
   const int n = hi - lo;
   // pass 1: covariance_ += p p^T, center_ += p  (voxel_map.cpp:63-67)
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // sum p (3), then xx xy xz yy yz zz
@@ -146,15 +149,15 @@ template <int LPG> __device__ __forceinline__ void plane_fit_core(const double *
         for (int q = 0; q < 3; q++) { Tt[q] = (Jt[r * 3] * var[q] + Jt[r * 3 + 1] * var[3 + q]) + Jt[r * 3 + 2] * var[6 + q]; Tb[q] = jq * var[r * 3 + q]; }
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-          pv[r * 6 + q] += (Tt[0] * Jt[q * 3] + Tt[1] * Jt[q * 3 + 1]) + Tt[2] * Jt[q * 3 + 2];
+          if (!SYM || q >= r) pv[r * 6 + q] += (Tt[0] * Jt[q * 3] + Tt[1] * Jt[q * 3 + 1]) + Tt[2] * Jt[q * 3 + 2];
           pv[r * 6 + 3 + q] += Tt[q] * jq;
-          pv[(3 + r) * 6 + q] += (Tb[0] * Jt[q * 3] + Tb[1] * Jt[q * 3 + 1]) + Tb[2] * Jt[q * 3 + 2];
-          pv[(3 + r) * 6 + 3 + q] += Tb[q] * jq;
+          if (!SYM) pv[(3 + r) * 6 + q] += (Tb[0] * Jt[q * 3] + Tb[1] * Jt[q * 3 + 1]) + Tb[2] * Jt[q * 3 + 2];
+          if (!SYM || q >= r) pv[(3 + r) * 6 + 3 + q] += Tb[q] * jq;
         }
       }
     }
 #pragma unroll
-    for (int k = 0; k < 36; k++) pv[k] = group_sum<LPG>(pv[k]);
+    for (int k = 0; k < 36; k++) if (!SYM || (k % 6) >= (k / 6)) pv[k] = group_sum<LPG>(pv[k]);
   }
 }
 

@@ -263,7 +263,7 @@ template <bool RECYCLE> struct MtGroup {
   __device__ void fit(DevNode &n) {
     wave_sync();                                              // the pushes of this group are visible to its 8 lanes
     FitRes R;
-    plane_fit_core<MT_LPG>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);
+    plane_fit_core<MT_LPG, true>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);      // upper triangle of plane_var_ only
     n.is_plane = R.is_plane ? 1 : 0;
     if (!R.is_plane) return;
     if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc_plane<RECYCLE>(a); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
@@ -280,7 +280,7 @@ template <bool RECYCLE> struct MtGroup {
 #pragma unroll
       for (int r = 0; r < 6; r++)
 #pragma unroll
-        for (int u = r; u < 6; u++) { S[q] = 0.5 * (R.pv[r * 6 + u] + R.pv[u * 6 + r]); put(6 + q, S[q]); q++; }
+        for (int u = r; u < 6; u++) { S[q] = R.pv[r * 6 + u]; put(6 + q, S[q]); q++; }
     }
     put(27, __builtin_bit_cast(double, make_float2(dd, radius)));
     double hot[PLANE_HOT_DOUBLES];
