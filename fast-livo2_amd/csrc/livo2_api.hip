@@ -1093,6 +1093,8 @@ int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sli
   if (!ctx) return LIVO2_ERR_INVALID;
   if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "no device map tree");
   if (!position_last) return fail(ctx, LIVO2_ERR_INVALID, "position_last is NULL");
+  if (half_map_size < 0 || !(sliding_thresh >= 0) || !std::isfinite(position_last[0]) || !std::isfinite(position_last[1]) || !std::isfinite(position_last[2]))
+    return fail(ctx, LIVO2_ERR_INVALID, "bad sliding arguments (half_map_size >= 0, sliding_thresh >= 0, finite position)");
   HIPCHK(hipSetDevice(ctx->device));
   const double dx = position_last[0] - ctx->mt_last_slide[0], dy = position_last[1] - ctx->mt_last_slide[1], dz = position_last[2] - ctx->mt_last_slide[2];
   int32_t c[5];                                                  // free nodes / planes / slabs, removed, pending

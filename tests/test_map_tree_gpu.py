@@ -65,6 +65,8 @@ def test_map_sliding_matches_oracle_and_recycles(ctx, orc):
     ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
     om = orc.OracleMap.build(pw0, var0.reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
     st0 = ctx.map_tree_stats()
+    with pytest.raises(Exception):
+        ctx.map_tree_slide(np.zeros(3), 1.0, -1)                                           # half_map_size < 0: LIVO2_ERR_INVALID
     # below the threshold (last_slide_position starts at the origin): nothing happens on either side
     assert ctx.map_tree_slide(t0 * 0.0 + 0.5, 8.0, 8)[0] == -1 and om.slide(t0 * 0.0 + 0.5, 8.0, 8) == -1
     assert ctx.map_tree_stats() == st0
