@@ -300,7 +300,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per launch in the batched-frames legs (extra); 0 disables them")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational legs")
-    ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,live,c2,c3,batched,ooc,map); default all; the widened rows run only with all")
+    ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,chains,live,c2,c3,batched,ooc,map); default all; the widened rows run only with all")
     ap.add_argument("--dist-selftest", action="store_true", help="run only the rank logic (gloo, no GPU)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.frames_per_step < 1:

@@ -56,13 +56,15 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
     launch (configs[4] shape on one GPU), whole frames per second including the PCIe legs.  `w` is bench.C4 (resident on ctx); the C4 map / scan are
     NOT resident any more on return (widened_rows re-uploads what it needs)."""
     extra = {}
-    legs = set((args.legs or "single,lockstep,live,c2,c3,batched,ooc,map").split(","))
+    legs = set((args.legs or "single,lockstep,chains,live,c2,c3,batched,ooc,map").split(","))
     steps = 100
     cur, vcur = w.lid[0], w.vis[0]
     if "single" in legs:
         _single_iteration_leg(ctx, w, extra, steps)
     if "lockstep" in legs:
         _lockstep_leg(ctx, w, extra, copy_gbs)
+    if "chains" in legs:
+        _chains_leg(ctx, livo2, w, extra)
     if "live" in legs:
         _live_leg(ctx, w, extra)
     if legs & {"c2", "c3", "batched", "ooc"}:
@@ -122,6 +124,47 @@ def _lockstep_leg(ctx, w, extra, copy_gbs):
                                         "share one map snapshot and one image here, so their records are cache hits after the first frame — extra.out_of_cache is the leg that streams from HBM"}
     except Exception as exc:
         extra["c4_lockstep"] = {"error": repr(exc)}
+
+
+def _chains_leg(ctx, livo2, w, extra, n_ctx=(2, 4)):
+    # K independent frame CHAINS on one GPU: K contexts (each its own stream, map / scan / frame copy and control block), each driven by its own host thread
+    # and enqueueing the headline's step (w.F frame updates, one frame in flight per chain).  No batching API, no change to any kernel: what the GPU does with
+    # the launch gaps of one chain when other chains exist (several sensors / several sequences replayed side by side).
+    import threading
+    import time
+    out = {}
+    try:
+        for K in n_ctx:
+            ctxs = [ctx] + [livo2.Context(ctx.device) for _ in range(K - 1)]
+            for c in ctxs[1:]:
+                c.upload_map(w.sc.fmap); c.set_scan(w.sc.xyz, w.cfg)
+                c.set_frame(w.vs.img, w.vs.pos, w.vs.warp_patch, w.vs.search_levels, w.vs.inv_expo_list)
+            def chain(c, steps):
+                for _ in range(steps):
+                    for f in range(w.F):
+                        c.lidar_update_async(w.lid[f], w.lid[f], w.cfg)
+                        c.visual_update_async(w.vis[f], w.vis[f], w.vcfg)
+                c.synchronize()
+            steps = 8
+            for c in ctxs:
+                chain(c, 1)
+            ths = [threading.Thread(target=chain, args=(c, steps)) for c in ctxs]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            dt = time.perf_counter() - t0
+            out[f"{K}_chains"] = {"evals_per_s": K * steps * w.evals_per_step / dt, "frame_updates_per_s": K * steps * w.F / dt, "ms_per_frame_update_per_chain": 1e3 * dt / (steps * w.F)}
+            for c in ctxs[1:]:
+                c.close()
+        out["note"] = ("K contexts on one GPU, one host thread and one stream each, every chain runs the headline step (frame-at-a-time updates of the C4 frame); "
+                       "aggregate rate over the K chains")
+        extra["c4_concurrent_chains"] = out
+    except Exception as exc:
+        extra["c4_concurrent_chains"] = {"error": repr(exc)}
+    ctx.upload_map(w.sc.fmap); ctx.set_scan(w.sc.xyz, w.cfg)
+    ctx.set_frame(w.vs.img, w.vs.pos, w.vs.warp_patch, w.vs.search_levels, w.vs.inv_expo_list)
 
 
 def _live_leg(ctx, w, extra):
