@@ -1,0 +1,366 @@
+"""The pin of the oracle: oracle/ (hand-written restatement) against oracle/_ref (the REFERENCE'S OWN translation units
+/root/reference/src/{voxel_map,vio,frame,visual_point}.cpp compiled textually unmodified — oracle/ref_build/Makefile — against stand-in
+headers for Eigen / PCL / OpenCV / Sophus / rpg_vikit / ROS, none of which exist in this image).
+
+Both libraries export the same entry points, so one seeded scenario goes through both and the results are compared:
+LiDAR `StateEstimation` (voxel_map.cpp:338-511 with calcBodyCov, TransformLidar, BuildResidualListOMP, build_single_residual), the visual
+`computeJacobianAndUpdateEKF` (vio.cpp:784-802 with updateState 1520-1688, updateStateInverse / precomputeReferencePatches 1327-1518,
+computeProjectionJacobian, updateFrameState), the VoxelMap state machine (BuildVoxelMap / UpdateVoxelMap / UpdateOctoTree / init_plane /
+mapSliding, voxel_map.cpp:55-290, 532-641, 924-972) and the state algebra (common_lib.h:170-206, so3_math.h:44-66).
+Locals of the reference's functions (H rows, R_inv, z, per-step errors) are not observable in unmodified code: they are covered through
+truncated runs (max_iterations = 1, 2, ...), every one of which ends in the covariance update that consumes them.
+
+Bars: decisions (matched plane per point, float32 residuals, float32 world points, iteration counts, accept / revert sequences via the state
+they lead to, tree shapes) IDENTICAL; doubles to 1e-12 relative (both sides sum in ascending order with -ffp-contract=off, so in practice
+they come out bit-equal; what neither side can reproduce is Eigen's own vectorised summation order — bounded separately in
+profiles/r02_oracle_sensitivity.txt).  Runs where /root/reference exists (this container) or where oracle/_ref/*.so were built beforehand
+(they travel with the snapshot); skipped otherwise."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from scenarios import synth
+from tests import handmaps as HM
+from tests import helpers as H
+from tests import plane_groups as PG
+from tests.test_map_update_gpu import _compare
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+REFERENCE = "/root/reference"
+
+
+def _ref_lib(orc, name):
+    path = os.path.join(REF_DIR, name)
+    if os.path.isdir(os.path.join(REFERENCE, "src")):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "ref_build")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    return orc.load(path)
+
+
+@pytest.fixture(scope="module")
+def ref(orc):
+    lib = _ref_lib(orc, "libref.so")
+    lib.ref_describe.restype = C.c_char_p
+    assert b"compiled unmodified" in lib.ref_describe() and lib.ref_mp_proc_num() == 1
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ref_mp4(orc):
+    lib = _ref_lib(orc, "libref_mp4.so")
+    assert lib.ref_mp_proc_num() == 4
+    return lib
+
+
+def _state_close(a, b, tol=1e-12):
+    d = H.state_diff(a, b)
+    assert d["R"] <= tol and d["t"] <= tol and d["P"] <= tol and d["inv_expo"] <= tol and d["rest"] <= tol, d
+
+
+def _lidar_both(orc, ref, sc, max_iterations=None, num_threads=1):
+    cfg = orc.lidar_cfg(dict(sc.cfg, max_iterations=max_iterations or sc.cfg["max_iterations"]), sc.extR, sc.extT, num_threads=num_threads)
+    out = []
+    for lib in (orc.load(), ref):
+        om = orc.OracleMap.from_flat(sc.fmap, lib)
+        cur, prop = H.states(sc, orc.StatePOD)
+        out.append(orc.lidar_state_estimation(om, cfg, sc.xyz, cur, prop))
+    return out
+
+
+def _lidar_check(a, b):
+    assert a["n_iters"] == b["n_iters"]
+    assert [t.n_eff for t in a["trace"]] == [t.n_eff for t in b["trace"]]                     # the reference's own "[ LIO ] ... effective feature num" line
+    for ta, tb in zip(a["trace"], b["trace"]):
+        if ta.n_eff == 0:
+            continue                                                                          # the reference prints 0 / 0 here (voxel_map.cpp:405)
+        assert abs(ta.total_residual - tb.total_residual) <= 2e-5 * max(1.0, abs(ta.total_residual))   # printed with 6 digits
+    assert np.array_equal(a["match_plane"], b["match_plane"]) and not np.any(b["match_plane"] == -2)
+    assert np.array_equal(a["dis"], b["dis"]) and np.array_equal(a["pw"], b["pw"])
+    assert np.array_equal(a["normal"], b["normal"])                                           # pv.normal side effect (voxel_map.cpp:744), persists over iterations
+    for k in ("var", "body_cov", "cross_mat"):
+        assert H.relerr(a[k], b[k]) <= 1e-14, k
+    _state_close(a["state"], b["state"])
+
+
+# --------------------------------------------------------------------------------------------------------------------------- LiDAR
+@pytest.mark.parametrize("k", range(12))
+def test_lidar_state_estimation_sweep(orc, ref, k):
+    """the 12 scenes of tests/sweeps/parity_sweep.py (the ones the GPU sweep and the sensitivity study use)"""
+    ext = None if k % 3 else synth.rot_from_rpy(0.05 * k, -0.03 * k, 0.02 * k)
+    sc = synth.lidar_scenario(seed=300 + k, n_points=20000, downsample=0.1, n_boxes=4 + k % 6, rot_sigma_deg=0.2 + 0.1 * (k % 5), pos_sigma=0.01 + 0.01 * (k % 4), extR=ext)
+    a, b = _lidar_both(orc, ref, sc)
+    assert (a["match_plane"] >= 0).sum() > 0.5 * len(sc.xyz)
+    _lidar_check(a, b)
+
+
+@pytest.mark.parametrize("max_it", [1, 2, 3, 4, 5, 8])
+def test_lidar_truncated_runs_pin_every_iteration(orc, ref, max_it):
+    """max_iterations = k ends with the covariance update of iteration k: H^T R^-1 H, K_1, G of EVERY iteration are pinned through P"""
+    sc = synth.lidar_scenario(seed=1, n_points=24000, downsample=0.1)                          # C1: the avia-like scan
+    a, b = _lidar_both(orc, ref, sc, max_iterations=max_it)
+    assert a["n_iters"] <= max_it
+    _lidar_check(a, b)
+
+
+def test_lidar_mp4_build_matches(orc, ref_mp4):
+    """the shipped configuration: MP_EN, MP_PROC_NUM = 4 (mutex-guarded OpenMP loop of BuildResidualListOMP)"""
+    sc = synth.lidar_scenario(seed=11, n_points=20000, downsample=0.1, extR=synth.rot_from_rpy(0.02, -0.01, 0.03))
+    a, b = _lidar_both(orc, ref_mp4, sc, num_threads=4)
+    _lidar_check(a, b)
+
+
+def test_lidar_cluttered_scene_deep_candidate_lists(orc, ref):
+    """non-plane roots with many descendant planes: the all-8-children recursion, max-probability choice (Q7)"""
+    sc = synth.lidar_scenario(seed=31, n_points=20000, room=(12.0, 12.0, 4.0), n_boxes=60, downsample=0.05, map_rays_factor=20, cfg=dict(min_eigen_value=0.0004))
+    a, b = _lidar_both(orc, ref, sc)
+    assert (a["match_plane"] >= 0).sum() > 10000
+    _lidar_check(a, b)
+
+
+def test_lidar_hand_maps_quirks(orc, ref):
+    """hand-derived decisions (tests/test_oracle_cpu.py): neighbour rule with the units mismatch (Q3), key rule for negatives (Q4), children (Q7)"""
+    b = HM.MapBuilder()
+    b.add_root([0, 0, -2], HM.plane_record([0, 0, 1], [0.25, 0.25, -0.5], radius=5.0))
+    b.add_root([0, 0, -1], HM.plane_record([0, 0, 1], [0.25, 0.25, -0.2], radius=5.0))
+    b.add_root([0, 0, 1], HM.plane_record([0, 0, 1], [0.25, 0.25, 0.7], radius=5.0))
+    far = HM.plane_record([0, 0, 1], [0.12, 0.12, 0.1004], radius=1.0, var_scale=1e-8)
+    near = HM.plane_record([0, 0, 1], [0.37, 0.37, 0.1001], radius=1.0, var_scale=1e-8)
+    b.add_root([0, 0, 0], None, children={0: far, 6: near})
+    b.add_root([2, 0, 0], HM.plane_record([0, 0, 1], [1.05, 0.25, 0.1], radius=0.01))
+    b.add_root([4, 0, 0], None)
+    b.add_root([5, 1, 1], HM.plane_record([0, 0, 1], [2.2, 0.3, 0.2], radius=2.0))
+    b.add_root([4, 0, 1], HM.plane_record([0, 0, 1], [2.2, 0.3, 0.2], radius=2.0))
+    pts = [[0.25, 0.25, -0.5], [0.25, 0.25, -0.2], [0.25, 0.25, 0.7], [0.25, 0.25, 0.1], [1.25, 0.25, 0.1], [2.15, 0.25, 0.2], [10, 10, 10], [0.3, 0.3, 0.0]]
+    for max_layer in (2, 0):
+        sc = HM.HandScene(b.build(), pts, max_layer=max_layer)
+        sc.cfg["max_iterations"] = 1                                                           # the matches of the FIRST pass are the hand-derived ones
+        x, y = _lidar_both(orc, ref, sc)
+        x["match_plane"][x["match_plane"] == 7] = 6        # planes 6 and 7 are the same record in two voxels: a PointToPlane cannot tell them apart (ref reports the lower)
+        if max_layer == 2:
+            assert list(y["match_plane"][:7]) == [0, 1, 2, 4, -1, 6, -1]
+        else:
+            assert y["match_plane"][3] == -1
+        _lidar_check(x, y)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 1000])
+def test_lidar_ragged_and_empty(orc, ref, n):
+    sc = synth.lidar_scenario(seed=8, n_points=1000, downsample=0.1)
+    sc.xyz = np.ascontiguousarray(sc.xyz[:n])
+    if n >= 2:
+        sc.xyz[1, 2] = 0.0                                                                     # z == 0: the 0.001 / 0.0001 patches (voxel_map.cpp:17, 352)
+    a, b = _lidar_both(orc, ref, sc)
+    _lidar_check(a, b)
+
+
+def test_calc_body_cov_and_state_algebra(orc, ref):
+    gold = orc.load()
+    rng = np.random.default_rng(3)
+    for lib in (gold, ref):
+        lib.orc_calc_body_cov.restype = None
+    for p in list(rng.normal(0, 5, (50, 3))) + [np.array([1.0, 2.0, 0.0]), np.array([0.0, 0.0, 3.0])]:
+        outs = []
+        for lib in (gold, ref):
+            cov, pb = np.zeros(9), np.zeros(3)
+            lib.orc_calc_body_cov(orc._p(np.ascontiguousarray(p), C.c_double), C.c_float(0.02), C.c_float(0.05), C.c_double(0.017453293), orc._p(cov, C.c_double), orc._p(pb, C.c_double))
+            outs.append((cov, pb))
+        assert np.array_equal(outs[0][1], outs[1][1]) and H.relerr(outs[0][0], outs[1][0]) <= 1e-15
+    s = orc.make_state(synth.rot_from_rpy(0.3, -0.2, 1.1), [1, 2, 3], synth.default_cov(), inv_expo=0.9, vel=[0.1, 0.2, 0.3], bg=[1e-3] * 3, ba=[2e-3] * 3, grav=[0, 0, -9.81])
+    for d in (rng.normal(0, 0.1, 19), rng.normal(0, 1e-7, 19), np.zeros(19)):                 # Exp's 1e-5 threshold on both sides of it
+        o = []
+        for lib in (gold, ref):
+            out, back = orc.StatePOD(), np.zeros(19)
+            lib.orc_state_boxplus(C.byref(s), orc._p(np.ascontiguousarray(d), C.c_double), C.byref(out))
+            lib.orc_state_boxminus(C.byref(out), C.byref(s), orc._p(back, C.c_double))
+            o.append((out, back))
+        _state_close(o[0][0], o[1][0], 1e-15)
+        assert np.allclose(o[0][1], o[1][1], rtol=0, atol=1e-16)
+        assert np.allclose(o[1][1][3:], d[3:], atol=1e-12)
+
+
+# -------------------------------------------------------------------------------------------------------------------------- visual
+def _visual_both(orc, ref, vs, num_threads=1, **kw):
+    cfg = orc.visual_cfg(vs, num_threads=num_threads, **kw)
+    out = []
+    for lib in (orc.load(), ref):
+        cur, prop = H.states(vs, orc.StatePOD)
+        out.append(orc.visual_update(cfg, vs, cur, prop, lib=lib))
+    return out
+
+
+def _visual_check(a, b, tol=1e-12):
+    assert np.array_equal(a["errors"], b["errors"])                                            # float patch_error of the last evaluated step, per patch
+    _state_close(a["state"], b["state"], tol)
+    assert H.relerr(a["G"], b["G"]) <= tol and H.relerr(a["Rcw"], b["Rcw"]) <= 1e-15 and H.relerr(a["Pcw"], b["Pcw"]) <= 1e-15
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_visual_update_sweep(orc, ref, k):
+    """the 8 visual scenes of tests/sweeps/parity_sweep.py"""
+    vs = synth.visual_scenario(seed=400 + k, n_patches=2000, rot_sigma_deg=0.03 + 0.01 * (k % 4))
+    a, b = _visual_both(orc, ref, vs)
+    assert len(a["trace"]) >= 4
+    _visual_check(a, b)
+
+
+@pytest.mark.parametrize("max_it", [1, 2, 3, 5])
+@pytest.mark.parametrize("variant", ["pinhole", "radtan", "no_exposure", "inverse", "inverse_radtan"])
+def test_visual_truncated_runs_pin_every_step(orc, ref, variant, max_it):
+    """max_iterations = k per level: the accept / revert decision, H^T H, K_1 and the state after every (level, iteration) step are pinned
+    through the state and covariance the run ends with"""
+    inverse = variant.startswith("inverse")
+    vs = synth.visual_inverse_scenario(seed=5, n_patches=300) if inverse else synth.visual_scenario(seed=12, n_patches=300)
+    kw = dict(max_iterations=max_it, inverse=inverse)
+    if variant.endswith("radtan"):
+        kw["distortion"] = synth.AVIA_RADTAN
+    if variant == "no_exposure":
+        kw["exposure"] = False
+    a, b = _visual_both(orc, ref, vs, **kw)
+    _visual_check(a, b)
+
+
+def test_visual_revert_path(orc, ref):
+    """a prior far enough from the optimum that some level rejects its step (error > last_error -> state restored, vio.cpp:1677-1681)"""
+    seen = False
+    for seed in range(20, 28):
+        vs = synth.visual_scenario(seed=seed, n_patches=200, rot_sigma_deg=0.25)
+        a, b = _visual_both(orc, ref, vs)
+        seen = seen or any(not t.accepted for t in a["trace"])
+        _visual_check(a, b)
+    assert seen
+
+
+@pytest.mark.parametrize("M", [1, 3, 5, 301])
+def test_visual_mp4_build_matches(orc, ref_mp4, M):
+    """MP_EN / MP_PROC_NUM = 4: `#pragma omp parallel for reduction(+:error, n_meas)` (vio.cpp:1552-1554).  The float `error` joins the threads' partial
+    sums; the oracle fixes the join order to thread 0, 1, 2, 3 — one of the orders libgomp produces.  M < 4 and M % 4 != 0 exercise the static partition."""
+    vs = synth.visual_scenario(seed=14, n_patches=M)
+    a, b = _visual_both(orc, ref_mp4, vs, num_threads=4)
+    _visual_check(a, b, tol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------------------------ VoxelMap
+def _scene(seed):
+    rng = np.random.default_rng(seed)
+    c = dict(synth.AVIA["lio"])
+    scene = synth.make_room(rng, (20.0, 20.0, 6.0), 8)
+    extR, extT = synth.AVIA["extrinsic_R"], synth.AVIA["extrinsic_T"]
+    R0, t0 = scene.R_ws @ synth.rot_from_rpy(0.01, -0.015, 0.4), scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    P0 = synth.default_cov() * 1e-3
+
+    def cloud(n, R, t):
+        xyz = synth.lidar_scan(rng, scene, R, t, extR, extT, n, c["dept_err"], c["beam_err"], synth.AVIA["blind"], False)
+        return xyz, synth.world_points_and_var(xyz, R, t, extR, extT, P0, c["dept_err"], c["beam_err"])
+    return c, cloud, R0, t0, P0, extR, extT
+
+
+def _compare_signed(a, b):
+    """tree shapes identical, plane parameters equal up to the sign of the normal (Eigen::EigenSolver's eigenvector sign is a property of Eigen's
+    implementation; the stand-in and the oracle both use a Jacobi solver and need not agree on it)"""
+    b2 = synth.FlatMap(b.voxel_size, b.max_layer, b.root_key, b.root_node, b.root_center, b.root_quarter, b.node_plane, b.node_child, b.plane_normal.copy(),
+                       b.plane_center, b.plane_var.copy(), b.plane_d.copy(), b.plane_radius)
+    ka = {tuple(np.round(c, 9)): i for i, c in enumerate(a.plane_center)}
+    for j, c in enumerate(b2.plane_center):
+        i = ka.get(tuple(np.round(c, 9)))
+        if i is not None and np.dot(a.plane_normal[i], b2.plane_normal[j]) < 0:
+            b2.plane_normal[j] *= -1; b2.plane_d[j] *= -1
+            S = np.diag([-1.0, -1, -1, 1, 1, 1]); b2.plane_var[j] = (S @ b2.plane_var[j].reshape(6, 6) @ S).ravel()
+    return _compare(a, b2)
+
+
+def test_update_voxel_map_sequence(orc, ref):
+    """UpdateVoxelMap from an empty map, then three more scans: every counter-driven decision of UpdateOctoTree / init_octo_tree / cut_octo_tree
+    (5-point thresholds, re-fit every 5 points, subdivision, freezing at max_points_num) must fall at the same point"""
+    c, cloud, R0, t0, P0, extR, extT = _scene(81)
+    args = (c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    lin = (C.c_int * 5)(*list(c["layer_init_num"])[:5])
+    maps = [orc.OracleMap(lib, lib.orc_map_create(C.c_double(args[0]), C.c_int(args[1]), lin, C.c_int(args[3]), C.c_double(args[4]))) for lib in (orc.load(), ref)]
+    n_prev = 0
+    for k in range(4):
+        Rk, tk = R0 @ synth.rot_from_rpy(0.0, 0.0, 0.12 * k), t0 + np.array([0.3 * k, 0.1 * k, 0.0])
+        _, (pw, var) = cloud(15000, Rk, tk)
+        for m in maps:
+            m.update(pw, var.reshape(-1, 9))
+        n = _compare_signed(maps[0].export(args[0], args[1]), maps[1].export(args[0], args[1]))
+        assert n > n_prev
+        n_prev = n
+    assert n_prev > 800
+
+
+@pytest.mark.parametrize("max_points_num", [50, 100])
+def test_build_voxel_map_from_scan(orc, ref, max_points_num):
+    """BuildVoxelMap (voxel_map.cpp:532-591) forms point_w / var itself: (R extR) C_b (R extR)^T + [p_l]x P_rr [p_l]x^T + P_tt with the LiDAR-frame point in the
+    cross matrix (549-552).  The oracle side gets exactly those (point_w, var); max_points_num = 100 is config/HILTI22.yaml:66."""
+    c, cloud, R0, t0, P0, extR, extT = _scene(83)
+    c["max_points_num"] = max_points_num
+    xyz, _ = cloud(30000, R0, t0)
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    pw = ((xyz.astype(np.float64) @ extR.T + extT) @ R0.T + t0).astype(np.float32)
+    st = orc.make_state(R0, t0, P0)
+    gold = orc.load()
+    gold.orc_calc_body_cov.restype = None
+    var = np.zeros((len(xyz), 9))
+    Re = R0 @ extR
+    for i, p in enumerate(xyz.astype(np.float64)):
+        cov, pb = np.zeros(9), np.zeros(3)
+        gold.orc_calc_body_cov(orc._p(np.ascontiguousarray(p), C.c_double), C.c_float(c["dept_err"]), C.c_float(c["beam_err"]), C.c_double(0.017453293), orc._p(cov, C.c_double), orc._p(pb, C.c_double))
+        X = np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0]])
+        var[i] = (Re @ cov.reshape(3, 3) @ Re.T + (-X) @ P0[:3, :3] @ (-X).T + P0[3:6, 3:6]).ravel()
+    args = (c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    om = orc.OracleMap.build(pw.astype(np.float64), var, *args)
+    lin = (C.c_int * 5)(*list(c["layer_init_num"])[:5])
+    rm = orc.OracleMap(ref, ref.orc_map_create(C.c_double(args[0]), C.c_int(args[1]), lin, C.c_int(args[3]), C.c_double(args[4])))
+    ref.ref_map_build_from_scan.restype = None
+    ref.ref_map_build_from_scan(rm.h, orc._p(xyz, C.c_float), orc._p(pw, C.c_float), C.c_int(len(xyz)), C.byref(st), orc._p(np.ascontiguousarray(extR, np.float64), C.c_double),
+                                C.c_double(c["dept_err"]), C.c_double(c["beam_err"]))
+    assert _compare_signed(om.export(args[0], args[1]), rm.export(args[0], args[1])) > 500
+    # and a follow-up update on both
+    _, (pw1, var1) = cloud(10000, R0, t0 + np.array([0.2, 0.0, 0.0]))
+    om.update(pw1, var1.reshape(-1, 9)); rm.update(pw1, var1.reshape(-1, 9))
+    assert _compare_signed(om.export(args[0], args[1]), rm.export(args[0], args[1])) > 500
+
+
+def test_init_plane_groups(orc, ref):
+    """VoxelOctoTree::init_plane (voxel_map.cpp:55-135): plane / non-plane decision identical; centre, covariance, eigenvalues, radius, plane_var equal; the normal up
+    to its sign (EigenSolver convention, see above)"""
+    pw, var, off, _ = PG.make_groups(seed=500, n_groups=300, big=(400,))
+    planes = 0
+    for g in range(len(off) - 1):
+        a = orc.init_plane(pw[off[g]:off[g + 1]], var[off[g]:off[g + 1]], 0.0025)
+        b = orc.init_plane(pw[off[g]:off[g + 1]], var[off[g]:off[g + 1]], 0.0025, lib=ref)
+        assert a.is_plane == b.is_plane and a.points_size == b.points_size
+        assert np.allclose(np.array(a.center), np.array(b.center), rtol=1e-14, atol=0) and H.relerr(np.array(a.covariance), np.array(b.covariance)) < 1e-12
+        if a.is_plane:
+            planes += 1
+            na, nb = np.array(a.normal), np.array(b.normal)
+            s = 1.0 if na @ nb > 0 else -1.0
+            assert np.linalg.norm(na - s * nb) < 1e-7
+            assert abs(a.radius - b.radius) <= 1e-6 * b.radius and abs(a.d - s * b.d) <= 1e-5 * max(1.0, abs(b.d))
+            assert abs(a.min_eigen_value - b.min_eigen_value) <= 1e-6 * b.max_eigen_value and abs(a.max_eigen_value - b.max_eigen_value) <= 1e-6 * b.max_eigen_value
+            S = np.diag([s, s, s, 1, 1, 1])
+            assert H.relerr(np.array(a.plane_var).reshape(6, 6), S @ np.array(b.plane_var).reshape(6, 6) @ S) < 1e-5
+    assert 50 < planes < len(off) - 1
+
+
+def test_map_sliding(orc, ref):
+    c, cloud, R0, t0, P0, extR, extT = _scene(85)
+    args = (c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    lin = (C.c_int * 5)(*list(c["layer_init_num"])[:5])
+    maps = [orc.OracleMap(lib, lib.orc_map_create(C.c_double(args[0]), C.c_int(args[1]), lin, C.c_int(args[3]), C.c_double(args[4]))) for lib in (orc.load(), ref)]
+    _, (pw, var) = cloud(30000, R0, t0)
+    for m in maps:
+        m.update(pw, var.reshape(-1, 9))
+    pos = np.asarray(t0, float)
+    thr = 0.5 * float(np.linalg.norm(pos))
+    for position, thresh, half in ((pos * 0 + 0.1, 8.0, 8), (pos, thr, 8), (pos + 0.05, thr, 4), (pos + np.array([3.0, 0, 0]), 1.0, 4)):
+        ra, rb = maps[0].slide(position, thresh, half), maps[1].slide(position, thresh, half)
+        assert ra == rb
+        ea, eb = maps[0].export(args[0], args[1]), maps[1].export(args[0], args[1])
+        assert {tuple(k) for k in ea.root_key} == {tuple(k) for k in eb.root_key}
+    assert ra > 0
