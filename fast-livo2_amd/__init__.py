@@ -70,6 +70,14 @@ class Context:
     def stream(self):
         return self.lib.livo2_ctx_stream(self.h)
 
+    def set_option(self, name, value):
+        self._chk(self.lib.livo2_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def counter(self, name):
+        v = C.c_int64()
+        self._chk(self.lib.livo2_ctx_get_counter(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def kernel_timing(self, enable):
         self._chk(self.lib.livo2_ctx_kernel_timing(self.h, 1 if enable else 0))
 

@@ -61,12 +61,53 @@ __device__ inline void esikf_log_lane(const DevCtl *ctl, SolveLds &s) {
   s.vec[0] = l[0]; s.vec[1] = l[1]; s.vec[2] = l[2];
 }
 
+// value held by lane SRC (compile-time constant) as a wave-uniform scalar: two v_readlane_b32
+template <int SRC> __device__ __forceinline__ double esikf_bcast(double v) {
+  const int2 w = __builtin_bit_cast(int2, v);
+  return __builtin_bit_cast(double, make_int2(__builtin_amdgcn_readlane(w.x, SRC), __builtin_amdgcn_readlane(w.y, SRC)));
+}
+
+// elimination step C of the column-per-lane scheme (see esikf_solve_wave): lane C holds column C of A, finds the pivot row and forms the multipliers
+template <int C, int k> __device__ __forceinline__ void esikf_eliminate(double (&col)[k]) {
+  if constexpr (C < k) {
+    int piv = C; double best = fabs(col[C]);
+#pragma unroll
+    for (int i = C + 1; i < k; i++) { const double v = fabs(col[i]); if (v > best) { best = v; piv = i; } }
+    piv = __builtin_amdgcn_readlane(piv, C);
+#pragma unroll
+    for (int i = C + 1; i < k; i++)
+      if (piv == i) { const double t = col[C]; col[C] = col[i]; col[i] = t; }     // wave-uniform row swap
+    const double inv = 1.0 / col[C];
+#pragma unroll
+    for (int i = C + 1; i < k; i++) {
+      const double li = esikf_bcast<C>(col[i] * inv);         // l = A[i][C] * inv, formed in lane C
+      col[i] = fma(-li, col[C], col[i]);
+    }
+    esikf_eliminate<C + 1, k>(col);
+  }
+}
+// t -= U[I][J] x[J] for J = I+1 .. k-1 (ascending), U[I][J] = entry I of lane J's column
+template <int I, int J, int k> __device__ __forceinline__ void esikf_back_row(const double (&col)[k], const double (&x)[k], double &t) {
+  if constexpr (J < k) { t = fma(-esikf_bcast<J>(col[I]), x[J], t); esikf_back_row<I, J + 1, k>(col, x, t); }
+}
+template <int I, int k> __device__ __forceinline__ void esikf_back(const double (&col)[k], double (&x)[k]) {
+  if constexpr (I >= 0) {
+    double t = col[I];
+    esikf_back_row<I, I + 1, k>(col, x, t);
+    x[I] = t / esikf_bcast<I>(col[I]);
+    esikf_back<I - 1, k>(col, x);
+  }
+}
+
 // Part 2: needs s.P / s.cur / s.prop (esikf_prefetch_wave), s.vec[0..2] (esikf_log_lane), the sums in s.hth / s.htz, and a barrier.
-//   S = I + H_k P'_kk is built once in LDS; then lane r (r < 19) solves  S^T x = P'[r, 0:k]^T  by LU with partial pivoting ENTIRELY IN
-//   REGISTERS (the matrix is the same in every lane, so pivoting is wave-uniform and row swaps are scalar branches), which gives
-//   x = K_1[r, 0:k]; G[r, :], the Kalman solution entry and the state update follow without further LDS round trips.
-//   (The LDS Gauss-Jordan this replaces cost 2.5 us of barriers and dependent LDS latency on the critical wave.)
-template <int k>
+//   S = I + H_k P'_kk is built once in LDS; K_1[r, 0:k] (r < 19) is the solution x of  S^T x = P'[r, 0:k]^T : Gaussian elimination with partial pivoting
+//   on the augmented matrix [S^T | B], B = the 19 right-hand sides, with ONE COLUMN PER LANE (lanes 0..k-1: the columns of S^T, lanes k..k+18: the right-hand
+//   sides): the pivot search and the multipliers of step c are formed in lane c and broadcast with v_readlane, every lane then updates its own column; the back
+//   substitution broadcasts the U entries the same way.  Every element sees exactly the operations (and their order) of a per-lane LU with partial pivoting of
+//   the full system — the form this replaces held the whole k x k matrix redundantly in every lane: ~250 VGPRs, which no kernel that inlines the solve next to
+//   other work could afford (k_visual_update_persistent) — and the results are bit-identical to it.  G[r, :], the Kalman solution entry and the new rotation follow
+//   without further LDS round trips.
+template <int k, bool MATH_CALLS = false>
 __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane) {
   if (lane < k * k) {                                        // S = I + H_k P'_kk, row-major stride k
     const int i = lane / k, j = lane % k;
@@ -77,44 +118,13 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
   }
   if (lane >= 9 && lane < 25) s.vec[lane - 6] = s.prop[lane] - s.cur[lane];     // pos, inv_expo, vel, bg, ba, grav parts of vec
   wave_sync();
-  const int r = lane < DS ? lane : DS - 1;
-  double A[k][k], b[k];
+  const int r = (lane < k) ? 0 : (lane - k < DS ? lane - k : DS - 1);             // right-hand side owned by this lane (lanes < k own a matrix column)
+  double col[k];
 #pragma unroll
-  for (int i = 0; i < k; i++) {
-#pragma unroll
-    for (int j = 0; j < k; j++) A[i][j] = s.aug[j * k + i];  // A = S^T
-    b[i] = s.P[r * DS + i];
-  }
-#pragma unroll
-  for (int c = 0; c < k; c++) {
-    int piv = c; double best = fabs(A[c][c]);
-#pragma unroll
-    for (int i = c + 1; i < k; i++) { const double v = fabs(A[i][c]); if (v > best) { best = v; piv = i; } }
-    piv = __builtin_amdgcn_readfirstlane(piv);
-#pragma unroll
-    for (int i = c + 1; i < k; i++)
-      if (piv == i) {                                        // wave-uniform
-#pragma unroll
-        for (int j = c; j < k; j++) { const double t = A[c][j]; A[c][j] = A[i][j]; A[i][j] = t; }
-        const double t = b[c]; b[c] = b[i]; b[i] = t;
-      }
-    const double inv = 1.0 / A[c][c];
-#pragma unroll
-    for (int i = c + 1; i < k; i++) {
-      const double l = A[i][c] * inv;
-#pragma unroll
-      for (int j = c + 1; j < k; j++) A[i][j] = fma(-l, A[c][j], A[i][j]);
-      b[i] = fma(-l, b[c], b[i]);
-    }
-  }
-  double x[k];                                               // back substitution: x = K_1[r, 0:k]
-#pragma unroll
-  for (int i = k - 1; i >= 0; i--) {
-    double t = b[i];
-#pragma unroll
-    for (int j = i + 1; j < k; j++) t = fma(-A[i][j], x[j], t);
-    x[i] = t / A[i][i];
-  }
+  for (int i = 0; i < k; i++) col[i] = (lane < k) ? s.aug[lane * k + i] : s.P[r * DS + i];   // column `lane` of A = S^T is row `lane` of S
+  esikf_eliminate<0, k>(col);                                // forward elimination, one pivot column at a time
+  double x[k];                                               // back substitution: x = K_1[r, 0:k] in the lanes that own a right-hand side
+  esikf_back<k - 1, k>(col, x);
   double kz = 0.0, gv = 0.0;                                 // G[r, 0:k] = K_1[r, 0:k] H_k
   double g[KMAX];
 #pragma unroll
@@ -126,7 +136,7 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     kz = fma(x[c], s.htz[c], kz);
     gv = fma(t, s.vec[c], gv);
   }
-  if (lane < DS) {
+  if (lane >= k && lane < k + DS) {
 #pragma unroll
     for (int c = 0; c < KMAX; c++) s.G[r * KMAX + c] = (c < k) ? g[c] : 0.0;
     s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
@@ -134,7 +144,8 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
   wave_sync();
   if (lane == 0) {                                           // state.rot_end * Exp(delta theta)  (common_lib.h:184), ~1 us of sin / cos / sqrt on one lane
     double E[9], Rn[9];
-    so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
+    if (MATH_CALLS) { const So3Mat m = so3_exp_call(s.sol[0], s.sol[1], s.sol[2]); for (int i = 0; i < 9; i++) E[i] = m.v[i]; }
+    else so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
     mat3_mul(s.cur, E, Rn);
     for (int i = 0; i < 9; i++) s.newR[i] = Rn[i];
   }

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -130,6 +131,13 @@ struct livo2_ctx {
   livo2_visual_result *vbd_results = nullptr, *vbh_results = nullptr;   // [LIVO2_MAX_BATCH], device / pinned
   // device-resident VoxelMap (map_tree_kernels.hpp)
   bool visual_fused = [] { const char *e = std::getenv("LIVO2_VISUAL_FUSED"); return e ? std::atoi(e) != 0 : false; }();   // LIVO2_VISUAL_FUSED=1: one k_visual_step launch per (level, iteration) instead of residual + solve (tools/vis_probe.py)
+  // persistent visual update (k_visual_update_persistent): one launch per computeJacobianAndUpdateEKF.  LIVO2_VISUAL_PERSISTENT=0 (or livo2_ctx_set_option) selects
+  // the launch-per-step sequence instead.
+  bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
+  unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0; uint32_t vp_seq = 0;
+  hipEvent_t vp_done = nullptr; int vp_blocks_inflight = 0;     // this ctx's last persistent launch (device-wide accounting below)
+  unsigned long long *d_vp_prof = nullptr; bool vp_prof = [] { const char *e = std::getenv("LIVO2_VP_PROF"); return e ? std::atoi(e) != 0 : false; }();
+  int vp_used = 0, vp_fallback = 0;                              // statistics: persistent launches / fallbacks to the per-step sequence
   bool tree_mode = false;
   MapTreeArgs mt{};
   double mt_last_slide[3] = {0, 0, 0};      // VoxelMapManager::last_slide_position
@@ -431,6 +439,52 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   return LIVO2_OK;
 }
 
+// ---- co-residency of persistent grids -----------------------------------------------------------------------------------------------
+// A grid that synchronises through an arrival counter must be resident as a whole.  Capacity = compute units x blocks per CU (occupancy query of the kernel);
+// all contexts of this process on one device share it: a launch is admitted only if the blocks of the persistent launches still in flight (their completion
+// events have not fired) plus its own fit, otherwise the caller takes the launch-per-step path.  Kernels that do not spin (everything else in this library) can
+// only delay a persistent grid, never deadlock it.
+struct PersistSlot { hipEvent_t ev; int blocks; int device; };
+std::mutex g_persist_mu;
+std::vector<PersistSlot> g_persist;
+int persist_capacity(int device) {
+  static int cap[64] = {};
+  if (device < 0 || device >= 64) return 0;
+  if (cap[device] == 0) {
+    hipDeviceProp_t prop; int per_cu = 0;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_visual_update_persistent, VIS_BLOCK, 0) != hipSuccess || per_cu < 1) return 0;
+    cap[device] = prop.multiProcessorCount * std::min(per_cu, 1);        // one block per CU: the redundant solve wants a CU's LDS bandwidth to itself
+  }
+  return cap[device];
+}
+// returns the grid size to launch (0: not admitted)
+int persist_admit(livo2_ctx *ctx, int want_blocks) {
+  const int cap = persist_capacity(ctx->device);
+  if (cap <= 0) return 0;
+  std::lock_guard<std::mutex> lk(g_persist_mu);
+  int busy = 0;
+  for (size_t i = 0; i < g_persist.size();) {
+    if (hipEventQuery(g_persist[i].ev) == hipSuccess) { g_persist[i] = g_persist.back(); g_persist.pop_back(); continue; }
+    if (g_persist[i].device == ctx->device) busy += g_persist[i].blocks;
+    i++;
+  }
+  const int grid = std::min(want_blocks, VP_MAX_BLOCKS);
+  if (busy + grid > cap) return 0;
+  return grid;
+}
+void persist_register(livo2_ctx *ctx, int blocks) {
+  if (!ctx->vp_done && hipEventCreateWithFlags(&ctx->vp_done, hipEventDisableTiming) != hipSuccess) return;
+  if (hipEventRecord(ctx->vp_done, ctx->stream) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(g_persist_mu);
+  for (auto &sl : g_persist) if (sl.ev == ctx->vp_done) { sl.blocks = blocks; return; }      // the event was re-recorded: it now stands for the newer launch (same stream: the older one completes first)
+  g_persist.push_back(PersistSlot{ctx->vp_done, blocks, ctx->device});
+}
+void persist_forget(livo2_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_persist_mu);
+  for (size_t i = 0; i < g_persist.size(); i++) if (g_persist[i].ev == ctx->vp_done) { g_persist[i] = g_persist.back(); g_persist.pop_back(); break; }
+}
+
 int check_visual_cfg(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
   if (!cfg) return fail(ctx, LIVO2_ERR_INVALID, "cfg is NULL");
   if (cfg->inverse_composition_en && ctx->M > 0 && !ctx->has_ref) return fail(ctx, LIVO2_ERR_INVALID, "inverse_composition_en needs livo2_visual_set_reference after set_frame");
@@ -535,7 +589,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list};
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -549,6 +603,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   for (auto &b : ctx->bins) for (auto &ev : b.used) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (int k = 0; k < IN_RING; k++) if (ctx->in_ev[k]) e = hipEventDestroy(ctx->in_ev[k]);
+  if (ctx->vp_done) { persist_forget(ctx); e = hipEventDestroy(ctx->vp_done); }
   if (ctx->span0) e = hipEventDestroy(ctx->span0);
   if (ctx->span1) e = hipEventDestroy(ctx->span1);
   if (ctx->own_stream && ctx->stream) e = hipStreamDestroy(ctx->stream);
@@ -559,6 +614,19 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
 const char *livo2_last_error(const livo2_ctx *ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
 void *livo2_ctx_stream(livo2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; HIPCHK(hipStreamSynchronize(ctx->stream)); return LIVO2_OK; }
+
+int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
+  if (!ctx || !name) return LIVO2_ERR_INVALID;
+  if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_fused") == 0) { ctx->visual_fused = value != 0; return LIVO2_OK; }
+  return fail(ctx, LIVO2_ERR_INVALID, "unknown option");
+}
+int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
+  if (!ctx || !name || !value) return LIVO2_ERR_INVALID;
+  if (std::strcmp(name, "visual_persistent_launches") == 0) { *value = ctx->vp_used; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_persistent_fallbacks") == 0) { *value = ctx->vp_fallback; return LIVO2_OK; }
+  return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
+}
 
 int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable) { if (!ctx) return LIVO2_ERR_INVALID; ctx->timing = enable != 0; return LIVO2_OK; }
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset) {
@@ -2132,6 +2200,36 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
   int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
   const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(ctx->M, 1)) : visual_grid(std::max(ctx->M, 1));
   VisualKernelArgs a{};
+  if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && !ctx->visual_fused && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
+    const int G = persist_admit(ctx, grid);
+    if (G > 0) {
+      {                        // exchange buffers start as all-zero words: tag 0 is never a step's tag
+        const size_t c0 = ctx->vp_rows_cap, c1 = ctx->vp_errs_cap;
+        rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_BLOCKS * VIS_PSTRIDE * 2); if (rc) return rc;
+        rc = ensure(ctx, ctx->d_vp_errs, ctx->vp_errs_cap, (size_t)2 * std::max(ctx->M_cap, 512)); if (rc) return rc;
+        if (ctx->vp_rows_cap != c0) HIPCHK(hipMemsetAsync(ctx->d_vp_rows, 0, ctx->vp_rows_cap * 8, ctx->stream));
+        if (ctx->vp_errs_cap != c1) HIPCHK(hipMemsetAsync(ctx->d_vp_errs, 0, ctx->vp_errs_cap * 8, ctx->stream));
+      }
+      VisPersistArgs p{};
+      p.a = make_visual_args(ctx, cfg, 0);
+      p.a.errors = ctx->d_errors;
+      p.rows = ctx->d_vp_rows; p.errs = ctx->d_vp_errs;
+      p.levels = cfg->patch_pyrimid_level; p.max_iterations = cfg->max_iterations; p.error_threads = cfg->mp_proc_num; p.img_point_cov = cfg->img_point_cov;
+      ctx->vp_seq = (ctx->vp_seq + 1) & 0xffffffu; if (ctx->vp_seq == 0) ctx->vp_seq = 1;       // tag 0 = never-written memory
+      p.tag_base = ctx->vp_seq << 8;
+      if (ctx->vp_prof) {
+        if (!ctx->d_vp_prof) HIPCHK(hipMalloc((void **)&ctx->d_vp_prof, 8 * 32 * 16 * 8));
+        HIPCHK(hipMemsetAsync(ctx->d_vp_prof, 0, 8 * 32 * 16 * 8, ctx->stream));
+        p.prof = ctx->d_vp_prof;
+      }
+      { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_update_persistent, dim3(G), dim3(VIS_BLOCK), 0, ctx->stream, p, ctx->d_ctl); t.done(); }
+      HIPCHK(hipGetLastError());
+      persist_register(ctx, G);
+      ctx->vp_used++;
+      return LIVO2_OK;
+    }
+    ctx->vp_fallback++;
+  }
   for (int level = level_hi; level >= level_lo; level--) {
     a = make_visual_args(ctx, cfg, level);
     a.errors = ctx->d_errors;
@@ -2181,8 +2279,11 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
   if (errors && ctx->M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ctx->h_out) + sizeof(livo2_visual_result));
+  HIPCHK(hipMemcpyAsync(flag, &ctx->d_ctl->hdr.pad[0], 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(result, ctx->h_out, sizeof(livo2_visual_result));
+  if (*flag) return fail(ctx, LIVO2_ERR_HIP, "persistent visual update: grid barrier timed out (the grid was not co-resident); result invalid");
   return LIVO2_OK;
 }
 
@@ -2334,6 +2435,13 @@ int livo2_visual_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, int32_
   return vbatch_enqueue(ctx, n_frames, state_in, prop, cfg, level, level, iters, 2);
 }
 
+// LIVO2_VP_PROF=1: stamps of the last persistent visual update, [8 blocks][32 steps][8] (tools/vis_persist_probe.py)
+int livo2_debug_vp_prof(livo2_ctx *ctx, unsigned long long *out) {
+  if (!ctx || !out || !ctx->d_vp_prof) return LIVO2_ERR_INVALID;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, ctx->d_vp_prof, 8 * 32 * 16 * 8, hipMemcpyDeviceToHost));
+  return LIVO2_OK;
+}
 #ifdef LIVO2_PHASE_PROF
 // profiling build only: per-wave stamps of the LAST k_visual_residual launch, [waves][8] (tools/vis_phase.py)
 int livo2_debug_vis_prof(livo2_ctx *ctx, unsigned long long *out, size_t n_waves) {

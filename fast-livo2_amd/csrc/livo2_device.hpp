@@ -155,6 +155,13 @@ __device__ inline void so3_log(const double *R, double *o) {
   else { double f = 0.5 * theta / sin(theta); o[0] = f * K0; o[1] = f * K1; o[2] = f * K2; }
 }
 
+// Out-of-line copies for kernels that call Exp / Log inside a device-side loop: inlined there, the polynomial coefficients of sin / cos / acos are hoisted out of
+// the loop as VGPR constants and, under register pressure, spilled — every use then becomes a dependent scratch load (measured in k_visual_update_persistent).
+struct So3Mat { double v[9]; };
+struct So3Vec { double v[3]; };
+__device__ __attribute__((noinline)) So3Mat so3_exp_call(double v1, double v2, double v3) { So3Mat m; so3_exp(v1, v2, v3, m.v); return m; }
+__device__ __attribute__((noinline)) So3Vec so3_log_call(So3Mat R) { So3Vec o; so3_log(R.v, o.v); return o; }
+
 // LDS hand-off inside ONE wave: orders this wave's LDS writes before its later LDS reads without a workgroup barrier (s_barrier counts every wave of the
 // block, so a phase that only one wave executes must not use __syncthreads())
 __device__ __forceinline__ void wave_sync() {

@@ -3,12 +3,14 @@
 //   k_visual_solve    : reduction + accept/revert + 19x19 solve reference src/vio.cpp:1636-1685
 //   k_visual_finish   : cov -= G*cov, T_f_w                    reference src/vio.cpp:800-801, 1690-1697
 //
-// Mapping: ONE wavefront per patch, one lane per pixel (lane = 8*x + y, x = patch row, y = patch column — the reference's
-// loop order).  The (8+3)^2 strided u8 window is staged once in LDS as float, the 10x10 grid of bilinear samples B is
-// built from it with the reference's float expression, and every lane then reads its 5 samples (centre, +-u, +-v).
+//   k_visual_update_persistent : the WHOLE computeJacobianAndUpdateEKF as one launch (level / iteration loops on the device, one grid barrier per step)
+//
+// Mapping: a wavefront owns FOUR patches (16 lanes each, 4 pixels per lane; pixel p = 8*x + y, x = patch row, y = patch column — the
+// reference's loop order).  The (8+3)^2 strided u8 window is staged once in LDS as float, the 10x10 grid of bilinear samples B is
+// built from it with the reference's float expression, and every lane then reads the 5 samples of each of its pixels (centre, +-u, +-v).
 // All rows of one patch share the patch-constant 2x6 matrix M with  row = [g*M, cur]  (g = image gradient scaled by
-// inv_expo/scale), so H^T H and H^T z are accumulated as 10 per-patch moment sums (wave butterflies) and expanded with M
-// once per patch:  sum J^T J = M^T (sum g g^T) M  etc. instead of a 64M x 7 dense product.
+// inv_expo/scale), so H^T H and H^T z are accumulated as 9 per-patch moment sums (registers, then an LDS transpose tile — no wave
+// butterflies) and expanded with M once per patch:  sum J^T J = M^T (sum g g^T) M  etc. instead of a 64M x 7 dense product.
 #pragma once
 #include "esikf_solve.hpp"
 #include <float.h>
@@ -152,8 +154,11 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
 
 // Four patches per wave (the body shared by the single-frame and the batched kernel).  patch0 = first patch of this wave.  Returns lane q's value q (q < 37) of the
 // SUM of the wave's patch vectors (slot order).
-template <bool DEBUG_ROWS, bool XB = false>
-__device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const DevCtl *__restrict__ ctl, VisWaveLds &L, int patch0, int lane) {
+// The iterate enters as three pointers (rot_end, pos_end, inv_expo_time): HBM (ctl->cur) in the per-step kernels, LDS in the persistent kernel.
+// errors_out: float[M] (plain / write-through stores), or — TAGGED — uint64[M] words {tag << 32 | float bits} written with one 8-byte write-through store each.
+template <bool DEBUG_ROWS, bool XB = false, bool TAGGED = false>
+__device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const int level, const double *Rwi, const double *Pwi, const double *tau_p, float *errors_out,
+                                                   VisWaveLds &L, int patch0, int lane, uint32_t tag = 0) {
   const int slot = lane / VIS_LPP, j = lane % VIS_LPP;
   const VisRC rc = vis_rc(lane);
   const int patch_raw = patch0 + slot;
@@ -165,9 +170,8 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   const double inv_ref_expo = a.inv_expo[patch];
   float Pref[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) Pref[k] = a.warp[((size_t)patch * a.L + a.level) * 64 + j + VIS_LPP * k];
-  const double *Rwi = ctl->cur.rot, *Pwi = ctl->cur.pos;
-  const double tau = ctl->cur.inv_expo;
+  for (int k = 0; k < 4; k++) Pref[k] = a.warp[((size_t)patch * a.L + level) * 64 + j + VIS_LPP * k];
+  const double tau = *tau_p;
   VPHASE(1);
   double Rcw[9], Pcw[3];
   mat3_mul_Bt(a.Rci, Rwi, Rcw);                            // Rcw = Rci * Rwi^T
@@ -178,7 +182,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   for (int i = 0; i < 3; i++) pf[i] = ((Rcw[i * 3] * p0 + Rcw[i * 3 + 1] * p1) + Rcw[i * 3 + 2] * p2) + Pcw[i];
   double pcx, pcy;
   vis_world2cam(a, pf, pcx, pcy);
-  const int scale = 1 << (a.level + search_level);
+  const int scale = 1 << (level + search_level);
   const float inv_scale = 1.0f / (float)scale;
   const float u_ref = (float)pcx, v_ref = (float)pcy;
   const int u_ref_i = (int)(floorf((float)(pcx / scale)) * (float)scale);
@@ -304,8 +308,15 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   VIS_CHAIN(40, 64)
 #undef VIS_CHAIN
   if (!ok) pe = 0.0f;
-  if (j == 0 && valid) xb_store<XB>(&a.errors[patch], pe);
+  if (j == 0 && valid) {
+    if (TAGGED) xb_store<true>(reinterpret_cast<unsigned long long *>(errors_out) + patch, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(pe));
+    else xb_store<XB>(&errors_out[patch], pe);
+  }
   return out_val;
+}
+template <bool DEBUG_ROWS, bool XB = false>
+__device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const DevCtl *__restrict__ ctl, VisWaveLds &L, int patch0, int lane) {
+  return visual_wave_body<DEBUG_ROWS, XB>(a, a.level, ctl->cur.rot, ctl->cur.pos, &ctl->cur.inv_expo, a.errors, L, patch0, lane);
 }
 
 // the block's 8 wave vectors -> one partial row (fixed order: deterministic)
@@ -382,27 +393,33 @@ __device__ __forceinline__ void lds_issue16(F16 &v, const float *p, float &acc) 
                : "=&v"(v.a), "=&v"(v.b), "=&v"(v.c), "=&v"(v.d), "+v"(acc) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ void lds_land16(F16 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.a), "+v"(v.b), "+v"(v.c), "+v"(v.d)); }
+// the oldest of three batches in flight has landed (LDS returns in order: 8 newer ds_read_b128 may still be outstanding)
+__device__ __forceinline__ void lds_land16_of3(F16 &v) { asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v.a), "+v"(v.b), "+v"(v.c), "+v"(v.d)); }
 __device__ __forceinline__ float add16(float acc, const F16 &v) {
   acc += v.a.x; acc += v.a.y; acc += v.a.z; acc += v.a.w; acc += v.b.x; acc += v.b.y; acc += v.b.z; acc += v.b.w;
   acc += v.c.x; acc += v.c.y; acc += v.c.z; acc += v.c.w; acc += v.d.x; acc += v.d.y; acc += v.d.z; acc += v.d.w;
   return acc;
 }
+// Three batches of 16 values are kept in flight: with one batch ahead the chain stalled at every hand-over (measured 12.5 cycles per element: the LDS round trip of
+// four ds_read_b128 is longer than the 16 dependent adds it was supposed to hide behind).
 __device__ __forceinline__ float float_chain(const float *e, int lo, int hi, float acc) {
   int i = lo;
   for (; i < hi && (i & 3); i++) acc += e[i];
-  if (i + 16 <= hi) {
-    F16 A, B;
-    lds_issue16(A, e + i, acc); lds_land16(A);
-    for (; i + 48 <= hi; i += 32) {
-      lds_issue16(B, e + i + 16, acc);
-      acc = add16(acc, A);
-      lds_land16(B);
-      lds_issue16(A, e + i + 32, acc);
-      acc = add16(acc, B);
-      lds_land16(A);
+  if (i + 48 <= hi) {
+    F16 A, B, C;
+    lds_issue16(A, e + i, acc); lds_issue16(B, e + i + 16, acc); lds_issue16(C, e + i + 32, acc);
+    for (; i + 96 <= hi; i += 48) {
+      lds_land16_of3(A); acc = add16(acc, A); lds_issue16(A, e + i + 48, acc);
+      lds_land16_of3(B); acc = add16(acc, B); lds_issue16(B, e + i + 64, acc);
+      lds_land16_of3(C); acc = add16(acc, C); lds_issue16(C, e + i + 80, acc);
     }
-    acc = add16(acc, A);
-    i += 16;
+    lds_land16(C);                                           // everything has landed
+    acc = add16(acc, A); acc = add16(acc, B); acc = add16(acc, C);
+    i += 48;
+  }
+  if (i + 16 <= hi) {
+    F16 A;
+    for (; i + 16 <= hi; i += 16) { lds_issue16(A, e + i, acc); lds_land16(A); acc = add16(acc, A); }
   }
   for (; i < hi; i++) acc += e[i];
   return acc;
@@ -654,3 +671,271 @@ __device__ __forceinline__ void visual_finish_body(DevCtl *__restrict__ ctl, con
 }
 
 __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict__ ctl, VisualKernelArgs a, int update_cov) { visual_finish_body(ctl, a, update_cov); }
+
+// ---- the whole computeJacobianAndUpdateEKF as ONE launch ---------------------------------------------------------------------------------------
+// reference src/vio.cpp:784-802 (level loop, cov -= G*cov, updateFrameState) around updateState 1520-1688.
+//
+// Why: a frame-at-a-time visual update is 4 levels x <= 5 iterations of (residual grid, single-block solve) — 40 dependent launches of which ~13 execute,
+// plus ~7 pairs that start only to read the stop flag (round 2: 42 % of a C4 frame ran on ONE compute unit, 10 % was launches of nothing).  Here the grid
+// stays resident: G blocks (one group of VIS_PPB = 32 patches each while M <= 32 G), and per (level, iteration) step
+//   1. every block evaluates its patches from the iterate it holds in LDS and publishes its partial row + per-patch errors,
+//   2. EVERY block collects all G rows and the M errors and runs the reduction, the float error chain, the accept / revert decision and the 19-dim solve
+//      REDUNDANTLY — same instructions on same data, so all blocks hold the same new iterate bit for bit and no second hand-off (solve -> publish ->
+//      everyone reloads) exists.  Block 0 alone writes the step trace and, at the end, the result.
+// Hand-off without a barrier: every published 8-byte word carries its own validity — {tag << 32 | 32 payload bits}, tag = launch sequence << 8 | step + 1 —
+// and is written with ONE write-through store (an aligned 8-byte store is single-copy atomic); a double travels as two such words.  A reader loads with
+// cache-bypassing loads and simply re-loads the words whose tag is not yet the step's: no arrival counter, no store-drain wait, no fence — the data is its own
+// flag, and a stale value (previous step: other buffer parity; previous launch: other sequence number) can never be mistaken for a fresh one.
+// Buffers alternate with the step parity: a block can be at most one step ahead of the slowest reader (it cannot finish step k+1 without everyone's row of
+// step k+1, and whoever wrote that has finished reading step k).
+// The loops end on the device: a level that stops after two iterations costs two steps, not five launch pairs.
+// Bit-compatibility: the residual body, the order in which rows are added, the error chain and the solve are the code of the per-step kernels; with one
+// patch group per block the partial rows are the same too, so the result equals the launch-per-step path bit for bit (tests/test_visual_gpu.py).
+// Co-residency: the host launches at most as many blocks as the device holds at once (occupancy query, in-flight accounting across contexts, else it falls
+// back to the per-step launches); a word that does not arrive within ~2 s sets hdr.pad[0] and every block leaves (livo2_visual_update_fetch reports it).
+#define VP_MAX_BLOCKS 256
+struct VisPersistArgs {
+  VisualKernelArgs a;
+  unsigned long long *rows;     // [2][G][VIS_PSTRIDE][2]: every double as two words {tag << 32 | low half}, {tag << 32 | high half}
+  unsigned long long *errs;     // [2][M]: {tag << 32 | float bits}
+  int32_t levels, max_iterations, error_threads;
+  uint32_t tag_base;            // launch sequence number << 8
+  double img_point_cov;
+  unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 8][step < 32][16] stamps of the 100 MHz clock, else null
+};
+#define VPP(k) do { if (p.prof && tid == 0 && blockIdx.x < 8 && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define VPP_W(k, w) do { if (p.prof && tid == (w) * LIVO2_WAVE && blockIdx.x < 8 && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+struct __attribute__((aligned(16))) VisPersistLds {
+  union {
+    struct { VisWaveLds lds[VIS_WAVES]; double red[VIS_WAVES][VIS_PSTRIDE]; } r;
+    struct { float errs[VIS_ERR_STAGE]; double scratch[12 * 41]; double sums[64]; float err_chunk[LIVO2_WAVE]; double cov[DS * DS]; } s;
+  } u;
+  SolveLds s;                   // s.P = cov / img_point_cov (constant over the update: `state += solution` leaves cov alone), s.cur / s.prop = the iterate / the prior
+  double old[25];               // old_state (vio.cpp:1523, 1650, 1679), scalars only (cov never differs)
+  double Gfull[DS * DS];        // G as the reference keeps it: written on accepted steps only (vio.cpp:1655-1665), zero-padded 19 x 19
+  float last_error, err_total;
+  int stop, n_steps, timed_out, stop_if_accepted;
+};
+
+__device__ __forceinline__ void vis_log_lds(SolveLds &s) {           // Log(cur^T prop) from the LDS copies (esikf_log_lane reads HBM)
+  double rotd[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) rotd[i * 3 + j] = (s.cur[i] * s.prop[j] + s.cur[3 + i] * s.prop[3 + j]) + s.cur[6 + i] * s.prop[6 + j];
+  double l[3]; so3_log(rotd, l);
+  s.vec[0] = l[0]; s.vec[1] = l[1]; s.vec[2] = l[2];
+}
+
+typedef unsigned long long vp_word;
+__device__ __forceinline__ vp_word vp_ld(const vp_word *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void vp_st(vp_word *p, vp_word v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(VIS_BLOCK) k_visual_update_persistent(VisPersistArgs p, DevCtl *__restrict__ ctl) {
+  __shared__ VisPersistLds SL;
+  SolveLds &s = SL.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = (int)gridDim.x, M = p.a.M;
+  const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
+  // ---- entry: the iterate, the prior, P' = cov / img_point_cov, the G the reference would still hold (all blocks read the same words)
+  {
+    double craw[6];
+    if (wave == 0) esikf_prefetch_wave(ctl, s, p.img_point_cov, lane, craw);
+    for (int e = tid; e < DS * DS; e += VIS_BLOCK) SL.Gfull[e] = ctl->G[e];
+    if (tid == 0) { SL.last_error = FLT_MAX; SL.stop = 0; SL.n_steps = 0; SL.timed_out = 0; }
+  }
+  __syncthreads();
+  if (tid < 25) SL.old[tid] = s.cur[tid];
+  int step_global = 0, last_buf = 0;
+  const VisualKernelArgs &a = p.a;
+  for (int level = p.levels - 1; level >= 0 && !SL.timed_out; level--) {
+    for (int it = 0; it < p.max_iterations; it++) {
+      const int buf = step_global & 1;
+      const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
+      vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
+      vp_word *errs = p.errs + (size_t)buf * M;
+      VPP(0);
+      // Per-thread index arithmetic (window offsets, row addresses, lane predicates, ...) is loop-invariant; hoisted out of the step loop it has to live in
+      // registers across every phase: the compiler filled all 256 VGPRs with it and spilled the rest (62 VGPRs + 130 SGPRs to scratch, reloaded in every phase).
+      // The thread index is therefore re-materialised opaquely once per step, and everything derived from it stays inside the step.
+      int tid_o = threadIdx.x;
+      asm volatile("" : "+v"(tid_o));
+      const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int lane_s = lane;
+      // ---- 1. residual of this block's patch groups; the row and the errors are published as tagged words
+      double out_val = 0.0;
+      for (int g = blockIdx.x; g < ngroups; g += G) {
+        const int patch0 = (g * VIS_WAVES + wave) * VIS_PPW;
+        if (patch0 < M) out_val += visual_wave_body<false, true, true>(a, level, s.cur, s.cur + 9, s.cur + 12, reinterpret_cast<float *>(errs), SL.u.r.lds[wave], patch0, lane_s, tag);
+        if (g + G < ngroups) wave_sync();
+      }
+      VPP(1);
+      if (lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
+      __syncthreads();
+      if (tid < VIS_PSTRIDE) {
+        double v = SL.u.r.red[0][tid];
+#pragma unroll
+        for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[w][tid];
+        const vp_word bits = (vp_word)__double_as_longlong(v), hi = (vp_word)tag << 32;
+        vp_word *dst = rows + ((size_t)blockIdx.x * VIS_PSTRIDE + tid) * 2;
+        vp_st(dst, hi | (bits & 0xffffffffull)); vp_st(dst + 1, hi | (bits >> 32));
+      }
+      if (tid == LIVO2_WAVE) vis_log_lds(s);                    // rotation part of vec = prior [-] iterate, while the words travel
+      last_buf = buf;
+      VPP(2);
+      // ---- 2. collect: all G rows and the M errors; words of blocks that are not there yet are simply loaded again
+      {
+        const int tid_c = tid;
+        const int kidx = tid_c % VIS_PSTRIDE, slice = tid_c / VIS_PSTRIDE;
+        const int n_stage = min(VIS_ERR_STAGE, M);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        double acc = 0.0;
+        vp_word ev[VIS_ERR_STAGE / 512];
+        uint32_t eneed = 0, ehave = 0;
+#pragma unroll
+        for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (tid_c + 512 * u < n_stage) eneed |= 1u << u;
+        for (int base = 0; base < G; base += 12 * 12) {          // (same order of additions as k_visual_solve: rows slice, slice + 12, ... per thread)
+          vp_word lo[12], hi[12];
+          uint32_t need = 0, have = 0;
+#pragma unroll
+          for (int u = 0; u < 12; u++) if (tid_c < VIS_SOLVE_THREADS && base + slice + 12 * u < G) need |= 1u << u;
+          while (have != need || ehave != eneed) {
+            const uint32_t todo = need & ~have, etodo = eneed & ~ehave;
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+              if (todo >> u & 1u) { const vp_word *src = rows + ((size_t)(base + slice + 12 * u) * VIS_PSTRIDE + kidx) * 2; lo[u] = vp_ld(src); hi[u] = vp_ld(src + 1); }
+#pragma unroll
+            for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (etodo >> u & 1u) ev[u] = vp_ld(errs + tid_c + 512 * u);
+#pragma unroll
+            for (int u = 0; u < 12; u++) if ((todo >> u & 1u) && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag) have |= 1u << u;
+#pragma unroll
+            for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if ((etodo >> u & 1u) && (uint32_t)(ev[u] >> 32) == tag) ehave |= 1u << u;
+            if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { SL.timed_out = 1; break; } }
+          }
+#pragma unroll
+          for (int u = 0; u < 12; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((lo[u] & 0xffffffffull) | (hi[u] << 32)));
+        }
+        {
+          const uint32_t need = eneed;
+          __syncthreads();                                       // every wave is done with the tiles of phase 1 (they alias the staging below)
+          if (tid_c < VIS_SOLVE_THREADS) SL.u.s.scratch[slice * 41 + kidx] = acc;
+#pragma unroll
+          for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (need >> u & 1u) SL.u.s.errs[tid_c + 512 * u] = __uint_as_float((uint32_t)ev[u]);
+        }
+        __syncthreads();
+        VPP(3);
+        if (SL.timed_out) break;
+        // ---- 3. reduction + frame error + solve, redundantly in every block (the body of k_visual_solve on LDS state)
+        if (tid < VIS_PSTRIDE) {
+          double rr = SL.u.s.scratch[tid];
+#pragma unroll
+          for (int sl = 1; sl < 12; sl++) rr += SL.u.s.scratch[sl * 41 + tid];
+          SL.u.s.sums[tid] = rr;
+        }
+        __syncthreads();
+        VPP(4);
+        if (wave == 0) {
+          if (lane < 49) {
+            const int rr = lane / 7, c = lane % 7, u = rr < c ? rr : c, v = rr < c ? c : rr;
+            s.hth[lane] = SL.u.s.sums[u * 7 - (u * (u - 1)) / 2 + (v - u)];
+          }
+          if (lane < 7) s.htz[lane] = SL.u.s.sums[28 + lane];
+          wave_sync();
+          VPP(8);
+          esikf_solve_wave<7, true>(s, -1, lane);               // speculative: LDS only (s.sol, s.G, s.newR)
+          if (lane == 0) {                                      // the convergence test of an accepted step (vio.cpp:1675), formed while the error chain still runs
+            const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
+            const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
+            SL.stop_if_accepted = ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) ? 1 : 0;
+          }
+          VPP(9);
+        } else if (wave == 2) {                                 // the frame error in the reference's float accumulation order (k_visual_solve, wave 2)
+          const int T = p.error_threads < 1 ? 1 : (p.error_threads > LIVO2_WAVE ? LIVO2_WAVE : p.error_threads);
+          const int q = M / T, r = M % T;
+          const int my_begin = lane < r ? lane * (q + 1) : lane * q + r, my_end = my_begin + (lane < r ? q + 1 : q);
+          float priv = 0.0f;
+          if (lane < T) {
+            priv = float_chain(SL.u.s.errs, my_begin, min(my_end, n_stage), priv);
+            for (int i = max(my_begin, n_stage); i < my_end; i++) {                 // sub-maps beyond the staging area: straight from the published words
+              vp_word w = vp_ld(errs + i);
+              while ((uint32_t)(w >> 32) != tag) { if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { SL.timed_out = 1; break; } w = vp_ld(errs + i); }
+              priv += __uint_as_float((uint32_t)w);
+            }
+            SL.u.s.err_chunk[lane] = priv;
+          }
+          wave_sync();
+          if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += SL.u.s.err_chunk[c]; SL.err_total = e; }
+          VPP_W(7, 2);
+        }
+        __syncthreads();
+        VPP(5);
+        if (wave == 0) {                                        // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
+          const int n_meas = (int)SL.u.s.sums[36];
+          float error = SL.err_total;
+          error = error / n_meas;
+          const float last_error = (it == 0) ? FLT_MAX : SL.last_error;
+          const bool accepted = error <= last_error;
+          const int step = SL.n_steps;
+          livo2_visual_step *st = (blockIdx.x == 0 && step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) ? &ctl->visual.steps[step] : nullptr;
+          int stop = 0;
+          if (st) {
+            if (lane < 49) st->HtH[lane] = s.hth[lane];
+            if (lane < 7) st->Htz[lane] = s.htz[lane];
+            if (lane < DS) st->solution[lane] = accepted ? s.sol[lane] : 0.0;
+            if (lane == 0) { st->level = level; st->iteration = it; st->accepted = accepted ? 1 : 0; st->n_meas = n_meas; st->error = error; st->pad = 0; }
+          }
+          if (accepted) {
+            stop = SL.stop_if_accepted;
+            double nv = 0.0;
+            if (lane < 9) nv = s.newR[lane]; else if (lane < 25) nv = s.cur[lane] + s.sol[lane - 6];
+            if (lane < 25) { SL.old[lane] = s.cur[lane]; s.cur[lane] = nv; }                              // old_state = *state ; *state += solution
+            if (lane < DS) {
+#pragma unroll
+              for (int c = 0; c < KMAX; c++) SL.Gfull[lane * DS + c] = s.G[lane * KMAX + c];
+            }
+          } else {
+            if (it > 0 && lane < 25) s.cur[lane] = SL.old[lane];                                           // *state = old_state ; EKF_end
+            stop = 1;
+          }
+          if (lane == 0) { if (accepted) SL.last_error = error; SL.stop = stop; SL.n_steps = step + 1; }
+        }
+        __syncthreads();
+        VPP(6);
+      }
+      step_global++;
+      if (SL.stop) break;
+    }
+    if (SL.timed_out) break;
+  }
+  __syncthreads();
+  // ---- every block: errors[] of the LAST evaluated step for its own patches (visual_submap->errors, vio.cpp:1632)
+  {
+    const vp_word *errs = p.errs + (size_t)last_buf * M;
+    for (int g = blockIdx.x; g < ngroups; g += G) {
+      const int patch = g * VIS_PPB + tid;
+      if (tid < VIS_PPB && patch < M) a.errors[patch] = __uint_as_float((uint32_t)vp_ld(errs + patch));
+    }
+  }
+  if (blockIdx.x != 0) return;
+  // ---- block 0: the result.  state->cov -= G * state->cov (vio.cpp:800), updateFrameState (vio.cpp:1690-1697)
+  for (int e = tid; e < DS * DS; e += VIS_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
+  __syncthreads();
+  double *dst = reinterpret_cast<double *>(&ctl->visual.state);
+  for (int e = tid; e < DS * DS; e += VIS_BLOCK) {
+    const int r = e / DS, c = e % DS;
+    double g = SL.Gfull[r * DS] * SL.u.s.cov[c];
+    for (int k = 1; k < DS; k++) g = g + SL.Gfull[r * DS + k] * SL.u.s.cov[k * DS + c];
+    const double v = SL.u.s.cov[e] - g;
+    ctl->cur.cov[e] = v; dst[25 + e] = v;
+    ctl->G[e] = SL.Gfull[e]; ctl->visual.G[e] = SL.Gfull[e];
+  }
+  if (tid < 25) { reinterpret_cast<double *>(&ctl->cur)[tid] = s.cur[tid]; dst[tid] = s.cur[tid]; }
+  if (tid == 0) {
+    double Rcw[9];
+    mat3_mul_Bt(a.Rci, s.cur, Rcw);
+    for (int j = 0; j < 9; j++) ctl->visual.Rcw[j] = Rcw[j];
+    for (int j = 0; j < 3; j++) ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * s.cur[9] + Rcw[j * 3 + 1] * s.cur[10]) + Rcw[j * 3 + 2] * s.cur[11]);
+    ctl->visual.n_steps = SL.n_steps; ctl->hdr.n_steps = SL.n_steps; ctl->hdr.last_error = SL.last_error; ctl->hdr.stop = SL.stop;
+    ctl->hdr.pad[0] = SL.timed_out;
+  }
+}

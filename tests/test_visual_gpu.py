@@ -142,7 +142,11 @@ def test_fused_step_kernel_gives_the_same_bits(livo2, ctx):
     cfg = H.visual_cfg_product(vs, mp_proc_num=4)
     cur, prop = H.states(vs, livo2.State)
     ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-    ref, ref_err = ctx.visual_update(cur, prop, cfg)
+    ctx.set_option("visual_persistent", 0)
+    try:
+        ref, ref_err = ctx.visual_update(cur, prop, cfg)
+    finally:
+        ctx.set_option("visual_persistent", 1)
     os.environ["LIVO2_VISUAL_FUSED"] = "1"
     try:
         c2 = livo2.Context(0)
@@ -154,3 +158,81 @@ def test_fused_step_kernel_gives_the_same_bits(livo2, ctx):
         assert res.n_steps == ref.n_steps and bytes(res.state) == bytes(ref.state) and np.array_equal(err, ref_err)
         assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
     c2.close()
+
+
+@pytest.mark.parametrize("M,threads,kw", [(3000, 4, {}), (4000, 4, {}), (300, 1, {}), (33, 4, {}), (1, 1, {}), (9000, 4, {}), (2000, 3, dict(exposure=False)),
+                                          (1000, 4, dict(distortion=synth.AVIA_RADTAN)), (500, 4, dict(max_iterations=1)), (700, 2, dict(rot_sigma_deg=0.25))])
+def test_persistent_update_gives_the_same_bits_as_the_per_step_launches(livo2, ctx, M, threads, kw):
+    """k_visual_update_persistent (default path): the whole computeJacobianAndUpdateEKF as one resident grid, one grid barrier per (level, iteration), the reduction /
+    error chain / accept-revert / solve run redundantly by every block.  Same residual body, same order of additions, same solve => the same bits as the
+    launch-per-step sequence: state, covariance, G, Rcw / Pcw, every recorded step, errors[].  Repeated: a stale read between workgroups would make it flaky.
+    M = 9000 > 32 x 256: blocks own several patch groups (rows are summed in another order there: tolerance instead of bits)."""
+    skw = {k: v for k, v in kw.items() if k == "rot_sigma_deg"}
+    ckw = {k: v for k, v in kw.items() if k != "rot_sigma_deg"}
+    vs = synth.visual_scenario(seed=90 + threads + M % 7, n_patches=M, **skw)
+    cfg = H.visual_cfg_product(vs, mp_proc_num=threads, **ckw)
+    cur, prop = H.states(vs, livo2.State)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    ctx.set_option("visual_persistent", 0)
+    try:
+        ref, ref_err = ctx.visual_update(cur, prop, cfg)
+    finally:
+        ctx.set_option("visual_persistent", 1)
+    n0 = ctx.counter("visual_persistent_launches")
+    for _ in range(10):
+        res, err = ctx.visual_update(cur, prop, cfg)
+        assert res.n_steps == ref.n_steps
+        assert [(res.steps[j].level, res.steps[j].iteration, res.steps[j].accepted, res.steps[j].error) for j in range(res.n_steps)] == \
+               [(ref.steps[j].level, ref.steps[j].iteration, ref.steps[j].accepted, ref.steps[j].error) for j in range(ref.n_steps)]
+        assert np.array_equal(err, ref_err)
+        if M <= 32 * 256:
+            assert bytes(res.state) == bytes(ref.state) and bytes(res.G) == bytes(ref.G) and bytes(res.Rcw) == bytes(ref.Rcw) and bytes(res.Pcw) == bytes(ref.Pcw)
+            assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
+        else:
+            d = H.state_diff(res.state, ref.state)
+            assert d["R"] < 1e-12 and d["t"] < 1e-12 and d["P"] < 1e-12, d
+    assert ctx.counter("visual_persistent_launches") == n0 + 10 and ctx.counter("visual_persistent_fallbacks") == 0
+
+
+def test_persistent_update_matches_oracle_with_reverts(livo2, ctx, orc):
+    """the persistent path against the oracle on scenes where levels end by a rejected step (state restored from old_state, vio.cpp:1677-1681)"""
+    seen = False
+    for seed in range(20, 26):
+        vs = synth.visual_scenario(seed=seed, n_patches=200, rot_sigma_deg=0.25)
+        ocur, oprop = H.states(vs, orc.StatePOD)
+        ref = orc.visual_update(orc.visual_cfg(vs, num_threads=4), vs, ocur, oprop)
+        cur, prop = H.states(vs, livo2.State)
+        ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+        res, err = ctx.visual_update(cur, prop, H.visual_cfg_product(vs, mp_proc_num=4))
+        assert [(res.steps[j].level, res.steps[j].iteration, res.steps[j].accepted, res.steps[j].error) for j in range(res.n_steps)] == \
+               [(t.level, t.iteration, t.accepted, t.error) for t in ref["trace"]]
+        seen = seen or any(not t.accepted for t in ref["trace"])
+        d = H.state_diff(res.state, ref["state"])
+        assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-8, d
+        assert np.array_equal(err, ref["errors"])
+    assert seen
+
+
+def test_concurrent_persistent_contexts(livo2):
+    """four contexts, each on its own stream and host thread, run persistent updates at the same time: admission keeps the resident grids within the device
+    (the ones that do not fit take the per-step path), nothing deadlocks, every result equals the single-context one"""
+    import threading
+    vs = synth.visual_scenario(seed=61, n_patches=4000)
+    cfg = H.visual_cfg_product(vs, mp_proc_num=4)
+    cur, prop = H.states(vs, livo2.State)
+    ctxs = [livo2.Context(0) for _ in range(4)]
+    for c in ctxs:
+        c.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    ref, ref_err = ctxs[0].visual_update(cur, prop, cfg)
+    bad = []
+    def work(c):
+        for _ in range(25):
+            res, err = c.visual_update(cur, prop, cfg)
+            if bytes(res.state) != bytes(ref.state) or not np.array_equal(err, ref_err):
+                bad.append(1)
+    th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+    [t.start() for t in th]; [t.join() for t in th]
+    used = sum(c.counter("visual_persistent_launches") for c in ctxs)
+    for c in ctxs:
+        c.close()
+    assert not bad and used >= 26
