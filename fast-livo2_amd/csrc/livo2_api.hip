@@ -148,6 +148,7 @@ struct livo2_ctx {
   int32_t *mt_idx = nullptr, *mt_order = nullptr, *mt_head = nullptr, *mt_slot = nullptr, *mt_seg_begin = nullptr, *mt_seg_root = nullptr, *mt_nseg = nullptr;
   size_t mt_idx_cap = 0, mt_order_cap = 0, mt_head_cap = 0, mt_slot_cap = 0, mt_seg_begin_cap = 0, mt_seg_root_cap = 0;
   livo2_state *mt_state = nullptr;
+  int32_t *mt_rp_rows = nullptr; size_t mt_rp_rows_cap = 0; double *mt_rp_out = nullptr; size_t mt_rp_out_cap = 0;   // livo2_map_tree_read_planes staging
   double mt_kernel_us = 0.0;
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
@@ -589,7 +590,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof};
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -1005,7 +1006,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
   {
     std::vector<RootSlot> empty(cap);
-    for (auto &sl : empty) sl.val = -1;
+    for (auto &sl : empty) { sl.val = -1; sl.kx = sl.ky = sl.kz = MT_NO_KEY; sl.pad = -1; }
     HIPCHK(hipMemcpy(ctx->d_slots, empty.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemset(m.counters, 0, MTC_TOTAL * 4));
@@ -1094,7 +1095,7 @@ int map_tree_finish(livo2_ctx *ctx) {
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->mt_kernel_us = 1e3 * ms;
   if (c[MTC_ERROR]) {
-    static char msg[160];
+    char msg[200];                                            // (fail() copies it into the ctx's own string)
     std::snprintf(msg, sizeof(msg), "device map tree: capacity / range error bits 0x%x (1 nodes, 2 points, 4 planes, 8 candidate lists, 16 hash table, 32 voxel key range, 64 node region)", c[MTC_ERROR]);
     return fail(ctx, LIVO2_ERR_RANGE, msg);
   }
@@ -1199,15 +1200,15 @@ int livo2_map_tree_read_planes(livo2_ctx *ctx, const int32_t *rows, int32_t n, d
   if (n == 0) return LIVO2_OK;
   for (int i = 0; i < n; i++) if (rows[i] < 0 || rows[i] >= ctx->mt.cap_planes) return fail(ctx, LIVO2_ERR_INVALID, "plane row out of range");
   HIPCHK(hipSetDevice(ctx->device));
-  int32_t *d_rows = nullptr; double *d_out = nullptr;
-  HIPCHK(hipMalloc((void **)&d_rows, (size_t)n * 4));
-  HIPCHK(hipMalloc((void **)&d_out, (size_t)n * PLANE_REC_DOUBLES * 8));
+  // ctx-owned, growable staging (a hipMalloc / hipFree pair per call synchronises the whole device: every other chain on the GPU would stall)
+  int rc = ensure(ctx, ctx->mt_rp_rows, ctx->mt_rp_rows_cap, (size_t)n); if (rc) return rc;
+  rc = ensure(ctx, ctx->mt_rp_out, ctx->mt_rp_out_cap, (size_t)n * PLANE_REC_DOUBLES); if (rc) return rc;
+  int32_t *d_rows = ctx->mt_rp_rows; double *d_out = ctx->mt_rp_out;
   HIPCHK(hipMemcpyAsync(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_mt_gather_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_planes, d_rows, n, d_out);
   std::vector<double> recs((size_t)n * PLANE_REC_DOUBLES);
   HIPCHK(hipMemcpyAsync(recs.data(), d_out, recs.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipFree(d_rows)); HIPCHK(hipFree(d_out));
   for (int p = 0; p < n; p++) {
     const double *rec = &recs[(size_t)p * PLANE_REC_DOUBLES];
     if (normal) for (int k = 0; k < 3; k++) normal[(size_t)p * 3 + k] = rec[k];
@@ -1227,6 +1228,7 @@ int livo2_map_tree_export(livo2_ctx *ctx, int64_t *root_key, int32_t *root_node,
   if (!ctx) return LIVO2_ERR_INVALID;
   if (!ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "no device map tree");
   HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));                  // an update enqueued on the ctx stream must have finished before the blocking copies below read the tree
   int32_t c[MTC_COUNT];
   HIPCHK(hipMemcpy(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost));
   const int nn = std::min(c[MTC_NODES], ctx->mt.cap_nodes), np = std::min(c[MTC_PLANES], ctx->mt.cap_planes);

@@ -18,6 +18,7 @@
 
 #define MT_LPG 8                 // lanes per root voxel
 #define MT_SLAB 52               // points a node's temp_points_ region holds by default (max_points_num_ 50 + the point that trips the limit + 1)
+#define MT_NO_KEY INT32_MIN     // key of an empty root bucket (voxel keys are 21-bit per axis)
 #define MT_STACK (LIVO2_MAX_LAYER + 2)
 enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8,
        // beyond what livo2_map_tree_stats reports: tops of the free stacks that mapSliding fills (k_mt_slide) and the allocators drain, root voxels it removed
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(256) k_mt_segments(const int32_t *__restrict__
 // ---- allocation ----------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int mt_alloc(const MapTreeArgs &a, int which, int count, int cap, int errbit) {      // one lane calls; -1 when the pool is exhausted
   const int at = atomicAdd(&a.counters[which], count);
-  if (at + count > cap) { mt_error(a, errbit); return -1; }
+  if (at + count > cap) { atomicSub(&a.counters[which], count); mt_error(a, errbit); return -1; }      // rolled back: the pool stays usable for requests that still fit
   return at;
 }
 // what mapSliding released comes back first (the stacks are only pushed by k_mt_slide, never while an update runs: a pop is one atomic)
@@ -186,9 +187,13 @@ template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_roots(MapTre
   mt_unpack(a.skeys[b], key);
   const uint32_t h1 = voxel_hash(key[0], key[1], key[2], a.seed1) & a.mask, h2 = voxel_hash(key[0], key[1], key[2], a.seed2) & a.mask;
   const uint32_t hh[2] = {h1, h2};
+  // Another thread of this launch may be half-way through claiming one of the two buckets (val == -3, key / pad not yet written): such a bucket holds either the
+  // empty-slot sentinel key (MT_NO_KEY: set at creation and by k_mt_slide, no voxel has it) or the claimer's key, which is not ours (one thread per distinct key) —
+  // it can never be mistaken for our root.  A finished bucket (val >= -2) was published behind a fence; the value word is read first, with acquire semantics.
   for (int t = 0; t < 2; t++) {
     const RootSlot &s = a.slots[hh[t]];
-    if (s.val != -1 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]) { a.seg_root[g] = s.pad; return; }
+    const int32_t val = __hip_atomic_load(&s.val, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (val != -1 && val != -3 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]) { a.seg_root[g] = s.pad; return; }
   }
   // new root voxel (voxel_map.cpp:574-583 / 630-637)
   const int cap = a.build ? max(MT_SLAB, e - b + 1) : MT_SLAB;
@@ -538,6 +543,7 @@ __global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
     nd.root = -1; nd.layer = -1; nd.plane = -1; nd.is_plane = 0;          // (livo2_map_tree_export recognises roots by layer == 0 && root == id)
     mt_free_nodes(a)[atomicAdd(&a.counters[MTC_FREE_NODES], 1)] = id;
   }
+  s->kx = s->ky = s->kz = MT_NO_KEY; s->pad = -1;              // an empty bucket matches no voxel, whatever val a concurrent claim puts there later
   s->val = -1;
   atomicSub(&a.counters[MTC_ROOTS], 1);
   atomicAdd(&a.counters[MTC_REMOVED], 1);

@@ -11,14 +11,7 @@ def product():
 
 
 def lidar_cfg_product(sc, max_iterations=None):
-    livo2 = product()
-    c = livo2.LidarCfg()
-    c.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
-    c.max_layer = int(sc.cfg["max_layer"])
-    c.sigma_num, c.dept_err, c.beam_err, c.voxel_size, c.deg2rad = float(sc.cfg["sigma_num"]), float(sc.cfg["dept_err"]), float(sc.cfg["beam_err"]), float(sc.cfg["voxel_size"]), 0.017453293
-    c.extR[:] = sc.extR.ravel().tolist()
-    c.extT[:] = sc.extT.tolist()
-    return c
+    return importlib.import_module("fast-livo2_amd.configs").lidar_cfg(sc, max_iterations)
 
 
 def states(sc, cls, R=None, t=None, inv_expo=1.0):
@@ -28,20 +21,8 @@ def states(sc, cls, R=None, t=None, inv_expo=1.0):
     return cur, prior
 
 
-def visual_cfg_product(sc, exposure=True, max_iterations=None, inverse=False, mp_proc_num=1, distortion=None):
-    livo2 = product()
-    c = livo2.VisualCfg()
-    c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = sc.cam["fx"], sc.cam["fy"], sc.cam["cx"], sc.cam["cy"]
-    c.cam.distortion, c.cam.width, c.cam.height = 0, sc.cam["width"], sc.cam["height"]
-    c.Rcl[:] = sc.Rcl.ravel().tolist(); c.Pcl[:] = sc.Pcl.tolist(); c.extR[:] = sc.extR.ravel().tolist(); c.extT[:] = sc.extT.tolist()
-    c.img_point_cov = float(sc.cfg["img_point_cov"])
-    c.patch_pyrimid_level = int(sc.cfg["patch_pyrimid_level"])
-    c.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
-    c.exposure_estimate_en, c.inverse_composition_en, c.mp_proc_num = int(exposure), int(inverse), int(mp_proc_num)
-    if distortion is not None:                      # radial-tangential d0..d4 of vk::PinholeCamera
-        c.cam.distortion = 1
-        c.cam.d[:] = [float(x) for x in distortion]
-    return c
+def visual_cfg_product(sc, **kw):
+    return importlib.import_module("fast-livo2_amd.configs").visual_cfg(sc, **kw)
 
 
 def relerr(a, b):

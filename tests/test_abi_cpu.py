@@ -82,12 +82,18 @@ def test_product_does_not_import_oracle():
                 if f.endswith((".py", ".sh", ".h")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(sub, f)
+                    assert "from tests" not in txt and "import tests" not in txt, os.path.join(sub, f)       # tests/helpers.py imports the oracle at module load
     import ast
     tree = ast.parse(open(os.path.join(root, "bench.py")).read())
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in ast.walk(fn))
         assert uses == (fn.name == "cpu_baseline"), fn.name
     assert not any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in tree.body)
+    # the timed GPU legs of bench.py take nothing from tests/ either: only the cpu_baseline legs do
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "tests" for n in ast.walk(fn))
+        assert not uses or fn.name in ("cpu_baseline", "cpu_widened_rows"), fn.name
+    assert not any(isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "tests" for n in tree.body)
     tree = ast.parse(open(os.path.join(root, "__graft_entry__.py")).read())
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and n.module == "oracle" for n in ast.walk(fn))

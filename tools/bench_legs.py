@@ -192,7 +192,7 @@ def _live_leg(ctx, w, extra):
 def _c2_legs(ctx, livo2, synth, H, args, extra, copy_gbs, legs):
     # ---- C2 (BASELINE configs[1], the round-1 headline): 100k-ray scan -> 0.1 m voxel grid, ONE ESIKF iteration per step ------------------------------
     sc2 = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12, downsample=synth.AVIA["filter_size_surf"])
-    cfg2 = H.lidar_cfg_product(sc2)
+    cfg2 = H.lidar_cfg(sc2)
     cur2, _ = make_states(livo2, sc2)
     n2 = len(sc2.xyz)
     ctx.upload_map(sc2.fmap); ctx.set_scan(sc2.xyz, cfg2)
@@ -214,7 +214,7 @@ def _c3_leg(ctx, livo2, synth, H, extra, sc2, cfg2, cur2, n2):
     steps = 200
     # C3 (configs[2]): C2 LiDAR iteration + 2k-patch visual iteration in flight together on two streams of this GPU
     vs3 = synth.visual_scenario(seed=3, n_patches=2000)
-    vcfg3 = H.visual_cfg_product(vs3)
+    vcfg3 = H.visual_cfg(vs3)
     vcur3, _ = make_states(livo2, vs3)
     ctx_v = livo2.Context(ctx.device)
     ctx_v.set_frame(vs3.img, vs3.pos, vs3.warp_patch, vs3.search_levels, vs3.inv_expo_list)
@@ -298,7 +298,7 @@ def _map_update_leg(ctx, livo2, synth, H, extra):
         rows = []
         for xyz, Rk, tk in frames:
             sc = synth.LidarScenario(None, xyz, Rk, tk, Rk @ synth.so3_exp(np.array([0.003, -0.002, 0.004])), tk + np.array([0.015, -0.01, 0.008]), synth.prior_cov(np.random.default_rng(3)), extR, extT, c)
-            cfg = H.lidar_cfg_product(sc)
+            cfg = H.lidar_cfg(sc)
             cur, prop = make_states(livo2, sc)
             t1 = time.perf_counter(); ctx.set_scan(xyz, cfg); t2 = time.perf_counter()
             res, _ = ctx.lidar_update(cur, prop, cfg); t3 = time.perf_counter()
@@ -384,11 +384,11 @@ def widened_rows(ctx, livo2, synth, H, sc, cfg):
     # reference's budget for this is 100 ms per frame on <= 4 host threads
     sc1 = synth.lidar_scenario(seed=1, n_points=10000, downsample=0.1)
     raw1 = synth.raw_scan_scenario(seed=1, n_raw=24000)
-    cfg1 = H.lidar_cfg_product(sc1)
+    cfg1 = H.lidar_cfg(sc1)
     cur1, prop1 = make_states(livo2, sc1)
     rs1 = synth.retrieve_scenario(seed=2, n_cand=400)
     vs1 = synth.visual_scenario(seed=3, n_patches=8); vs1.img, vs1.cam = rs1.img, rs1.cam
-    vcfg1 = H.visual_cfg_product(vs1)
+    vcfg1 = H.visual_cfg(vs1)
     vcur1, vprop1 = make_states(livo2, vs1)
     fpw1, fvar1, foff1 = plane_fit_groups(n_groups=800, seed=5)
     ctx.upload_map(sc1.fmap)
@@ -412,7 +412,7 @@ def widened_rows(ctx, livo2, synth, H, sc, cfg):
     # three stages called one after the other, on a raw scan that is registered to its map
     try:
         lf = synth.lio_frame_scenario(seed=61, n_raw=24000, n_steps=20)
-        lcfg = H.lidar_cfg_product(lf.sc)
+        lcfg = H.lidar_cfg(lf.sc)
         lst = livo2.State.from_pose(lf.sc.R_prior, lf.sc.t_prior, lf.sc.P)
         lst.inv_expo = lf.inv_expo; lst.vel[:] = lf.vel.tolist(); lst.bg[:] = lf.bg.tolist(); lst.ba[:] = lf.ba.tolist(); lst.grav[:] = lf.grav.tolist()
         licfg = livo2.ImuCfg()
@@ -440,7 +440,7 @@ def widened_rows(ctx, livo2, synth, H, sc, cfg):
         extra["lio_frame"] = {"error": repr(exc)}
     ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
     # IMU forward propagation (20 samples = 100 ms at 200 Hz)
-    from tests import imu_inputs as IMU
+    from scenarios import imu_inputs as IMU
     ist = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P); ist.grav[:] = [0.0, 0.0, -9.81]
     icfg = livo2.ImuCfg()
     for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):

@@ -13,7 +13,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from scenarios import synth  # noqa: E402
-from tests import helpers as H  # noqa: E402
+import importlib as _il  # noqa: E402
+H = _il.import_module("fast-livo2_amd.configs")  # noqa: E402
 
 livo2 = importlib.import_module("fast-livo2_amd")
 abi = livo2.abi
@@ -34,9 +35,9 @@ for suffix in (args or [""]):
     ctx = livo2.Context(0)
     row = [(suffix or "lib") + " block=" + os.environ.get("LIVO2_LIDAR_BLOCK", "auto")]
     for s in (sc, small):
-        cfg = H.lidar_cfg_product(s)
+        cfg = H.lidar_cfg(s)
         ctx.upload_map(s.fmap); ctx.set_scan(s.xyz, cfg)
-        cur, prop = H.states(s, livo2.State)
+        cur, prop = H.prior_states(s)
         ctx.lidar_iterations_async(cur, prop, cfg, 20); ctx.synchronize()
         best = 1e9
         for _ in range(3):

@@ -17,7 +17,8 @@ def main():
     livo2 = importlib.import_module("fast-livo2_amd")
     livo2.abi.LIB_PATH = os.path.join(ROOT, "fast-livo2_amd", "lib", "liblivo2_hip_prof.so")
     from scenarios import synth
-    from tests import helpers as H
+    import importlib as _il
+    H = _il.import_module("fast-livo2_amd.configs")
     import bench
     from tools import bench_legs
     if order == "c4":
@@ -26,7 +27,7 @@ def main():
         sc = synth.lidar_scenario(seed=2, n_points=100000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays_factor=12,
                                   downsample=(0.1 if order == "voxelgrid" else None))
     ctx = livo2.Context(0)
-    cfg = H.lidar_cfg_product(sc)
+    cfg = H.lidar_cfg(sc)
     ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
     cur, prop = bench_legs.make_states(livo2, sc)
     ctx.lidar_iterations_async(cur, prop, cfg, 10); ctx.synchronize()

@@ -24,14 +24,13 @@ def cfg_of(vs, mp=4):
 
 
 def main():
-    from oracle import orc as _o   # only for make_state (struct filling)
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ctx = livo2.Context(0)
     for seed in (4, 5):
         vs = synth.visual_scenario(seed=seed, n_patches=M)
         cfg = cfg_of(vs)
-        prior = _o.make_state(vs.R_prior, vs.t_prior, vs.P, inv_expo=getattr(vs, "tau_prior", 1.0), cls=livo2.State)
+        prior = livo2.State.from_pose(vs.R_prior, vs.t_prior, vs.P, inv_expo=getattr(vs, "tau_prior", 1.0))
         ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
         for name, opt in (("per-step", 0), ("persistent", 1), ("per-step", 0), ("persistent", 1)):
             ctx.set_option("visual_persistent", opt)

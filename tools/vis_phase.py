@@ -12,12 +12,13 @@ import numpy as np  # noqa: E402
 livo2 = importlib.import_module("fast-livo2_amd")
 livo2.abi.LIB_PATH = os.path.join(ROOT, "fast-livo2_amd", "lib", "liblivo2_hip_prof.so")
 from scenarios import synth  # noqa: E402
-from tests import helpers as H  # noqa: E402
+import importlib as _il  # noqa: E402
+H = _il.import_module("fast-livo2_amd.configs")  # noqa: E402
 
 vs = synth.visual_scenario(seed=5, n_patches=int(sys.argv[1]) if len(sys.argv) > 1 else 4000)
 ctx = livo2.Context(0)
-cfg = H.visual_cfg_product(vs, mp_proc_num=4)
-cur, prop = H.states(vs, livo2.State)
+cfg = H.visual_cfg(vs, mp_proc_num=4)
+cur, prop = H.prior_states(vs)
 ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
 ctx.visual_iterations_async(0, cur, prop, cfg, 20); ctx.synchronize()
 ctx.visual_iterations_async(0, cur, prop, cfg, 5); ctx.synchronize()

@@ -10,7 +10,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from scenarios import synth  # noqa: E402
-from tests import helpers as H  # noqa: E402
+import importlib as _il  # noqa: E402
+H = _il.import_module("fast-livo2_amd.configs")  # noqa: E402
 
 livo2 = importlib.import_module("fast-livo2_amd")
 abi = livo2.abi
@@ -22,8 +23,8 @@ for suffix in (sys.argv[1:] or [""]):
         print(suffix, "missing", path); continue
     abi._lib, abi.LIB_PATH = None, path
     ctx = livo2.Context(0)
-    cfg = H.visual_cfg_product(vs, mp_proc_num=4)
-    cur, prop = H.states(vs, livo2.State)
+    cfg = H.visual_cfg(vs, mp_proc_num=4)
+    cur, prop = H.prior_states(vs)
     ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
     row = [suffix or "base"]
     for level in (0, 3):
