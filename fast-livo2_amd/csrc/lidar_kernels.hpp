@@ -725,10 +725,17 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
   PHASE(6);
 }
 
+// chunks = number of BLOCK-point chunks of the scan (a multiple of 8).  The grid may be SMALLER than that: block b then works through chunks b, b + gridDim, ...
+// (same XCD slab: gridDim is a multiple of 8) — at C4 the scan has 782 chunks against the 512 blocks the chip holds at once, and a second-round block pays the
+// dispatcher, the LDS allocation and the scalar state loads again (measured life: 10.7 us against 7.8 us for a first-round block).  Row `chunk` of `partials`
+// receives the sums whichever block produced them: the reduction order does not depend on the grid.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
-                                                                int check_stop) {
-  lidar_residual_body<BLOCK>(a, ctl, partials, check_stop, (int)blockIdx.x, (int)gridDim.x);
+                                                                int check_stop, int chunks) {
+  for (int pb = (int)blockIdx.x; pb < chunks; pb += (int)gridDim.x) {
+    lidar_residual_body<BLOCK>(a, ctl, partials, check_stop, pb, chunks);
+    if (pb + (int)gridDim.x < chunks) __syncthreads();           // the next chunk's cooperative-visit tiles alias the reduction tiles just read
+  }
 }
 
 // Batched launch: several independent (scan, state) problems against the resident map in ONE grid.  A single 100k-point scan is

@@ -299,9 +299,14 @@ int lidar_block_for(int n) {
 void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop);
 
 void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop) {
-  const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
-  if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop);
-  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop);
+  const int chunks = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
+  // LIVO2_LIDAR_RESIDENT=<blocks>: a resident grid looping over the chunks instead of one block per chunk (default).  Measured at C4 (782 chunks): 512 resident
+  // blocks 26.5 us, 384: 26.4, 640: 24.5 against 24.7 us for one block per chunk — a static chunk -> block assignment loses more to the cluttered chunks than
+  // it saves in block start-up; the hardware dispatcher's dynamic placement stays (profiles/r03_lidar_resident_grid_probe.txt).
+  static const int resident = [] { const char *e = std::getenv("LIVO2_LIDAR_RESIDENT"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (v + 7) / 8 * 8 : 0; }();
+  const int grid = resident > 0 ? std::min(chunks, resident * (ctx->lidar_block == 128 ? 2 : 1)) : chunks;
+  if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks);
+  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks);
 }
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {

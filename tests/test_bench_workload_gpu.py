@@ -82,7 +82,9 @@ def test_headline_frames_match_oracle(ctx, c4, oracle_results):
 
 
 def test_lockstep_batch_equals_single_updates_and_oracle(ctx, c4, oracle_results):
-    """extra.c4_lockstep: the same 8 frame updates as ONE batch per launch — bit-equal to the 8 single updates, and equal to the oracle"""
+    """extra.c4_lockstep: the same 8 frame updates as ONE batch per launch, against the 8 single updates and the oracle.  Visual: bit-equal (same bodies, same
+    per-frame reduction order).  LiDAR: the batch grid uses 64-point blocks (single scans: 256), so its partial sums are added in another order — identical
+    decisions (iteration counts, n_eff), states to rounding."""
     sc, vs, cfg, vcfg, lid, vis = c4
     ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
     ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
@@ -96,7 +98,10 @@ def test_lockstep_batch_equals_single_updates_and_oracle(ctx, c4, oracle_results
     rb = ctx.batch_update(lid, lid, cfg)
     vb = ctx.visual_batch_update(vis, vis, vcfg)
     for f in range(F):
-        assert rb[f].n_iters == single[f][0].n_iters and bytes(rb[f].state) == bytes(single[f][0].state)
+        assert rb[f].n_iters == single[f][0].n_iters
+        assert [rb[f].iter_sums[i].n_eff for i in range(rb[f].n_iters)] == [single[f][0].iter_sums[i].n_eff for i in range(rb[f].n_iters)]
+        d = H.state_diff(rb[f].state, single[f][0].state)
+        assert d["R"] < 1e-12 and d["t"] < 1e-12 and d["P"] < 1e-11, d
         assert vb[f].n_steps == single[f][1][0].n_steps and bytes(vb[f].state) == bytes(single[f][1][0].state)
         _check_lidar(rb[f], None, oracle_results[f][0], sc, lid[f])
         _check_visual(vb[f], None, oracle_results[f][1])
