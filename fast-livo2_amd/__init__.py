@@ -24,7 +24,11 @@ def _f64(a):
 
 
 def _cam_distortion(c, cam):
-    """cam["d"] (optional): the five radial-tangential coefficients d0..d4 of vk::PinholeCamera"""
+    """cam["d"] (optional): the five radial-tangential coefficients d0..d4 of vk::PinholeCamera; cam["k"] (optional): k1..k4 of vk::EquidistantCamera"""
+    if cam.get("k") is not None:
+        c.distortion = 2
+        c.d[:] = [float(x) for x in cam["k"]] + [0.0]
+        return
     d = cam.get("d")
     c.distortion = 0 if d is None else 1
     c.d[:] = [0.0] * 5 if d is None else [float(x) for x in d]

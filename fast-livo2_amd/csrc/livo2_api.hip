@@ -499,6 +499,7 @@ int check_visual_cfg(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
   if (ctx->M > 0 && cfg->patch_pyrimid_level > ctx->L) return fail(ctx, LIVO2_ERR_INVALID, "patch_pyrimid_level exceeds the uploaded warp_patch levels");
   if (!(cfg->img_point_cov > 0)) return fail(ctx, LIVO2_ERR_INVALID, "img_point_cov must be > 0");
   if (cfg->mp_proc_num < 0 || cfg->mp_proc_num > LIVO2_WAVE) return fail(ctx, LIVO2_ERR_INVALID, "mp_proc_num out of [0,64]");
+  if (cfg->cam.distortion < 0 || cfg->cam.distortion > LIVO2_CAM_EQUIDISTANT) return fail(ctx, LIVO2_ERR_INVALID, "cam.distortion must be 0 (pinhole), 1 (radtan) or 2 (equidistant)");
   return LIVO2_OK;
 }
 
@@ -976,9 +977,10 @@ int scan_pipeline(livo2_ctx *ctx, int n, const livo2_lidar_cfg *cfg) {
 // ---- device-resident VoxelMap ------------------------------------------------------------------------------------------------------------
 int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   if (!ctx) return LIVO2_ERR_INVALID;
-  if (!cfg || !(cfg->voxel_size > 0) || cfg->max_layer < 0 || cfg->max_layer > LIVO2_MAX_LAYER || cfg->max_points_num < 1 || cfg->max_points_num > MT_SLAB - 2 || cfg->max_roots < 1)
-    return fail(ctx, LIVO2_ERR_INVALID, "bad map tree cfg (max_layer in [0,LIVO2_MAX_LAYER], max_points_num in [1,50], max_roots >= 1)");
-  for (int k = 0; k < 5; k++) if (cfg->layer_init_num[k] < 1 || cfg->layer_init_num[k] > MT_SLAB - 2) return fail(ctx, LIVO2_ERR_INVALID, "layer_init_num out of [1,50]");
+  if (!cfg || !(cfg->voxel_size > 0) || cfg->max_layer < 0 || cfg->max_layer > LIVO2_MAX_LAYER || cfg->max_points_num < 1 || cfg->max_points_num > LIVO2_MAX_POINTS_NUM || cfg->max_roots < 1)
+    return fail(ctx, LIVO2_ERR_INVALID, "bad map tree cfg (max_layer in [0,LIVO2_MAX_LAYER], max_points_num in [1,LIVO2_MAX_POINTS_NUM], max_roots >= 1)");
+  const int slab = std::max(MT_SLAB_MIN, cfg->max_points_num + 2);
+  for (int k = 0; k < 5; k++) if (cfg->layer_init_num[k] < 1 || cfg->layer_init_num[k] > slab - 2) return fail(ctx, LIVO2_ERR_INVALID, "layer_init_num out of [1, max(50, max_points_num)]");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   hipError_t e;
@@ -991,7 +993,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   const long long R = cfg->max_roots;
   m.cap_nodes = (int32_t)std::min<long long>(cfg->max_nodes > 0 ? cfg->max_nodes : 3 * R, INT32_MAX / 2);
   m.cap_planes = (int32_t)std::min<long long>(cfg->max_planes > 0 ? cfg->max_planes : 2 * R, (1 << CAND_LAYER_SHIFT) - 1);
-  m.cap_points = (int32_t)std::min<long long>(cfg->max_points > 0 ? cfg->max_points : 80 * R, INT32_MAX / 16);
+  m.cap_points = (int32_t)std::min<long long>(cfg->max_points > 0 ? cfg->max_points : (long long)(80 * std::max(MT_SLAB_MIN, cfg->max_points_num + 2) / MT_SLAB_MIN) * R, INT32_MAX / 16);
   m.cap_cand = (int32_t)std::min<long long>(cfg->max_cand > 0 ? cfg->max_cand : R, INT32_MAX / 64);
   m.cap_overflow = (int32_t)std::max<long long>(1024, R / 4);
   uint32_t cap = 64;
@@ -1006,7 +1008,8 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   HIPCHK(hipMalloc((void **)&m.pool_pw, (size_t)m.cap_points * 24));
   HIPCHK(hipMalloc((void **)&m.pool_var, (size_t)m.cap_points * 72));
   // counters + the free stacks behind them (map_tree_kernels.hpp: mt_free_nodes ... mt_pending_slabs)
-  HIPCHK(hipMalloc((void **)&m.counters, ((size_t)MTC_TOTAL + m.cap_nodes + m.cap_planes + ((size_t)m.cap_points / MT_SLAB + 1)) * 4));
+  HIPCHK(hipMalloc((void **)&m.counters, ((size_t)MTC_TOTAL + m.cap_nodes + m.cap_planes + ((size_t)m.cap_points / slab + 1)) * 4));
+  m.slab = slab;
   HIPCHK(hipMalloc((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
   HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
   {

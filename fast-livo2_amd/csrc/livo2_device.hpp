@@ -101,6 +101,60 @@ struct DevCtl {
   double solve_hth[49], solve_htz[7], solve_solution[DS];   // livo2_esikf_solve scratch
 };
 
+// ---- camera models of rpg_vikit (third party, unpinned: reference README.md:76-84) as used through cam->world2cam / cam->cam2world ------------------
+// model 0: vk::PinholeCamera without distortion; 1: vk::PinholeCamera with the radial-tangential coefficients d0..d4 (config/camera_pinhole.yaml);
+// 2: vk::EquidistantCamera with k1..k4 in d[0..3] (config/camera_fisheye_HILTI22.yaml) — the Kannala-Brandt / OpenCV-fisheye polynomial
+//    theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8), theta = atan(r).
+// (u, v) = the point projected onto z = 1 (vk::project2d).  Operation order = oracle/orc_visual.hpp (PinholeCam::world2cam).
+#define LIVO2_CAM_PINHOLE 0
+#define LIVO2_CAM_RADTAN 1
+#define LIVO2_CAM_EQUIDISTANT 2
+__device__ __forceinline__ void cam_project(int model, const double *d, double fx, double fy, double cx, double cy, double u, double v, double &px, double &py) {
+  if (model == LIVO2_CAM_PINHOLE) { px = fx * u + cx; py = fy * v + cy; }
+  else if (model == LIVO2_CAM_RADTAN) {
+    const double x = u, y = v, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    const double cdist = 1 + d[0] * r2 + d[1] * r4 + d[4] * r6;
+    const double xd = x * cdist + d[2] * a1 + d[3] * a2, yd = y * cdist + d[2] * a3 + d[3] * a1;
+    px = xd * fx + cx; py = yd * fy + cy;
+  } else {
+    const double r = sqrt(u * u + v * v), theta = atan(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double thetad = theta * (1 + d[0] * t2 + d[1] * t4 + d[2] * t6 + d[3] * t8);
+    const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+    px = fx * u * scaling + cx; py = fy * v * scaling + cy;
+  }
+}
+// cam2world before the final normalisation: (x, y) with bearing ~ (x, y, 1).  Radtan: OpenCV's undistortPoints as vikit calls it (float32 pixel in, five
+// fixed-point iterations in double, float32 out); equidistant: OpenCV-fisheye's undistortPoints scheme (ten fixed-point iterations on theta).
+__device__ __forceinline__ void cam_unproject(int model, const double *d, double fx, double fy, double cx, double cy, double u, double v, double &x, double &y) {
+  if (model == LIVO2_CAM_PINHOLE) { x = (u - cx) / fx; y = (v - cy) / fy; }
+  else if (model == LIVO2_CAM_RADTAN) {
+    const double uf = (double)(float)u, vf = (double)(float)v;
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    const double x0 = (uf - cx) * ifx, y0 = (vf - cy) * ify;
+    x = x0; y = y0;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1.0 / (1.0 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2);
+      if (icdist < 0) { x = x0; y = y0; break; }
+      const double deltaX = 2.0 * d[2] * x * y + d[3] * (r2 + 2.0 * x * x);
+      const double deltaY = d[2] * (r2 + 2.0 * y * y) + 2.0 * d[3] * x * y;
+      x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
+    }
+    x = (double)(float)x; y = (double)(float)y;
+  } else {
+    const double xd = (u - cx) / fx, yd = (v - cy) / fy;
+    const double thetad = sqrt(xd * xd + yd * yd);
+    double theta = thetad;
+    for (int j = 0; j < 10; j++) {
+      const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+      theta = thetad / (1 + d[0] * t2 + d[1] * t4 + d[2] * t6 + d[3] * t8);
+    }
+    const double scaling = (thetad > 1e-8) ? tan(theta) / thetad : 1.0;
+    x = xd * scaling; y = yd * scaling;
+  }
+}
+
 // ---- tiny 3x3 helpers (row-major) ------------------------------------------------------------------------------------
 __device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
 #pragma unroll

@@ -17,7 +17,8 @@
 #include "map_kernels.hpp"
 
 #define MT_LPG 8                 // lanes per root voxel
-#define MT_SLAB 52               // points a node's temp_points_ region holds by default (max_points_num_ 50 + the point that trips the limit + 1)
+#define MT_SLAB_MIN 52           // smallest region size: max_points_num_ 50 (every shipped config but HILTI22) + the point that trips the limit + 1.  The size in use is
+                                 // MapTreeArgs::slab = max(MT_SLAB_MIN, max_points_num + 2), fixed at livo2_map_tree_create (config/HILTI22.yaml:66 has max_points_num 100)
 #define MT_NO_KEY INT32_MIN     // key of an empty root bucket (voxel keys are 21-bit per axis)
 #define MT_STACK (LIVO2_MAX_LAYER + 2)
 enum { MTC_NODES = 0, MTC_POINTS = 1, MTC_PLANES = 2, MTC_CAND = 3, MTC_OVERFLOW = 4, MTC_ERROR = 5, MTC_DIRTY = 6, MTC_ROOTS = 7, MTC_COUNT = 8,
@@ -57,11 +58,12 @@ struct MapTreeArgs {
   const int32_t *seg_head, *seg_slot;                // [n] head flags / exclusive scan (segment number at heads)
   int32_t *seg_begin, *seg_root;                     // [n_seg + 1], [n_seg]
   int32_t n, build;
+  int32_t slab;                                      // points per default temp_points_ region (see MT_SLAB_MIN)
   int32_t may_pop;                                   // host-side note: bit 0 / 1 / 2 = the free stack of node ids / plane rows / 52-point regions is non-empty
 };
 
 // The free stacks live behind the counters in the SAME allocation — [MTC_TOTAL counters][node ids: cap_nodes][plane rows: cap_planes][regions: cap_points /
-// MT_SLAB + 1] — so that they need no kernel arguments of their own: k_mt_update sits at the register limit, and four more pointers
+// slab + 1] — so that they need no kernel arguments of their own: k_mt_update sits at the register limit, and four more pointers
 // in its argument block cost a 70 % longer build (measured).
 __device__ __forceinline__ int32_t *mt_free_nodes(const MapTreeArgs &a) { return a.counters + MTC_TOTAL; }
 __device__ __forceinline__ int32_t *mt_free_planes(const MapTreeArgs &a) { return a.counters + MTC_TOTAL + a.cap_nodes; }
@@ -165,7 +167,7 @@ template <bool RECYCLE> __device__ __forceinline__ int mt_take(const MapTreeArgs
 template <bool RECYCLE> __device__ __forceinline__ int mt_alloc_node(const MapTreeArgs &a) { return mt_take<RECYCLE>(a, MTC_FREE_NODES, mt_free_nodes(a), MTC_NODES, 1, a.cap_nodes, MTE_NODES); }
 template <bool RECYCLE> __device__ __forceinline__ int mt_alloc_plane(const MapTreeArgs &a) { return mt_take<RECYCLE>(a, MTC_FREE_PLANES, mt_free_planes(a), MTC_PLANES, 1, a.cap_planes, MTE_PLANES); }
 template <bool RECYCLE> __device__ __forceinline__ int mt_alloc_region(const MapTreeArgs &a, int cap) {
-  if (RECYCLE && cap == MT_SLAB) { const int off = mt_pop(a, MTC_FREE_SLABS, mt_free_slabs(a)); if (off >= 0) return off; }
+  if (RECYCLE && cap == a.slab) { const int off = mt_pop(a, MTC_FREE_SLABS, mt_free_slabs(a)); if (off >= 0) return off; }
   return mt_alloc(a, MTC_POINTS, cap, a.cap_points, MTE_POINTS);
 }
 __device__ __forceinline__ void mt_init_node(DevNode &nd, const double c[3], float quarter, int layer, int root, int pts_off, int pts_cap) {
@@ -196,7 +198,7 @@ template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_roots(MapTre
     if (val != -1 && val != -3 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]) { a.seg_root[g] = s.pad; return; }
   }
   // new root voxel (voxel_map.cpp:574-583 / 630-637)
-  const int cap = a.build ? max(MT_SLAB, e - b + 1) : MT_SLAB;
+  const int cap = a.build ? max(a.slab, e - b + 1) : a.slab;
   const int id = mt_alloc_node<RECYCLE>(a);
   const int off = mt_alloc_region<RECYCLE>(a, cap);
   if (id < 0 || off < 0) { a.seg_root[g] = -1; return; }
@@ -261,9 +263,9 @@ template <bool RECYCLE> struct MtGroup {
     return true;
   }
   // std::vector<pointWithVar>().swap(temp_points_); update_enable_ = false
-  // A frozen node never stores a point again: its MT_SLAB region goes back to the pool.  Here it is only MARKED (pts_cap = -MT_SLAB): an atomic per freeze on one
+  // A frozen node never stores a point again: its slab-sized region goes back to the pool.  Here it is only MARKED (pts_cap = -slab): an atomic per freeze on one
   // counter would serialise behind the allocators' (a build freezes most of its planes); k_mt_collect gathers the marks of the touched roots after the update.
-  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; if (n.pts_cap == MT_SLAB) n.pts_cap = -MT_SLAB; }
+  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; if (n.pts_cap == a.slab) n.pts_cap = -a.slab; }
   // init_plane(temp_points_, plane_ptr_): fit + the packed record the residual kernel reads
   __device__ void fit(DevNode &n) {
     wave_sync();                                              // the pushes of this group are visible to its 8 lanes
@@ -351,7 +353,7 @@ template <bool RECYCLE> struct MtGroup {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 8; k++)
-          if (cnt[k] > 0 && f.n.child[k] < 0) { f.n.child[k] = new_leaf(f.n, k, max(MT_SLAB, cnt[k] + 1)); if (f.n.child[k] < 0) ok = false; }
+          if (cnt[k] > 0 && f.n.child[k] < 0) { f.n.child[k] = new_leaf(f.n, k, max(a.slab, cnt[k] + 1)); if (f.n.child[k] < 0) ok = false; }
         if (!ok) { if (lane == 0) a.nodes[f.id] = f.n; if (sp == 0) n = f.n; return; }
         wave_sync();                                          // the new leaves are in memory for every lane
         // copy the points to the leaves in list order (temp_points_.push_back, new_points_++)
@@ -434,7 +436,7 @@ template <bool RECYCLE> struct MtGroup {
 #pragma unroll
         for (int q = 0; q < 8; q++) if (q == leafnum) cid = n.child[q];
         if (cid < 0) {
-          cid = new_leaf(n, leafnum, MT_SLAB);
+          cid = new_leaf(n, leafnum, a.slab);
           if (cid < 0) return;
 #pragma unroll
           for (int q = 0; q < 8; q++) if (q == leafnum) n.child[q] = cid;
@@ -505,7 +507,7 @@ __global__ void __launch_bounds__(256) k_mt_collect(MapTreeArgs a) {
       const int id = st[sp--];
       DevNode &nd = a.nodes[id];
       for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
-      if (nd.pts_cap == -MT_SLAB) { off = nd.pts_off; nd.pts_cap = 0; nd.pts_off = 0; }
+      if (nd.pts_cap == -a.slab) { off = nd.pts_off; nd.pts_cap = 0; nd.pts_off = 0; }
     }
     const unsigned long long m = __ballot(off >= 0);
     if (m) {
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(256) k_mt_collect(MapTreeArgs a) {
 
 // ---- VoxelMapManager::mapSliding / clearMemOutOfMap (voxel_map.cpp:924-972): every root voxel whose key lies outside the box is deleted with its subtree ----------
 // One thread per bucket.  The bucket becomes empty (a 2-choice table needs no tombstone: a lookup reads both buckets of a key whatever else they hold); the
-// subtree's node ids, plane rows and MT_SLAB-point regions go onto the free stacks, from where the next updates take them before they touch fresh pool memory
+// subtree's node ids, plane rows and slab-point regions go onto the free stacks, from where the next updates take them before they touch fresh pool memory
 // (regions of another size — the build sizes them by count — and candidate ranges are not recycled).
 struct SlideBox { int32_t x_max, x_min, y_max, y_min, z_max, z_min; };
 __global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
     DevNode &nd = a.nodes[id];
     for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
     if (nd.plane >= 0) mt_free_planes(a)[atomicAdd(&a.counters[MTC_FREE_PLANES], 1)] = nd.plane;
-    if (nd.pts_cap == MT_SLAB) mt_free_slabs(a)[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off;
+    if (nd.pts_cap == a.slab) mt_free_slabs(a)[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off;
     nd.root = -1; nd.layer = -1; nd.plane = -1; nd.is_plane = 0;          // (livo2_map_tree_export recognises roots by layer == 0 && root == id)
     mt_free_nodes(a)[atomicAdd(&a.counters[MTC_FREE_NODES], 1)] = id;
   }

@@ -47,36 +47,15 @@ __device__ __forceinline__ void w_mat3t_vec(const double *A, const double *v, do
 #pragma unroll
   for (int r = 0; r < 3; r++) o[r] = (A[r] * v[0] + A[3 + r] * v[1]) + A[6 + r] * v[2];
 }
-// vk::PinholeCamera::world2cam / cam2world (rpg_vikit; the distorted cam2world is OpenCV's undistortPoints: float32 in, five fixed-point iterations in double,
-// float32 out) — operation order of oracle/orc_visual.hpp (world2cam) and oracle/orc_warp.hpp (cam2world)
+// cam->world2cam / cam->cam2world: the camera models of livo2_device.hpp (cam_project / cam_unproject) — operation order of oracle/orc_visual.hpp (world2cam)
+// and oracle/orc_warp.hpp (cam2world)
 __device__ __forceinline__ void w_world2cam(const WarpKernelArgs &a, const double *p, double *px) {
   const double u = p[0] / p[2], v = p[1] / p[2];
-  if (!a.distortion) { px[0] = a.fx * u + a.cx; px[1] = a.fy * v + a.cy; return; }
-  const double x = u, y = v, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-  const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-  const double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
-  const double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2;
-  const double yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
-  px[0] = xd * a.fx + a.cx; px[1] = yd * a.fy + a.cy;
+  cam_project(a.distortion, a.d, a.fx, a.fy, a.cx, a.cy, u, v, px[0], px[1]);
 }
 __device__ __forceinline__ void w_cam2world(const WarpKernelArgs &a, double u, double v, double *o) {
   double x, y;
-  if (!a.distortion) { x = (u - a.cx) / a.fx; y = (v - a.cy) / a.fy; }
-  else {
-    const double uf = (double)(float)u, vf = (double)(float)v;
-    const double ifx = 1.0 / a.fx, ify = 1.0 / a.fy;
-    const double x0 = (uf - a.cx) * ifx, y0 = (vf - a.cy) * ify;
-    x = x0; y = y0;
-    for (int j = 0; j < 5; j++) {
-      const double r2 = x * x + y * y;
-      const double icdist = 1.0 / (1.0 + ((a.d[4] * r2 + a.d[1]) * r2 + a.d[0]) * r2);
-      if (icdist < 0) { x = x0; y = y0; break; }
-      const double deltaX = 2.0 * a.d[2] * x * y + a.d[3] * (r2 + 2.0 * x * x);
-      const double deltaY = a.d[2] * (r2 + 2.0 * y * y) + 2.0 * a.d[3] * x * y;
-      x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
-    }
-    x = (double)(float)x; y = (double)(float)y;
-  }
+  cam_unproject(a.distortion, a.d, a.fx, a.fy, a.cx, a.cy, u, v, x, y);
   const double nrm = sqrt((x * x + y * y) + 1.0 * 1.0);
   o[0] = x / nrm; o[1] = y / nrm; o[2] = 1.0 / nrm;
 }

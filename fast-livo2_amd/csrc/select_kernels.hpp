@@ -45,13 +45,7 @@ __device__ __forceinline__ bool sel_project(const SelectArgs &a, const double *p
 #pragma unroll
   for (int r = 0; r < 3; r++) pc3[r] = ((a.R[r * 3] * p[0] + a.R[r * 3 + 1] * p[1]) + a.R[r * 3 + 2] * p[2]) + a.t[r];
   const double u = pc3[0] / pc3[2], v = pc3[1] / pc3[2];
-  if (!a.distortion) { px[0] = a.fx * u + a.cx; px[1] = a.fy * v + a.cy; return true; }
-  const double x = u, y = v, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;      // rpg_vikit's radtan model, order of oracle/orc_visual.hpp
-  const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-  const double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
-  const double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2;
-  const double yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
-  px[0] = xd * a.fx + a.cx; px[1] = yd * a.fy + a.cy;
+  cam_project(a.distortion, a.d, a.fx, a.fy, a.cx, a.cy, u, v, px[0], px[1]);
   return true;
 }
 __device__ __forceinline__ bool sel_in_frame(const SelectArgs &a, int x, int y) { return x >= a.border && x < a.width - a.border && y >= a.border && y < a.height - a.border; }

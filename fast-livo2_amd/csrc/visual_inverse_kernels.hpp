@@ -111,15 +111,8 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_inverse_residual(VisualKer
     for (int j = 0; j < 3; j++) pf[j] = ((Rcw[j * 3] * p0 + Rcw[j * 3 + 1] * p1) + Rcw[j * 3 + 2] * p2) + Pcw[j];
     double pcx, pcy;
     {
-      double u0 = pf[0] / pf[2], u1 = pf[1] / pf[2];
-      if (!a.distortion) { pcx = a.fx * u0 + a.cx; pcy = a.fy * u1 + a.cy; }
-      else {
-        double x = u0, y = u1, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-        double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-        double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
-        double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2, yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
-        pcx = xd * a.fx + a.cx; pcy = yd * a.fy + a.cy;
-      }
+      const double u0 = pf[0] / pf[2], u1 = pf[1] / pf[2];
+      cam_project(a.distortion, a.d, a.fx, a.fy, a.cx, a.cy, u0, u1, pcx, pcy);
     }
     const int scale = 1 << a.level;                          // vio.cpp:1437 (no search level)
     const Anchor A = make_anchor(pcx, pcy, scale);

@@ -57,17 +57,10 @@ __device__ __forceinline__ void jac_row(double g0, double g1, const double Jpi[6
   }
 }
 
-// pc = cam->world2cam(pf): vk::PinholeCamera (rpg_vikit): projection to z = 1, optional radial-tangential distortion d0..d4, then fx, fy, cx, cy
+// pc = cam->world2cam(pf): projection to z = 1, then the camera model (livo2_device.hpp, cam_project: pinhole / radtan / equidistant)
 __device__ __forceinline__ void vis_world2cam(const VisualKernelArgs &a, const double pf[3], double &pcx, double &pcy) {
   const double u0 = pf[0] / pf[2], u1 = pf[1] / pf[2];
-  if (!a.distortion) { pcx = a.fx * u0 + a.cx; pcy = a.fy * u1 + a.cy; }
-  else {
-    const double x = u0, y = u1, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-    const double cdist = 1 + a.d[0] * r2 + a.d[1] * r4 + a.d[4] * r6;
-    const double xd = x * cdist + a.d[2] * a1 + a.d[3] * a2, yd = y * cdist + a.d[2] * a3 + a.d[3] * a1;
-    pcx = xd * a.fx + a.cx; pcy = yd * a.fy + a.cy;
-  }
+  cam_project(a.distortion, a.d, a.fx, a.fy, a.cx, a.cy, u0, u1, pcx, pcy);
 }
 
 #ifdef LIVO2_PHASE_PROF

@@ -26,6 +26,7 @@ extern "C" {
 #define LIVO2_MAX_BATCH 64      /* frames per livo2_lidar_batch_* call */
 #define LIVO2_MAX_ITERS 16      /* upper bound accepted for lio/vio max_iterations (reference default 5) */
 #define LIVO2_MAX_LEVELS 8      /* upper bound for vio/patch_pyrimid_level (reference default 4) */
+#define LIVO2_MAX_POINTS_NUM 1000 /* upper bound for lio/max_points_num of the device-resident tree (reference configs: 50, HILTI22: 100) */
 #define LIVO2_MAX_LAYER 4       /* upper bound for lio/max_layer (layer_init_num has 5 entries, voxel_map.cpp:46) */
 #define LIVO2_PATCH 8           /* vio/patch_size; the kernels are specialised for 8x8 (config/avia.yaml:33) */
 
@@ -302,7 +303,11 @@ int livo2_lidar_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, const l
 
 /* ---- visual photometric update ---------------------------------------------------------------------------------- */
 /* vk::AbstractCamera as used on the path: cam->fx()/fy()/cx()/cy()/width()/height() already scaled (vio.cpp:45-54) and
- * cam->world2cam() (vio.cpp:1574; rpg_vikit pinhole + optional radtan d[0..4]; distortion=0 => pure pinhole). */
+ * cam->world2cam() (vio.cpp:1574).  distortion selects the rpg_vikit model (cam_model of the camera yaml):
+ *   0  Pinhole without distortion
+ *   1  Pinhole with the radial-tangential coefficients cam_d0..cam_d3 (+ d4 = r^6 term) in d[0..4]   (config/camera_pinhole.yaml)
+ *   2  EquidistantCamera with k1..k4 in d[0..3]: theta_d = theta (1 + k1 theta^2 + ... + k4 theta^8)   (config/camera_fisheye_HILTI22.yaml)
+ * computeProjectionJacobian (vio.cpp:189-201) ignores the distortion in every model, as in the reference. */
 typedef struct livo2_cam {
   double fx, fy, cx, cy;
   double d[5];

@@ -188,10 +188,10 @@ class WarpCfg(C.Structure):
 
 
 def _cam_distortion(c, cam):
-    """cam["d"] (optional): the five radial-tangential coefficients d0..d4 of vk::PinholeCamera"""
-    d = cam.get("d")
-    c.distortion = 0 if d is None else 1
-    c.d[:] = [0.0] * 5 if d is None else [float(x) for x in d]
+    """cam["d"] (optional): the five radial-tangential coefficients d0..d4 of vk::PinholeCamera; cam["k"] (optional): k1..k4 of vk::EquidistantCamera"""
+    d, k = cam.get("d"), cam.get("k")
+    c.distortion = 2 if k is not None else (0 if d is None else 1)
+    c.d[:] = ([float(x) for x in k] + [0.0]) if k is not None else ([0.0] * 5 if d is None else [float(x) for x in d])
 
 
 def cam_roundtrip(cam, uv, lib=None):
@@ -419,13 +419,16 @@ def lidar_state_estimation(omap, cfg, xyz, state_in, prop, want_points=True):
     return dict(state=out, n_iters=nit.value, seconds=secs.value, trace=[trace[i] for i in range(nit.value)], **(b if want_points else {}))
 
 
-def visual_cfg(sc, num_threads=1, exposure=True, inverse=False, max_iterations=None, distortion=None):
+def visual_cfg(sc, num_threads=1, exposure=True, inverse=False, max_iterations=None, distortion=None, equidistant=None):
     cfg = VisualCfg()
     cfg.fx, cfg.fy, cfg.cx, cfg.cy = sc.cam["fx"], sc.cam["fy"], sc.cam["cx"], sc.cam["cy"]
     cfg.distortion, cfg.width, cfg.height = 0, sc.cam["width"], sc.cam["height"]
     if distortion is not None:                      # vk::PinholeCamera radial-tangential d0..d4
         cfg.distortion = 1
         cfg.d[:] = [float(x) for x in distortion]
+    if equidistant is not None:                     # vk::EquidistantCamera k1..k4
+        cfg.distortion = 2
+        cfg.d[:] = [float(x) for x in equidistant] + [0.0]
     cfg.patch_pyrimid_level = int(sc.cfg["patch_pyrimid_level"])
     cfg.max_iterations = int(max_iterations or sc.cfg["max_iterations"])
     cfg.exposure_estimate_en, cfg.inverse_composition_en, cfg.num_threads = int(exposure), int(inverse), num_threads

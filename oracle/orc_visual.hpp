@@ -30,12 +30,17 @@ namespace orc {
 struct PinholeCam {                  // vk::PinholeCamera (values already multiplied by `scale`, vio.cpp:45-54)
   double fx, fy, cx, cy;
   double d[5];
-  int distortion;
+  int distortion;                    // 0 pinhole, 1 radial-tangential, 2 equidistant
   int width, height;
   void world2cam(const V3 &xyz_c, double px[2]) const {
     double uv0 = xyz_c[0] / xyz_c[2], uv1 = xyz_c[1] / xyz_c[2];       // vk::project2d
     if (!distortion) { px[0] = fx * uv0 + cx; px[1] = fy * uv1 + cy; }
-    else {
+    else if (distortion == 2) {       // vk::EquidistantCamera (config/camera_fisheye_HILTI22.yaml): k1..k4 in d[0..3]; rpg_vikit's published Kannala-Brandt form
+      const double r = std::sqrt(uv0 * uv0 + uv1 * uv1), theta = std::atan(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+      const double thetad = theta * (1 + d[0] * t2 + d[1] * t4 + d[2] * t6 + d[3] * t8);
+      const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+      px[0] = fx * uv0 * scaling + cx; px[1] = fy * uv1 * scaling + cy;
+    } else {
       double x = uv0, y = uv1, r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
       double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
       double cdist = 1 + d[0] * r2 + d[1] * r4 + d[4] * r6;

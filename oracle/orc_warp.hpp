@@ -52,6 +52,18 @@ inline V3 cam2world(const PinholeCam &c, double u, double v) {
     V3 xyz = vec3((u - c.cx) / c.fx, (v - c.cy) / c.fy, 1.0);
     return xyz / norm(xyz);
   }
+  if (c.distortion == 2) {            // vk::EquidistantCamera: OpenCV-fisheye undistortPoints scheme (ten fixed-point iterations on theta); third-party, unpinned
+    const double xd = (u - c.cx) / c.fx, yd = (v - c.cy) / c.fy;
+    const double thetad = std::sqrt(xd * xd + yd * yd);
+    double theta = thetad;
+    for (int j = 0; j < 10; j++) {
+      const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+      theta = thetad / (1 + c.d[0] * t2 + c.d[1] * t4 + c.d[2] * t6 + c.d[3] * t8);
+    }
+    const double scaling = (thetad > 1e-8) ? std::tan(theta) / thetad : 1.0;
+    V3 xyz = vec3(xd * scaling, yd * scaling, 1.0);
+    return xyz / norm(xyz);
+  }
   const double uf = (double)(float)u, vf = (double)(float)v;           // cv::Point2f uv(u, v)
   const double ifx = 1.0 / c.fx, ify = 1.0 / c.fy;
   const double x0 = (uf - c.cx) * ifx, y0 = (vf - c.cy) * ify;

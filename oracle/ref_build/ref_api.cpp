@@ -8,6 +8,7 @@
 // reference's.  Quantities that are locals of the reference's functions (per-iteration H rows, R_inv, z, H_sub) cannot be read out of
 // unmodified code; the tests reach them through truncated runs (max_iterations = 1, 2, ...) instead.
 #include "vio.h"
+#include <vikit/equidistant_camera.h>
 #include <chrono>
 #include <cstring>
 #include <sstream>
@@ -299,7 +300,7 @@ int orc_lidar_state_estimation(void *m, const orc_lidar_cfg *cfg, const float *x
 namespace {
 struct VioRig {
   VIOManager vio;
-  std::unique_ptr<vk::PinholeCamera> cam;
+  std::unique_ptr<vk::AbstractCamera> cam;
   std::vector<std::unique_ptr<VisualPoint>> pts;
   StatesGroup st, prop;
   cv::Mat img;
@@ -311,8 +312,9 @@ void setup_vio(VioRig &r, const orc_visual_cfg *cfg, const uint8_t *img, const d
                const double *inv_expo_list, int M, const uint8_t *ref_imgs, const int32_t *ref_img_idx, const double *ref_px, const double *ref_f, const double *ref_R,
                const double *ref_pos) {
   VIOManager &vio = r.vio;
-  r.cam.reset(new vk::PinholeCamera(cfg->width, cfg->height, 1.0, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->distortion ? cfg->d[0] : 0.0, cfg->distortion ? cfg->d[1] : 0.0,
-                                    cfg->distortion ? cfg->d[2] : 0.0, cfg->distortion ? cfg->d[3] : 0.0, cfg->distortion ? cfg->d[4] : 0.0));
+  if (cfg->distortion == 2) r.cam.reset(new vk::EquidistantCamera(cfg->width, cfg->height, 1.0, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->d[0], cfg->d[1], cfg->d[2], cfg->d[3]));
+  else r.cam.reset(new vk::PinholeCamera(cfg->width, cfg->height, 1.0, cfg->fx, cfg->fy, cfg->cx, cfg->cy, cfg->distortion ? cfg->d[0] : 0.0, cfg->distortion ? cfg->d[1] : 0.0,
+                                         cfg->distortion ? cfg->d[2] : 0.0, cfg->distortion ? cfg->d[3] : 0.0, cfg->distortion ? cfg->d[4] : 0.0));
   vio.cam = r.cam.get();
   vio.grid_size = 5; vio.grid_n_height = 17; vio.patch_size = 8; vio.patch_pyrimid_level = cfg->patch_pyrimid_level; vio.max_iterations = cfg->max_iterations;
   vio.img_point_cov = cfg->img_point_cov; vio.exposure_estimate_en = cfg->exposure_estimate_en; vio.inverse_composition_en = cfg->inverse_composition_en;

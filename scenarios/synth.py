@@ -426,6 +426,7 @@ class VisualScenario:
     cfg: dict
 
 
+HILTI_EQUIDISTANT = (-0.03696737352869157, -0.008917880497032812, 0.008912969593422046, -0.0037685977496087313)   # config/camera_fisheye_HILTI22.yaml:9-12 k1..k4 (vk::EquidistantCamera)
 AVIA_RADTAN = (-0.076160, 0.123001, -0.00113, 0.000251, 0.0)      # config/camera_pinhole.yaml:9-12 cam_d0..cam_d3 (+ d4 = 0); the coefficients act on
                                                                    # normalised coordinates, so the yaml's `scale: 0.5` leaves them unchanged
 

@@ -51,6 +51,31 @@ def test_build_and_update_sequence_match_oracle(ctx, orc):
         n_prev = n
 
 
+@pytest.mark.parametrize("max_points_num", [100, 7])
+def test_max_points_num_of_hilti22(ctx, orc, max_points_num):
+    """lio/max_points_num = 100 (reference config/HILTI22.yaml:66; every other shipped config has 50): the point regions of the device tree are sized at creation
+    (max_points_num + 2), so nodes keep collecting and re-fitting up to the 100th point and freeze there, like the oracle's (voxel_map.cpp:146-151, 240-245, 280-285).
+    A small value (7) freezes almost every plane node during the build."""
+    c, cloud, R0, t0, P0, extR, extT = _scene(87)
+    c["max_points_num"] = max_points_num
+    _, (pw0, var0) = cloud(60000, R0, t0)
+    ctx.map_tree_create(c, max_roots=60000)
+    ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+    om = orc.OracleMap.build(pw0, var0.reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    n_prev = _compare(_flat(ctx.map_tree_export(), c), om.export(c["voxel_size"], c["max_layer"]))
+    assert n_prev > 500
+    for k in range(3):
+        Rk, tk = R0 @ synth.rot_from_rpy(0.0, 0.0, 0.05 * (k + 1)), t0 + np.array([0.1 * (k + 1), 0.05 * k, 0.0])
+        _, (pw, var) = cloud(30000, Rk, tk)
+        ctx.map_tree_update(pw, var.reshape(-1, 9))
+        om.update(pw, var.reshape(-1, 9))
+        n = _compare(_flat(ctx.map_tree_export(), c), om.export(c["voxel_size"], c["max_layer"]))
+        assert n >= n_prev and ctx.map_tree_stats()["error"] == 0
+        n_prev = n
+    with pytest.raises(Exception):
+        ctx.map_tree_create(dict(c, max_points_num=100000), max_roots=1000)              # beyond LIVO2_MAX_POINTS_NUM: LIVO2_ERR_INVALID
+
+
 def test_map_sliding_matches_oracle_and_recycles(ctx, orc):
     """VoxelMapManager::mapSliding / clearMemOutOfMap (reference src/voxel_map.cpp:924-972) on the device tree: the same root voxels disappear as in the oracle,
     a call below sliding_thresh changes nothing, and the next updates take the released nodes / plane rows / point regions before fresh pool memory while the

@@ -210,7 +210,7 @@ def test_visual_update_sweep(orc, ref, k):
 
 
 @pytest.mark.parametrize("max_it", [1, 2, 3, 5])
-@pytest.mark.parametrize("variant", ["pinhole", "radtan", "no_exposure", "inverse", "inverse_radtan"])
+@pytest.mark.parametrize("variant", ["pinhole", "radtan", "equidistant", "no_exposure", "inverse", "inverse_radtan", "inverse_equidistant"])
 def test_visual_truncated_runs_pin_every_step(orc, ref, variant, max_it):
     """max_iterations = k per level: the accept / revert decision, H^T H, K_1 and the state after every (level, iteration) step are pinned
     through the state and covariance the run ends with"""
@@ -219,6 +219,8 @@ def test_visual_truncated_runs_pin_every_step(orc, ref, variant, max_it):
     kw = dict(max_iterations=max_it, inverse=inverse)
     if variant.endswith("radtan"):
         kw["distortion"] = synth.AVIA_RADTAN
+    if variant.endswith("equidistant"):
+        kw["equidistant"] = synth.HILTI_EQUIDISTANT                  # vk::EquidistantCamera, config/camera_fisheye_HILTI22.yaml
     if variant == "no_exposure":
         kw["exposure"] = False
     a, b = _visual_both(orc, ref, vs, **kw)

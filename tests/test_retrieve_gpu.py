@@ -54,6 +54,21 @@ def test_radtan_camera_matches_oracle(ctx, orc, normal_en):
     assert 0.3 < ref["accepted"].mean() < 0.98
 
 
+def test_equidistant_camera_through_the_warp(ctx, orc):
+    """vk::EquidistantCamera (config/camera_fisheye_HILTI22.yaml) through world2cam and cam2world of the affine warp (vio.cpp:247-290); atan / tan may differ in
+    the last bit between host and device libm: accept / search-level decisions identical, patches to float rounding"""
+    rs = synth.retrieve_scenario(seed=27, n_cand=900, normal_en=True)
+    pin = orc.warp_candidates(rs)
+    rs.cam = dict(rs.cam); rs.cam["k"] = synth.HILTI_EQUIDISTANT
+    ref = orc.warp_candidates(rs)
+    out = ctx.retrieve_warp(rs)
+    assert np.abs(ref["A"] - pin["A"]).max() > 1e-4
+    assert np.array_equal(out["accepted"], ref["accepted"]) and np.array_equal(out["search_level"], ref["search_level"])
+    assert np.allclose(out["A"], ref["A"], rtol=1e-9, atol=1e-12)
+    assert np.abs(out["patch_wrap"] - ref["patch_wrap"]).max() < 1e-2 and (out["patch_wrap"] == ref["patch_wrap"]).mean() > 0.999
+    assert np.allclose(out["error"], ref["error"], rtol=1e-4)
+
+
 def test_survivors_become_the_resident_frame(ctx, livo2, orc):
     """After the call the frame of the next visual update is the compacted survivor list: the update gives byte-identical results to
     livo2_visual_set_frame with the survivors' arrays taken from the oracle."""

@@ -36,6 +36,16 @@ def test_select_with_radtan_camera(ctx, orc):
     assert not np.array_equal(ref["cell_point"], pin["cell_point"]) or not np.array_equal(ref["cell_dist"], pin["cell_dist"])
 
 
+def test_select_with_equidistant_camera(ctx, orc):
+    """vk::EquidistantCamera (config/camera_fisheye_HILTI22.yaml) in the selection half"""
+    ss = synth.select_scenario(seed=73, n_pg=8000, n_vis=5000)
+    pin = orc.visual_select(ss)
+    ss.cam = dict(ss.cam); ss.cam["k"] = synth.HILTI_EQUIDISTANT
+    ref = _compare(ctx, orc, ss)
+    assert (ref["cell_point"] >= 0).sum() > 100
+    assert not np.array_equal(ref["cell_point"], pin["cell_point"]) or not np.array_equal(ref["cell_dist"], pin["cell_dist"])
+
+
 def test_select_keys_computed_on_device(ctx, orc):
     """voxel_key = NULL: the device files every visual point with insertPointIntoVoxelMap's own formula (negative coordinates included)."""
     ss = synth.select_scenario(seed=74, n_pg=4000, n_vis=3000)

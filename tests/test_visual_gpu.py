@@ -109,6 +109,37 @@ def test_radtan_camera_of_the_avia_config(ctx, livo2, orc):
     assert np.linalg.norm(np.array(res.state.pos) - vs.t_true) < np.linalg.norm(vs.t_prior - vs.t_true)
 
 
+def test_equidistant_camera_of_the_hilti22_config(ctx, livo2, orc):
+    """cam_model: EquidistantCamera (config/camera_fisheye_HILTI22.yaml, k1..k4; livo2_cam.distortion = 2) through world2cam of the forward update (vio.cpp:1574).
+    The model contains atan(): device and host libm may differ in the last bit of the projected pixel, which a float32 bilinear weight feels in rare pixels —
+    residuals are compared to 1e-3 grey levels with >= 99.9 % of them bit-identical, every decision identical."""
+    k = synth.HILTI_EQUIDISTANT
+    vs = synth.visual_scenario(seed=9, n_patches=500)
+    ocur, oprop = H.states(vs, orc.StatePOD)
+    pcur, pprop = H.states(vs, livo2.State)
+    ocfg, pcfg = orc.visual_cfg(vs, equidistant=k, num_threads=4), H.visual_cfg_product(vs, equidistant=k, mp_proc_num=4)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    for level in (2, 0):
+        ref = orc.visual_iterate(ocfg, vs, level, ocur)
+        plain = orc.visual_iterate(orc.visual_cfg(vs), vs, level, ocur)
+        assert not np.array_equal(ref["z"], plain["z"])
+        sums, errors, z, Hs = ctx.visual_iterate(level, pcur, pcfg, rows=True)
+        assert np.abs(z - ref["z"]).max() < 1e-3 and (z == ref["z"]).mean() > 0.999
+        assert np.allclose(errors, ref["errors"], rtol=1e-4)
+        assert H.relerr(Hs, ref["H"]) < 1e-6 and H.relerr(np.array(sums.HtH).reshape(7, 7), ref["HtH"]) < 1e-6
+    ref = orc.visual_update(ocfg, vs, ocur, oprop)
+    for persistent in (1, 0):
+        ctx.set_option("visual_persistent", persistent)
+        res, errors = ctx.visual_update(pcur, pprop, pcfg)
+        assert [(res.steps[j].level, res.steps[j].iteration, res.steps[j].accepted) for j in range(res.n_steps)] == [(t.level, t.iteration, t.accepted) for t in ref["trace"]]
+        dd = H.state_diff(res.state, ref["state"])
+        assert dd["R"] < 1e-7 and dd["t"] < 1e-7 and dd["P"] < 1e-7, dd
+    ctx.set_option("visual_persistent", 1)
+    bad = H.visual_cfg_product(vs); bad.cam.distortion = 3
+    with pytest.raises(Exception):
+        ctx.visual_update(pcur, pprop, bad)                        # unknown camera model: LIVO2_ERR_INVALID
+
+
 def test_batched_frames_equal_single_updates(ctx, livo2, orc):
     """livo2_visual_batch_*: B independent updates in lockstep grids produce the bits of B separate livo2_visual_update calls (ragged sizes, an empty frame)."""
     sizes = [700, 0, 64, 1500, 9]

@@ -87,3 +87,22 @@ def test_inverse_needs_reference(ctx, livo2, vs_inv):
     with pytest.raises(livo2.Livo2Error) as e:
         ctx.visual_update(pcur, pprop, H.visual_cfg_product(vs, inverse=True))
     assert e.value.code == livo2.abi.ERR_INVALID
+
+
+def test_inverse_update_with_equidistant_camera(ctx, livo2, orc, vs_inv):
+    """vk::EquidistantCamera (config/camera_fisheye_HILTI22.yaml) inside updateStateInverse's cam->world2cam (vio.cpp:1447)"""
+    vs = vs_inv
+    ocfg = orc.visual_cfg(vs, inverse=True, equidistant=synth.HILTI_EQUIDISTANT)
+    pcfg = H.visual_cfg_product(vs, inverse=True, equidistant=synth.HILTI_EQUIDISTANT)
+    ocur, oprop = H.states(vs, orc.StatePOD)
+    pcur, pprop = H.states(vs, livo2.State)
+    ref = orc.visual_iterate_inverse(ocfg, vs, 0, ocur)
+    _upload(ctx, vs)
+    sums, errors, z, Hs = ctx.visual_iterate(0, pcur, pcfg, rows=True)
+    assert sums.n_meas == ref["n_meas"]
+    assert np.abs(z - ref["z"]).max() < 1e-3 and (z == ref["z"]).mean() > 0.999
+    full = orc.visual_update(ocfg, vs, ocur, oprop)
+    res, _ = ctx.visual_update(pcur, pprop, pcfg)
+    assert [(res.steps[j].level, res.steps[j].accepted) for j in range(res.n_steps)] == [(t.level, t.accepted) for t in full["trace"]]
+    d = H.state_diff(res.state, full["state"])
+    assert d["R"] < 1e-7 and d["t"] < 1e-7, d
