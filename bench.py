@@ -139,6 +139,70 @@ def c4_frame(seed, n_points, n_patches):
     return sc, vs
 
 
+def c5_frames(n_frames, shape):
+    """SURVEY 8(d) C5 frames (scenarios.synth.frame_sequence, seeds 1000 + f), cached like c4_frame.  shape "c1": avia-like 24 000-ray scans (~10 k points after the
+    0.1 m filter) + 350 patches; "c4": 200 000 post-filter points + 4 000 patches per frame against the C4-sized room."""
+    import pickle
+    from scenarios import synth
+    path = os.path.join(tempfile.gettempdir(), f"livo2_c5_{shape}_f{n_frames}_v1.pkl")
+    if os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:
+            pass
+    if shape == "c1":
+        seq = synth.frame_sequence(n_frames)
+    else:
+        seq = synth.frame_sequence(n_frames, n_raw=620000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_points=1600000, n_patches=4000, max_points=200000)
+    try:
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            pickle.dump(seq, f, protocol=4)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return seq
+
+
+class _Sc:            # what fast-livo2_amd.configs.lidar_cfg reads
+    def __init__(self, cfg, extR, extT):
+        self.cfg, self.extR, self.extT = cfg, extR, extT
+
+
+def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_frames, shape, barrier):
+    """Batched distinct frames round-robin over the ranks, H2D of every scan / image / sub-map and D2H of every result inside the timed region; the per-frame
+    records are gathered on every rank (RCCL all_gather) and rank 0 re-runs the first frame of every other rank to check the gathered copy bit for bit."""
+    fmap, lio_cfg, extR, extT, frames = c5_frames(n_frames, shape)
+    cfg = cfgs.lidar_cfg(_Sc(lio_cfg, extR, extT)); vcfg = cfgs.visual_cfg(frames[0]["vs"], mp_proc_num=4)
+    ctx.upload_map(fmap)
+    frames_mod.run_frame(ctx, livo2.State, frames[rank % len(frames)], cfg, vcfg)            # warm-up: allocations of this frame size
+    barrier()
+    t0 = time.perf_counter()
+    recs, evals = frames_mod.run_frames_sharded(ctx, livo2.State, frames, cfg, vcfg, rank, world)
+    ctx.synchronize()
+    dt_local = time.perf_counter() - t0
+    dt = frames_mod.max_over_ranks(dt_local, dist, device=device)
+    allrec = frames_mod.gather_results(recs, len(frames), dist, device=device)
+    ev = frames_mod.gather_results(np.array([[float(evals)]]), world, dist, device=device)
+    check = None
+    if rank == 0:
+        bad = 0
+        for r in range(world):
+            if r < len(frames):
+                rec, _ = frames_mod.run_frame(ctx, livo2.State, frames[r], cfg, vcfg)
+                bad += int(not np.array_equal(rec, allrec[r]))
+        check = {"frames_recomputed_on_rank0": min(world, len(frames)), "mismatches": bad}
+    pts = [len(f["xyz"]) for f in frames]
+    h2d = float(np.mean([f["xyz"].nbytes + f["vs"].img.nbytes + f["vs"].pos.nbytes + f["vs"].warp_patch.nbytes + 12 * len(f["vs"].pos) for f in frames]))
+    return {"shape": shape, "frames": len(frames), "frames_per_s": len(frames) / dt, "ms_per_frame_per_gpu": 1e3 * dt / (len(frames) / world), "evals_per_s": float(ev.sum()) / dt,
+            "points_per_frame_mean": float(np.mean(pts)), "patches_per_frame": int(len(frames[0]["vs"].pos)), "h2d_bytes_per_frame": h2d,
+            "d2h_bytes_per_frame": 8 * frames_mod.RESULT_DOUBLES + 2 * 8 * 400, "gather": "all_gather of the per-frame records (%d doubles each)" % frames_mod.RESULT_DOUBLES,
+            "gathered_copy_check": check,
+            "def": "F distinct frames (seeds 1000+f) round-robin over the ranks; per frame: scan H2D + Morton sort + body covariance, full LiDAR update from the frame's prior, image + "
+                   "sub-map H2D, full visual update, results D2H; host-synchronous calls from Python, caller memory pageable (the scan goes through the ctx's pinned staging); map resident"}
+
+
 def frame_priors(livo2, synth, sc, vs, F, seed):
     """F distinct priors of the same frame: the scenario's prior pose perturbed a little (each frame converges on its own path)."""
     rng = np.random.default_rng(seed)
@@ -286,8 +350,59 @@ def cpu_widened_rows(orc, lib):
             pw, var = _synth.world_points_and_var(xyz, Rk, tk, extR, extT, P0, c["dept_err"], c["beam_err"])
             t0 = time.perf_counter(); om.update(pw, var.reshape(-1, 9)); ts.append(time.perf_counter() - t0)
         mu[case[0]] = {"build_ms": 1e3 * tb, "update_ms_median": 1e3 * float(np.median(ts)), "points_per_frame": int(np.mean([len(f[0]) for f in frames]))}
-    return {"map_update_ms": mu, "imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
+    live = {}
+    try:
+        live = cpu_live_chain(orc, lib)
+    except Exception as exc:
+        live = {"error": repr(exc)}
+    return {"live_chain": live, "map_update_ms": mu, "imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
             "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s}
+
+
+def cpu_live_chain(orc, lib, sizes=("avia",)):
+    """the oracle over the frames of extra.live_chain (scenarios/live_inputs.py, same seeds): StateEstimation, LIVMapper.cpp:413-423 + UpdateVoxelMap,
+    retrieveFromVisualSparseMap, computeJacobianAndUpdateEKF per frame, single thread apart from the reference's own OpenMP loops (4 threads)"""
+    from scenarios import live_inputs, synth
+    out = {}
+    for size in sizes:
+        live = live_inputs.make_live(**live_inputs.SIZES[size])
+        c, extR, extT, cs = live["c"], live["extR"], live["extT"], live["cs"]
+        om = orc.OracleMap.build(live["pw0"], live["var0"].reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"], lib)
+        cfg = orc.lidar_cfg(c, extR, extT, num_threads=4)
+        R, t, P = live["R0"], live["t0"], live["P0"].copy()
+        vcfg = None
+        stage = np.zeros((len(live["scans"]), 4))
+        for f, xyz in enumerate(live["scans"]):
+            mo = live["motion"][f]
+            Rp, tp = R @ mo[:9].reshape(3, 3), t + mo[9:]
+            Pp = P + np.diag(live["q"])
+            prior = orc.make_state(Rp, tp, Pp)
+            t0 = time.perf_counter()
+            r = orc.lidar_state_estimation(om, cfg, xyz, prior, prior, want_points=False)
+            a = time.perf_counter()
+            st = orc.state_arrays(r["state"]); R, t, P = st["R"], st["t"], st["P"]
+            pw, var = synth.world_points_and_var(xyz, R, t, extR, extT, P, c["dept_err"], c["beam_err"])
+            om.update(pw, var.reshape(-1, 9))
+            b = time.perf_counter()
+            ret = orc.visual_retrieve(cs, lib)
+            cc = time.perf_counter()
+            keep = ret["tail"]["accepted"] != 0
+            sub = type("Sub", (), {})()
+            vs_c = live["vs_c"]
+            for k in ("cam", "cfg", "Rcl", "Pcl", "extR", "extT"):
+                setattr(sub, k, getattr(vs_c, k))
+            sub.cfg = dict(vs_c.cfg, patch_pyrimid_level=live["L"])
+            sub.img, sub.pos = cs.img, cs.sel.pos[ret["sub_point"]]
+            sub.warp_patch, sub.search_levels, sub.inv_expo_list = ret["tail"]["patch_wrap"][keep], ret["tail"]["search_level"][keep], cs.obs_inv_expo[ret["sub_obs"]]
+            vprior = orc.make_state(vs_c.R_prior, vs_c.t_prior, vs_c.P, inv_expo=cs.inv_expo_cur)
+            if len(sub.pos):
+                orc.visual_update(orc.visual_cfg(sub, num_threads=4), sub, vprior, vprior, lib)
+            dd = time.perf_counter()
+            stage[f] = [a - t0, b - a, cc - b, dd - cc]
+        m = 1e3 * stage[1:].mean(0)
+        out[size] = {"ms_per_frame": float(m.sum()), "StateEstimation_ms": float(m[0]), "UpdateVoxelMap_ms": float(m[1]), "retrieveFromVisualSparseMap_ms": float(m[2]),
+                     "computeJacobianAndUpdateEKF_ms": float(m[3]), "frames_timed": int(len(stage) - 1)}
+    return out
 
 
 def main():
@@ -303,6 +418,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the informational legs")
     ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,chains,live,c2,c3,batched,ooc,map); default all; the widened rows run only with all")
     ap.add_argument("--dist-selftest", action="store_true", help="run only the rank logic (gloo, no GPU)")
+    ap.add_argument("--c5-frames", type=int, default=64, help="distinct frames of the C5 leg (extra.c5, every --gpus N; 0 disables)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.frames_per_step < 1:
         raise SystemExit("bench.py: bad --gpus / --steps / --warmup / --frames-per-step")
@@ -383,6 +499,17 @@ def main():
     extra = {"frame_updates_per_s": frames_all / elapsed, "lidar_iterations_per_frame": w.iters, "visual_steps_per_frame": w.vsteps,
              "lidar_evals_per_step": float(sum(w.iters)) * w.N, "visual_evals_per_step": float(sum(w.vsteps)) * 64.0 * w.M,
              "per_rank_evals": per_rank[:, 0].tolist()}
+    if args.c5_frames > 0 and not args.no_extra:
+        try:
+            c5 = {"c1_shaped": c5_leg(ctx, livo2, frames, H, dist, device, rank, world, args.c5_frames, "c1", barrier)}
+            if world == 1 or args.c5_frames >= 8 * world:
+                c5["c4_shaped"] = c5_leg(ctx, livo2, frames, H, dist, device, rank, world, max(8, world), "c4", barrier)
+            extra["c5"] = c5
+        except Exception as exc:
+            extra["c5"] = {"error": repr(exc)}
+        # the headline's resident frame again for the legs below
+        ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, w.cfg)
+        ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
     cpu = None
     if rank == 0 and world == 1:
         from tools import bench_legs as legs

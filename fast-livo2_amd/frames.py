@@ -42,3 +42,40 @@ def max_over_ranks(value, dist=None, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- whole frames, transfers included --------------------------------------------------------------------------------------
+RESULT_DOUBLES = 2 * (25 + 361) + 4         # per frame: LiDAR posterior (25 scalars + P) + n_iters + n_eff of the last iteration, visual posterior + n_steps + last error
+
+
+def pack_result(lres, vres):
+    """the per-frame record that travels to rank 0: what LIVMapper keeps of a frame (state_ after handleLIO, state after handleVIO) plus the loop counters"""
+    def st(s):
+        return np.concatenate([np.array(s.rot), np.array(s.pos), [s.inv_expo], np.array(s.vel), np.array(s.bg), np.array(s.ba), np.array(s.grav), np.array(s.cov)])
+    n_it = int(lres.n_iters)
+    last_err = float(vres.steps[vres.n_steps - 1].error) if vres.n_steps > 0 else 0.0
+    return np.concatenate([st(lres.state), [n_it, float(lres.iter_sums[n_it - 1].n_eff) if n_it > 0 else 0.0], st(vres.state), [float(vres.n_steps), last_err]])
+
+
+def run_frame(ctx, State, frame, cfg, vcfg):
+    """One LIO + VIO frame through the C ABI as LIVMapper::handleLIO / handleVIO would drive it (LIVMapper.cpp:336-482, 281-334): the down-sampled scan goes up
+    (H2D + per-scan precompute), StateEstimation from the frame's prior, the image + visual sub-map go up, computeJacobianAndUpdateEKF starts from the LiDAR
+    posterior, the two results come back (D2H).  The map stays resident."""
+    prior = State.from_pose(frame["R_prior"], frame["t_prior"], frame["P"])
+    ctx.set_scan(frame["xyz"], cfg)
+    lres, _ = ctx.lidar_update(prior, prior, cfg)
+    vs = frame["vs"]
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    vprior = State.from_pose(vs.R_prior, vs.t_prior, vs.P, inv_expo=getattr(vs, "tau_prior", 1.0))     # (the synthetic image has its own pose: the visual prior is the sub-map's)
+    vres, _ = ctx.visual_update(vprior, vprior, vcfg)
+    return pack_result(lres, vres), int(lres.n_iters) * len(frame["xyz"]) + int(vres.n_steps) * 64 * len(vs.pos)
+
+
+def run_frames_sharded(ctx, State, frames, cfg, vcfg, rank, world):
+    """rank's share (frames rank, rank + world, ...) in order; returns (records [n_local, RESULT_DOUBLES], residual evaluations done)"""
+    mine = frames_for_rank(len(frames), rank, world)
+    recs, evals = np.zeros((len(mine), RESULT_DOUBLES)), 0
+    for k, f in enumerate(mine):
+        recs[k], e = run_frame(ctx, State, frames[f], cfg, vcfg)
+        evals += e
+    return recs, evals

@@ -352,7 +352,7 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   livo2_state s_in, s_prop;
   state_.to_abi(s_in); state_propagat.to_abi(s_prop);
   livo2_lidar_result res;
-  dev_.check(livo2_lidar_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, &pts));
+  dev_.check(livo2_lidar_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, host_point_lists_ ? &pts : nullptr));
   state_.from_abi(res.state);
   std::memcpy(position_last_.data(), res.position_last, 24);
   {   // euler_cur = RotMtoEuler(state_.rot_end) (so3_math.h:68-87); geoQuat_ = tf::createQuaternionMsgFromRollPitchYaw(euler_cur) (voxel_map.cpp:493)
@@ -366,6 +366,11 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     geoQuat_ = {{sr * cp * cy - cr * sp * sn, cr * sp * cy + sr * cp * sn, cr * cp * sn - sr * sp * cy, cr * cp * cy + sr * sp * sn}};
   }
 
+  if (!host_point_lists_) {          // see livo2_host.hpp: the per-point members stay empty
+    pv_list_.clear(); ptpl_list_.clear(); cross_mat_list_.clear(); body_cov_list_.clear();
+    effct_feat_num_ = res.n_iters > 0 ? res.iter_sums[res.n_iters - 1].n_eff : 0;
+    return;
+  }
   // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811)
   // device-resident map: the VoxelPlane members of the matched rows come from the device plane table
   std::vector<int32_t> rows; std::vector<double> r_normal, r_center, r_pvar; std::vector<float> r_d; std::vector<int32_t> r_layer;

@@ -178,6 +178,10 @@ public:
   // plane rows of the matches.  UpdateVoxelMapFromPosterior() is LIVMapper.cpp:413-424 in one call: pv_list_[i].point_w / .var of the posterior state_ are
   // formed on the device from the scan that StateEstimation left resident, and fed to UpdateVoxelMap there (nothing crosses PCIe but the state).
   bool device_map_ = false;
+  // per-point members StateEstimation leaves behind (pv_list_, ptpl_list_, body_cov_list_, cross_mat_list_: 168 B / point D2H + ~900 B / point of host structs).
+  // With device_map_ their consumers UpdateVoxelMap (LIVMapper.cpp:413-424 -> UpdateVoxelMapFromPosterior) run on the device; a caller that neither publishes
+  // (publish_effect_world, LIVMapper.cpp:1308) nor feeds generateVisualMapPoints (vio.cpp:811) can switch them off: only state_, effct_feat_num_, position_last_, geoQuat_ come back.
+  bool host_point_lists_ = true;
   int device_map_max_roots_ = 300000;
   void UpdateVoxelMapFromPosterior();
   // reference src/voxel_map.cpp:924-972 (LIVMapper.cpp:430-433 calls it when config_setting_.map_sliding_en): root voxels outside the box around

@@ -366,6 +366,37 @@ def lidar_scenario(seed=1, n_points=10000, room=(20.0, 20.0, 6.0), n_boxes=8, fu
     return LidarScenario(fmap, np.ascontiguousarray(xyz, np.float32), R_true, t_true, R_prior, t_prior, prior_cov(rng), extR, extT, c)
 
 
+def frame_sequence(n_frames, seed0=1000, n_raw=24000, room=(20.0, 20.0, 6.0), n_boxes=8, full_sphere=False, map_rays_factor=12, downsample=0.1, n_patches=350,
+                   max_points=None, map_points=None):
+    """F distinct frames against one VoxelMap — frame f (seed seed0 + f) has its own sensor pose (a walk around the map pose), its own noisy scan of
+    n_raw rays through the voxel-grid filter, its own perturbed prior, and its own image / visual sub-map.  Returns (fmap, cfg dict, extR, extT, frames) with
+    frames[f] = dict(xyz float32 [n][3], R_prior, t_prior, P, vs = VisualScenario)."""
+    rng = np.random.default_rng(seed0 - 1)
+    c = dict(AVIA["lio"])
+    extR, extT = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy()
+    scene = make_room(rng, room, n_boxes)
+    R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
+    t0 = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    P0 = default_cov() * 1e-3
+    n_map = int(map_points or n_raw * map_rays_factor)
+    chunks = [lidar_scan(rng, scene, R0, t0, extR, extT, min(n_map, 400000), c["dept_err"], c["beam_err"], AVIA["blind"], full_sphere) for _ in range(max(1, n_map // 400000 + 1))]
+    pw, var = world_points_and_var(np.concatenate(chunks)[:n_map], R0, t0, extR, extT, P0, c["dept_err"], c["beam_err"])
+    fmap = build_voxel_map(pw, var, c["voxel_size"], c["max_layer"], c["layer_init_num"], c["min_eigen_value"])
+    frames = []
+    for f in range(n_frames):
+        r = np.random.default_rng(seed0 + f)
+        Rf = R0 @ so3_exp(r.normal(0, np.deg2rad(2.0), 3))
+        tf = t0 + scene.R_ws @ np.array([r.normal(0, 0.3), r.normal(0, 0.3), r.normal(0, 0.05)])
+        xyz = lidar_scan(r, scene, Rf, tf, extR, extT, n_raw, c["dept_err"], c["beam_err"], AVIA["blind"], full_sphere)
+        if downsample:
+            xyz = voxel_grid_downsample(xyz, downsample)
+        if max_points and len(xyz) > max_points:
+            xyz = xyz[np.sort(r.permutation(len(xyz))[:max_points])]
+        vs = visual_scenario(seed=seed0 + f, n_patches=n_patches)
+        frames.append(dict(xyz=np.ascontiguousarray(xyz, np.float32), R_prior=Rf @ so3_exp(r.normal(0, np.deg2rad(0.5), 3)), t_prior=tf + r.normal(0, 0.03, 3), P=prior_cov(r), vs=vs))
+    return fmap, c, extR, extT, frames
+
+
 # ---- visual scenario -----------------------------------------------------------------------------------------------------------
 def make_image(rng, width=640, height=512, sigma=2.0):
     from scipy.ndimage import gaussian_filter

@@ -57,3 +57,88 @@ def test_single_process_passthrough():
     a = np.arange(6.0).reshape(3, 2)
     assert np.array_equal(frames.gather_results(a, 3), a)
     assert frames.max_over_ranks(3.5) == 3.5
+
+
+# ---- C5 path (frames.run_frames_sharded + gather) at world size 2, with a stand-in context: no GPU, the same sharding / packing / gather code as bench.py's c5_leg ----
+class _Obj:
+    pass
+
+
+class _FakeState:
+    @staticmethod
+    def from_pose(R, t, P, inv_expo=1.0):
+        s = _Obj(); s.R, s.t, s.P, s.inv_expo = np.asarray(R, float), np.asarray(t, float), np.asarray(P, float), inv_expo
+        return s
+
+
+class _FakeCtx:
+    """deterministic stand-in for fast-livo2_amd.Context: results are a function of the frame's content only"""
+    def set_scan(self, xyz, cfg):
+        self.xyz = np.asarray(xyz)
+
+    def _state(self, prior, salt):
+        st = _Obj()
+        st.rot = list((prior.R + salt).ravel()); st.pos = list(prior.t + salt); st.inv_expo = prior.inv_expo
+        st.vel = [salt, 0.0, 0.0]; st.bg = [0.0] * 3; st.ba = [0.0] * 3; st.grav = [0.0, 0.0, -9.81]; st.cov = list((prior.P * (1.0 + salt)).ravel())
+        return st
+
+    def lidar_update(self, prior, prop, cfg):
+        r = _Obj(); r.n_iters = 3; r.state = self._state(prior, float(self.xyz.sum()) * 1e-6)
+        r.iter_sums = [_Obj() for _ in range(3)]
+        for k, it in enumerate(r.iter_sums):
+            it.n_eff = len(self.xyz) - k
+        return r, None
+
+    def set_frame(self, img, pos, warp, sl, ie):
+        self.m = len(pos)
+
+    def visual_update(self, prior, prop, cfg):
+        v = _Obj(); v.n_steps = 2; v.state = self._state(prior, 1e-3 * self.m)
+        v.steps = [_Obj(), _Obj()]; v.steps[0].error = 5.0; v.steps[1].error = 4.0 + self.m
+        return v, None
+
+
+def _fake_frames(n):
+    rng = np.random.default_rng(0)
+    out = []
+    for f in range(n):
+        vs = _Obj(); vs.img = np.zeros((4, 4), np.uint8); vs.pos = rng.normal(size=(3 + f % 4, 3)); vs.warp_patch = None; vs.search_levels = None; vs.inv_expo_list = None
+        vs.R_prior, vs.t_prior, vs.P = np.eye(3), rng.normal(size=3), np.eye(19) * 1e-3
+        out.append(dict(xyz=rng.normal(size=(10 + f, 3)).astype(np.float32), R_prior=np.eye(3), t_prior=rng.normal(size=3), P=np.eye(19) * 1e-4, vs=vs))
+    return out
+
+
+def _c5_worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = importlib.import_module("fast-livo2_amd.frames")
+    fr = _fake_frames(n_frames)
+    recs, evals = frames.run_frames_sharded(_FakeCtx(), _FakeState, fr, None, None, rank, world)
+    allrec = frames.gather_results(recs, n_frames, dist)
+    ev = frames.gather_results(np.array([[float(evals)]]), world, dist)
+    dist.barrier()
+    q.put((rank, allrec.tolist(), float(ev.sum())))
+    dist.destroy_process_group()
+
+
+def test_c5_frames_sharded_and_gathered_world2():
+    sys.path.insert(0, ROOT)
+    frames = importlib.import_module("fast-livo2_amd.frames")
+    world, n_frames = 2, 9
+    single, ev1 = frames.run_frames_sharded(_FakeCtx(), _FakeState, _fake_frames(n_frames), None, None, 0, 1)
+    assert single.shape == (n_frames, frames.RESULT_DOUBLES)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_c5_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, allrec, ev in outs:
+        assert np.array_equal(np.array(allrec), single)          # every rank holds the single-rank results, frame by frame, bit for bit
+        assert ev == ev1

@@ -2,6 +2,8 @@
 returns a dict that bench.py files under `extra`."""
 import time
 
+import os
+
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0
@@ -65,6 +67,8 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
         _lockstep_leg(ctx, w, extra, copy_gbs)
     if "chains" in legs:
         _chains_leg(ctx, livo2, w, extra)
+    if "chain" in legs or "live" in legs:
+        _live_chain_leg(extra)
     if "live" in legs:
         _live_leg(ctx, w, extra)
     if legs & {"c2", "c3", "batched", "ooc"}:
@@ -165,6 +169,46 @@ def _chains_leg(ctx, livo2, w, extra, n_ctx=(2, 4)):
         extra["c4_concurrent_chains"] = {"error": repr(exc)}
     ctx.upload_map(w.sc.fmap); ctx.set_scan(w.sc.xyz, w.cfg)
     ctx.set_frame(w.vs.img, w.vs.pos, w.vs.warp_patch, w.vs.search_levels, w.vs.inv_expo_list)
+
+
+def _live_chain_leg(extra, sizes=("avia", "c4")):
+    # One chained live LIO + VIO frame through the C++ host shim (fast-livo2_amd/host/live_chain.cpp): StateEstimation on the device-resident tree ->
+    # UpdateVoxelMapFromPosterior -> retrieveFromVisualSparseMap -> computeJacobianAndUpdateEKF, called back to back on the reference's own containers — the
+    # latency a ROS maintainer would see per frame (LIVMapper.cpp:336-482, 281-334), host-synchronous where the shim scatters results back into the containers.
+    import re
+    import subprocess
+    import tempfile
+    from scenarios import live_inputs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fast-livo2_amd", "lib", "live_chain")
+    out = {}
+    for size in sizes:
+        try:
+            d = os.path.join(tempfile.gettempdir(), f"livo2_live_{size}_v1")
+            if not os.path.exists(os.path.join(d, "chain_obs_patch.bin")):
+                info = live_inputs.write_live_dir(d, live_inputs.make_live(**live_inputs.SIZES[size]))
+            else:
+                info = {}
+            res = dict(info)
+            for mode in ("full", "lean"):
+                r = subprocess.run([exe, d] + (["lean"] if mode == "lean" else []), capture_output=True, text=True, timeout=600)
+                m = re.search(r"live_chain[^:]*: (\d+) frames timed, ([\d.]+) ms per frame \(StateEstimation ([\d.]+), UpdateVoxelMapFromPosterior ([\d.]+), retrieveFromVisualSparseMap ([\d.]+), "
+                              r"computeJacobianAndUpdateEKF ([\d.]+)\); mean scan ([\d.]+) points, effct_feat_num_ ([\d.]+), sub-map ([\d.]+) patches", r.stdout)
+                if r.returncode != 0 or not m:
+                    res[mode] = {"error": (r.stderr or r.stdout)[-300:]}
+                    continue
+                res[mode] = {"frames_timed": int(m.group(1)), "ms_per_frame": float(m.group(2)), "StateEstimation_ms": float(m.group(3)), "UpdateVoxelMapFromPosterior_ms": float(m.group(4)),
+                             "retrieveFromVisualSparseMap_ms": float(m.group(5)), "computeJacobianAndUpdateEKF_ms": float(m.group(6)), "points_per_scan_mean": float(m.group(7)),
+                             "effct_feat_num": float(m.group(8)), "sub_map_patches": float(m.group(9))}
+            out[size] = res
+        except Exception as exc:
+            out[size] = {"error": repr(exc)}
+    out["def"] = ("fast-livo2_amd/host/live_chain: per frame the four shim calls of handleLIO + handleVIO back to back on std::vector containers (pageable; the scan is staged through the "
+                  "ctx's pinned buffer); 'full': StateEstimation also fills pv_list_ / ptpl_list_ / body_cov_list_ / cross_mat_list_ on the host (168 B per point D2H + ~900 B per point of "
+                  "reference structs) as the reference does; 'lean' (VoxelMapManager::host_point_lists_ = false): those lists stay on the device, where their consumers run in "
+                  "device_map_ mode; frame 0 (allocations, feat_map mirror) not timed; "
+                  "cpu_baseline.live_chain has the oracle's time for the same sequence")
+    extra["live_chain"] = out
 
 
 def _live_leg(ctx, w, extra):
