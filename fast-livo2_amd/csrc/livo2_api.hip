@@ -150,6 +150,7 @@ struct livo2_ctx {
   livo2_state *mt_state = nullptr;
   int32_t *mt_rp_rows = nullptr; size_t mt_rp_rows_cap = 0; double *mt_rp_out = nullptr; size_t mt_rp_out_cap = 0;   // livo2_map_tree_read_planes staging
   double mt_kernel_us = 0.0;
+  int mt_grow_events = 0;                   // pool growths / candidate re-packs so far (livo2_ctx_get_counter "map_tree_grow_events")
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
 #endif
@@ -179,6 +180,17 @@ template <typename T> int ensure(livo2_ctx *ctx, T *&p, size_t &cap, size_t need
   size_t newcap = std::max(need, cap + cap / 2);
   HIPCHK(hipMalloc((void **)&p, newcap * sizeof(T)));
   cap = newcap;
+  return LIVO2_OK;
+}
+
+template <typename T> int grow_array(livo2_ctx *ctx, T *&p, size_t old_n, size_t new_n, bool zero_tail) {
+  T *q = nullptr;
+  HIPCHK(hipMalloc((void **)&q, new_n * sizeof(T)));
+  if (old_n) HIPCHK(hipMemcpyAsync(q, p, old_n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+  if (zero_tail && new_n > old_n) HIPCHK(hipMemsetAsync(q + old_n, 0, (new_n - old_n) * sizeof(T), ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(p));
+  p = q;
   return LIVO2_OK;
 }
 
@@ -632,6 +644,7 @@ int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
   if (!ctx || !name || !value) return LIVO2_ERR_INVALID;
   if (std::strcmp(name, "visual_persistent_launches") == 0) { *value = ctx->vp_used; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_fallbacks") == 0) { *value = ctx->vp_fallback; return LIVO2_OK; }
+  if (std::strcmp(name, "map_tree_grow_events") == 0) { *value = ctx->mt_grow_events; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
 }
 
@@ -1088,6 +1101,100 @@ int map_tree_run(livo2_ctx *ctx, int n, int build) {
   HIPCHK(hipGetLastError());
   return LIVO2_OK;
 }
+// ---- the pools of the device tree grow on demand --------------------------------------------------------------------------------------------
+// After every update the host looks at the pool counters (it reads them anyway).  A pool that is more than `MT_GROW_AT` full is doubled before the next update:
+// new allocation, device-to-device copy, pointers swapped (the ctx stream is idle here).  An update can therefore only fail with a capacity error if ONE frame needs
+// more than the free part of a pool — i.e. more than (1 - MT_GROW_AT) of everything the map has accumulated so far.  The root hash table does not grow (its
+// size is fixed by max_roots; 8 buckets per root).  Candidate ranges are first re-packed (all lists re-emitted back to back) and only grown if that is not enough.
+#define MT_GROW_AT 0.6
+int map_tree_relayout_counters(livo2_ctx *ctx, int new_nodes, int new_planes, int new_points) {
+  MapTreeArgs &m = ctx->mt;
+  const size_t new_total = (size_t)MTC_TOTAL + new_nodes + new_planes + ((size_t)new_points / m.slab + 1);
+  int32_t *q = nullptr;
+  HIPCHK(hipMalloc((void **)&q, new_total * 4));
+  HIPCHK(hipMemcpyAsync(q, m.counters, (size_t)MTC_TOTAL * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  // the three free stacks move to their new offsets (copied whole: their tops are the counters MTC_FREE_*)
+  HIPCHK(hipMemcpyAsync(q + MTC_TOTAL, m.counters + MTC_TOTAL, (size_t)m.cap_nodes * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(q + MTC_TOTAL + new_nodes, m.counters + MTC_TOTAL + m.cap_nodes, (size_t)m.cap_planes * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(q + MTC_TOTAL + new_nodes + new_planes, m.counters + MTC_TOTAL + m.cap_nodes + m.cap_planes, ((size_t)m.cap_points / m.slab + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(m.counters));
+  m.counters = q;
+  return LIVO2_OK;
+}
+int map_tree_grow(livo2_ctx *ctx, const int32_t *c) {
+  MapTreeArgs &m = ctx->mt;
+  int rc;
+  const auto over = [](long long used, long long cap) { return (double)used > MT_GROW_AT * (double)cap; };
+  // candidate ranges: re-pack first
+  if (over(c[MTC_CAND], m.cap_cand)) {
+    HIPCHK(hipMemsetAsync(m.counters + MTC_CAND, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
+    MapTreeArgs a = m;
+    hipLaunchKernelGGL(k_mt_all_roots_dirty, dim3((m.mask + 256) / 256), dim3(256), 0, ctx->stream, a);
+    int32_t nd = 0;
+    HIPCHK(hipMemcpyAsync(&nd, m.counters + MTC_DIRTY, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // worst case of the re-emit: every list takes max(16, 2 count) again — make room for twice what was in use before packing
+    if (2LL * c[MTC_CAND] > m.cap_cand) {
+      const int nc = (int)std::min<long long>(4LL * c[MTC_CAND], INT32_MAX / 64);
+      if ((rc = grow_array(ctx, ctx->d_cand, 0, (size_t)nc * PLANE_HOT_DOUBLES, false))) return rc;
+      if ((rc = grow_array(ctx, ctx->d_cand_aux, 0, (size_t)nc, false))) return rc;
+      m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
+      a = m;
+    }
+    for (int attempt = 0; attempt < 4 && nd > 0; attempt++) {
+      hipLaunchKernelGGL(k_mt_emit, dim3(((size_t)nd * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a);
+      int32_t err = 0;
+      HIPCHK(hipMemcpyAsync(&err, m.counters + MTC_ERROR, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (!(err & MTE_CAND)) break;
+      // the re-packed lists did not fit either: double the pool and emit again (every root is still queued; ranges handed out by the failed pass are dropped)
+      const int nc = (int)std::min<long long>(2LL * m.cap_cand, INT32_MAX / 64);
+      if ((rc = grow_array(ctx, ctx->d_cand, 0, (size_t)nc * PLANE_HOT_DOUBLES, false))) return rc;
+      if ((rc = grow_array(ctx, ctx->d_cand_aux, 0, (size_t)nc, false))) return rc;
+      m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
+      err &= ~MTE_CAND;
+      HIPCHK(hipMemcpyAsync(m.counters + MTC_ERROR, &err, 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemsetAsync(m.counters + MTC_CAND, 0, 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
+      a = m;
+      hipLaunchKernelGGL(k_mt_all_roots_dirty, dim3((m.mask + 256) / 256), dim3(256), 0, ctx->stream, a);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    set_map_view(ctx);
+    ctx->mt_grow_events++;
+  }
+  const bool gn = over(c[MTC_NODES], m.cap_nodes), gp = over(c[MTC_POINTS], m.cap_points), gl = over(c[MTC_PLANES], m.cap_planes);
+  if (gn || gp || gl) {
+    const int nn = gn ? (int)std::min<long long>(2LL * m.cap_nodes, INT32_MAX / 2) : m.cap_nodes;
+    const int np = gp ? (int)std::min<long long>(2LL * m.cap_points, INT32_MAX / 16) : m.cap_points;
+    const int nl = gl ? (int)std::min<long long>(2LL * m.cap_planes, (1 << CAND_LAYER_SHIFT) - 1) : m.cap_planes;
+    if ((rc = map_tree_relayout_counters(ctx, nn, nl, np))) return rc;
+    if (gn) {
+      if ((rc = grow_array(ctx, m.nodes, (size_t)m.cap_nodes, (size_t)nn, false))) return rc;
+      if ((rc = grow_array(ctx, m.dirty_list, (size_t)m.cap_nodes, (size_t)nn, false))) return rc;
+    }
+    if (gp) {
+      if ((rc = grow_array(ctx, m.pool_pw, (size_t)m.cap_points * 3, (size_t)np * 3, false))) return rc;
+      if ((rc = grow_array(ctx, m.pool_var, (size_t)m.cap_points * 9, (size_t)np * 9, false))) return rc;
+    }
+    if (gl) {
+      if ((rc = grow_array(ctx, ctx->d_planes, (size_t)m.cap_planes * PLANE_REC_DOUBLES, (size_t)nl * PLANE_REC_DOUBLES, true))) return rc;
+      if ((rc = grow_array(ctx, ctx->d_planes_hot, (size_t)m.cap_planes * PLANE_HOT_DOUBLES, (size_t)nl * PLANE_HOT_DOUBLES, true))) return rc;
+      if ((rc = grow_array(ctx, ctx->d_plane_aux, (size_t)m.cap_planes, (size_t)nl, true))) return rc;
+    }
+    m.cap_nodes = nn; m.cap_points = np; m.cap_planes = nl;
+    m.planes = ctx->d_planes; m.planes_hot = ctx->d_planes_hot; m.plane_aux = ctx->d_plane_aux;
+    set_map_view(ctx);
+    ctx->map.n_planes = m.cap_planes;
+    ctx->mt_grow_events++;
+  }
+  return LIVO2_OK;
+}
+
 int map_tree_finish(livo2_ctx *ctx) {
   int32_t c[MTC_COUNT], fr[5];
   HIPCHK(hipMemcpyAsync(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
@@ -1102,6 +1209,7 @@ int map_tree_finish(livo2_ctx *ctx) {
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->mt_kernel_us = 1e3 * ms;
+  if (!c[MTC_ERROR]) { const int rc = map_tree_grow(ctx, c); if (rc) return rc; }
   if (c[MTC_ERROR]) {
     char msg[200];                                            // (fail() copies it into the ctx's own string)
     std::snprintf(msg, sizeof(msg), "device map tree: capacity / range error bits 0x%x (1 nodes, 2 points, 4 planes, 8 candidate lists, 16 hash table, 32 voxel key range, 64 node region)", c[MTC_ERROR]);

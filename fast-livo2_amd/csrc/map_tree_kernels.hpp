@@ -69,6 +69,8 @@ __device__ __forceinline__ int32_t *mt_free_nodes(const MapTreeArgs &a) { return
 __device__ __forceinline__ int32_t *mt_free_planes(const MapTreeArgs &a) { return a.counters + MTC_TOTAL + a.cap_nodes; }
 __device__ __forceinline__ int32_t *mt_free_slabs(const MapTreeArgs &a) { return a.counters + MTC_TOTAL + a.cap_nodes + a.cap_planes; }
 
+// point regions come in whole multiples of `slab` points, so that a freed region of any size goes back as `slab`-sized pieces
+__device__ __forceinline__ int mt_round_slab(const MapTreeArgs &a, int points) { return ((points + a.slab - 1) / a.slab) * a.slab; }
 __device__ __forceinline__ int grp_first(int v) { return __shfl(v, (threadIdx.x & 63) & ~(MT_LPG - 1), 64); }
 __device__ __forceinline__ void mt_error(const MapTreeArgs &a, int bit) { atomicOr(&a.counters[MTC_ERROR], bit); }
 
@@ -198,7 +200,7 @@ template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_roots(MapTre
     if (val != -1 && val != -3 && s.kx == key[0] && s.ky == key[1] && s.kz == key[2]) { a.seg_root[g] = s.pad; return; }
   }
   // new root voxel (voxel_map.cpp:574-583 / 630-637)
-  const int cap = a.build ? max(a.slab, e - b + 1) : a.slab;
+  const int cap = a.build ? mt_round_slab(a, e - b + 1) : a.slab;
   const int id = mt_alloc_node<RECYCLE>(a);
   const int off = mt_alloc_region<RECYCLE>(a, cap);
   if (id < 0 || off < 0) { a.seg_root[g] = -1; return; }
@@ -265,7 +267,7 @@ template <bool RECYCLE> struct MtGroup {
   // std::vector<pointWithVar>().swap(temp_points_); update_enable_ = false
   // A frozen node never stores a point again: its slab-sized region goes back to the pool.  Here it is only MARKED (pts_cap = -slab): an atomic per freeze on one
   // counter would serialise behind the allocators' (a build freezes most of its planes); k_mt_collect gathers the marks of the touched roots after the update.
-  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; if (n.pts_cap == a.slab) n.pts_cap = -a.slab; }
+  __device__ void freeze(DevNode &n) { n.update_enable = 0; n.n_temp = 0; if (n.pts_cap > 0) n.pts_cap = -n.pts_cap; }
   // init_plane(temp_points_, plane_ptr_): fit + the packed record the residual kernel reads
   __device__ void fit(DevNode &n) {
     wave_sync();                                              // the pushes of this group are visible to its 8 lanes
@@ -353,7 +355,7 @@ template <bool RECYCLE> struct MtGroup {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 8; k++)
-          if (cnt[k] > 0 && f.n.child[k] < 0) { f.n.child[k] = new_leaf(f.n, k, max(a.slab, cnt[k] + 1)); if (f.n.child[k] < 0) ok = false; }
+          if (cnt[k] > 0 && f.n.child[k] < 0) { f.n.child[k] = new_leaf(f.n, k, mt_round_slab(a, cnt[k] + 1)); if (f.n.child[k] < 0) ok = false; }
         if (!ok) { if (lane == 0) a.nodes[f.id] = f.n; if (sp == 0) n = f.n; return; }
         wave_sync();                                          // the new leaves are in memory for every lane
         // copy the points to the leaves in list order (temp_points_.push_back, new_points_++)
@@ -502,20 +504,21 @@ __global__ void __launch_bounds__(256) k_mt_collect(MapTreeArgs a) {
   int sp = -1;
   if (t < n_dirty) { sp = 0; st[0] = a.dirty_list[t]; }
   while (__any(sp >= 0)) {
-    int off = -1;
+    int off = -1, pieces = 0;
     if (sp >= 0) {
       const int id = st[sp--];
       DevNode &nd = a.nodes[id];
       for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
-      if (nd.pts_cap == -a.slab) { off = nd.pts_off; nd.pts_cap = 0; nd.pts_off = 0; }
+      if (nd.pts_cap < 0) { off = nd.pts_off; pieces = -nd.pts_cap / a.slab; nd.pts_cap = 0; nd.pts_off = 0; }
     }
-    const unsigned long long m = __ballot(off >= 0);
-    if (m) {
+    while (true) {                                               // one slab-sized piece per lane and turn (a build-time region is a few pieces)
+      const unsigned long long m = __ballot(pieces > 0);
+      if (!m) break;
       const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
       int base = 0;
       if (lane == leader) base = atomicAdd(&a.counters[MTC_FREE_SLABS], __popcll(m));
       base = __shfl(base, leader, 64);
-      if (off >= 0) mt_free_slabs(a)[base + __popcll(m & ((1ull << lane) - 1))] = off;
+      if (pieces > 0) { mt_free_slabs(a)[base + __popcll(m & ((1ull << lane) - 1))] = off; off += a.slab; pieces--; }
     }
   }
 }
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
     DevNode &nd = a.nodes[id];
     for (int k = 0; k < 8; k++) if (nd.child[k] >= 0 && sp + 1 < (int)(sizeof(st) / sizeof(st[0]))) st[++sp] = nd.child[k];
     if (nd.plane >= 0) mt_free_planes(a)[atomicAdd(&a.counters[MTC_FREE_PLANES], 1)] = nd.plane;
-    if (nd.pts_cap == a.slab) mt_free_slabs(a)[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off;
+    for (int q = 0; q < nd.pts_cap; q += a.slab) mt_free_slabs(a)[atomicAdd(&a.counters[MTC_FREE_SLABS], 1)] = nd.pts_off + q;      // (a frozen node has pts_cap 0)
     nd.root = -1; nd.layer = -1; nd.plane = -1; nd.is_plane = 0;          // (livo2_map_tree_export recognises roots by layer == 0 && root == id)
     mt_free_nodes(a)[atomicAdd(&a.counters[MTC_FREE_NODES], 1)] = id;
   }
@@ -555,6 +558,18 @@ __global__ void __launch_bounds__(256) k_mt_slide(MapTreeArgs a, SlideBox b) {
 __global__ void __launch_bounds__(256) k_mt_gather_planes(const double *__restrict__ planes, const int32_t *__restrict__ rows, int n, double *__restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, p = t >> 5, k = t & 31;
   if (p < n) out[(size_t)p * PLANE_REC_DOUBLES + k] = planes[(size_t)rows[p] * PLANE_REC_DOUBLES + k];
+}
+
+// ---- candidate-range compaction: every root becomes "dirty" with an empty range, the bump counter restarts, k_mt_emit rewrites all lists back to back ----
+// (a root whose list outgrew its range took a new one and left the old behind: on a long run the ranges are re-packed when the pool is more than half used)
+__global__ void __launch_bounds__(256) k_mt_all_roots_dirty(MapTreeArgs a) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h > a.mask) return;
+  const RootSlot &s = a.slots[h];
+  if (s.val == -1) return;
+  DevNode &r = a.nodes[s.pad];
+  r.cand_begin = 0; r.cand_cap = 0;
+  a.dirty_list[atomicAdd(&a.counters[MTC_DIRTY], 1)] = s.pad;
 }
 
 // ---- what k_lidar_residual reads: the root's slot and, for a non-plane root, the depth-first list of its descendant planes (record copies) -----------

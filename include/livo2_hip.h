@@ -174,8 +174,12 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
  * between frames.  Points of one root voxel are processed in input order like the reference's loop; root voxels are independent and run in
  * parallel.  livo2_map_tree_create makes the (empty) tree the resident map of the ctx, replacing any snapshot of livo2_map_upload (and vice versa);
  * with a tree resident, the plane indices of livo2_lidar_points (match_plane / normal_plane) are rows of the device plane table — livo2_map_tree_export
- * returns the planes in that numbering.  Capacities are fixed at creation (0 = defaults derived from max_roots); exhausting one fails the update
- * with LIVO2_ERR_RANGE and leaves the tree unusable. */
+ * returns the planes in that numbering.  The capacities given at creation (0 = defaults derived from max_roots) are STARTING sizes: after every update the
+ * pools of nodes, points, plane rows and candidate records are checked and, when more than 60 % full, doubled (device-to-device copy; candidate ranges are first
+ * re-packed) before the next frame, and what mapSliding / freezing nodes release is reused first.  An update can therefore only fail with LIVO2_ERR_RANGE if a
+ * SINGLE frame needs more than the free 40 % of a pool (the failed frame's points are then partly dropped; allocation counters are rolled back, so the tree
+ * stays usable for later frames), or if the number of root voxels outgrows the hash table (8 buckets per max_roots; not grown).  max_points_num up to
+ * LIVO2_MAX_POINTS_NUM (the point regions are sized max_points_num + 2 at creation). */
 typedef struct livo2_map_tree_cfg {
   double voxel_size;            /* lio/voxel_size (narrowed to float like BuildVoxelMap's local, voxel_map.cpp:534) */
   double planer_threshold;      /* lio/min_eigen_value (narrowed to float: VoxelOctoTree::planer_threshold_) */

@@ -187,3 +187,46 @@ def test_lidar_update_reads_the_device_tree(ctx, livo2, orc):
     res2, _ = ctx.lidar_update(pcur, pprop, pcfg)
     assert res2.n_iters >= 1 and abs(res2.iter_sums[0].n_eff - res_tree.iter_sums[0].n_eff) < 0.05 * res_tree.iter_sums[0].n_eff
     ctx.upload_map(fm)                                        # leave a snapshot resident for whatever test comes next on this ctx
+
+
+def test_soak_random_walk_with_sliding_grows_recycles_and_matches_oracle(ctx, orc):
+    """200 frames of a random walk through a long corridor with mapSliding on (a +-6 m box follows the sensor), pools deliberately small at creation: they must grow on
+    demand instead of killing the tree (LIVO2_ERR_RANGE), what sliding and freezing release must be reused (pool high-water marks stay bounded once the box is full),
+    candidate ranges are re-packed, and after the last frame the tree has the oracle's shape (voxel_map.cpp:609-641, 924-972)."""
+    rng = np.random.default_rng(201)
+    c = dict(synth.AVIA["lio"])
+    scene = synth.make_room(rng, (80.0, 8.0, 5.0), 30)
+    extR, extT = synth.AVIA["extrinsic_R"], synth.AVIA["extrinsic_T"]
+    R0 = scene.R_ws @ synth.rot_from_rpy(0.0, 0.0, 0.1)
+    t0 = scene.R_ws @ np.array([-30.0, 0.0, 1.4]) + scene.t_ws
+    P0 = synth.default_cov() * 1e-3
+
+    def cloud(n, R, t):
+        xyz = synth.lidar_scan(rng, scene, R, t, extR, extT, n, c["dept_err"], c["beam_err"], synth.AVIA["blind"], False)
+        return synth.world_points_and_var(xyz, R, t, extR, extT, P0, c["dept_err"], c["beam_err"])
+    pw0, var0 = cloud(20000, R0, t0)
+    ctx.map_tree_create(c, max_roots=40000, max_nodes=9000, max_planes=4000, max_points=260000, max_cand=1500)     # fits the build, not the walk
+    ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+    om = orc.OracleMap.build(pw0, var0.reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"])
+    thresh, half = 1.0, 12
+    marks = []
+    R, t = R0, t0
+    for k in range(200):
+        step = scene.R_ws @ np.array([0.3 if k < 160 else -0.3, rng.normal(0, 0.05), 0.0])
+        R, t = R @ synth.rot_from_rpy(0.0, 0.0, rng.normal(0, 0.01)), t + step
+        pw, var = cloud(2500, R, t)
+        ctx.map_tree_update(pw, var.reshape(-1, 9))
+        om.update(pw, var.reshape(-1, 9))
+        ra, rb = ctx.map_tree_slide(t, thresh, half)[0], om.slide(t, thresh, half)
+        assert ra == rb, k
+        st = ctx.map_tree_stats()
+        assert st["error"] == 0, (k, st)
+        marks.append((st["nodes"], st["points"], st["planes"]))
+        if k % 20 == 0:
+            print("soak frame", k, st, "grow events", ctx.counter("map_tree_grow_events"))
+    assert ctx.counter("map_tree_grow_events") > 0                       # the initial pools were too small
+    dev = _flat(ctx.map_tree_export(), c)
+    assert _compare(dev, om.export(c["voxel_size"], c["max_layer"])) > 100
+    # no leak: while the box moves at constant speed through similar clutter the bump counters stop climbing (recycling covers the demand)
+    late = np.array(marks[120:160], float)
+    assert late[-1, 0] <= 1.25 * late[0, 0] and late[-1, 1] <= 1.25 * late[0, 1] and late[-1, 2] <= 1.25 * late[0, 2], (late[0], late[-1])
