@@ -397,6 +397,88 @@ int ref_visual_level(const orc_visual_cfg *cfg, const uint8_t *img, const double
   return 0;
 }
 
+// VIOManager::retrieveFromVisualSparseMap (vio.cpp:352-782) on a visual map given as flat arrays (scenarios.synth.RetrieveChainScenario): feat_map of VisualPoints with
+// their Feature lists (obs_ in the given order), the current Frame, resetGrid, then the call as processFrame makes it (vio.cpp:1802-1808).  raycast_en = false.
+struct ref_retrieve_cfg {
+  double fx, fy, cx, cy, d[5]; int32_t distortion, width, height;
+  double R_cur[9], t_cur[3], inv_expo_cur;
+  int32_t patch_pyrimid_level, normal_en, ncc_en, border, grid_size, grid_n_height;
+  double ncc_thre, outlier_threshold;
+};
+int ref_visual_retrieve(const ref_retrieve_cfg *c, const uint8_t *img, const uint8_t *ref_imgs, int n_ref, const double *pg, int n_pg, int n_pts, const double *pos,
+                        const double *normal, const int64_t *keys, const uint8_t *active, const uint8_t *ninit, const int32_t *ref_patch_in, const int32_t *obs_offset,
+                        const int32_t *obs_id, const int32_t *obs_img_idx, const int32_t *obs_level, const double *obs_px, const double *obs_f, const double *obs_R,
+                        const double *obs_t, const double *obs_inv_expo, const float *obs_patch,
+                        int32_t *cell_type, int32_t *cell_point, float *cell_dist, int32_t *ref_patch_out, int32_t *n_sub, int32_t *sub_point, int32_t *sub_obs,
+                        int32_t *sub_search, float *sub_error, float *sub_patch /*[n_sub][L][64]*/, double *sub_inv_expo) {
+  VIOManager vio;
+  std::unique_ptr<vk::AbstractCamera> cam;
+  if (c->distortion == 2) cam.reset(new vk::EquidistantCamera(c->width, c->height, 1.0, c->fx, c->fy, c->cx, c->cy, c->d[0], c->d[1], c->d[2], c->d[3]));
+  else cam.reset(new vk::PinholeCamera(c->width, c->height, 1.0, c->fx, c->fy, c->cx, c->cy, c->distortion ? c->d[0] : 0.0, c->distortion ? c->d[1] : 0.0, c->distortion ? c->d[2] : 0.0,
+                                       c->distortion ? c->d[3] : 0.0, c->distortion ? c->d[4] : 0.0));
+  vio.cam = cam.get();
+  StatesGroup st, prop; st.inv_expo_time = c->inv_expo_cur;
+  vio.state = &st; vio.state_propagat = &prop;
+  vio.grid_size = c->grid_size; vio.grid_n_height = c->grid_n_height; vio.patch_size = 8; vio.patch_pyrimid_level = c->patch_pyrimid_level; vio.max_iterations = 5;
+  vio.img_point_cov = 100; vio.exposure_estimate_en = true; vio.inverse_composition_en = false; vio.normal_en = c->normal_en != 0; vio.raycast_en = false; vio.ncc_en = c->ncc_en != 0;
+  vio.colmap_output_en = false; vio.has_ref_patch_cache = false; vio.plot_flag = false; vio.outlier_threshold = c->outlier_threshold; vio.ncc_thre = c->ncc_thre;
+  vio.Rcl = M3D::Identity(); vio.Rli = M3D::Identity(); vio.Pcl = V3D::Zero(); vio.Pli = V3D::Zero();
+  { CoutCapture cap; vio.initializeVIO(); }
+  vio.border = c->border;
+  const size_t bytes = (size_t)c->width * c->height;
+  cv::Mat cur(c->height, c->width, CV_8UC1); std::memcpy(cur.data, img, bytes);
+  std::vector<cv::Mat> refs(n_ref);
+  for (int k = 0; k < n_ref; k++) { refs[k] = cv::Mat(c->height, c->width, CV_8UC1); std::memcpy(refs[k].data, ref_imgs + bytes * k, bytes); }
+  vio.new_frame_.reset(new Frame(vio.cam, cur));
+  { M3D R; V3D t; rm_in(R, c->R_cur); rm_in(t, c->t_cur); vio.new_frame_->T_f_w_ = SE3(R, t); }
+  std::vector<VisualPoint *> pts(n_pts, nullptr);
+  std::unordered_map<const Feature *, int> obs_index;
+  std::unordered_map<const VisualPoint *, int> pt_index;
+  for (int i = 0; i < n_pts; i++) {
+    VisualPoint *pt = new VisualPoint(V3D(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+    pt->normal_ = V3D(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]); pt->previous_normal_ = pt->normal_;
+    pt->is_normal_initialized_ = ninit[i] != 0;
+    pt->ref_patch = nullptr;
+    if (active[i]) {
+      for (int k = obs_offset[i]; k < obs_offset[i + 1]; k++) {
+        M3D R; rm_in(R, obs_R + (size_t)k * 9);
+        float *patch = new float[64]; std::memcpy(patch, obs_patch + (size_t)k * 64, 256);
+        Feature *f = new Feature(pt, patch, V2D(obs_px[2 * k], obs_px[2 * k + 1]), V3D(obs_f[3 * k], obs_f[3 * k + 1], obs_f[3 * k + 2]), SE3(R, V3D(obs_t[3 * k], obs_t[3 * k + 1], obs_t[3 * k + 2])),
+                                 obs_level[k]);
+        f->img_ = refs[obs_img_idx[k]]; f->id_ = obs_id[k]; f->inv_expo_time_ = obs_inv_expo[k];
+        pt->obs_.push_back(f);                            // list order = the order given
+        obs_index[f] = k;
+        if (ref_patch_in[i] == k) { pt->ref_patch = f; pt->has_ref_patch_ = true; }
+      }
+    }
+    pts[i] = pt; pt_index[pt] = i;
+    VOXEL_LOCATION key(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]);
+    auto it = vio.feat_map.find(key);
+    if (it == vio.feat_map.end()) { VOXEL_POINTS *vp = new VOXEL_POINTS(0); vio.feat_map[key] = vp; it = vio.feat_map.find(key); }
+    it->second->voxel_points.push_back(pt); it->second->count++;
+  }
+  std::vector<pointWithVar> pgv(n_pg);
+  for (int i = 0; i < n_pg; i++) pgv[i].point_w = V3D(pg[3 * i], pg[3 * i + 1], pg[3 * i + 2]);
+  std::unordered_map<VOXEL_LOCATION, VoxelOctoTree *> plane_map;
+  vio.resetGrid();
+  { CoutCapture cap; vio.retrieveFromVisualSparseMap(cur, pgv, plane_map); }
+  for (int i = 0; i < vio.length; i++) {
+    cell_type[i] = vio.grid_num[i]; cell_dist[i] = vio.map_dist[i];
+    cell_point[i] = (vio.grid_num[i] == VIOManager::TYPE_MAP && vio.retrieve_voxel_points[i]) ? pt_index[vio.retrieve_voxel_points[i]] : -1;
+  }
+  for (int i = 0; i < n_pts; i++) ref_patch_out[i] = (pts[i]->has_ref_patch_ && pts[i]->ref_patch) ? obs_index[pts[i]->ref_patch] : -1;
+  SubSparseMap &sm = *vio.visual_submap;
+  const int L = c->patch_pyrimid_level;
+  *n_sub = (int)sm.voxel_points.size();
+  for (int k = 0; k < *n_sub; k++) {
+    sub_point[k] = pt_index[sm.voxel_points[k]];
+    sub_obs[k] = sm.voxel_points[k]->ref_patch ? obs_index[sm.voxel_points[k]->ref_patch] : -1;
+    sub_search[k] = sm.search_levels[k]; sub_error[k] = sm.errors[k]; sub_inv_expo[k] = sm.inv_expo_list[k];
+    std::memcpy(sub_patch + (size_t)k * L * 64, sm.warp_patch[k].data(), (size_t)L * 256);
+  }
+  return vio.length;
+}
+
 // calcBodyCov (voxel_map.cpp:15-34)
 void orc_calc_body_cov(const double *pb3, float range_inc, float degree_inc, double deg2rad, double *cov9, double *pb_out3) {
   (void)deg2rad;
@@ -428,3 +510,4 @@ void orc_so3_exp(const double *v3, double *R9) { M3D R = Exp(v3[0], v3[1], v3[2]
 void orc_so3_log(const double *R9, double *v3) { M3D R; rm_in(R, R9); V3D v = Log(R); for (int k = 0; k < 3; k++) v3[k] = v[k]; }
 
 } // extern "C"
+

@@ -100,6 +100,12 @@ public:
     for (Index j = 0; j < cols(); j++) for (Index i = 0; i < rows(); i++) r.coeffRef(i, j) = internal::real_part(coeff(i, j));
     return r;
   }
+  Matrix<Scalar, internal::pick(RowsAtCompileTime, ColsAtCompileTime), internal::pick(RowsAtCompileTime, ColsAtCompileTime)> asDiagonal() const {   // of a vector
+    const Index n = size();
+    Matrix<Scalar, internal::pick(RowsAtCompileTime, ColsAtCompileTime), internal::pick(RowsAtCompileTime, ColsAtCompileTime)> r; r.resize(n, n);
+    for (Index j = 0; j < n; j++) for (Index i = 0; i < n; i++) r.coeffRef(i, j) = (i == j) ? lin(i) : Scalar(0);
+    return r;
+  }
   Matrix<Scalar, RowsAtCompileTime, 1> diagonal() const { Matrix<Scalar, RowsAtCompileTime, 1> r; r.resize(rows(), 1); for (Index i = 0; i < rows(); i++) r.coeffRef(i, 0) = coeff(i, i); return r; }
 
   template <int BR, int BC> Matrix<Scalar, BR, BC> block(Index i0, Index j0) const {
@@ -234,7 +240,7 @@ public:
   typedef DenseBase<D> Base;
   typedef typename Base::Scalar Scalar;
   typedef Eigen::Index Index;
-  using Base::block; using Base::col; using Base::cols; using Base::derived; using Base::row; using Base::rows; using Base::size;
+  using Base::block; using Base::col; using Base::cols; using Base::derived; using Base::row; using Base::rows; using Base::size; using Base::diagonal;
   using Base::operator(); using Base::operator[]; using Base::x; using Base::y; using Base::z; using Base::w;
 
   Scalar &coeffRef(Index i, Index j) { return derived().coeffRef_(i, j); }
@@ -271,6 +277,13 @@ public:
   Block<D, Dynamic, Dynamic> block(Index i0, Index j0, Index nr, Index nc) { return Block<D, Dynamic, Dynamic>(derived(), i0, j0, nr, nc); }
   Block<D, 1, Base::ColsAtCompileTime> row(Index i) { return Block<D, 1, Base::ColsAtCompileTime>(derived(), i, 0, 1, cols()); }
   Block<D, Base::RowsAtCompileTime, 1> col(Index j) { return Block<D, Base::RowsAtCompileTime, 1>(derived(), 0, j, rows(), 1); }
+
+  struct DiagonalRef {                                        // m.diagonal() = v
+    D &m;
+    template <class O> DiagonalRef &operator=(const DenseBase<O> &o) { assert(o.size() == std::min(m.rows(), m.cols())); for (Index i = 0; i < o.size(); i++) m.coeffRef(i, i) = o.lin(i); return *this; }
+    operator Matrix<Scalar, Base::RowsAtCompileTime, 1>() const { return static_cast<const D &>(m).diagonal(); }
+  };
+  DiagonalRef diagonal() { return DiagonalRef{derived()}; }
 
   template <class S, internal::if_arith<S> = 0> CommaInitializer<D> operator<<(const S &s) { CommaInitializer<D> c(derived()); c.put(static_cast<Scalar>(s)); return c; }
   template <class O> CommaInitializer<D> operator<<(const DenseBase<O> &o) { CommaInitializer<D> c(derived()); c.put(o); return c; }

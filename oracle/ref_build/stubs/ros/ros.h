@@ -27,3 +27,4 @@ public:
 #define ROS_ERROR(...) ((void)0)
 #define ROS_WARN(...) ((void)0)
 #define ROS_INFO(...) ((void)0)
+#define ROS_ASSERT(c) ((void)0)

@@ -3,6 +3,8 @@
 #pragma once
 #include <cmath>
 #include <geometry_msgs/Quaternion.h>
+#include <omp.h>
+#include <ros/ros.h>
 namespace tf {
 inline geometry_msgs::Quaternion createQuaternionMsgFromRollPitchYaw(double roll, double pitch, double yaw) {
   const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;

@@ -247,6 +247,93 @@ def test_visual_mp4_build_matches(orc, ref_mp4, M):
     _visual_check(a, b, tol=1e-9)
 
 
+# ----------------------------------------------------------------------------------------------- retrieveFromVisualSparseMap (row N2)
+class _RetrCfg(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5), ("distortion", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("inv_expo_cur", C.c_double), ("patch_pyrimid_level", C.c_int32),
+                ("normal_en", C.c_int32), ("ncc_en", C.c_int32), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_height", C.c_int32), ("ncc_thre", C.c_double),
+                ("outlier_threshold", C.c_double)]
+
+
+def _ref_retrieve(ref, cs):
+    sel = cs.sel
+    c = _RetrCfg()
+    c.fx, c.fy, c.cx, c.cy, c.width, c.height = sel.cam["fx"], sel.cam["fy"], sel.cam["cx"], sel.cam["cy"], sel.cam["width"], sel.cam["height"]
+    d, k = sel.cam.get("d"), sel.cam.get("k")
+    c.distortion = 2 if k is not None else (0 if d is None else 1)
+    c.d[:] = ([float(x) for x in k] + [0.0]) if k is not None else ([0.0] * 5 if d is None else [float(x) for x in d])
+    c.R_cur[:] = sel.R_cur.ravel().tolist(); c.t_cur[:] = sel.t_cur.tolist(); c.inv_expo_cur = float(cs.inv_expo_cur)
+    L = int(cs.cfg["patch_pyrimid_level"])
+    c.patch_pyrimid_level, c.normal_en, c.ncc_en = L, int(cs.cfg["normal_en"]), int(cs.cfg["ncc_en"])
+    c.border, c.grid_size, c.grid_n_height = int(sel.border), int(sel.grid_size), int(sel.grid_n_height)
+    c.ncc_thre, c.outlier_threshold = float(cs.cfg["ncc_thre"]), float(cs.cfg["outlier_threshold"])
+    n, length = len(sel.pos), sel.grid_n_width * sel.grid_n_height
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    keep = dict(img=np.ascontiguousarray(cs.img, np.uint8), refs=np.ascontiguousarray(cs.ref_imgs, np.uint8), pg=f64(sel.pg), pos=f64(sel.pos), normal=f64(cs.normal),
+                keys=np.ascontiguousarray(sel.keys, np.int64), active=np.ascontiguousarray(sel.active, np.uint8), ninit=np.ascontiguousarray(cs.normal_initialized, np.uint8),
+                rp=i32(cs.ref_patch), off=i32(cs.obs_offset), oid=i32(cs.obs_id), oimg=i32(cs.obs_img_idx), olvl=i32(cs.obs_level), opx=f64(cs.obs_px), of=f64(cs.obs_f),
+                oR=f64(cs.obs_R), ot=f64(cs.obs_t), oie=f64(cs.obs_inv_expo), opatch=np.ascontiguousarray(cs.obs_patch, np.float32))
+    out = dict(cell_type=np.zeros(length, np.int32), cell_point=np.zeros(length, np.int32), cell_dist=np.zeros(length, np.float32), ref_patch=np.zeros(n, np.int32),
+               sub_point=np.zeros(length, np.int32), sub_obs=np.zeros(length, np.int32), sub_search=np.zeros(length, np.int32), sub_error=np.zeros(length, np.float32),
+               sub_patch=np.zeros((length, L, 64), np.float32), sub_inv_expo=np.zeros(length))
+    ns = C.c_int32()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    ref.ref_visual_retrieve.restype = C.c_int
+    ref.ref_visual_retrieve.argtypes = [C.POINTER(_RetrCfg), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 16 + [C.c_void_p] * 4 + [C.POINTER(C.c_int32)] + [C.c_void_p] * 6
+    got = ref.ref_visual_retrieve(C.byref(c), vp(keep["img"]), vp(keep["refs"]), len(keep["refs"]), vp(keep["pg"]), len(keep["pg"]), n, vp(keep["pos"]), vp(keep["normal"]),
+                                  vp(keep["keys"]), vp(keep["active"]), vp(keep["ninit"]), vp(keep["rp"]), vp(keep["off"]), vp(keep["oid"]), vp(keep["oimg"]), vp(keep["olvl"]),
+                                  vp(keep["opx"]), vp(keep["of"]), vp(keep["oR"]), vp(keep["ot"]), vp(keep["oie"]), vp(keep["opatch"]),
+                                  vp(out["cell_type"]), vp(out["cell_point"]), vp(out["cell_dist"]), vp(out["ref_patch"]), C.byref(ns), vp(out["sub_point"]), vp(out["sub_obs"]),
+                                  vp(out["sub_search"]), vp(out["sub_error"]), vp(out["sub_patch"]), vp(out["sub_inv_expo"]))
+    assert got == length, (got, length)
+    m = ns.value
+    for k in ("sub_point", "sub_obs", "sub_search", "sub_error", "sub_patch", "sub_inv_expo"):
+        out[k] = out[k][:m]
+    return out
+
+
+@pytest.mark.parametrize("normal_en,camera", [(True, None), (False, None), (True, "radtan"), (True, "equidistant")])
+def test_retrieve_from_visual_sparse_map(orc, ref, normal_en, camera):
+    """the WHOLE VIOManager::retrieveFromVisualSparseMap of the reference (depth image, grid selection by distance, depth-continuity gate, reference-patch choice
+    incl. the remembered choice / getCloseViewObs / warp_map reuse, affine warp, photometric + NCC gates) against the oracle's three stages, on one visual map:
+    which point every grid cell keeps (and at which float distance), which observation becomes its reference patch, which candidates survive, their search level,
+    float error and warped patches — identical."""
+    cs = synth.retrieve_chain_scenario(seed=83, n_pg=8000, n_vis=12000, grid_n_height=51, normal_en=normal_en, ncc_en=not normal_en, ncc_thre=0.6)
+    # In the pipeline a point gets at most ONE Feature per frame (id_ = new_frame_->id_, vio.cpp:882, 961), so the ids inside a point's obs_ are distinct.  The synthetic
+    # generator repeats ids; with ALL ids of a point equal the reference divides 0 / 0, never assigns `ref_ftr` and then uses the uninitialised pointer (vio.cpp:644-676) —
+    # undefined behaviour that nothing can be pinned to.  Repeats get their own id here.
+    cs.obs_id = np.array(cs.obs_id).copy()
+    for i in range(len(cs.sel.pos)):
+        seen = {}
+        for k in range(cs.obs_offset[i], cs.obs_offset[i + 1]):
+            j = seen.get(int(cs.obs_id[k]), 0); seen[int(cs.obs_id[k])] = j + 1
+            cs.obs_id[k] += 1000 * j
+    if camera == "radtan":
+        cs.sel.cam = dict(cs.sel.cam); cs.sel.cam["d"] = synth.AVIA_RADTAN
+    if camera == "equidistant":
+        cs.sel.cam = dict(cs.sel.cam); cs.sel.cam["k"] = synth.HILTI_EQUIDISTANT
+    a = orc.visual_retrieve(cs)
+    b = _ref_retrieve(ref, cs)
+    TYPE_MAP = 1
+    sel = a["sel"]
+    assert np.array_equal(sel["cell_type"] == TYPE_MAP, b["cell_type"] == TYPE_MAP)
+    on = b["cell_type"] == TYPE_MAP
+    assert on.sum() > 200
+    assert np.array_equal(sel["cell_point"][on], b["cell_point"][on]) and np.array_equal(sel["cell_dist"][on], b["cell_dist"][on])
+    act = np.asarray(cs.sel.active) != 0                                                    # (points without observations carry no Feature in the driver: nothing to compare)
+    assert np.array_equal(a["ref_patch"][act], b["ref_patch"][act])                        # pt->ref_patch / has_ref_patch_ after the call
+    assert len(a["sub_point"]) > 50
+    assert np.array_equal(a["sub_point"], b["sub_point"])
+    if normal_en:                                                                           # (!normal_en: ref_ftr of getCloseViewObs is a local; its inv_expo_time_ and warped patch below identify it)
+        assert np.array_equal(a["sub_obs"], b["sub_obs"])
+    keep = a["tail"]["accepted"] != 0
+    assert np.array_equal(a["tail"]["search_level"][keep], b["sub_search"])
+    assert np.array_equal(a["tail"]["error"][keep], b["sub_error"])
+    assert np.array_equal(a["tail"]["patch_wrap"][keep], b["sub_patch"])
+    assert np.array_equal(cs.obs_inv_expo[a["sub_obs"]], b["sub_inv_expo"])
+
+
 # ------------------------------------------------------------------------------------------------------------------------ VoxelMap
 def _scene(seed):
     rng = np.random.default_rng(seed)
@@ -366,3 +453,90 @@ def test_map_sliding(orc, ref):
         ea, eb = maps[0].export(args[0], args[1]), maps[1].export(args[0], args[1])
         assert {tuple(k) for k in ea.root_key} == {tuple(k) for k in eb.root_key}
     assert ra > 0
+
+
+# ---- rows N3 / N4: ImuProcess::UndistortPcl (IMU_Processing.cpp:237-541), whole function: message queue -> steps, forward propagation, backward undistortion ----
+class _RefImuCfg(C.Structure):
+    _fields_ = [("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3), ("cov_bias_acc", C.c_double * 3), ("cov_inv_expo", C.c_double),
+                ("mean_acc_norm", C.c_double), ("ba_bg_est_en", C.c_int32), ("gravity_est_en", C.c_int32), ("exposure_estimate_en", C.c_int32), ("first_call", C.c_int32),
+                ("extR", C.c_double * 9), ("extT", C.c_double * 3), ("last_prop_end_time", C.c_double), ("prop_end_time", C.c_double), ("acc_s_last", C.c_double * 3),
+                ("angvel_last", C.c_double * 3)]
+
+
+def _imu_messages(seed, n, hz=200.0, t0=1700000000.25):
+    """a message queue as LIVMapper::sync_packages leaves it: msgs[0] = last_imu (before the propagation start), the scan's messages after it"""
+    rng = np.random.default_rng(seed)
+    t = t0 + np.arange(n) / hz + rng.uniform(-2e-4, 2e-4, n)
+    return np.c_[t, rng.normal(0, 0.4, (n, 3)) + [0.1, -0.2, 0.3], rng.normal(0, 0.6, (n, 3)) + [0.2, -0.1, 9.8]]
+
+
+def _steps_from_messages(msgs, prop_beg, prop_end):
+    """the caller's half of the oracle contract (orc_imu.hpp header): IMU_Processing.cpp:332 (skip), 335-341 (averages), 355-372 (dt, offs_t)"""
+    steps = []
+    for i in range(len(msgs) - 1):
+        head, tail = msgs[i], msgs[i + 1]
+        if tail[0] < prop_beg:
+            continue
+        avg = 0.5 * (head[1:] + tail[1:])
+        if head[0] < prop_beg:
+            dt, offs = tail[0] - prop_beg, tail[0] - prop_beg
+        elif i != len(msgs) - 2:
+            dt, offs = tail[0] - head[0], tail[0] - prop_beg
+        else:
+            dt, offs = prop_end - head[0], prop_end - prop_beg
+        steps.append(np.r_[avg, dt, offs])
+    return np.array(steps).reshape(-1, 8)
+
+
+@pytest.mark.parametrize("seed,flags,first_call,stale", [(0, (1, 1, 1), 0, 0), (1, (0, 1, 1), 0, 0), (2, (1, 0, 0), 0, 2), (3, (1, 1, 1), 1, 0), (4, (0, 0, 0), 0, 1)])
+def test_imu_undistort_pcl(orc, ref, seed, flags, first_call, stale):
+    """The reference's own UndistortPcl on a message queue and a scan == the oracle's imu_propagate on the steps derived from the same queue + orc.undistort on the
+    poses.  `stale` > 0 puts that many extra messages BEFORE the propagation start (the `continue` at IMU_Processing.cpp:332).  mean_acc_norm is exactly representable
+    so that mean_acc.norm() == it."""
+    from scenarios import imu_inputs as II
+    rng = np.random.default_rng(50 + seed)
+    n = 22
+    msgs = _imu_messages(seed, n)
+    prop_beg = msgs[stale, 0] + 0.6 / 200.0                   # between msgs[stale] and msgs[stale + 1]
+    prop_end = msgs[-2, 0] + 0.4 / 200.0                      # before the last message (IMU_Processing.cpp:367-372)
+    cfgd = dict(II.CFG, mean_acc_norm=9.75, first_call=first_call)
+    cfgd["ba_bg_est_en"], cfgd["gravity_est_en"], cfgd["exposure_estimate_en"] = flags
+    st = II.make_state(orc, orc.StatePOD, seed)
+    extR, extT = synth.so3_exp(np.array([0.02, -0.01, 0.03])), np.array([0.04, 0.02, -0.03])
+    npts = 4000
+    xyz = rng.uniform(-20, 20, (npts, 3)).astype(np.float32)
+    curv = np.sort(rng.uniform(0, (prop_end - prop_beg) * 1000.0, npts)).astype(np.float32)        # time offsets in ms, ascending (as preprocess leaves them)
+    acc_last, gyr_last = rng.normal(0, 0.5, 3) + [0, 0, 0.1], rng.normal(0, 0.2, 3)
+
+    c = _RefImuCfg()
+    for k in ("cov_gyr", "cov_acc", "cov_bias_gyr", "cov_bias_acc"):
+        getattr(c, k)[:] = cfgd[k]
+    c.cov_inv_expo, c.mean_acc_norm, c.first_call = cfgd["cov_inv_expo"], cfgd["mean_acc_norm"], first_call
+    c.ba_bg_est_en, c.gravity_est_en, c.exposure_estimate_en = flags
+    c.extR[:] = extR.ravel().tolist(); c.extT[:] = extT.tolist()
+    c.last_prop_end_time, c.prop_end_time = prop_beg, prop_end
+    c.acc_s_last[:] = acc_last.tolist(); c.angvel_last[:] = gyr_last.tolist()
+    out_ref, poses_ref, n_poses = orc.StatePOD(), np.zeros((n + 1, 22)), C.c_int(0)
+    xyz_ref = xyz.copy()
+    M = np.ascontiguousarray(msgs)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    ref.ref_imu_undistort.restype = C.c_int
+    ref.ref_imu_undistort.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = ref.ref_imu_undistort(C.byref(c), C.byref(st), vp(M), n, vp(xyz_ref), vp(curv), npts, C.byref(out_ref), vp(poses_ref), C.byref(n_poses))
+    assert rc == 0
+
+    steps = _steps_from_messages(msgs, prop_beg, prop_end)
+    assert len(steps) == n - 1 - stale and n_poses.value == len(steps) + 1
+    out, poses, _ = orc.imu_propagate(st, steps, cfgd)
+    # the reference's G_m_s2 is the constant of common_lib.h:29 — the value the oracle's configuration carries
+    assert cfgd["G_m_s2"] == 9.81
+    first = np.r_[0.0, acc_last, gyr_last, np.array(st.vel), np.array(st.pos), np.array(st.rot)]                # IMU_Processing.cpp:281
+    assert np.array_equal(poses_ref[0], first)
+    assert np.abs(poses_ref[1:n_poses.value] - poses).max() < 1e-12
+    assert np.array_equal(poses_ref[1:n_poses.value, 0], poses[:, 0])                                            # offs_t: exact
+    _state_close(out, out_ref)
+    assert out_ref.inv_expo == (1.0 if first_call else st.inv_expo)
+    # backward undistortion, row N3: on the REFERENCE's poses (so that a last-bit difference in a pose cannot hide a difference in the loop)
+    und = orc.undistort(xyz, curv, poses_ref[:n_poses.value], np.array(out_ref.rot), np.array(out_ref.pos), extR, extT)
+    assert np.array_equal(und, xyz_ref)
+    assert np.abs(xyz_ref - xyz).max() > 1e-3                                                                    # the scan did move
