@@ -170,37 +170,59 @@ class _Sc:            # what fast-livo2_amd.configs.lidar_cfg reads
         self.cfg, self.extR, self.extT = cfg, extR, extT
 
 
-def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_frames, shape, barrier):
+C5_CONTEXTS = 3
+
+
+def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_frames, shape, barrier, local_device=0):
     """Batched distinct frames round-robin over the ranks, H2D of every scan / image / sub-map and D2H of every result inside the timed region; the per-frame
-    records are gathered on every rank (RCCL all_gather) and rank 0 re-runs the first frame of every other rank to check the gathered copy bit for bit."""
+    records are gathered on every rank (RCCL all_gather) and rank 0 re-runs the first frame of every other rank to check the gathered copy bit for bit.
+    Timed twice: one context per GPU (host-synchronous calls, nothing overlaps) and C5_CONTEXTS contexts per GPU, one host thread each (transfers of one frame
+    overlap the updates of another); the records of the two passes must be identical."""
     fmap, lio_cfg, extR, extT, frames = c5_frames(n_frames, shape)
     cfg = cfgs.lidar_cfg(_Sc(lio_cfg, extR, extT)); vcfg = cfgs.visual_cfg(frames[0]["vs"], mp_proc_num=4)
     ctx.upload_map(fmap)
-    frames_mod.run_frame(ctx, livo2.State, frames[rank % len(frames)], cfg, vcfg)            # warm-up: allocations of this frame size
-    barrier()
-    t0 = time.perf_counter()
-    recs, evals = frames_mod.run_frames_sharded(ctx, livo2.State, frames, cfg, vcfg, rank, world)
-    ctx.synchronize()
-    dt_local = time.perf_counter() - t0
-    dt = frames_mod.max_over_ranks(dt_local, dist, device=device)
-    allrec = frames_mod.gather_results(recs, len(frames), dist, device=device)
-    ev = frames_mod.gather_results(np.array([[float(evals)]]), world, dist, device=device)
-    check = None
-    if rank == 0:
-        bad = 0
-        for r in range(world):
-            if r < len(frames):
-                rec, _ = frames_mod.run_frame(ctx, livo2.State, frames[r], cfg, vcfg)
-                bad += int(not np.array_equal(rec, allrec[r]))
-        check = {"frames_recomputed_on_rank0": min(world, len(frames)), "mismatches": bad}
+    more = [livo2.Context(local_device) for _ in range(C5_CONTEXTS - 1)]
+    try:
+        for c in [ctx] + more:
+            if c is not ctx:
+                c.upload_map(fmap)
+            frames_mod.run_frame(c, livo2.State, frames[rank % len(frames)], cfg, vcfg)            # warm-up: allocations of this frame size
+        out = {}
+        for name, cs in (("one_context", ctx), ("pipelined", [ctx] + more)):
+            barrier()
+            t0 = time.perf_counter()
+            recs, evals = frames_mod.run_frames_sharded(cs, livo2.State, frames, cfg, vcfg, rank, world)
+            for c in ([cs] if cs is ctx else cs):
+                c.synchronize()
+            dt_local = time.perf_counter() - t0
+            dt = frames_mod.max_over_ranks(dt_local, dist, device=device)
+            allrec = frames_mod.gather_results(recs, len(frames), dist, device=device)
+            ev = frames_mod.gather_results(np.array([[float(evals)]]), world, dist, device=device)
+            out[name] = (dt, allrec, float(ev.sum()))
+        check = None
+        if rank == 0:
+            bad = 0
+            for r in range(world):
+                if r < len(frames):
+                    rec, _ = frames_mod.run_frame(ctx, livo2.State, frames[r], cfg, vcfg)
+                    bad += int(not np.array_equal(rec, out["one_context"][1][r])) + int(not np.array_equal(rec, out["pipelined"][1][r]))
+            check = {"frames_recomputed_on_rank0": min(world, len(frames)), "mismatches": bad,
+                     "pipelined_records_equal_one_context_records": bool(np.array_equal(out["one_context"][1], out["pipelined"][1]))}
+    finally:
+        for c in more:
+            c.close()
     pts = [len(f["xyz"]) for f in frames]
     h2d = float(np.mean([f["xyz"].nbytes + f["vs"].img.nbytes + f["vs"].pos.nbytes + f["vs"].warp_patch.nbytes + 12 * len(f["vs"].pos) for f in frames]))
-    return {"shape": shape, "frames": len(frames), "frames_per_s": len(frames) / dt, "ms_per_frame_per_gpu": 1e3 * dt / (len(frames) / world), "evals_per_s": float(ev.sum()) / dt,
+    dt1, _, ev1 = out["one_context"]; dtk, _, evk = out["pipelined"]
+    return {"shape": shape, "frames": len(frames), "frames_per_s": len(frames) / dtk, "ms_per_frame_per_gpu": 1e3 * dtk / (len(frames) / world), "evals_per_s": evk / dtk,
+            "contexts_per_gpu": C5_CONTEXTS, "frames_per_s_one_context": len(frames) / dt1, "ms_per_frame_per_gpu_one_context": 1e3 * dt1 / (len(frames) / world),
+            "evals_per_s_one_context": ev1 / dt1,
             "points_per_frame_mean": float(np.mean(pts)), "patches_per_frame": int(len(frames[0]["vs"].pos)), "h2d_bytes_per_frame": h2d,
             "d2h_bytes_per_frame": 8 * frames_mod.RESULT_DOUBLES + 2 * 8 * 400, "gather": "all_gather of the per-frame records (%d doubles each)" % frames_mod.RESULT_DOUBLES,
             "gathered_copy_check": check,
             "def": "F distinct frames (seeds 1000+f) round-robin over the ranks; per frame: scan H2D + Morton sort + body covariance, full LiDAR update from the frame's prior, image + "
-                   "sub-map H2D, full visual update, results D2H; host-synchronous calls from Python, caller memory pageable (the scan goes through the ctx's pinned staging); map resident"}
+                   "sub-map H2D, full visual update, results D2H; calls from Python, caller memory pageable (the scan goes through the ctx's pinned staging); map resident. "
+                   "frames_per_s: %d contexts per GPU, one host thread and one stream each (frames_per_s_one_context: a single context, host-synchronous)" % C5_CONTEXTS}
 
 
 def frame_priors(livo2, synth, sc, vs, F, seed):
@@ -302,12 +324,37 @@ def cpu_baseline(sc, vs, budget_s=20.0):
             runs += 1
         out[threads] = dict(value=(le + ve) / (ls + vsec), lidar=le / ls, visual=ve / vsec, runs=runs, lidar_ms=1e3 * ls / runs, visual_ms=1e3 * vsec / runs)
     o4 = out[4]
-    return {"value": o4["value"], "unit": "evals/s", "cores": 4, "kind": "port",
+    ref_build = reference_sources_timing(orc, sc, vs, cur, prop, vcur, vprop, o4)
+    return {"reference_sources": ref_build, "value": o4["value"], "unit": "evals/s", "cores": 4, "kind": "port",
             "sample": f"{o4['runs']} frame updates of the same C4 frame ({len(sc.xyz)} points + {len(vs.pos)} patches): StateEstimation window (LIVMapper.cpp:368-374) + "
                       f"computeJacobianAndUpdateEKF window (vio.cpp:1808-1812), OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "lidar_evals_per_s": o4["lidar"], "visual_evals_per_s": o4["visual"], "lidar_update_ms": o4["lidar_ms"], "visual_update_ms": o4["visual_ms"],
             "value_1thread": out[1]["value"], "lidar_evals_per_s_1thread": out[1]["lidar"], "visual_evals_per_s_1thread": out[1]["visual"],
             "value_all_cores": out[ncores]["value"], "host_cores": ncores}, (orc, lib)
+
+
+def reference_sources_timing(orc, sc, vs, cur, prop, vcur, vprop, o4):
+    """The reference's OWN translation units (oracle/_ref/libref_mp4.so: voxel_map.cpp / vio.cpp compiled unmodified with -DMP_EN -DMP_PROC_NUM=4 against the
+    stand-in headers of oracle/ref_build/stubs, -O2 -ffp-contract=off) on the same C4 frame, same two windows.  A datum beside the port, not the baseline: the
+    stand-in Eigen evaluates eagerly without Eigen's vectorised kernels, and the library is the portable -O2 build that travelled with the snapshot."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_mp4.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        rlib = orc.load(path)
+        rom = orc.OracleMap.from_flat(sc.fmap, rlib)
+        cfg = orc.lidar_cfg(sc.cfg, sc.extR, sc.extT, num_threads=4)
+        vcfg = orc.visual_cfg(vs, num_threads=4)
+        ls, vsec, runs = [], [], 0
+        while runs < 3:
+            r = orc.lidar_state_estimation(rom, cfg, sc.xyz, cur, prop, want_points=False)
+            v = orc.visual_update(vcfg, vs, vcur, vprop, rlib)
+            ls.append(r["seconds"]); vsec.append(v["seconds"]); runs += 1
+        return {"lidar_update_ms": 1e3 * min(ls), "visual_update_ms": 1e3 * min(vsec), "runs": runs, "threads": 4,
+                "build": "oracle/ref_build/Makefile: g++ -O2 -ffp-contract=off -fopenmp -DMP_EN -DMP_PROC_NUM=4, reference sources unmodified, stand-in Eigen/PCL/OpenCV/vikit headers",
+                "port_lidar_update_ms": o4["lidar_ms"], "port_visual_update_ms": o4["visual_ms"]}
+    except Exception as exc:                                                              # the checker must never take the bench line down
+        return {"error": repr(exc)}
 
 
 def cpu_widened_rows(orc, lib):
@@ -501,9 +548,9 @@ def main():
              "per_rank_evals": per_rank[:, 0].tolist()}
     if args.c5_frames > 0 and not args.no_extra:
         try:
-            c5 = {"c1_shaped": c5_leg(ctx, livo2, frames, H, dist, device, rank, world, args.c5_frames, "c1", barrier)}
+            c5 = {"c1_shaped": c5_leg(ctx, livo2, frames, H, dist, device, rank, world, args.c5_frames, "c1", barrier, local_device=local_rank)}
             if world == 1 or args.c5_frames >= 8 * world:
-                c5["c4_shaped"] = c5_leg(ctx, livo2, frames, H, dist, device, rank, world, max(8, world), "c4", barrier)
+                c5["c4_shaped"] = c5_leg(ctx, livo2, frames, H, dist, device, rank, world, 12 if world == 1 else 2 * world, "c4", barrier, local_device=local_rank)
             extra["c5"] = c5
         except Exception as exc:
             extra["c5"] = {"error": repr(exc)}

@@ -72,10 +72,35 @@ def run_frame(ctx, State, frame, cfg, vcfg):
 
 
 def run_frames_sharded(ctx, State, frames, cfg, vcfg, rank, world):
-    """rank's share (frames rank, rank + world, ...) in order; returns (records [n_local, RESULT_DOUBLES], residual evaluations done)"""
+    """rank's share (frames rank, rank + world, ...) in order; returns (records [n_local, RESULT_DOUBLES], residual evaluations done).
+    `ctx` may be a list of K contexts of the rank's GPU (each with the map resident): frame k of the share then runs on context k % K from its own host thread, so
+    that the H2D of one frame, the updates of another and the D2H of a third overlap on the contexts' streams (the C ABI calls release the GIL).  The records do
+    not depend on K: a context's results depend on its inputs only."""
     mine = frames_for_rank(len(frames), rank, world)
-    recs, evals = np.zeros((len(mine), RESULT_DOUBLES)), 0
-    for k, f in enumerate(mine):
-        recs[k], e = run_frame(ctx, State, frames[f], cfg, vcfg)
-        evals += e
-    return recs, evals
+    recs = np.zeros((len(mine), RESULT_DOUBLES))
+    ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+    if len(ctxs) == 1 or len(mine) < 2:
+        evals = 0
+        for k, f in enumerate(mine):
+            recs[k], e = run_frame(ctxs[0], State, frames[f], cfg, vcfg)
+            evals += e
+        return recs, evals
+    import threading
+    K = len(ctxs)
+    evals, errors = [0] * K, []
+
+    def work(j):
+        try:
+            for k in range(j, len(mine), K):
+                recs[k], e = run_frame(ctxs[j], State, frames[mine[k]], cfg, vcfg)
+                evals[j] += e
+        except BaseException as exc:                                   # re-raised on the caller's thread
+            errors.append(exc)
+    th = [threading.Thread(target=work, args=(j,)) for j in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+    return recs, sum(evals)

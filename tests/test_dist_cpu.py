@@ -115,7 +115,7 @@ def _c5_worker(rank, world, port, n_frames, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = importlib.import_module("fast-livo2_amd.frames")
     fr = _fake_frames(n_frames)
-    recs, evals = frames.run_frames_sharded(_FakeCtx(), _FakeState, fr, None, None, rank, world)
+    recs, evals = frames.run_frames_sharded([_FakeCtx(), _FakeCtx(), _FakeCtx()] if rank else _FakeCtx(), _FakeState, fr, None, None, rank, world)   # rank 1: three contexts, one thread each
     allrec = frames.gather_results(recs, n_frames, dist)
     ev = frames.gather_results(np.array([[float(evals)]]), world, dist)
     dist.barrier()
@@ -129,6 +129,8 @@ def test_c5_frames_sharded_and_gathered_world2():
     world, n_frames = 2, 9
     single, ev1 = frames.run_frames_sharded(_FakeCtx(), _FakeState, _fake_frames(n_frames), None, None, 0, 1)
     assert single.shape == (n_frames, frames.RESULT_DOUBLES)
+    piped, evk = frames.run_frames_sharded([_FakeCtx() for _ in range(4)], _FakeState, _fake_frames(n_frames), None, None, 0, 1)      # contexts in threads: same records
+    assert np.array_equal(piped, single) and evk == ev1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

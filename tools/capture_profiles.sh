@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root (gpurun -- 'bash tools/capture_profiles.sh r02'): the bench line, the rocprofv3 kernel trace of the headline-only
+# Run ON THE GPU BOX from the repo root (gpurun -- 'bash tools/capture_profiles.sh r03'): the bench line, the rocprofv3 kernel trace of the headline-only
 # command (one workload per trace: C4 frame updates), and the PMC passes (each in its own run, counters only with --kernel-trace) -> gpurun_out/prof_<tag>/ .
 # Copy what should be judged into profiles/ afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd); export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p "$OUT"
 HEAD="python bench.py --no-cpu --no-extra --steps 10 --warmup 2"
@@ -26,4 +26,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   timeout 900 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc$k -o pmc -- python bench.py --no-cpu > /dev/null 2>> "$OUT/pmc.err"
   python tools/kt_summary.py "$(find /tmp/pmc$k -name '*results.db' | head -1)" "pmc pass $k ($set), python bench.py --no-cpu (all legs)" --split-us 3 | grep -E "^#|_batch" >> "$OUT/pmc_batched.txt"
 done
+ls -la "$OUT"
+# round 3: the persistent visual update against the launch-per-step sequence, and the parity sweep with this library
+timeout 300 python tools/vis_persist_probe.py > "$OUT/vis_persist_probe.txt" 2> "$OUT/vis_persist_probe.err"
+timeout 900 python tests/sweeps/parity_sweep.py 12 8 > "$OUT/parity_sweep.txt" 2> "$OUT/parity_sweep.err"
 ls -la "$OUT"
