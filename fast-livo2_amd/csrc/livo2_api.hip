@@ -130,7 +130,6 @@ struct livo2_ctx {
   VisualBatchEntry *vbd_entries = nullptr, *vbh_entries = nullptr;      // [LIVO2_MAX_BATCH], device / pinned
   livo2_visual_result *vbd_results = nullptr, *vbh_results = nullptr;   // [LIVO2_MAX_BATCH], device / pinned
   // device-resident VoxelMap (map_tree_kernels.hpp)
-  bool visual_fused = [] { const char *e = std::getenv("LIVO2_VISUAL_FUSED"); return e ? std::atoi(e) != 0 : false; }();   // LIVO2_VISUAL_FUSED=1: one k_visual_step launch per (level, iteration) instead of residual + solve (tools/vis_probe.py)
   // persistent visual update (k_visual_update_persistent): one launch per computeJacobianAndUpdateEKF.  LIVO2_VISUAL_PERSISTENT=0 (or livo2_ctx_set_option) selects
   // the launch-per-step sequence instead.
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
@@ -462,7 +461,7 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
 // all contexts of this process on one device share it: a launch is admitted only if the blocks of the persistent launches still in flight (their completion
 // events have not fired) plus its own fit, otherwise the caller takes the launch-per-step path.  Kernels that do not spin (everything else in this library) can
 // only delay a persistent grid, never deadlock it.
-struct PersistSlot { hipEvent_t ev; int blocks; int device; };
+struct PersistSlot { const livo2_ctx *owner; hipEvent_t ev; int blocks; int device; bool pending; };
 std::mutex g_persist_mu;
 std::vector<PersistSlot> g_persist;
 int persist_capacity(int device) {
@@ -471,36 +470,49 @@ int persist_capacity(int device) {
   if (cap[device] == 0) {
     hipDeviceProp_t prop; int per_cu = 0;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_visual_update_persistent, VIS_BLOCK, 0) != hipSuccess || per_cu < 1) return 0;
-    cap[device] = prop.multiProcessorCount * std::min(per_cu, 1);        // one block per CU: the redundant solve wants a CU's LDS bandwidth to itself
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_visual_update_persistent, VP_BLOCK, 0) != hipSuccess || per_cu < 1) return 0;
+    cap[device] = prop.multiProcessorCount * std::min(per_cu, 2);        // a C4 frame takes 250 blocks (one per CU); a second grid of another context may share the CUs
   }
   return cap[device];
 }
-// returns the grid size to launch (0: not admitted)
+// Returns the grid size to launch (0: not admitted).  Admission RESERVES the blocks under the lock (slot marked pending until persist_register has recorded the
+// event behind the launch): two host threads admitting at the same time must not both see a free device — two half-resident grids would wait for each other's
+// words until the watchdog fires.
 int persist_admit(livo2_ctx *ctx, int want_blocks) {
   const int cap = persist_capacity(ctx->device);
   if (cap <= 0) return 0;
+  if (!ctx->vp_done && hipEventCreateWithFlags(&ctx->vp_done, hipEventDisableTiming) != hipSuccess) return 0;
   std::lock_guard<std::mutex> lk(g_persist_mu);
-  int busy = 0;
+  int busy = 0, own = -1;
   for (size_t i = 0; i < g_persist.size();) {
-    if (hipEventQuery(g_persist[i].ev) == hipSuccess) { g_persist[i] = g_persist.back(); g_persist.pop_back(); continue; }
+    if (g_persist[i].owner == ctx) { own = (int)i; i++; continue; }            // this context's own earlier grid runs BEFORE the new one (same stream)
+    if (!g_persist[i].pending && hipEventQuery(g_persist[i].ev) == hipSuccess) {
+      if (own == (int)g_persist.size() - 1) own = (int)i;
+      g_persist[i] = g_persist.back(); g_persist.pop_back(); continue;
+    }
     if (g_persist[i].device == ctx->device) busy += g_persist[i].blocks;
     i++;
   }
   const int grid = std::min(want_blocks, VP_MAX_BLOCKS);
   if (busy + grid > cap) return 0;
+  if (own >= 0) { g_persist[own].blocks = std::max(g_persist[own].blocks, grid); g_persist[own].pending = true; }
+  else g_persist.push_back(PersistSlot{ctx, ctx->vp_done, grid, ctx->device, true});
   return grid;
 }
+// after the launch (or instead of it, blocks = 0): the event now stands for the newest grid of this context
 void persist_register(livo2_ctx *ctx, int blocks) {
-  if (!ctx->vp_done && hipEventCreateWithFlags(&ctx->vp_done, hipEventDisableTiming) != hipSuccess) return;
-  if (hipEventRecord(ctx->vp_done, ctx->stream) != hipSuccess) return;
+  const bool recorded = blocks > 0 && hipEventRecord(ctx->vp_done, ctx->stream) == hipSuccess;
   std::lock_guard<std::mutex> lk(g_persist_mu);
-  for (auto &sl : g_persist) if (sl.ev == ctx->vp_done) { sl.blocks = blocks; return; }      // the event was re-recorded: it now stands for the newer launch (same stream: the older one completes first)
-  g_persist.push_back(PersistSlot{ctx->vp_done, blocks, ctx->device});
+  for (size_t i = 0; i < g_persist.size(); i++)
+    if (g_persist[i].owner == ctx) {
+      if (recorded) { g_persist[i].blocks = blocks; g_persist[i].pending = false; }
+      else { g_persist[i] = g_persist.back(); g_persist.pop_back(); }
+      return;
+    }
 }
 void persist_forget(livo2_ctx *ctx) {
   std::lock_guard<std::mutex> lk(g_persist_mu);
-  for (size_t i = 0; i < g_persist.size(); i++) if (g_persist[i].ev == ctx->vp_done) { g_persist[i] = g_persist.back(); g_persist.pop_back(); break; }
+  for (size_t i = 0; i < g_persist.size(); i++) if (g_persist[i].owner == ctx) { g_persist[i] = g_persist.back(); g_persist.pop_back(); break; }
 }
 
 int check_visual_cfg(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
@@ -637,7 +649,6 @@ int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; 
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (!ctx || !name) return LIVO2_ERR_INVALID;
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
-  if (std::strcmp(name, "visual_fused") == 0) { ctx->visual_fused = value != 0; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown option");
 }
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
@@ -2318,16 +2329,18 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
   int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
   const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(ctx->M, 1)) : visual_grid(std::max(ctx->M, 1));
   VisualKernelArgs a{};
-  if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && !ctx->visual_fused && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
+  if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
+    {                        // (before the admission: nothing between the reservation and the launch may fail) exchange buffers start as all-zero words: tag 0 is never a step's tag
+      const size_t c0 = ctx->vp_rows_cap, c1 = ctx->vp_errs_cap;
+      rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_BLOCKS * VIS_PSTRIDE * 2); if (rc) return rc;
+      rc = ensure(ctx, ctx->d_vp_errs, ctx->vp_errs_cap, (size_t)2 * std::max(ctx->M_cap, 512)); if (rc) return rc;
+      if (ctx->vp_rows_cap != c0) HIPCHK(hipMemsetAsync(ctx->d_vp_rows, 0, ctx->vp_rows_cap * 8, ctx->stream));
+      if (ctx->vp_errs_cap != c1) HIPCHK(hipMemsetAsync(ctx->d_vp_errs, 0, ctx->vp_errs_cap * 8, ctx->stream));
+      if (ctx->vp_prof && !ctx->d_vp_prof) HIPCHK(hipMalloc((void **)&ctx->d_vp_prof, VP_MAX_BLOCKS * 32 * 16 * 8));
+      if (ctx->vp_prof) HIPCHK(hipMemsetAsync(ctx->d_vp_prof, 0, VP_MAX_BLOCKS * 32 * 16 * 8, ctx->stream));
+    }
     const int G = persist_admit(ctx, grid);
     if (G > 0) {
-      {                        // exchange buffers start as all-zero words: tag 0 is never a step's tag
-        const size_t c0 = ctx->vp_rows_cap, c1 = ctx->vp_errs_cap;
-        rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_BLOCKS * VIS_PSTRIDE * 2); if (rc) return rc;
-        rc = ensure(ctx, ctx->d_vp_errs, ctx->vp_errs_cap, (size_t)2 * std::max(ctx->M_cap, 512)); if (rc) return rc;
-        if (ctx->vp_rows_cap != c0) HIPCHK(hipMemsetAsync(ctx->d_vp_rows, 0, ctx->vp_rows_cap * 8, ctx->stream));
-        if (ctx->vp_errs_cap != c1) HIPCHK(hipMemsetAsync(ctx->d_vp_errs, 0, ctx->vp_errs_cap * 8, ctx->stream));
-      }
       VisPersistArgs p{};
       p.a = make_visual_args(ctx, cfg, 0);
       p.a.errors = ctx->d_errors;
@@ -2335,14 +2348,11 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       p.levels = cfg->patch_pyrimid_level; p.max_iterations = cfg->max_iterations; p.error_threads = cfg->mp_proc_num; p.img_point_cov = cfg->img_point_cov;
       ctx->vp_seq = (ctx->vp_seq + 1) & 0xffffffu; if (ctx->vp_seq == 0) ctx->vp_seq = 1;       // tag 0 = never-written memory
       p.tag_base = ctx->vp_seq << 8;
-      if (ctx->vp_prof) {
-        if (!ctx->d_vp_prof) HIPCHK(hipMalloc((void **)&ctx->d_vp_prof, 8 * 32 * 16 * 8));
-        HIPCHK(hipMemsetAsync(ctx->d_vp_prof, 0, 8 * 32 * 16 * 8, ctx->stream));
-        p.prof = ctx->d_vp_prof;
-      }
-      { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_update_persistent, dim3(G), dim3(VIS_BLOCK), 0, ctx->stream, p, ctx->d_ctl); t.done(); }
-      HIPCHK(hipGetLastError());
-      persist_register(ctx, G);
+      if (ctx->vp_prof) p.prof = ctx->d_vp_prof;
+      { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_update_persistent, dim3(G), dim3(VP_BLOCK), 0, ctx->stream, p, ctx->d_ctl); t.done(); }
+      const hipError_t le = hipGetLastError();
+      persist_register(ctx, le == hipSuccess ? G : 0);            // a failed launch gives its reservation back
+      HIPCHK(le);
       ctx->vp_used++;
       return LIVO2_OK;
     }
@@ -2358,13 +2368,6 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       hipLaunchKernelGGL(k_visual_ref_precompute, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r);
     }
     for (int it = 0; it < iters; it++) {
-      if (!inverse && ctx->visual_fused) {        // one launch per step: residual grid + last-block solve
-        Timed t(ctx, 1);
-        hipLaunchKernelGGL(k_visual_step, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, ctx->d_ctl, ctx->d_partials, mode, mode == 1 ? it : (it == 0 ? 0 : 1), cfg->img_point_cov,
-                           cfg->mp_proc_num);
-        t.done();
-        continue;
-      }
       {
         Timed t(ctx, 1);
         if (inverse) hipLaunchKernelGGL(k_visual_inverse_residual<false>, dim3(grid), dim3(VIS_BLOCK), 0, ctx->stream, a, r, ctx->d_ctl, ctx->d_partials, (mode == 1 && it > 0) ? 1 : 0);
@@ -2553,11 +2556,11 @@ int livo2_visual_batch_iterations_async(livo2_ctx *ctx, int32_t n_frames, int32_
   return vbatch_enqueue(ctx, n_frames, state_in, prop, cfg, level, level, iters, 2);
 }
 
-// LIVO2_VP_PROF=1: stamps of the last persistent visual update, [8 blocks][32 steps][8] (tools/vis_persist_probe.py)
+// LIVO2_VP_PROF=1: stamps of the last persistent visual update, [VP_MAX_BLOCKS = 256 blocks][32 steps][16] (tools/vis_persist_probe.py)
 int livo2_debug_vp_prof(livo2_ctx *ctx, unsigned long long *out) {
   if (!ctx || !out || !ctx->d_vp_prof) return LIVO2_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(out, ctx->d_vp_prof, 8 * 32 * 16 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, ctx->d_vp_prof, VP_MAX_BLOCKS * 32 * 16 * 8, hipMemcpyDeviceToHost));
   return LIVO2_OK;
 }
 #ifdef LIVO2_PHASE_PROF

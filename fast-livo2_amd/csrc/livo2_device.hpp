@@ -101,6 +101,9 @@ struct DevCtl {
   double solve_hth[49], solve_htz[7], solve_solution[DS];   // livo2_esikf_solve scratch
 };
 
+// atan out of line: inlined into a kernel with a device-side loop its 20 polynomial coefficients are hoisted above the loop and spilled (see so3_exp_call below)
+__device__ __attribute__((noinline)) double atan_call(double x) { return atan(x); }
+
 // ---- camera models of rpg_vikit (third party, unpinned: reference README.md:76-84) as used through cam->world2cam / cam->cam2world ------------------
 // model 0: vk::PinholeCamera without distortion; 1: vk::PinholeCamera with the radial-tangential coefficients d0..d4 (config/camera_pinhole.yaml);
 // 2: vk::EquidistantCamera with k1..k4 in d[0..3] (config/camera_fisheye_HILTI22.yaml) — the Kannala-Brandt / OpenCV-fisheye polynomial
@@ -118,7 +121,7 @@ __device__ __forceinline__ void cam_project(int model, const double *d, double f
     const double xd = x * cdist + d[2] * a1 + d[3] * a2, yd = y * cdist + d[2] * a3 + d[3] * a1;
     px = xd * fx + cx; py = yd * fy + cy;
   } else {
-    const double r = sqrt(u * u + v * v), theta = atan(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double r = sqrt(u * u + v * v), theta = atan_call(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
     const double thetad = theta * (1 + d[0] * t2 + d[1] * t4 + d[2] * t6 + d[3] * t8);
     const double scaling = (r > 1e-8) ? thetad / r : 1.0;
     px = fx * u * scaling + cx; py = fy * v * scaling + cy;

@@ -15,7 +15,7 @@
 #include "esikf_solve.hpp"
 #include <float.h>
 
-#define VIS_BLOCK 512
+#define VIS_BLOCK 256          // residual kernels: 4 waves = one per SIMD of a CU (round 3: 512-thread blocks put two waves of a latency chain on every SIMD of HALF the chip)
 #define VIS_WAVES (VIS_BLOCK / LIVO2_WAVE)
 #define VIS_NSUM 37          // 28 (sym 7x7) + 7 + err_sum + n_meas
 #define VIS_PSTRIDE 40
@@ -108,7 +108,7 @@ struct __attribute__((aligned(16))) VisWaveLds {
   float nm[VIS_PPW];
 };
 
-// Stores / loads of data that another workgroup of the SAME launch consumes (k_visual_step): relaxed atomics at agent scope = write-through stores and
+// Stores / loads of data that another workgroup of the SAME launch consumes (formerly the fused step kernel; kept for experiments): relaxed atomics at agent scope = write-through stores and
 // cache-bypassing loads (sc1), so the hand-off needs no L2 write-back / invalidate fence (HIP guide section 6, guideline 16, second recipe).
 template <bool XB, typename T> __device__ __forceinline__ void xb_store(T *p, T v) {
   if (XB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
@@ -577,40 +577,6 @@ __global__ void __launch_bounds__(512) k_visual_solve(DevCtl *__restrict__ ctl, 
   visual_solve_body(SL, ctl, partials, nblocks, mode, level, iter, img_point_cov, va);
 }
 
-// One launch per (level, iteration): the residual grid, and the LAST block to finish runs the reduction + accept / revert + solve (the body of k_visual_solve)
-// — a dependent launch costs ~4 us on this stack before its first useful instruction, a frame's visual update issues 40 of them as two kernels per step.
-// Hand-off (HIP guide section 6, guideline 16: placement-independent): the partial row and the per-patch errors are written with agent-scope (write-through) stores, every wave drains them, block barrier,
-// ONE lane takes a ticket (hdr.reserved, zeroed with the header at every update and by the last block); the block that draws the last ticket reads the other
-// blocks' rows and errors with agent-scope (cache-bypassing) loads — no L2 write-back / invalidate fence (the fenced variant measured +5 us per step).  The LDS of the two phases is a union.
-union VisStepLds { struct { VisWaveLds lds[VIS_WAVES]; double red[VIS_WAVES][VIS_PSTRIDE]; } r; VisSolveLds s; };
-__global__ void __launch_bounds__(VIS_BLOCK) k_visual_step(VisualKernelArgs a, DevCtl *ctl, double *partials, int mode, int iter, double img_point_cov, int error_threads) {
-  VPHASE(0);
-  if (mode == 1 && iter > 0 && ctl->hdr.stop) return;        // the level has ended: nothing to evaluate, nothing to solve
-  __shared__ VisStepLds U;
-  __shared__ int last_block;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int patch0 = (blockIdx.x * VIS_WAVES + wave) * VIS_PPW;
-  double out_val = 0.0;
-  if (patch0 < a.M) out_val = visual_wave_body<false, true>(a, ctl, U.r.lds[wave], patch0, lane);
-  VPHASE(6);
-  vis_block_store<true>(U.r.red, out_val, partials + (size_t)blockIdx.x * VIS_PSTRIDE);
-  // every block fetches what the solve needs besides the rows (P, both states) while its stores drain: the block that turns out to be last starts the
-  // solve with them in LDS / registers (U.s.s does not overlap `red`, and the barrier inside vis_block_store ended all use of the wave tiles)
-  double craw[6] = {0, 0, 0, 0, 0, 0};
-  if (mode != 0 && wave == 0) esikf_prefetch_wave(ctl, U.s.s, img_point_cov, lane, craw);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores (errors, partial row) are acknowledged
-  __syncthreads();
-  if (tid == 0) {
-    const int ticket = atomicAdd(&ctl->hdr.reserved, 1);
-    last_block = (ticket == (int)gridDim.x - 1) ? 1 : 0;
-    if (last_block) ctl->hdr.reserved = 0;
-  }
-  __syncthreads();
-  VPHASE(7);
-  if (!last_block) return;
-  const VisualSolveArgs va = {a.errors, a.M, error_threads};
-  visual_solve_body<true>(U.s, ctl, partials, (int)gridDim.x, mode, a.level, iter, img_point_cov, va, mode != 0 ? craw : nullptr);
-}
 // one block per frame of a batch
 __global__ void __launch_bounds__(512) k_visual_solve_batch(const VisualBatchEntry *__restrict__ entries, int mode, int level, int iter, double img_point_cov, int error_threads) {
   const VisualBatchEntry &e = entries[blockIdx.x];
@@ -687,6 +653,14 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict
 // Co-residency: the host launches at most as many blocks as the device holds at once (occupancy query, in-flight accounting across contexts, else it falls
 // back to the per-step launches); a word that does not arrive within ~2 s sets hdr.pad[0] and every block leaves (livo2_visual_update_fetch reports it).
 #define VP_MAX_BLOCKS 256
+#ifndef VP_SLEEP0
+#define VP_SLEEP0 0
+#endif
+#ifndef VP_SLEEP
+#define VP_SLEEP 1
+#endif
+#define VP_RPT 21                // rows per thread and pass of the collect: 12 slices x 21 = 252 rows in ONE round of loads (a second pass is a second ~2-us round trip)
+#define VP_BLOCK 512             // the collect / solve phases use 480 threads; the residual phase runs on waves 0..VIS_WAVES-1 (one per SIMD), the others wait at the barrier
 struct VisPersistArgs {
   VisualKernelArgs a;
   unsigned long long *rows;     // [2][G][VIS_PSTRIDE][2]: every double as two words {tag << 32 | low half}, {tag << 32 | high half}
@@ -694,10 +668,10 @@ struct VisPersistArgs {
   int32_t levels, max_iterations, error_threads;
   uint32_t tag_base;            // launch sequence number << 8
   double img_point_cov;
-  unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 8][step < 32][16] stamps of the 100 MHz clock, else null
+  unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 256][step < 32][16] stamps of the 100 MHz clock, else null
 };
-#define VPP(k) do { if (p.prof && tid == 0 && blockIdx.x < 8 && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define VPP_W(k, w) do { if (p.prof && tid == (w) * LIVO2_WAVE && blockIdx.x < 8 && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define VPP(k) do { if (p.prof && tid == 0 && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define VPP_W(k, w) do { if (p.prof && tid == (w) * LIVO2_WAVE && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 struct __attribute__((aligned(16))) VisPersistLds {
   union {
     struct { VisWaveLds lds[VIS_WAVES]; double red[VIS_WAVES][VIS_PSTRIDE]; } r;
@@ -716,17 +690,216 @@ __device__ __forceinline__ void vis_log_lds(SolveLds &s) {           // Log(cur^
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) rotd[i * 3 + j] = (s.cur[i] * s.prop[j] + s.cur[3 + i] * s.prop[3 + j]) + s.cur[6 + i] * s.prop[6 + j];
-  double l[3]; so3_log(rotd, l);
-  s.vec[0] = l[0]; s.vec[1] = l[1]; s.vec[2] = l[2];
+  So3Mat m;
+#pragma unroll
+  for (int i = 0; i < 9; i++) m.v[i] = rotd[i];
+  const So3Vec l = so3_log_call(m);
+  s.vec[0] = l.v[0]; s.vec[1] = l.v[1]; s.vec[2] = l.v[2];
 }
 
 typedef unsigned long long vp_word;
 __device__ __forceinline__ vp_word vp_ld(const vp_word *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void vp_st(vp_word *p, vp_word v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ void __launch_bounds__(VIS_BLOCK) k_visual_update_persistent(VisPersistArgs p, DevCtl *__restrict__ ctl) {
+// The phases of a step are separate NON-inlined functions: inlined into one loop body the compiler hoists each phase's invariants (addresses, lane predicates,
+// libm constants) above the step loop, where they are live across every other phase — 256 VGPRs + 112 spilled + 194 spilled SGPRs, reloaded in every phase.  A call
+// costs ~0.1 us; a phase's registers now are its own (kernel maximum = the largest phase).  The kernel arguments are read where they are needed from the kernarg
+// segment (scalar loads; VisPersistArgs is the kernel's first parameter, offset 0), the block's LDS through an address-space-3 pointer.
+#ifndef VP_PHASE_ATTR
+#define VP_PHASE_ATTR __forceinline__
+#endif
+typedef __attribute__((address_space(3))) VisPersistLds *VpLds;
+__device__ __forceinline__ const VisPersistArgs &vp_args() {
+  return *(const VisPersistArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+}
+#define VP_TIMEOUT 200000000ull          // 100 MHz ticks: 2 s
+
+// ---- 1. residual of this block's patch groups; the row and the errors are published as tagged words
+__device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step_v) {
+  VisPersistLds &SL = *(VisPersistLds *)slp;
+  const VisPersistArgs &p = vp_args();
+  const int level = __builtin_amdgcn_readfirstlane(level_v), step_global = __builtin_amdgcn_readfirstlane(step_v);
+  // Per-thread index arithmetic (window offsets, row addresses, lane predicates, ...) is invariant over the steps; hoisted out of the step loop it would live in
+  // registers across every phase.  The thread index is therefore re-materialised opaquely in every phase, and everything derived from it stays inside the phase.
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));
+  const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = (int)gridDim.x, M = p.a.M;
+  const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
+  const int buf = step_global & 1;
+  const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
+  vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
+  vp_word *errs = p.errs + (size_t)buf * M;
+  VPP(0);
+  double out_val = 0.0;
+  if (wave < VIS_WAVES) {
+    for (int g = blockIdx.x; g < ngroups; g += G) {
+      const int patch0 = (g * VIS_WAVES + wave) * VIS_PPW;
+      if (patch0 < M) out_val += visual_wave_body<false, true, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, reinterpret_cast<float *>(errs), SL.u.r.lds[wave], patch0, lane, tag);
+      if (g + G < ngroups) wave_sync();
+    }
+    if (lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
+  }
+  VPP(1);
+  __syncthreads();
+  if (tid < VIS_PSTRIDE) {
+    double v = SL.u.r.red[0][tid];
+#pragma unroll
+    for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[w][tid];
+    const vp_word bits = (vp_word)__double_as_longlong(v), hi = (vp_word)tag << 32;
+    vp_word *dst = rows + ((size_t)blockIdx.x * VIS_PSTRIDE + tid) * 2;
+    vp_st(dst, hi | (bits & 0xffffffffull)); vp_st(dst + 1, hi | (bits >> 32));
+  }
+  if (tid == LIVO2_WAVE) vis_log_lds(SL.s);                    // rotation part of vec = prior [-] iterate, while the words travel
+  VPP(2);
+}
+
+// ---- 2. collect: all G rows and the M errors; words of blocks that are not there yet are simply loaded again
+__device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
+  VisPersistLds &SL = *(VisPersistLds *)slp;
+  const VisPersistArgs &p = vp_args();
+  const int step_global = __builtin_amdgcn_readfirstlane(step_v);
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));
+  const int tid_c = tid_o;
+  const int tid = tid_c;                                     // (VPP)
+  const int G = (int)gridDim.x, M = p.a.M;
+  const int buf = step_global & 1;
+  const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
+  const vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
+  const vp_word *errs = p.errs + (size_t)buf * M;
+  const int kidx = tid_c % VIS_PSTRIDE, slice = tid_c / VIS_PSTRIDE;
+  const int n_stage = min(VIS_ERR_STAGE, M);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  double acc = 0.0;
+  vp_word ev[VIS_ERR_STAGE / 512];
+  uint32_t eneed = 0, ehave = 0;
+#pragma unroll
+  for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (tid_c + 512 * u < n_stage) eneed |= 1u << u;
+  for (int base = 0; base < G; base += 12 * VP_RPT) {          // (same order of additions as k_visual_solve: rows slice, slice + 12, ... per thread)
+    vp_word lo[VP_RPT], hi[VP_RPT];
+    uint32_t need = 0, have = 0;
+#pragma unroll
+    for (int u = 0; u < VP_RPT; u++) if (tid_c < VIS_SOLVE_THREADS && base + slice + 12 * u < G) need |= 1u << u;
+    while (have != need || ehave != eneed) {
+      const uint32_t todo = need & ~have, etodo = eneed & ~ehave;
+#pragma unroll
+      for (int u = 0; u < VP_RPT; u++)
+        if (todo >> u & 1u) { const vp_word *src = rows + ((size_t)(base + slice + 12 * u) * VIS_PSTRIDE + kidx) * 2; lo[u] = vp_ld(src); hi[u] = vp_ld(src + 1); }
+#pragma unroll
+      for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (etodo >> u & 1u) ev[u] = vp_ld(errs + tid_c + 512 * u);
+#pragma unroll
+      for (int u = 0; u < VP_RPT; u++) if ((todo >> u & 1u) && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag) have |= 1u << u;
+#pragma unroll
+      for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if ((etodo >> u & 1u) && (uint32_t)(ev[u] >> 32) == tag) ehave |= 1u << u;
+      if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > VP_TIMEOUT) { SL.timed_out = 1; break; } }
+    }
+#pragma unroll
+    for (int u = 0; u < VP_RPT; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((lo[u] & 0xffffffffull) | (hi[u] << 32)));
+  }
+  __syncthreads();                                       // every wave is done with the tiles of phase 1 (they alias the staging below)
+  if (tid_c < VIS_SOLVE_THREADS) SL.u.s.scratch[slice * 41 + kidx] = acc;
+#pragma unroll
+  for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (eneed >> u & 1u) SL.u.s.errs[tid_c + 512 * u] = __uint_as_float((uint32_t)ev[u]);
+  __syncthreads();
+  VPP(3);
+}
+
+// ---- 3. reduction + frame error + solve + accept / revert, redundantly in every block (the body of k_visual_solve on LDS state)
+__device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v, int it_v, int step_v) {
+  VisPersistLds &SL = *(VisPersistLds *)slp;
+  SolveLds &s = SL.s;
+  const VisPersistArgs &p = vp_args();
+  const int level = __builtin_amdgcn_readfirstlane(level_v), it = __builtin_amdgcn_readfirstlane(it_v), step_global = __builtin_amdgcn_readfirstlane(step_v);
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));
+  const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = p.a.M;
+  const int n_stage = min(VIS_ERR_STAGE, M);
+  const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
+  const vp_word *errs = p.errs + (size_t)(step_global & 1) * M;
+  if (tid < VIS_PSTRIDE) {
+    double rr = SL.u.s.scratch[tid];
+#pragma unroll
+    for (int sl = 1; sl < 12; sl++) rr += SL.u.s.scratch[sl * 41 + tid];
+    SL.u.s.sums[tid] = rr;
+  }
+  __syncthreads();
+  VPP(4);
+  if (wave == 0) {
+    if (lane < 49) {
+      const int rr = lane / 7, c = lane % 7, u = rr < c ? rr : c, v = rr < c ? c : rr;
+      s.hth[lane] = SL.u.s.sums[u * 7 - (u * (u - 1)) / 2 + (v - u)];
+    }
+    if (lane < 7) s.htz[lane] = SL.u.s.sums[28 + lane];
+    wave_sync();
+    VPP(8);
+    esikf_solve_wave<7, true>(s, -1, lane);               // speculative: LDS only (s.sol, s.G, s.newR)
+    if (lane == 0) {                                      // the convergence test of an accepted step (vio.cpp:1675), formed while the error chain still runs
+      const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
+      const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
+      SL.stop_if_accepted = ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) ? 1 : 0;
+    }
+    VPP(9);
+  } else if (wave == 2) {                                 // the frame error in the reference's float accumulation order (k_visual_solve, wave 2)
+    const int T = p.error_threads < 1 ? 1 : (p.error_threads > LIVO2_WAVE ? LIVO2_WAVE : p.error_threads);
+    const int q = M / T, r = M % T;
+    const int my_begin = lane < r ? lane * (q + 1) : lane * q + r, my_end = my_begin + (lane < r ? q + 1 : q);
+    float priv = 0.0f;
+    if (lane < T) {
+      priv = float_chain(SL.u.s.errs, my_begin, min(my_end, n_stage), priv);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int i = max(my_begin, n_stage); i < my_end; i++) {                 // sub-maps beyond the staging area: straight from the published words
+        vp_word w = vp_ld(errs + i);
+        while ((uint32_t)(w >> 32) != tag) { if (__builtin_amdgcn_s_memrealtime() - t0 > VP_TIMEOUT) { SL.timed_out = 1; break; } w = vp_ld(errs + i); }
+        priv += __uint_as_float((uint32_t)w);
+      }
+      SL.u.s.err_chunk[lane] = priv;
+    }
+    wave_sync();
+    if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += SL.u.s.err_chunk[c]; SL.err_total = e; }
+    VPP_W(7, 2);
+  }
+  __syncthreads();
+  VPP(5);
+  if (wave == 0) {                                        // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
+    const int n_meas = (int)SL.u.s.sums[36];
+    float error = SL.err_total;
+    error = error / n_meas;
+    const float last_error = (it == 0) ? FLT_MAX : SL.last_error;
+    const bool accepted = error <= last_error;
+    const int step = SL.n_steps;
+    livo2_visual_step *st = (blockIdx.x == 0 && step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) ? &ctl->visual.steps[step] : nullptr;
+    int stop = 0;
+    if (st) {
+      if (lane < 49) st->HtH[lane] = s.hth[lane];
+      if (lane < 7) st->Htz[lane] = s.htz[lane];
+      if (lane < DS) st->solution[lane] = accepted ? s.sol[lane] : 0.0;
+      if (lane == 0) { st->level = level; st->iteration = it; st->accepted = accepted ? 1 : 0; st->n_meas = n_meas; st->error = error; st->pad = 0; }
+    }
+    if (accepted) {
+      stop = SL.stop_if_accepted;
+      double nv = 0.0;
+      if (lane < 9) nv = s.newR[lane]; else if (lane < 25) nv = s.cur[lane] + s.sol[lane - 6];
+      if (lane < 25) { SL.old[lane] = s.cur[lane]; s.cur[lane] = nv; }                              // old_state = *state ; *state += solution
+      if (lane < DS) {
+#pragma unroll
+        for (int c = 0; c < KMAX; c++) SL.Gfull[lane * DS + c] = s.G[lane * KMAX + c];
+      }
+    } else {
+      if (it > 0 && lane < 25) s.cur[lane] = SL.old[lane];                                           // *state = old_state ; EKF_end
+      stop = 1;
+    }
+    if (lane == 0) { if (accepted) SL.last_error = error; SL.stop = stop; SL.n_steps = step + 1; }
+  }
+  __syncthreads();
+  VPP(6);
+}
+
+__global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersistArgs p, DevCtl *__restrict__ ctl) {
   __shared__ VisPersistLds SL;
   SolveLds &s = SL.s;
+  const VpLds slp = (VpLds)&SL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = (int)gridDim.x, M = p.a.M;
   const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
@@ -734,173 +907,27 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_update_persistent(VisPersi
   {
     double craw[6];
     if (wave == 0) esikf_prefetch_wave(ctl, s, p.img_point_cov, lane, craw);
-    for (int e = tid; e < DS * DS; e += VIS_BLOCK) SL.Gfull[e] = ctl->G[e];
+    for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.Gfull[e] = ctl->G[e];
     if (tid == 0) { SL.last_error = FLT_MAX; SL.stop = 0; SL.n_steps = 0; SL.timed_out = 0; }
   }
   __syncthreads();
   if (tid < 25) SL.old[tid] = s.cur[tid];
+  __syncthreads();
   int step_global = 0, last_buf = 0;
-  const VisualKernelArgs &a = p.a;
   for (int level = p.levels - 1; level >= 0 && !SL.timed_out; level--) {
     for (int it = 0; it < p.max_iterations; it++) {
-      const int buf = step_global & 1;
-      const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
-      vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
-      vp_word *errs = p.errs + (size_t)buf * M;
-      VPP(0);
-      // Per-thread index arithmetic (window offsets, row addresses, lane predicates, ...) is loop-invariant; hoisted out of the step loop it has to live in
-      // registers across every phase: the compiler filled all 256 VGPRs with it and spilled the rest (62 VGPRs + 130 SGPRs to scratch, reloaded in every phase).
-      // The thread index is therefore re-materialised opaquely once per step, and everything derived from it stays inside the step.
-      int tid_o = threadIdx.x;
-      asm volatile("" : "+v"(tid_o));
-      const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      const int lane_s = lane;
-      // ---- 1. residual of this block's patch groups; the row and the errors are published as tagged words
-      double out_val = 0.0;
-      for (int g = blockIdx.x; g < ngroups; g += G) {
-        const int patch0 = (g * VIS_WAVES + wave) * VIS_PPW;
-        if (patch0 < M) out_val += visual_wave_body<false, true, true>(a, level, s.cur, s.cur + 9, s.cur + 12, reinterpret_cast<float *>(errs), SL.u.r.lds[wave], patch0, lane_s, tag);
-        if (g + G < ngroups) wave_sync();
-      }
-      VPP(1);
-      if (lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
-      __syncthreads();
-      if (tid < VIS_PSTRIDE) {
-        double v = SL.u.r.red[0][tid];
-#pragma unroll
-        for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[w][tid];
-        const vp_word bits = (vp_word)__double_as_longlong(v), hi = (vp_word)tag << 32;
-        vp_word *dst = rows + ((size_t)blockIdx.x * VIS_PSTRIDE + tid) * 2;
-        vp_st(dst, hi | (bits & 0xffffffffull)); vp_st(dst + 1, hi | (bits >> 32));
-      }
-      if (tid == LIVO2_WAVE) vis_log_lds(s);                    // rotation part of vec = prior [-] iterate, while the words travel
-      last_buf = buf;
-      VPP(2);
-      // ---- 2. collect: all G rows and the M errors; words of blocks that are not there yet are simply loaded again
-      {
-        const int tid_c = tid;
-        const int kidx = tid_c % VIS_PSTRIDE, slice = tid_c / VIS_PSTRIDE;
-        const int n_stage = min(VIS_ERR_STAGE, M);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        double acc = 0.0;
-        vp_word ev[VIS_ERR_STAGE / 512];
-        uint32_t eneed = 0, ehave = 0;
-#pragma unroll
-        for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (tid_c + 512 * u < n_stage) eneed |= 1u << u;
-        for (int base = 0; base < G; base += 12 * 12) {          // (same order of additions as k_visual_solve: rows slice, slice + 12, ... per thread)
-          vp_word lo[12], hi[12];
-          uint32_t need = 0, have = 0;
-#pragma unroll
-          for (int u = 0; u < 12; u++) if (tid_c < VIS_SOLVE_THREADS && base + slice + 12 * u < G) need |= 1u << u;
-          while (have != need || ehave != eneed) {
-            const uint32_t todo = need & ~have, etodo = eneed & ~ehave;
-#pragma unroll
-            for (int u = 0; u < 12; u++)
-              if (todo >> u & 1u) { const vp_word *src = rows + ((size_t)(base + slice + 12 * u) * VIS_PSTRIDE + kidx) * 2; lo[u] = vp_ld(src); hi[u] = vp_ld(src + 1); }
-#pragma unroll
-            for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (etodo >> u & 1u) ev[u] = vp_ld(errs + tid_c + 512 * u);
-#pragma unroll
-            for (int u = 0; u < 12; u++) if ((todo >> u & 1u) && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag) have |= 1u << u;
-#pragma unroll
-            for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if ((etodo >> u & 1u) && (uint32_t)(ev[u] >> 32) == tag) ehave |= 1u << u;
-            if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { SL.timed_out = 1; break; } }
-          }
-#pragma unroll
-          for (int u = 0; u < 12; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((lo[u] & 0xffffffffull) | (hi[u] << 32)));
-        }
-        {
-          const uint32_t need = eneed;
-          __syncthreads();                                       // every wave is done with the tiles of phase 1 (they alias the staging below)
-          if (tid_c < VIS_SOLVE_THREADS) SL.u.s.scratch[slice * 41 + kidx] = acc;
-#pragma unroll
-          for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (need >> u & 1u) SL.u.s.errs[tid_c + 512 * u] = __uint_as_float((uint32_t)ev[u]);
-        }
-        __syncthreads();
-        VPP(3);
-        if (SL.timed_out) break;
-        // ---- 3. reduction + frame error + solve, redundantly in every block (the body of k_visual_solve on LDS state)
-        if (tid < VIS_PSTRIDE) {
-          double rr = SL.u.s.scratch[tid];
-#pragma unroll
-          for (int sl = 1; sl < 12; sl++) rr += SL.u.s.scratch[sl * 41 + tid];
-          SL.u.s.sums[tid] = rr;
-        }
-        __syncthreads();
-        VPP(4);
-        if (wave == 0) {
-          if (lane < 49) {
-            const int rr = lane / 7, c = lane % 7, u = rr < c ? rr : c, v = rr < c ? c : rr;
-            s.hth[lane] = SL.u.s.sums[u * 7 - (u * (u - 1)) / 2 + (v - u)];
-          }
-          if (lane < 7) s.htz[lane] = SL.u.s.sums[28 + lane];
-          wave_sync();
-          VPP(8);
-          esikf_solve_wave<7, true>(s, -1, lane);               // speculative: LDS only (s.sol, s.G, s.newR)
-          if (lane == 0) {                                      // the convergence test of an accepted step (vio.cpp:1675), formed while the error chain still runs
-            const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
-            const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
-            SL.stop_if_accepted = ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) ? 1 : 0;
-          }
-          VPP(9);
-        } else if (wave == 2) {                                 // the frame error in the reference's float accumulation order (k_visual_solve, wave 2)
-          const int T = p.error_threads < 1 ? 1 : (p.error_threads > LIVO2_WAVE ? LIVO2_WAVE : p.error_threads);
-          const int q = M / T, r = M % T;
-          const int my_begin = lane < r ? lane * (q + 1) : lane * q + r, my_end = my_begin + (lane < r ? q + 1 : q);
-          float priv = 0.0f;
-          if (lane < T) {
-            priv = float_chain(SL.u.s.errs, my_begin, min(my_end, n_stage), priv);
-            for (int i = max(my_begin, n_stage); i < my_end; i++) {                 // sub-maps beyond the staging area: straight from the published words
-              vp_word w = vp_ld(errs + i);
-              while ((uint32_t)(w >> 32) != tag) { if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { SL.timed_out = 1; break; } w = vp_ld(errs + i); }
-              priv += __uint_as_float((uint32_t)w);
-            }
-            SL.u.s.err_chunk[lane] = priv;
-          }
-          wave_sync();
-          if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += SL.u.s.err_chunk[c]; SL.err_total = e; }
-          VPP_W(7, 2);
-        }
-        __syncthreads();
-        VPP(5);
-        if (wave == 0) {                                        // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
-          const int n_meas = (int)SL.u.s.sums[36];
-          float error = SL.err_total;
-          error = error / n_meas;
-          const float last_error = (it == 0) ? FLT_MAX : SL.last_error;
-          const bool accepted = error <= last_error;
-          const int step = SL.n_steps;
-          livo2_visual_step *st = (blockIdx.x == 0 && step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) ? &ctl->visual.steps[step] : nullptr;
-          int stop = 0;
-          if (st) {
-            if (lane < 49) st->HtH[lane] = s.hth[lane];
-            if (lane < 7) st->Htz[lane] = s.htz[lane];
-            if (lane < DS) st->solution[lane] = accepted ? s.sol[lane] : 0.0;
-            if (lane == 0) { st->level = level; st->iteration = it; st->accepted = accepted ? 1 : 0; st->n_meas = n_meas; st->error = error; st->pad = 0; }
-          }
-          if (accepted) {
-            stop = SL.stop_if_accepted;
-            double nv = 0.0;
-            if (lane < 9) nv = s.newR[lane]; else if (lane < 25) nv = s.cur[lane] + s.sol[lane - 6];
-            if (lane < 25) { SL.old[lane] = s.cur[lane]; s.cur[lane] = nv; }                              // old_state = *state ; *state += solution
-            if (lane < DS) {
-#pragma unroll
-              for (int c = 0; c < KMAX; c++) SL.Gfull[lane * DS + c] = s.G[lane * KMAX + c];
-            }
-          } else {
-            if (it > 0 && lane < 25) s.cur[lane] = SL.old[lane];                                           // *state = old_state ; EKF_end
-            stop = 1;
-          }
-          if (lane == 0) { if (accepted) SL.last_error = error; SL.stop = stop; SL.n_steps = step + 1; }
-        }
-        __syncthreads();
-        VPP(6);
-      }
+      vp_phase_residual(slp, level, step_global);
+      last_buf = step_global & 1;
+      vp_phase_collect(slp, step_global);
+      if (SL.timed_out) break;
+      vp_phase_solve(slp, ctl, level, it, step_global);
       step_global++;
       if (SL.stop) break;
     }
     if (SL.timed_out) break;
   }
   __syncthreads();
+  const VisualKernelArgs &a = p.a;
   // ---- every block: errors[] of the LAST evaluated step for its own patches (visual_submap->errors, vio.cpp:1632)
   {
     const vp_word *errs = p.errs + (size_t)last_buf * M;
@@ -911,10 +938,10 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_update_persistent(VisPersi
   }
   if (blockIdx.x != 0) return;
   // ---- block 0: the result.  state->cov -= G * state->cov (vio.cpp:800), updateFrameState (vio.cpp:1690-1697)
-  for (int e = tid; e < DS * DS; e += VIS_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
+  for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
   __syncthreads();
   double *dst = reinterpret_cast<double *>(&ctl->visual.state);
-  for (int e = tid; e < DS * DS; e += VIS_BLOCK) {
+  for (int e = tid; e < DS * DS; e += VP_BLOCK) {
     const int r = e / DS, c = e % DS;
     double g = SL.Gfull[r * DS] * SL.u.s.cov[c];
     for (int k = 1; k < DS; k++) g = g + SL.Gfull[r * DS + k] * SL.u.s.cov[k * DS + c];

@@ -512,7 +512,7 @@ void VIOManager::gridSetup() {                                                  
 
 livo2_select_cfg VIOManager::selectCfg() const {
   livo2_select_cfg sc{};
-  sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = distortion_en ? 1 : 0; std::memcpy(sc.cam.d, cam_d, sizeof(cam_d)); sc.cam.width = width; sc.cam.height = height;
+  sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = cam_distortion_model(); std::memcpy(sc.cam.d, cam_d, sizeof(cam_d)); sc.cam.width = width; sc.cam.height = height;
   std::memcpy(sc.R_cur, R_f_w_new.data(), 72); std::memcpy(sc.t_cur, t_f_w_new.data(), 24);
   sc.border = border; sc.grid_size = grid_size; sc.grid_n_width = grid_n_width; sc.grid_n_height = grid_n_height; sc.patch_size_half = patch_size / 2;
   return sc;
@@ -587,7 +587,7 @@ void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<C
   for (size_t k = 0; k < imgs.size(); k++) std::memcpy(&pool[k * bytes], imgs[k], bytes);
   livo2_retrieve_candidates cd{n, 0, pos.data(), nrm.data(), idx.data(), px.data(), f.data(), R.data(), t.data(), lvl.data(), ie.data()};
   livo2_retrieve_cfg rc{};
-  rc.cam.fx = fx; rc.cam.fy = fy; rc.cam.cx = cx; rc.cam.cy = cy; rc.cam.distortion = distortion_en ? 1 : 0; std::memcpy(rc.cam.d, cam_d, sizeof(cam_d)); rc.cam.width = width; rc.cam.height = height;
+  rc.cam.fx = fx; rc.cam.fy = fy; rc.cam.cx = cx; rc.cam.cy = cy; rc.cam.distortion = cam_distortion_model(); std::memcpy(rc.cam.d, cam_d, sizeof(cam_d)); rc.cam.width = width; rc.cam.height = height;
   std::memcpy(rc.R_cur, R_f_w_new.data(), 72); std::memcpy(rc.t_cur, t_f_w_new.data(), 24);
   rc.inv_expo_cur = state->inv_expo_time; rc.patch_pyrimid_level = L; rc.normal_en = normal_en; rc.ncc_en = ncc_en; rc.ncc_thre = ncc_thre; rc.outlier_threshold = outlier_threshold;
   std::vector<int32_t> acc(n), sl(n); std::vector<float> err(n);
@@ -634,12 +634,13 @@ void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
     dev_.check(livo2_visual_set_reference(dev_.ctx(), stack.data(), (int32_t)imgs.size(), idx.data(), px.data(), f.data(), R.data(), rp.data()));
   }
   livo2_visual_cfg cfg{};
-  cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = distortion_en ? 1 : 0; std::memcpy(cfg.cam.d, cam_d, sizeof(cam_d)); cfg.cam.width = width; cfg.cam.height = height;
+  cfg.cam.fx = fx; cfg.cam.fy = fy; cfg.cam.cx = cx; cfg.cam.cy = cy; cfg.cam.distortion = cam_distortion_model(); std::memcpy(cfg.cam.d, cam_d, sizeof(cam_d)); cfg.cam.width = width; cfg.cam.height = height;
   std::memcpy(cfg.Rcl, Rcl.data(), 72); std::memcpy(cfg.Pcl, Pcl.data(), 24); std::memcpy(cfg.extR, extR.data(), 72); std::memcpy(cfg.extT, extT.data(), 24);
   cfg.img_point_cov = img_point_cov; cfg.patch_pyrimid_level = L; cfg.max_iterations = max_iterations;
   cfg.exposure_estimate_en = exposure_estimate_en; cfg.inverse_composition_en = inverse_composition_en; cfg.mp_proc_num = mp_proc_num;
   compute_jacobian_time = update_ekf_time = 0.0;                                            // vio.cpp:788
-  if (kernel_times_en) { dev_.check(livo2_ctx_kernel_timing(dev_.ctx(), 1)); livo2_ctx_kernel_timing_read(dev_.ctx(), 1, nullptr, nullptr, 1); livo2_ctx_kernel_timing_read(dev_.ctx(), 3, nullptr, nullptr, 1); }
+  // the residual / solve split only exists in the launch-per-step sequence: with the times requested that sequence runs instead of the one-launch update
+  if (kernel_times_en) { dev_.check(livo2_ctx_set_option(dev_.ctx(), "visual_persistent", 0)); dev_.check(livo2_ctx_kernel_timing(dev_.ctx(), 1)); livo2_ctx_kernel_timing_read(dev_.ctx(), 1, nullptr, nullptr, 1); livo2_ctx_kernel_timing_read(dev_.ctx(), 3, nullptr, nullptr, 1); }
   livo2_state s_in, s_prop;
   state->to_abi(s_in); state_propagat->to_abi(s_prop);
   static livo2_visual_result res;
@@ -650,6 +651,7 @@ void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
     dev_.check(livo2_ctx_kernel_timing_read(dev_.ctx(), 1, &ms, &nl, 1)); compute_jacobian_time = ms * 1e-3;
     dev_.check(livo2_ctx_kernel_timing_read(dev_.ctx(), 3, &ms, &nl, 1)); update_ekf_time = ms * 1e-3;
     dev_.check(livo2_ctx_kernel_timing(dev_.ctx(), 0));
+    dev_.check(livo2_ctx_set_option(dev_.ctx(), "visual_persistent", 1));
   }
   state->from_abi(res.state);
   std::memcpy(G.data(), res.G, sizeof(res.G));

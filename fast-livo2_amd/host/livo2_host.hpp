@@ -260,6 +260,9 @@ public:
   // cam_d0..cam_d4 of config/camera_pinhole.yaml (vk::PinholeCamera's radial-tangential model); distortion_en = vikit's `distortion_` (any coefficient non-zero)
   double cam_d[5] = {0, 0, 0, 0, 0};
   bool distortion_en = false;
+  // cam_model "EquidistantCamera" of config/camera_fisheye_HILTI22.yaml (vk::EquidistantCamera: k1..k4 in cam_d[0..3]); takes precedence over distortion_en
+  bool equidistant_en = false;
+  int cam_distortion_model() const { return equidistant_en ? 2 : (distortion_en ? 1 : 0); }
   int width = 0, height = 0;
   int patch_pyrimid_level = 4, patch_size = 8, max_iterations = 5, total_points = 0;
   double img_point_cov = 100;

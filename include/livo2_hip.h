@@ -76,7 +76,6 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *   "visual_persistent" (default 1): livo2_visual_update runs computeJacobianAndUpdateEKF (vio.cpp:784-802) as ONE resident grid with the level / iteration
  *                        loops on the device; 0: one residual + one solve launch per (level, iteration).  The persistent grid is used only when it fits on
  *                        the device next to the persistent grids of this process that are still in flight; otherwise the per-step sequence runs.
- *   "visual_fused"      (default 0): one fused launch per (level, iteration) (experimental).
  * Counters: "visual_persistent_launches", "visual_persistent_fallbacks". */
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value);
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value);

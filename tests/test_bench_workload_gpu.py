@@ -120,12 +120,15 @@ def test_concurrent_contexts_give_the_same_bits(livo2, ctx, c4):
     bad = []
 
     def work(c):
-        for rep in range(3):
-            for f in range(F):
-                r = c.lidar_update(lid[f], lid[f], cfg)[0]
-                v = c.visual_update(vis[f], vis[f], vcfg)[0]
-                if bytes(r.state) != bytes(ref[f][0].state) or bytes(v.state) != bytes(ref[f][1].state) or v.n_steps != ref[f][1].n_steps:
-                    bad.append((rep, f))
+        try:
+            for rep in range(3):
+                for f in range(F):
+                    r = c.lidar_update(lid[f], lid[f], cfg)[0]
+                    v = c.visual_update(vis[f], vis[f], vcfg)[0]
+                    if bytes(r.state) != bytes(ref[f][0].state) or bytes(v.state) != bytes(ref[f][1].state) or v.n_steps != ref[f][1].n_steps:
+                        bad.append((rep, f))
+        except BaseException as exc:                     # (an exception in a thread would otherwise only be a pytest warning)
+            bad.append(repr(exc))
     th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
     [t.start() for t in th]; [t.join() for t in th]
     for c in ctxs:

@@ -165,32 +165,6 @@ def test_batched_frames_equal_single_updates(ctx, livo2, orc):
         assert [(res[k].steps[j].level, res[k].steps[j].accepted, res[k].steps[j].error) for j in range(res[k].n_steps)] == [(t.level, t.accepted, t.error) for t in ref["trace"]]
 
 
-def test_fused_step_kernel_gives_the_same_bits(livo2, ctx):
-    """LIVO2_VISUAL_FUSED=1: residual grid + last-block solve in ONE launch per (level, iteration) (k_visual_step: write-through stores, ticket, cache-bypassing
-    loads between workgroups of the same launch) — same bits as the two-launch form, repeatedly (a stale read across workgroups would show up as a flaky diff)."""
-    import os
-    vs = synth.visual_scenario(seed=77, n_patches=3000)
-    cfg = H.visual_cfg_product(vs, mp_proc_num=4)
-    cur, prop = H.states(vs, livo2.State)
-    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-    ctx.set_option("visual_persistent", 0)
-    try:
-        ref, ref_err = ctx.visual_update(cur, prop, cfg)
-    finally:
-        ctx.set_option("visual_persistent", 1)
-    os.environ["LIVO2_VISUAL_FUSED"] = "1"
-    try:
-        c2 = livo2.Context(0)
-    finally:
-        del os.environ["LIVO2_VISUAL_FUSED"]
-    c2.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-    for _ in range(20):
-        res, err = c2.visual_update(cur, prop, cfg)
-        assert res.n_steps == ref.n_steps and bytes(res.state) == bytes(ref.state) and np.array_equal(err, ref_err)
-        assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
-    c2.close()
-
-
 @pytest.mark.parametrize("M,threads,kw", [(3000, 4, {}), (4000, 4, {}), (300, 1, {}), (33, 4, {}), (1, 1, {}), (9000, 4, {}), (2000, 3, dict(exposure=False)),
                                           (1000, 4, dict(distortion=synth.AVIA_RADTAN)), (500, 4, dict(max_iterations=1)), (700, 2, dict(rot_sigma_deg=0.25))])
 def test_persistent_update_gives_the_same_bits_as_the_per_step_launches(livo2, ctx, M, threads, kw):
@@ -257,10 +231,13 @@ def test_concurrent_persistent_contexts(livo2):
     ref, ref_err = ctxs[0].visual_update(cur, prop, cfg)
     bad = []
     def work(c):
-        for _ in range(25):
-            res, err = c.visual_update(cur, prop, cfg)
-            if bytes(res.state) != bytes(ref.state) or not np.array_equal(err, ref_err):
-                bad.append(1)
+        try:
+            for _ in range(25):
+                res, err = c.visual_update(cur, prop, cfg)
+                if bytes(res.state) != bytes(ref.state) or not np.array_equal(err, ref_err):
+                    bad.append(1)
+        except BaseException as exc:                     # (an exception in a thread would otherwise only be a pytest warning)
+            bad.append(repr(exc))
     th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
     [t.start() for t in th]; [t.join() for t in th]
     used = sum(c.counter("visual_persistent_launches") for c in ctxs)

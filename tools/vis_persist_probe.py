@@ -32,7 +32,10 @@ def main():
         cfg = cfg_of(vs)
         prior = livo2.State.from_pose(vs.R_prior, vs.t_prior, vs.P, inv_expo=getattr(vs, "tau_prior", 1.0))
         ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+        only = os.environ.get("LIVO2_PROBE_ONLY", "")            # "per-step": experiments with builds whose persistent kernel is not valid
         for name, opt in (("per-step", 0), ("persistent", 1), ("per-step", 0), ("persistent", 1)):
+            if only and name != only:
+                continue
             ctx.set_option("visual_persistent", opt)
             res, _ = ctx.visual_update(prior, prior, cfg)
             for _ in range(20):
@@ -46,6 +49,8 @@ def main():
             print(f"seed {seed} M {M} {name:10s} steps {res.n_steps:2d}  {dt * 1e6:8.1f} us per update  ({dt * 1e6 / max(res.n_steps, 1):6.2f} us per executed step)", flush=True)
     print("persistent launches", ctx.counter("visual_persistent_launches"), "fallbacks", ctx.counter("visual_persistent_fallbacks"))
     ctx.close()
+    if only:
+        return
     # phase stamps of one persistent update (100 MHz clock): 0 step start, 1 residual done, 2 row stored, 3 barrier passed, 4 rows + errors in LDS, 5 solve + chain done, 6 decision
     import ctypes as C
     import numpy as np
@@ -55,7 +60,7 @@ def main():
     c2.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
     for _ in range(3):
         res, _ = c2.visual_update(prior, prior, cfg)
-    buf = np.zeros((8, 32, 16), np.uint64)
+    buf = np.zeros((256, 32, 16), np.uint64)
     c2.lib.livo2_debug_vp_prof.argtypes = [C.c_void_p, C.c_void_p]
     assert c2.lib.livo2_debug_vp_prof(c2.h, buf.ctypes.data_as(C.c_void_p)) == 0
     t00 = int(buf[0, 0, 0])
@@ -65,6 +70,16 @@ def main():
             t = buf[b, st].astype(np.int64)
             d = [(int(t[k + 1]) - int(t[k])) / 100.0 for k in range(6)]
             print(f"  {b} {st:2d} : {(int(t[0]) - t00) / 100.0:7.2f}  " + "  ".join(f"{x:6.2f}" for x in d) + f"   from sums: chain_end {(int(t[7]) - int(t[4])) / 100.0:5.2f} hth {(int(t[8]) - int(t[4])) / 100.0:5.2f} solve_end {(int(t[9]) - int(t[4])) / 100.0:5.2f}")
+    # all blocks: when does a block finish its residual / see every word, relative to block 0's step start (which blocks make the others wait?)
+    G = int((buf[:, 0, 0] != 0).sum())
+    print(f"# {G} blocks; per step: residual-end offsets (us, vs block 0's step start) min / median / p90 / max ; all-words-arrived min / max ; slowest 6 blocks (by residual end)")
+    for st in range(min(res.n_steps, 6)):
+        s0 = int(buf[0, st, 0])
+        r_end = (buf[:G, st, 1].astype(np.int64) - s0) / 100.0
+        start = (buf[:G, st, 0].astype(np.int64) - s0) / 100.0
+        arr = (buf[:G, st, 3].astype(np.int64) - s0) / 100.0
+        slow = np.argsort(r_end)[-6:][::-1]
+        print(f"  step {st}: start {start.min():6.2f}..{start.max():6.2f}  residual end {r_end.min():6.2f} / {np.median(r_end):6.2f} / {np.percentile(r_end, 90):6.2f} / {r_end.max():6.2f} ; arrived {arr.min():6.2f} .. {arr.max():6.2f} ; slowest " + " ".join(f"{b}:{r_end[b]:.2f}" for b in slow))
     c2.close()
 
 
