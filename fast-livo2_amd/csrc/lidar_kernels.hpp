@@ -840,7 +840,9 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
   const bool stop_now = (rematch >= 2 || (iter == max_iter - 1));
   wave_sync();
   if (stop_now && mode == 1) {
-    // cov = (I - G) * cov ; s.P holds cov (meas_cov_scale = 1) and G is zero beyond column 5
+    // cov = (I - G) * cov ; s.P holds cov (meas_cov_scale = 1) and G is zero beyond column 5.  The posterior goes to the result block here, in the launch that
+    // ends the loop (round 3: a separate k_lidar_finish launch cost ~5 us per frame); exactly one iteration of an update takes this branch (iter == max_iter - 1 at the latest).
+    double *post = reinterpret_cast<double *>(&ctl->lidar.state);
     for (int e = lane; e < DS * DS; e += LIVO2_WAVE) {
       const int r = e / DS, c = e % DS;
       double v = 0.0;
@@ -848,8 +850,9 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
         const double coef = ((r == k) ? 1.0 : 0.0) - ((k < 6) ? s.G[r * KMAX + k] : 0.0);
         v = v + coef * s.P[k * DS + c];
       }
-      ctl->cur.cov[e] = v;
+      ctl->cur.cov[e] = v; post[25 + e] = v;
     }
+    if (lane < 9) post[lane] = s.newR[lane]; else if (lane < 25) post[lane] = s.cur[lane] + s.sol[lane - 6];      // the values esikf_commit_wave stored in ctl->cur
     if (lane < 3) ctl->lidar.position_last[lane] = s.cur[9 + lane] + s.sol[3 + lane];
   }
   if (lane == 0) {
@@ -880,7 +883,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve_batch(const Lidar
 #endif
 }
 
-// copies the posterior into the result block after the loop (always runs)
+// copies the iterate into the result block after a loop that never takes the stopping branch (mode 0 / 2: fixed iteration counts)
 __global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_finish(DevCtl *__restrict__ ctl_base) {
   DevCtl *ctl = ctl_base + blockIdx.x;             // one block per frame (a single update has one)
   const int lane = threadIdx.x;

@@ -1554,7 +1554,7 @@ static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int it
     { Timed t(ctx, 0); launch_lidar_residual(ctx, a, mode == 1 ? 1 : 0); t.done(); }
     { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30) SOLVE_PROF_ARG); t.done(); }
   }
-  hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);
+  if (mode != 1 || iters < 1) hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);       // mode 1: the stopping iteration has written the result block
   HIPCHK(hipGetLastError());
   return LIVO2_OK;
 }
@@ -1772,7 +1772,7 @@ static int batch_enqueue(livo2_ctx *ctx, int32_t n_frames, const livo2_state *st
     { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual_batch, dim3(ctx->b_blocks), dim3(LIDAR_BLOCK_BATCH), LIDAR_LDS_BYTES_OF(LIDAR_BLOCK_BATCH) + LIDAR_LDS_DUMP, ctx->stream, ctx->bd_entries, ctx->bd_block_frame, mode == 1 ? 1 : 0); t.done(); }
     { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve_batch, dim3(n_frames), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->bd_entries, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); }
   }
-  hipLaunchKernelGGL(k_lidar_finish, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_ctl);
+  if (mode != 1 || iters < 1) hipLaunchKernelGGL(k_lidar_finish, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_ctl);
   hipLaunchKernelGGL(k_batch_gather_out, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_ctl, ctx->bd_results);
   HIPCHK(hipGetLastError());
   return LIVO2_OK;
