@@ -478,37 +478,36 @@ int persist_capacity(int device) {
 // Returns the grid size to launch (0: not admitted).  Admission RESERVES the blocks under the lock (slot marked pending until persist_register has recorded the
 // event behind the launch): two host threads admitting at the same time must not both see a free device — two half-resident grids would wait for each other's
 // words until the watchdog fires.
-int persist_admit(livo2_ctx *ctx, int want_blocks) {
+int persist_admit(livo2_ctx *ctx, int rows, int *halves) {
   const int cap = persist_capacity(ctx->device);
   if (cap <= 0) return 0;
   if (!ctx->vp_done && hipEventCreateWithFlags(&ctx->vp_done, hipEventDisableTiming) != hipSuccess) return 0;
   std::lock_guard<std::mutex> lk(g_persist_mu);
-  int busy = 0, own = -1;
+  int busy = 0, own = -1, others = 0;
   for (size_t i = 0; i < g_persist.size();) {
     if (g_persist[i].owner == ctx) { own = (int)i; i++; continue; }            // this context's own earlier grid runs BEFORE the new one (same stream)
-    if (!g_persist[i].pending && hipEventQuery(g_persist[i].ev) == hipSuccess) {
-      if (own == (int)g_persist.size() - 1) own = (int)i;
-      g_persist[i] = g_persist.back(); g_persist.pop_back(); continue;
-    }
+    if (g_persist[i].device == ctx->device) others++;
+    if (!g_persist[i].pending && g_persist[i].blocks > 0 && hipEventQuery(g_persist[i].ev) == hipSuccess) g_persist[i].blocks = 0;      // done: the slot stays (its owner is alive)
     if (g_persist[i].device == ctx->device) busy += g_persist[i].blocks;
     i++;
   }
-  const int grid = std::min(want_blocks, VP_MAX_BLOCKS);
+  // Block shape (the published rows, and so the results, are the same for both): alone on the device, one row per block (16 patches, the residual on one wave
+  // per SIMD, 250 blocks for a C4 frame); as soon as another context of this process uses resident grids too, two rows per block (all 8 waves evaluate, 125
+  // blocks) so that two updates fit on the device side by side instead of one of them falling back to the launch-per-step sequence.
+  *halves = others > 0 ? 2 : 1;
+  const int grid = (std::min(rows, VP_MAX_ROWS) + *halves - 1) / *halves;
   if (busy + grid > cap) return 0;
   if (own >= 0) { g_persist[own].blocks = std::max(g_persist[own].blocks, grid); g_persist[own].pending = true; }
   else g_persist.push_back(PersistSlot{ctx, ctx->vp_done, grid, ctx->device, true});
   return grid;
 }
-// after the launch (or instead of it, blocks = 0): the event now stands for the newest grid of this context
+// after the launch (or instead of it, blocks = 0): the event now stands for the newest grid of this context.  The slot of a context lives until the context is
+// destroyed (persist_forget): `others` above counts the contexts that use resident grids, not the grids in flight at one instant.
 void persist_register(livo2_ctx *ctx, int blocks) {
   const bool recorded = blocks > 0 && hipEventRecord(ctx->vp_done, ctx->stream) == hipSuccess;
   std::lock_guard<std::mutex> lk(g_persist_mu);
   for (size_t i = 0; i < g_persist.size(); i++)
-    if (g_persist[i].owner == ctx) {
-      if (recorded) { g_persist[i].blocks = blocks; g_persist[i].pending = false; }
-      else { g_persist[i] = g_persist.back(); g_persist.pop_back(); }
-      return;
-    }
+    if (g_persist[i].owner == ctx) { g_persist[i].blocks = recorded ? blocks : 0; g_persist[i].pending = false; return; }
 }
 void persist_forget(livo2_ctx *ctx) {
   std::lock_guard<std::mutex> lk(g_persist_mu);
@@ -2332,19 +2331,21 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
   if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
     {                        // (before the admission: nothing between the reservation and the launch may fail) exchange buffers start as all-zero words: tag 0 is never a step's tag
       const size_t c0 = ctx->vp_rows_cap, c1 = ctx->vp_errs_cap;
-      rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_BLOCKS * VIS_PSTRIDE * 2); if (rc) return rc;
+      rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_ROWS * VIS_PSTRIDE * 2); if (rc) return rc;
       rc = ensure(ctx, ctx->d_vp_errs, ctx->vp_errs_cap, (size_t)2 * std::max(ctx->M_cap, 512)); if (rc) return rc;
       if (ctx->vp_rows_cap != c0) HIPCHK(hipMemsetAsync(ctx->d_vp_rows, 0, ctx->vp_rows_cap * 8, ctx->stream));
       if (ctx->vp_errs_cap != c1) HIPCHK(hipMemsetAsync(ctx->d_vp_errs, 0, ctx->vp_errs_cap * 8, ctx->stream));
       if (ctx->vp_prof && !ctx->d_vp_prof) HIPCHK(hipMalloc((void **)&ctx->d_vp_prof, VP_MAX_BLOCKS * 32 * 16 * 8));
       if (ctx->vp_prof) HIPCHK(hipMemsetAsync(ctx->d_vp_prof, 0, VP_MAX_BLOCKS * 32 * 16 * 8, ctx->stream));
     }
-    const int G = persist_admit(ctx, grid);
+    int halves = 1;
+    const int G = persist_admit(ctx, grid, &halves);
     if (G > 0) {
       VisPersistArgs p{};
       p.a = make_visual_args(ctx, cfg, 0);
       p.a.errors = ctx->d_errors;
       p.rows = ctx->d_vp_rows; p.errs = ctx->d_vp_errs;
+      p.n_rows = std::min(grid, VP_MAX_ROWS); p.halves = halves;
       p.levels = cfg->patch_pyrimid_level; p.max_iterations = cfg->max_iterations; p.error_threads = cfg->mp_proc_num; p.img_point_cov = cfg->img_point_cov;
       ctx->vp_seq = (ctx->vp_seq + 1) & 0xffffffu; if (ctx->vp_seq == 0) ctx->vp_seq = 1;       // tag 0 = never-written memory
       p.tag_base = ctx->vp_seq << 8;

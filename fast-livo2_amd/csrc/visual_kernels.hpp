@@ -653,6 +653,7 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict
 // Co-residency: the host launches at most as many blocks as the device holds at once (occupancy query, in-flight accounting across contexts, else it falls
 // back to the per-step launches); a word that does not arrive within ~2 s sets hdr.pad[0] and every block leaves (livo2_visual_update_fetch reports it).
 #define VP_MAX_BLOCKS 256
+#define VP_MAX_ROWS 256
 #ifndef VP_SLEEP0
 #define VP_SLEEP0 0
 #endif
@@ -666,6 +667,7 @@ struct VisPersistArgs {
   unsigned long long *rows;     // [2][G][VIS_PSTRIDE][2]: every double as two words {tag << 32 | low half}, {tag << 32 | high half}
   unsigned long long *errs;     // [2][M]: {tag << 32 | float bits}
   int32_t levels, max_iterations, error_threads;
+  int32_t n_rows, halves;       // rows published per step (= min(patch groups, 256)); rows per block: 1 (grid = n_rows, residual on 4 waves) or 2 (grid = n_rows / 2, all 8 waves)
   uint32_t tag_base;            // launch sequence number << 8
   double img_point_cov;
   unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 256][step < 32][16] stamps of the 100 MHz clock, else null
@@ -674,7 +676,7 @@ struct VisPersistArgs {
 #define VPP_W(k, w) do { if (p.prof && tid == (w) * LIVO2_WAVE && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 struct __attribute__((aligned(16))) VisPersistLds {
   union {
-    struct { VisWaveLds lds[VIS_WAVES]; double red[VIS_WAVES][VIS_PSTRIDE]; } r;
+    struct { VisWaveLds lds[2 * VIS_WAVES]; double red[2 * VIS_WAVES][VIS_PSTRIDE]; } r;
     struct { float errs[VIS_ERR_STAGE]; double scratch[12 * 41]; double sums[64]; float err_chunk[LIVO2_WAVE]; double cov[DS * DS]; } s;
   } u;
   SolveLds s;                   // s.P = cov / img_point_cov (constant over the update: `state += solution` leaves cov alone), s.cur / s.prop = the iterate / the prior
@@ -724,31 +726,37 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   int tid_o = threadIdx.x;
   asm volatile("" : "+v"(tid_o));
   const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int G = (int)gridDim.x, M = p.a.M;
+  const int M = p.a.M, R = p.n_rows, halves = p.halves;
   const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
   const int buf = step_global & 1;
   const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
-  vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
+  vp_word *rows = p.rows + (size_t)buf * R * VIS_PSTRIDE * 2;
   vp_word *errs = p.errs + (size_t)buf * M;
   VPP(0);
   double out_val = 0.0;
-  if (wave < VIS_WAVES) {
-    for (int g = blockIdx.x; g < ngroups; g += G) {
-      const int patch0 = (g * VIS_WAVES + wave) * VIS_PPW;
+  // row r = blockIdx.x * halves + (wave / VIS_WAVES) sums the patch groups r, r + R, ... (a group = VIS_PPB = 16 patches = the row unit of k_visual_residual):
+  // the rows — and with them every sum — do not depend on the block shape the host chose
+  const int my_row = (int)blockIdx.x * halves + wave / VIS_WAVES, wv = wave % VIS_WAVES;
+  if (wave < VIS_WAVES * halves && my_row < R) {
+    for (int g = my_row; g < ngroups; g += R) {
+      const int patch0 = (g * VIS_WAVES + wv) * VIS_PPW;
       if (patch0 < M) out_val += visual_wave_body<false, true, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, reinterpret_cast<float *>(errs), SL.u.r.lds[wave], patch0, lane, tag);
-      if (g + G < ngroups) wave_sync();
+      if (g + R < ngroups) wave_sync();
     }
     if (lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
   }
   VPP(1);
   __syncthreads();
-  if (tid < VIS_PSTRIDE) {
-    double v = SL.u.r.red[0][tid];
+  if (tid < VIS_PSTRIDE * halves) {
+    const int h = tid / VIS_PSTRIDE, k = tid % VIS_PSTRIDE, r = (int)blockIdx.x * halves + h;
+    if (r < R) {
+      double v = SL.u.r.red[h * VIS_WAVES][k];
 #pragma unroll
-    for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[w][tid];
-    const vp_word bits = (vp_word)__double_as_longlong(v), hi = (vp_word)tag << 32;
-    vp_word *dst = rows + ((size_t)blockIdx.x * VIS_PSTRIDE + tid) * 2;
-    vp_st(dst, hi | (bits & 0xffffffffull)); vp_st(dst + 1, hi | (bits >> 32));
+      for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[h * VIS_WAVES + w][k];
+      const vp_word bits = (vp_word)__double_as_longlong(v), hi = (vp_word)tag << 32;
+      vp_word *dst = rows + ((size_t)r * VIS_PSTRIDE + k) * 2;
+      vp_st(dst, hi | (bits & 0xffffffffull)); vp_st(dst + 1, hi | (bits >> 32));
+    }
   }
   if (tid == LIVO2_WAVE) vis_log_lds(SL.s);                    // rotation part of vec = prior [-] iterate, while the words travel
   VPP(2);
@@ -763,7 +771,7 @@ __device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
   asm volatile("" : "+v"(tid_o));
   const int tid_c = tid_o;
   const int tid = tid_c;                                     // (VPP)
-  const int G = (int)gridDim.x, M = p.a.M;
+  const int G = p.n_rows, M = p.a.M;                      // G rows (not blocks) from here on
   const int buf = step_global & 1;
   const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
   const vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
