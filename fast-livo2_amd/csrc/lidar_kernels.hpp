@@ -4,12 +4,12 @@
 //                       (world transform -> voxel key -> cuckoo root lookup -> plane / candidate-list visit with radius gate,
 //                        3-sigma gate and max-probability choice -> neighbour-voxel retry -> H / R^-1 / z row ->
 //                        per-block partial sums of H^T R^-1 H and H^T R^-1 z)
-//   k_lidar_solve     : partial-sum reduction + k x k solve + state update + convergence / rematch / covariance update
+//   k_lidar_solve     : partial-sum reduction + k x k solve + state update + convergence / rematch / covariance update + (stopping iteration) result block
 //                                                           reference src/voxel_map.cpp:464-499
 // Layout: points SoA float x[],y[],z[] (coalesced 4-B/lane loads); body covariance SoA 6 x double[n];
-// root slots 64 B (two fetched per lookup), plane records 256 B fetched whole per lane.
+// root slots 64 B (two fetched per lookup), plane HOT records 128 B + a 16-B side word per lane (the 256-B master records are read by the map kernels only).
 //
-// The pass is LATENCY bound (every wave of a 100k-point scan is resident at once; rocprof shows waves parked in s_waitcnt),
+// The pass is LATENCY bound (17 000 points on an otherwise empty chip take 14 us, 200 000 take 24 us; rocprof shows waves parked in s_waitcnt),
 // so it is organised as the shortest possible chain of dependent round trips:
 //   T1 xyz + body covariance  ->  T2 both cuckoo slots  ->  T3 plane record  ||  both neighbour slots (speculative)
 //   ->  T4 neighbour plane (only lanes whose first visit failed)  ->  reduction.

@@ -3,7 +3,8 @@
 //   k_visual_solve    : reduction + accept/revert + 19x19 solve reference src/vio.cpp:1636-1685
 //   k_visual_finish   : cov -= G*cov, T_f_w                    reference src/vio.cpp:800-801, 1690-1697
 //
-//   k_visual_update_persistent : the WHOLE computeJacobianAndUpdateEKF as one launch (level / iteration loops on the device, one grid barrier per step)
+//   k_visual_update_persistent : the WHOLE computeJacobianAndUpdateEKF as one launch (level / iteration loops on the device; per step one all-to-all exchange
+//                                of tagged words between the resident blocks, no grid barrier)  reference src/vio.cpp:784-802 around 1520-1697
 //
 // Mapping: a wavefront owns FOUR patches (16 lanes each, 4 pixels per lane; pixel p = 8*x + y, x = patch row, y = patch column — the
 // reference's loop order).  The (8+3)^2 strided u8 window is staged once in LDS as float, the 10x10 grid of bilinear samples B is
