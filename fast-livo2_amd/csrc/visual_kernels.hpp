@@ -750,7 +750,7 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   __syncthreads();
   if (tid < VIS_PSTRIDE * halves) {
     const int h = tid / VIS_PSTRIDE, k = tid % VIS_PSTRIDE, r = (int)blockIdx.x * halves + h;
-    if (r < R) {
+    if (r < R && k < VIS_NSUM) {
       double v = SL.u.r.red[h * VIS_WAVES][k];
 #pragma unroll
       for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[h * VIS_WAVES + w][k];
@@ -789,7 +789,7 @@ __device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
     vp_word lo[VP_RPT], hi[VP_RPT];
     uint32_t need = 0, have = 0;
 #pragma unroll
-    for (int u = 0; u < VP_RPT; u++) if (tid_c < VIS_SOLVE_THREADS && base + slice + 12 * u < G) need |= 1u << u;
+    for (int u = 0; u < VP_RPT; u++) if (tid_c < VIS_SOLVE_THREADS && kidx < VIS_NSUM && base + slice + 12 * u < G) need |= 1u << u;      // (entries >= VIS_NSUM of a row are padding: never published, never read)
     while (have != need || ehave != eneed) {
       const uint32_t todo = need & ~have, etodo = eneed & ~ehave;
 #pragma unroll
