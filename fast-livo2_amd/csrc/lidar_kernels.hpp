@@ -729,12 +729,18 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
 // (same XCD slab: gridDim is a multiple of 8) — at C4 the scan has 782 chunks against the 512 blocks the chip holds at once, and a second-round block pays the
 // dispatcher, the LDS allocation and the scalar state loads again (measured life: 10.7 us against 7.8 us for a first-round block).  Row `chunk` of `partials`
 // receives the sums whichever block produced them: the reduction order does not depend on the grid.
+// `order` (nullable): launch slot -> chunk.  Blocks are dispatched in blockIdx order, so order[] decides which chunks start in the first round of blocks; the chunk
+// index (not the slot) selects the points and the partial row, so results do not depend on it.  `cost` (nullable): cost[chunk] = lifetime of the block that
+// worked on the chunk, in 10-ns ticks.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
-                                                                int check_stop, int chunks) {
-  for (int pb = (int)blockIdx.x; pb < chunks; pb += (int)gridDim.x) {
+                                                                int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost) {
+  for (int slot = (int)blockIdx.x; slot < chunks; slot += (int)gridDim.x) {
+    const int pb = order ? order[slot] : slot;
+    const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
     lidar_residual_body<BLOCK>(a, ctl, partials, check_stop, pb, chunks);
-    if (pb + (int)gridDim.x < chunks) __syncthreads();           // the next chunk's cooperative-visit tiles alias the reduction tiles just read
+    if (cost && threadIdx.x == 0) cost[pb] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
+    if (slot + (int)gridDim.x < chunks) __syncthreads();           // the next chunk's cooperative-visit tiles alias the reduction tiles just read
   }
 }
 
@@ -795,22 +801,59 @@ __device__ inline void reduce_partials_block(const double *__restrict__ partials
 #define SPHASE(k) do { } while (0)
 #define SOLVE_PROF_PARAM
 #endif
+// ---- block order of the NEXT k_lidar_residual launch: longest lifetime first ------------------------------------------------------------------------------
+// A C4 scan is 784 blocks against the 512 the chip holds at once: the blocks of the second round start at 7-10 us, and when one of them is a cluttered chunk (12-13 us
+// instead of 7) the launch ends with it.  Lifetimes are stable from iteration to iteration, so the residual kernel records them per chunk and one otherwise idle
+// wave of the solve turns them into a launch order (blocks are dispatched in blockIdx order): counting sort over 64 buckets of 160 ns, descending.  Only the ORDER in
+// which chunks start changes; the chunk index selects points and partial row, so every result is unchanged.  Measured at C4: 25.1 -> 21.7 us per launch (events).
+struct LptArgs { const uint32_t *cost; int32_t *order; int32_t chunks, pad; };
+#define LPT_MAX_CHUNKS 1024                                      // 16 lifetimes per lane of the ordering wave, all in registers (262 144 points per scan; larger scans keep the identity order)
+__device__ __forceinline__ void lidar_block_order_load(const LptArgs &lpt, int lane, uint32_t (&cc)[LPT_MAX_CHUNKS / LIVO2_WAVE]) {
+#pragma unroll
+  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) { const int c = lane + LIVO2_WAVE * u; cc[u] = (c < lpt.chunks) ? lpt.cost[c] : 0u; }      // one batch of loads, issued with the kernel's other reads
+}
+__device__ inline void lidar_block_order_wave(const LptArgs &lpt, uint32_t *hist /*[64]*/, uint32_t *fill /*[64]*/, int lane, const uint32_t (&cc)[LPT_MAX_CHUNKS / LIVO2_WAVE]) {
+  hist[lane] = 0u;
+  wave_sync();
+#pragma unroll
+  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) if (lane + LIVO2_WAVE * u < lpt.chunks) atomicAdd(&hist[min(63u, cc[u] >> 4)], 1u);
+  wave_sync();
+  const uint32_t v = hist[63 - lane];                            // lane l <-> bucket 63 - l: the exclusive prefix over the lanes is the start of the bucket in descending order
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < LIVO2_WAVE; d <<= 1) { const uint32_t up = __shfl_up(incl, d, LIVO2_WAVE); if (lane >= d) incl += up; }
+  fill[63 - lane] = incl - v;
+  wave_sync();
+#pragma unroll
+  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) {
+    const int c = lane + LIVO2_WAVE * u;
+    if (c < lpt.chunks) lpt.order[atomicAdd(&fill[min(63u, cc[u] >> 4)], 1u)] = c;      // a permutation of 0 .. chunks-1 by construction
+  }
+}
+
 __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
-                                                 int max_iter SOLVE_PROF_PARAM) {
+                                                 int max_iter, const LptArgs &lpt SOLVE_PROF_PARAM) {
   SPHASE(0);
   __shared__ SolveLds s;
   __shared__ double scratch[16 * 33];
   __shared__ double sums[32];
+  __shared__ uint32_t lpt_hist[64], lpt_fill[64];
   // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
   const int hdr_stop = ctl->hdr.stop, hdr_rematch = ctl->hdr.rematch_num;
   double craw[6];
   if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, 1.0, threadIdx.x, craw);
   if (mode != 0 && threadIdx.x == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
+  const bool lpt_wave = lpt.order && (threadIdx.x >> 6) == SOLVE_THREADS / LIVO2_WAVE - 1;       // last wave: the block order of the next residual launch
+  uint32_t lpt_cc[LPT_MAX_CHUNKS / LIVO2_WAVE];
+  if (lpt_wave) lidar_block_order_load(lpt, threadIdx.x & 63, lpt_cc);
   SPHASE(1);
   reduce_partials_block(partials, nblocks, scratch, sums);
   SPHASE(2);
   if (mode == 1 && hdr_stop) return;
-  if (threadIdx.x >= LIVO2_WAVE) return;            // the 19-dim algebra is one wave: wave-local synchronisation only from here on
+  if (threadIdx.x >= LIVO2_WAVE) {                   // the 19-dim algebra is one wave: wave-local synchronisation only from here on
+    if (lpt_wave) lidar_block_order_wave(lpt, lpt_hist, lpt_fill, threadIdx.x & 63, lpt_cc);
+    return;
+  }
   const int lane = threadIdx.x;
   // expand symmetric 21 -> 6x6
   if (lane < 36) {
@@ -865,11 +908,11 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
 }
 
 __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
-                                                              int max_iter SOLVE_PROF_PARAM) {
+                                                              int max_iter, LptArgs lpt SOLVE_PROF_PARAM) {
 #ifdef LIVO2_PHASE_PROF
-  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, sprof);
+  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, lpt, sprof);
 #else
-  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter);
+  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, lpt);
 #endif
 }
 
@@ -877,9 +920,9 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
 __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve_batch(const LidarBatchEntry *__restrict__ entries, int mode, int iter, int max_iter) {
   const LidarBatchEntry &e = entries[blockIdx.x];
 #ifdef LIVO2_PHASE_PROF
-  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, nullptr);
+  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, LptArgs{nullptr, nullptr, 0, 0}, nullptr);
 #else
-  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter);
+  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, LptArgs{nullptr, nullptr, 0, 0});
 #endif
 }
 

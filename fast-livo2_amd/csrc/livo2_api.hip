@@ -134,6 +134,8 @@ struct livo2_ctx {
   // the launch-per-step sequence instead.
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
   unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0; uint32_t vp_seq = 0;
+  // block order of k_lidar_residual (lidar_kernels.hpp, LptArgs): lifetimes per chunk written by every launch, order written by every solve; valid once a solve of this scan has run
+  int32_t *d_lpt_order = nullptr; uint32_t *d_lpt_cost = nullptr; size_t lpt_order_cap = 0, lpt_cost_cap = 0; int lpt_chunks = 0; bool lpt_valid = false, lidar_block_order = true;
   hipEvent_t vp_done = nullptr; int vp_blocks_inflight = 0;     // this ctx's last persistent launch (device-wide accounting below)
   unsigned long long *d_vp_prof = nullptr; bool vp_prof = [] { const char *e = std::getenv("LIVO2_VP_PROF"); return e ? std::atoi(e) != 0 : false; }();
   int vp_used = 0, vp_fallback = 0;                              // statistics: persistent launches / fallbacks to the per-step sequence
@@ -308,6 +310,14 @@ int lidar_block_for(int n) {
   return forced ? forced : 256;
 }
 void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop);
+// The launch order only matters when a scan needs more than one round of blocks (2 waves per SIMD: 8 waves = two 256-thread blocks per CU), and it costs every
+// block a dependent scalar load at its start and a store at its end (measured: +0.6 us on a single-round launch): on above that size only.
+bool lidar_lpt_on(livo2_ctx *ctx, int chunks) {
+  static int cus[64] = {};
+  if (!ctx->lidar_block_order || ctx->lpt_chunks != chunks || chunks > LPT_MAX_CHUNKS || ctx->device < 0 || ctx->device >= 64) return false;
+  if (cus[ctx->device] == 0) { hipDeviceProp_t prop; cus[ctx->device] = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256; }
+  return chunks * (ctx->lidar_block / LIVO2_WAVE) > cus[ctx->device] * 8;
+}
 
 void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop) {
   const int chunks = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
@@ -316,8 +326,11 @@ void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_s
   // it saves in block start-up; the hardware dispatcher's dynamic placement stays (profiles/r03_lidar_resident_grid_probe.txt).
   static const int resident = [] { const char *e = std::getenv("LIVO2_LIDAR_RESIDENT"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (v + 7) / 8 * 8 : 0; }();
   const int grid = resident > 0 ? std::min(chunks, resident * (ctx->lidar_block == 128 ? 2 : 1)) : chunks;
-  if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks);
-  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks);
+  const bool lpt = lidar_lpt_on(ctx, chunks) && resident == 0;
+  const int32_t *order = (lpt && ctx->lpt_valid) ? ctx->d_lpt_order : nullptr;
+  uint32_t *cost = lpt ? ctx->d_lpt_cost : nullptr;
+  if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
 }
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
@@ -619,7 +632,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out};
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost};
   for (void *p : dev) if (p) e = hipFree(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -647,6 +660,7 @@ int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; 
 
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (!ctx || !name) return LIVO2_ERR_INVALID;
+  if (std::strcmp(name, "lidar_block_order") == 0) { ctx->lidar_block_order = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown option");
 }
@@ -979,6 +993,11 @@ int scan_pipeline(livo2_ctx *ctx, int n, const livo2_lidar_cfg *cfg) {
   const int grid = lidar_grid(std::max(n, 1), ctx->lidar_block);
   int rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * 32, (size_t)64));
   if (rc) return rc;
+  // a new scan: the block lifetimes of the last one say nothing about it (identity order until this scan's first solve has run)
+  rc = ensure(ctx, ctx->d_lpt_order, ctx->lpt_order_cap, (size_t)std::max(grid, 64)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_lpt_cost, ctx->lpt_cost_cap, (size_t)std::max(grid, 64)); if (rc) return rc;
+  HIPCHK(hipMemsetAsync(ctx->d_lpt_cost, 0, (size_t)grid * 4, ctx->stream));
+  ctx->lpt_chunks = grid; ctx->lpt_valid = false;
   if (n > 0) {
     hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, n, (float)(1.0 / cfg->voxel_size), ctx->d_keys, ctx->d_idx);
     size_t need = 0;
@@ -1531,7 +1550,7 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
   { Timed t(ctx, 0); launch_lidar_residual(ctx, a, 0); t.done(); }
-  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations SOLVE_PROF_ARG); t.done(); }
+  { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations, LptArgs{nullptr, nullptr, 0, 0} SOLVE_PROF_ARG); t.done(); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1549,9 +1568,11 @@ static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int it
   if (ctx->want_l.normal_plane) HIPCHK(hipMemsetAsync(ctx->d_normal_plane, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
+  const LptArgs lpt = lidar_lpt_on(ctx, grid) ? LptArgs{ctx->d_lpt_cost, ctx->d_lpt_order, grid, 0} : LptArgs{nullptr, nullptr, 0, 0};
   for (int it = 0; it < iters; it++) {
     { Timed t(ctx, 0); launch_lidar_residual(ctx, a, mode == 1 ? 1 : 0); t.done(); }
-    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30) SOLVE_PROF_ARG); t.done(); }
+    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30), lpt SOLVE_PROF_ARG); t.done(); }
+    if (lpt.order) ctx->lpt_valid = true;                          // the launches enqueued from here on read the order this solve writes
   }
   if (mode != 1 || iters < 1) hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);       // mode 1: the stopping iteration has written the result block
   HIPCHK(hipGetLastError());

@@ -134,3 +134,23 @@ def test_concurrent_contexts_give_the_same_bits(livo2, ctx, c4):
     for c in ctxs:
         c.close()
     assert not bad, bad
+
+
+def test_block_order_of_the_residual_launch_does_not_change_a_bit(ctx, c4):
+    """option "lidar_block_order": k_lidar_residual starts the chunks that lived longest in the previous launch first (the order is written by the solve of the previous
+    iteration; 784 chunks at C4 = more than one round of blocks, so it is active here).  Chunk index, not launch slot, selects points and partial row: same bytes."""
+    sc, vs, cfg, vcfg, lid, vis = c4
+    ctx.upload_map(sc.fmap)
+    out = {}
+    for on in (1, 0, 1):
+        ctx.set_option("lidar_block_order", on)
+        ctx.set_scan(sc.xyz, cfg)
+        rs = []
+        for rep in range(2):                     # second pass: the order left by the previous update of the same scan is in use from the first iteration on
+            for f in range(3):
+                r, pts = ctx.lidar_update(lid[f], lid[f], cfg, want=("match_plane", "dis_to_plane"))
+                rs.append((bytes(r.state), r.n_iters, pts["match_plane"].tobytes(), pts["dis_to_plane"].tobytes(), bytes(r.iter_sums[0])))
+        out.setdefault(on, []).append(rs)
+    ctx.set_option("lidar_block_order", 1)
+    assert out[1][0] == out[0][0] == out[1][1]
+    assert out[1][0][:3] == out[1][0][3:]
