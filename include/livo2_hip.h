@@ -76,7 +76,10 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *   "visual_persistent" (default 1): livo2_visual_update runs computeJacobianAndUpdateEKF (vio.cpp:784-802) as ONE resident grid with the level / iteration
  *                        loops on the device; 0: one residual + one solve launch per (level, iteration).  The persistent grid is used only when it fits on
  *                        the device next to the persistent grids of this process that are still in flight; otherwise the per-step sequence runs.
- * Counters: "visual_persistent_launches", "visual_persistent_fallbacks". */
+ *   "lidar_block_order" (default 1): a LiDAR launch that needs more than one round of blocks starts the chunks of the scan in the order of their block lifetimes in
+ *                        the previous launch (longest first; recorded by every launch, sorted on the device by the solve of the previous iteration, reset by
+ *                        livo2_lidar_set_scan); 0: scan order.
+ * Counters: "visual_persistent_launches", "visual_persistent_fallbacks", "map_tree_grow_events". */
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value);
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value);
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
