@@ -135,7 +135,8 @@ struct livo2_ctx {
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
   unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0; uint32_t vp_seq = 0;
   // block order of k_lidar_residual (lidar_kernels.hpp, LptArgs): lifetimes per chunk written by every launch, order written by every solve; valid once a solve of this scan has run
-  int32_t *d_lpt_order = nullptr; uint32_t *d_lpt_cost = nullptr; size_t lpt_order_cap = 0, lpt_cost_cap = 0; int lpt_chunks = 0; bool lpt_valid = false, lidar_block_order = true;
+  int32_t *d_lpt_order = nullptr; uint32_t *d_lpt_cost = nullptr; size_t lpt_order_cap = 0, lpt_cost_cap = 0; int lpt_chunks = 0; bool lpt_valid = false;
+  bool lidar_block_order = [] { const char *e = std::getenv("LIVO2_LIDAR_BLOCK_ORDER"); return e ? std::atoi(e) != 0 : true; }();
   hipEvent_t vp_done = nullptr; int vp_blocks_inflight = 0;     // this ctx's last persistent launch (device-wide accounting below)
   unsigned long long *d_vp_prof = nullptr; bool vp_prof = [] { const char *e = std::getenv("LIVO2_VP_PROF"); return e ? std::atoi(e) != 0 : false; }();
   int vp_used = 0, vp_fallback = 0;                              // statistics: persistent launches / fallbacks to the per-step sequence
