@@ -804,7 +804,7 @@ __device__ inline void reduce_partials_block(const double *__restrict__ partials
 // ---- block order of the NEXT k_lidar_residual launch: longest lifetime first ------------------------------------------------------------------------------
 // A C4 scan is 784 blocks against the 512 the chip holds at once: the blocks of the second round start at 7-10 us, and when one of them is a cluttered chunk (12-13 us
 // instead of 7) the launch ends with it.  Lifetimes are stable from iteration to iteration, so the residual kernel records them per chunk and one otherwise idle
-// wave of the solve turns them into a launch order (blocks are dispatched in blockIdx order): counting sort over 64 buckets of 160 ns, descending.  Only the ORDER in
+// wave of the solve turns them into a launch order (blocks are dispatched in blockIdx order): counting sort over 64 buckets between the shortest and the longest, descending.  Only the ORDER in
 // which chunks start changes; the chunk index selects points and partial row, so every result is unchanged.  Measured at C4: 25.1 -> 21.7 us per launch (events).
 struct LptArgs { const uint32_t *cost; int32_t *order; int32_t chunks, pad; };
 #define LPT_MAX_CHUNKS 1024                                      // 16 lifetimes per lane of the ordering wave, all in registers (262 144 points per scan; larger scans keep the identity order)
@@ -814,9 +814,20 @@ __device__ __forceinline__ void lidar_block_order_load(const LptArgs &lpt, int l
 }
 __device__ inline void lidar_block_order_wave(const LptArgs &lpt, uint32_t *hist /*[64]*/, uint32_t *fill /*[64]*/, int lane, const uint32_t (&cc)[LPT_MAX_CHUNKS / LIVO2_WAVE]) {
   hist[lane] = 0u;
+  // the 64 buckets span [shortest, longest] lifetime of THIS launch (a fixed 160-ns grid clamps every block of a slow device into the last bucket: 1 000 LDS atomics
+  // on one address, +4 us, and no order at all)
+  uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) if (lane + LIVO2_WAVE * u < lpt.chunks) { lo = min(lo, cc[u]); hi = max(hi, cc[u]); }
+#pragma unroll
+  for (int d = 1; d < LIVO2_WAVE; d <<= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, LIVO2_WAVE)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, LIVO2_WAVE)); }
+  const uint32_t span = max(hi - lo, 1u);
+  uint32_t bk[LPT_MAX_CHUNKS / LIVO2_WAVE];
+#pragma unroll
+  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) bk[u] = (uint32_t)(((unsigned long long)(max(cc[u], lo) - lo) * 63ull) / span);
   wave_sync();
 #pragma unroll
-  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) if (lane + LIVO2_WAVE * u < lpt.chunks) atomicAdd(&hist[min(63u, cc[u] >> 4)], 1u);
+  for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) if (lane + LIVO2_WAVE * u < lpt.chunks) atomicAdd(&hist[bk[u]], 1u);
   wave_sync();
   const uint32_t v = hist[63 - lane];                            // lane l <-> bucket 63 - l: the exclusive prefix over the lanes is the start of the bucket in descending order
   uint32_t incl = v;
@@ -827,7 +838,7 @@ __device__ inline void lidar_block_order_wave(const LptArgs &lpt, uint32_t *hist
 #pragma unroll
   for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) {
     const int c = lane + LIVO2_WAVE * u;
-    if (c < lpt.chunks) lpt.order[atomicAdd(&fill[min(63u, cc[u] >> 4)], 1u)] = c;      // a permutation of 0 .. chunks-1 by construction
+    if (c < lpt.chunks) lpt.order[atomicAdd(&fill[bk[u]], 1u)] = c;      // a permutation of 0 .. chunks-1 by construction
   }
 }
 

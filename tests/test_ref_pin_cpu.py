@@ -1,12 +1,13 @@
 """The pin of the oracle: oracle/ (hand-written restatement) against oracle/_ref (the REFERENCE'S OWN translation units
-/root/reference/src/{voxel_map,vio,frame,visual_point}.cpp compiled textually unmodified — oracle/ref_build/Makefile — against stand-in
+/root/reference/src/{voxel_map,vio,frame,visual_point,IMU_Processing}.cpp compiled textually unmodified — oracle/ref_build/Makefile — against stand-in
 headers for Eigen / PCL / OpenCV / Sophus / rpg_vikit / ROS, none of which exist in this image).
 
 Both libraries export the same entry points, so one seeded scenario goes through both and the results are compared:
 LiDAR `StateEstimation` (voxel_map.cpp:338-511 with calcBodyCov, TransformLidar, BuildResidualListOMP, build_single_residual), the visual
 `computeJacobianAndUpdateEKF` (vio.cpp:784-802 with updateState 1520-1688, updateStateInverse / precomputeReferencePatches 1327-1518,
 computeProjectionJacobian, updateFrameState), the VoxelMap state machine (BuildVoxelMap / UpdateVoxelMap / UpdateOctoTree / init_plane /
-mapSliding, voxel_map.cpp:55-290, 532-641, 924-972) and the state algebra (common_lib.h:170-206, so3_math.h:44-66).
+mapSliding, voxel_map.cpp:55-290, 532-641, 924-972), the whole `retrieveFromVisualSparseMap` (vio.cpp:352-782) from a flat visual map, `ImuProcess::UndistortPcl`
+(IMU_Processing.cpp:237-541: message queue -> steps, forward propagation, backward undistortion) and the state algebra (common_lib.h:170-206, so3_math.h:44-66).
 Locals of the reference's functions (H rows, R_inv, z, per-step errors) are not observable in unmodified code: they are covered through
 truncated runs (max_iterations = 1, 2, ...), every one of which ends in the covariance update that consumes them.
 
