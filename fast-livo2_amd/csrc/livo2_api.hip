@@ -180,7 +180,7 @@ template <typename T> int ensure(livo2_ctx *ctx, T *&p, size_t &cap, size_t need
   if (need <= cap && p) return LIVO2_OK;
   if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; }
   size_t newcap = std::max(need, cap + cap / 2);
-  HIPCHK(hipMalloc((void **)&p, newcap * sizeof(T)));
+  HIPCHK(hipMalloc((void **)&p, newcap * sizeof(T) + 8192));          // (two spare pages behind every buffer)
   cap = newcap;
   return LIVO2_OK;
 }
