@@ -115,7 +115,7 @@ def _lockstep_leg(ctx, w, extra, copy_gbs):
         lres_us, vres_us = us_b[0] * (w.cfg.max_iterations * ksteps) / n_lid_b, us_b[1] * (4 * w.vcfg.max_iterations * ksteps) / n_vis_b
         ach_b = LIDAR_BYTES_PER_EVAL * w.N * w.F / (lres_us * 1e-6) / 1e9
         vach_b = VISUAL_BYTES_PER_PATCH * w.M * w.F / (vres_us * 1e-6) / 1e9
-        traffic_b, note_b = _load_traffic("r02_traffic_c4_lockstep.json", points=w.N * w.F)
+        traffic_b, note_b = _load_traffic("c4_lockstep", points=w.N * w.F)
         extra["c4_lockstep"] = {"frames_per_launch": w.F, "evals_per_s": evals_b * ksteps / dtb, "ms_per_step": 1e3 * dtb / ksteps, "frame_updates_per_s": w.F * ksteps / dtb,
                                 "evals_per_step": evals_b, "lidar_iterations_per_frame": it_b, "visual_steps_per_frame": st_b,
                                 "same_iteration_counts_as_headline": it_b == list(w.iters) and st_b == list(w.vsteps),
@@ -294,7 +294,7 @@ def _batched_leg(ctx, livo2, synth, args, extra, copy_gbs, sc2, cfg2, n2):
             ctx.batch_set_scans(scans, cfg2); ctx.batch_update_async(bst, bst, cfg2); rb = ctx.batch_update_fetch()
         tfb = time.perf_counter() - tb1
         bach = LIDAR_BYTES_PER_EVAL * npts / (bres_us * 1e-6) / 1e9
-        traffic_b, note_b = _load_traffic("r02_traffic_batched.json", points=npts)
+        traffic_b, note_b = _load_traffic("batched", points=npts)
         extra["batched"] = {"frames_per_launch": B, "points_per_launch": npts, "evals_per_s": npts * steps / tb, "ms_per_step": 1e3 * tb / steps,
                             "residual_kernel_us": bres_us, "solve_kernel_us": bsol_us,
                             "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS, "frac_of_copy_kernel": bach / copy_gbs,
@@ -398,7 +398,7 @@ def _out_of_cache_leg(ctx, livo2, synth, extra, copy_gbs, sc2, cfg2, n2):
     tb, (bres_us, bsol_us) = _timed_iters(ctx, lambda k: ctx.batch_iterations_async(bst, bst, cfg2, k), steps, (0, 2))
     bach = LIDAR_BYTES_PER_EVAL * npts / (bres_us * 1e-6) / 1e9
     unique = len(big.plane_d) * 256 + len(big.root_node) * 4 * 64 + npts * (12 + 48 + 4)
-    traffic, note = _load_traffic("r02_traffic_out_of_cache.json", points=npts)
+    traffic, note = _load_traffic("out_of_cache", points=npts)
     extra["out_of_cache"] = {"frames_per_launch": B, "points_per_launch": npts, "plane_records": int(len(big.plane_d)), "voxels": int(len(big.root_node)),
                              "unique_working_set_MB": unique / 1e6, "evals_per_s": npts * steps / tb, "ms_per_step": 1e3 * tb / steps, "residual_kernel_us": bres_us, "solve_kernel_us": bsol_us,
                              "n_eff_frame0": int(rb[0].iter_sums[rb[0].n_iters - 1].n_eff), "n_eff_frame63": int(rb[-1].iter_sums[rb[-1].n_iters - 1].n_eff),
@@ -409,16 +409,10 @@ def _out_of_cache_leg(ctx, livo2, synth, extra, copy_gbs, sc2, cfg2, n2):
                                      "~0.03 mm of resolution, the matched fraction stays that of C2"}
 
 
-def _load_traffic(name, **match):
-    import json
-    import os
-    try:
-        rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)))
-        if all(rec.get(k) == v for k, v in match.items()):
-            return (rec["fetch_size_kb_reported"] * rec["fetch_correction"] + rec["write_size_kb"]) * 1024.0, rec["source"]
-    except Exception:
-        pass
-    return None, "no PMC pass recorded for this workload; see profiles/"
+def _load_traffic(workload, **match):
+    """profiles/r*_traffic_<workload>.json of THIS build only (tools/traffic.py: the record's csrc_sha must be the tree's)"""
+    from tools import traffic
+    return traffic.load(workload, **match)
 
 
 def widened_rows(ctx, livo2, synth, H, sc, cfg):
