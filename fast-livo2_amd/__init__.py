@@ -82,6 +82,12 @@ class Context:
         self._chk(self.lib.livo2_ctx_get_counter(self.h, name.encode(), C.byref(v)))
         return v.value
 
+    def redzone_check(self):
+        """(mode, damaged guard words): LIVO2_REDZONE debug allocator; raises Livo2Error naming the allocation when a guard was overwritten"""
+        m, bad = C.c_int32(), C.c_int64()
+        self._chk(self.lib.livo2_debug_redzone_check(self.h, C.byref(m), C.byref(bad)))
+        return m.value, bad.value
+
     def kernel_timing(self, enable):
         self._chk(self.lib.livo2_ctx_kernel_timing(self.h, 1 if enable else 0))
 

@@ -1,0 +1,181 @@
+// Device allocations of liblivo2_hip.so: EVERY hipMalloc / hipFree of the library goes through dev_malloc / dev_free (DMALLOC / DFREE record the source line).
+// Default: exact-size hipMalloc, nothing else (no slack: round 3's "+ 8192" behind ensure() is gone).
+//
+// Debug modes, selected by the environment variable LIVO2_REDZONE before the first allocation of the process (tests/test_redzone_gpu.py):
+//   1  write redzones: RZ_GUARD poisoned bytes in front of and behind every allocation; livo2_debug_redzone_check (called by livo2_ctx_synchronize and every
+//      *_fetch in this mode) scans all guards with k_rz_scan and names the allocation (source line, size, side, offset) whose guard changed.
+//   2  electric fence behind: the allocation is its own HIP virtual-memory mapping whose END is the end of the mapped range — the next byte is reserved but
+//      unmapped address space, so an out-of-bounds READ or write past the end faults at once and deterministically ("Memory access fault by GPU" + the abort
+//      handler's table of allocations), not only when the neighbouring page happens to be unmapped on some box.  User pointers keep 16-byte alignment
+//      (the widest vector access of the kernels), so up to 15 bytes behind an odd-sized array stay mapped.
+//   3  electric fence in front: the allocation starts at the first byte of its mapping, below it reserved unmapped address space (index underflow).
+// Modes 2 / 3 serialise nothing by themselves; run them with AMD_SERIALIZE_KERNEL=3 to have the fault reported against the launch that caused it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <csignal>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace devalloc {
+
+constexpr size_t RZ_GUARD = 65536;
+constexpr uint32_t RZ_WORD = 0xCBCBCBCBu;
+
+struct Rec { void *base; size_t bytes; size_t mapped; int line; int mode; hipMemGenericAllocationHandle_t handle; size_t reserved; };
+
+inline int mode() {
+  static const int m = [] { const char *e = std::getenv("LIVO2_REDZONE"); return e ? std::atoi(e) : 0; }();
+  return m;
+}
+inline std::mutex &mtx() { static std::mutex m; return m; }
+inline std::unordered_map<void *, Rec> &table() { static std::unordered_map<void *, Rec> t; return t; }
+
+inline void dump_table(FILE *f) {
+  // (called from the abort handler too: no locking, plain stdio — a debugging aid, not a service)
+  fprintf(f, "livo2 device allocations (LIVO2_REDZONE=%d): user pointer .. end, bytes, source line of livo2_api.hip\n", mode());
+  for (auto &kv : table())
+    fprintf(f, "  %p .. %p  %zu B  line %d\n", kv.first, (void *)((char *)kv.first + kv.second.bytes), kv.second.bytes, kv.second.line);
+  fflush(f);
+}
+inline void on_abort(int) { dump_table(stderr); std::signal(SIGABRT, SIG_DFL); std::abort(); }
+
+__global__ void k_rz_fill(uint32_t *p, size_t words) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = RZ_WORD;
+}
+struct RzDesc { const uint32_t *guard; int id; int side; };
+struct RzOut { unsigned long long bad_words; int first_id; int first_side; long long first_byte; int lock; int pad; };
+__global__ void k_rz_scan(const RzDesc *d, RzOut *out) {
+  const RzDesc g = d[blockIdx.x];
+  unsigned long long bad = 0; long long first = -1;
+  for (size_t i = threadIdx.x; i < RZ_GUARD / 4; i += blockDim.x)
+    if (g.guard[i] != RZ_WORD) { bad++; if (first < 0) first = (long long)i * 4; }
+  if (bad) {
+    atomicAdd(&out->bad_words, bad);
+    if (atomicCAS(&out->lock, 0, 1) == 0) { out->first_id = g.id; out->first_side = g.side; out->first_byte = first; }
+  }
+}
+
+inline hipError_t fence_alloc(void **p, size_t bytes, int line, int m) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+  size_t gran = 0;
+  if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+  const size_t mapped = (bytes + gran - 1) / gran * gran, reserved = mapped + 2 * gran;
+  void *va = nullptr;
+  if ((e = hipMemAddressReserve(&va, reserved, gran, nullptr, 0)) != hipSuccess) return e;
+  hipMemGenericAllocationHandle_t h;
+  if ((e = hipMemCreate(&h, mapped, &prop, 0)) != hipSuccess) return e;
+  char *map_at = (char *)va + gran;                         // one unmapped granule on either side of the mapping
+  if ((e = hipMemMap(map_at, mapped, 0, h, 0)) != hipSuccess) return e;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  if ((e = hipMemSetAccess(map_at, mapped, &acc, 1)) != hipSuccess) return e;
+  char *user = (m == 2) ? map_at + ((mapped - bytes) & ~(size_t)15) : map_at;
+  *p = user;
+  std::lock_guard<std::mutex> lk(mtx());
+  table()[user] = Rec{va, bytes, mapped, line, m, h, reserved};
+  return hipSuccess;
+}
+
+inline hipError_t dev_malloc(void **p, size_t bytes, int line) {
+  const int m = mode();
+  if (bytes == 0) { *p = nullptr; return hipSuccess; }
+  if (m == 0) return hipMalloc(p, bytes);
+  static const bool hooked = [] { std::signal(SIGABRT, on_abort); return true; }();
+  (void)hooked;
+  if (m == 2 || m == 3) return fence_alloc(p, bytes, line, m);
+  // mode 1: [guard | user, rounded up to 256 B | guard]
+  const size_t body = (bytes + 255) & ~(size_t)255;
+  char *base = nullptr;
+  hipError_t e = hipMalloc((void **)&base, body + 2 * RZ_GUARD);
+  if (e != hipSuccess) return e;
+  k_rz_fill<<<64, 256>>>((uint32_t *)base, RZ_GUARD / 4);
+  k_rz_fill<<<64, 256>>>((uint32_t *)(base + RZ_GUARD + bytes / 4 * 4 + ((bytes & 3) ? 4 : 0)), (body - (bytes + 3) / 4 * 4 + RZ_GUARD) / 4);   // the rounding tail is guard too
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+  *p = base + RZ_GUARD;
+  std::lock_guard<std::mutex> lk(mtx());
+  table()[*p] = Rec{base, bytes, body + 2 * RZ_GUARD, line, 1, {}, 0};
+  return hipSuccess;
+}
+
+inline hipError_t dev_free(void *p) {
+  if (!p) return hipSuccess;
+  if (mode() == 0) return hipFree(p);
+  Rec r;
+  {
+    std::lock_guard<std::mutex> lk(mtx());
+    auto it = table().find(p);
+    if (it == table().end()) return hipFree(p);
+    r = it->second; table().erase(it);
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (r.mode == 1) return hipFree(r.base);
+  char *map_at = (char *)r.base + (r.reserved - r.mapped) / 2;
+  if ((e = hipMemUnmap(map_at, r.mapped)) != hipSuccess) return e;
+  if ((e = hipMemRelease(r.handle)) != hipSuccess) return e;
+  return hipMemAddressFree(r.base, r.reserved);
+}
+
+// Mode 1: scan every guard of the process.  Returns the number of damaged 4-byte words (0 = intact) and describes the first damaged allocation in `msg`.
+inline long long check(char *msg, size_t msg_len) {
+  if (msg && msg_len) msg[0] = 0;
+  if (mode() != 1) return 0;
+  std::vector<RzDesc> desc; std::vector<Rec> recs; std::vector<void *> users;
+  {
+    std::lock_guard<std::mutex> lk(mtx());
+    for (auto &kv : table()) {
+      const Rec &r = kv.second;
+      const int id = (int)recs.size();
+      recs.push_back(r); users.push_back(kv.first);
+      desc.push_back(RzDesc{(const uint32_t *)r.base, id, 0});
+      desc.push_back(RzDesc{(const uint32_t *)((char *)r.base + r.mapped - RZ_GUARD), id, 1});
+      // (the rounding tail between the last user byte and the rear guard is poisoned as well; it is checked through a third descriptor when it is a whole guard
+      //  long only — the rear guard proper catches every overrun of more than 255 bytes, the tail word check below the shorter ones)
+    }
+  }
+  if (desc.empty()) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  RzDesc *d_desc = nullptr; RzOut *d_out = nullptr;
+  if (hipMalloc((void **)&d_desc, desc.size() * sizeof(RzDesc)) != hipSuccess || hipMalloc((void **)&d_out, sizeof(RzOut)) != hipSuccess) return -1;
+  RzOut out = {}; out.first_id = -1;
+  hipError_t e = hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(RzDesc), hipMemcpyHostToDevice);
+  e = hipMemcpy(d_out, &out, sizeof(out), hipMemcpyHostToDevice);
+  k_rz_scan<<<(int)desc.size(), 256>>>(d_desc, d_out);
+  e = hipMemcpy(&out, d_out, sizeof(out), hipMemcpyDeviceToHost);
+  // short overruns: the (< 256 B) rounding tail right behind the user bytes
+  long long tail_bad = 0; int tail_id = -1; long long tail_off = 0;
+  for (size_t i = 0; i < recs.size() && tail_id < 0; i++) {
+    const Rec &r = recs[i];
+    const size_t start = (r.bytes + 3) / 4 * 4, body = r.mapped - 2 * RZ_GUARD;
+    if (body == start) continue;
+    uint32_t w[64];
+    if (hipMemcpy(w, (char *)users[i] + start, body - start, hipMemcpyDeviceToHost) != hipSuccess) continue;
+    for (size_t k = 0; k < (body - start) / 4; k++) if (w[k] != RZ_WORD) { tail_bad++; if (tail_id < 0) { tail_id = (int)i; tail_off = (long long)(start + 4 * k - r.bytes); } }
+  }
+  e = hipFree(d_desc); e = hipFree(d_out); (void)e;
+  const long long bad = (long long)out.bad_words + tail_bad;
+  if (bad && msg && msg_len) {
+    if (tail_id >= 0)
+      snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B BEHIND its end", recs[tail_id].bytes, recs[tail_id].line, tail_off);
+    else if (out.first_id >= 0) {
+      const Rec &r = recs[out.first_id];
+      if (out.first_side == 0) snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B IN FRONT of its start (%llu damaged words in all)",
+                                        r.bytes, r.line, (long long)RZ_GUARD - out.first_byte, out.bad_words);
+      else snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B BEHIND its end (%llu damaged words in all)", r.bytes, r.line,
+                    (long long)(r.mapped - 2 * RZ_GUARD - r.bytes) + out.first_byte, out.bad_words);
+    }
+  }
+  return bad;
+}
+
+}  // namespace devalloc
+
+#define DMALLOC(pp, bytes) devalloc::dev_malloc((void **)(pp), (bytes), __LINE__)
+#define DFREE(p) devalloc::dev_free((void *)(p))

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include "dev_alloc.hpp"
 #include "lidar_kernels.hpp"
 #include "visual_inverse_kernels.hpp"
 #include "map_kernels.hpp"
@@ -176,22 +177,33 @@ namespace {
 
 int fail(livo2_ctx *ctx, int code, const char *msg) { if (ctx) ctx->err = msg; return code; }
 
+// LIVO2_REDZONE=1 (dev_alloc.hpp): every synchronising entry point ends by scanning the guards of all device allocations of the process
+int rz_gate(livo2_ctx *ctx) {
+  if (devalloc::mode() != 1) return LIVO2_OK;
+  char msg[320];
+  const long long bad = devalloc::check(msg, sizeof(msg));
+  if (bad == 0) return LIVO2_OK;
+  ctx->err = bad < 0 ? "redzone check could not run" : msg;
+  fprintf(stderr, "liblivo2_hip: %s\n", ctx->err.c_str());
+  return LIVO2_ERR_HIP;
+}
+
 template <typename T> int ensure(livo2_ctx *ctx, T *&p, size_t &cap, size_t need) {
   if (need <= cap && p) return LIVO2_OK;
-  if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; }
+  if (p) { hipError_t e = DFREE(p); (void)e; p = nullptr; }
   size_t newcap = std::max(need, cap + cap / 2);
-  HIPCHK(hipMalloc((void **)&p, newcap * sizeof(T) + 8192));          // (two spare pages behind every buffer)
+  HIPCHK(DMALLOC((void **)&p, newcap * sizeof(T)));
   cap = newcap;
   return LIVO2_OK;
 }
 
 template <typename T> int grow_array(livo2_ctx *ctx, T *&p, size_t old_n, size_t new_n, bool zero_tail) {
   T *q = nullptr;
-  HIPCHK(hipMalloc((void **)&q, new_n * sizeof(T)));
+  HIPCHK(DMALLOC((void **)&q, new_n * sizeof(T)));
   if (old_n) HIPCHK(hipMemcpyAsync(q, p, old_n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
   if (zero_tail && new_n > old_n) HIPCHK(hipMemsetAsync(q + old_n, 0, (new_n - old_n) * sizeof(T), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipFree(p));
+  HIPCHK(DFREE(p));
   p = q;
   return LIVO2_OK;
 }
@@ -215,7 +227,7 @@ void set_map_view(livo2_ctx *ctx) {
 }
 void free_map_arrays(livo2_ctx *ctx) {
   void *p[] = {ctx->d_slots, ctx->d_cand, ctx->d_planes, ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand_aux};
-  for (void *q : p) if (q) { hipError_t e = hipFree(q); (void)e; }
+  for (void *q : p) if (q) { hipError_t e = DFREE(q); (void)e; }
   ctx->d_slots = nullptr; ctx->d_cand = nullptr; ctx->d_planes = nullptr; ctx->d_planes_hot = nullptr; ctx->d_plane_aux = nullptr; ctx->d_cand_aux = nullptr;
 }
 
@@ -372,11 +384,11 @@ int ensure_lidar_outputs(livo2_ctx *ctx, const livo2_lidar_points *want) {
   ctx->want_l = *want;
   if (ctx->out_cap < ctx->n) {
     hipError_t e;
-    if (ctx->d_match) { e = hipFree(ctx->d_match); e = hipFree(ctx->d_normal_plane); e = hipFree(ctx->d_dis); e = hipFree(ctx->d_pw); e = hipFree(ctx->d_var); e = hipFree(ctx->d_rinv); e = hipFree(ctx->d_hrow); (void)e; }
+    if (ctx->d_match) { e = DFREE(ctx->d_match); e = DFREE(ctx->d_normal_plane); e = DFREE(ctx->d_dis); e = DFREE(ctx->d_pw); e = DFREE(ctx->d_var); e = DFREE(ctx->d_rinv); e = DFREE(ctx->d_hrow); (void)e; }
     size_t n = (size_t)ctx->n_cap;
-    HIPCHK(hipMalloc((void **)&ctx->d_match, n * 4)); HIPCHK(hipMalloc((void **)&ctx->d_normal_plane, n * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_dis, n * 4)); HIPCHK(hipMalloc((void **)&ctx->d_pw, n * 12));
-    HIPCHK(hipMalloc((void **)&ctx->d_var, n * 72)); HIPCHK(hipMalloc((void **)&ctx->d_rinv, n * 8)); HIPCHK(hipMalloc((void **)&ctx->d_hrow, n * 48));
+    HIPCHK(DMALLOC((void **)&ctx->d_match, n * 4)); HIPCHK(DMALLOC((void **)&ctx->d_normal_plane, n * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_dis, n * 4)); HIPCHK(DMALLOC((void **)&ctx->d_pw, n * 12));
+    HIPCHK(DMALLOC((void **)&ctx->d_var, n * 72)); HIPCHK(DMALLOC((void **)&ctx->d_rinv, n * 8)); HIPCHK(DMALLOC((void **)&ctx->d_hrow, n * 48));
     ctx->out_cap = ctx->n_cap;
   }
   return LIVO2_OK;
@@ -390,7 +402,7 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
 #ifdef LIVO2_PHASE_PROF
   {
     size_t waves = (size_t)lidar_grid(std::max(ctx->n, 1), 128) * 4;
-    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = hipFree(ctx->d_prof); (void)e; } hipError_t e = hipMalloc((void **)&ctx->d_prof, waves * 64 + 128 + waves * 16 + waves * 128); (void)e; ctx->prof_waves = waves; }
+    if (waves > ctx->prof_waves) { if (ctx->d_prof) { hipError_t e = DFREE(ctx->d_prof); (void)e; } hipError_t e = DMALLOC((void **)&ctx->d_prof, waves * 64 + 128 + waves * 16 + waves * 128); (void)e; ctx->prof_waves = waves; }
     hipError_t e = hipMemsetAsync(ctx->d_prof, 0, waves * 64, ctx->stream); (void)e;
     a.prof = ctx->d_prof;
   }
@@ -603,7 +615,7 @@ static int ctx_create_impl(int device, void *stream, bool external, livo2_ctx **
   ctx->device = device;
   if (external) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LIVO2_ERR_HIP; } ctx->own_stream = true; }
-  if (hipMalloc((void **)&ctx->d_ctl, sizeof(DevCtl)) != hipSuccess || hipHostMalloc((void **)&ctx->h_in, sizeof(HostIn) * IN_RING) != hipSuccess ||
+  if (DMALLOC((void **)&ctx->d_ctl, sizeof(DevCtl)) != hipSuccess || hipHostMalloc((void **)&ctx->h_in, sizeof(HostIn) * IN_RING) != hipSuccess ||
       hipHostMalloc(&ctx->h_out, sizeof(DevCtl)) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   if (hipEventCreate(&ctx->span0) != hipSuccess || hipEventCreate(&ctx->span1) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
   for (int k = 0; k < IN_RING; k++) if (hipEventCreateWithFlags(&ctx->in_ev[k], hipEventDisableTiming) != hipSuccess) { livo2_ctx_destroy(ctx); return LIVO2_ERR_HIP; }
@@ -634,7 +646,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
                  ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost};
-  for (void *p : dev) if (p) e = hipFree(p);
+  for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
   if (ctx->h_pts) e = hipHostFree(ctx->h_pts);
@@ -657,7 +669,33 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
 
 const char *livo2_last_error(const livo2_ctx *ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
 void *livo2_ctx_stream(livo2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
-int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; HIPCHK(hipStreamSynchronize(ctx->stream)); return LIVO2_OK; }
+int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; HIPCHK(hipStreamSynchronize(ctx->stream)); return rz_gate(ctx); }
+
+// checker self-test: one 4-byte store at `byte_offset` relative to the END of the ctx's control block (negative: relative to its start)
+__global__ void k_rz_poke(char *p) { *reinterpret_cast<volatile uint32_t *>(p) = 0x600DF00Du; }
+int livo2_debug_redzone_poke(livo2_ctx *ctx, int64_t byte_offset) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (devalloc::mode() == 0) return fail(ctx, LIVO2_ERR_INVALID, "LIVO2_REDZONE is not set: an out-of-bounds store would hit live memory");
+  HIPCHK(hipSetDevice(ctx->device));
+  char *base = reinterpret_cast<char *>(ctx->d_ctl);
+  k_rz_poke<<<1, 1, 0, ctx->stream>>>(byte_offset >= 0 ? base + sizeof(DevCtl) + byte_offset : base + byte_offset);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LIVO2_OK;
+}
+
+int livo2_debug_redzone_check(livo2_ctx *ctx, int32_t *mode, int64_t *damaged_words) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (mode) *mode = devalloc::mode();
+  if (damaged_words) *damaged_words = 0;
+  if (devalloc::mode() != 1) return LIVO2_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  char msg[320];
+  const long long bad = devalloc::check(msg, sizeof(msg));
+  if (damaged_words) *damaged_words = bad;
+  if (bad) { ctx->err = bad < 0 ? "redzone check could not run" : msg; return LIVO2_ERR_HIP; }
+  return LIVO2_OK;
+}
 
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (!ctx || !name) return LIVO2_ERR_INVALID;
@@ -798,12 +836,12 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   free_map_arrays(ctx);
   ctx->has_map = false;
   const size_t n_rows = (size_t)std::max(1, m->n_planes), n_cand = std::max<size_t>(1, cand.size());
-  HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand, n_cand * PLANE_HOT_DOUBLES * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand_aux, n_cand * sizeof(PlaneAux)));
-  HIPCHK(hipMalloc((void **)&ctx->d_planes, recs.size() * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_planes_hot, n_rows * PLANE_HOT_DOUBLES * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_plane_aux, n_rows * sizeof(PlaneAux)));
+  HIPCHK(DMALLOC((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
+  HIPCHK(DMALLOC((void **)&ctx->d_cand, n_cand * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(DMALLOC((void **)&ctx->d_cand_aux, n_cand * sizeof(PlaneAux)));
+  HIPCHK(DMALLOC((void **)&ctx->d_planes, recs.size() * 8));
+  HIPCHK(DMALLOC((void **)&ctx->d_planes_hot, n_rows * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(DMALLOC((void **)&ctx->d_plane_aux, n_rows * sizeof(PlaneAux)));
   HIPCHK(hipMemcpy(ctx->d_slots, slots.data(), (size_t)cap * sizeof(RootSlot), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_planes, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemsetAsync(ctx->d_cand, 0, n_cand * PLANE_HOT_DOUBLES * 8, ctx->stream));
@@ -813,12 +851,12 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
                      ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand, ctx->d_cand_aux);
   if (!cand.empty()) {
     int32_t *d_meta = nullptr;
-    HIPCHK(hipMalloc((void **)&d_meta, cand.size() * 4));
+    HIPCHK(DMALLOC((void **)&d_meta, cand.size() * 4));
     HIPCHK(hipMemcpyAsync(d_meta, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_cand_fill, dim3((unsigned)((cand.size() * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_planes_hot, ctx->d_plane_aux, d_meta, (int)cand.size(), ctx->d_cand, ctx->d_cand_aux);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(d_meta));
+    HIPCHK(DFREE(d_meta));
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -828,7 +866,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   ctx->has_map = true;
   ctx->plane_tabs_fresh = false;
   if (ctx->tree_mode) {            // the snapshot replaces a device-resident tree
-    hipError_t e2 = hipFree(ctx->mt.nodes); e2 = hipFree(ctx->mt.pool_pw); e2 = hipFree(ctx->mt.pool_var); e2 = hipFree(ctx->mt.counters); e2 = hipFree(ctx->mt.dirty_list); e2 = hipFree(ctx->mt.overflow_list); (void)e2;
+    hipError_t e2 = DFREE(ctx->mt.nodes); e2 = DFREE(ctx->mt.pool_pw); e2 = DFREE(ctx->mt.pool_var); e2 = DFREE(ctx->mt.counters); e2 = DFREE(ctx->mt.dirty_list); e2 = DFREE(ctx->mt.overflow_list); (void)e2;
     ctx->mt = MapTreeArgs{}; ctx->tree_mode = false;
   }
   return LIVO2_OK;
@@ -847,9 +885,9 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   std::vector<int32_t> gpos(n), didx(n);
   for (int p = 0; p < n; p++) { gpos[p] = ctx->plane_cand_pos[plane_idx[p]]; didx[p] = ctx->plane_internal[plane_idx[p]]; }
   double *d_recs = nullptr; int32_t *d_idx = nullptr, *d_gpos = nullptr;
-  HIPCHK(hipMalloc((void **)&d_recs, recs.size() * 8));
-  HIPCHK(hipMalloc((void **)&d_idx, (size_t)n * 4));
-  HIPCHK(hipMalloc((void **)&d_gpos, (size_t)n * 4));
+  HIPCHK(DMALLOC((void **)&d_recs, recs.size() * 8));
+  HIPCHK(DMALLOC((void **)&d_idx, (size_t)n * 4));
+  HIPCHK(DMALLOC((void **)&d_gpos, (size_t)n * 4));
   HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_idx, didx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -857,7 +895,7 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   hipLaunchKernelGGL(k_planes_hot, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_planes, d_idx, d_gpos, n, ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand, ctx->d_cand_aux);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipFree(d_recs)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_gpos));
+  HIPCHK(DFREE(d_recs)); HIPCHK(DFREE(d_idx)); HIPCHK(DFREE(d_gpos));
   return LIVO2_OK;
 }
 
@@ -881,7 +919,7 @@ int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2
   int rc;
   if ((rc = ensure(ctx, ctx->d_imu_steps, ctx->imu_steps_cap, std::max((size_t)n * 8, (size_t)8)))) return rc;
   if ((rc = ensure(ctx, ctx->d_imu_poses, ctx->imu_poses_cap, std::max((size_t)n * 22, (size_t)22)))) return rc;
-  if (!ctx->d_imu_state) HIPCHK(hipMalloc((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
+  if (!ctx->d_imu_state) HIPCHK(DMALLOC((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
   static_assert(sizeof(livo2_imu_step) == 64, "livo2_imu_step is 8 doubles");
   HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
   if (n > 0) HIPCHK(hipMemcpyAsync(ctx->d_imu_steps, steps, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
@@ -966,13 +1004,13 @@ namespace {
 int scan_reserve(livo2_ctx *ctx, int n) {
   if (n > ctx->n_cap) {
     hipError_t e;
-    if (ctx->d_x) { e = hipFree(ctx->d_xyz_aos); e = hipFree(ctx->d_x); e = hipFree(ctx->d_y); e = hipFree(ctx->d_z); e = hipFree(ctx->d_cb); e = hipFree(ctx->d_keys); e = hipFree(ctx->d_keys2); e = hipFree(ctx->d_idx); e = hipFree(ctx->d_perm); (void)e; }
+    if (ctx->d_x) { e = DFREE(ctx->d_xyz_aos); e = DFREE(ctx->d_x); e = DFREE(ctx->d_y); e = DFREE(ctx->d_z); e = DFREE(ctx->d_cb); e = DFREE(ctx->d_keys); e = DFREE(ctx->d_keys2); e = DFREE(ctx->d_idx); e = DFREE(ctx->d_perm); (void)e; }
     int cap = std::max(n, 1024);
-    HIPCHK(hipMalloc((void **)&ctx->d_xyz_aos, (size_t)cap * 12)); HIPCHK(hipMalloc((void **)&ctx->d_x, (size_t)cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_y, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_z, (size_t)cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_cb, (size_t)cap * 48));
-    HIPCHK(hipMalloc((void **)&ctx->d_keys, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_keys2, (size_t)cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_idx, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_perm, (size_t)cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_xyz_aos, (size_t)cap * 12)); HIPCHK(DMALLOC((void **)&ctx->d_x, (size_t)cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_y, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_z, (size_t)cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_cb, (size_t)cap * 48));
+    HIPCHK(DMALLOC((void **)&ctx->d_keys, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_keys2, (size_t)cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_idx, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_perm, (size_t)cap * 4));
     ctx->n_cap = cap;
   }
   return LIVO2_OK;
@@ -980,9 +1018,9 @@ int scan_reserve(livo2_ctx *ctx, int n) {
 int sort_reserve(livo2_ctx *ctx, size_t need) {
   if (need > ctx->sort_tmp_bytes) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->d_sort_tmp) HIPCHK(hipFree(ctx->d_sort_tmp));
+    if (ctx->d_sort_tmp) HIPCHK(DFREE(ctx->d_sort_tmp));
     ctx->d_sort_tmp = nullptr;
-    HIPCHK(hipMalloc(&ctx->d_sort_tmp, need + need / 2 + 256));
+    HIPCHK(DMALLOC(&ctx->d_sort_tmp, need + need / 2 + 256));
     ctx->sort_tmp_bytes = need + need / 2 + 256;
   }
   return LIVO2_OK;
@@ -1029,7 +1067,7 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   hipError_t e;
   e = hipSuccess;
   free_map_arrays(ctx);
-  if (ctx->mt.nodes) { e = hipFree(ctx->mt.nodes); e = hipFree(ctx->mt.pool_pw); e = hipFree(ctx->mt.pool_var); e = hipFree(ctx->mt.counters); e = hipFree(ctx->mt.dirty_list); e = hipFree(ctx->mt.overflow_list); }
+  if (ctx->mt.nodes) { e = DFREE(ctx->mt.nodes); e = DFREE(ctx->mt.pool_pw); e = DFREE(ctx->mt.pool_var); e = DFREE(ctx->mt.counters); e = DFREE(ctx->mt.dirty_list); e = DFREE(ctx->mt.overflow_list); }
   (void)e;
   ctx->has_map = false; ctx->tree_mode = false; ctx->mt = MapTreeArgs{};
   MapTreeArgs &m = ctx->mt;
@@ -1041,20 +1079,20 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   m.cap_overflow = (int32_t)std::max<long long>(1024, R / 4);
   uint32_t cap = 64;
   while ((long long)cap < 8 * R) cap <<= 1;
-  HIPCHK(hipMalloc((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
-  HIPCHK(hipMalloc((void **)&ctx->d_planes, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand, (size_t)m.cap_cand * PLANE_HOT_DOUBLES * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_cand_aux, (size_t)m.cap_cand * sizeof(PlaneAux)));
-  HIPCHK(hipMalloc((void **)&ctx->d_planes_hot, (size_t)m.cap_planes * PLANE_HOT_DOUBLES * 8));
-  HIPCHK(hipMalloc((void **)&ctx->d_plane_aux, (size_t)m.cap_planes * sizeof(PlaneAux)));
-  HIPCHK(hipMalloc((void **)&m.nodes, (size_t)m.cap_nodes * sizeof(DevNode)));
-  HIPCHK(hipMalloc((void **)&m.pool_pw, (size_t)m.cap_points * 24));
-  HIPCHK(hipMalloc((void **)&m.pool_var, (size_t)m.cap_points * 72));
+  HIPCHK(DMALLOC((void **)&ctx->d_slots, (size_t)cap * sizeof(RootSlot)));
+  HIPCHK(DMALLOC((void **)&ctx->d_planes, (size_t)m.cap_planes * PLANE_REC_DOUBLES * 8));
+  HIPCHK(DMALLOC((void **)&ctx->d_cand, (size_t)m.cap_cand * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(DMALLOC((void **)&ctx->d_cand_aux, (size_t)m.cap_cand * sizeof(PlaneAux)));
+  HIPCHK(DMALLOC((void **)&ctx->d_planes_hot, (size_t)m.cap_planes * PLANE_HOT_DOUBLES * 8));
+  HIPCHK(DMALLOC((void **)&ctx->d_plane_aux, (size_t)m.cap_planes * sizeof(PlaneAux)));
+  HIPCHK(DMALLOC((void **)&m.nodes, (size_t)m.cap_nodes * sizeof(DevNode)));
+  HIPCHK(DMALLOC((void **)&m.pool_pw, (size_t)m.cap_points * 24));
+  HIPCHK(DMALLOC((void **)&m.pool_var, (size_t)m.cap_points * 72));
   // counters + the free stacks behind them (map_tree_kernels.hpp: mt_free_nodes ... mt_pending_slabs)
-  HIPCHK(hipMalloc((void **)&m.counters, ((size_t)MTC_TOTAL + m.cap_nodes + m.cap_planes + ((size_t)m.cap_points / slab + 1)) * 4));
+  HIPCHK(DMALLOC((void **)&m.counters, ((size_t)MTC_TOTAL + m.cap_nodes + m.cap_planes + ((size_t)m.cap_points / slab + 1)) * 4));
   m.slab = slab;
-  HIPCHK(hipMalloc((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
-  HIPCHK(hipMalloc((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
+  HIPCHK(DMALLOC((void **)&m.dirty_list, (size_t)m.cap_nodes * 4));
+  HIPCHK(DMALLOC((void **)&m.overflow_list, (size_t)m.cap_overflow * 4));
   {
     std::vector<RootSlot> empty(cap);
     for (auto &sl : empty) { sl.val = -1; sl.kx = sl.ky = sl.kz = MT_NO_KEY; sl.pad = -1; }
@@ -1077,8 +1115,8 @@ int livo2_map_tree_create(livo2_ctx *ctx, const livo2_map_tree_cfg *cfg) {
   ctx->map.n_planes = m.cap_planes;
   ctx->mt_cfg = *cfg;
   ctx->plane_internal.clear(); ctx->plane_orig.clear(); ctx->plane_cand_pos.clear();
-  if (!ctx->mt_nseg) HIPCHK(hipMalloc((void **)&ctx->mt_nseg, 64));
-  if (!ctx->mt_state) HIPCHK(hipMalloc((void **)&ctx->mt_state, sizeof(livo2_state)));
+  if (!ctx->mt_nseg) HIPCHK(DMALLOC((void **)&ctx->mt_nseg, 64));
+  if (!ctx->mt_state) HIPCHK(DMALLOC((void **)&ctx->mt_state, sizeof(livo2_state)));
   ctx->has_map = true; ctx->tree_mode = true;
   return LIVO2_OK;
 }
@@ -1141,14 +1179,14 @@ int map_tree_relayout_counters(livo2_ctx *ctx, int new_nodes, int new_planes, in
   MapTreeArgs &m = ctx->mt;
   const size_t new_total = (size_t)MTC_TOTAL + new_nodes + new_planes + ((size_t)new_points / m.slab + 1);
   int32_t *q = nullptr;
-  HIPCHK(hipMalloc((void **)&q, new_total * 4));
+  HIPCHK(DMALLOC((void **)&q, new_total * 4));
   HIPCHK(hipMemcpyAsync(q, m.counters, (size_t)MTC_TOTAL * 4, hipMemcpyDeviceToDevice, ctx->stream));
   // the three free stacks move to their new offsets (copied whole: their tops are the counters MTC_FREE_*)
   HIPCHK(hipMemcpyAsync(q + MTC_TOTAL, m.counters + MTC_TOTAL, (size_t)m.cap_nodes * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(q + MTC_TOTAL + new_nodes, m.counters + MTC_TOTAL + m.cap_nodes, (size_t)m.cap_planes * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(q + MTC_TOTAL + new_nodes + new_planes, m.counters + MTC_TOTAL + m.cap_nodes + m.cap_planes, ((size_t)m.cap_points / m.slab + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipFree(m.counters));
+  HIPCHK(DFREE(m.counters));
   m.counters = q;
   return LIVO2_OK;
 }
@@ -1448,7 +1486,7 @@ int preprocess_reserve(livo2_ctx *ctx, int n, int n_poses) {
   rc = ensure(ctx, ctx->d_poses, ctx->poses_cap, std::max((size_t)n_poses * 22, (size_t)22)); if (rc) return rc;
   rc = ensure(ctx, ctx->d_vg_head, ctx->vg_head_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
   rc = ensure(ctx, ctx->d_vg_slot, ctx->vg_slot_cap, std::max((size_t)n, (size_t)1)); if (rc) return rc;
-  if (!ctx->d_vg_misc) HIPCHK(hipMalloc((void **)&ctx->d_vg_misc, 64));      // bounds[6] float, overflow flag, leaf count
+  if (!ctx->d_vg_misc) HIPCHK(DMALLOC((void **)&ctx->d_vg_misc, 64));      // bounds[6] float, overflow flag, leaf count
   return LIVO2_OK;
 }
 // undistortion + voxel grid of the n > 0 raw points in d_raw / d_curv with the poses in d_poses: kernels only.  The scan-end pose comes from the host
@@ -1594,7 +1632,8 @@ int livo2_lidar_update_fetch(livo2_ctx *ctx, livo2_lidar_result *result, const l
   HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->lidar, sizeof(livo2_lidar_result), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(result, ctx->h_out, sizeof(livo2_lidar_result));
-  return fetch_lidar_points(ctx, points);
+  int rc = fetch_lidar_points(ctx, points);
+  return rc ? rc : rz_gate(ctx);
 }
 
 int livo2_lidar_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg, livo2_lidar_result *result,
@@ -1619,7 +1658,7 @@ int livo2_lio_frame(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const int n_poses = n_steps + 1;
   if ((rc = ensure(ctx, ctx->d_imu_steps, ctx->imu_steps_cap, std::max((size_t)n_steps * 8, (size_t)8)))) return rc;
-  if (!ctx->d_imu_state) HIPCHK(hipMalloc((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
+  if (!ctx->d_imu_state) HIPCHK(DMALLOC((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
   if ((rc = preprocess_reserve(ctx, n, n_poses))) return rc;
   *n_down = 0;
   HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
@@ -1681,10 +1720,10 @@ static_assert(sizeof(HostIn) % 8 == 0 && sizeof(livo2_lidar_result) % 8 == 0 && 
 
 int batch_alloc_fixed(livo2_ctx *ctx) {
   if (ctx->bd_ctl) return LIVO2_OK;
-  HIPCHK(hipMalloc((void **)&ctx->bd_ctl, sizeof(DevCtl) * LIVO2_MAX_BATCH));
-  HIPCHK(hipMalloc((void **)&ctx->bd_entries, sizeof(LidarBatchEntry) * LIVO2_MAX_BATCH));
-  HIPCHK(hipMalloc((void **)&ctx->bd_in, sizeof(HostIn) * LIVO2_MAX_BATCH));
-  HIPCHK(hipMalloc((void **)&ctx->bd_results, sizeof(livo2_lidar_result) * LIVO2_MAX_BATCH));
+  HIPCHK(DMALLOC((void **)&ctx->bd_ctl, sizeof(DevCtl) * LIVO2_MAX_BATCH));
+  HIPCHK(DMALLOC((void **)&ctx->bd_entries, sizeof(LidarBatchEntry) * LIVO2_MAX_BATCH));
+  HIPCHK(DMALLOC((void **)&ctx->bd_in, sizeof(HostIn) * LIVO2_MAX_BATCH));
+  HIPCHK(DMALLOC((void **)&ctx->bd_results, sizeof(livo2_lidar_result) * LIVO2_MAX_BATCH));
   HIPCHK(hipHostMalloc((void **)&ctx->bh_in, sizeof(HostIn) * LIVO2_MAX_BATCH));
   HIPCHK(hipHostMalloc((void **)&ctx->bh_results, sizeof(livo2_lidar_result) * LIVO2_MAX_BATCH));
   HIPCHK(hipHostMalloc((void **)&ctx->bh_entries, sizeof(LidarBatchEntry) * LIVO2_MAX_BATCH));
@@ -1708,12 +1747,12 @@ int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *x
   rc = batch_alloc_fixed(ctx); if (rc) return rc;
   if ((int)total > ctx->b_cap) {
     hipError_t e;
-    if (ctx->bd_x) { e = hipFree(ctx->bd_xyz_aos); e = hipFree(ctx->bd_x); e = hipFree(ctx->bd_y); e = hipFree(ctx->bd_z); e = hipFree(ctx->bd_cb); e = hipFree(ctx->bd_keys); e = hipFree(ctx->bd_keys2); e = hipFree(ctx->bd_idx); e = hipFree(ctx->bd_perm); (void)e; }
+    if (ctx->bd_x) { e = DFREE(ctx->bd_xyz_aos); e = DFREE(ctx->bd_x); e = DFREE(ctx->bd_y); e = DFREE(ctx->bd_z); e = DFREE(ctx->bd_cb); e = DFREE(ctx->bd_keys); e = DFREE(ctx->bd_keys2); e = DFREE(ctx->bd_idx); e = DFREE(ctx->bd_perm); (void)e; }
     ctx->bd_x = nullptr;
     size_t cap = std::max((size_t)total, (size_t)1024);
-    HIPCHK(hipMalloc((void **)&ctx->bd_xyz_aos, cap * 12)); HIPCHK(hipMalloc((void **)&ctx->bd_x, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_y, cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->bd_z, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_cb, cap * 48)); HIPCHK(hipMalloc((void **)&ctx->bd_keys, cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->bd_keys2, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->bd_perm, cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->bd_xyz_aos, cap * 12)); HIPCHK(DMALLOC((void **)&ctx->bd_x, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->bd_y, cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->bd_z, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->bd_cb, cap * 48)); HIPCHK(DMALLOC((void **)&ctx->bd_keys, cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->bd_keys2, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->bd_idx, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->bd_perm, cap * 4));
     ctx->b_cap = (int)cap;
   }
   ctx->bn = n_frames; ctx->b_total = (int)total;
@@ -1740,9 +1779,9 @@ int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *x
     HIPCHK(rocprim::radix_sort_pairs(nullptr, need, ctx->bd_keys, ctx->bd_keys2, ctx->bd_idx, ctx->bd_perm, (size_t)nmax, 0, 30, ctx->stream));
     if (need > ctx->sort_tmp_bytes) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
-      if (ctx->d_sort_tmp) HIPCHK(hipFree(ctx->d_sort_tmp));
+      if (ctx->d_sort_tmp) HIPCHK(DFREE(ctx->d_sort_tmp));
       ctx->d_sort_tmp = nullptr;
-      HIPCHK(hipMalloc(&ctx->d_sort_tmp, need + need / 2 + 256));
+      HIPCHK(DMALLOC(&ctx->d_sort_tmp, need + need / 2 + 256));
       ctx->sort_tmp_bytes = need + need / 2 + 256;
     }
     for (int f = 0; f < n_frames; f++) {          // same per-scan pipeline as livo2_lidar_set_scan, on this frame's slice
@@ -1812,7 +1851,7 @@ int livo2_lidar_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_lidar
   HIPCHK(hipMemcpyAsync(ctx->bh_results, ctx->bd_results, sizeof(livo2_lidar_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(results, ctx->bh_results, sizeof(livo2_lidar_result) * n_frames);
-  return LIVO2_OK;
+  return rz_gate(ctx);
 }
 
 int livo2_lidar_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_lidar_cfg *cfg,
@@ -1840,10 +1879,10 @@ int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, in
   int rc = ensure(ctx, ctx->d_img, ctx->img_cap, (size_t)stride * height); if (rc) return rc;
   if (M > ctx->M_cap) {
     hipError_t e;
-    if (ctx->d_pos) { e = hipFree(ctx->d_pos); e = hipFree(ctx->d_invexpo); e = hipFree(ctx->d_search); e = hipFree(ctx->d_errors); (void)e; }
+    if (ctx->d_pos) { e = DFREE(ctx->d_pos); e = DFREE(ctx->d_invexpo); e = DFREE(ctx->d_search); e = DFREE(ctx->d_errors); (void)e; }
     int cap = std::max(M, 512);
-    HIPCHK(hipMalloc((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_invexpo, (size_t)cap * 8));
-    HIPCHK(hipMalloc((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_errors, (size_t)cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(DMALLOC((void **)&ctx->d_invexpo, (size_t)cap * 8));
+    HIPCHK(DMALLOC((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_errors, (size_t)cap * 4));
     ctx->M_cap = cap;
   }
   rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)M * L * 64, (size_t)64)); if (rc) return rc;
@@ -1876,11 +1915,11 @@ int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t 
   int rc = ensure(ctx, ctx->d_ref_imgs, ctx->ref_img_cap, img_bytes * n_ref); if (rc) return rc;
   if (M > ctx->ref_cap) {
     hipError_t e;
-    if (ctx->d_ref_idx) { e = hipFree(ctx->d_ref_idx); e = hipFree(ctx->d_ref_px); e = hipFree(ctx->d_ref_f); e = hipFree(ctx->d_ref_R); e = hipFree(ctx->d_ref_pos); e = hipFree(ctx->d_gref); e = hipFree(ctx->d_mref); (void)e; }
+    if (ctx->d_ref_idx) { e = DFREE(ctx->d_ref_idx); e = DFREE(ctx->d_ref_px); e = DFREE(ctx->d_ref_f); e = DFREE(ctx->d_ref_R); e = DFREE(ctx->d_ref_pos); e = DFREE(ctx->d_gref); e = DFREE(ctx->d_mref); (void)e; }
     const size_t cap = (size_t)std::max(M, 512);
-    HIPCHK(hipMalloc((void **)&ctx->d_ref_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_ref_px, cap * 16)); HIPCHK(hipMalloc((void **)&ctx->d_ref_f, cap * 24));
-    HIPCHK(hipMalloc((void **)&ctx->d_ref_R, cap * 72)); HIPCHK(hipMalloc((void **)&ctx->d_ref_pos, cap * 24));
-    HIPCHK(hipMalloc((void **)&ctx->d_gref, cap * 64 * 16)); HIPCHK(hipMalloc((void **)&ctx->d_mref, cap * 16 * 8));
+    HIPCHK(DMALLOC((void **)&ctx->d_ref_idx, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_ref_px, cap * 16)); HIPCHK(DMALLOC((void **)&ctx->d_ref_f, cap * 24));
+    HIPCHK(DMALLOC((void **)&ctx->d_ref_R, cap * 72)); HIPCHK(DMALLOC((void **)&ctx->d_ref_pos, cap * 24));
+    HIPCHK(DMALLOC((void **)&ctx->d_gref, cap * 64 * 16)); HIPCHK(DMALLOC((void **)&ctx->d_mref, cap * 16 * 8));
     ctx->ref_cap = (int)cap;
   }
   HIPCHK(hipMemcpyAsync(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
@@ -1908,7 +1947,7 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
   if ((rc = ensure(ctx, ctx->d_vm_pkey, ctx->vm_pkey_cap, std::max((size_t)n, (size_t)1)))) return rc;
   if ((rc = ensure(ctx, ctx->d_vm_active, ctx->vm_active_cap, std::max((size_t)n, (size_t)1)))) return rc;
   if ((rc = ensure(ctx, ctx->d_vm_fov, ctx->vm_fov_cap, std::max((size_t)n, (size_t)1)))) return rc;
-  if (!ctx->d_sel_flag) HIPCHK(hipMalloc((void **)&ctx->d_sel_flag, 64));
+  if (!ctx->d_sel_flag) HIPCHK(DMALLOC((void **)&ctx->d_sel_flag, 64));
   HIPCHK(hipMemsetAsync(ctx->d_sel_flag, 0, 64, ctx->stream));
   if (n > 0) {
     HIPCHK(hipMemcpyAsync(ctx->d_vm_pos, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
@@ -2019,16 +2058,16 @@ static int tail_reserve(livo2_ctx *ctx, int n, int L) {
   if (n > ctx->cand_cap) {
     void *old[] = {ctx->d_c_pos, ctx->d_c_normal, ctx->d_c_px, ctx->d_c_f, ctx->d_c_R, ctx->d_c_t, ctx->d_c_ie, ctx->d_c_ncc, ctx->d_c_A, ctx->d_c_idx, ctx->d_c_lvl,
                    ctx->d_c_acc, ctx->d_c_sl, ctx->d_c_slot, ctx->d_c_err};
-    for (void *p : old) if (p) { hipError_t e = hipFree(p); (void)e; }
+    for (void *p : old) if (p) { hipError_t e = DFREE(p); (void)e; }
     const size_t cap = (size_t)std::max(n, 512);
-    HIPCHK(hipMalloc((void **)&ctx->d_c_pos, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_normal, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_px, cap * 16));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_f, cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_c_R, cap * 72)); HIPCHK(hipMalloc((void **)&ctx->d_c_t, cap * 24));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_ie, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_ncc, cap * 8)); HIPCHK(hipMalloc((void **)&ctx->d_c_A, cap * 32));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_idx, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_lvl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_acc, cap * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_c_sl, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_slot, cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_c_err, cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_c_pos, cap * 24)); HIPCHK(DMALLOC((void **)&ctx->d_c_normal, cap * 24)); HIPCHK(DMALLOC((void **)&ctx->d_c_px, cap * 16));
+    HIPCHK(DMALLOC((void **)&ctx->d_c_f, cap * 24)); HIPCHK(DMALLOC((void **)&ctx->d_c_R, cap * 72)); HIPCHK(DMALLOC((void **)&ctx->d_c_t, cap * 24));
+    HIPCHK(DMALLOC((void **)&ctx->d_c_ie, cap * 8)); HIPCHK(DMALLOC((void **)&ctx->d_c_ncc, cap * 8)); HIPCHK(DMALLOC((void **)&ctx->d_c_A, cap * 32));
+    HIPCHK(DMALLOC((void **)&ctx->d_c_idx, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_c_lvl, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_c_acc, cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_c_sl, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_c_slot, cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_c_err, cap * 4));
     ctx->cand_cap = (int)cap;
   }
-  if (!ctx->d_c_count) HIPCHK(hipMalloc((void **)&ctx->d_c_count, 64));
+  if (!ctx->d_c_count) HIPCHK(DMALLOC((void **)&ctx->d_c_count, 64));
   int rc = ensure(ctx, ctx->d_c_patch, ctx->c_patch_cap, std::max((size_t)n * L * 64, (size_t)64)); if (rc) return rc;
   size_t ld = 1024; while (ld < 2 * (size_t)std::max(n, 1)) ld <<= 1;
   if ((rc = ensure(ctx, ctx->d_c_id, ctx->c_id_cap, (size_t)std::max(n, 1)))) return rc;
@@ -2038,10 +2077,10 @@ static int tail_reserve(livo2_ctx *ctx, int n, int L) {
   // the frame arrays must be able to hold every candidate
   if (n > ctx->M_cap) {
     hipError_t e;
-    if (ctx->d_pos) { e = hipFree(ctx->d_pos); e = hipFree(ctx->d_invexpo); e = hipFree(ctx->d_search); e = hipFree(ctx->d_errors); (void)e; }
+    if (ctx->d_pos) { e = DFREE(ctx->d_pos); e = DFREE(ctx->d_invexpo); e = DFREE(ctx->d_search); e = DFREE(ctx->d_errors); (void)e; }
     int cap = std::max(n, 512);
-    HIPCHK(hipMalloc((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(hipMalloc((void **)&ctx->d_invexpo, (size_t)cap * 8));
-    HIPCHK(hipMalloc((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(hipMalloc((void **)&ctx->d_errors, (size_t)cap * 4));
+    HIPCHK(DMALLOC((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(DMALLOC((void **)&ctx->d_invexpo, (size_t)cap * 8));
+    HIPCHK(DMALLOC((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_errors, (size_t)cap * 4));
     ctx->M_cap = cap;
   }
   if ((rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)n * L * 64, (size_t)64)))) return rc;
@@ -2239,7 +2278,7 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if ((rc = ensure(ctx, ctx->d_cand_obs, ctx->cand_obs_cap, len))) return rc;
   if ((rc = ensure(ctx, ctx->d_sub_point, ctx->sub_point_cap, len))) return rc;
   if ((rc = ensure(ctx, ctx->d_sub_obs, ctx->sub_obs_cap, len))) return rc;
-  if (!ctx->d_ch_count) HIPCHK(hipMalloc((void **)&ctx->d_ch_count, 64));
+  if (!ctx->d_ch_count) HIPCHK(DMALLOC((void **)&ctx->d_ch_count, 64));
   HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
@@ -2312,8 +2351,8 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   if (level < 0 || level >= cfg->patch_pyrimid_level) return fail(ctx, LIVO2_ERR_INVALID, "level out of range");
   const int M = ctx->M;
   if ((z || H_sub) && ctx->dbg_cap < M) {
-    hipError_t e; if (ctx->d_zdbg) { e = hipFree(ctx->d_zdbg); e = hipFree(ctx->d_Hdbg); (void)e; }
-    HIPCHK(hipMalloc((void **)&ctx->d_zdbg, (size_t)std::max(M, 1) * 64 * 8)); HIPCHK(hipMalloc((void **)&ctx->d_Hdbg, (size_t)std::max(M, 1) * 64 * 56));
+    hipError_t e; if (ctx->d_zdbg) { e = DFREE(ctx->d_zdbg); e = DFREE(ctx->d_Hdbg); (void)e; }
+    HIPCHK(DMALLOC((void **)&ctx->d_zdbg, (size_t)std::max(M, 1) * 64 * 8)); HIPCHK(DMALLOC((void **)&ctx->d_Hdbg, (size_t)std::max(M, 1) * 64 * 56));
     ctx->dbg_cap = M;
   }
   rc = upload_states(ctx, cur, cur); if (rc) return rc;
@@ -2357,7 +2396,7 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       rc = ensure(ctx, ctx->d_vp_errs, ctx->vp_errs_cap, (size_t)2 * std::max(ctx->M_cap, 512)); if (rc) return rc;
       if (ctx->vp_rows_cap != c0) HIPCHK(hipMemsetAsync(ctx->d_vp_rows, 0, ctx->vp_rows_cap * 8, ctx->stream));
       if (ctx->vp_errs_cap != c1) HIPCHK(hipMemsetAsync(ctx->d_vp_errs, 0, ctx->vp_errs_cap * 8, ctx->stream));
-      if (ctx->vp_prof && !ctx->d_vp_prof) HIPCHK(hipMalloc((void **)&ctx->d_vp_prof, VP_MAX_BLOCKS * 32 * 16 * 8));
+      if (ctx->vp_prof && !ctx->d_vp_prof) HIPCHK(DMALLOC((void **)&ctx->d_vp_prof, VP_MAX_BLOCKS * 32 * 16 * 8));
       if (ctx->vp_prof) HIPCHK(hipMemsetAsync(ctx->d_vp_prof, 0, VP_MAX_BLOCKS * 32 * 16 * 8, ctx->stream));
     }
     int halves = 1;
@@ -2428,7 +2467,7 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(result, ctx->h_out, sizeof(livo2_visual_result));
   if (*flag) return fail(ctx, LIVO2_ERR_HIP, "persistent visual update: grid barrier timed out (the grid was not co-resident); result invalid");
-  return LIVO2_OK;
+  return rz_gate(ctx);
 }
 
 int livo2_visual_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, livo2_visual_result *result,
@@ -2474,8 +2513,8 @@ int livo2_visual_batch_set_frames(livo2_ctx *ctx, int32_t n_frames, const uint8_
   HIPCHK(hipStreamSynchronize(ctx->stream));
   int rc = batch_alloc_fixed(ctx); if (rc) return rc;
   if (!ctx->vbd_entries) {
-    HIPCHK(hipMalloc((void **)&ctx->vbd_entries, sizeof(VisualBatchEntry) * LIVO2_MAX_BATCH));
-    HIPCHK(hipMalloc((void **)&ctx->vbd_results, sizeof(livo2_visual_result) * LIVO2_MAX_BATCH));
+    HIPCHK(DMALLOC((void **)&ctx->vbd_entries, sizeof(VisualBatchEntry) * LIVO2_MAX_BATCH));
+    HIPCHK(DMALLOC((void **)&ctx->vbd_results, sizeof(livo2_visual_result) * LIVO2_MAX_BATCH));
     HIPCHK(hipHostMalloc((void **)&ctx->vbh_entries, sizeof(VisualBatchEntry) * LIVO2_MAX_BATCH));
     HIPCHK(hipHostMalloc((void **)&ctx->vbh_results, sizeof(livo2_visual_result) * LIVO2_MAX_BATCH));
   }
@@ -2566,7 +2605,7 @@ int livo2_visual_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_visu
   HIPCHK(hipMemcpyAsync(ctx->vbh_results, ctx->vbd_results, sizeof(livo2_visual_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(results, ctx->vbh_results, sizeof(livo2_visual_result) * n_frames);
-  return LIVO2_OK;
+  return rz_gate(ctx);
 }
 int livo2_visual_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, livo2_visual_result *results) {
   int rc = livo2_visual_batch_update_async(ctx, n_frames, state_in, prop, cfg); if (rc) return rc;

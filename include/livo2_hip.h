@@ -83,6 +83,15 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value);
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value);
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
+/* Debug allocator (no reference counterpart; fast-livo2_amd/csrc/dev_alloc.hpp).  The environment variable LIVO2_REDZONE, read at the first device allocation
+ * of the process, puts every device allocation of the library behind a checker: 1 = poisoned guard regions in front of and behind each allocation, scanned by
+ * livo2_ctx_synchronize, every *_fetch and this call (a damaged guard => LIVO2_ERR_HIP, livo2_last_error names the allocation's source line, size, side and
+ * offset); 2 / 3 = each allocation is its own virtual-memory mapping that ends (2) or starts (3) at unmapped address space, so that an out-of-bounds READ
+ * faults deterministically.  *mode receives the active mode, *damaged_words the number of overwritten guard words (mode 1). */
+int livo2_debug_redzone_check(livo2_ctx *ctx, int32_t *mode, int64_t *damaged_words);
+/* Self-test of the checker: one 4-byte device store `byte_offset` bytes behind the END of the ctx's control block (negative: in front of its start).
+ * Refused (LIVO2_ERR_INVALID) unless LIVO2_REDZONE is set. */
+int livo2_debug_redzone_poke(livo2_ctx *ctx, int64_t byte_offset);
 
 /* ---- VoxelMap snapshot ("flat map") -------------------------------------------------------------------------- */
 /* Index-based mirror of `std::unordered_map<VOXEL_LOCATION, VoxelOctoTree*> voxel_map_` (reference include/voxel_map.h:194)
