@@ -374,6 +374,7 @@ def emit(full):
 def cpu_baseline(sc, vs, budget_s=20.0):
     """Oracle (restated reference CPU path) timed on this host on the same C4 frame.  Bounded sample: ~budget_s seconds."""
     from oracle import orc
+    from oracle import live_chain as orc_chain
     from tests import helpers as H
     try:
         path = orc.build("fast", out_dir=tempfile.mkdtemp(prefix="orc_fast_"))     # -march=native: must be compiled on this host
@@ -407,7 +408,7 @@ def cpu_baseline(sc, vs, budget_s=20.0):
                       f"computeJacobianAndUpdateEKF window (vio.cpp:1808-1812), OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "lidar_evals_per_s": o4["lidar"], "visual_evals_per_s": o4["visual"], "lidar_update_ms": o4["lidar_ms"], "visual_update_ms": o4["visual_ms"],
             "value_1thread": out[1]["value"], "lidar_evals_per_s_1thread": out[1]["lidar"], "visual_evals_per_s_1thread": out[1]["visual"],
-            "value_all_cores": out[ncores]["value"], "host_cores": ncores}, (orc, lib)
+            "value_all_cores": out[ncores]["value"], "host_cores": ncores}, (orc, lib, orc_chain)
 
 
 def reference_sources_timing(orc, sc, vs, cur, prop, vcur, vprop, o4):
@@ -434,7 +435,7 @@ def reference_sources_timing(orc, sc, vs, cur, prop, vcur, vprop, o4):
         return {"error": repr(exc)}
 
 
-def cpu_widened_rows(orc, lib):
+def cpu_widened_rows(orc, lib, orc_chain):
     """oracle timings of the widened rows on one host core (the figures the widened_rows notes refer to)"""
     from scenarios import synth as _synth
     from scenarios import imu_inputs as IMU
@@ -476,56 +477,24 @@ def cpu_widened_rows(orc, lib):
         mu[case[0]] = {"build_ms": 1e3 * tb, "update_ms_median": 1e3 * float(np.median(ts)), "points_per_frame": int(np.mean([len(f[0]) for f in frames]))}
     live = {}
     try:
-        live = cpu_live_chain(orc, lib)
+        live = cpu_live_chain(orc_chain, lib)
     except Exception as exc:
         live = {"error": repr(exc)}
     return {"live_chain": live, "map_update_ms": mu, "imu_propagate_us_20_samples": imu_us, "select_seconds_1thread": sel_s, "retrieve_from_map_seconds_1thread": min(tch), "preprocess_points_per_s_1thread": len(raw.xyz) / min(tpre),
             "plane_fit_points_per_s_1thread": len(pw) / fit_s, "plane_fit_groups": len(off) - 1, "retrieve_candidates_per_s_1thread": len(rs.pos) / warp_s}
 
 
-def cpu_live_chain(orc, lib, sizes=("avia",)):
-    """the oracle over the frames of extra.live_chain (scenarios/live_inputs.py, same seeds): StateEstimation, LIVMapper.cpp:413-423 + UpdateVoxelMap,
-    retrieveFromVisualSparseMap, computeJacobianAndUpdateEKF per frame, single thread apart from the reference's own OpenMP loops (4 threads)"""
-    from scenarios import live_inputs, synth
+def cpu_live_chain(OC, lib, sizes=("avia",)):
+    """the oracle over the frames of extra.live_chain (scenarios/live_inputs.py, same seeds, same one-scene data flow: oracle/live_chain.py): StateEstimation,
+    LIVMapper.cpp:413-423 + UpdateVoxelMap, retrieveFromVisualSparseMap, computeJacobianAndUpdateEKF per frame, the reference's own OpenMP loops on 4 threads"""
+    from scenarios import live_inputs
     out = {}
     for size in sizes:
         live = live_inputs.make_live(**live_inputs.SIZES[size])
-        c, extR, extT, cs = live["c"], live["extR"], live["extT"], live["cs"]
-        om = orc.OracleMap.build(live["pw0"], live["var0"].reshape(-1, 9), c["voxel_size"], c["max_layer"], c["layer_init_num"], c["max_points_num"], c["min_eigen_value"], lib)
-        cfg = orc.lidar_cfg(c, extR, extT, num_threads=4)
-        R, t, P = live["R0"], live["t0"], live["P0"].copy()
-        vcfg = None
-        stage = np.zeros((len(live["scans"]), 4))
-        for f, xyz in enumerate(live["scans"]):
-            mo = live["motion"][f]
-            Rp, tp = R @ mo[:9].reshape(3, 3), t + mo[9:]
-            Pp = P + np.diag(live["q"])
-            prior = orc.make_state(Rp, tp, Pp)
-            t0 = time.perf_counter()
-            r = orc.lidar_state_estimation(om, cfg, xyz, prior, prior, want_points=False)
-            a = time.perf_counter()
-            st = orc.state_arrays(r["state"]); R, t, P = st["R"], st["t"], st["P"]
-            pw, var = synth.world_points_and_var(xyz, R, t, extR, extT, P, c["dept_err"], c["beam_err"])
-            om.update(pw, var.reshape(-1, 9))
-            b = time.perf_counter()
-            ret = orc.visual_retrieve(cs, lib)
-            cc = time.perf_counter()
-            keep = ret["tail"]["accepted"] != 0
-            sub = type("Sub", (), {})()
-            vs_c = live["vs_c"]
-            for k in ("cam", "cfg", "Rcl", "Pcl", "extR", "extT"):
-                setattr(sub, k, getattr(vs_c, k))
-            sub.cfg = dict(vs_c.cfg, patch_pyrimid_level=live["L"])
-            sub.img, sub.pos = cs.img, cs.sel.pos[ret["sub_point"]]
-            sub.warp_patch, sub.search_levels, sub.inv_expo_list = ret["tail"]["patch_wrap"][keep], ret["tail"]["search_level"][keep], cs.obs_inv_expo[ret["sub_obs"]]
-            vprior = orc.make_state(vs_c.R_prior, vs_c.t_prior, vs_c.P, inv_expo=cs.inv_expo_cur)
-            if len(sub.pos):
-                orc.visual_update(orc.visual_cfg(sub, num_threads=4), sub, vprior, vprior, lib)
-            dd = time.perf_counter()
-            stage[f] = [a - t0, b - a, cc - b, dd - cc]
-        m = 1e3 * stage[1:].mean(0)
+        recs, _ = OC.run(live, lib, num_threads=4, timing=True)
+        m = 1e3 * np.array([r["stage_s"] for r in recs[1:]]).mean(0)
         out[size] = {"ms_per_frame": float(m.sum()), "StateEstimation_ms": float(m[0]), "UpdateVoxelMap_ms": float(m[1]), "retrieveFromVisualSparseMap_ms": float(m[2]),
-                     "computeJacobianAndUpdateEKF_ms": float(m[3]), "frames_timed": int(len(stage) - 1)}
+                     "computeJacobianAndUpdateEKF_ms": float(m[3]), "frames_timed": int(len(recs) - 1)}
     return out
 
 
@@ -658,9 +627,9 @@ def main():
                     extra["widened_rows_error"] = repr(exc)
         if not args.no_cpu:
             try:
-                cpu, (orc_mod, lib) = cpu_baseline(sc, vs)
+                cpu, (orc_mod, lib, orc_chain) = cpu_baseline(sc, vs)
                 if not args.no_extra:
-                    cpu.update(cpu_widened_rows(orc_mod, lib))
+                    cpu.update(cpu_widened_rows(orc_mod, lib, orc_chain))
             except Exception as exc:
                 extra["cpu_baseline_error"] = repr(exc)
 

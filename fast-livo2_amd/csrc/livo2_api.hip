@@ -151,6 +151,7 @@ struct livo2_ctx {
   int32_t *mt_idx = nullptr, *mt_order = nullptr, *mt_head = nullptr, *mt_slot = nullptr, *mt_seg_begin = nullptr, *mt_seg_root = nullptr, *mt_nseg = nullptr;
   size_t mt_idx_cap = 0, mt_order_cap = 0, mt_head_cap = 0, mt_slot_cap = 0, mt_seg_begin_cap = 0, mt_seg_root_cap = 0;
   livo2_state *mt_state = nullptr;
+  int mt_pv_n = -1;                         // points of the pv_list in mt_in_pw / mt_in_var (last map-tree update), -1: none since the last set_scan
   int32_t *mt_rp_rows = nullptr; size_t mt_rp_rows_cap = 0; double *mt_rp_out = nullptr; size_t mt_rp_out_cap = 0;   // livo2_map_tree_read_planes staging
   double mt_kernel_us = 0.0;
   int mt_grow_events = 0;                   // pool growths / candidate re-packs so far (livo2_ctx_get_counter "map_tree_grow_events")
@@ -1301,6 +1302,7 @@ int livo2_map_tree_update(livo2_ctx *ctx, const double *point_w, const double *v
     HIPCHK(hipMemcpyAsync(ctx->mt_in_var, var, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
+  ctx->mt_pv_n = n;
   rc = map_tree_run(ctx, n, build); if (rc) return rc;
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   return map_tree_finish(ctx);
@@ -1326,9 +1328,24 @@ int livo2_map_tree_update_from_scan(livo2_ctx *ctx, const livo2_state *state, co
     p.out_pw = ctx->mt_in_pw; p.out_var = ctx->mt_in_var;
     hipLaunchKernelGGL(k_mt_pv_from_scan, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p, ctx->mt_state);
   }
+  ctx->mt_pv_n = n;
   rc = map_tree_run(ctx, n, build); if (rc) return rc;
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   return map_tree_finish(ctx);
+}
+
+int livo2_map_tree_read_pv(livo2_ctx *ctx, double *point_w, double *var, int32_t capacity, int32_t *n) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (ctx->mt_pv_n < 0) return fail(ctx, LIVO2_ERR_NO_SCAN, "no livo2_map_tree_update[_from_scan] since the last livo2_lidar_set_scan");
+  if (n) *n = ctx->mt_pv_n;
+  if (capacity < ctx->mt_pv_n) return fail(ctx, LIVO2_ERR_INVALID, "capacity smaller than the pv_list");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->mt_pv_n > 0) {
+    if (point_w) HIPCHK(hipMemcpyAsync(point_w, ctx->mt_in_pw, (size_t)ctx->mt_pv_n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (var) HIPCHK(hipMemcpyAsync(var, ctx->mt_in_var, (size_t)ctx->mt_pv_n * 72, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LIVO2_OK;
 }
 
 int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts) {
@@ -1453,6 +1470,7 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
   int rc = check_lidar_cfg(ctx, cfg); if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
   if (n > ctx->n_cap) HIPCHK(hipStreamSynchronize(ctx->stream));      // the scan buffers are about to be re-allocated
+  ctx->mt_pv_n = -1;                                                   // the resident pv_list belonged to the previous scan
   rc = scan_reserve(ctx, n); if (rc) return rc;
   if (n > 0) {
     // the caller's (pageable) array goes through one of two pinned staging blocks: no stream synchronisation at entry or exit, the H2D of this scan
@@ -1473,7 +1491,7 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
     ctx->scan_stage_used[k] = true;
   }
   rc = scan_pipeline(ctx, n, cfg); if (rc) return rc;
-  ctx->has_scan = true;
+  ctx->has_scan = true; ctx->mt_pv_n = -1;
   return LIVO2_OK;
 }
 
@@ -1543,7 +1561,7 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
   HIPCHK(hipStreamSynchronize(ctx->stream));
   rc = preprocess_reserve(ctx, n, n_poses); if (rc) return rc;
   *n_down = 0;
-  if (n == 0) { rc = scan_pipeline(ctx, 0, cfg); if (rc) return rc; ctx->has_scan = true; return LIVO2_OK; }
+  if (n == 0) { rc = scan_pipeline(ctx, 0, cfg); if (rc) return rc; ctx->has_scan = true; ctx->mt_pv_n = -1; return LIVO2_OK; }
   static_assert(sizeof(livo2_imu_pose) == 22 * 8, "livo2_imu_pose is 22 doubles");
   HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1564,7 +1582,7 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
   rc = scan_pipeline(ctx, m, cfg); if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *n_down = m;
-  ctx->has_scan = true;
+  ctx->has_scan = true; ctx->mt_pv_n = -1;
   return LIVO2_OK;
 }
 double livo2_lidar_preprocess_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->preprocess_kernel_us : 0.0; }
@@ -1682,7 +1700,7 @@ int livo2_lio_frame(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu
   if (misc[0]) return fail(ctx, LIVO2_ERR_RANGE, "leaf size too small for the cloud: the voxel grid overflows int32 (pcl::VoxelGrid refuses it too)");
   const int m = misc[1];
   if ((rc = scan_pipeline(ctx, m, cfg))) return rc;
-  ctx->has_scan = true;
+  ctx->has_scan = true; ctx->mt_pv_n = -1;
   *n_down = m;
   // 3. StateEstimation(state_propagat) with state_ = state_propagat (LIVMapper.cpp:366-370)
   if ((rc = ensure_lidar_outputs(ctx, nullptr))) return rc;
@@ -2255,7 +2273,12 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
                                    const livo2_select_cfg *sel, const livo2_retrieve_cfg *cfg, livo2_retrieve_chain_out *out, int32_t *n_candidates, int32_t *n_accepted) {
   if (!ctx) return LIVO2_ERR_INVALID;
   if (!img || width <= 0 || height <= 0 || stride < width) return fail(ctx, LIVO2_ERR_INVALID, "bad image");
-  if (!sel || !cfg || !n_accepted || n_pg < 0 || (n_pg > 0 && !pg)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  const bool pg_resident = !pg && n_pg == LIVO2_PG_FROM_MAP_UPDATE;      // the pv_list_ of the last livo2_map_tree_update[_from_scan] (LIVMapper.cpp:413-426: _pv_list)
+  if (pg_resident) {
+    if (ctx->mt_pv_n < 0) return fail(ctx, LIVO2_ERR_NO_SCAN, "LIVO2_PG_FROM_MAP_UPDATE: no livo2_map_tree_update[_from_scan] since the last livo2_lidar_set_scan");
+    n_pg = ctx->mt_pv_n;
+  }
+  if (!sel || !cfg || !n_accepted || n_pg < 0 || (n_pg > 0 && !pg && !pg_resident)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
   if (!ctx->has_obs) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_obs_upload has not been called (after livo2_visual_map_upload)");
   const int L = cfg->patch_pyrimid_level;
   if (L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad patch_pyrimid_level");
@@ -2280,7 +2303,7 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if ((rc = ensure(ctx, ctx->d_sub_obs, ctx->sub_obs_cap, len))) return rc;
   if (!ctx->d_ch_count) HIPCHK(DMALLOC((void **)&ctx->d_ch_count, 64));
   HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
-  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
+  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg_resident ? ctx->mt_in_pw : pg, (size_t)n_pg * 24, pg_resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   // 1. selection
   if ((rc = select_enqueue(ctx, sel, n_pg, cap))) return rc;

@@ -58,16 +58,17 @@ def pack_result(lres, vres):
 
 
 def run_frame(ctx, State, frame, cfg, vcfg):
-    """One LIO + VIO frame through the C ABI as LIVMapper::handleLIO / handleVIO would drive it (LIVMapper.cpp:336-482, 281-334): the down-sampled scan goes up
-    (H2D + per-scan precompute), StateEstimation from the frame's prior, the image + visual sub-map go up, computeJacobianAndUpdateEKF starts from the LiDAR
-    posterior, the two results come back (D2H).  The map stays resident."""
-    prior = State.from_pose(frame["R_prior"], frame["t_prior"], frame["P"])
+    """One LIO + VIO frame through the C ABI as LIVMapper::handleLIO / handleVIO drive it (LIVMapper.cpp:336-482, 281-334): the down-sampled scan goes up
+    (H2D + per-scan precompute), StateEstimation from the frame's prior, the image + visual sub-map go up, computeJacobianAndUpdateEKF runs on the SHARED state:
+    `state` is the LiDAR posterior (LIVMapper.cpp:135, 371) and so is `state_propagat` (processImu re-assigns it from _state before the VIO step,
+    LIVMapper.cpp:256); the two results come back (D2H).  The map stays resident.  The frame's image / sub-map are generated at the pose the scan was
+    taken from (scenarios.synth.frame_sequence), so the chained update is well posed."""
+    vs = frame["vs"]
+    prior = State.from_pose(frame["R_prior"], frame["t_prior"], frame["P"], inv_expo=getattr(vs, "tau_prior", 1.0))
     ctx.set_scan(frame["xyz"], cfg)
     lres, _ = ctx.lidar_update(prior, prior, cfg)
-    vs = frame["vs"]
     ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-    vprior = State.from_pose(vs.R_prior, vs.t_prior, vs.P, inv_expo=getattr(vs, "tau_prior", 1.0))     # (the synthetic image has its own pose: the visual prior is the sub-map's)
-    vres, _ = ctx.visual_update(vprior, vprior, vcfg)
+    vres, _ = ctx.visual_update(lres.state, lres.state, vcfg)
     return pack_result(lres, vres), int(lres.n_iters) * len(frame["xyz"]) + int(vres.n_steps) * 64 * len(vs.pos)
 
 

@@ -275,6 +275,13 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
   livo2_state s; state_.to_abi(s);
   dev_.check(livo2_map_tree_update_from_scan(dev_.ctx(), &s, &cfg, 0));
   last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
+  if (host_point_lists_ && !pv_list_.empty()) {        // the reference leaves the posterior point_w / var in pv_list_ (LIVMapper.cpp:417-424; `_pv_list` of :426 feeds handleVIO)
+    const int32_t n = (int32_t)pv_list_.size();
+    std::vector<double> pw((size_t)n * 3), var((size_t)n * 9);
+    int32_t got = 0;
+    dev_.check(livo2_map_tree_read_pv(dev_.ctx(), pw.data(), var.data(), n, &got));
+    for (int32_t i = 0; i < got; i++) { std::memcpy(pv_list_[i].point_w.data(), &pw[(size_t)i * 3], 24); std::memcpy(pv_list_[i].var.data(), &var[(size_t)i * 9], 72); }
+  }
 }
 
 int VoxelMapManager::mapSliding() {
@@ -535,6 +542,21 @@ std::vector<VisualPoint *> VIOManager::selectFromVisualSparseMap(const std::vect
   return kept;
 }
 
+void VIOManager::updateFrameState(const StatesGroup &s) {                         // reference src/vio.cpp:1690-1697 (+ initializeVIO 57-58 for Rci / Pci)
+  M3D Rci; V3D Pci;
+  for (int r = 0; r < 3; r++) {                                                   // Rli = extR^T, Pli = -extR^T extT; Rci = Rcl Rli; Pci = Rcl Pli + Pcl
+    for (int c = 0; c < 3; c++) Rci[r * 3 + c] = Rcl[r * 3] * extR[c * 3] + Rcl[r * 3 + 1] * extR[c * 3 + 1] + Rcl[r * 3 + 2] * extR[c * 3 + 2];
+  }
+  V3D Pli;
+  for (int r = 0; r < 3; r++) Pli[r] = -(extR[r] * extT[0] + extR[3 + r] * extT[1] + extR[6 + r] * extT[2]);
+  for (int r = 0; r < 3; r++) Pci[r] = (Rcl[r * 3] * Pli[0] + Rcl[r * 3 + 1] * Pli[1] + Rcl[r * 3 + 2] * Pli[2]) + Pcl[r];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Rci[r * 3] * s.rot_end[c * 3] + Rci[r * 3 + 1] * s.rot_end[c * 3 + 1] + Rci[r * 3 + 2] * s.rot_end[c * 3 + 2];   // Rci * Rwi^T
+    Pcw[r] = -(Rcw[r * 3] * s.pos_end[0] + Rcw[r * 3 + 1] * s.pos_end[1] + Rcw[r * 3 + 2] * s.pos_end[2]) + Pci[r];
+  }
+  R_f_w_new = Rcw; t_f_w_new = Pcw;
+}
+
 void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg) {
   if (feat_map.empty()) return;                                                   // reference src/vio.cpp:354
   SubSparseMap &sm = *visual_submap;                                              // visual_submap->reset(), vio.cpp:359
@@ -556,7 +578,8 @@ void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::ve
   out.cell_point = cell.data(); out.cell_dist = map_dist.data(); out.cell_obs = cobs.data(); out.cand_cell = cand_cell.data();
   out.tail.accepted = acc.data(); out.tail.search_level = sl.data(); out.tail.error = err.data();
   int32_t n_cand = 0, n_acc = 0;
-  dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, pgw.data(), (int32_t)pg.size(), &sc, &rc, &out, &n_cand, &n_acc));
+  if (pg_from_map_update_) dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, nullptr, LIVO2_PG_FROM_MAP_UPDATE, &sc, &rc, &out, &n_cand, &n_acc));
+  else dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, pgw.data(), (int32_t)pg.size(), &sc, &rc, &out, &n_cand, &n_acc));
   for (int i = 0; i < n_cand; i++) {
     const int c = cand_cell[i];
     VisualPoint *pt = mirror_[cell[c]]; Feature *ref_ftr = obs_mirror_[cobs[c]];

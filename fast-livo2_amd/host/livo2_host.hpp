@@ -280,6 +280,8 @@ public:
   void setImuToLidarExtrinsic(const V3D &transl, const M3D &rot) { extT = transl; extR = rot; }      // reference src/vio.cpp:27-31
   void setLidarToCameraExtrinsic(const M3D &R, const V3D &P) { Rcl = R; Pcl = P; }                     // reference src/vio.cpp:33-37
   void computeJacobianAndUpdateEKF(const GrayImage &img);                                              // reference src/vio.cpp:784-802
+  // Rcw / Pcw and new_frame_->T_f_w_ from a state (processFrame calls it with *state before the retrieval, vio.cpp:1799-1800)  reference src/vio.cpp:1690-1697
+  void updateFrameState(const StatesGroup &s);
 
   // Tail of retrieveFromVisualSparseMap (reference src/vio.cpp:698-767) for the points the host-side selection kept: warp, search level,
   // patches, gates on the device; fills visual_submap (voxel_points, search_levels, errors, inv_expo_list) and total_points, and leaves
@@ -301,6 +303,12 @@ public:
   // Fills visual_submap (voxel_points, search_levels, errors, inv_expo_list), map_dist and total_points; the survivors stay resident as the frame
   // of the next computeJacobianAndUpdateEKF.  feat_map_dirty_ must be set whenever feat_map, an obs_ list, a normal or a ref_patch changed on the host.
   void retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg);
+  // pg_from_map_update_: `pg` is ignored and the scan's posterior world points are read where VoxelMapManager::UpdateVoxelMap[FromPosterior] (same Device) left
+  // them on the GPU (LIVMapper.cpp:413-426 `_pv_list`, :306) — the lean form: pv_list_ never exists on the host.
+  bool pg_from_map_update_ = false;
+  // mirror feat_map (+ observations, reference images) on the device now instead of inside the next retrieveFromVisualSparseMap (the cost of a visual-map change,
+  // which the reference's map maintenance — out of scope — causes once per frame)
+  void syncFeatMap(const GrayImage &img) { mirrorFeatMap(true, &img); }
 
 private:
   Device &dev_;

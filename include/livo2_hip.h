@@ -208,6 +208,9 @@ int livo2_map_tree_update(livo2_ctx *ctx, const double *point_w, const double *v
  * StateEstimation and UpdateVoxelMap (src/LIVMapper.cpp:413-423): point_w = float32(R (extR p + extT) + t), var = (R extR) body_cov (R extR)^T +
  * [p_i]x P_rr [p_i]x^T + P_tt.  Nothing crosses PCIe but the state. */
 int livo2_map_tree_update_from_scan(livo2_ctx *ctx, const livo2_state *state, const livo2_lidar_cfg *cfg, int32_t build);
+/* pv_list_[i].point_w ([n][3]) / .var ([n][9]) as the last livo2_map_tree_update[_from_scan] consumed them (the reference keeps them: `_pv_list =
+ * voxelmap_manager->pv_list_`, LIVMapper.cpp:426, read by handleVIO :306 and the publishers); either pointer may be NULL.  *n receives the point count. */
+int livo2_map_tree_read_pv(livo2_ctx *ctx, double *point_w, double *var, int32_t capacity, int32_t *n);
 /* counts[8]: nodes, temp points reserved, plane rows, candidate records reserved, (0), error bits of the last update, roots touched by it, root voxels */
 int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts);
 /* Export as a flat map (same arrays as livo2_map_view; caller buffers sized from livo2_map_tree_stats: roots = counts[7], nodes = counts[0],
@@ -470,6 +473,9 @@ typedef struct livo2_retrieve_chain_out {
   livo2_retrieve_out tail;
   int32_t *sub_point, *sub_obs;
 } livo2_retrieve_chain_out;
+/* pg_point_w = NULL with n_pg = LIVO2_PG_FROM_MAP_UPDATE: `pg` is the pv_list_ the last livo2_map_tree_update[_from_scan] of this scan consumed — the scan's world
+ * points at the LIO posterior, which is what the reference passes (LIVMapper.cpp:413-426 `_pv_list`, handed to processFrame at :306); they never leave the device. */
+#define LIVO2_PG_FROM_MAP_UPDATE (-1)
 int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride, const double *pg_point_w, int32_t n_pg,
                                    const livo2_select_cfg *sel, const livo2_retrieve_cfg *cfg, livo2_retrieve_chain_out *out, int32_t *n_candidates,
                                    int32_t *n_accepted);

@@ -369,8 +369,10 @@ def lidar_scenario(seed=1, n_points=10000, room=(20.0, 20.0, 6.0), n_boxes=8, fu
 def frame_sequence(n_frames, seed0=1000, n_raw=24000, room=(20.0, 20.0, 6.0), n_boxes=8, full_sphere=False, map_rays_factor=12, downsample=0.1, n_patches=350,
                    max_points=None, map_points=None):
     """F distinct frames against one VoxelMap — frame f (seed seed0 + f) has its own sensor pose (a walk around the map pose), its own noisy scan of
-    n_raw rays through the voxel-grid filter, its own perturbed prior, and its own image / visual sub-map.  Returns (fmap, cfg dict, extR, extT, frames) with
-    frames[f] = dict(xyz float32 [n][3], R_prior, t_prior, P, vs = VisualScenario)."""
+    n_raw rays through the voxel-grid filter, its own perturbed prior, and its own image / visual sub-map.  ONE scene per frame: the image and the sub-map are
+    generated at the frame's TRUE sensor pose (the photometric optimum is the pose the scan was taken from), so the visual update can start from the LiDAR
+    posterior as in the reference (LIVMapper.cpp:135-136, 371; vio.cpp:1799-1810), and the frame's prior carries the exposure prior.  Returns
+    (fmap, cfg dict, extR, extT, frames) with frames[f] = dict(xyz float32 [n][3], R_prior, t_prior, P, vs = VisualScenario, R_true, t_true)."""
     rng = np.random.default_rng(seed0 - 1)
     c = dict(AVIA["lio"])
     extR, extT = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy()
@@ -392,8 +394,9 @@ def frame_sequence(n_frames, seed0=1000, n_raw=24000, room=(20.0, 20.0, 6.0), n_
             xyz = voxel_grid_downsample(xyz, downsample)
         if max_points and len(xyz) > max_points:
             xyz = xyz[np.sort(r.permutation(len(xyz))[:max_points])]
-        vs = visual_scenario(seed=seed0 + f, n_patches=n_patches)
-        frames.append(dict(xyz=np.ascontiguousarray(xyz, np.float32), R_prior=Rf @ so3_exp(r.normal(0, np.deg2rad(0.5), 3)), t_prior=tf + r.normal(0, 0.03, 3), P=prior_cov(r), vs=vs))
+        vs = visual_scenario(seed=seed0 + f, n_patches=n_patches, R_true=Rf, t_true=tf)
+        frames.append(dict(xyz=np.ascontiguousarray(xyz, np.float32), R_prior=Rf @ so3_exp(r.normal(0, np.deg2rad(0.5), 3)), t_prior=tf + r.normal(0, 0.03, 3), P=prior_cov(r), vs=vs,
+                           R_true=Rf, t_true=tf))
     return fmap, c, extR, extT, frames
 
 
@@ -666,14 +669,17 @@ def feat_map_key_np(pos):
     return loc.astype(np.int64)
 
 
-def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17):
+def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scene=None, R0=None, t0=None):
+    """scene / R0 / t0: take the visual points and the scan from THIS room at THIS sensor pose (scenarios/live_inputs.py: the one-scene live chain) instead of a
+    room of the scenario's own."""
     rng = np.random.default_rng(seed)
     cam = dict(AVIA["cam"])
     extR, extT, Rcl, Pcl = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy(), AVIA["Rcl"].copy(), AVIA["Pcl"].copy()
     c = dict(AVIA["lio"])
-    scene = make_room(rng, (20.0, 20.0, 6.0), 8)
-    R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
-    t0 = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+    if scene is None:
+        scene = make_room(rng, (20.0, 20.0, 6.0), 8)
+        R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
+        t0 = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
     xyz = lidar_scan(rng, scene, R0, t0, extR, extT, n_pg + 3 * n_vis, c["dept_err"], c["beam_err"], AVIA["blind"], False).astype(np.float64)
     pw = (xyz @ extR.T + extT) @ R0.T + t0
     pg = pw[:n_pg].astype(np.float32).astype(np.float64)            # point_w comes from a float32 cloud
@@ -720,12 +726,12 @@ class RetrieveChainScenario:
 
 
 def retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=20000, L=4, grid_n_height=17, normal_en=True, ncc_en=False, ncc_thre=0.5, outlier_threshold=1000.0,
-                            max_obs=6):
+                            max_obs=6, scene=None, R0=None, t0=None):
     """Visual points of select_scenario, each observed by 1..max_obs features made in a handful of earlier frames: frames 0-3 stand close to the
     current pose and show the current texture (their patches warp almost identically and pass the gates), frame 4 is a close-up with another
     texture, frame 5 looks at the scene from the side (more than 60 degrees off: getCloseViewObs rejects it).  A share of points carries two
     observations of ONE frame (same id_), only same-id observations, a preset ref_patch, or an uninitialised normal."""
-    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height)
+    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height, scene=scene, R0=R0, t0=t0)
     rng = np.random.default_rng(seed + 1000)
     cam = base.cam
     W, H = cam["width"], cam["height"]

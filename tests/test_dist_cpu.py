@@ -78,6 +78,9 @@ class _FakeCtx:
 
     def _state(self, prior, salt):
         st = _Obj()
+        if hasattr(prior, "rot"):                    # a posterior handed on as the next prior (the visual update starts from the LiDAR posterior)
+            p = _Obj(); p.R, p.t, p.P, p.inv_expo = np.array(prior.rot).reshape(3, 3), np.array(prior.pos), np.array(prior.cov).reshape(19, 19), prior.inv_expo
+            prior = p
         st.rot = list((prior.R + salt).ravel()); st.pos = list(prior.t + salt); st.inv_expo = prior.inv_expo
         st.vel = [salt, 0.0, 0.0]; st.bg = [0.0] * 3; st.ba = [0.0] * 3; st.grav = [0.0, 0.0, -9.81]; st.cov = list((prior.P * (1.0 + salt)).ravel())
         return st

@@ -184,8 +184,8 @@ def _live_chain_leg(extra, sizes=("avia", "c4")):
     out = {}
     for size in sizes:
         try:
-            d = os.path.join(tempfile.gettempdir(), f"livo2_live_{size}_v1")
-            if not os.path.exists(os.path.join(d, "chain_obs_patch.bin")):
+            d = os.path.join(tempfile.gettempdir(), f"livo2_live_{size}_v2")
+            if not os.path.exists(os.path.join(d, "chain_cfg.bin")):
                 info = live_inputs.write_live_dir(d, live_inputs.make_live(**live_inputs.SIZES[size]))
             else:
                 info = {}
@@ -193,17 +193,18 @@ def _live_chain_leg(extra, sizes=("avia", "c4")):
             for mode in ("full", "lean"):
                 r = subprocess.run([exe, d] + (["lean"] if mode == "lean" else []), capture_output=True, text=True, timeout=600)
                 m = re.search(r"live_chain[^:]*: (\d+) frames timed, ([\d.]+) ms per frame \(StateEstimation ([\d.]+), UpdateVoxelMapFromPosterior ([\d.]+), retrieveFromVisualSparseMap ([\d.]+), "
-                              r"computeJacobianAndUpdateEKF ([\d.]+)\); mean scan ([\d.]+) points, effct_feat_num_ ([\d.]+), sub-map ([\d.]+) patches", r.stdout)
+                              r"computeJacobianAndUpdateEKF ([\d.]+)\); mean scan ([\d.]+) points, effct_feat_num_ ([\d.]+), sub-map ([\d.]+) patches; syncFeatMap ([\d.]+) ms", r.stdout)
                 if r.returncode != 0 or not m:
                     res[mode] = {"error": (r.stderr or r.stdout)[-300:]}
                     continue
                 res[mode] = {"frames_timed": int(m.group(1)), "ms_per_frame": float(m.group(2)), "StateEstimation_ms": float(m.group(3)), "UpdateVoxelMapFromPosterior_ms": float(m.group(4)),
                              "retrieveFromVisualSparseMap_ms": float(m.group(5)), "computeJacobianAndUpdateEKF_ms": float(m.group(6)), "points_per_scan_mean": float(m.group(7)),
-                             "effct_feat_num": float(m.group(8)), "sub_map_patches": float(m.group(9))}
+                             "effct_feat_num": float(m.group(8)), "sub_map_patches": float(m.group(9)), "syncFeatMap_ms_outside_the_stages": float(m.group(10))}
             out[size] = res
         except Exception as exc:
             out[size] = {"error": repr(exc)}
-    out["def"] = ("fast-livo2_amd/host/live_chain: per frame the four shim calls of handleLIO + handleVIO back to back on std::vector containers (pageable; the scan is staged through the "
+    out["def"] = ("fast-livo2_amd/host/live_chain: ONE scene, the reference's data flow (VIO from the LIO posterior through the shared state, pg and T_f_w from that posterior, next frame "
+                  "from the VIO posterior and the updated map; checked against the oracle chain in tests/test_live_chain_gpu.py); per frame the four shim calls of handleLIO + handleVIO back to back on std::vector containers (pageable; the scan is staged through the "
                   "ctx's pinned buffer); 'full': StateEstimation also fills pv_list_ / ptpl_list_ / body_cov_list_ / cross_mat_list_ on the host (168 B per point D2H + ~900 B per point of "
                   "reference structs) as the reference does; 'lean' (VoxelMapManager::host_point_lists_ = false): those lists stay on the device, where their consumers run in "
                   "device_map_ mode; frame 0 (allocations, feat_map mirror) not timed; "
