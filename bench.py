@@ -166,29 +166,39 @@ def c4_frame(seed, n_points, n_patches):
     return sc, vs
 
 
-def c5_frames(n_frames, shape):
+def c5_frames(n_frames, shape, rank=0, barrier=None):
     """SURVEY 8(d) C5 frames (scenarios.synth.frame_sequence, seeds 1000 + f), cached like c4_frame.  shape "c1": avia-like 24 000-ray scans (~10 k points after the
-    0.1 m filter) + 350 patches; "c4": 200 000 post-filter points + 4 000 patches per frame against the C4-sized room."""
+    0.1 m filter) + 350 patches; "c4": 200 000 post-filter points + 4 000 patches per frame against the C4-sized room.  With several ranks only rank 0 generates
+    (barrier: the others wait for its file instead of generating the same sequence N times)."""
     import pickle
     from scenarios import synth
-    path = os.path.join(tempfile.gettempdir(), f"livo2_c5_{shape}_f{n_frames}_v1.pkl")
-    if os.path.exists(path):
+    path = os.path.join(tempfile.gettempdir(), f"livo2_c5_{shape}_f{n_frames}_v2.pkl")
+
+    def load():
         try:
             with open(path, "rb") as f:
                 return pickle.load(f)
         except Exception:
+            return None
+    seq = load() if os.path.exists(path) else None
+    if seq is None and rank == 0:
+        if shape == "c1":
+            seq = synth.frame_sequence(n_frames)
+        else:
+            seq = synth.frame_sequence(n_frames, n_raw=620000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_points=1600000, n_patches=4000, max_points=200000)
+        try:
+            tmp = path + f".{os.getpid()}"
+            with open(tmp, "wb") as f:
+                pickle.dump(seq, f, protocol=4)
+            os.replace(tmp, path)
+        except Exception:
             pass
-    if shape == "c1":
-        seq = synth.frame_sequence(n_frames)
-    else:
-        seq = synth.frame_sequence(n_frames, n_raw=620000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_points=1600000, n_patches=4000, max_points=200000)
-    try:
-        tmp = path + f".{os.getpid()}"
-        with open(tmp, "wb") as f:
-            pickle.dump(seq, f, protocol=4)
-        os.replace(tmp, path)
-    except Exception:
-        pass
+    if barrier is not None:
+        barrier()
+    if seq is None:
+        seq = load()
+        if seq is None:
+            raise RuntimeError("c5_frames: rank 0 did not leave " + path)
     return seq
 
 
@@ -200,12 +210,40 @@ class _Sc:            # what fast-livo2_amd.configs.lidar_cfg reads
 C5_CONTEXTS = 3
 
 
-def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_frames, shape, barrier, local_device=0):
-    """Batched distinct frames round-robin over the ranks, H2D of every scan / image / sub-map and D2H of every result inside the timed region; the per-frame
-    records are gathered on every rank (RCCL all_gather) and rank 0 re-runs the first frame of every other rank to check the gathered copy bit for bit.
-    Timed twice: one context per GPU (host-synchronous calls, nothing overlaps) and C5_CONTEXTS contexts per GPU, one host thread each (transfers of one frame
-    overlap the updates of another); the records of the two passes must be identical."""
-    fmap, lio_cfg, extR, extT, frames = c5_frames(n_frames, shape)
+def pin_frames(frames, torch):
+    """the caller's frame buffers in page-locked memory (a driver node keeps its scan / image ring buffers pinned): hipMemcpyAsync from pageable memory is staged
+    synchronously by the runtime, which would serialise the three contexts' uploads"""
+    keep = []
+
+    def pin(a, dtype):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype))
+        if torch.cuda.is_available():                       # (the gloo test of this leg runs without a device)
+            t = t.pin_memory()
+        keep.append(t)
+        return t.numpy()
+    out = []
+    for f in frames:
+        vs = f["vs"]
+        g = dict(f, xyz=pin(f["xyz"], np.float32))
+        pv = type("PinnedSubMap", (), {})()
+        pv.__dict__.update(vs.__dict__)
+        pv.img, pv.pos, pv.warp_patch = pin(vs.img, np.uint8), pin(vs.pos, np.float64), pin(vs.warp_patch, np.float32)
+        pv.search_levels, pv.inv_expo_list = pin(vs.search_levels, np.int32), pin(vs.inv_expo_list, np.float64)
+        g["vs"] = pv
+        out.append(g)
+    return out, keep
+
+
+def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_distinct, per_rank, shape, barrier, torch, local_device=0):
+    """Batched distinct frames round-robin over the ranks (`per_rank` frames each; the list cycles through `n_distinct` generated frames when that is fewer), H2D of
+    every scan / image / sub-map and D2H of every result inside the timed region; the visual update of a frame starts from its LiDAR posterior
+    (fast-livo2_amd/frames.py::run_frame, checked against the oracle by tests/test_c5_gpu.py).  The per-frame records are gathered on every rank (RCCL all_gather, timed
+    on its own) and rank 0 re-runs the first frame of every other rank to check the gathered copy bit for bit.  Two passes, BOTH reported: one context per GPU
+    (host-synchronous calls, nothing overlaps) and C5_CONTEXTS contexts per GPU, one host thread each (transfers of one frame overlap the updates of another)."""
+    fmap, lio_cfg, extR, extT, distinct = c5_frames(n_distinct, shape, rank, barrier if world > 1 else None)
+    n_frames = per_rank * world
+    pinned, keep = pin_frames(distinct, torch)
+    frames = [pinned[f % len(pinned)] for f in range(n_frames)]
     cfg = cfgs.lidar_cfg(_Sc(lio_cfg, extR, extT)); vcfg = cfgs.visual_cfg(frames[0]["vs"], mp_proc_num=4)
     ctx.upload_map(fmap)
     more = [livo2.Context(local_device) for _ in range(C5_CONTEXTS - 1)]
@@ -223,9 +261,14 @@ def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_frames, sh
                 c.synchronize()
             dt_local = time.perf_counter() - t0
             dt = frames_mod.max_over_ranks(dt_local, dist, device=device)
+            tg = time.perf_counter()
             allrec = frames_mod.gather_results(recs, len(frames), dist, device=device)
+            if device == "cuda":
+                torch.cuda.synchronize()
+            gather_s = time.perf_counter() - tg
             ev = frames_mod.gather_results(np.array([[float(evals)]]), world, dist, device=device)
-            out[name] = (dt, allrec, float(ev.sum()))
+            per_rank_fps = frames_mod.gather_results(np.array([[len(recs) / dt_local]]), world, dist, device=device)[:, 0]
+            out[name] = (dt, allrec, float(ev.sum()), gather_s, per_rank_fps.tolist())
         check = None
         if rank == 0:
             bad = 0
@@ -240,17 +283,18 @@ def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_frames, sh
             c.close()
     pts = [len(f["xyz"]) for f in frames]
     h2d = float(np.mean([f["xyz"].nbytes + f["vs"].img.nbytes + f["vs"].pos.nbytes + f["vs"].warp_patch.nbytes + 12 * len(f["vs"].pos) for f in frames]))
-    dt1, _, ev1 = out["one_context"]; dtk, _, evk = out["pipelined"]
-    best, evb, nctx = (dtk, evk, C5_CONTEXTS) if dtk <= dt1 else (dt1, ev1, 1)          # small frames are bound by the host's call rate: more contexts do not help them
-    return {"shape": shape, "frames": len(frames), "frames_per_s": len(frames) / best, "ms_per_frame_per_gpu": 1e3 * best / (len(frames) / world), "evals_per_s": evb / best,
-            "contexts_per_gpu": nctx, "frames_per_s_one_context": len(frames) / dt1, "frames_per_s_%d_contexts" % C5_CONTEXTS: len(frames) / dtk,
-            "ms_per_frame_per_gpu_one_context": 1e3 * dt1 / (len(frames) / world), "evals_per_s_one_context": ev1 / dt1,
+    dt1, _, ev1, g1, fps1 = out["one_context"]; dtk, _, evk, gk, fpsk = out["pipelined"]
+    return {"shape": shape, "frames": len(frames), "frames_per_rank": per_rank, "distinct_frames": len(distinct),
+            "frames_per_s": len(frames) / dtk, "contexts_per_gpu": C5_CONTEXTS, "ms_per_frame_per_gpu": 1e3 * dtk / per_rank, "evals_per_s": evk / dtk,
+            "frames_per_s_per_rank": fpsk, "all_gather_ms": 1e3 * gk,
+            "frames_per_s_one_context": len(frames) / dt1, "ms_per_frame_per_gpu_one_context": 1e3 * dt1 / per_rank, "evals_per_s_one_context": ev1 / dt1,
+            "frames_per_s_per_rank_one_context": fps1, "all_gather_ms_one_context": 1e3 * g1,
             "points_per_frame_mean": float(np.mean(pts)), "patches_per_frame": int(len(frames[0]["vs"].pos)), "h2d_bytes_per_frame": h2d,
-            "d2h_bytes_per_frame": 8 * frames_mod.RESULT_DOUBLES + 2 * 8 * 400, "gather": "all_gather of the per-frame records (%d doubles each)" % frames_mod.RESULT_DOUBLES,
+            "d2h_bytes_per_frame": 8 * frames_mod.RESULT_DOUBLES + 2 * 8 * 400, "gather": "all_gather of the per-frame records (%d doubles each), outside the timed region, timed as all_gather_ms" % frames_mod.RESULT_DOUBLES,
             "gathered_copy_check": check,
-            "def": "F distinct frames (seeds 1000+f) round-robin over the ranks; per frame: scan H2D + Morton sort + body covariance, full LiDAR update from the frame's prior, image + "
-                   "sub-map H2D, full visual update, results D2H; calls from Python, caller memory pageable (the scan goes through the ctx's pinned staging); map resident. "
-                   "both passes are timed: a single context, host-synchronous, and %d contexts per GPU (one host thread and one stream each); frames_per_s is the faster one (contexts_per_gpu says which)" % C5_CONTEXTS}
+            "def": "per_rank frames per rank (seeds 1000 + f) round-robin over the ranks; per frame: scan H2D + Morton sort + body covariance, full LiDAR update from the frame's prior, image + "
+                   "sub-map H2D, full visual update from the LiDAR posterior, results D2H; calls from Python, caller buffers pinned; map resident. frames_per_s = the %d-contexts-per-GPU pass "
+                   "(one host thread and one stream each); frames_per_s_one_context = a single host-synchronous context; both passes always reported, records must be identical" % C5_CONTEXTS}
 
 
 def frame_priors(livo2, synth, sc, vs, F, seed):
@@ -513,7 +557,7 @@ def main():
     ap.add_argument("--dist-selftest", action="store_true", help="run only the rank logic (gloo, no GPU)")
     ap.add_argument("--emit-selftest", action="store_true", help="run only the emission of the result line (no GPU)")
     ap.add_argument("--pre-warm-s", type=float, default=1.0, help="seconds of the same step run untimed BEFORE the --warmup steps (a fresh box starts at idle clocks); 0 disables; reported as pre_warm_s")
-    ap.add_argument("--c5-frames", type=int, default=64, help="distinct frames of the C5 leg (extra.c5, every --gpus N; 0 disables)")
+    ap.add_argument("--c5-frames", type=int, default=64, help="C1-shaped frames of the C5 leg in all (extra.c5, every --gpus N; at least 8 per rank; 0 disables); the C4-shaped leg runs 8 frames per rank (12 on one GPU)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.frames_per_step < 1:
         raise SystemExit("bench.py: bad --gpus / --steps / --warmup / --frames-per-step")
@@ -603,9 +647,10 @@ def main():
              "per_rank_evals": per_rank[:, 0].tolist()}
     if args.c5_frames > 0 and not args.no_extra:
         try:
-            c5 = {"c1_shaped": c5_leg(ctx, livo2, frames, H, dist, device, rank, world, args.c5_frames, "c1", barrier, local_device=local_rank)}
-            if world == 1 or args.c5_frames >= 8 * world:
-                c5["c4_shaped"] = c5_leg(ctx, livo2, frames, H, dist, device, rank, world, 12 if world == 1 else 2 * world, "c4", barrier, local_device=local_rank)
+            per_rank_c1 = max(8, args.c5_frames // world)
+            c5 = {"c1_shaped": c5_leg(ctx, livo2, frames, H, dist, device, rank, world, min(per_rank_c1 * world, 64), per_rank_c1, "c1", barrier, torch, local_device=local_rank)}
+            per_rank_c4 = 12 if world == 1 else 8
+            c5["c4_shaped"] = c5_leg(ctx, livo2, frames, H, dist, device, rank, world, min(per_rank_c4 * world, 32), per_rank_c4, "c4", barrier, torch, local_device=local_rank)
             extra["c5"] = c5
         except Exception as exc:
             extra["c5"] = {"error": repr(exc)}

@@ -1195,46 +1195,48 @@ int map_tree_grow(livo2_ctx *ctx, const int32_t *c) {
   MapTreeArgs &m = ctx->mt;
   int rc;
   const auto over = [](long long used, long long cap) { return (double)used > MT_GROW_AT * (double)cap; };
-  // candidate ranges: re-pack first
+  // candidate ranges: re-pack first (every root re-emits its list into an empty pool), and only if the PACKED lists still fill more than MT_GROW_AT of the pool, or do
+  // not fit at all, grow it.  A pool that cannot hold the lists after four doublings leaves MTE_CAND set: the caller fails the frame instead of running residuals
+  // against slots that point into a pool nobody filled (advisor, round 3).
   if (over(c[MTC_CAND], m.cap_cand)) {
-    HIPCHK(hipMemsetAsync(m.counters + MTC_CAND, 0, 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
-    MapTreeArgs a = m;
-    hipLaunchKernelGGL(k_mt_all_roots_dirty, dim3((m.mask + 256) / 256), dim3(256), 0, ctx->stream, a);
-    int32_t nd = 0;
-    HIPCHK(hipMemcpyAsync(&nd, m.counters + MTC_DIRTY, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    // worst case of the re-emit: every list takes max(16, 2 count) again — make room for twice what was in use before packing
-    if (2LL * c[MTC_CAND] > m.cap_cand) {
-      const int nc = (int)std::min<long long>(4LL * c[MTC_CAND], INT32_MAX / 64);
-      if ((rc = grow_array(ctx, ctx->d_cand, 0, (size_t)nc * PLANE_HOT_DOUBLES, false))) return rc;
-      if ((rc = grow_array(ctx, ctx->d_cand_aux, 0, (size_t)nc, false))) return rc;
-      m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
-      a = m;
-    }
-    for (int attempt = 0; attempt < 4 && nd > 0; attempt++) {
-      hipLaunchKernelGGL(k_mt_emit, dim3(((size_t)nd * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a);
-      int32_t err = 0;
-      HIPCHK(hipMemcpyAsync(&err, m.counters + MTC_ERROR, 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      if (!(err & MTE_CAND)) break;
-      // the re-packed lists did not fit either: double the pool and emit again (every root is still queued; ranges handed out by the failed pass are dropped)
-      const int nc = (int)std::min<long long>(2LL * m.cap_cand, INT32_MAX / 64);
-      if ((rc = grow_array(ctx, ctx->d_cand, 0, (size_t)nc * PLANE_HOT_DOUBLES, false))) return rc;
-      if ((rc = grow_array(ctx, ctx->d_cand_aux, 0, (size_t)nc, false))) return rc;
-      m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
-      err &= ~MTE_CAND;
-      HIPCHK(hipMemcpyAsync(m.counters + MTC_ERROR, &err, 4, hipMemcpyHostToDevice, ctx->stream));
+    int32_t err = 0, used = 0;
+    for (int attempt = 0; attempt < 5; attempt++) {
+      if (attempt > 0) {                                                  // the packed lists did not fit: double the pool (nothing to preserve: every list is re-emitted)
+        const int nc = (int)std::min<long long>(2LL * m.cap_cand, INT32_MAX / 64);
+        if (nc <= m.cap_cand) break;
+        if ((rc = grow_array(ctx, ctx->d_cand, 0, (size_t)nc * PLANE_HOT_DOUBLES, false))) return rc;
+        if ((rc = grow_array(ctx, ctx->d_cand_aux, 0, (size_t)nc, false))) return rc;
+        m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
+        err &= ~MTE_CAND;
+        HIPCHK(hipMemcpyAsync(m.counters + MTC_ERROR, &err, 4, hipMemcpyHostToDevice, ctx->stream));
+      }
       HIPCHK(hipMemsetAsync(m.counters + MTC_CAND, 0, 4, ctx->stream));
       HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
-      a = m;
+      MapTreeArgs a = m;
       hipLaunchKernelGGL(k_mt_all_roots_dirty, dim3((m.mask + 256) / 256), dim3(256), 0, ctx->stream, a);
+      int32_t nd = 0;
+      HIPCHK(hipMemcpyAsync(&nd, m.counters + MTC_DIRTY, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (nd > 0) hipLaunchKernelGGL(k_mt_emit, dim3(((size_t)nd * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a);
+      HIPCHK(hipMemcpyAsync(&err, m.counters + MTC_ERROR, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(&used, m.counters + MTC_CAND, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (!(err & MTE_CAND)) break;
     }
     HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     set_map_view(ctx);
     ctx->mt_grow_events++;
+    if (err & MTE_CAND) return fail(ctx, LIVO2_ERR_RANGE, "device map tree: the candidate lists do not fit the candidate pool even after re-packing and four doublings");
+    if (over(used, m.cap_cand)) {                                         // packed and still more than MT_GROW_AT full: double, keeping the lists
+      const int nc = (int)std::min<long long>(2LL * m.cap_cand, INT32_MAX / 64);
+      if (nc > m.cap_cand) {
+        if ((rc = grow_array(ctx, ctx->d_cand, (size_t)used * PLANE_HOT_DOUBLES, (size_t)nc * PLANE_HOT_DOUBLES, false))) return rc;
+        if ((rc = grow_array(ctx, ctx->d_cand_aux, (size_t)used, (size_t)nc, false))) return rc;
+        m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
+        set_map_view(ctx);
+      }
+    }
   }
   const bool gn = over(c[MTC_NODES], m.cap_nodes), gp = over(c[MTC_POINTS], m.cap_points), gl = over(c[MTC_PLANES], m.cap_planes);
   if (gn || gp || gl) {
@@ -1280,8 +1282,26 @@ int map_tree_finish(livo2_ctx *ctx) {
   ctx->mt_kernel_us = 1e3 * ms;
   if (!c[MTC_ERROR]) { const int rc = map_tree_grow(ctx, c); if (rc) return rc; }
   if (c[MTC_ERROR]) {
-    char msg[200];                                            // (fail() copies it into the ctx's own string)
-    std::snprintf(msg, sizeof(msg), "device map tree: capacity / range error bits 0x%x (1 nodes, 2 points, 4 planes, 8 candidate lists, 16 hash table, 32 voxel key range, 64 node region)", c[MTC_ERROR]);
+    // A frame that exhausted a pool: the allocators rolled their counters back, so the pool is still (nearly) full and every later frame would fail the same way
+    // (advisor, round 3).  Double every pool whose bit is set NOW, clear those bits, and report this frame as dropped: the tree stays usable for the next one.
+    const int32_t cap_bits = c[MTC_ERROR] & (MTE_NODES | MTE_POINTS | MTE_PLANES | MTE_CAND);
+    int grown = 0;
+    if (cap_bits) {
+      int32_t forced[MTC_COUNT];
+      std::memcpy(forced, c, sizeof(forced));
+      if (cap_bits & MTE_NODES) forced[MTC_NODES] = ctx->mt.cap_nodes;
+      if (cap_bits & MTE_POINTS) forced[MTC_POINTS] = ctx->mt.cap_points;
+      if (cap_bits & MTE_PLANES) forced[MTC_PLANES] = ctx->mt.cap_planes;
+      if (cap_bits & MTE_CAND) forced[MTC_CAND] = ctx->mt.cap_cand;
+      const int32_t rest = c[MTC_ERROR] & ~cap_bits;
+      HIPCHK(hipMemcpyAsync(ctx->mt.counters + MTC_ERROR, &rest, 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      const int rc = map_tree_grow(ctx, forced);
+      grown = rc == LIVO2_OK;
+    }
+    char msg[320];                                            // (fail() copies it into the ctx's own string)
+    std::snprintf(msg, sizeof(msg), "device map tree: capacity / range error bits 0x%x (1 nodes, 2 points, 4 planes, 8 candidate lists, 16 hash table, 32 voxel key range, 64 node region)%s",
+                  c[MTC_ERROR], grown ? "; this frame's update is incomplete, the exhausted pools were doubled for the next one" : "");
     return fail(ctx, LIVO2_ERR_RANGE, msg);
   }
   return LIVO2_OK;

@@ -147,3 +147,59 @@ def test_c5_frames_sharded_and_gathered_world2():
     for rank, allrec, ev in outs:
         assert np.array_equal(np.array(allrec), single)          # every rank holds the single-rank results, frame by frame, bit for bit
         assert ev == ev1
+
+
+# ---- bench.py's c5 leg itself at world size 2 (gloo): rank 0 generates the frames and the others wait for its file, frames cycle through the distinct ones,
+# ---- per-rank rates and the all-gather are reported, the gathered copy is checked on rank 0 — with stand-in contexts, no GPU
+class _FakeCtx2(_FakeCtx):
+    def __init__(self, device=0):
+        pass
+
+    def upload_map(self, fm):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def _bench_c5_worker(rank, world, port, cache_dir, q):
+    sys.path.insert(0, ROOT)
+    os.environ["TMPDIR"] = cache_dir
+    import tempfile
+    tempfile.tempdir = cache_dir
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    frames = importlib.import_module("fast-livo2_amd.frames")
+    cfgs = importlib.import_module("fast-livo2_amd.configs")
+    fake = type("FakeLivo2", (), {"Context": _FakeCtx2, "State": _FakeState})
+    out = bench.c5_leg(_FakeCtx2(), fake, frames, cfgs, dist, "cpu", rank, world, 3, 4, "c1", dist.barrier, torch)
+    dist.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_bench_c5_leg_world2(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bench_c5_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    outs = dict(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len([f for f in os.listdir(tmp_path) if f.startswith("livo2_c5_c1_f3")]) == 1          # generated once (rank 0), read by rank 1
+    o = outs[0]
+    assert o["frames"] == 8 and o["frames_per_rank"] == 4 and o["distinct_frames"] == 3
+    assert len(o["frames_per_s_per_rank"]) == 2 and len(o["frames_per_s_per_rank_one_context"]) == 2
+    assert o["all_gather_ms"] >= 0 and o["frames_per_s"] > 0 and o["frames_per_s_one_context"] > 0
+    assert o["gathered_copy_check"] == {"frames_recomputed_on_rank0": 2, "mismatches": 0, "pipelined_records_equal_one_context_records": True}
+    assert outs[1]["gathered_copy_check"] is None

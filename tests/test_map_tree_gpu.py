@@ -230,3 +230,34 @@ def test_soak_random_walk_with_sliding_grows_recycles_and_matches_oracle(ctx, or
     # no leak: while the box moves at constant speed through similar clutter the bump counters stop climbing (recycling covers the demand)
     late = np.array(marks[120:160], float)
     assert late[-1, 0] <= 1.25 * late[0, 0] and late[-1, 1] <= 1.25 * late[0, 1] and late[-1, 2] <= 1.25 * late[0, 2], (late[0], late[-1])
+
+
+def test_a_frame_that_exhausts_a_pool_is_dropped_and_the_pools_grow_for_the_next_one(livo2, orc):
+    """advisor (round 3): after a capacity error the allocators roll back, the pool stays full, and — because growth only ran on error-free frames — every later frame
+    failed the same way.  Now the exhausted pools are doubled on the failing call itself: that frame is reported (LIVO2_ERR_RANGE, 'doubled'), the next ones run,
+    and a LiDAR update reads the structure."""
+    c, cloud, R0, t0, P0, extR, extT = _scene(23)
+    _, (pw0, var0) = cloud(6000, R0, t0)
+    ctx = livo2.Context(0)
+    try:
+        ctx.map_tree_create(c, max_roots=20000, max_nodes=6000, max_planes=4000, max_points=400000, max_cand=64)
+        ctx.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+        before = ctx.counter("map_tree_grow_events")
+        dropped = 0
+        for k in range(1, 7):                                            # a walk into unseen space: every frame brings new root voxels
+            _, (pw, var) = cloud(30000, R0, t0 + np.array([0.8 * k, 0.3 * k, 0.0]))
+            for attempt in range(6):
+                try:
+                    ctx.map_tree_update(pw, var.reshape(-1, 9))
+                    break
+                except livo2.Livo2Error as exc:
+                    assert exc.code == livo2.abi.ERR_RANGE and "doubled" in str(exc), str(exc)
+                    dropped += 1
+            else:
+                raise AssertionError("the tree never recovered from the capacity error")
+        st = ctx.map_tree_stats()
+        assert st["error"] == 0 and st["roots"] > 1000
+        assert ctx.counter("map_tree_grow_events") > before
+        print("dropped frames:", dropped, st)
+    finally:
+        ctx.close()
