@@ -196,6 +196,8 @@ SIGNATURES = {
     "livo2_ctx_kernel_timing": (C.c_int, [_CTX, C.c_int]),
     "livo2_ctx_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_int32]),
     "livo2_ctx_get_counter": (C.c_int, [_CTX, C.c_char_p, _P(C.c_int64)]),
+    "livo2_host_alloc_pinned": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
+    "livo2_host_free_pinned": (None, [C.c_void_p]),
     "livo2_debug_redzone_check": (C.c_int, [_CTX, _P(C.c_int32), _P(C.c_int64)]),
     "livo2_debug_redzone_poke": (C.c_int, [_CTX, C.c_int64]),
     "livo2_ctx_kernel_timing_read": (C.c_int, [_CTX, C.c_int, _P(C.c_double), _P(C.c_int64), C.c_int]),

@@ -98,6 +98,7 @@ struct livo2_ctx {
   float *d_xyz_aos = nullptr, *d_x = nullptr, *d_y = nullptr, *d_z = nullptr; double *d_cb = nullptr;
   uint32_t *d_keys = nullptr, *d_keys2 = nullptr; int32_t *d_idx = nullptr, *d_perm = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_partials = nullptr; size_t partials_cap = 0;
+  double *d_bcov_rows = nullptr; size_t bcov_rows_cap = 0;      // body_cov_list_ as 3x3 rows in caller order (fetch_lidar_points)
   int32_t *d_match = nullptr, *d_normal_plane = nullptr; float *d_dis = nullptr, *d_pw = nullptr; double *d_var = nullptr, *d_rinv = nullptr, *d_hrow = nullptr;
   int out_cap = 0;
   livo2_lidar_points want_l{};              // which per-point arrays the last enqueue produced
@@ -418,6 +419,15 @@ LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
 // Per-point outputs (pv_list_ / ptpl_list_ / body_cov_list_ members) come back through ONE pinned staging block owned by the ctx: every selected
 // array is copied D2H into it asynchronously (pinned memory: DMA at link rate, no hidden pageable bounce buffer per call), one synchronisation, then a host copy
 // into the caller's arrays.
+// body_cov_list_ for the caller: the scan keeps the symmetric six of calcBodyCov (voxel_map.cpp:15-34) in sorted order; this writes full 3x3 matrices in the caller's order
+__global__ void k_body_cov_rows(const double *__restrict__ cb, const int32_t *__restrict__ perm, int n, double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = t / 9, e = t % 9;
+  if (j >= n) return;
+  const int r = e / 3, c = e % 3, u = r < c ? r : c, v = r < c ? c : r;
+  out[(size_t)perm[j] * 9 + e] = cb[(size_t)(u * 3 - (u * (u - 1)) / 2 + (v - u)) * n + j];
+}
+
 int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   if (!p) return LIVO2_OK;
   const livo2_lidar_points &w = ctx->want_l;
@@ -426,27 +436,21 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
       (p->var && !w.var) || (p->r_inv && !w.r_inv) || (p->h_row && !w.h_row))
     return fail(ctx, LIVO2_ERR_INVALID, "per-point array requested at fetch was not selected at enqueue");
   struct Item { void *dst; const void *src; size_t bytes; };
+  if (p->body_cov && n > 0) {
+    int rc = ensure(ctx, ctx->d_bcov_rows, ctx->bcov_rows_cap, n * 9); if (rc) return rc;
+    hipLaunchKernelGGL(k_body_cov_rows, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cb, ctx->d_perm, (int)n, ctx->d_bcov_rows);
+  }
   const Item items[] = {{p->match_plane, ctx->d_match, n * 4}, {p->dis_to_plane, ctx->d_dis, n * 4}, {p->point_w, ctx->d_pw, n * 12}, {p->normal_plane, ctx->d_normal_plane, n * 4},
-                        {p->var, ctx->d_var, n * 72}, {p->r_inv, ctx->d_rinv, n * 8}, {p->h_row, ctx->d_hrow, n * 48},
-                        {p->body_cov ? (void *)p->body_cov : nullptr, ctx->d_cb, 6 * n * 8}, {p->body_cov ? (void *)p->body_cov : nullptr, ctx->d_perm, n * 4}};
+                        {p->var, ctx->d_var, n * 72}, {p->r_inv, ctx->d_rinv, n * 8}, {p->h_row, ctx->d_hrow, n * 48}, {p->body_cov, ctx->d_bcov_rows, n * 72}};
+  constexpr int NITEMS = 8;
   size_t total = 0;
   for (const Item &it : items) if (it.dst) total += (it.bytes + 63) & ~(size_t)63;
   if (total == 0) return LIVO2_OK;
   if (total > ((size_t)8 << 20)) {
     // large outputs (C4: 168 B x 200 000 points = 34 MB): copy straight into the caller's arrays — the runtime pipelines a pageable D2H through its own pinned
     // chunks while it copies the previous chunk out, which a stage-everything-then-memcpy scheme does not (measured: 3.0 ms against 3.8 ms per C4 frame)
-    std::vector<double> cb; std::vector<int32_t> perm;
-    for (int k = 0; k < 7; k++) if (items[k].dst && items[k].bytes) HIPCHK(hipMemcpyAsync(items[k].dst, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (p->body_cov) {
-      cb.resize(6 * n); perm.resize(n);
-      HIPCHK(hipMemcpyAsync(cb.data(), ctx->d_cb, 6 * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(perm.data(), ctx->d_perm, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    for (int k = 0; k < NITEMS; k++) if (items[k].dst && items[k].bytes) HIPCHK(hipMemcpyAsync(items[k].dst, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (p->body_cov) {
-      const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-      for (size_t j = 0; j < n; j++) for (int e = 0; e < 9; e++) p->body_cov[(size_t)perm[j] * 9 + e] = cb[(size_t)map9[e] * n + j];
-    }
     if (!ctx->tree_mode) {
       if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
       if (p->normal_plane) for (size_t i = 0; i < n; i++) if (p->normal_plane[i] >= 0) p->normal_plane[i] = ctx->plane_orig[p->normal_plane[i]];
@@ -460,21 +464,15 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
     ctx->h_pts_cap = total + total / 4;
   }
   char *base = static_cast<char *>(ctx->h_pts);
-  size_t off = 0, offs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int k = 0; k < 9; k++) {
+  size_t off = 0, offs[NITEMS] = {};
+  for (int k = 0; k < NITEMS; k++) {
     if (!items[k].dst) continue;
     offs[k] = off;
     if (items[k].bytes) HIPCHK(hipMemcpyAsync(base + off, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
     off += (items[k].bytes + 63) & ~(size_t)63;
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < 7; k++) if (items[k].dst && items[k].bytes) std::memcpy(items[k].dst, base + offs[k], items[k].bytes);
-  if (p->body_cov) {          // body_cov_list_: the device keeps the symmetric 6 in sorted order; expand to 3x3 in caller order
-    const double *cb = reinterpret_cast<const double *>(base + offs[7]);
-    const int32_t *perm = reinterpret_cast<const int32_t *>(base + offs[8]);
-    const int map9[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-    for (size_t j = 0; j < n; j++) for (int e = 0; e < 9; e++) p->body_cov[(size_t)perm[j] * 9 + e] = cb[(size_t)map9[e] * n + j];
-  }
+  for (int k = 0; k < NITEMS; k++) if (items[k].dst && items[k].bytes) std::memcpy(items[k].dst, base + offs[k], items[k].bytes);
   // device plane numbering (Morton order) -> the caller's
   if (!ctx->tree_mode) {
     if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
@@ -646,7 +644,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost};
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_bcov_rows};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -670,6 +668,13 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
 
 const char *livo2_last_error(const livo2_ctx *ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
 void *livo2_ctx_stream(livo2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int livo2_host_alloc_pinned(size_t bytes, void **out) {
+  if (!out) return LIVO2_ERR_INVALID;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes ? bytes : 1) == hipSuccess ? LIVO2_OK : LIVO2_ERR_HIP;
+}
+void livo2_host_free_pinned(void *p) { if (p) { hipError_t e = hipHostFree(p); (void)e; } }
+
 int livo2_ctx_synchronize(livo2_ctx *ctx) { if (!ctx) return LIVO2_ERR_INVALID; HIPCHK(hipStreamSynchronize(ctx->stream)); return rz_gate(ctx); }
 
 // checker self-test: one 4-byte store at `byte_offset` relative to the END of the ctx's control block (negative: relative to its start)

@@ -350,12 +350,23 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   if (!scan_resident_) dev_.check(livo2_lidar_set_scan(dev_.ctx(), n ? &feats_down_body_[0].x : nullptr, n, &cfg));
   scan_resident_ = false;
 
-  std::vector<int32_t> match(n), normal_plane(n);
-  std::vector<float> dis(n), pw((size_t)n * 3);
-  std::vector<double> var((size_t)n * 9), bcov((size_t)n * 9);
+  // per-point outputs land in page-locked buffers the manager keeps (D2H at PCIe speed, no bounce through the runtime's staging)
+  int32_t *match = nullptr, *normal_plane = nullptr; float *dis = nullptr, *pw = nullptr; double *var = nullptr, *bcov = nullptr;
   livo2_lidar_points pts{};
-  pts.match_plane = match.data(); pts.dis_to_plane = dis.data(); pts.point_w = pw.data(); pts.normal_plane = normal_plane.data();
-  pts.var = var.data(); pts.body_cov = bcov.data();
+  if (host_point_lists_) {
+    const size_t nn = (size_t)std::max(n, 1);
+    const size_t bytes = nn * (4 + 4 + 4 + 12 + 72 + 72) + 6 * 64;
+    if (bytes > pin_bytes_) {
+      livo2_host_free_pinned(pin_); pin_ = nullptr; pin_bytes_ = 0;
+      dev_.check(livo2_host_alloc_pinned(bytes + bytes / 4, &pin_));
+      pin_bytes_ = bytes + bytes / 4;
+    }
+    char *b = static_cast<char *>(pin_);
+    auto take = [&](size_t sz) { char *q = b; b += (sz + 63) & ~(size_t)63; return q; };
+    var = reinterpret_cast<double *>(take(nn * 72)); bcov = reinterpret_cast<double *>(take(nn * 72)); pw = reinterpret_cast<float *>(take(nn * 12));
+    match = reinterpret_cast<int32_t *>(take(nn * 4)); normal_plane = reinterpret_cast<int32_t *>(take(nn * 4)); dis = reinterpret_cast<float *>(take(nn * 4));
+    pts.match_plane = match; pts.dis_to_plane = dis; pts.point_w = pw; pts.normal_plane = normal_plane; pts.var = var; pts.body_cov = bcov;
+  }
   livo2_state s_in, s_prop;
   state_.to_abi(s_in); state_propagat.to_abi(s_prop);
   livo2_lidar_result res;
@@ -378,23 +389,30 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     effct_feat_num_ = res.n_iters > 0 ? res.iter_sums[res.n_iters - 1].n_eff : 0;
     return;
   }
-  // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811)
+  // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811): ~900 B of reference structs per point, written by
+  // fill_threads_ host threads (the lists are indexed, so the points are independent once the position of every match in ptpl_list_ is known)
   // device-resident map: the VoxelPlane members of the matched rows come from the device plane table
-  std::vector<int32_t> rows; std::vector<double> r_normal, r_center, r_pvar; std::vector<float> r_d; std::vector<int32_t> r_layer;
-  std::unordered_map<int32_t, int32_t> row_at;
+  std::vector<int32_t> rows, row_pos; std::vector<double> r_normal, r_center, r_pvar; std::vector<float> r_d; std::vector<int32_t> r_layer;
   if (device_map_) {
+    int32_t max_row = -1;
+    for (int i = 0; i < n; i++) max_row = std::max(max_row, std::max(match[i], normal_plane[i]));
+    row_pos.assign((size_t)(max_row + 1), -1);
     for (int i = 0; i < n; i++)
-      for (int32_t r : {match[i], normal_plane[i]}) if (r >= 0 && row_at.emplace(r, (int32_t)rows.size()).second) rows.push_back(r);
+      for (int32_t r : {match[i], normal_plane[i]}) if (r >= 0 && row_pos[r] < 0) { row_pos[r] = (int32_t)rows.size(); rows.push_back(r); }
     r_normal.resize(rows.size() * 3); r_center.resize(rows.size() * 3); r_pvar.resize(rows.size() * 36); r_d.resize(rows.size()); r_layer.resize(rows.size());
     dev_.check(livo2_map_tree_read_planes(dev_.ctx(), rows.data(), (int32_t)rows.size(), r_normal.data(), r_center.data(), r_pvar.data(), r_d.data(), nullptr, r_layer.data()));
   }
-  pv_list_.assign(n, pointWithVar());
-  cross_mat_list_.resize(n); body_cov_list_.resize(n);
-  ptpl_list_.clear();
+  std::vector<int32_t> slot((size_t)n);                                     // position of point i's PointToPlane in ptpl_list_ (the reference pushes them in scan order)
+  int n_match = 0;
+  for (int i = 0; i < n; i++) { slot[i] = n_match; n_match += match[i] >= 0 ? 1 : 0; }
+  pv_list_.resize(n); cross_mat_list_.resize(n); body_cov_list_.resize(n); ptpl_list_.resize(n_match);
+  const int threads = std::max(1, std::min(fill_threads_, n / 2048 + 1));
+#pragma omp parallel for schedule(static) num_threads(threads)
   for (int i = 0; i < n; i++) {
     pointWithVar &pv = pv_list_[i];
     const PointXYZ &p = feats_down_body_[i];
     pv.point_b = {p.x, p.y, p.z};
+    pv.point_i = {}; pv.var_nostate = {}; pv.point_crossmat = {}; pv.normal = {};
     pv.point_w = {pw[(size_t)i * 3], pw[(size_t)i * 3 + 1], pw[(size_t)i * 3 + 2]};
     std::memcpy(pv.var.data(), &var[(size_t)i * 9], 72);
     std::memcpy(pv.body_var.data(), &bcov[(size_t)i * 9], 72);
@@ -404,24 +422,22 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     for (int j = 0; j < 3; j++) q[j] = extR_[j * 3] * p.x + extR_[j * 3 + 1] * p.y + extR_[j * 3 + 2] * pz + extT_[j];
     cross_mat_list_[i] = {0.0, -q[2], q[1], q[2], 0.0, -q[0], -q[1], q[0], 0.0};
     if (device_map_) {
-      if (normal_plane[i] >= 0) std::memcpy(pv.normal.data(), &r_normal[(size_t)row_at[normal_plane[i]] * 3], 24);
+      if (normal_plane[i] >= 0) std::memcpy(pv.normal.data(), &r_normal[(size_t)row_pos[normal_plane[i]] * 3], 24);
       if (match[i] >= 0) {
-        const size_t k = (size_t)row_at[match[i]];
-        PointToPlane pp;
+        const size_t k = (size_t)row_pos[match[i]];
+        PointToPlane &pp = ptpl_list_[slot[i]];
         pp.point_b_ = pv.point_b; pp.point_w_ = pv.point_w; std::memcpy(pp.normal_.data(), &r_normal[k * 3], 24); std::memcpy(pp.center_.data(), &r_center[k * 3], 24);
         std::memcpy(pp.plane_var_.data(), &r_pvar[k * 36], 288);
-        pp.body_cov_ = pv.body_var; pp.layer_ = r_layer[k]; pp.d_ = r_d[k]; pp.is_valid_ = true; pp.dis_to_plane_ = dis[i];
-        ptpl_list_.push_back(pp);
+        pp.body_cov_ = pv.body_var; pp.layer_ = r_layer[k]; pp.d_ = r_d[k]; pp.eigen_value_ = 0; pp.is_valid_ = true; pp.dis_to_plane_ = dis[i];
       }
       continue;
     }
     if (normal_plane[i] >= 0) pv.normal = plane_by_index_[normal_plane[i]]->normal_;
     if (match[i] >= 0) {
       const VoxelPlane *pl = plane_by_index_[match[i]];
-      PointToPlane pp;
+      PointToPlane &pp = ptpl_list_[slot[i]];
       pp.point_b_ = pv.point_b; pp.point_w_ = pv.point_w; pp.normal_ = pl->normal_; pp.center_ = pl->center_; pp.plane_var_ = pl->plane_var_;
-      pp.body_cov_ = pv.body_var; pp.layer_ = plane_layer_[match[i]]; pp.d_ = pl->d_; pp.is_valid_ = true; pp.dis_to_plane_ = dis[i];
-      ptpl_list_.push_back(pp);
+      pp.body_cov_ = pv.body_var; pp.layer_ = plane_layer_[match[i]]; pp.d_ = pl->d_; pp.eigen_value_ = 0; pp.is_valid_ = true; pp.dis_to_plane_ = dis[i];
     }
   }
   effct_feat_num_ = (int)ptpl_list_.size();

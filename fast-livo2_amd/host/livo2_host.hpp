@@ -145,7 +145,7 @@ public:
   std::vector<PointToPlane> ptpl_list_;
 
   explicit VoxelMapManager(Device &dev) : dev_(dev) {}
-  ~VoxelMapManager() { for (auto &kv : voxel_map_) delete kv.second; }
+  ~VoxelMapManager() { for (auto &kv : voxel_map_) delete kv.second; livo2_host_free_pinned(pin_); }
 
   // Call after BuildVoxelMap / UpdateVoxelMap changed the tree structure (new voxels / nodes).  Plane-only refreshes can go
   // through RefreshPlanes instead.
@@ -182,6 +182,7 @@ public:
   // With device_map_ their consumers UpdateVoxelMap (LIVMapper.cpp:413-424 -> UpdateVoxelMapFromPosterior) run on the device; a caller that neither publishes
   // (publish_effect_world, LIVMapper.cpp:1308) nor feeds generateVisualMapPoints (vio.cpp:811) can switch them off: only state_, effct_feat_num_, position_last_, geoQuat_ come back.
   bool host_point_lists_ = true;
+  int fill_threads_ = 16;                   // host threads that write the per-point lists (one per 2048 points, at most this many)
   int device_map_max_roots_ = 300000;
   void UpdateVoxelMapFromPosterior();
   // reference src/voxel_map.cpp:924-972 (LIVMapper.cpp:430-433 calls it when config_setting_.map_sliding_en): root voxels outside the box around
@@ -198,6 +199,7 @@ private:
   std::unordered_map<const VoxelPlane *, int32_t> plane_index_;
   std::vector<const VoxelPlane *> plane_by_index_;
   std::vector<int> plane_layer_;
+  void *pin_ = nullptr; size_t pin_bytes_ = 0;       // page-locked receive buffer of the per-point outputs
 };
 
 // ---- IMU ------------------------------------------------------------------------------------------------------------------

@@ -64,6 +64,10 @@ void livo2_ctx_destroy(livo2_ctx *ctx);
 const char *livo2_last_error(const livo2_ctx *ctx);
 void *livo2_ctx_stream(livo2_ctx *ctx);                 /* the hipStream_t this ctx launches on */
 int livo2_ctx_synchronize(livo2_ctx *ctx);
+/* Page-locked host memory for the caller's buffers (scans, images, per-point outputs): transfers from / to it run at PCIe speed and asynchronously; from pageable
+ * memory the runtime stages every copy through its own bounce buffers.  (No reference counterpart: the reference never leaves the host.) */
+int livo2_host_alloc_pinned(size_t bytes, void **out);
+void livo2_host_free_pinned(void *p);
 const char *livo2_version(void);
 /* sizeof() of a struct of this header as the library was compiled ("livo2_state", "livo2_lidar_cfg", ...), 0 for an unknown name: lets a
  * foreign-language binding check its mirror of the layouts at load time. */
