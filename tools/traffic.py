@@ -78,9 +78,28 @@ def make(tag, workload, kernel, points, fetch_db, write_db, tcc_db, use_max=Fals
     print(out, json.dumps(rec))
 
 
+WORKLOADS = {            # workload -> (kernel, where bench_full.json holds the points of one launch, aggregate)
+    "c4": ("k_lidar_residual", ("config", "points_per_frame"), False),
+    "c4_lockstep": ("k_lidar_residual_batch", ("extra", "c4_lockstep", "roofline", "bytes_per_launch"), False),
+    "batched": ("k_lidar_residual_batch", ("extra", "batched", "points_per_launch"), False),
+    "out_of_cache": ("k_lidar_residual_batch", ("extra", "out_of_cache", "points_per_launch"), True),      # the 64-frame launches are the largest dispatches of the run
+}
+
+
+def make_from_bench(tag, workload, fetch_db, write_db, tcc_db, bench_full, command):
+    kernel, path, use_max = WORKLOADS[workload]
+    v = json.load(open(bench_full))
+    for k in path:
+        v = v[k]
+    points = int(round(v / 276.0)) if path[-1] == "bytes_per_launch" else int(v)
+    make(tag, workload, kernel, points, fetch_db, write_db, tcc_db, use_max, command)
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
-    if a and a[0] == "sha":
+    if a and a[0] == "make-from-bench":
+        make_from_bench(a[1], a[2], a[3], a[4], a[5], a[6], a[7] if len(a) > 7 else "")
+    elif a and a[0] == "sha":
         print(csrc_sha(), lib_sha())
     elif a and a[0] == "make":
         use_max = "--max" in a
