@@ -57,7 +57,8 @@ def load(workload, **match):
 def _counter(db, kernel, counter, use_max):
     c = sqlite3.connect(db)
     agg = "max" if use_max else "avg"
-    row = c.execute(f"select {agg}(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", (kernel + "%", counter)).fetchone()
+    pattern = "%" + kernel + ("<%" if kernel == "k_lidar_residual" else "%")          # (k_lidar_residual<256> must not pick up k_lidar_residual_batch)
+    row = c.execute(f"select {agg}(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", (pattern, counter)).fetchone()
     if row is None or row[0] is None:
         raise SystemExit(f"traffic.py: no {counter} for {kernel} in {db}")
     return float(row[0]), int(row[1])
