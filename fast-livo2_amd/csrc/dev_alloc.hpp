@@ -84,7 +84,31 @@ inline hipError_t fence_alloc(void **p, size_t bytes, int line, int m) {
   return hipSuccess;
 }
 
+// LIVO2_POISON=<byte, e.g. 0xCB>: every new allocation (any mode, also the plain one) is filled with that byte, so that a kernel which READS memory nobody wrote
+// computes on garbage instead of on whatever the allocator recycled (hipMalloc mostly hands out zeros, which hides such reads).  LIVO2_POISON_LINES=<lo>:<hi>
+// restricts the fill to the allocations made at those source lines (tools/poison_bisect.py walks the lines to name the buffer a failing test depends on).
+inline int poison_byte() {
+  static const int b = [] { const char *e = std::getenv("LIVO2_POISON"); return e ? (int)(std::strtol(e, nullptr, 0) & 0xff) : -1; }();
+  return b;
+}
+inline bool poison_line(int line) {        // LIVO2_POISON_LINES=lo:hi restricts the fill to allocations made at source lines lo..hi
+  static const std::pair<int, int> r = [] {
+    const char *e = std::getenv("LIVO2_POISON_LINES");
+    int lo = 0, hi = 1 << 30;
+    if (e) { if (std::sscanf(e, "%d:%d", &lo, &hi) < 2) hi = lo; }
+    return std::make_pair(lo, hi);
+  }();
+  return line >= r.first && line <= r.second;
+}
+inline hipError_t dev_malloc_raw(void **p, size_t bytes, int line);
 inline hipError_t dev_malloc(void **p, size_t bytes, int line) {
+  hipError_t e = dev_malloc_raw(p, bytes, line);
+  if (e != hipSuccess || !*p || poison_byte() < 0) return e;
+  if (!poison_line(line)) return e;
+  if ((e = hipMemset(*p, poison_byte(), bytes)) != hipSuccess) return e;
+  return hipDeviceSynchronize();
+}
+inline hipError_t dev_malloc_raw(void **p, size_t bytes, int line) {
   const int m = mode();
   if (bytes == 0) { *p = nullptr; return hipSuccess; }
   if (m == 0) return hipMalloc(p, bytes);
@@ -178,4 +202,5 @@ inline long long check(char *msg, size_t msg_len) {
 }  // namespace devalloc
 
 #define DMALLOC(pp, bytes) devalloc::dev_malloc((void **)(pp), (bytes), __LINE__)
+#define DMALLOC_AT(line, pp, bytes) devalloc::dev_malloc((void **)(pp), (bytes), (line))
 #define DFREE(p) devalloc::dev_free((void *)(p))

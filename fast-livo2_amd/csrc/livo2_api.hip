@@ -190,18 +190,20 @@ int rz_gate(livo2_ctx *ctx) {
   return LIVO2_ERR_HIP;
 }
 
-template <typename T> int ensure(livo2_ctx *ctx, T *&p, size_t &cap, size_t need) {
+// (ensure / grow_array are macros over *_at so that the debug allocator records the CALLER's line: one line per buffer, dev_alloc.hpp)
+template <typename T> int ensure_at(int line, livo2_ctx *ctx, T *&p, size_t &cap, size_t need) {
   if (need <= cap && p) return LIVO2_OK;
   if (p) { hipError_t e = DFREE(p); (void)e; p = nullptr; }
   size_t newcap = std::max(need, cap + cap / 2);
-  HIPCHK(DMALLOC((void **)&p, newcap * sizeof(T)));
+  HIPCHK(DMALLOC_AT(line, (void **)&p, newcap * sizeof(T)));
   cap = newcap;
   return LIVO2_OK;
 }
+#define ensure(...) ensure_at(__LINE__, __VA_ARGS__)
 
-template <typename T> int grow_array(livo2_ctx *ctx, T *&p, size_t old_n, size_t new_n, bool zero_tail) {
+template <typename T> int grow_array_at(int line, livo2_ctx *ctx, T *&p, size_t old_n, size_t new_n, bool zero_tail) {
   T *q = nullptr;
-  HIPCHK(DMALLOC((void **)&q, new_n * sizeof(T)));
+  HIPCHK(DMALLOC_AT(line, (void **)&q, new_n * sizeof(T)));
   if (old_n) HIPCHK(hipMemcpyAsync(q, p, old_n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
   if (zero_tail && new_n > old_n) HIPCHK(hipMemsetAsync(q + old_n, 0, (new_n - old_n) * sizeof(T), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -209,6 +211,7 @@ template <typename T> int grow_array(livo2_ctx *ctx, T *&p, size_t old_n, size_t
   p = q;
   return LIVO2_OK;
 }
+#define grow_array(...) grow_array_at(__LINE__, __VA_ARGS__)
 
 struct Timed {                 // RAII-free helper: brackets one launch with an event pair when timing is on
   livo2_ctx *ctx; int bin; EvPair ev{}; bool on = false;
