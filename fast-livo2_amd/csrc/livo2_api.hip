@@ -141,7 +141,9 @@ struct livo2_ctx {
   bool lidar_block_order = [] { const char *e = std::getenv("LIVO2_LIDAR_BLOCK_ORDER"); return e ? std::atoi(e) != 0 : true; }();
   hipEvent_t vp_done = nullptr; int vp_blocks_inflight = 0;     // this ctx's last persistent launch (device-wide accounting below)
   unsigned long long *d_vp_prof = nullptr; bool vp_prof = [] { const char *e = std::getenv("LIVO2_VP_PROF"); return e ? std::atoi(e) != 0 : false; }();
-  int vp_used = 0, vp_fallback = 0;                              // statistics: persistent launches / fallbacks to the per-step sequence
+  int vp_used = 0, vp_fallback = 0, vp_timeouts = 0;             // statistics: persistent launches / fallbacks to the per-step sequence / grids that gave up and were re-run per step
+  bool vp_debug_timeout = false, vp_rerun = false, vp_last_valid = false;
+  livo2_state vp_last_in{}, vp_last_prop{}; livo2_visual_cfg vp_last_cfg{};       // inputs of the last persistent launch (a timed-out grid is re-run from them)
   bool tree_mode = false;
   MapTreeArgs mt{};
   double mt_last_slide[3] = {0, 0, 0};      // VoxelMapManager::last_slide_position
@@ -710,12 +712,14 @@ int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (!ctx || !name) return LIVO2_ERR_INVALID;
   if (std::strcmp(name, "lidar_block_order") == 0) { ctx->lidar_block_order = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_persistent_debug_timeout") == 0) { ctx->vp_debug_timeout = value != 0; return LIVO2_OK; }     // test hook: the last block of the grid leaves at once, the others give up after 2 ms
   return fail(ctx, LIVO2_ERR_INVALID, "unknown option");
 }
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
   if (!ctx || !name || !value) return LIVO2_ERR_INVALID;
   if (std::strcmp(name, "visual_persistent_launches") == 0) { *value = ctx->vp_used; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_fallbacks") == 0) { *value = ctx->vp_fallback; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_persistent_timeouts") == 0) { *value = ctx->vp_timeouts; return LIVO2_OK; }
   if (std::strcmp(name, "map_tree_grow_events") == 0) { *value = ctx->mt_grow_events; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
 }
@@ -2440,7 +2444,8 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
   int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
   const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(ctx->M, 1)) : visual_grid(std::max(ctx->M, 1));
   VisualKernelArgs a{};
-  if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
+  ctx->vp_last_valid = false;
+  if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && !ctx->vp_rerun && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
     {                        // (before the admission: nothing between the reservation and the launch may fail) exchange buffers start as all-zero words: tag 0 is never a step's tag
       const size_t c0 = ctx->vp_rows_cap, c1 = ctx->vp_errs_cap;
       rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_ROWS * VIS_PSTRIDE * 2); if (rc) return rc;
@@ -2462,6 +2467,9 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       ctx->vp_seq = (ctx->vp_seq + 1) & 0xffffffu; if (ctx->vp_seq == 0) ctx->vp_seq = 1;       // tag 0 = never-written memory
       p.tag_base = ctx->vp_seq << 8;
       if (ctx->vp_prof) p.prof = ctx->d_vp_prof;
+      p.timeout = ctx->vp_debug_timeout ? 200000ull : VP_TIMEOUT;              // debug: 2 ms
+      p.debug_drop_block = (ctx->vp_debug_timeout && G > 1) ? G - 1 : -1;
+      ctx->vp_last_in = *state_in; ctx->vp_last_prop = *prop; ctx->vp_last_cfg = *cfg; ctx->vp_last_valid = true;    // what a timed-out grid is re-run from
       { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_update_persistent, dim3(G), dim3(VP_BLOCK), 0, ctx->stream, p, ctx->d_ctl); t.done(); }
       const hipError_t le = hipGetLastError();
       persist_register(ctx, le == hipSuccess ? G : 0);            // a failed launch gives its reservation back
@@ -2516,8 +2524,22 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
   int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ctx->h_out) + sizeof(livo2_visual_result));
   HIPCHK(hipMemcpyAsync(flag, &ctx->d_ctl->hdr.pad[0], 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (*flag) {
+    // the resident grid gave up (a block was not co-resident: another process or a long foreign kernel held its CU) and committed nothing.  Re-run the update as the
+    // launch-per-step sequence from the inputs kept at enqueue; the caller sees the same result, "visual_persistent_timeouts" counts the event.
+    if (!ctx->vp_last_valid) return fail(ctx, LIVO2_ERR_HIP, "persistent visual update timed out and its inputs are gone");
+    ctx->vp_timeouts++;
+    HIPCHK(hipMemsetAsync(&ctx->d_ctl->hdr.pad[0], 0, 4, ctx->stream));
+    const livo2_state in = ctx->vp_last_in, pr = ctx->vp_last_prop; const livo2_visual_cfg vc = ctx->vp_last_cfg;
+    ctx->vp_rerun = true;
+    const int rc = visual_enqueue(ctx, &in, &pr, &vc, vc.patch_pyrimid_level - 1, 0, vc.max_iterations, 1);
+    ctx->vp_rerun = false;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (errors && ctx->M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   std::memcpy(result, ctx->h_out, sizeof(livo2_visual_result));
-  if (*flag) return fail(ctx, LIVO2_ERR_HIP, "persistent visual update: grid barrier timed out (the grid was not co-resident); result invalid");
   return rz_gate(ctx);
 }
 

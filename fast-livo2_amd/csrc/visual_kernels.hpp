@@ -672,6 +672,9 @@ struct VisPersistArgs {
   uint32_t tag_base;            // launch sequence number << 8
   double img_point_cov;
   unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 256][step < 32][16] stamps of the 100 MHz clock, else null
+  unsigned long long timeout;   // 100 MHz ticks a block waits for a word before it gives the update up (VP_TIMEOUT; option "visual_persistent_debug_timeout" shortens it)
+  int32_t debug_drop_block;     // -1; else this block leaves at once (a grid that is not co-resident, simulated: tests/test_visual_gpu.py)
+  int32_t pad_;
 };
 #define VPP(k) do { if (p.prof && tid == 0 && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define VPP_W(k, w) do { if (p.prof && tid == (w) * LIVO2_WAVE && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -801,7 +804,7 @@ __device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
       for (int u = 0; u < VP_RPT; u++) if ((todo >> u & 1u) && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag) have |= 1u << u;
 #pragma unroll
       for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if ((etodo >> u & 1u) && (uint32_t)(ev[u] >> 32) == tag) ehave |= 1u << u;
-      if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > VP_TIMEOUT) { SL.timed_out = 1; break; } }
+      if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } }
     }
 #pragma unroll
     for (int u = 0; u < VP_RPT; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((lo[u] & 0xffffffffull) | (hi[u] << 32)));
@@ -860,7 +863,7 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       for (int i = max(my_begin, n_stage); i < my_end; i++) {                 // sub-maps beyond the staging area: straight from the published words
         vp_word w = vp_ld(errs + i);
-        while ((uint32_t)(w >> 32) != tag) { if (__builtin_amdgcn_s_memrealtime() - t0 > VP_TIMEOUT) { SL.timed_out = 1; break; } w = vp_ld(errs + i); }
+        while ((uint32_t)(w >> 32) != tag) { if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } w = vp_ld(errs + i); }
         priv += __uint_as_float((uint32_t)w);
       }
       SL.u.s.err_chunk[lane] = priv;
@@ -912,6 +915,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = (int)gridDim.x, M = p.a.M;
   const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
+  if ((int)blockIdx.x == p.debug_drop_block) return;
   // ---- entry: the iterate, the prior, P' = cov / img_point_cov, the G the reference would still hold (all blocks read the same words)
   {
     double craw[6];
@@ -946,6 +950,9 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
     }
   }
   if (blockIdx.x != 0) return;
+  // A grid that lost a block (not co-resident: admission is per process, advisor round 3) commits NOTHING: ctl->cur, cov and G stay what the launch found, only the
+  // flag goes up, and livo2_visual_update_fetch re-runs the update as the launch-per-step sequence from the inputs it kept.
+  if (SL.timed_out) { if (tid == 0) ctl->hdr.pad[0] = 1; return; }
   // ---- block 0: the result.  state->cov -= G * state->cov (vio.cpp:800), updateFrameState (vio.cpp:1690-1697)
   for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
   __syncthreads();
@@ -965,6 +972,6 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
     for (int j = 0; j < 9; j++) ctl->visual.Rcw[j] = Rcw[j];
     for (int j = 0; j < 3; j++) ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * s.cur[9] + Rcw[j * 3 + 1] * s.cur[10]) + Rcw[j * 3 + 2] * s.cur[11]);
     ctl->visual.n_steps = SL.n_steps; ctl->hdr.n_steps = SL.n_steps; ctl->hdr.last_error = SL.last_error; ctl->hdr.stop = SL.stop;
-    ctl->hdr.pad[0] = SL.timed_out;
+    ctl->hdr.pad[0] = 0;
   }
 }

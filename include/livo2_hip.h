@@ -83,7 +83,10 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *   "lidar_block_order" (default 1): a LiDAR launch that needs more than one round of blocks starts the chunks of the scan in the order of their block lifetimes in
  *                        the previous launch (longest first; recorded by every launch, sorted on the device by the solve of the previous iteration, reset by
  *                        livo2_lidar_set_scan); 0: scan order.
- * Counters: "visual_persistent_launches", "visual_persistent_fallbacks", "map_tree_grow_events". */
+ *                        Admission counts the resident grids of THIS process only; if another process or a long foreign kernel keeps a block of the grid off the
+ *                        device, every block gives up after 2 s, nothing is committed, and livo2_visual_update_fetch re-runs the update as the per-step sequence
+ *                        (counter "visual_persistent_timeouts"; "visual_persistent_debug_timeout" = 1 provokes exactly that in 2 ms, for the tests).
+ * Counters: "visual_persistent_launches", "visual_persistent_fallbacks", "visual_persistent_timeouts", "map_tree_grow_events". */
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value);
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value);
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);

@@ -244,3 +244,25 @@ def test_concurrent_persistent_contexts(livo2):
     for c in ctxs:
         c.close()
     assert not bad and used >= 26
+
+
+def test_a_resident_grid_that_loses_a_block_is_rerun_per_step_with_the_same_result(livo2, ctx):
+    """advisor (round 3): admission of the resident grid is per process; if anything keeps a block off the device every block gives up — and used to overwrite
+    ctl->cur / cov / G with garbage, the fetch returning a hard error.  Now a grid that timed out commits nothing and livo2_visual_update_fetch re-runs the update
+    as the launch-per-step sequence from the inputs kept at enqueue.  The test hook drops the last block of the grid and shortens the wait to 2 ms."""
+    vs = synth.visual_scenario(seed=77, n_patches=1200)
+    cfg = H.visual_cfg_product(vs, mp_proc_num=4)
+    cur, prop = H.states(vs, livo2.State)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    ref, ref_err = ctx.visual_update(cur, prop, cfg)
+    t0, f0 = ctx.counter("visual_persistent_timeouts"), ctx.counter("visual_persistent_launches")
+    ctx.set_option("visual_persistent_debug_timeout", 1)
+    try:
+        for _ in range(3):
+            res, err = ctx.visual_update(cur, prop, cfg)
+            assert bytes(res.state) == bytes(ref.state) and bytes(res.G) == bytes(ref.G) and res.n_steps == ref.n_steps and np.array_equal(err, ref_err)
+    finally:
+        ctx.set_option("visual_persistent_debug_timeout", 0)
+    assert ctx.counter("visual_persistent_timeouts") == t0 + 3 and ctx.counter("visual_persistent_launches") == f0 + 3
+    res, err = ctx.visual_update(cur, prop, cfg)                    # and the resident grid works again afterwards
+    assert bytes(res.state) == bytes(ref.state) and ctx.counter("visual_persistent_timeouts") == t0 + 3
