@@ -33,12 +33,17 @@ inline int mode() {
 }
 inline std::mutex &mtx() { static std::mutex m; return m; }
 inline std::unordered_map<void *, Rec> &table() { static std::unordered_map<void *, Rec> t; return t; }
+struct Freed { void *user; size_t bytes; int line; };
+inline std::vector<Freed> &graveyard() { static std::vector<Freed> g; return g; }      // freed allocations, oldest first (a fault inside one of them = use after free)
 
 inline void dump_table(FILE *f) {
   // (called from the abort handler too: no locking, plain stdio — a debugging aid, not a service)
   fprintf(f, "livo2 device allocations (LIVO2_REDZONE=%d): user pointer .. end, bytes, source line of livo2_api.hip\n", mode());
   for (auto &kv : table())
     fprintf(f, "  %p .. %p  %zu B  line %d\n", kv.first, (void *)((char *)kv.first + kv.second.bytes), kv.second.bytes, kv.second.line);
+  fprintf(f, "freed allocations (oldest first; an address inside one of them is a use after free):\n");
+  for (auto &g : graveyard())
+    fprintf(f, "  freed %p .. %p  %zu B  line %d\n", g.user, (void *)((char *)g.user + g.bytes), g.bytes, g.line);
   fflush(f);
 }
 inline void on_abort(int) { dump_table(stderr); std::signal(SIGABRT, SIG_DFL); std::abort(); }
@@ -66,7 +71,8 @@ inline hipError_t fence_alloc(void **p, size_t bytes, int line, int m) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
   size_t gran = 0;
-  if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+  static const bool recommended = [] { const char *g = std::getenv("LIVO2_FENCE_GRAN"); return g && g[0] == 'r'; }();      // "recommended": the runtime's preferred granule (2 MiB) instead of the minimum (4 KiB)
+  if ((e = hipMemGetAllocationGranularity(&gran, &prop, recommended ? hipMemAllocationGranularityRecommended : hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
   const size_t mapped = (bytes + gran - 1) / gran * gran, reserved = mapped + 2 * gran;
   void *va = nullptr;
   if ((e = hipMemAddressReserve(&va, reserved, gran, nullptr, 0)) != hipSuccess) return e;
@@ -138,6 +144,7 @@ inline hipError_t dev_free(void *p) {
     auto it = table().find(p);
     if (it == table().end()) return hipFree(p);
     r = it->second; table().erase(it);
+    if (graveyard().size() < 65536) graveyard().push_back(Freed{p, r.bytes, r.line});
   }
   hipError_t e = hipDeviceSynchronize();
   if (r.mode == 1) return hipFree(r.base);
@@ -197,6 +204,16 @@ inline long long check(char *msg, size_t msg_len) {
     }
   }
   return bad;
+}
+
+// hipMemcpyAsync as the library calls it.  From pageable host memory the runtime stages a copy into ordinary device memory before it returns, so callers may free
+// or reuse the host buffer at once — the library (and every HIP program) relies on that.  For destinations in hipMemMap'ed ranges (modes 2 / 3) that was observed
+// NOT to hold on ROCm 7.2 (results changed with the fence allocator and came back under AMD_SERIALIZE_KERNEL=3, gpurun_out/r04c-e): in those modes every copy is
+// completed before the call returns.
+inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
+  hipError_t e = ::hipMemcpyAsync(dst, src, bytes, kind, stream);
+  if (e != hipSuccess || mode() < 2) return e;
+  return hipStreamSynchronize(stream);
 }
 
 }  // namespace devalloc

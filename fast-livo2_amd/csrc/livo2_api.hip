@@ -206,7 +206,7 @@ template <typename T> int ensure_at(int line, livo2_ctx *ctx, T *&p, size_t &cap
 template <typename T> int grow_array_at(int line, livo2_ctx *ctx, T *&p, size_t old_n, size_t new_n, bool zero_tail) {
   T *q = nullptr;
   HIPCHK(DMALLOC_AT(line, (void **)&q, new_n * sizeof(T)));
-  if (old_n) HIPCHK(hipMemcpyAsync(q, p, old_n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+  if (old_n) HIPCHK(devalloc::memcpy_async(q, p, old_n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
   if (zero_tail && new_n > old_n) HIPCHK(hipMemsetAsync(q + old_n, 0, (new_n - old_n) * sizeof(T), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(DFREE(p));
@@ -379,7 +379,7 @@ int upload_states(livo2_ctx *ctx, const livo2_state *cur, const livo2_state *pro
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
       h->hdr.RE[i * 3 + j] = (prop->rot[i * 3] * extR[j] + prop->rot[i * 3 + 1] * extR[3 + j]) + prop->rot[i * 3 + 2] * extR[6 + j];
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_ctl, h, sizeof(HostIn), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_ctl, h, sizeof(HostIn), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->in_ev[k], ctx->stream));
   ctx->in_used[k] = true;
   return LIVO2_OK;
@@ -454,7 +454,7 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   if (total > ((size_t)8 << 20)) {
     // large outputs (C4: 168 B x 200 000 points = 34 MB): copy straight into the caller's arrays — the runtime pipelines a pageable D2H through its own pinned
     // chunks while it copies the previous chunk out, which a stage-everything-then-memcpy scheme does not (measured: 3.0 ms against 3.8 ms per C4 frame)
-    for (int k = 0; k < NITEMS; k++) if (items[k].dst && items[k].bytes) HIPCHK(hipMemcpyAsync(items[k].dst, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < NITEMS; k++) if (items[k].dst && items[k].bytes) HIPCHK(devalloc::memcpy_async(items[k].dst, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (!ctx->tree_mode) {
       if (p->match_plane) for (size_t i = 0; i < n; i++) if (p->match_plane[i] >= 0) p->match_plane[i] = ctx->plane_orig[p->match_plane[i]];
@@ -473,7 +473,7 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   for (int k = 0; k < NITEMS; k++) {
     if (!items[k].dst) continue;
     offs[k] = off;
-    if (items[k].bytes) HIPCHK(hipMemcpyAsync(base + off, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (items[k].bytes) HIPCHK(devalloc::memcpy_async(base + off, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
     off += (items[k].bytes + 63) & ~(size_t)63;
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -865,7 +865,7 @@ int livo2_map_upload(livo2_ctx *ctx, const livo2_map_view *m) {
   if (!cand.empty()) {
     int32_t *d_meta = nullptr;
     HIPCHK(DMALLOC((void **)&d_meta, cand.size() * 4));
-    HIPCHK(hipMemcpyAsync(d_meta, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(d_meta, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_cand_fill, dim3((unsigned)((cand.size() * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_planes_hot, ctx->d_plane_aux, d_meta, (int)cand.size(), ctx->d_cand, ctx->d_cand_aux);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -901,9 +901,9 @@ int livo2_map_update_planes(livo2_ctx *ctx, const int32_t *plane_idx, int32_t n,
   HIPCHK(DMALLOC((void **)&d_recs, recs.size() * 8));
   HIPCHK(DMALLOC((void **)&d_idx, (size_t)n * 4));
   HIPCHK(DMALLOC((void **)&d_gpos, (size_t)n * 4));
-  HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(d_idx, didx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(d_idx, didx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_scatter_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, d_recs, d_idx, n, ctx->d_planes);
   hipLaunchKernelGGL(k_planes_hot, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_planes, d_idx, d_gpos, n, ctx->d_planes_hot, ctx->d_plane_aux, ctx->d_cand, ctx->d_cand_aux);
   HIPCHK(hipGetLastError());
@@ -934,15 +934,15 @@ int livo2_imu_propagate(livo2_ctx *ctx, const livo2_state *state_in, const livo2
   if ((rc = ensure(ctx, ctx->d_imu_poses, ctx->imu_poses_cap, std::max((size_t)n * 22, (size_t)22)))) return rc;
   if (!ctx->d_imu_state) HIPCHK(DMALLOC((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
   static_assert(sizeof(livo2_imu_step) == 64, "livo2_imu_step is 8 doubles");
-  HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
-  if (n > 0) HIPCHK(hipMemcpyAsync(ctx->d_imu_steps, steps, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) HIPCHK(devalloc::memcpy_async(ctx->d_imu_steps, steps, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
   ImuKernelArgs a = make_imu_args(ctx, cfg, n, ctx->d_imu_poses);
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   hipLaunchKernelGGL(k_imu_propagate, dim3(1), dim3(IMU_THREADS), 0, ctx->stream, a);
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(state_out, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
-  if (n > 0) HIPCHK(hipMemcpyAsync(poses, ctx->d_imu_poses, (size_t)n * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(state_out, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
+  if (n > 0) HIPCHK(devalloc::memcpy_async(poses, ctx->d_imu_poses, (size_t)n * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
@@ -977,21 +977,21 @@ int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *v
     const size_t np = ctx->plane_internal.size();
     if ((rc = ensure(ctx, ctx->d_plane_internal, ctx->plane_tab_cap, std::max(np, (size_t)1)))) return rc;
     if ((rc = ensure(ctx, ctx->d_plane_cand_pos, ctx->plane_tab_cap2, std::max(np, (size_t)1)))) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->d_plane_internal, ctx->plane_internal.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_plane_cand_pos, ctx->plane_cand_pos.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_plane_internal, ctx->plane_internal.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_plane_cand_pos, ctx->plane_cand_pos.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
     ctx->plane_tabs_fresh = true;
   }
   if (N > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_fit_pw, point_w, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_fit_var, var, N * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_fit_pw, point_w, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_fit_var, var, N * 72, hipMemcpyHostToDevice, ctx->stream));
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_fit_off, offsets, ((size_t)n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (plane_idx) HIPCHK(hipMemcpyAsync(ctx->d_fit_idx, plane_idx, (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_fit_off, offsets, ((size_t)n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (plane_idx) HIPCHK(devalloc::memcpy_async(ctx->d_fit_idx, plane_idx, (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
   // small voxels (the UpdateVoxelMap case) go 8 to a wave, large ones (BuildVoxelMap) get a whole wave
   std::vector<int32_t> list((size_t)n_groups);
   int n_small = 0, n_big = 0;
   for (int g = 0; g < n_groups; g++) { if (offsets[g + 1] - offsets[g] <= 64) list[n_small++] = g; else list[n_groups - 1 - n_big++] = g; }
-  HIPCHK(hipMemcpyAsync(ctx->d_fit_list, list.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_fit_list, list.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
   PlaneFitArgs a{};
   a.pw = ctx->d_fit_pw; a.var = ctx->d_fit_var; a.offsets = ctx->d_fit_off; a.planer_threshold = planer_threshold; a.out = ctx->d_fit_out;
   a.plane_idx = plane_idx ? ctx->d_fit_idx : nullptr; a.plane_internal = ctx->d_plane_internal; a.plane_cand_pos = ctx->d_plane_cand_pos;
@@ -1002,7 +1002,7 @@ int livo2_plane_fit_batch(livo2_ctx *ctx, const double *point_w, const double *v
   if (n_big) { a.list = ctx->d_fit_list + n_small; a.n_list = n_big; hipLaunchKernelGGL(k_plane_fit<64>, dim3((n_big * 64 + tpb - 1) / tpb), dim3(tpb), 0, ctx->stream, a); }
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, ctx->d_fit_out, (size_t)n_groups * sizeof(livo2_plane_fit), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(out, ctx->d_fit_out, (size_t)n_groups * sizeof(livo2_plane_fit), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
@@ -1193,11 +1193,11 @@ int map_tree_relayout_counters(livo2_ctx *ctx, int new_nodes, int new_planes, in
   const size_t new_total = (size_t)MTC_TOTAL + new_nodes + new_planes + ((size_t)new_points / m.slab + 1);
   int32_t *q = nullptr;
   HIPCHK(DMALLOC((void **)&q, new_total * 4));
-  HIPCHK(hipMemcpyAsync(q, m.counters, (size_t)MTC_TOTAL * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(q, m.counters, (size_t)MTC_TOTAL * 4, hipMemcpyDeviceToDevice, ctx->stream));
   // the three free stacks move to their new offsets (copied whole: their tops are the counters MTC_FREE_*)
-  HIPCHK(hipMemcpyAsync(q + MTC_TOTAL, m.counters + MTC_TOTAL, (size_t)m.cap_nodes * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(q + MTC_TOTAL + new_nodes, m.counters + MTC_TOTAL + m.cap_nodes, (size_t)m.cap_planes * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(q + MTC_TOTAL + new_nodes + new_planes, m.counters + MTC_TOTAL + m.cap_nodes + m.cap_planes, ((size_t)m.cap_points / m.slab + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(q + MTC_TOTAL, m.counters + MTC_TOTAL, (size_t)m.cap_nodes * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(q + MTC_TOTAL + new_nodes, m.counters + MTC_TOTAL + m.cap_nodes, (size_t)m.cap_planes * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(q + MTC_TOTAL + new_nodes + new_planes, m.counters + MTC_TOTAL + m.cap_nodes + m.cap_planes, ((size_t)m.cap_points / m.slab + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(DFREE(m.counters));
   m.counters = q;
@@ -1220,18 +1220,18 @@ int map_tree_grow(livo2_ctx *ctx, const int32_t *c) {
         if ((rc = grow_array(ctx, ctx->d_cand_aux, 0, (size_t)nc, false))) return rc;
         m.cap_cand = nc; m.cand = ctx->d_cand; m.cand_aux = ctx->d_cand_aux;
         err &= ~MTE_CAND;
-        HIPCHK(hipMemcpyAsync(m.counters + MTC_ERROR, &err, 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(devalloc::memcpy_async(m.counters + MTC_ERROR, &err, 4, hipMemcpyHostToDevice, ctx->stream));
       }
       HIPCHK(hipMemsetAsync(m.counters + MTC_CAND, 0, 4, ctx->stream));
       HIPCHK(hipMemsetAsync(m.counters + MTC_DIRTY, 0, 4, ctx->stream));
       MapTreeArgs a = m;
       hipLaunchKernelGGL(k_mt_all_roots_dirty, dim3((m.mask + 256) / 256), dim3(256), 0, ctx->stream, a);
       int32_t nd = 0;
-      HIPCHK(hipMemcpyAsync(&nd, m.counters + MTC_DIRTY, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(devalloc::memcpy_async(&nd, m.counters + MTC_DIRTY, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       if (nd > 0) hipLaunchKernelGGL(k_mt_emit, dim3(((size_t)nd * MT_LPG + 255) / 256), dim3(256), 0, ctx->stream, a);
-      HIPCHK(hipMemcpyAsync(&err, m.counters + MTC_ERROR, 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(&used, m.counters + MTC_CAND, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(devalloc::memcpy_async(&err, m.counters + MTC_ERROR, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(devalloc::memcpy_async(&used, m.counters + MTC_CAND, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       if (!(err & MTE_CAND)) break;
     }
@@ -1280,8 +1280,8 @@ int map_tree_grow(livo2_ctx *ctx, const int32_t *c) {
 
 int map_tree_finish(livo2_ctx *ctx) {
   int32_t c[MTC_COUNT], fr[5];
-  HIPCHK(hipMemcpyAsync(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(fr, ctx->mt.counters + MTC_FREE_NODES, sizeof(fr), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(c, ctx->mt.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(fr, ctx->mt.counters + MTC_FREE_NODES, sizeof(fr), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // what the next update may pop: the stacks as they are + the regions this update's frozen nodes released (joined to the stack before that update starts)
   ctx->mt.may_pop = (fr[0] > 0 ? 1 : 0) | (fr[1] > 0 ? 2 : 0) | (fr[2] > 0 ? 4 : 0);
@@ -1306,7 +1306,7 @@ int map_tree_finish(livo2_ctx *ctx) {
       if (cap_bits & MTE_PLANES) forced[MTC_PLANES] = ctx->mt.cap_planes;
       if (cap_bits & MTE_CAND) forced[MTC_CAND] = ctx->mt.cap_cand;
       const int32_t rest = c[MTC_ERROR] & ~cap_bits;
-      HIPCHK(hipMemcpyAsync(ctx->mt.counters + MTC_ERROR, &rest, 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(devalloc::memcpy_async(ctx->mt.counters + MTC_ERROR, &rest, 4, hipMemcpyHostToDevice, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       const int rc = map_tree_grow(ctx, forced);
       grown = rc == LIVO2_OK;
@@ -1330,8 +1330,8 @@ int livo2_map_tree_update(livo2_ctx *ctx, const double *point_w, const double *v
   if ((rc = ensure(ctx, ctx->mt_in_pw, ctx->mt_in_pw_cap, (size_t)std::max(n, 1) * 3))) return rc;
   if ((rc = ensure(ctx, ctx->mt_in_var, ctx->mt_in_var_cap, (size_t)std::max(n, 1) * 9))) return rc;
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->mt_in_pw, point_w, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->mt_in_var, var, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->mt_in_pw, point_w, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->mt_in_var, var, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   ctx->mt_pv_n = n;
@@ -1351,7 +1351,7 @@ int livo2_map_tree_update_from_scan(livo2_ctx *ctx, const livo2_state *state, co
   const int n = ctx->n;
   if ((rc = ensure(ctx, ctx->mt_in_pw, ctx->mt_in_pw_cap, (size_t)std::max(n, 1) * 3))) return rc;
   if ((rc = ensure(ctx, ctx->mt_in_var, ctx->mt_in_var_cap, (size_t)std::max(n, 1) * 9))) return rc;
-  HIPCHK(hipMemcpyAsync(ctx->mt_state, state, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->mt_state, state, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   if (n > 0) {
     MapPvArgs p{};
@@ -1373,8 +1373,8 @@ int livo2_map_tree_read_pv(livo2_ctx *ctx, double *point_w, double *var, int32_t
   if (capacity < ctx->mt_pv_n) return fail(ctx, LIVO2_ERR_INVALID, "capacity smaller than the pv_list");
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->mt_pv_n > 0) {
-    if (point_w) HIPCHK(hipMemcpyAsync(point_w, ctx->mt_in_pw, (size_t)ctx->mt_pv_n * 24, hipMemcpyDeviceToHost, ctx->stream));
-    if (var) HIPCHK(hipMemcpyAsync(var, ctx->mt_in_var, (size_t)ctx->mt_pv_n * 72, hipMemcpyDeviceToHost, ctx->stream));
+    if (point_w) HIPCHK(devalloc::memcpy_async(point_w, ctx->mt_in_pw, (size_t)ctx->mt_pv_n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (var) HIPCHK(devalloc::memcpy_async(var, ctx->mt_in_var, (size_t)ctx->mt_pv_n * 72, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LIVO2_OK;
@@ -1384,7 +1384,7 @@ int livo2_map_tree_stats(livo2_ctx *ctx, int32_t *counts) {
   if (!ctx) return LIVO2_ERR_INVALID;
   if (!ctx->tree_mode || !counts) return fail(ctx, LIVO2_ERR_INVALID, "no device map tree / counts is NULL");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(counts, ctx->mt.counters, MTC_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(counts, ctx->mt.counters, MTC_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LIVO2_OK;
 }
@@ -1418,7 +1418,7 @@ int livo2_map_tree_slide(livo2_ctx *ctx, const double *position_last, double sli
     hipLaunchKernelGGL(k_mt_slide, dim3((ctx->mt.mask + 256) / 256), dim3(256), 0, ctx->stream, ctx->mt, b);
     HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipMemcpyAsync(c, ctx->mt.counters + MTC_FREE_NODES, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(c, ctx->mt.counters + MTC_FREE_NODES, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->mt.may_pop = (c[0] > 0 ? 1 : 0) | (c[1] > 0 ? 2 : 0) | (c[2] > 0 ? 4 : 0);
   if (removed) *removed = slid ? c[3] : -1;
@@ -1437,10 +1437,10 @@ int livo2_map_tree_read_planes(livo2_ctx *ctx, const int32_t *rows, int32_t n, d
   int rc = ensure(ctx, ctx->mt_rp_rows, ctx->mt_rp_rows_cap, (size_t)n); if (rc) return rc;
   rc = ensure(ctx, ctx->mt_rp_out, ctx->mt_rp_out_cap, (size_t)n * PLANE_REC_DOUBLES); if (rc) return rc;
   int32_t *d_rows = ctx->mt_rp_rows; double *d_out = ctx->mt_rp_out;
-  HIPCHK(hipMemcpyAsync(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_mt_gather_planes, dim3((n * 32 + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_planes, d_rows, n, d_out);
   std::vector<double> recs((size_t)n * PLANE_REC_DOUBLES);
-  HIPCHK(hipMemcpyAsync(recs.data(), d_out, recs.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(recs.data(), d_out, recs.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (int p = 0; p < n; p++) {
     const double *rec = &recs[(size_t)p * PLANE_REC_DOUBLES];
@@ -1518,7 +1518,7 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
     }
     if (!ctx->scan_stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->scan_stage_ev[k], hipEventDisableTiming));
     std::memcpy(ctx->scan_stage[k], xyz, bytes);
-    HIPCHK(hipMemcpyAsync(ctx->d_xyz_aos, ctx->scan_stage[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_xyz_aos, ctx->scan_stage[k], bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipEventRecord(ctx->scan_stage_ev[k], ctx->stream));
     ctx->scan_stage_used[k] = true;
   }
@@ -1595,22 +1595,22 @@ int livo2_lidar_preprocess_scan(livo2_ctx *ctx, const float *xyz, const float *c
   *n_down = 0;
   if (n == 0) { rc = scan_pipeline(ctx, 0, cfg); if (rc) return rc; ctx->has_scan = true; ctx->mt_pv_n = -1; return LIVO2_OK; }
   static_assert(sizeof(livo2_imu_pose) == 22 * 8, "livo2_imu_pose is 22 doubles");
-  HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (n_poses > 0) HIPCHK(hipMemcpyAsync(ctx->d_poses, poses, (size_t)n_poses * sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_poses > 0) HIPCHK(devalloc::memcpy_async(ctx->d_poses, poses, (size_t)n_poses * sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   rc = preprocess_enqueue(ctx, n, n_poses, cfg, leaf_size, rot_end, pos_end, nullptr); if (rc) return rc;
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   int32_t misc[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(misc, ctx->d_vg_misc + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (feats_undistort) HIPCHK(hipMemcpyAsync(feats_undistort, ctx->d_raw, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(misc, ctx->d_vg_misc + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (feats_undistort) HIPCHK(devalloc::memcpy_async(feats_undistort, ctx->d_raw, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
   ctx->preprocess_kernel_us = 1e3 * ms;
   if (misc[0]) return fail(ctx, LIVO2_ERR_RANGE, "leaf size too small for the cloud: the voxel grid overflows int32 (pcl::VoxelGrid refuses it too)");
   const int m = misc[1];
-  if (feats_down_body && m > 0) HIPCHK(hipMemcpyAsync(feats_down_body, ctx->d_xyz_aos, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (feats_down_body && m > 0) HIPCHK(devalloc::memcpy_async(feats_down_body, ctx->d_xyz_aos, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
   rc = scan_pipeline(ctx, m, cfg); if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *n_down = m;
@@ -1641,7 +1641,7 @@ int livo2_lidar_iterate(livo2_ctx *ctx, const livo2_state *cur, const livo2_stat
   { Timed t(ctx, 0); launch_lidar_residual(ctx, a, 0); t.done(); }
   { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, 0, cfg->max_iterations, LptArgs{nullptr, nullptr, 0, 0} SOLVE_PROF_ARG); t.done(); }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->h_out, &ctx->d_ctl->sums_l, sizeof(livo2_lidar_sums), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(sums, ctx->h_out, sizeof(livo2_lidar_sums));
   return fetch_lidar_points(ctx, points);
@@ -1679,7 +1679,7 @@ int livo2_lidar_update_fetch(livo2_ctx *ctx, livo2_lidar_result *result, const l
   if (!ctx) return LIVO2_ERR_INVALID;
   if (!result) return fail(ctx, LIVO2_ERR_INVALID, "result is NULL");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->lidar, sizeof(livo2_lidar_result), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->h_out, &ctx->d_ctl->lidar, sizeof(livo2_lidar_result), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(result, ctx->h_out, sizeof(livo2_lidar_result));
   int rc = fetch_lidar_points(ctx, points);
@@ -1711,12 +1711,12 @@ int livo2_lio_frame(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu
   if (!ctx->d_imu_state) HIPCHK(DMALLOC((void **)&ctx->d_imu_state, 2 * sizeof(livo2_state)));
   if ((rc = preprocess_reserve(ctx, n, n_poses))) return rc;
   *n_down = 0;
-  HIPCHK(hipMemcpyAsync(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
-  if (n_steps > 0) HIPCHK(hipMemcpyAsync(ctx->d_imu_steps, steps, (size_t)n_steps * 64, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_poses, first_pose, sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));      // IMUpose[0] (IMU_Processing.cpp:312-313)
+  HIPCHK(devalloc::memcpy_async(ctx->d_imu_state, state_in, sizeof(livo2_state), hipMemcpyHostToDevice, ctx->stream));
+  if (n_steps > 0) HIPCHK(devalloc::memcpy_async(ctx->d_imu_steps, steps, (size_t)n_steps * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_poses, first_pose, sizeof(livo2_imu_pose), hipMemcpyHostToDevice, ctx->stream));      // IMUpose[0] (IMU_Processing.cpp:312-313)
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_raw, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_curv, curvature, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   // 1. forward propagation: d_imu_state[1] = state_propagat, IMUpose[1..] behind the first pose
   ImuKernelArgs ia = make_imu_args(ctx, imu_cfg, n_steps, ctx->d_poses + 22);
@@ -1725,9 +1725,9 @@ int livo2_lio_frame(livo2_ctx *ctx, const livo2_state *state_in, const livo2_imu
   // 2. backward propagation to the scan-end pose (read from the device state) + voxel grid
   if (n > 0) { rc = preprocess_enqueue(ctx, n, n_poses, cfg, leaf_size, nullptr, nullptr, ctx->d_imu_state + 1); if (rc) return rc; }
   int32_t misc[2] = {0, 0};
-  if (n > 0) HIPCHK(hipMemcpyAsync(misc, ctx->d_vg_misc + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (state_propagat) HIPCHK(hipMemcpyAsync(state_propagat, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
-  if (poses && n_steps > 0) HIPCHK(hipMemcpyAsync(poses, ctx->d_poses + 22, (size_t)n_steps * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
+  if (n > 0) HIPCHK(devalloc::memcpy_async(misc, ctx->d_vg_misc + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (state_propagat) HIPCHK(devalloc::memcpy_async(state_propagat, ctx->d_imu_state + 1, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
+  if (poses && n_steps > 0) HIPCHK(devalloc::memcpy_async(poses, ctx->d_poses + 22, (size_t)n_steps * sizeof(livo2_imu_pose), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));        // the leaf count sizes the launches of the update
   if (misc[0]) return fail(ctx, LIVO2_ERR_RANGE, "leaf size too small for the cloud: the voxel grid overflows int32 (pcl::VoxelGrid refuses it too)");
   const int m = misc[1];
@@ -1822,7 +1822,7 @@ int livo2_lidar_batch_set_scans(livo2_ctx *ctx, int32_t n_frames, const float *x
     HIPCHK(hipMemcpy(ctx->bd_block_frame, bf.data(), (size_t)blocks * 4, hipMemcpyHostToDevice));
   }
   if (total > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->bd_xyz_aos, xyz, (size_t)total * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->bd_xyz_aos, xyz, (size_t)total * 12, hipMemcpyHostToDevice, ctx->stream));
     const double deg2rad = cfg->deg2rad != 0.0 ? cfg->deg2rad : 0.017453293;
     int nmax = 0; for (int f = 0; f < n_frames; f++) nmax = std::max(nmax, counts[f]);
     size_t need = 0;
@@ -1875,8 +1875,8 @@ static int batch_enqueue(livo2_ctx *ctx, int32_t n_frames, const livo2_state *st
     std::memcpy(e.a.ER, cfg->extR, 72); std::memcpy(e.a.Et, cfg->extT, 24);
     e.ctl = ctx->bd_ctl + f; e.partials = ctx->bd_partials + (size_t)ctx->b_block_begin[f] * 32; e.block_begin = ctx->b_block_begin[f]; e.nblocks = ctx->b_grid[f];
   }
-  HIPCHK(hipMemcpyAsync(ctx->bd_in, ctx->bh_in, sizeof(HostIn) * n_frames, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->bd_entries, ctx->bh_entries, sizeof(LidarBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->bd_in, ctx->bh_in, sizeof(HostIn) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->bd_entries, ctx->bh_entries, sizeof(LidarBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_batch_scatter_in, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_in, ctx->bd_ctl);
   for (int it = 0; it < iters; it++) {
     { Timed t(ctx, 0); hipLaunchKernelGGL(k_lidar_residual_batch, dim3(ctx->b_blocks), dim3(LIDAR_BLOCK_BATCH), LIDAR_LDS_BYTES_OF(LIDAR_BLOCK_BATCH) + LIDAR_LDS_DUMP, ctx->stream, ctx->bd_entries, ctx->bd_block_frame, mode == 1 ? 1 : 0); t.done(); }
@@ -1898,7 +1898,7 @@ int livo2_lidar_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_lidar
   if (!results) return fail(ctx, LIVO2_ERR_INVALID, "results is NULL");
   if (!ctx->has_batch || n_frames != ctx->bn) return fail(ctx, LIVO2_ERR_INVALID, "n_frames differs from the batch set by livo2_lidar_batch_set_scans");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(ctx->bh_results, ctx->bd_results, sizeof(livo2_lidar_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->bh_results, ctx->bd_results, sizeof(livo2_lidar_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(results, ctx->bh_results, sizeof(livo2_lidar_result) * n_frames);
   return rz_gate(ctx);
@@ -1938,12 +1938,12 @@ int livo2_visual_set_frame(livo2_ctx *ctx, const uint8_t *img, int32_t width, in
   rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)M * L * 64, (size_t)64)); if (rc) return rc;
   const int grid = visual_grid_inverse(std::max(M, 1));     // the larger of the two grids
   rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * VIS_PSTRIDE, (size_t)64)); if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(ctx->d_img, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_img, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream));
   if (M > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_pos, pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_warp, warp_patch, (size_t)M * L * 256, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_search, search_levels, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_invexpo, inv_expo_list, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_pos, pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_warp, warp_patch, (size_t)M * L * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_search, search_levels, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_invexpo, inv_expo_list, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->width = width; ctx->height = height; ctx->stride = stride; ctx->M = M; ctx->L = L;
@@ -1972,13 +1972,13 @@ int livo2_visual_set_reference(livo2_ctx *ctx, const uint8_t *ref_imgs, int32_t 
     HIPCHK(DMALLOC((void **)&ctx->d_gref, cap * 64 * 16)); HIPCHK(DMALLOC((void **)&ctx->d_mref, cap * 16 * 8));
     ctx->ref_cap = (int)cap;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
   if (M > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_ref_idx, ref_img_idx, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ref_px, ref_px, (size_t)M * 16, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ref_f, ref_f, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ref_R, ref_R, (size_t)M * 72, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ref_pos, ref_pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ref_idx, ref_img_idx, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ref_px, ref_px, (size_t)M * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ref_f, ref_f, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ref_R, ref_R, (size_t)M * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ref_pos, ref_pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n_ref = n_ref;
@@ -2000,8 +2000,8 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
   if (!ctx->d_sel_flag) HIPCHK(DMALLOC((void **)&ctx->d_sel_flag, 64));
   HIPCHK(hipMemsetAsync(ctx->d_sel_flag, 0, 64, ctx->stream));
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_vm_pos, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    if (active) HIPCHK(hipMemcpyAsync(ctx->d_vm_active, active, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_vm_pos, pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (active) HIPCHK(devalloc::memcpy_async(ctx->d_vm_active, active, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     else HIPCHK(hipMemsetAsync(ctx->d_vm_active, 1, (size_t)n, ctx->stream));
     if (voxel_key) {
       std::vector<unsigned long long> pk((size_t)n);
@@ -2018,7 +2018,7 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
     }
   }
   int32_t flag = 0;
-  HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (flag) return fail(ctx, LIVO2_ERR_RANGE, "visual voxel key outside 21 bits per axis");
   ctx->n_vm = n; ctx->has_vmap = true;
@@ -2083,16 +2083,16 @@ int livo2_visual_select(livo2_ctx *ctx, const double *pg, int32_t n_pg, const li
   size_t cap = 0;
   int rc = select_reserve(ctx, cfg, n_pg, &cap); if (rc) return rc;
   const int length = cfg->grid_n_width * cfg->grid_n_height;
-  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
+  if (n_pg > 0) HIPCHK(devalloc::memcpy_async(ctx->d_sel_pg, pg, (size_t)n_pg * 24, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   if ((rc = select_enqueue(ctx, cfg, n_pg, cap))) return rc;
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   int32_t flag = 0;
-  HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(cell_point, ctx->d_sel_point, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (cell_dist) HIPCHK(hipMemcpyAsync(cell_dist, ctx->d_sel_dist, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (cell_disc) HIPCHK(hipMemcpyAsync(cell_disc, ctx->d_sel_disc, (size_t)length, hipMemcpyDeviceToHost, ctx->stream));
-  if (point_in_fov && ctx->n_vm > 0) HIPCHK(hipMemcpyAsync(point_in_fov, ctx->d_vm_fov, (size_t)ctx->n_vm, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(cell_point, ctx->d_sel_point, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (cell_dist) HIPCHK(devalloc::memcpy_async(cell_dist, ctx->d_sel_dist, (size_t)length * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (cell_disc) HIPCHK(devalloc::memcpy_async(cell_disc, ctx->d_sel_disc, (size_t)length, hipMemcpyDeviceToHost, ctx->stream));
+  if (point_in_fov && ctx->n_vm > 0) HIPCHK(devalloc::memcpy_async(point_in_fov, ctx->d_vm_fov, (size_t)ctx->n_vm, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
@@ -2174,12 +2174,12 @@ static int tail_enqueue(livo2_ctx *ctx, const livo2_retrieve_cfg *cfg, int width
 // per-candidate outputs of the tail stage -> host (n candidates)
 static int tail_fetch(livo2_ctx *ctx, const livo2_retrieve_out *out, int n, int L) {
   if (!out || n <= 0) return LIVO2_OK;
-  if (out->accepted) HIPCHK(hipMemcpyAsync(out->accepted, ctx->d_c_acc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out->search_level) HIPCHK(hipMemcpyAsync(out->search_level, ctx->d_c_sl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out->error) HIPCHK(hipMemcpyAsync(out->error, ctx->d_c_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out->ncc) HIPCHK(hipMemcpyAsync(out->ncc, ctx->d_c_ncc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (out->A_cur_ref) HIPCHK(hipMemcpyAsync(out->A_cur_ref, ctx->d_c_A, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  if (out->patch_wrap) HIPCHK(hipMemcpyAsync(out->patch_wrap, ctx->d_c_patch, (size_t)n * L * 256, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->accepted) HIPCHK(devalloc::memcpy_async(out->accepted, ctx->d_c_acc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->search_level) HIPCHK(devalloc::memcpy_async(out->search_level, ctx->d_c_sl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->error) HIPCHK(devalloc::memcpy_async(out->error, ctx->d_c_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->ncc) HIPCHK(devalloc::memcpy_async(out->ncc, ctx->d_c_ncc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->A_cur_ref) HIPCHK(devalloc::memcpy_async(out->A_cur_ref, ctx->d_c_A, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (out->patch_wrap) HIPCHK(devalloc::memcpy_async(out->patch_wrap, ctx->d_c_patch, (size_t)n * L * 256, hipMemcpyDeviceToHost, ctx->stream));
   return LIVO2_OK;
 }
 
@@ -2204,25 +2204,25 @@ int livo2_visual_retrieve_warp(livo2_ctx *ctx, const uint8_t *img, int32_t width
   int rc = ensure(ctx, ctx->d_img, ctx->img_cap, img_bytes); if (rc) return rc;
   if (n > 0) { rc = ensure(ctx, ctx->d_ref_imgs, ctx->ref_img_cap, img_bytes * n_ref); if (rc) return rc; }
   if ((rc = tail_reserve(ctx, n, L))) return rc;
-  HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
   int32_t count = 0;
   ctx->retrieve_kernel_us = 0.0;
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_pos, cand->pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_normal, cand->normal, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_px, cand->ref_px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_f, cand->ref_f, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_R, cand->ref_R, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_t, cand->ref_t, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_ie, cand->ref_inv_expo, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_idx, cand->ref_img_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_c_lvl, cand->ref_level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (cand->ref_id) HIPCHK(hipMemcpyAsync(ctx->d_c_id, cand->ref_id, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ref_imgs, ref_imgs, img_bytes * n_ref, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_pos, cand->pos, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_normal, cand->normal, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_px, cand->ref_px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_f, cand->ref_f, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_R, cand->ref_R, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_t, cand->ref_t, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_ie, cand->ref_inv_expo, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_idx, cand->ref_img_idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_c_lvl, cand->ref_level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (cand->ref_id) HIPCHK(devalloc::memcpy_async(ctx->d_c_id, cand->ref_id, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
     if ((rc = tail_enqueue(ctx, cfg, width, height, stride, ctx->d_ref_imgs, n, nullptr, cand->ref_id != nullptr, nullptr, nullptr))) return rc;
     HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&count, ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(&count, ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = tail_fetch(ctx, out, n, L))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -2277,23 +2277,23 @@ int livo2_visual_obs_upload(livo2_ctx *ctx, const livo2_visual_obs *o) {
   if ((rc = ensure(ctx, ctx->d_vm_ninit, ctx->vm_ninit_cap, n1))) return rc;
   if ((rc = ensure(ctx, ctx->d_vm_refpatch, ctx->vm_refpatch_cap, n1))) return rc;
   if ((rc = ensure(ctx, ctx->d_ob_imgs, ctx->ob_imgs_cap, std::max(img_bytes * (size_t)o->n_ref, (size_t)64)))) return rc;
-  HIPCHK(hipMemcpyAsync(ctx->d_ob_off, o->point_offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_ob_off, o->point_offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_vm_normal, o->normal, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_vm_ninit, o->normal_initialized, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_vm_refpatch, o->ref_patch, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_vm_normal, o->normal, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_vm_ninit, o->normal_initialized, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_vm_refpatch, o->ref_patch, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   if (m > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_id, o->id, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_img, o->img_idx, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_lvl, o->level, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_px, o->px, (size_t)m * 16, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_f, o->f, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_R, o->R, (size_t)m * 72, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_t, o->t, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_ie, o->inv_expo, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_patch, o->patch, (size_t)m * 256, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_ob_imgs, o->ref_imgs, img_bytes * (size_t)o->n_ref, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_id, o->id, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_img, o->img_idx, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_lvl, o->level, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_px, o->px, (size_t)m * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_f, o->f, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_R, o->R, (size_t)m * 72, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_t, o->t, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_ie, o->inv_expo, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_patch, o->patch, (size_t)m * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_ob_imgs, o->ref_imgs, img_bytes * (size_t)o->n_ref, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n_obs = m; ctx->ob_n_ref = o->n_ref; ctx->ob_w = o->width; ctx->ob_h = o->height; ctx->ob_stride = o->stride;
@@ -2334,8 +2334,8 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if ((rc = ensure(ctx, ctx->d_sub_point, ctx->sub_point_cap, len))) return rc;
   if ((rc = ensure(ctx, ctx->d_sub_obs, ctx->sub_obs_cap, len))) return rc;
   if (!ctx->d_ch_count) HIPCHK(DMALLOC((void **)&ctx->d_ch_count, 64));
-  HIPCHK(hipMemcpyAsync(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
-  if (n_pg > 0) HIPCHK(hipMemcpyAsync(ctx->d_sel_pg, pg_resident ? ctx->mt_in_pw : pg, (size_t)n_pg * 24, pg_resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (n_pg > 0) HIPCHK(devalloc::memcpy_async(ctx->d_sel_pg, pg_resident ? ctx->mt_in_pw : pg, (size_t)n_pg * 24, pg_resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->span0, ctx->stream));
   // 1. selection
   if ((rc = select_enqueue(ctx, sel, n_pg, cap))) return rc;
@@ -2360,9 +2360,9 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if ((rc = tail_enqueue(ctx, cfg, width, height, stride, ctx->d_ob_imgs, length, ctx->d_ch_count, true, ctx->d_cand_point, ctx->d_cand_obs))) return rc;
   HIPCHK(hipEventRecord(ctx->span1, ctx->stream));
   int32_t counts[2] = {0, 0}, flag = 0;
-  HIPCHK(hipMemcpyAsync(&counts[0], ctx->d_ch_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&counts[1], ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&counts[0], ctx->d_ch_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&counts[1], ctx->d_c_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, ctx->span0, ctx->span1));
@@ -2370,15 +2370,15 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   if (flag) return fail(ctx, LIVO2_ERR_RANGE, "scan voxel key outside 21 bits per axis");
   const int nc = counts[0], na = counts[1];
   if (out) {
-    if (out->cell_point) HIPCHK(hipMemcpyAsync(out->cell_point, ctx->d_sel_point, len * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->cell_dist) HIPCHK(hipMemcpyAsync(out->cell_dist, ctx->d_sel_dist, len * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->cell_discontinuous) HIPCHK(hipMemcpyAsync(out->cell_discontinuous, ctx->d_sel_disc, len, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->cell_obs) HIPCHK(hipMemcpyAsync(out->cell_obs, ctx->d_ch_obs, len * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->ref_patch && ctx->n_vm > 0) HIPCHK(hipMemcpyAsync(out->ref_patch, ctx->d_vm_refpatch, (size_t)ctx->n_vm * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->cand_cell && nc > 0) HIPCHK(hipMemcpyAsync(out->cand_cell, ctx->d_cand_cell, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_point) HIPCHK(devalloc::memcpy_async(out->cell_point, ctx->d_sel_point, len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_dist) HIPCHK(devalloc::memcpy_async(out->cell_dist, ctx->d_sel_dist, len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_discontinuous) HIPCHK(devalloc::memcpy_async(out->cell_discontinuous, ctx->d_sel_disc, len, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cell_obs) HIPCHK(devalloc::memcpy_async(out->cell_obs, ctx->d_ch_obs, len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->ref_patch && ctx->n_vm > 0) HIPCHK(devalloc::memcpy_async(out->ref_patch, ctx->d_vm_refpatch, (size_t)ctx->n_vm * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cand_cell && nc > 0) HIPCHK(devalloc::memcpy_async(out->cand_cell, ctx->d_cand_cell, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = tail_fetch(ctx, &out->tail, nc, L))) return rc;
-    if (out->sub_point && na > 0) HIPCHK(hipMemcpyAsync(out->sub_point, ctx->d_sub_point, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->sub_obs && na > 0) HIPCHK(hipMemcpyAsync(out->sub_obs, ctx->d_sub_obs, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->sub_point && na > 0) HIPCHK(devalloc::memcpy_async(out->sub_point, ctx->d_sub_point, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->sub_obs && na > 0) HIPCHK(devalloc::memcpy_async(out->sub_obs, ctx->d_sub_obs, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   if (n_candidates) *n_candidates = nc;
@@ -2430,10 +2430,10 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   }
   { Timed t(ctx, 3); hipLaunchKernelGGL(k_visual_solve, dim3(1), dim3(512), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, 0, level, 0, cfg->img_point_cov, visual_solve_args(ctx, cfg)); t.done(); }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->sums_v, sizeof(livo2_visual_sums), hipMemcpyDeviceToHost, ctx->stream));
-  if (errors && M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (z && M > 0) HIPCHK(hipMemcpyAsync(z, ctx->d_zdbg, (size_t)M * 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (H_sub && M > 0) HIPCHK(hipMemcpyAsync(H_sub, ctx->d_Hdbg, (size_t)M * 64 * 56, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->h_out, &ctx->d_ctl->sums_v, sizeof(livo2_visual_sums), hipMemcpyDeviceToHost, ctx->stream));
+  if (errors && M > 0) HIPCHK(devalloc::memcpy_async(errors, ctx->d_errors, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (z && M > 0) HIPCHK(devalloc::memcpy_async(z, ctx->d_zdbg, (size_t)M * 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (H_sub && M > 0) HIPCHK(devalloc::memcpy_async(H_sub, ctx->d_Hdbg, (size_t)M * 64 * 56, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(sums, ctx->h_out, sizeof(livo2_visual_sums));
   return LIVO2_OK;
@@ -2519,10 +2519,10 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
   if (!ctx) return LIVO2_ERR_INVALID;
   if (!result) return fail(ctx, LIVO2_ERR_INVALID, "result is NULL");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
-  if (errors && ctx->M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
+  if (errors && ctx->M > 0) HIPCHK(devalloc::memcpy_async(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
   int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(ctx->h_out) + sizeof(livo2_visual_result));
-  HIPCHK(hipMemcpyAsync(flag, &ctx->d_ctl->hdr.pad[0], 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(flag, &ctx->d_ctl->hdr.pad[0], 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (*flag) {
     // the resident grid gave up (a block was not co-resident: another process or a long foreign kernel held its CU) and committed nothing.  Re-run the update as the
@@ -2535,8 +2535,8 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
     const int rc = visual_enqueue(ctx, &in, &pr, &vc, vc.patch_pyrimid_level - 1, 0, vc.max_iterations, 1);
     ctx->vp_rerun = false;
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
-    if (errors && ctx->M > 0) HIPCHK(hipMemcpyAsync(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (errors && ctx->M > 0) HIPCHK(devalloc::memcpy_async(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   std::memcpy(result, ctx->h_out, sizeof(livo2_visual_result));
@@ -2611,12 +2611,12 @@ int livo2_visual_batch_set_frames(livo2_ctx *ctx, int32_t n_frames, const uint8_
     for (int f = 0; f < n_frames; f++) std::fill(bf.begin() + ctx->vb_block_begin[f], bf.begin() + ctx->vb_block_begin[f] + ctx->vb_grid[f], f);
     HIPCHK(hipMemcpy(ctx->vbd_block_frame, bf.data(), (size_t)blocks * 4, hipMemcpyHostToDevice));
   }
-  HIPCHK(hipMemcpyAsync(ctx->vbd_img, imgs, img_bytes * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->vbd_img, imgs, img_bytes * n_frames, hipMemcpyHostToDevice, ctx->stream));
   if (total > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->vbd_pos, pos, (size_t)total * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->vbd_warp, warp_patch, (size_t)total * L * 256, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->vbd_search, search_levels, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->vbd_invexpo, inv_expo_list, (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->vbd_pos, pos, (size_t)total * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->vbd_warp, warp_patch, (size_t)total * L * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->vbd_search, search_levels, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->vbd_invexpo, inv_expo_list, (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->has_vbatch = true;
@@ -2652,8 +2652,8 @@ static int vbatch_enqueue(livo2_ctx *ctx, int32_t n_frames, const livo2_state *s
     e.ctl = ctx->bd_ctl + f; e.partials = ctx->vbd_partials + (size_t)ctx->vb_block_begin[f] * VIS_PSTRIDE; e.block_begin = ctx->vb_block_begin[f]; e.nblocks = ctx->vb_grid[f];
   }
   ctx->M = keepM; ctx->L = keepL;
-  HIPCHK(hipMemcpyAsync(ctx->bd_in, ctx->bh_in, sizeof(HostIn) * n_frames, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->vbd_entries, ctx->vbh_entries, sizeof(VisualBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->bd_in, ctx->bh_in, sizeof(HostIn) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->vbd_entries, ctx->vbh_entries, sizeof(VisualBatchEntry) * n_frames, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_batch_scatter_in, dim3(n_frames), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->bd_in, ctx->bd_ctl);
   for (int level = level_hi; level >= level_lo; level--)
     for (int it = 0; it < iters; it++) {
@@ -2675,7 +2675,7 @@ int livo2_visual_batch_update_fetch(livo2_ctx *ctx, int32_t n_frames, livo2_visu
   if (!results) return fail(ctx, LIVO2_ERR_INVALID, "results is NULL");
   if (!ctx->has_vbatch || n_frames != ctx->vbn) return fail(ctx, LIVO2_ERR_INVALID, "n_frames differs from the batch set by livo2_visual_batch_set_frames");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(ctx->vbh_results, ctx->vbd_results, sizeof(livo2_visual_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->vbh_results, ctx->vbd_results, sizeof(livo2_visual_result) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memcpy(results, ctx->vbh_results, sizeof(livo2_visual_result) * n_frames);
   return rz_gate(ctx);
@@ -2725,13 +2725,13 @@ int livo2_esikf_solve(livo2_ctx *ctx, const double *HtH, const double *Htz, int3
   if (!HtH || !Htz || !cur || !prop || (k != 6 && k != 7) || !(meas_cov_scale > 0) || (sign != 1 && sign != -1)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
   int rc = upload_states(ctx, cur, prop); if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(ctx->d_ctl->solve_hth, HtH, (size_t)k * k * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_ctl->solve_htz, Htz, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_ctl->solve_hth, HtH, (size_t)k * k * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(ctx->d_ctl->solve_htz, Htz, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
   { Timed t(ctx, 2); hipLaunchKernelGGL(k_esikf_solve_only, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, k, meas_cov_scale, sign); t.done(); }
   HIPCHK(hipGetLastError());
-  if (out_state) HIPCHK(hipMemcpyAsync(out_state, &ctx->d_ctl->cur, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
-  if (solution) HIPCHK(hipMemcpyAsync(solution, ctx->d_ctl->solve_solution, DS * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (G) HIPCHK(hipMemcpyAsync(G, ctx->d_ctl->G, DS * DS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_state) HIPCHK(devalloc::memcpy_async(out_state, &ctx->d_ctl->cur, sizeof(livo2_state), hipMemcpyDeviceToHost, ctx->stream));
+  if (solution) HIPCHK(devalloc::memcpy_async(solution, ctx->d_ctl->solve_solution, DS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (G) HIPCHK(devalloc::memcpy_async(G, ctx->d_ctl->G, DS * DS * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LIVO2_OK;
 }

@@ -2,7 +2,8 @@
 mode 1: the smoke sequence (LiDAR update, visual update as one resident grid and per step, batches, plane fits, retrieval chain, device-resident map build +
         update) + a 3-context C5 pass with every guard of every device allocation checked; then the checker is shown to work: a store 0 / 300 bytes behind and
         4 bytes in front of the control block must be reported with the allocation's source line.
-mode 2 / 3: the same sequence with every allocation ending / starting at unmapped address space: an out-of-bounds READ aborts the process."""
+With LIVO2_POISON set as well every new allocation is filled with that byte first: the results (checked against the oracle by smoke(), and 1 context == 3 contexts)
+must not change.  (mode 2 / 3 run the same sequence on hipMemMap'ed allocations; not part of the suite, see tests/test_redzone_gpu.py.)"""
 import importlib
 import os
 import sys
