@@ -843,28 +843,34 @@ __device__ inline void lidar_block_order_wave(const LptArgs &lpt, uint32_t *hist
 }
 
 __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
-                                                 int max_iter, const LptArgs &lpt SOLVE_PROF_PARAM) {
+                                                 int max_iter, const LptArgs &lpt, const bool order_block SOLVE_PROF_PARAM) {
   SPHASE(0);
   __shared__ SolveLds s;
   __shared__ double scratch[16 * 33];
   __shared__ double sums[32];
   __shared__ uint32_t lpt_hist[64], lpt_fill[64];
+  // The block order of the next residual launch is the work of a SECOND block (blockIdx 1, one wave; the host launches it only when an order is wanted): round 3 ran
+  // it on an otherwise idle wave of THIS block, and on some boxes the solve went from 8.7 to 13.3 us (profiles/r03_lidar_block_order_ab.txt) — the sort's ~1 000 LDS
+  // atomics and 16 loads per lane share the CU's LDS and its memory pipeline with the wave whose latency chain is the critical path of the iteration.  On its own CU
+  // it costs the solve nothing and ends well inside the solve's shadow.
+  if (order_block) {
+    if (threadIdx.x < LIVO2_WAVE && lpt.order && !(mode == 1 && ctl->hdr.stop)) {
+      uint32_t lpt_cc[LPT_MAX_CHUNKS / LIVO2_WAVE];
+      lidar_block_order_load(lpt, threadIdx.x, lpt_cc);
+      lidar_block_order_wave(lpt, lpt_hist, lpt_fill, threadIdx.x, lpt_cc);
+    }
+    return;
+  }
   // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
   const int hdr_stop = ctl->hdr.stop, hdr_rematch = ctl->hdr.rematch_num;
   double craw[6];
   if (mode != 0 && threadIdx.x < LIVO2_WAVE) esikf_prefetch_wave(ctl, s, 1.0, threadIdx.x, craw);
   if (mode != 0 && threadIdx.x == LIVO2_WAVE) esikf_log_lane(ctl, s);                   // second wave: overlaps the partial rows
-  const bool lpt_wave = lpt.order && (threadIdx.x >> 6) == SOLVE_THREADS / LIVO2_WAVE - 1;       // last wave: the block order of the next residual launch
-  uint32_t lpt_cc[LPT_MAX_CHUNKS / LIVO2_WAVE];
-  if (lpt_wave) lidar_block_order_load(lpt, threadIdx.x & 63, lpt_cc);
   SPHASE(1);
   reduce_partials_block(partials, nblocks, scratch, sums);
   SPHASE(2);
   if (mode == 1 && hdr_stop) return;
-  if (threadIdx.x >= LIVO2_WAVE) {                   // the 19-dim algebra is one wave: wave-local synchronisation only from here on
-    if (lpt_wave) lidar_block_order_wave(lpt, lpt_hist, lpt_fill, threadIdx.x & 63, lpt_cc);
-    return;
-  }
+  if (threadIdx.x >= LIVO2_WAVE) return;             // the 19-dim algebra is one wave: wave-local synchronisation only from here on
   const int lane = threadIdx.x;
   // expand symmetric 21 -> 6x6
   if (lane < 36) {
@@ -921,9 +927,9 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
 __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
                                                               int max_iter, LptArgs lpt SOLVE_PROF_PARAM) {
 #ifdef LIVO2_PHASE_PROF
-  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, lpt, sprof);
+  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, lpt, blockIdx.x == 1, sprof);
 #else
-  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, lpt);
+  lidar_solve_body(ctl, partials, nblocks, mode, iter, max_iter, lpt, blockIdx.x == 1);
 #endif
 }
 
@@ -931,9 +937,9 @@ __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restric
 __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve_batch(const LidarBatchEntry *__restrict__ entries, int mode, int iter, int max_iter) {
   const LidarBatchEntry &e = entries[blockIdx.x];
 #ifdef LIVO2_PHASE_PROF
-  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, LptArgs{nullptr, nullptr, 0, 0}, nullptr);
+  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, LptArgs{nullptr, nullptr, 0, 0}, false, nullptr);
 #else
-  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, LptArgs{nullptr, nullptr, 0, 0});
+  lidar_solve_body(e.ctl, e.partials, e.nblocks, mode, iter, max_iter, LptArgs{nullptr, nullptr, 0, 0}, false);
 #endif
 }
 

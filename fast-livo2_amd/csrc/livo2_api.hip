@@ -1660,7 +1660,7 @@ static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int it
   const LptArgs lpt = lidar_lpt_on(ctx, grid) ? LptArgs{ctx->d_lpt_cost, ctx->d_lpt_order, grid, 0} : LptArgs{nullptr, nullptr, 0, 0};
   for (int it = 0; it < iters; it++) {
     { Timed t(ctx, 0); launch_lidar_residual(ctx, a, mode == 1 ? 1 : 0); t.done(); }
-    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30), lpt SOLVE_PROF_ARG); t.done(); }
+    { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(lpt.order ? 2 : 1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30), lpt SOLVE_PROF_ARG); t.done(); }
     if (lpt.order) ctx->lpt_valid = true;                          // the launches enqueued from here on read the order this solve writes
   }
   if (mode != 1 || iters < 1) hipLaunchKernelGGL(k_lidar_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl);       // mode 1: the stopping iteration has written the result block
