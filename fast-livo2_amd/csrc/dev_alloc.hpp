@@ -52,7 +52,7 @@ __global__ void k_rz_fill(uint32_t *p, size_t words) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = RZ_WORD;
 }
 struct RzDesc { const uint32_t *guard; int id; int side; };
-struct RzOut { unsigned long long bad_words; int first_id; int first_side; long long first_byte; int lock; int pad; };
+struct RzOut { unsigned long long bad_words; int first_id; int first_side; long long first_byte; int lock; int pad; long long last_byte; uint32_t sample[8]; };
 __global__ void k_rz_scan(const RzDesc *d, RzOut *out) {
   const RzDesc g = d[blockIdx.x];
   unsigned long long bad = 0; long long first = -1;
@@ -60,7 +60,12 @@ __global__ void k_rz_scan(const RzDesc *d, RzOut *out) {
     if (g.guard[i] != RZ_WORD) { bad++; if (first < 0) first = (long long)i * 4; }
   if (bad) {
     atomicAdd(&out->bad_words, bad);
-    if (atomicCAS(&out->lock, 0, 1) == 0) { out->first_id = g.id; out->first_side = g.side; out->first_byte = first; }
+    if (atomicCAS(&out->lock, 0, 1) == 0) {                       // (one thread of one block describes its guard: extent of the damage and the first damaged words)
+      out->first_id = g.id; out->first_side = g.side;
+      long long lo = -1, hi = -1; int ns = 0;
+      for (size_t i = 0; i < RZ_GUARD / 4; i++) if (g.guard[i] != RZ_WORD) { if (lo < 0) lo = (long long)i * 4; hi = (long long)i * 4; if (ns < 8) out->sample[ns++] = g.guard[i]; }
+      out->first_byte = lo; out->last_byte = hi;
+    }
   }
 }
 
@@ -139,8 +144,10 @@ inline hipError_t dev_free(void *p) {
   if (!p) return hipSuccess;
   if (mode() == 0) return hipFree(p);
   Rec r;
+  // the lock is held until the memory is gone: check() (another host thread, another context) scans the guards of every allocation in the table and must never look
+  // at one that is being freed — its address may already belong to a new, larger allocation whose user bytes would then be taken for a damaged guard
+  std::lock_guard<std::mutex> lk(mtx());
   {
-    std::lock_guard<std::mutex> lk(mtx());
     auto it = table().find(p);
     if (it == table().end()) return hipFree(p);
     r = it->second; table().erase(it);
@@ -159,8 +166,8 @@ inline long long check(char *msg, size_t msg_len) {
   if (msg && msg_len) msg[0] = 0;
   if (mode() != 1) return 0;
   std::vector<RzDesc> desc; std::vector<Rec> recs; std::vector<void *> users;
+  std::lock_guard<std::mutex> lk(mtx());                      // held to the end: no allocation of the table is freed (or its address re-used) while its guards are read
   {
-    std::lock_guard<std::mutex> lk(mtx());
     for (auto &kv : table()) {
       const Rec &r = kv.second;
       const int id = (int)recs.size();
@@ -190,7 +197,8 @@ inline long long check(char *msg, size_t msg_len) {
     if (hipMemcpy(w, (char *)users[i] + start, body - start, hipMemcpyDeviceToHost) != hipSuccess) continue;
     for (size_t k = 0; k < (body - start) / 4; k++) if (w[k] != RZ_WORD) { tail_bad++; if (tail_id < 0) { tail_id = (int)i; tail_off = (long long)(start + 4 * k - r.bytes); } }
   }
-  e = hipFree(d_desc); e = hipFree(d_out); (void)e;
+  e = hipFree(d_desc); e = hipFree(d_out);
+  e = hipGetLastError(); (void)e;                              // leave no error of the checker's own calls behind: the caller's next library call (rocPRIM) reads the thread's last error
   const long long bad = (long long)out.bad_words + tail_bad;
   if (bad && msg && msg_len) {
     if (tail_id >= 0)
@@ -199,8 +207,9 @@ inline long long check(char *msg, size_t msg_len) {
       const Rec &r = recs[out.first_id];
       if (out.first_side == 0) snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B IN FRONT of its start (%llu damaged words in all)",
                                         r.bytes, r.line, (long long)RZ_GUARD - out.first_byte, out.bad_words);
-      else snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B BEHIND its end (%llu damaged words in all)", r.bytes, r.line,
-                    (long long)(r.mapped - 2 * RZ_GUARD - r.bytes) + out.first_byte, out.bad_words);
+      else snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld .. %lld B BEHIND its end (%llu damaged words in all; first words %08x %08x %08x %08x %08x %08x)", r.bytes, r.line,
+                    (long long)(r.mapped - 2 * RZ_GUARD - r.bytes) + out.first_byte, (long long)(r.mapped - 2 * RZ_GUARD - r.bytes) + out.last_byte, out.bad_words,
+                    out.sample[0], out.sample[1], out.sample[2], out.sample[3], out.sample[4], out.sample[5]);
     }
   }
   return bad;
