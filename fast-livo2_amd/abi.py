@@ -92,7 +92,7 @@ class LidarSums(C.Structure):
 class LidarPoints(C.Structure):
     _fields_ = [("match_plane", C.POINTER(C.c_int32)), ("dis_to_plane", C.POINTER(C.c_float)), ("point_w", C.POINTER(C.c_float)),
                 ("normal_plane", C.POINTER(C.c_int32)), ("var", C.POINTER(C.c_double)), ("body_cov", C.POINTER(C.c_double)),
-                ("r_inv", C.POINTER(C.c_double)), ("h_row", C.POINTER(C.c_double))]
+                ("r_inv", C.POINTER(C.c_double)), ("h_row", C.POINTER(C.c_double)), ("pinned", C.c_int64)]
 
 
 class LidarResult(C.Structure):

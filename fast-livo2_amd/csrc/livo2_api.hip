@@ -451,8 +451,8 @@ int fetch_lidar_points(livo2_ctx *ctx, const livo2_lidar_points *p) {
   size_t total = 0;
   for (const Item &it : items) if (it.dst) total += (it.bytes + 63) & ~(size_t)63;
   if (total == 0) return LIVO2_OK;
-  if (total > ((size_t)8 << 20)) {
-    // large outputs (C4: 168 B x 200 000 points = 34 MB): copy straight into the caller's arrays — the runtime pipelines a pageable D2H through its own pinned
+  if (p->pinned || total > ((size_t)8 << 20)) {
+    // page-locked destinations (p->pinned), or large outputs (C4: 168 B x 200 000 points = 34 MB): copy straight into the caller's arrays — the runtime pipelines a pageable D2H through its own pinned
     // chunks while it copies the previous chunk out, which a stage-everything-then-memcpy scheme does not (measured: 3.0 ms against 3.8 ms per C4 frame)
     for (int k = 0; k < NITEMS; k++) if (items[k].dst && items[k].bytes) HIPCHK(devalloc::memcpy_async(items[k].dst, items[k].src, items[k].bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

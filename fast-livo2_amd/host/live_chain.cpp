@@ -15,6 +15,7 @@
 //         live_sub_pos.bin: pos_ of visual_submap->voxel_points, frame after frame.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -180,6 +181,7 @@ int main(int argc, char **argv) {
     auto wr = [&](const char *name, const void *p, size_t bytes) { std::ofstream o(dir + "/" + name, std::ios::binary); o.write((const char *)p, bytes); };
     wr("live_out.bin", stage.data(), stage.size() * 8); wr("live_states.bin", states.data(), states.size() * 8);
     wr("live_counts.bin", counts.data(), counts.size() * 4); wr("live_sub_pos.bin", sub_pos.data(), sub_pos.size() * 8);
+    if (std::getenv("LIVO2_SHIM_PROF")) for (size_t f = 0; f < F; f++) std::fprintf(stderr, "frame %zu: %.3f %.3f %.3f %.3f ms (sync %.3f)\n", f, stage[f * 5], stage[f * 5 + 1], stage[f * 5 + 2], stage[f * 5 + 3], stage[f * 5 + 4]);
     double s[5] = {0, 0, 0, 0, 0};
     for (size_t f = 1; f < F; f++) for (int k = 0; k < 5; k++) s[k] += stage[f * 5 + k];
     const double T = timed ? (double)timed : 1.0;

@@ -1,5 +1,8 @@
 // See livo2_host.hpp.  Pure data movement between the reference-shaped containers and the C ABI.
 #include "livo2_host.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -277,9 +280,17 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
   last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
   if (host_point_lists_ && !pv_list_.empty()) {        // the reference leaves the posterior point_w / var in pv_list_ (LIVMapper.cpp:417-424; `_pv_list` of :426 feeds handleVIO)
     const int32_t n = (int32_t)pv_list_.size();
-    std::vector<double> pw((size_t)n * 3), var((size_t)n * 9);
+    const size_t bytes = (size_t)n * 96 + 64;
+    if (bytes > pin_bytes_) {
+      livo2_host_free_pinned(pin_); pin_ = nullptr; pin_bytes_ = 0;
+      dev_.check(livo2_host_alloc_pinned(bytes + bytes / 4, &pin_));
+      pin_bytes_ = bytes + bytes / 4;
+    }
+    double *pw = static_cast<double *>(pin_), *var = pw + (size_t)n * 3;             // the per-point receive buffer of StateEstimation is free again by now
     int32_t got = 0;
-    dev_.check(livo2_map_tree_read_pv(dev_.ctx(), pw.data(), var.data(), n, &got));
+    dev_.check(livo2_map_tree_read_pv(dev_.ctx(), pw, var, n, &got));
+    const int threads = std::max(1, std::min(fill_threads_, got / 2048 + 1));
+#pragma omp parallel for schedule(static) num_threads(threads)
     for (int32_t i = 0; i < got; i++) { std::memcpy(pv_list_[i].point_w.data(), &pw[(size_t)i * 3], 24); std::memcpy(pv_list_[i].var.data(), &var[(size_t)i * 9], 72); }
   }
 }
@@ -347,8 +358,12 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
   std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
   static_assert(sizeof(PointXYZ) == 12, "xyz AoS");
+  static const bool shim_prof = std::getenv("LIVO2_SHIM_PROF") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); };
   if (!scan_resident_) dev_.check(livo2_lidar_set_scan(dev_.ctx(), n ? &feats_down_body_[0].x : nullptr, n, &cfg));
   scan_resident_ = false;
+  const double t_scan = since();
 
   // per-point outputs land in page-locked buffers the manager keeps (D2H at PCIe speed, no bounce through the runtime's staging)
   int32_t *match = nullptr, *normal_plane = nullptr; float *dis = nullptr, *pw = nullptr; double *var = nullptr, *bcov = nullptr;
@@ -365,12 +380,13 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     auto take = [&](size_t sz) { char *q = b; b += (sz + 63) & ~(size_t)63; return q; };
     var = reinterpret_cast<double *>(take(nn * 72)); bcov = reinterpret_cast<double *>(take(nn * 72)); pw = reinterpret_cast<float *>(take(nn * 12));
     match = reinterpret_cast<int32_t *>(take(nn * 4)); normal_plane = reinterpret_cast<int32_t *>(take(nn * 4)); dis = reinterpret_cast<float *>(take(nn * 4));
-    pts.match_plane = match; pts.dis_to_plane = dis; pts.point_w = pw; pts.normal_plane = normal_plane; pts.var = var; pts.body_cov = bcov;
+    pts.match_plane = match; pts.dis_to_plane = dis; pts.point_w = pw; pts.normal_plane = normal_plane; pts.var = var; pts.body_cov = bcov; pts.pinned = 1;
   }
   livo2_state s_in, s_prop;
   state_.to_abi(s_in); state_propagat.to_abi(s_prop);
   livo2_lidar_result res;
   dev_.check(livo2_lidar_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, host_point_lists_ ? &pts : nullptr));
+  const double t_update = since();
   state_.from_abi(res.state);
   std::memcpy(position_last_.data(), res.position_last, 24);
   {   // euler_cur = RotMtoEuler(state_.rot_end) (so3_math.h:68-87); geoQuat_ = tf::createQuaternionMsgFromRollPitchYaw(euler_cur) (voxel_map.cpp:493)
@@ -387,6 +403,7 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   if (!host_point_lists_) {          // see livo2_host.hpp: the per-point members stay empty
     pv_list_.clear(); ptpl_list_.clear(); cross_mat_list_.clear(); body_cov_list_.clear();
     effct_feat_num_ = res.n_iters > 0 ? res.iter_sums[res.n_iters - 1].n_eff : 0;
+    if (shim_prof) std::fprintf(stderr, "StateEstimation (lean, %d points): set_scan %.3f ms, update %.3f ms\n", n, t_scan, t_update - t_scan);
     return;
   }
   // what the reference leaves behind for LIVMapper (src/LIVMapper.cpp:371-426, 446) and VIO (src/vio.cpp:811): ~900 B of reference structs per point, written by
@@ -402,6 +419,7 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     r_normal.resize(rows.size() * 3); r_center.resize(rows.size() * 3); r_pvar.resize(rows.size() * 36); r_d.resize(rows.size()); r_layer.resize(rows.size());
     dev_.check(livo2_map_tree_read_planes(dev_.ctx(), rows.data(), (int32_t)rows.size(), r_normal.data(), r_center.data(), r_pvar.data(), r_d.data(), nullptr, r_layer.data()));
   }
+  const double t_planes = since();
   std::vector<int32_t> slot((size_t)n);                                     // position of point i's PointToPlane in ptpl_list_ (the reference pushes them in scan order)
   int n_match = 0;
   for (int i = 0; i < n; i++) { slot[i] = n_match; n_match += match[i] >= 0 ? 1 : 0; }
@@ -441,6 +459,8 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
     }
   }
   effct_feat_num_ = (int)ptpl_list_.size();
+  if (shim_prof) std::fprintf(stderr, "StateEstimation (full, %d points): set_scan %.3f ms, update + D2H %.3f ms, plane rows %.3f ms (%zu rows), lists %.3f ms (%d threads)\n", n, t_scan, t_update - t_scan, t_planes - t_update,
+                              rows.size(), since() - t_planes, threads);
 }
 
 void VoxelMapManager::UndistortAndDownsample(const std::vector<PointXYZ> &pcl_wait_proc, const std::vector<float> &curvature, const std::vector<livo2_imu_pose> &IMUpose,

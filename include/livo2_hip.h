@@ -277,6 +277,8 @@ typedef struct livo2_lidar_points {
   double *body_cov;             /* [n][9] body_cov_list_[i] */
   double *r_inv;                /* [n]    R_inv(i) of matched points (debug / parity), 0 when unmatched */
   double *h_row;                /* [n][6] Hsub.row(i) of matched points (debug / parity) */
+  int64_t pinned;               /* != 0: every array above lies in page-locked memory (livo2_host_alloc_pinned / hipHostMalloc): the results are copied straight into
+                                 * them instead of through the context's staging block (one host copy less) */
 } livo2_lidar_points;
 
 /* One pass for the given current iterate `cur` and prior `prop` (state_propagat); no state update. */
