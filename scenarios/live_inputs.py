@@ -20,7 +20,7 @@ def _state_vec(R, t, P, inv_expo=1.0):
 
 SIZES = {
     "avia": dict(),                                                           # 24 000 rays per scan (~12.5 k points after the 0.1 m filter), 30 000 visual points per frame
-    "c4": dict(n_raw=620000, max_points=200000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays=1600000, n_vis=120000, n_frames=5),
+    "c4": dict(n_raw=620000, max_points=200000, room=(60.0, 60.0, 10.0), n_boxes=24, full_sphere=True, map_rays=1600000, n_vis=120000, n_frames=6),
     "test": dict(n_frames=5, n_raw=8000, map_rays=60000, n_vis=6000),       # tests/test_live_chain_gpu.py
 }
 
