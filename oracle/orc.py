@@ -269,13 +269,15 @@ def voxel_grid(xyz, leaf, lib=None):
 class SelectCfg(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("width", C.c_int32), ("height", C.c_int32),
                 ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_width", C.c_int32),
-                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32), ("d", C.c_double * 5), ("distortion", C.c_int32), ("pad2", C.c_int32)]
+                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32), ("d", C.c_double * 5), ("distortion", C.c_int32), ("raycast_en", C.c_int32)]
 
 
-def visual_select(ss, lib=None):
-    """Selection half of retrieveFromVisualSparseMap over a scenarios.synth.SelectScenario; returns per-cell / per-point arrays."""
+def visual_select(ss, lib=None, raycast=False, omap=None):
+    """Selection half of retrieveFromVisualSparseMap over a scenarios.synth.SelectScenario; returns per-cell / per-point arrays.  raycast: the RayCasting module
+    (vio.cpp:487-591) with `omap` (OracleMap or None) as plane_map; adds `add_from_voxel_map` [k][6] = center_, normal_."""
     lib = lib or load()
     c = SelectCfg()
+    c.raycast_en = 1 if raycast else 0
     c.fx, c.fy, c.cx, c.cy, c.width, c.height = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"], ss.cam["width"], ss.cam["height"]
     _cam_distortion(c, ss.cam)
     c.R_cur[:] = ss.R_cur.ravel().tolist(); c.t_cur[:] = ss.t_cur.tolist()
@@ -285,11 +287,14 @@ def visual_select(ss, lib=None):
     keys = np.ascontiguousarray(ss.keys, np.int64); act = np.ascontiguousarray(ss.active, np.uint8)
     out = dict(cell_point=np.zeros(length, np.int32), cell_dist=np.zeros(length, np.float32), cell_type=np.zeros(length, np.int32), discont=np.zeros(length, np.int32),
                in_fov=np.zeros(len(pos), np.int32), depth_img=np.zeros((ss.cam["height"], ss.cam["width"]), np.float32))
-    lib.orc_visual_select.restype = C.c_double
-    lib.orc_visual_select.argtypes = [C.POINTER(SelectCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    lib.orc_visual_select_rc.restype = C.c_double
+    lib.orc_visual_select_rc.argtypes = [C.POINTER(SelectCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    out["seconds"] = lib.orc_visual_select(C.byref(c), vp(pg), len(pg), vp(pos), vp(keys), vp(act), len(pos), vp(out["cell_point"]), vp(out["cell_dist"]),
-                                           vp(out["cell_type"]), vp(out["discont"]), vp(out["in_fov"]), vp(out["depth_img"]))
+    add = np.zeros((length, 6)); n_add = C.c_int32(0)
+    out["seconds"] = lib.orc_visual_select_rc(C.byref(c), vp(pg), len(pg), vp(pos), vp(keys), vp(act), len(pos), vp(out["cell_point"]), vp(out["cell_dist"]),
+                                              vp(out["cell_type"]), vp(out["discont"]), vp(out["in_fov"]), vp(out["depth_img"]), omap.h if omap is not None else None,
+                                              vp(add), length, C.cast(C.byref(n_add), C.c_void_p))
+    out["add_from_voxel_map"] = add[:n_add.value]
     return out
 
 
@@ -316,12 +321,12 @@ class _Cand:
     pass
 
 
-def visual_retrieve(cs, lib=None):
-    """The whole retrieveFromVisualSparseMap (raycast_en = false) over a RetrieveChainScenario: selection -> reference-patch choice -> warp / gate
+def visual_retrieve(cs, lib=None, raycast=False, omap=None):
+    """The whole retrieveFromVisualSparseMap (raycast_en = `raycast`, plane_map = `omap`) over a RetrieveChainScenario: selection -> reference-patch choice -> warp / gate
     tail.  Returns the stage outputs: sel (dict of visual_select), cell_obs, ref_patch, cand_cell (grid cell of every candidate, ascending),
     cand_point, cand_obs, tail (dict of warp_candidates), and the appended sub-map: sub_point, sub_obs (survivors in order)."""
     lib = lib or load()
-    sel = visual_select(cs.sel, lib)
+    sel = visual_select(cs.sel, lib, raycast=raycast, omap=omap)
     cell_obs, ref_patch = choose_ref(cs, sel["cell_point"], sel["discont"], lib=lib)
     cand_cell = np.nonzero(cell_obs >= 0)[0].astype(np.int32)
     cand_point, cand_obs = sel["cell_point"][cand_cell], cell_obs[cand_cell]

@@ -442,9 +442,19 @@ void orc_world2cam(const orc_warp_cfg *c, const double *xyz, double *px) {
 
 // Selection half of retrieveFromVisualSparseMap (orc_select.hpp).  keys: [n_pts][3] int64 feat_map keys (NULL: computed from pos with
 // insertPointIntoVoxelMap's formula).  Returns seconds.
-struct orc_select_cfg { double fx, fy, cx, cy; int32_t width, height; double R_cur[9], t_cur[3]; int32_t border, grid_size, grid_n_width, grid_n_height, patch_size_half, pad; double d[5]; int32_t distortion, pad2; };
+struct orc_select_cfg { double fx, fy, cx, cy; int32_t width, height; double R_cur[9], t_cur[3]; int32_t border, grid_size, grid_n_width, grid_n_height, patch_size_half, pad; double d[5]; int32_t distortion, raycast_en; };
+// map (nullable): the LiDAR VoxelMap the RayCasting module looks into (plane_map of retrieveFromVisualSparseMap); add6 [add_cap][6]: center_, normal_ of
+// visual_submap->add_from_voxel_map in push order, *n_add their number
+double orc_visual_select_rc(const orc_select_cfg *c, const double *pg, int n_pg, const double *pos, const int64_t *keys, const uint8_t *active, int n_pts,
+                            int32_t *cell_point, float *cell_dist, int32_t *cell_type, int32_t *discont, int32_t *in_fov, float *depth_img, void *map, double *add6, int add_cap,
+                            int32_t *n_add);
 double orc_visual_select(const orc_select_cfg *c, const double *pg, int n_pg, const double *pos, const int64_t *keys, const uint8_t *active, int n_pts,
                          int32_t *cell_point, float *cell_dist, int32_t *cell_type, int32_t *discont, int32_t *in_fov, float *depth_img) {
+  return orc_visual_select_rc(c, pg, n_pg, pos, keys, active, n_pts, cell_point, cell_dist, cell_type, discont, in_fov, depth_img, nullptr, nullptr, 0, nullptr);
+}
+double orc_visual_select_rc(const orc_select_cfg *c, const double *pg, int n_pg, const double *pos, const int64_t *keys, const uint8_t *active, int n_pts,
+                            int32_t *cell_point, float *cell_dist, int32_t *cell_type, int32_t *discont, int32_t *in_fov, float *depth_img, void *map, double *add6, int add_cap,
+                            int32_t *n_add) {
   SelectCfg cfg;
   cfg.cam.fx = c->fx; cfg.cam.fy = c->fy; cfg.cam.cx = c->cx; cfg.cam.cy = c->cy; cfg.cam.distortion = c->distortion; cfg.cam.width = c->width; cfg.cam.height = c->height;
   for (int k = 0; k < 5; k++) cfg.cam.d[k] = c->d[k];
@@ -455,9 +465,23 @@ double orc_visual_select(const orc_select_cfg *c, const double *pg, int n_pg, co
     pts[i].pos = vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); pts[i].active = active ? active[i] : 1;
     if (keys) for (int j = 0; j < 3; j++) pts[i].key[j] = keys[3 * (size_t)i + j]; else feat_map_key(pts[i].pos, pts[i].key);
   }
+  cfg.raycast_en = c->raycast_en;
+  MapHandle *mh = (MapHandle *)map;
+  const PlaneLookup lookup = [mh](const int64_t key[3], const V3 &pw, V3 &center, V3 &normal) {
+    auto it = mh->map.voxel_map_.find(VOXEL_LOCATION(key[0], key[1], key[2]));
+    if (it == mh->map.voxel_map_.end()) return false;
+    VoxelOctoTree *current_octo = it->second->find_correspond(pw);
+    if (!current_octo->plane_ptr_->is_plane_) return false;
+    center = current_octo->plane_ptr_->center_; normal = current_octo->plane_ptr_->normal_;
+    return true;
+  };
+  std::vector<RayHit> add;
   const double t0 = omp_get_wtime();
-  visual_select(cfg, pg, n_pg, pts.data(), n_pts, cell_point, cell_dist, cell_type, discont, in_fov, depth_img);
-  return omp_get_wtime() - t0;
+  visual_select(cfg, pg, n_pg, pts.data(), n_pts, cell_point, cell_dist, cell_type, discont, in_fov, depth_img, mh ? &lookup : nullptr, &add);
+  const double dt = omp_get_wtime() - t0;
+  if (n_add) *n_add = (int32_t)add.size();
+  for (int k = 0; k < (int)add.size() && k < add_cap && add6; k++) { std::memcpy(add6 + 6 * (size_t)k, add[k].center.a, 24); std::memcpy(add6 + 6 * (size_t)k + 3, add[k].normal.a, 24); }
+  return dt;
 }
 void orc_feat_map_key(const double *pos3, int64_t *key3) { feat_map_key(vec3(pos3[0], pos3[1], pos3[2]), key3); }
 

@@ -86,6 +86,17 @@ struct VoxelOctoTree {               // include/voxel_map.h:129-183
   }
   ~VoxelOctoTree() { for (int i = 0; i < 8; i++) delete leaves_[i]; delete plane_ptr_; }
 
+  // src/voxel_map.cpp:292-305
+  VoxelOctoTree *find_correspond(const V3 &pw) {
+    if (!init_octo_ || plane_ptr_->is_plane_ || (layer_ >= max_layer_)) return this;
+    int xyz[3] = {0, 0, 0};
+    xyz[0] = pw[0] > voxel_center_[0] ? 1 : 0;
+    xyz[1] = pw[1] > voxel_center_[1] ? 1 : 0;
+    xyz[2] = pw[2] > voxel_center_[2] ? 1 : 0;
+    int leafnum = 4 * xyz[0] + 2 * xyz[1] + xyz[2];
+    return (leaves_[leafnum] != nullptr) ? leaves_[leafnum]->find_correspond(pw) : this;
+  }
+
   // src/voxel_map.cpp:55-135
   void init_plane(const std::vector<MapPoint> &points, VoxelPlane *plane) {
     plane->plane_var_ = Mat<6, 6>::Zero();

@@ -405,6 +405,10 @@ struct ref_retrieve_cfg {
   int32_t patch_pyrimid_level, normal_en, ncc_en, border, grid_size, grid_n_height;
   double ncc_thre, outlier_threshold;
 };
+// the RayCasting module (vio.cpp:80-118, 487-591) of the NEXT ref_visual_retrieve call: raycast_en, the LiDAR VoxelMap handed to it as plane_map (a MapHandle of this
+// library, nullable) and where visual_submap->add_from_voxel_map (center_, normal_ per entry) is copied to
+namespace { struct RaycastSetup { int en = 0; void *map = nullptr; double *add6 = nullptr; int cap = 0; int32_t *n_add = nullptr; } g_rc; }
+void ref_visual_retrieve_raycast(int raycast_en, void *map, double *add6, int add_cap, int32_t *n_add) { g_rc.en = raycast_en; g_rc.map = map; g_rc.add6 = add6; g_rc.cap = add_cap; g_rc.n_add = n_add; }
 int ref_visual_retrieve(const ref_retrieve_cfg *c, const uint8_t *img, const uint8_t *ref_imgs, int n_ref, const double *pg, int n_pg, int n_pts, const double *pos,
                         const double *normal, const int64_t *keys, const uint8_t *active, const uint8_t *ninit, const int32_t *ref_patch_in, const int32_t *obs_offset,
                         const int32_t *obs_id, const int32_t *obs_img_idx, const int32_t *obs_level, const double *obs_px, const double *obs_f, const double *obs_R,
@@ -420,7 +424,7 @@ int ref_visual_retrieve(const ref_retrieve_cfg *c, const uint8_t *img, const uin
   StatesGroup st, prop; st.inv_expo_time = c->inv_expo_cur;
   vio.state = &st; vio.state_propagat = &prop;
   vio.grid_size = c->grid_size; vio.grid_n_height = c->grid_n_height; vio.patch_size = 8; vio.patch_pyrimid_level = c->patch_pyrimid_level; vio.max_iterations = 5;
-  vio.img_point_cov = 100; vio.exposure_estimate_en = true; vio.inverse_composition_en = false; vio.normal_en = c->normal_en != 0; vio.raycast_en = false; vio.ncc_en = c->ncc_en != 0;
+  vio.img_point_cov = 100; vio.exposure_estimate_en = true; vio.inverse_composition_en = false; vio.normal_en = c->normal_en != 0; vio.raycast_en = g_rc.en != 0; vio.ncc_en = c->ncc_en != 0;
   vio.colmap_output_en = false; vio.has_ref_patch_cache = false; vio.plot_flag = false; vio.outlier_threshold = c->outlier_threshold; vio.ncc_thre = c->ncc_thre;
   vio.Rcl = M3D::Identity(); vio.Rli = M3D::Identity(); vio.Pcl = V3D::Zero(); vio.Pli = V3D::Zero();
   { CoutCapture cap; vio.initializeVIO(); }
@@ -460,8 +464,16 @@ int ref_visual_retrieve(const ref_retrieve_cfg *c, const uint8_t *img, const uin
   std::vector<pointWithVar> pgv(n_pg);
   for (int i = 0; i < n_pg; i++) pgv[i].point_w = V3D(pg[3 * i], pg[3 * i + 1], pg[3 * i + 2]);
   std::unordered_map<VOXEL_LOCATION, VoxelOctoTree *> plane_map;
+  if (g_rc.map) plane_map = ((MapHandle *)g_rc.map)->voxel_map;              // (a copy of the key -> tree pointers; the trees stay the MapHandle's)
   vio.resetGrid();
   { CoutCapture cap; vio.retrieveFromVisualSparseMap(cur, pgv, plane_map); }
+  if (g_rc.n_add) {
+    const auto &add = vio.visual_submap->add_from_voxel_map;
+    *g_rc.n_add = (int32_t)add.size();
+    for (int k = 0; k < (int)add.size() && k < g_rc.cap && g_rc.add6; k++)
+      for (int j = 0; j < 3; j++) { g_rc.add6[6 * k + j] = add[k].point_w[j]; g_rc.add6[6 * k + 3 + j] = add[k].normal[j]; }
+  }
+  g_rc = RaycastSetup{};
   for (int i = 0; i < vio.length; i++) {
     cell_type[i] = vio.grid_num[i]; cell_dist[i] = vio.map_dist[i];
     cell_point[i] = (vio.grid_num[i] == VIOManager::TYPE_MAP && vio.retrieve_voxel_points[i]) ? pt_index[vio.retrieve_voxel_points[i]] : -1;

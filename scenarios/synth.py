@@ -669,7 +669,7 @@ def feat_map_key_np(pos):
     return loc.astype(np.int64)
 
 
-def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scene=None, R0=None, t0=None):
+def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scene=None, R0=None, t0=None, raycast=False):
     """scene / R0 / t0: take the visual points and the scan from THIS room at THIS sensor pose (scenarios/live_inputs.py: the one-scene live chain) instead of a
     room of the scenario's own."""
     rng = np.random.default_rng(seed)
@@ -679,7 +679,7 @@ def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scen
     if scene is None:
         scene = make_room(rng, (20.0, 20.0, 6.0), 8)
         R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
-        t0 = scene.R_ws @ np.array([0.3, -0.2, 1.4]) + scene.t_ws
+        t0 = scene.R_ws @ np.array([0.3, -0.2, 1.0 if raycast else 1.4]) + scene.t_ws          # (raycast: low enough for the 2.9-m rays to reach the floor's planes)
     xyz = lidar_scan(rng, scene, R0, t0, extR, extT, n_pg + 3 * n_vis, c["dept_err"], c["beam_err"], AVIA["blind"], False).astype(np.float64)
     pw = (xyz @ extR.T + extT) @ R0.T + t0
     pg = pw[:n_pg].astype(np.float32).astype(np.float64)            # point_w comes from a float32 cloud
@@ -694,12 +694,33 @@ def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scen
     Rci, Pci = vio_constants(extR, extT, Rcl, Pcl)
     R_cur = Rci @ R0.T
     t_cur = -Rci @ R0.T @ t0 + Pci
+    map_pw = None
+    if raycast:
+        # A scene for the RayCasting module (vio.cpp:487-591; rays are sampled to 2.9 m only): the LiDAR map keeps every scan point (`map_pw`), but most scan points
+        # within 3.5 m of the camera are dropped from `pg`, so that the near voxels are NOT in sub_feat_map and the rays of cells without a map point get to work;
+        # a few dozen visual points are re-drawn inside the right half of the near field (1.2 .. 2.9 m along random pixels), where only a ray can find them.
+        map_pw = pg.copy()
+        cam_c = -R_cur.T @ t_cur
+        near = np.linalg.norm(pg - cam_c, axis=1) < 3.5
+        pg = pg[~near | (pg[:, 1] > cam_c[1] + 1.2)]                  # (the near field keeps its scan points on one side only: rays into it end at a sub_feat_map voxel)
+        k = 48                                                            # few and not closer than 1.2 m: a voxel holding one of them stops EVERY ray that crosses it
+        bd = (4 + 1) * (1 << L)
+        u = rng.uniform(cam["cx"], cam["width"] - bd - 2, k); v = rng.uniform(bd + 2, cam["height"] - bd - 2, k); dd = rng.uniform(1.2, 2.9, k)
+        p_c = np.stack([(u - cam["cx"]) / cam["fx"] * dd, (v - cam["cy"]) / cam["fy"] * dd, dd], 1)
+        pos[-k:] = (p_c - t_cur) @ R_cur
+        # ... and the left half of the near field has NO visual points at all: there a ray finds nothing in feat_map and goes on to the LiDAR map's planes
+        empty = (np.linalg.norm(pos - cam_c, axis=1) < 3.6) & (((pos - cam_c) @ R_cur.T)[:, 0] < 0.0)
+        far = np.flatnonzero(np.linalg.norm(pos - cam_c, axis=1) >= 3.6)
+        pos[empty] = pos[rng.choice(far, int(empty.sum()))] + rng.normal(0, 0.02, (int(empty.sum()), 3))
     grid_size = int(cam["height"] / grid_n_height)                   # vio.cpp:74-76
     gh = int(np.ceil(float(int(cam["height"] / grid_size))))
     gw = int(np.ceil(float(int(cam["width"] / grid_size))))
     border = (4 + 1) * (1 << L)                                      # vio.cpp:154
     active = (rng.uniform(size=n_vis) > 0.05).astype(np.uint8)
-    return SelectScenario(pg, pos, feat_map_key_np(pos), active, R_cur, t_cur, cam, border, grid_size, gw, gh)
+    ss = SelectScenario(pg, pos, feat_map_key_np(pos), active, R_cur, t_cur, cam, border, grid_size, gw, gh)
+    if raycast:
+        ss.map_pw = map_pw
+    return ss
 
 
 # ---- the whole retrieveFromVisualSparseMap: selection -> reference-patch choice -> warp/gate tail (reference src/vio.cpp:352-780) -----------
@@ -726,12 +747,12 @@ class RetrieveChainScenario:
 
 
 def retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=20000, L=4, grid_n_height=17, normal_en=True, ncc_en=False, ncc_thre=0.5, outlier_threshold=1000.0,
-                            max_obs=6, scene=None, R0=None, t0=None):
+                            max_obs=6, scene=None, R0=None, t0=None, raycast=False):
     """Visual points of select_scenario, each observed by 1..max_obs features made in a handful of earlier frames: frames 0-3 stand close to the
     current pose and show the current texture (their patches warp almost identically and pass the gates), frame 4 is a close-up with another
     texture, frame 5 looks at the scene from the side (more than 60 degrees off: getCloseViewObs rejects it).  A share of points carries two
     observations of ONE frame (same id_), only same-id observations, a preset ref_patch, or an uninitialised normal."""
-    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height, scene=scene, R0=R0, t0=t0)
+    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height, scene=scene, R0=R0, t0=t0, raycast=raycast)
     rng = np.random.default_rng(seed + 1000)
     cam = base.cam
     W, H = cam["width"], cam["height"]

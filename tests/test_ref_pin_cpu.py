@@ -256,8 +256,12 @@ class _RetrCfg(C.Structure):
                 ("outlier_threshold", C.c_double)]
 
 
-def _ref_retrieve(ref, cs):
+def _ref_retrieve(ref, cs, raycast=False, rmap=None):
     sel = cs.sel
+    add, n_add = np.zeros((sel.grid_n_width * sel.grid_n_height, 6)), C.c_int32(0)
+    ref.ref_visual_retrieve_raycast.restype = None
+    ref.ref_visual_retrieve_raycast.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+    ref.ref_visual_retrieve_raycast(1 if raycast else 0, rmap.h if rmap is not None else None, add.ctypes.data_as(C.c_void_p), len(add), C.byref(n_add))
     c = _RetrCfg()
     c.fx, c.fy, c.cx, c.cy, c.width, c.height = sel.cam["fx"], sel.cam["fy"], sel.cam["cx"], sel.cam["cy"], sel.cam["width"], sel.cam["height"]
     d, k = sel.cam.get("d"), sel.cam.get("k")
@@ -291,6 +295,7 @@ def _ref_retrieve(ref, cs):
     m = ns.value
     for k in ("sub_point", "sub_obs", "sub_search", "sub_error", "sub_patch", "sub_inv_expo"):
         out[k] = out[k][:m]
+    out["add_from_voxel_map"] = add[:n_add.value]
     return out
 
 
@@ -333,6 +338,51 @@ def test_retrieve_from_visual_sparse_map(orc, ref, normal_en, camera):
     assert np.array_equal(a["tail"]["error"][keep], b["sub_error"])
     assert np.array_equal(a["tail"]["patch_wrap"][keep], b["sub_patch"])
     assert np.array_equal(cs.obs_inv_expo[a["sub_obs"]], b["sub_inv_expo"])
+
+
+@pytest.mark.parametrize("seed,camera,with_map", [(91, None, True), (92, None, True), (93, "radtan", True), (94, "equidistant", True), (91, None, False)])
+def test_retrieve_with_raycast_module(orc, ref, seed, camera, with_map):
+    """vio/raycast_en = true (off in every shipped config, inside the cited range of row N2): the RayCasting module of retrieveFromVisualSparseMap (vio.cpp:487-591) with
+    the rays initializeVIO builds (vio.cpp:80-118) and the LiDAR VoxelMap as plane_map — the reference's own loop (order-dependent through grid_num and
+    sub_feat_map) against the oracle: which cells a ray turns into TYPE_MAP, the point and float distance each cell ends with, the (center_, normal_) entries of
+    add_from_voxel_map in push order, and everything the rest of the function then does with that selection."""
+    cs = synth.retrieve_chain_scenario(seed=seed, n_pg=12000, n_vis=6000, L=2, grid_n_height=34, raycast=True)
+    cs.obs_id = np.array(cs.obs_id).copy()
+    for i in range(len(cs.sel.pos)):
+        seen = {}
+        for k in range(cs.obs_offset[i], cs.obs_offset[i + 1]):
+            j = seen.get(int(cs.obs_id[k]), 0); seen[int(cs.obs_id[k])] = j + 1
+            cs.obs_id[k] += 1000 * j
+    if camera == "radtan":
+        cs.sel.cam = dict(cs.sel.cam); cs.sel.cam["d"] = synth.AVIA_RADTAN
+    if camera == "equidistant":
+        cs.sel.cam = dict(cs.sel.cam); cs.sel.cam["k"] = synth.HILTI_EQUIDISTANT
+    c = dict(synth.AVIA["lio"])
+    var = np.tile((np.eye(3) * 1e-4).ravel(), (len(cs.sel.map_pw), 1))
+    def build(lib):                                   # the LiDAR map on both sides by the same route: UpdateVoxelMap of all points into an empty map
+        lib = lib or orc.load()
+        lib.orc_map_create.restype = C.c_void_p
+        m = orc.OracleMap(lib, lib.orc_map_create(C.c_double(c["voxel_size"]), C.c_int(c["max_layer"]), (C.c_int * 5)(*list(c["layer_init_num"])[:5]), C.c_int(c["max_points_num"]),
+                                                  C.c_double(c["min_eigen_value"])))
+        m.update(cs.sel.map_pw, var)
+        return m
+    om, rm = (build(None), build(ref)) if with_map else (None, None)
+    plain = orc.visual_select(cs.sel)
+    a = orc.visual_retrieve(cs, raycast=True, omap=om)
+    b = _ref_retrieve(ref, cs, raycast=True, rmap=rm)
+    sel = a["sel"]
+    assert int((sel["cell_point"] != plain["cell_point"]).sum()) >= 3                      # the rays did something
+    assert np.array_equal(sel["cell_type"] == 1, b["cell_type"] == 1)
+    on = b["cell_type"] == 1
+    assert np.array_equal(sel["cell_point"][on], b["cell_point"][on]) and np.array_equal(sel["cell_dist"][on], b["cell_dist"][on])
+    assert len(sel["add_from_voxel_map"]) == len(b["add_from_voxel_map"]) and (len(b["add_from_voxel_map"]) >= 3) == with_map
+    if with_map:
+        assert np.array_equal(sel["add_from_voxel_map"][:, :3], b["add_from_voxel_map"][:, :3])                       # center_: same points, same order of additions
+        n1, n2 = sel["add_from_voxel_map"][:, 3:], b["add_from_voxel_map"][:, 3:]
+        assert np.abs(np.abs((n1 * n2).sum(1)) - 1.0).max() < 1e-9                              # normal_: the eigenvector's sign is the solver's (stand-in Eigen)
+    assert np.array_equal(a["sub_point"], b["sub_point"]) and len(a["sub_point"]) > 50
+    keep = a["tail"]["accepted"] != 0
+    assert np.array_equal(a["tail"]["error"][keep], b["sub_error"]) and np.array_equal(a["tail"]["patch_wrap"][keep], b["sub_patch"])
 
 
 # ------------------------------------------------------------------------------------------------------------------------ VoxelMap
