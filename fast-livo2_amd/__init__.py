@@ -338,9 +338,17 @@ class Context:
         self._chk(self.lib.livo2_visual_map_upload(self.h, len(pos), abi.as_ptr(pos, C.c_double), abi.as_ptr(k, C.c_int64) if k is not None else None,
                                                    abi.as_ptr(a, C.c_uint8) if a is not None else None))
 
-    def visual_select(self, ss):
-        """Selection half of retrieveFromVisualSparseMap over a scenario-like object (pg, R_cur, t_cur, cam, border, grid_*)."""
+    def raycast_fetch(self, capacity=32768):
+        """visual_submap->add_from_voxel_map of the last selection that ran with raycast_en: [n][6] = center_, normal_"""
+        add, n = np.zeros((capacity, 6)), C.c_int32(0)
+        self._chk(self.lib.livo2_visual_raycast_fetch(self.h, abi.as_ptr(add, C.c_double), capacity, C.byref(n)))
+        return add[: n.value]
+
+    def visual_select(self, ss, raycast=False):
+        """Selection half of retrieveFromVisualSparseMap over a scenario-like object (pg, R_cur, t_cur, cam, border, grid_*).  raycast: vio/raycast_en (the RayCasting
+        module looks into the device-resident VoxelMap of this context, if there is one); adds out["add_from_voxel_map"]."""
         c = SelectCfg()
+        c.raycast_en = 1 if raycast else 0
         c.cam.fx, c.cam.fy, c.cam.cx, c.cam.cy = ss.cam["fx"], ss.cam["fy"], ss.cam["cx"], ss.cam["cy"]
         c.cam.distortion, c.cam.width, c.cam.height = 0, ss.cam["width"], ss.cam["height"]
         _cam_distortion(c.cam, ss.cam)
@@ -352,6 +360,8 @@ class Context:
         self._chk(self.lib.livo2_visual_select(self.h, abi.as_ptr(pg, C.c_double), len(pg), C.byref(c), abi.as_ptr(out["cell_point"], C.c_int32),
                                                abi.as_ptr(out["cell_dist"], C.c_float), abi.as_ptr(out["discont"], C.c_uint8), abi.as_ptr(out["in_fov"], C.c_uint8)))
         out["in_fov"] = out["in_fov"][: self.n_vm]
+        if raycast:
+            out["add_from_voxel_map"] = self.raycast_fetch(length)
         return out
 
     def select_last_kernel_us(self):
@@ -409,7 +419,7 @@ class Context:
                       int(refs.shape[2]), 0)
         self._chk(self.lib.livo2_visual_obs_upload(self.h, C.byref(o)))
 
-    def visual_retrieve_from_map(self, cs, want_patches=True):
+    def visual_retrieve_from_map(self, cs, want_patches=True, raycast=False):
         """The whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail) over a RetrieveChainScenario-like object
         whose points / observations were uploaded with visual_map_upload + visual_obs_upload.  Returns the stage outputs (same names as
         oracle.orc.visual_retrieve) and leaves the survivors resident as the frame."""
@@ -420,6 +430,7 @@ class Context:
         _cam_distortion(sc.cam, ss.cam)
         sc.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); sc.t_cur[:] = np.asarray(ss.t_cur, float).tolist()
         sc.border, sc.grid_size, sc.grid_n_width, sc.grid_n_height, sc.patch_size_half = int(ss.border), int(ss.grid_size), int(ss.grid_n_width), int(ss.grid_n_height), 4
+        sc.raycast_en = 1 if raycast else 0
         c = RetrieveCfg()
         c.cam = sc.cam
         c.R_cur[:] = np.asarray(ss.R_cur, float).ravel().tolist(); c.t_cur[:] = np.asarray(ss.t_cur, float).tolist(); c.inv_expo_cur = float(cs.inv_expo_cur)
@@ -445,6 +456,8 @@ class Context:
         r["tail"] = {k: (v[:nc] if v is not None else None) for k, v in t.items()}
         r["n_candidates"], r["n_accepted"] = nc, na
         self.M, self.L = na, L
+        if raycast:
+            r["add_from_voxel_map"] = self.raycast_fetch(length)
         return r
 
     def retrieve_from_map_last_kernel_us(self):

@@ -152,7 +152,7 @@ class ImuCfg(C.Structure):
 
 class SelectCfg(C.Structure):
     _fields_ = [("cam", Cam), ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3), ("border", C.c_int32), ("grid_size", C.c_int32), ("grid_n_width", C.c_int32),
-                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("pad", C.c_int32)]
+                ("grid_n_height", C.c_int32), ("patch_size_half", C.c_int32), ("raycast_en", C.c_int32)]
 
 
 class VisualCfg(C.Structure):
@@ -196,6 +196,7 @@ SIGNATURES = {
     "livo2_ctx_kernel_timing": (C.c_int, [_CTX, C.c_int]),
     "livo2_ctx_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_int32]),
     "livo2_ctx_get_counter": (C.c_int, [_CTX, C.c_char_p, _P(C.c_int64)]),
+    "livo2_visual_raycast_fetch": (C.c_int, [_CTX, _P(C.c_double), C.c_int32, _P(C.c_int32)]),
     "livo2_host_alloc_pinned": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     "livo2_host_free_pinned": (None, [C.c_void_p]),
     "livo2_debug_redzone_check": (C.c_int, [_CTX, _P(C.c_int32), _P(C.c_int64)]),

@@ -13,6 +13,7 @@
 #include "retrieve_kernels.hpp"
 #include "preprocess_kernels.hpp"
 #include "select_kernels.hpp"
+#include "raycast_kernels.hpp"
 #include "choice_kernels.hpp"
 #include "imu_kernels.hpp"
 #include <algorithm>
@@ -77,6 +78,11 @@ struct livo2_ctx {
   double *d_sel_pg = nullptr; size_t sel_pg_cap = 0; unsigned long long *d_sel_set = nullptr, *d_sel_depth = nullptr, *d_sel_best = nullptr; size_t sel_set_cap = 0, sel_depth_cap = 0, sel_best_cap = 0;
   int32_t *d_sel_type = nullptr, *d_sel_point = nullptr, *d_sel_flag = nullptr; float *d_sel_dist = nullptr; uint8_t *d_sel_disc = nullptr; size_t sel_type_cap = 0, sel_point_cap = 0, sel_dist_cap = 0, sel_disc_cap = 0;
   double select_kernel_us = 0.0;
+  // RayCasting module (raycast_kernels.hpp): voxel set of the visual map, per-call ray state, add_from_voxel_map of the last call
+  unsigned long long *d_vm_set = nullptr; size_t vm_set_cap = 0; uint32_t vm_set_mask = 0;
+  unsigned long long *d_ray_set = nullptr, *d_ray_key = nullptr, *d_ray_hit_key = nullptr, *d_ray_hit_best = nullptr; size_t ray_set_cap = 0, ray_key_cap = 0, ray_hit_key_cap = 0, ray_hit_best_cap = 0;
+  int32_t *d_ray_action = nullptr, *d_ray_hit_cell = nullptr, *d_ray_counters = nullptr; size_t ray_action_cap = 0, ray_hit_cell_cap = 0;
+  double *d_ray_add = nullptr; size_t ray_add_cap = 0; int ray_add_n = -1;
   // observation table of the visual map, reference-patch choice, chained retrieval (N2)
   bool has_obs = false; int n_obs = 0, ob_n_ref = 0, ob_w = 0, ob_h = 0, ob_stride = 0;
   int32_t *d_ob_off = nullptr, *d_ob_id = nullptr, *d_ob_img = nullptr, *d_ob_lvl = nullptr, *d_vm_refpatch = nullptr;
@@ -649,7 +655,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_bcov_rows};
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
+                 ctx->d_ray_counters, ctx->d_ray_add};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -2017,6 +2024,14 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
       HIPCHK(hipGetLastError());
     }
   }
+  {                                                    // the voxels that hold visual points, as a set (the RayCasting module asks "is there anything in this voxel")
+    size_t cap = 1024; while (cap < 2 * (size_t)std::max(n, 1)) cap <<= 1;
+    if ((rc = ensure(ctx, ctx->d_vm_set, ctx->vm_set_cap, cap))) return rc;
+    ctx->vm_set_mask = (uint32_t)(cap - 1);
+    HIPCHK(hipMemsetAsync(ctx->d_vm_set, 0xFF, cap * 8, ctx->stream));
+    if (n > 0) hipLaunchKernelGGL(k_vm_voxel_set, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_vm_pkey, n, ctx->d_vm_set, ctx->vm_set_mask);
+    HIPCHK(hipGetLastError());
+  }
   int32_t flag = 0;
   HIPCHK(devalloc::memcpy_async(&flag, ctx->d_sel_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2043,6 +2058,20 @@ static int select_reserve(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n
   if ((rc = ensure(ctx, ctx->d_sel_point, ctx->sel_point_cap, (size_t)length))) return rc;
   if ((rc = ensure(ctx, ctx->d_sel_dist, ctx->sel_dist_cap, (size_t)length))) return rc;
   if ((rc = ensure(ctx, ctx->d_sel_disc, ctx->sel_disc_cap, (size_t)length))) return rc;
+  if (cfg->raycast_en) {
+    if (length > RAY_MAX_CELLS) return fail(ctx, LIVO2_ERR_INVALID, "raycast_en: more than RAY_MAX_CELLS (32768) grid cells");
+    if (ctx->has_map && !ctx->tree_mode) return fail(ctx, LIVO2_ERR_NO_MAP, "raycast_en looks into the LiDAR VoxelMap (plane_map, vio.cpp:573-585): it needs the device-resident map (livo2_map_tree_*), not a snapshot");
+    size_t rcap = 1024; while (rcap < 2 * (size_t)length) rcap <<= 1;
+    const size_t nv = (size_t)std::max(ctx->n_vm, 1);
+    if ((rc = ensure(ctx, ctx->d_ray_set, ctx->ray_set_cap, rcap))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ray_key, ctx->ray_key_cap, (size_t)length))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ray_action, ctx->ray_action_cap, (size_t)length))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ray_hit_key, ctx->ray_hit_key_cap, nv))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ray_hit_best, ctx->ray_hit_best_cap, nv))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ray_hit_cell, ctx->ray_hit_cell_cap, nv))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ray_add, ctx->ray_add_cap, (size_t)length * 6))) return rc;
+    if (!ctx->d_ray_counters) HIPCHK(DMALLOC((void **)&ctx->d_ray_counters, 64));
+  }
   *cap_out = cap;
   return LIVO2_OK;
 }
@@ -2069,6 +2098,27 @@ static int select_enqueue(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n
   }
   if (n_pg > 0) hipLaunchKernelGGL(k_sel_scan, dim3((n_pg + 255) / 256), dim3(256), 0, ctx->stream, a);
   if (ctx->n_vm > 0) hipLaunchKernelGGL(k_sel_points, dim3((ctx->n_vm + 255) / 256), dim3(256), 0, ctx->stream, a);
+  ctx->ray_add_n = -1;
+  if (cfg->raycast_en) {                               // RayCasting module (vio.cpp:487-591) between stages B and C
+    RayArgs r{};
+    r.s = a;
+    r.vmset = ctx->d_vm_set; r.vm_mask = ctx->vm_set_mask;
+    size_t rcap = 1024; while (rcap < 2 * (size_t)length) rcap <<= 1;
+    r.rayset = ctx->d_ray_set; r.ray_mask = (uint32_t)(rcap - 1);
+    r.action = ctx->d_ray_action; r.key = ctx->d_ray_key; r.hit_key = ctx->d_ray_hit_key; r.hit_best = ctx->d_ray_hit_best; r.hit_cell = ctx->d_ray_hit_cell;
+    r.counters = ctx->d_ray_counters; r.add6 = ctx->d_ray_add;
+    if (ctx->tree_mode) {
+      r.nodes = ctx->mt.nodes; r.slots = ctx->d_slots; r.planes = ctx->d_planes; r.lmask = ctx->mt.mask; r.lseed1 = ctx->mt.seed1; r.lseed2 = ctx->mt.seed2; r.max_layer = ctx->mt.max_layer;
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.Rt[i * 3 + j] = cfg->R_cur[j * 3 + i];
+    for (int i = 0; i < 3; i++) r.tinv[i] = ((r.Rt[i * 3] * cfg->t_cur[0] + r.Rt[i * 3 + 1] * cfg->t_cur[1]) + r.Rt[i * 3 + 2] * cfg->t_cur[2]) * (-1.0);
+    HIPCHK(hipMemsetAsync(ctx->d_ray_set, 0xFF, rcap * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_ray_counters, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_ray_find, dim3((length + 255) / 256), dim3(256), 0, ctx->stream, r);
+    if (ctx->n_vm > 0) hipLaunchKernelGGL(k_ray_points, dim3((ctx->n_vm + 255) / 256), dim3(256), 0, ctx->stream, r);
+    hipLaunchKernelGGL(k_ray_resolve, dim3(1), dim3(256), 0, ctx->stream, r);
+    ctx->ray_add_n = 0;                                 // (the count stays on the device until livo2_visual_raycast_fetch)
+  }
   hipLaunchKernelGGL(k_sel_cells, dim3((length + 3) / 4), dim3(256), 0, ctx->stream, a);
   HIPCHK(hipGetLastError());
   return LIVO2_OK;
@@ -2388,6 +2438,20 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   ctx->has_ref = false;
   return LIVO2_OK;
 }
+int livo2_visual_raycast_fetch(livo2_ctx *ctx, double *center_normal, int32_t capacity, int32_t *n) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!n || capacity < 0 || (capacity > 0 && !center_normal)) return fail(ctx, LIVO2_ERR_INVALID, "bad arguments");
+  if (ctx->ray_add_n < 0) return fail(ctx, LIVO2_ERR_INVALID, "the last selection ran without raycast_en");
+  HIPCHK(hipSetDevice(ctx->device));
+  int32_t cnt[2] = {0, 0};
+  HIPCHK(devalloc::memcpy_async(cnt, ctx->d_ray_counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n = cnt[1];
+  const int m = std::min(cnt[1], capacity);
+  if (m > 0) { HIPCHK(devalloc::memcpy_async(center_normal, ctx->d_ray_add, (size_t)m * 48, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); }
+  return LIVO2_OK;
+}
+
 double livo2_visual_retrieve_from_map_last_kernel_us(const livo2_ctx *ctx) { return ctx ? ctx->chain_kernel_us : 0.0; }
 
 static int visual_ready(livo2_ctx *ctx, const livo2_state *a, const livo2_state *b, const livo2_visual_cfg *cfg) {

@@ -557,7 +557,7 @@ livo2_select_cfg VIOManager::selectCfg() const {
   livo2_select_cfg sc{};
   sc.cam.fx = fx; sc.cam.fy = fy; sc.cam.cx = cx; sc.cam.cy = cy; sc.cam.distortion = cam_distortion_model(); std::memcpy(sc.cam.d, cam_d, sizeof(cam_d)); sc.cam.width = width; sc.cam.height = height;
   std::memcpy(sc.R_cur, R_f_w_new.data(), 72); std::memcpy(sc.t_cur, t_f_w_new.data(), 24);
-  sc.border = border; sc.grid_size = grid_size; sc.grid_n_width = grid_n_width; sc.grid_n_height = grid_n_height; sc.patch_size_half = patch_size / 2;
+  sc.border = border; sc.grid_size = grid_size; sc.grid_n_width = grid_n_width; sc.grid_n_height = grid_n_height; sc.patch_size_half = patch_size / 2; sc.raycast_en = raycast_en ? 1 : 0;
   return sc;
 }
 
@@ -625,6 +625,14 @@ void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::ve
   }
   total_points = n_acc;
   frame_resident_ = true;
+  sm.add_from_voxel_map.clear();
+  if (raycast_en) {
+    std::vector<double> add((size_t)length * 6);
+    int32_t n_add = 0;
+    dev_.check(livo2_visual_raycast_fetch(dev_.ctx(), add.data(), length, &n_add));
+    sm.add_from_voxel_map.resize(n_add);
+    for (int k = 0; k < n_add; k++) { std::memcpy(sm.add_from_voxel_map[k].point_w.data(), &add[(size_t)k * 6], 24); std::memcpy(sm.add_from_voxel_map[k].normal.data(), &add[(size_t)k * 6 + 3], 24); }
+  }
 }
 
 void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands) {

@@ -249,6 +249,7 @@ struct SubSparseMap {                       // reference include/vio.h:26-57
   std::vector<int> search_levels;
   std::vector<VisualPoint *> voxel_points;
   std::vector<double> inv_expo_list;
+  std::vector<pointWithVar> add_from_voxel_map;   // raycast_en: planes of the LiDAR map the rays ended at (point_w = center_, normal = normal_; reference include/vio.h:34, src/vio.cpp:578-583)
 };
 
 struct GrayImage { const uint8_t *data = nullptr; int cols = 0, rows = 0, step = 0; };   // cv::Mat CV_8UC1 view
@@ -269,6 +270,8 @@ public:
   int patch_pyrimid_level = 4, patch_size = 8, max_iterations = 5, total_points = 0;
   double img_point_cov = 100;
   bool exposure_estimate_en = true, inverse_composition_en = false, normal_en = true, ncc_en = false;
+  bool raycast_en = false;                      // vio/raycast_en (reference include/vio.h:100): the RayCasting module runs inside retrieveFromVisualSparseMap / selectFromVisualSparseMap;
+                                                // plane_map = the device-resident VoxelMap of the same Device (VoxelMapManager::device_map_)
   int mp_proc_num = 4;                          // MP_PROC_NUM of the reference build (CMakeLists.txt:44-55): partition of the float error reduction (vio.cpp:1554)
   double compute_jacobian_time = 0, update_ekf_time = 0;   // reference include/vio.h:114: seconds inside the residual / solve kernels of the last update when
   bool kernel_times_en = false;                 // kernel_times_en (HIP event pair per launch, off by default: the events cost what they measure); else 0 (vio.cpp:788)

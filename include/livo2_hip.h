@@ -392,8 +392,15 @@ typedef struct livo2_select_cfg {
   double R_cur[9], t_cur[3];    /* new_frame_->T_f_w_ */
   int32_t border;               /* (patch_size_half + 1) * (1 << patch_pyrimid_level), src/vio.cpp:154 */
   int32_t grid_size, grid_n_width, grid_n_height;   /* src/vio.cpp:67-78 */
-  int32_t patch_size_half, pad;
+  int32_t patch_size_half;
+  int32_t raycast_en;           /* vio/raycast_en (LIVMapper.cpp:63, 141; off in the shipped configs): the RayCasting module of retrieveFromVisualSparseMap (vio.cpp:487-591,
+                                 * rays of initializeVIO vio.cpp:80-118) runs between the nearest-point selection and the depth-continuity test.  plane_map = the
+                                 * device-resident VoxelMap (livo2_map_tree_*); with a snapshot map resident the call fails (LIVO2_ERR_NO_MAP), with no LiDAR map the rays
+                                 * see no planes.  At most 32768 grid cells. */
 } livo2_select_cfg;
+/* visual_submap->add_from_voxel_map of the last selection / retrieval that ran with raycast_en: [n][6] = plane center_, normal_ in push (= grid cell) order
+ * (vio.cpp:578-583; its consumer generateVisualMapPoints is out of scope).  *n receives the number of entries, at most `capacity` are copied. */
+int livo2_visual_raycast_fetch(livo2_ctx *ctx, double *center_normal, int32_t capacity, int32_t *n);
 int livo2_visual_select(livo2_ctx *ctx, const double *pg_point_w, int32_t n_pg, const livo2_select_cfg *cfg, int32_t *cell_point, float *cell_dist,
                         uint8_t *cell_discontinuous, uint8_t *point_in_fov);
 double livo2_visual_select_last_kernel_us(const livo2_ctx *ctx);
