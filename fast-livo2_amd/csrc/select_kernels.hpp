@@ -1,4 +1,5 @@
-// Visual sub-map retrieval, selection half (reference src/vio.cpp:352-486 and 598-635, raycast_en = false):
+// Visual sub-map retrieval, selection half (reference src/vio.cpp:352-486 and 598-635; the RayCasting module of raycast_en = true, vio.cpp:487-591,
+// runs between B and C: raycast_kernels.hpp):
 //   A  k_sel_scan    every point of the current scan (pv_list_.point_w): its lookup voxel goes into a hash set (sub_feat_map), its
 //                    projection writes the depth image — the LAST scan point landing on a pixel wins, as in the serial loop
 //                    (64-bit atomicMax keyed by the point index);
