@@ -536,7 +536,7 @@ def cpu_live_chain(OC, lib, sizes=("avia",)):
     for size in sizes:
         live = live_inputs.make_live(**live_inputs.SIZES[size])
         recs, _ = OC.run(live, lib, num_threads=4, timing=True)
-        m = 1e3 * np.array([r["stage_s"] for r in recs[2:]]).mean(0)                      # (live_chain times the frames after its two warm-up frames)
+        m = 1e3 * np.median(np.array([r["stage_s"] for r in recs[2:]]), axis=0)           # (live_chain: per-stage medians of the frames after its two warm-up frames)
         out[size] = {"ms_per_frame": float(m.sum()), "StateEstimation_ms": float(m[0]), "UpdateVoxelMap_ms": float(m[1]), "retrieveFromVisualSparseMap_ms": float(m[2]),
                      "computeJacobianAndUpdateEKF_ms": float(m[3]), "frames_timed": int(len(recs) - 2)}
     return out

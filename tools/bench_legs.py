@@ -207,7 +207,7 @@ def _live_chain_leg(extra, sizes=("avia", "c4")):
                   "from the VIO posterior and the updated map; checked against the oracle chain in tests/test_live_chain_gpu.py); per frame the four shim calls of handleLIO + handleVIO back to back on std::vector containers (pageable; the scan is staged through the "
                   "ctx's pinned buffer); 'full': StateEstimation also fills pv_list_ / ptpl_list_ / body_cov_list_ / cross_mat_list_ on the host (168 B per point D2H + ~900 B per point of "
                   "reference structs) as the reference does; 'lean' (VoxelMapManager::host_point_lists_ = false): those lists stay on the device, where their consumers run in "
-                  "device_map_ mode; the first two frames (allocations, pinned buffers, the first update of the freshly built tree) not timed; "
+                  "device_map_ mode; the first two frames (allocations, pinned buffers, the first update of the freshly built tree) not timed, per-stage medians over the others (a frame in which a pool of the device tree grows is an outlier); "
                   "cpu_baseline.live_chain has the oracle's time for the same sequence")
     extra["live_chain"] = out
 
