@@ -145,6 +145,7 @@ int main(int argc, char **argv) {
       GrayImage img{vmap.img.data(), vio.width, vio.height, vio.width};
       const auto tm = std::chrono::steady_clock::now();
       vio.syncFeatMap(img);
+      dev.check(livo2_ctx_synchronize(dev.ctx()));                                   // (the mirror's uploads are asynchronous: their tail must not be billed to StateEstimation)
       stage[f * 5 + 4] = ms_since(tm);
       // processImu: the propagated state (stand-in: posterior (+) commanded motion, inflated covariance)
       const double *mo = &motion[f * 12];
