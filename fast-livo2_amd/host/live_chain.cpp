@@ -147,6 +147,10 @@ int main(int argc, char **argv) {
       vio.syncFeatMap(img);
       dev.check(livo2_ctx_synchronize(dev.ctx()));                                   // (the mirror's uploads are asynchronous: their tail must not be billed to StateEstimation)
       stage[f * 5 + 4] = ms_since(tm);
+      // Installing a whole new visual map is 30-150 ms of HOST work per frame in this program (the reference changes its map incrementally): long enough for the GPU to
+      // drop into an idle power state, and the first device operation afterwards then waits 10-20 ms for it to come back (seen as StateEstimation 15-28 ms on some
+      // frames of the C4-sized chain, with every kernel of the update taking its usual 20 us in the rocprofv3 trace).  One tiny device round trip absorbs that here.
+      { int32_t counts[8]; for (int k = 0; k < 3; k++) dev.check(livo2_map_tree_stats(dev.ctx(), counts)); }
       // processImu: the propagated state (stand-in: posterior (+) commanded motion, inflated covariance)
       const double *mo = &motion[f * 12];
       StatesGroup prop = state;

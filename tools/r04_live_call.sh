@@ -1,30 +1,37 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r04p; mkdir -p $O; export TMPDIR=/tmp
+export TMPDIR=/tmp
 python - <<'PY'
 import os, tempfile
 from scenarios import live_inputs as LI
-for size in ("avia", "c4"):
-    d = os.path.join(tempfile.gettempdir(), f"livo2_live_{size}_v2")
-    if not os.path.exists(os.path.join(d, "chain_cfg.bin")):
-        LI.write_live_dir(d, LI.make_live(**LI.SIZES[size]))
+d = os.path.join(tempfile.gettempdir(), "livo2_live_c4_v3")
+if not os.path.exists(os.path.join(d, "chain_cfg.bin")):
+    LI.write_live_dir(d, LI.make_live(**LI.SIZES["c4"]))
 PY
-for size in avia c4; do
-  LIVO2_SHIM_PROF=1 fast-livo2_amd/lib/live_chain /tmp/livo2_live_${size}_v2 2>&1 | grep -a "frame \|live_chain" | cut -c1-330
-done
-rm -rf /tmp/kt; rocprofv3 --kernel-trace -d /tmp/kt -o kt -- fast-livo2_amd/lib/live_chain /tmp/livo2_live_c4_v2 lean > /dev/null 2>&1
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/kt -o kt -- fast-livo2_amd/lib/live_chain /tmp/livo2_live_c4_v3 lean > /tmp/lc.out 2>&1; grep -a "^live_chain" /tmp/lc.out | cut -c1-200
 python - <<'PY'
 import sqlite3, glob
 db = glob.glob('/tmp/kt/**/*results.db', recursive=True)[0]
 c = sqlite3.connect(db)
+tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 t0 = rows[0][1]
-slow = [(n[:50], (s - t0) / 1e6, (e - s) / 1e3) for n, s, e in rows if (e - s) > 300e3]
-print("kernels longer than 300 us (name, start ms, duration us):")
-for r in slow[:60]: print("  %-50s %10.3f %10.1f" % r)
-import collections
-agg = collections.defaultdict(lambda: [0, 0.0])
-for n, s, e in rows: agg[n[:50]][0] += 1; agg[n[:50]][1] += (e - s) / 1e3
-for n, (k, t) in sorted(agg.items(), key=lambda x: -x[1][1])[:12]: print("  %-50s calls %5d total %10.1f us" % (n, k, t))
+res = [(s, e) for n, s, e in rows if 'k_lidar_residual' in n]
+print("residual launches:", len(res))
+prev_end = None
+allk = [(s, e, n) for n, s, e in rows]
+import bisect
+starts = [s for s, e, n in allk]
+for k, (s, e) in enumerate(res):
+    i = bisect.bisect_left(starts, s)
+    pe = allk[i - 1][1] if i > 0 else s
+    pn = allk[i - 1][2][:30] if i > 0 else ''
+    print("  residual %2d start %9.3f ms dur %7.1f us, gap after previous kernel (%s) %9.1f us" % (k, (s - t0) / 1e6, (e - s) / 1e3, pn, (s - pe) / 1e3))
+mc = [t for t in tabs if 'memory_cop' in t or 'memcpy' in t.lower()]
+print("memcpy tables:", mc)
+for t in mc[:1]:
+    cols = [r[1] for r in c.execute(f"pragma table_info({t})")]
+    print(cols)
+    big = c.execute(f"select * from {t} order by (end-start) desc limit 8").fetchall()
+    for b in big: print("   ", [x for x in b][:12])
 PY
-python -m pytest tests/test_host_shim_gpu.py tests/test_live_chain_gpu.py tests/test_sequence_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3
