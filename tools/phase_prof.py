@@ -75,6 +75,13 @@ def main():
         m = (W >= lo) & (W <= hi)
         if m.any():
             print(f"  waves with {lo}..{hi} candidate pairs: {m.sum():5d}  T3 mean {d3[m].mean():7.2f} p95 {np.percentile(d3[m], 95):7.2f} max {d3[m].max():7.2f}")
+    xs = cst[buf[:waves, 0] > 0][:, 12:16]
+    if (xs > 0).all(axis=1).any():                         # scratch sub-stamps of T3 (an experiment build only): issue | plan barrier | record landed | plane evaluation | rest
+        okx = (xs > 0).all(axis=1) & (W == 0)
+        raw = buf[:waves][buf[:waves, 0] > 0].astype(np.int64)      # (st is normalised per XCD; the sub-stamps are not)
+        seg = np.stack([xs[:, 0] - raw[:, 2], xs[:, 1] - xs[:, 0], xs[:, 2] - xs[:, 1], xs[:, 3] - xs[:, 2], raw[:, 3] - xs[:, 3]], axis=1)[okx] / 2100.0
+        print("  T3 of waves without candidate pairs, us @2.1 GHz: " + ", ".join(f"{n} mean {seg[:, k].mean():.2f} p95 {np.percentile(seg[:, k], 95):.2f}" for k, n in
+              enumerate(["key/hash/issue", "plan barrier", "record lands", "plane evaluation", "rest of T3"])))
     slow = np.argsort(-d3)[:8]
     print('  slowest T3 waves (index, W, T3):', [(int(k), int(W[k]), round(float(d3[k]), 1)) for k in slow])
     live = buf[:waves, 0] > 0
