@@ -222,14 +222,20 @@ __device__ __forceinline__ bool radius_gate(const double *n, const double *c, fl
 // measurement row (voxel_map.cpp:425-457), for a plane that passed the radius gate.
 // StateRefs: the wave-uniform operands of a plane evaluation.  R / RE / Rp / tp point into the control block (scalar loads), sP at the block's LDS copy of
 // sym(P[0:3,0:3]) (6) and sym(P[3:6,3:6]) (6) — twelve broadcast LDS reads per evaluation instead of 24 VGPRs held for the whole kernel.
-struct StateRefs { const double *R, *RE, *Rp, *tp, *sP; };
+struct StateRefs {               // ONE base pointer: every operand is a scalar load at a constant offset from it (five separate pointers were five SGPR pairs held — and spilled — for the whole kernel)
+  const DevCtl *ctl; const double *sP;
+  __device__ __forceinline__ const double *R() const { return ctl->cur.rot; }
+  __device__ __forceinline__ const double *RE() const { return ctl->hdr.RE; }
+  __device__ __forceinline__ const double *Rp() const { return ctl->prop.rot; }
+  __device__ __forceinline__ const double *tp() const { return ctl->prop.pos; }
+};
 __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double *c, const double *See, const double *pv, double pk, const GateOut &g, int32_t pidx,
                                                    double sigma_num, const double *pc, const double *pi, const double *Cb, const StateRefs &st, Best &best) {
   // sigma_l = J_nq plane_var J_nq^T + n^T Sigma_w n ,  J_nq = [p_w - c, -n]
   const double aw[3] = {-g.e[0], -g.e[1], -g.e[2]};
   double sigma_l = quad_plane(See, pv, pk, aw);
   // n^T Sigma_w n = m^T Cb m + q^T Prr q + n^T Ptt n  with m = R^T n, q = n x p_i  (Sigma_w = R Cb R^T + X Prr X^T + Ptt, X = [p_i]x)
-  double m[3]; mat3t_vec_fma(st.R, n, m);
+  double m[3]; mat3t_vec_fma(st.R(), n, m);
   const double qx[3] = {n[1] * pc[2] - n[2] * pc[1], n[2] * pc[0] - n[0] * pc[2], n[0] * pc[1] - n[1] * pc[0]};
   {
     double sPrr[6], sPtt[6];
@@ -253,10 +259,10 @@ __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double
       // H / R^-1 row (voxel_map.cpp:414-458): sigma_l' at the PRIOR-pose point, var with the PRIOR rotation, A with the CURRENT one
       double q[3];                                          // PRIOR-pose world point R^ p_i + t^, un-rounded (voxel_map.cpp:425)
 #pragma unroll
-      for (int j = 0; j < 3; j++) q[j] = ((st.Rp[j * 3] * pi[0] + st.Rp[j * 3 + 1] * pi[1]) + st.Rp[j * 3 + 2] * pi[2]) + st.tp[j];
+      for (int j = 0; j < 3; j++) q[j] = ((st.Rp()[j * 3] * pi[0] + st.Rp()[j * 3 + 1] * pi[1]) + st.Rp()[j * 3 + 2] * pi[2]) + st.tp()[j];
       const double aq[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
       const double sig_q = quad_plane(See, pv, pk, aq);
-      double mp[3]; mat3t_vec_fma(st.RE, n, mp);            // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
+      double mp[3]; mat3t_vec_fma(st.RE(), n, mp);            // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
       best.w = 1.0 / (0.001 + sig_q + quad3_sym(Cb, mp));
       best.h[0] = pi[1] * m[2] - pi[2] * m[1];             // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
       best.h[1] = pi[2] * m[0] - pi[0] * m[2];
@@ -528,8 +534,10 @@ template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L,
 // (pblock, pgrid): this block's index within the scan's own grid and that grid's size — blockIdx/gridDim for a single scan, the
 // frame-local values in a batched launch.  Row `pblock` of `partials` receives the block's sums, so a frame reduces in the same
 // order whether it is launched alone or inside a batch (for the same BLOCK).
-template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const DevCtl *__restrict__ ctl, double *__restrict__ partials, int check_stop,
-                                                    int pblock, int pgrid) {
+// `ext`: extR (9) and extT (3) of `a` once more, as an ADDRESS (the kernel-argument segment / the batch entry): after T1 only the z == 0 patch of a plane evaluation
+// reads them (voxel_map.cpp:352-358), and as values they were 24 SGPRs held — and spilled — for the whole kernel on behalf of a branch almost no lane takes.
+template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const double *__restrict__ ext, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+                                                    int check_stop, int pblock, int pgrid) {
   if (check_stop && ctl->hdr.stop) return;
   extern __shared__ __attribute__((aligned(16))) double lds_red[];
   const int per_xcd = pgrid >> 3;                                // host launches a multiple of 8 blocks per scan
@@ -542,8 +550,7 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
 
   PHASE(0);
   // wave-uniform state (scalar loads)
-  const double *R = ctl->cur.rot, *t = ctl->cur.pos, *Rp = ctl->prop.rot, *tp = ctl->prop.pos, *cov = ctl->cur.cov;
-  const double *RE = ctl->hdr.RE;
+  const double *R = ctl->cur.rot, *t = ctl->cur.pos, *cov = ctl->cur.cov;
   const double plx = a.x[ic], ply = a.y[ic], plz = a.z[ic];
   const int o = a.perm[ic];                                     // per-point outputs go back to the caller's order
   PointCtx pt;
@@ -587,7 +594,7 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     for (int k = 0; k < 6; k++) if (k == e) { i_ = ii[k]; j_ = jj[k]; }
     sP[tid] = 0.5 * (cov[(o3 + i_) * DS + o3 + j_] + cov[(o3 + j_) * DS + o3 + i_]);
   }
-  const StateRefs st = {R, RE, Rp, tp, sP};
+  const StateRefs st = {ctl, sP};
   if (a.var && valid) {       // pv.var = R Cb R^T + X Prr X^T + Ptt (voxel_map.cpp:387), only materialised when the caller asks for it
     double pc[3]; point_pc(pt, a.ER, a.Et, pc);
     const double Cbf[9] = {Cb[0], Cb[1], Cb[2], Cb[1], Cb[3], Cb[4], Cb[2], Cb[4], Cb[5]};
@@ -640,10 +647,10 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     // A plane-root neighbour is visited only if the first visit fails, one dependent trip later: start pulling its two cache
     // lines towards this CU now (a discarded dword per line), so that trip is an L2 hit instead of an HBM miss.
     if (nb.val >= 0) { touch_line<BLOCK>(a.map.planes + (size_t)nb.val * PLANE_HOT_DOUBLES); touch_line<BLOCK>(a.map.plane_aux + nb.val); }
-    if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, a.ER, a.Et, st, best);
+    if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, ext, ext + 9, st, best);
     plan1W = plan1.W;
     if (plan1.W > 0) {              // block-uniform
-      coop_park_ctx(coop, pt, a.ER, a.Et);      // (the first barrier inside coop_run orders these rows before the evaluators' reads)
+      coop_park_ctx(coop, pt, ext, ext + 9);      // (the first barrier inside coop_run orders these rows before the evaluators' reads)
       coop_run(coop, a.map, plan1, a.max_layer, a.sigma_num, st, best COOP_PROF_ARG1);
       coop_unpark_ctx(coop, pt);
     }
@@ -657,10 +664,10 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     const CoopPlan plan2 = coop_plan(coop, 1, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin);
     if (retry && nb.val >= 0) {
       PlaneRec p1; load_plane(a.map, nb.val, p1);
-      visit_plane_root(p1, nb.val, a.sigma_num, pt, a.ER, a.Et, st, best);
+      visit_plane_root(p1, nb.val, a.sigma_num, pt, ext, ext + 9, st, best);
     }
     if (plan2.W > 0) {
-      if (plan1W == 0) coop_park_ctx(coop, pt, a.ER, a.Et);
+      if (plan1W == 0) coop_park_ctx(coop, pt, ext, ext + 9);
       coop_run(coop, a.map, plan2, a.max_layer, a.sigma_num, st, best COOP_PROF_ARG2);
     }
   }
@@ -732,13 +739,30 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
 // `order` (nullable): launch slot -> chunk.  Blocks are dispatched in blockIdx order, so order[] decides which chunks start in the first round of blocks; the chunk
 // index (not the slot) selects the points and the partial row, so results do not depend on it.  `cost` (nullable): cost[chunk] = lifetime of the block that
 // worked on the chunk, in 10-ns ticks.
+static_assert(offsetof(LidarKernelArgs, Et) == offsetof(LidarKernelArgs, ER) + 72, "extR and extT are read as twelve consecutive doubles");
+// the same twelve doubles in the kernel-argument segment (LidarKernelArgs is the first argument of both single-scan kernels)
+__device__ __forceinline__ const double *lidar_kernarg_ext() {
+  return (const double *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LidarKernelArgs, ER));      // (constant address space -> generic)
+}
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+                                                                int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost) {
+  // One block per chunk, and NO loop around the body: inside a loop every launch-invariant value of the body (kernel arguments, addresses into the control block, the
+  // "is this output wanted" conditions) is hoisted in front of it and stays live across the whole body — 145 spilled SGPRs, i.e. ~140 v_writelane at the start of every
+  // wave and ~180 v_readlane along its way, a quarter of the VALU instructions a wave issues (the body is bound by instruction issue, profiles/r04_l2_retention_probe.txt).
+  const int pb = order ? order[blockIdx.x] : (int)blockIdx.x;
+  const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  lidar_residual_body<BLOCK>(a, lidar_kernarg_ext(), ctl, partials, check_stop, pb, chunks);
+  if (cost && threadIdx.x == 0) cost[pb] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
+}
+// The resident-grid variant (LIVO2_LIDAR_RESIDENT=<blocks>, tools/lidar_resident_probe.py): block b works through chunks b, b + gridDim, ...
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual_resident(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost) {
   for (int slot = (int)blockIdx.x; slot < chunks; slot += (int)gridDim.x) {
     const int pb = order ? order[slot] : slot;
     const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    lidar_residual_body<BLOCK>(a, ctl, partials, check_stop, pb, chunks);
+    lidar_residual_body<BLOCK>(a, lidar_kernarg_ext(), ctl, partials, check_stop, pb, chunks);
     if (cost && threadIdx.x == 0) cost[pb] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
     if (slot + (int)gridDim.x < chunks) __syncthreads();           // the next chunk's cooperative-visit tiles alias the reduction tiles just read
   }
@@ -753,7 +777,7 @@ __global__ void __launch_bounds__(LIDAR_BLOCK_BATCH) __attribute__((amdgpu_waves
   const int f = block_frame[blockIdx.x];                         // block-uniform: scalar loads
   const LidarBatchEntry &e = entries[f];
   const LidarKernelArgs a = e.a;
-  lidar_residual_body<LIDAR_BLOCK_BATCH>(a, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);
+  lidar_residual_body<LIDAR_BLOCK_BATCH>(a, e.a.ER, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);
 }
 
 // Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 16 slices

@@ -355,8 +355,11 @@ void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_s
   const bool lpt = lidar_lpt_on(ctx, chunks) && resident == 0;
   const int32_t *order = (lpt && ctx->lpt_valid) ? ctx->d_lpt_order : nullptr;
   uint32_t *cost = lpt ? ctx->d_lpt_cost : nullptr;
-  if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
-  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+  if (resident > 0) {
+    if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual_resident<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+    else hipLaunchKernelGGL(k_lidar_residual_resident<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+  } else if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(chunks), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(chunks), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
 }
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {

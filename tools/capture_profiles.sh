@@ -7,6 +7,7 @@
 set -u
 TAG=${1:-r04}
 ROOT=$(pwd); export TMPDIR=/tmp
+cp .c4cache/livo2_c4_*.pkl /tmp/ 2>/dev/null          # the headline frame, if a generated copy travelled with the tree (bench.c4_frame caches it under $TMPDIR; ~40 s of numpy otherwise)
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p "$OUT"
 python tools/traffic.py sha > "$OUT/build_sha.txt"
 HEAD="python bench.py --no-cpu --no-extra --steps 10 --warmup 2"
@@ -42,6 +43,6 @@ pmc3 out_of_cache python bench.py --no-cpu --c5-frames 0 --legs ooc --steps 5 --
 cp gpurun_out/${TAG}_traffic_*.json profiles/ 2>/dev/null
 # 5. the bench line of the default command, LAST (its roofline.traffic now cites the records above), then the probes
 timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cp gpurun_out/bench_full.json "$OUT/bench_full.json"
-timeout 300 python tools/vis_persist_probe.py > "$OUT/vis_persist_probe.txt" 2> "$OUT/vis_persist_probe.err"
-timeout 900 python tests/sweeps/parity_sweep.py 12 8 > "$OUT/parity_sweep.txt" 2> "$OUT/parity_sweep.err"
+[ -n "${SKIP_VIS_PROBE:-}" ] || timeout 300 python tools/vis_persist_probe.py > "$OUT/vis_persist_probe.txt" 2> "$OUT/vis_persist_probe.err"
+timeout 900 python tests/sweeps/parity_sweep.py ${SWEEP_ARGS:-12 8} > "$OUT/parity_sweep.txt" 2> "$OUT/parity_sweep.err"
 ls -la "$OUT"
