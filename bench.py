@@ -22,7 +22,8 @@ Extra objects on the same line:
   cpu_baseline  the oracle ("port": restated reference CPU path, -O3 -march=native -fopenmp, 4 threads = the reference's MP_PROC_NUM)
                 timed on this host on the same frame: StateEstimation window (LIVMapper.cpp:368-374) + computeJacobianAndUpdateEKF window
                 (vio.cpp:1808-1812), same unit as `value`.
-  extra         C2 / C3 / batched / out-of-cache legs, frames/s, the widened rows (tools/bench_legs.py).
+  extra         C2 / C3 / batched / out-of-cache legs, frames/s, the widened rows (tools/bench_legs.py) — in the full report only (gpurun_out/bench_full.json + stderr);
+                --full adds the slow informational ones (C4-sized live chain: minutes of host-side scene generation on a fresh box; oracle timings of the widened rows).
 """
 import argparse
 import importlib
@@ -554,6 +555,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational legs")
     ap.add_argument("--legs", default="", help="comma list of the headline legs to run (single,lockstep,chains,live,c2,c3,batched,ooc,map); default all; the widened rows run only with all")
+    ap.add_argument("--full", action="store_true", help="also the slow informational legs: the C4-sized live chain (1-2 min of host-side scene generation on a fresh box) and the oracle (CPU) "
+                                                        "timings of the widened rows; the stdout line is the same with or without it (those legs only add to the full report's extra / cpu_baseline)")
     ap.add_argument("--dist-selftest", action="store_true", help="run only the rank logic (gloo, no GPU)")
     ap.add_argument("--emit-selftest", action="store_true", help="run only the emission of the result line (no GPU)")
     ap.add_argument("--pre-warm-s", type=float, default=1.0, help="seconds of the same step run untimed BEFORE the --warmup steps (a fresh box starts at idle clocks); 0 disables; reported as pre_warm_s")
@@ -673,7 +676,7 @@ def main():
         if not args.no_cpu:
             try:
                 cpu, (orc_mod, lib, orc_chain) = cpu_baseline(sc, vs)
-                if not args.no_extra:
+                if not args.no_extra and args.full:
                     cpu.update(cpu_widened_rows(orc_mod, lib, orc_chain))
             except Exception as exc:
                 extra["cpu_baseline_error"] = repr(exc)

@@ -67,8 +67,8 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
         _lockstep_leg(ctx, w, extra, copy_gbs)
     if "chains" in legs:
         _chains_leg(ctx, livo2, w, extra)
-    if "chain" in legs or "live" in legs:
-        _live_chain_leg(extra)
+    if "chain" in legs or "live" in legs:                   # (the C4-sized chain: 6 frames of 200 000 points + 120 000 visual points to generate on the host first — only with --full / --legs live_c4)
+        _live_chain_leg(extra, ("avia", "c4") if (getattr(args, "full", False) or "live_c4" in legs) else ("avia",))
     if "live" in legs:
         _live_leg(ctx, w, extra)
     if legs & {"c2", "c3", "batched", "ooc"}:

@@ -41,8 +41,8 @@ pmc3 batched python bench.py --no-cpu --c5-frames 0 --legs batched --steps 5 --w
 pmc3 out_of_cache python bench.py --no-cpu --c5-frames 0 --legs ooc --steps 5 --warmup 1
 # 4. the records are in gpurun_out/<tag>_traffic_*.json; make them visible to the bench run below the way the committed ones will be (profiles/ on this box only)
 cp gpurun_out/${TAG}_traffic_*.json profiles/ 2>/dev/null
-# 5. the bench line of the default command, LAST (its roofline.traffic now cites the records above), then the probes
-timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cp gpurun_out/bench_full.json "$OUT/bench_full.json"
+# 5. the bench line (default command + --full: every informational leg in the full report; the stdout line is the default command's), LAST (its roofline.traffic now cites the records above), then the probes
+timeout 1200 python bench.py --full > "$OUT/bench.json" 2> "$OUT/bench.err"; cp gpurun_out/bench_full.json "$OUT/bench_full.json"
 [ -n "${SKIP_VIS_PROBE:-}" ] || timeout 300 python tools/vis_persist_probe.py > "$OUT/vis_persist_probe.txt" 2> "$OUT/vis_persist_probe.err"
 timeout 900 python tests/sweeps/parity_sweep.py ${SWEEP_ARGS:-12 8} > "$OUT/parity_sweep.txt" 2> "$OUT/parity_sweep.err"
 ls -la "$OUT"
