@@ -536,7 +536,8 @@ template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L,
 // order whether it is launched alone or inside a batch (for the same BLOCK).
 // `ext`: extR (9) and extT (3) of `a` once more, as an ADDRESS (the kernel-argument segment / the batch entry): after T1 only the z == 0 patch of a plane evaluation
 // reads them (voxel_map.cpp:352-358), and as values they were 24 SGPRs held — and spilled — for the whole kernel on behalf of a branch almost no lane takes.
-template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const double *__restrict__ ext, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+// PUBLISH (k_lidar_iteration): the partial row is consumed by another block of the SAME launch — write-through (sc1) stores, HIP guide section 6 guideline 16, recipe R1.
+template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar_residual_body(const LidarKernelArgs &a, const double *__restrict__ ext, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                     int check_stop, int pblock, int pgrid) {
   if (check_stop && ctl->hdr.stop) return;
   extern __shared__ __attribute__((aligned(16))) double lds_red[];
@@ -727,7 +728,9 @@ template <int BLOCK> __device__ __forceinline__ void lidar_residual_body(const L
     double v = lds_red[tid];
 #pragma unroll
     for (int w = 1; w < BLOCK / LIVO2_WAVE; w++) v = v + lds_red[32 * w + tid];
-    partials[(size_t)pblock * 32 + tid] = (tid < LIDAR_NSUM) ? v : 0.0;
+    const double out = (tid < LIDAR_NSUM) ? v : 0.0;
+    if (PUBLISH) __hip_atomic_store(&partials[(size_t)pblock * 32 + tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partials[(size_t)pblock * 32 + tid] = out;
   }
   PHASE(6);
 }
@@ -744,15 +747,21 @@ static_assert(offsetof(LidarKernelArgs, Et) == offsetof(LidarKernelArgs, ER) + 7
 __device__ __forceinline__ const double *lidar_kernarg_ext() {
   return (const double *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LidarKernelArgs, ER));      // (constant address space -> generic)
 }
+__device__ __forceinline__ const LidarKernelArgs &lidar_kernarg_args() { return *(const LidarKernelArgs *)__builtin_amdgcn_kernarg_segment_ptr(); }
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost) {
   // One block per chunk, and NO loop around the body: inside a loop every launch-invariant value of the body (kernel arguments, addresses into the control block, the
   // "is this output wanted" conditions) is hoisted in front of it and stays live across the whole body — 145 spilled SGPRs, i.e. ~140 v_writelane at the start of every
   // wave and ~180 v_readlane along its way, a quarter of the VALU instructions a wave issues (the body is bound by instruction issue, profiles/r04_l2_retention_probe.txt).
+  if (check_stop && ctl->hdr.stop) return;
   const int pb = order ? order[blockIdx.x] : (int)blockIdx.x;
   const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  lidar_residual_body<BLOCK>(a, lidar_kernarg_ext(), ctl, partials, check_stop, pb, chunks);
+  // The body reads the launch arguments BY ADDRESS from the kernel-argument segment (scalar loads where a value is used): as by-value parameters LLVM loads all ~70
+  // SGPRs of them in the prologue and keeps them live across the whole body — 70 spilled SGPRs, i.e. v_writelane / v_readlane traffic in a body that is bound by
+  // instruction issue.  By address: 30 spills (exec masks of the nested branches), k_lidar_residual 21.1 -> 20.35 us by events, 28.45 -> 27.2 us per iteration
+  // (profiles/r05_lidar_args_by_address_ab.txt).
+  lidar_residual_body<BLOCK>(lidar_kernarg_args(), lidar_kernarg_ext(), ctl, partials, 0, pb, chunks);
   if (cost && threadIdx.x == 0) cost[pb] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
 }
 // The resident-grid variant (LIVO2_LIDAR_RESIDENT=<blocks>, tools/lidar_resident_probe.py): block b works through chunks b, b + gridDim, ...
@@ -762,7 +771,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   for (int slot = (int)blockIdx.x; slot < chunks; slot += (int)gridDim.x) {
     const int pb = order ? order[slot] : slot;
     const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    lidar_residual_body<BLOCK>(a, lidar_kernarg_ext(), ctl, partials, check_stop, pb, chunks);
+    lidar_residual_body<BLOCK>(lidar_kernarg_args(), lidar_kernarg_ext(), ctl, partials, check_stop, pb, chunks);
     if (cost && threadIdx.x == 0) cost[pb] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
     if (slot + (int)gridDim.x < chunks) __syncthreads();           // the next chunk's cooperative-visit tiles alias the reduction tiles just read
   }
@@ -776,8 +785,12 @@ __global__ void __launch_bounds__(LIDAR_BLOCK_BATCH) __attribute__((amdgpu_waves
                                                                 const int32_t *__restrict__ block_frame, int check_stop) {
   const int f = block_frame[blockIdx.x];                         // block-uniform: scalar loads
   const LidarBatchEntry &e = entries[f];
+#ifdef LIDAR_BATCH_ARGS_COPY
   const LidarKernelArgs a = e.a;
   lidar_residual_body<LIDAR_BLOCK_BATCH>(a, e.a.ER, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);
+#else
+  lidar_residual_body<LIDAR_BLOCK_BATCH>(e.a, e.a.ER, e.ctl, e.partials, check_stop, (int)blockIdx.x - e.block_begin, e.nblocks);      // (by address, as in k_lidar_residual)
+#endif
 }
 
 // Deterministic reduction of per-block partial sums: partials[nblocks][32] -> out[32] (LDS).  SOLVE_THREADS threads = 16 slices
@@ -866,6 +879,7 @@ __device__ inline void lidar_block_order_wave(const LptArgs &lpt, uint32_t *hist
   }
 }
 
+__device__ __forceinline__ void lidar_solve_algebra(DevCtl *__restrict__ ctl, SolveLds &s, const double *sums, int mode, int iter, int max_iter, int hdr_rematch, const int lane);
 __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
                                                  int max_iter, const LptArgs &lpt, const bool order_block SOLVE_PROF_PARAM) {
   SPHASE(0);
@@ -895,7 +909,15 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
   SPHASE(2);
   if (mode == 1 && hdr_stop) return;
   if (threadIdx.x >= LIVO2_WAVE) return;             // the 19-dim algebra is one wave: wave-local synchronisation only from here on
-  const int lane = threadIdx.x;
+  SPHASE(3);
+  lidar_solve_algebra(ctl, s, sums, mode, iter, max_iter, hdr_rematch, threadIdx.x);
+  SPHASE(5);
+}
+
+// The 19-dim part of one iteration, ONE wave (wave-local synchronisation only): sums (reduced partial rows, LDS) -> H^T R^-1 H / H^T R^-1 z -> Kalman update of
+// ctl->cur -> convergence / rematch / covariance update and, on the stopping iteration, the result block (voxel_map.cpp:464-499).  s.P / s.cur / s.prop
+// (esikf_prefetch_wave) and s.vec[0..2] (esikf_log_lane) must be in LDS.  Shared by k_lidar_solve and by the last-arriving block of k_lidar_iteration.
+__device__ __forceinline__ void lidar_solve_algebra(DevCtl *__restrict__ ctl, SolveLds &s, const double *sums, int mode, int iter, int max_iter, int hdr_rematch, const int lane) {
   // expand symmetric 21 -> 6x6
   if (lane < 36) {
     int r = lane / 6, c = lane % 6;
@@ -910,9 +932,7 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
   if (lane < 6) out->Htz[lane] = s.htz[lane];
   if (lane == 0) { out->total_residual = sums[28]; out->n_eff = (int32_t)sums[27]; out->pad = 0; }
   if (mode == 0) return;
-  SPHASE(3);
   esikf_update_wave<6>(ctl, s, +1, lane);
-  SPHASE(4);
   if (lane < DS) ctl->lidar.iter_solution[iter][lane] = s.sol[lane];
 
   // convergence / rematch / covariance update (voxel_map.cpp:475-499)
@@ -945,7 +965,6 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
     ctl->lidar.converged = conv ? 1 : 0;
     if (stop_now && mode == 1) ctl->hdr.stop = 1;
   }
-  SPHASE(5);
 }
 
 __global__ void __launch_bounds__(SOLVE_THREADS) k_lidar_solve(DevCtl *__restrict__ ctl, const double *__restrict__ partials, int nblocks, int mode, int iter,
@@ -974,4 +993,123 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_lidar_finish(DevCtl *__restrict_
   const double *src = reinterpret_cast<const double *>(&ctl->cur);
   double *dst = reinterpret_cast<double *>(&ctl->lidar.state);
   for (int e = lane; e < (int)(sizeof(livo2_state) / sizeof(double)); e += LIVO2_WAVE) dst[e] = src[e];
+}
+
+// ---- one ESIKF iteration as ONE launch: residual grid + reduction + solve (round 5) -------------------------------------------------------------------------------
+// reference src/voxel_map.cpp:372-500 (one turn of the iteration loop of StateEstimation).
+// Rounds 1-4 ran every iteration as two launches: the residual grid, then k_lidar_solve on ONE compute unit — 11-15 us of which ~2 are the kernel boundary, ~3 the
+// start-up and the partial rows' trip through one CU, and, on some boxes, several more because two blocks alone on the chip between two full-grid launches look like
+// an idle chip to the power management (VERDICT r04 "weak" 3).  Here the last block of the residual grid to publish its row does the solve:
+//   every block : partial row with write-through (sc1) stores -> the storing wave drains (s_waitcnt vmcnt(0)) -> one lane draws a ticket (relaxed agent-scope
+//                 fetch_add) — HIP guide section 6 guideline 16, recipe R1 in its counter form; no fence, no polling of rows.
+//   tickets are HIERARCHICAL: 784 fetch_adds on one address are served one after the other at ~30-40 ns each (measured: the flat counter made the launch 31 us
+//                 longer); a block draws from the counter of its group (launch slot & 31: ~25 blocks, and — the dispatcher deals slots round-robin over the XCDs —
+//                 all on one XCD), the last of a group draws from the top counter, the last there is the last arriver of the launch.
+//   last arriver: P / both states / Log(cur^T prop) exactly as k_lidar_solve issues them, all rows with cache-bypassing loads in the order of
+//                 reduce_partials_block (16 slices, rows s, s + 16, ... ascending, slices joined in order: bit-identical sums), then lidar_solve_algebra; it leaves
+//                 every counter at zero again (nobody else touches them any more) and flips the order selector.
+//   second-to-last top ticket : the launch order of the NEXT launch (the counting sort of lidar_block_order_wave) on its own CU, into the order buffer this launch
+//                 does NOT read (a block reads order[blockIdx.x] as its first instruction, and the one block that is still missing may not have got there yet).
+// The fused arguments are read from the kernel-argument segment where they are needed (scalar loads by address): as by-value parameters they would be ~12 more
+// SGPRs live across the whole residual body.
+#define LIDAR_TICKET_GROUPS 32
+#define LIDAR_TICKET_WORDS (LIDAR_TICKET_GROUPS + 2)             // group counters, top counter, order-buffer selector
+struct LidarFuseArgs { int32_t mode, iter, max_iter, order_cap; const uint32_t *cost; int32_t *order_buf; int32_t *tickets; };   // order_buf: [2][order_cap] or null
+struct LidarIterationKernargs { LidarKernelArgs a; const DevCtl *ctl; double *partials; int32_t check_stop, chunks; const int32_t *order_buf; uint32_t *cost; LidarFuseArgs fz; };   // mirror of the kernel's parameter list
+__device__ __forceinline__ const LidarFuseArgs &lidar_kernarg_fuse() {
+  return *(const LidarFuseArgs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LidarIterationKernargs, fz));
+}
+#define LIDAR_FUSE_FLAG_OFF 384                                  // behind the reduction tiles: [0,256) prefetch landing area, [256,352) sym(P_rr), sym(P_tt), [384,388) "my top ticket"
+#define LIDAR_FUSE_PASS 32                                       // rows per slice and pass of the last arriver: 64 doubles per thread in flight (512 rows per pass)
+
+template <int BLOCK>
+__device__ __forceinline__ void lidar_fused_tail(DevCtl *__restrict__ ctl, const double *partials, int chunks, int sel, double *lds) {
+  static_assert(BLOCK == 256, "16 reduction slices x 16 lanes");
+  const LidarFuseArgs &fz = lidar_kernarg_fuse();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int *flag = reinterpret_cast<int *>(reinterpret_cast<char *>(lds) + LIDAR_LDS_BYTES_OF(BLOCK) + LIDAR_FUSE_FLAG_OFF);
+  const int ngroups = min(chunks, LIDAR_TICKET_GROUPS);
+  if (wave == 0) {                                                // the wave that stored the row (and the lifetime)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const int g = (int)blockIdx.x & (LIDAR_TICKET_GROUPS - 1);
+      const int members = chunks / LIDAR_TICKET_GROUPS + (g < chunks % LIDAR_TICKET_GROUPS ? 1 : 0);
+      int top = -1;
+      if (__hip_atomic_fetch_add(fz.tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
+        top = __hip_atomic_fetch_add(fz.tickets + LIDAR_TICKET_GROUPS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = top;
+    }
+  }
+  __syncthreads();
+  const int top = *flag;
+  if (top < ngroups - 2) return;
+  if (top == ngroups - 2) {
+    // every lifetime but those of the last group's stragglers has been published (sc1 stores ahead of the tickets): any permutation is a valid order
+    if (wave == 0 && fz.order_buf) {
+      uint32_t cc[LPT_MAX_CHUNKS / LIVO2_WAVE];
+#pragma unroll
+      for (int u = 0; u < LPT_MAX_CHUNKS / LIVO2_WAVE; u++) { const int c = lane + LIVO2_WAVE * u; cc[u] = (c < chunks) ? __hip_atomic_load(fz.cost + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; }
+      const LptArgs lpt = {fz.cost, fz.order_buf + (size_t)(1 - sel) * fz.order_cap, chunks, 0};
+      lidar_block_order_wave(lpt, reinterpret_cast<uint32_t *>(lds), reinterpret_cast<uint32_t *>(lds) + 64, lane, cc);
+    }
+    return;
+  }
+  // ---- the last arriver: every row of this launch has been published
+  SolveLds &s = *reinterpret_cast<SolveLds *>(lds);
+  static_assert(sizeof(SolveLds) <= 1024 * 8, "SolveLds in the first 8 KB of the tiles");
+  double *scratch = lds + 1024, *sums = scratch + 16 * 33;
+  const int mode = fz.mode, iter = fz.iter, max_iter = fz.max_iter;
+  const int hdr_rematch = ctl->hdr.rematch_num;
+  double craw[6];
+  if (wave == 0) esikf_prefetch_wave(ctl, s, 1.0, lane, craw);
+  if (tid == LIVO2_WAVE) esikf_log_lane(ctl, s);
+  if (tid >= 2 * LIVO2_WAVE && tid < 2 * LIVO2_WAVE + LIDAR_TICKET_GROUPS + 1) __hip_atomic_store(fz.tickets + (tid - 2 * LIVO2_WAVE), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all tickets are drawn
+  if (tid == 3 * LIVO2_WAVE && fz.order_buf) __hip_atomic_store(fz.tickets + LIDAR_TICKET_GROUPS + 1, 1 - sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the next launch reads the buffer the sorter of this one fills
+  {
+    const int kp = tid & 15, slice = tid >> 4;                    // two of the 32 values of a row per thread; slice s adds rows s, s + 16, ... (reduce_partials_block's order)
+    double a0 = 0.0, a1 = 0.0;
+    for (int base = 0; base < chunks; base += 16 * LIDAR_FUSE_PASS) {
+      double v0[LIDAR_FUSE_PASS], v1[LIDAR_FUSE_PASS];
+#pragma unroll
+      for (int u = 0; u < LIDAR_FUSE_PASS; u++) {
+        const int b = base + slice + 16 * u;
+        const double *src = partials + (size_t)(b < chunks ? b : 0) * 32 + 2 * kp;
+        v0[u] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v1[u] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b >= chunks) { v0[u] = 0.0; v1[u] = 0.0; }
+      }
+#pragma unroll
+      for (int u = 0; u < LIDAR_FUSE_PASS; u++) { a0 += v0[u]; a1 += v1[u]; }
+    }
+    scratch[slice * 33 + 2 * kp] = a0; scratch[slice * 33 + 2 * kp + 1] = a1;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double r = scratch[tid];
+#pragma unroll
+    for (int sl = 1; sl < 16; sl++) r += scratch[sl * 33 + tid];
+    sums[tid] = r;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  lidar_solve_algebra(ctl, s, sums, mode, iter, max_iter, hdr_rematch, lane);
+}
+
+// order_buf: two launch orders of `fz.order_cap` entries each (null: scan order); word LIDAR_TICKET_GROUPS + 1 of fz.tickets selects the one this launch reads.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_iteration(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+                                                                int check_stop, int chunks, const int32_t *__restrict__ order_buf, uint32_t *__restrict__ cost, LidarFuseArgs fz_by_address) {
+  static_assert(offsetof(LidarIterationKernargs, fz) == sizeof(LidarKernelArgs) + 40, "kernel-argument layout");
+  if (check_stop && ctl->hdr.stop) return;                        // the loop has ended: no row, no ticket
+  extern __shared__ __attribute__((aligned(16))) double lds_red[];
+  int sel = 0, pb = (int)blockIdx.x;
+  if (order_buf) {                                                // three independent scalar loads, one round trip
+    const LidarFuseArgs &fz = lidar_kernarg_fuse();
+    const int o0 = order_buf[blockIdx.x], o1 = order_buf[(size_t)fz.order_cap + blockIdx.x];
+    sel = fz.tickets[LIDAR_TICKET_GROUPS + 1] & 1;
+    pb = sel ? o1 : o0;
+  }
+  const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  lidar_residual_body<BLOCK, true>(lidar_kernarg_args(), lidar_kernarg_ext(), ctl, partials, 0, pb, chunks);
+  if (cost && threadIdx.x == 0) __hip_atomic_store(&cost[pb], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lidar_fused_tail<BLOCK>(const_cast<DevCtl *>(ctl), partials, chunks, sel, lds_red);
 }

@@ -143,12 +143,23 @@ struct livo2_ctx {
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
   unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0; uint32_t vp_seq = 0;
   // block order of k_lidar_residual (lidar_kernels.hpp, LptArgs): lifetimes per chunk written by every launch, order written by every solve; valid once a solve of this scan has run
+  int32_t *d_lidar_tickets = nullptr;
   int32_t *d_lpt_order = nullptr; uint32_t *d_lpt_cost = nullptr; size_t lpt_order_cap = 0, lpt_cost_cap = 0; int lpt_chunks = 0; bool lpt_valid = false;
   bool lidar_block_order = [] { const char *e = std::getenv("LIVO2_LIDAR_BLOCK_ORDER"); return e ? std::atoi(e) != 0 : true; }();
+  // one launch per ESIKF iteration (k_lidar_iteration: the last block of the residual grid to arrive reduces and solves) instead of k_lidar_residual + k_lidar_solve:
+  // option "lidar_fused_iteration" / LIVO2_LIDAR_FUSED=1.  Same results bit for bit (tests/test_bench_workload_gpu.py) — and measured SLOWER at C4 (31.0 against 28.2 us
+  // per iteration, profiles/r05_lidar_fused_iteration_ab.txt: every block pays a store drain + an atomic round trip before it may leave), so the default stays off.
+  bool lidar_fused = [] { const char *e = std::getenv("LIVO2_LIDAR_FUSED"); return e ? std::atoi(e) != 0 : false; }();
+  int lidar_fused_launches = 0;
   hipEvent_t vp_done = nullptr; int vp_blocks_inflight = 0;     // this ctx's last persistent launch (device-wide accounting below)
   unsigned long long *d_vp_prof = nullptr; bool vp_prof = [] { const char *e = std::getenv("LIVO2_VP_PROF"); return e ? std::atoi(e) != 0 : false; }();
   int vp_used = 0, vp_fallback = 0, vp_timeouts = 0;             // statistics: persistent launches / fallbacks to the per-step sequence / grids that gave up and were re-run per step
   bool vp_debug_timeout = false, vp_rerun = false, vp_last_valid = false;
+  // watchdog of the resident grid: a word that does not arrive within vp_timeout_us makes every block leave; the update is then re-run per step.  Default 20 ms
+  // (a C4 update is 0.25 ms; a 10 Hz pipeline must not spin for seconds): option "visual_persistent_timeout_us" / LIVO2_VP_TIMEOUT_US.  After a time-out the ctx
+  // uses the launch-per-step sequence for vp_backoff_left further updates (8, doubling up to 1024 while time-outs repeat) before it tries a resident grid again.
+  int vp_timeout_us = [] { const char *e = std::getenv("LIVO2_VP_TIMEOUT_US"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 20000; }();
+  int vp_backoff_left = 0, vp_backoff_len = 0, vp_backoff_skips = 0;
   livo2_state vp_last_in{}, vp_last_prop{}; livo2_visual_cfg vp_last_cfg{};       // inputs of the last persistent launch (a timed-out grid is re-run from them)
   bool tree_mode = false;
   MapTreeArgs mt{};
@@ -360,6 +371,27 @@ void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_s
     else hipLaunchKernelGGL(k_lidar_residual_resident<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
   } else if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(chunks), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
   else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(chunks), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+}
+
+// One ESIKF iteration as ONE launch (lidar_kernels.hpp, k_lidar_iteration).  False: this configuration runs the two-launch sequence (128-point blocks, the resident-grid
+// experiment, the profiling build with its stamps in k_lidar_solve, option off).
+bool lidar_fused_on(livo2_ctx *ctx) {
+#ifdef LIVO2_PHASE_PROF
+  return false;
+#else
+  static const bool resident = [] { const char *e = std::getenv("LIVO2_LIDAR_RESIDENT"); return e && std::atoi(e) > 0; }();
+  return ctx->lidar_fused && ctx->lidar_block == 256 && !resident;
+#endif
+}
+void launch_lidar_iteration(livo2_ctx *ctx, const LidarKernelArgs &a, int check_stop, int mode, int iter, int max_iter) {
+  const int chunks = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
+  const bool lpt = lidar_lpt_on(ctx, chunks);
+  const int32_t *order = (lpt && ctx->lpt_valid) ? ctx->d_lpt_order : nullptr;
+  uint32_t *cost = lpt ? ctx->d_lpt_cost : nullptr;
+  const LidarFuseArgs fz = {mode, iter, max_iter, (int32_t)(ctx->lpt_order_cap / 2), cost, lpt ? ctx->d_lpt_order : nullptr, ctx->d_lidar_tickets};
+  hipLaunchKernelGGL(k_lidar_iteration<256>, dim3(chunks), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost, fz);
+  if (lpt) ctx->lpt_valid = true;                                  // the launches enqueued from here on read the order this one writes
+  ctx->lidar_fused_launches++;
 }
 
 int check_lidar_cfg(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
@@ -603,7 +635,7 @@ VisualSolveArgs visual_solve_args(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
 
 extern "C" {
 
-const char *livo2_version(void) { return "livo2_hip 0.1 (gfx950)"; }
+const char *livo2_version(void) { return "livo2_hip 0.2 (gfx950)"; }     // 0.2: livo2_select_cfg.raycast_en (was pad), livo2_lidar_points.pinned (appended): bindings check livo2_abi_sizeof
 int32_t livo2_abi_sizeof(const char *name) {
   if (!name) return 0;
 #define LIVO2_SZ(T) if (std::strcmp(name, #T) == 0) return (int32_t)sizeof(T);
@@ -658,7 +690,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
                  ctx->d_ray_counters, ctx->d_ray_add};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
@@ -721,7 +753,12 @@ int livo2_debug_redzone_check(livo2_ctx *ctx, int32_t *mode, int64_t *damaged_wo
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (!ctx || !name) return LIVO2_ERR_INVALID;
   if (std::strcmp(name, "lidar_block_order") == 0) { ctx->lidar_block_order = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
+  if (std::strcmp(name, "lidar_fused_iteration") == 0) { ctx->lidar_fused = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_persistent_timeout_us") == 0) {
+    if (value < 100 || value > 10000000) return fail(ctx, LIVO2_ERR_INVALID, "visual_persistent_timeout_us out of [100, 10000000]");
+    ctx->vp_timeout_us = value; return LIVO2_OK;
+  }
   if (std::strcmp(name, "visual_persistent_debug_timeout") == 0) { ctx->vp_debug_timeout = value != 0; return LIVO2_OK; }     // test hook: the last block of the grid leaves at once, the others give up after 2 ms
   return fail(ctx, LIVO2_ERR_INVALID, "unknown option");
 }
@@ -730,7 +767,9 @@ int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
   if (std::strcmp(name, "visual_persistent_launches") == 0) { *value = ctx->vp_used; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_fallbacks") == 0) { *value = ctx->vp_fallback; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_timeouts") == 0) { *value = ctx->vp_timeouts; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_persistent_backoff_skips") == 0) { *value = ctx->vp_backoff_skips; return LIVO2_OK; }
   if (std::strcmp(name, "map_tree_grow_events") == 0) { *value = ctx->mt_grow_events; return LIVO2_OK; }
+  if (std::strcmp(name, "lidar_fused_launches") == 0) { *value = ctx->lidar_fused_launches; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
 }
 
@@ -1056,9 +1095,12 @@ int scan_pipeline(livo2_ctx *ctx, int n, const livo2_lidar_cfg *cfg) {
   int rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, std::max((size_t)grid * 32, (size_t)64));
   if (rc) return rc;
   // a new scan: the block lifetimes of the last one say nothing about it (identity order until this scan's first solve has run)
-  rc = ensure(ctx, ctx->d_lpt_order, ctx->lpt_order_cap, (size_t)std::max(grid, 64)); if (rc) return rc;
+  rc = ensure(ctx, ctx->d_lpt_order, ctx->lpt_order_cap, 2 * (size_t)std::max(grid, 64)); if (rc) return rc;       // two orders: k_lidar_iteration fills one while its blocks read the other
   rc = ensure(ctx, ctx->d_lpt_cost, ctx->lpt_cost_cap, (size_t)std::max(grid, 64)); if (rc) return rc;
   HIPCHK(hipMemsetAsync(ctx->d_lpt_cost, 0, (size_t)grid * 4, ctx->stream));
+  // arrival counters of k_lidar_iteration: zero here, and left at zero by the last arriver of every launch (a launch that was torn down half-way cannot poison the next scan)
+  if (!ctx->d_lidar_tickets) HIPCHK(DMALLOC((void **)&ctx->d_lidar_tickets, LIDAR_TICKET_WORDS * 4));
+  HIPCHK(hipMemsetAsync(ctx->d_lidar_tickets, 0, LIDAR_TICKET_WORDS * 4, ctx->stream));
   ctx->lpt_chunks = grid; ctx->lpt_valid = false;
   if (n > 0) {
     hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_xyz_aos, n, (float)(1.0 / cfg->voxel_size), ctx->d_keys, ctx->d_idx);
@@ -1668,7 +1710,9 @@ static int lidar_enqueue_loop(livo2_ctx *ctx, const livo2_lidar_cfg *cfg, int it
   LidarKernelArgs a = make_lidar_args(ctx, cfg);
   const int grid = lidar_grid(std::max(ctx->n, 1), ctx->lidar_block);
   const LptArgs lpt = lidar_lpt_on(ctx, grid) ? LptArgs{ctx->d_lpt_cost, ctx->d_lpt_order, grid, 0} : LptArgs{nullptr, nullptr, 0, 0};
+  const bool fused = lidar_fused_on(ctx);
   for (int it = 0; it < iters; it++) {
+    if (fused) { Timed t(ctx, 0); launch_lidar_iteration(ctx, a, mode == 1 ? 1 : 0, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30)); t.done(); continue; }
     { Timed t(ctx, 0); launch_lidar_residual(ctx, a, mode == 1 ? 1 : 0); t.done(); }
     { Timed t(ctx, 2); hipLaunchKernelGGL(k_lidar_solve, dim3(lpt.order ? 2 : 1), dim3(SOLVE_THREADS), 0, ctx->stream, ctx->d_ctl, ctx->d_partials, grid, mode, it % LIVO2_MAX_ITERS, mode == 1 ? iters : (1 << 30), lpt SOLVE_PROF_ARG); t.done(); }
     if (lpt.order) ctx->lpt_valid = true;                          // the launches enqueued from here on read the order this solve writes
@@ -2512,7 +2556,9 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
   const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(ctx->M, 1)) : visual_grid(std::max(ctx->M, 1));
   VisualKernelArgs a{};
   ctx->vp_last_valid = false;
-  if (mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && !ctx->vp_rerun && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations) {
+  bool want_persistent = mode == 1 && !cfg->inverse_composition_en && ctx->visual_persistent && !ctx->vp_rerun && level_lo == 0 && level_hi == cfg->patch_pyrimid_level - 1 && iters == cfg->max_iterations;
+  if (want_persistent && ctx->vp_backoff_left > 0) { ctx->vp_backoff_left--; ctx->vp_backoff_skips++; want_persistent = false; }     // a recent grid timed out: stay on the per-step path for a while
+  if (want_persistent) {
     {                        // (before the admission: nothing between the reservation and the launch may fail) exchange buffers start as all-zero words: tag 0 is never a step's tag
       const size_t c0 = ctx->vp_rows_cap, c1 = ctx->vp_errs_cap;
       rc = ensure(ctx, ctx->d_vp_rows, ctx->vp_rows_cap, (size_t)2 * VP_MAX_ROWS * VIS_PSTRIDE * 2); if (rc) return rc;
@@ -2534,7 +2580,7 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       ctx->vp_seq = (ctx->vp_seq + 1) & 0xffffffu; if (ctx->vp_seq == 0) ctx->vp_seq = 1;       // tag 0 = never-written memory
       p.tag_base = ctx->vp_seq << 8;
       if (ctx->vp_prof) p.prof = ctx->d_vp_prof;
-      p.timeout = ctx->vp_debug_timeout ? 200000ull : VP_TIMEOUT;              // debug: 2 ms
+      p.timeout = ctx->vp_debug_timeout ? 200000ull : (unsigned long long)ctx->vp_timeout_us * 100ull;      // 100 MHz ticks; debug: 2 ms
       p.debug_drop_block = (ctx->vp_debug_timeout && G > 1) ? G - 1 : -1;
       ctx->vp_last_in = *state_in; ctx->vp_last_prop = *prop; ctx->vp_last_cfg = *cfg; ctx->vp_last_valid = true;    // what a timed-out grid is re-run from
       { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_update_persistent, dim3(G), dim3(VP_BLOCK), 0, ctx->stream, p, ctx->d_ctl); t.done(); }
@@ -2596,6 +2642,8 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
     // launch-per-step sequence from the inputs kept at enqueue; the caller sees the same result, "visual_persistent_timeouts" counts the event.
     if (!ctx->vp_last_valid) return fail(ctx, LIVO2_ERR_HIP, "persistent visual update timed out and its inputs are gone");
     ctx->vp_timeouts++;
+    ctx->vp_backoff_len = ctx->vp_backoff_len ? std::min(2 * ctx->vp_backoff_len, 1024) : 8;       // sustained contention: back off longer each time
+    ctx->vp_backoff_left = ctx->vp_debug_timeout ? 0 : ctx->vp_backoff_len;                         // (the test hook times out on purpose, every time)
     HIPCHK(hipMemsetAsync(&ctx->d_ctl->hdr.pad[0], 0, 4, ctx->stream));
     const livo2_state in = ctx->vp_last_in, pr = ctx->vp_last_prop; const livo2_visual_cfg vc = ctx->vp_last_cfg;
     ctx->vp_rerun = true;
@@ -2606,6 +2654,7 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
     if (errors && ctx->M > 0) HIPCHK(devalloc::memcpy_async(errors, ctx->d_errors, (size_t)ctx->M * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
+  else if (ctx->vp_backoff_left == 0) ctx->vp_backoff_len = 0;     // a resident grid completed: the next time-out starts the back-off from 8 again
   std::memcpy(result, ctx->h_out, sizeof(livo2_visual_result));
   return rz_gate(ctx);
 }

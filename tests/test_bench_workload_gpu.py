@@ -154,3 +154,54 @@ def test_block_order_of_the_residual_launch_does_not_change_a_bit(ctx, c4):
     ctx.set_option("lidar_block_order", 1)
     assert out[1][0] == out[0][0] == out[1][1]
     assert out[1][0][:3] == out[1][0][3:]
+
+
+def test_fused_iteration_launch_equals_the_two_launch_sequence(ctx, c4):
+    """option "lidar_fused_iteration" (round 5): one launch per ESIKF iteration — the last block of the residual grid to publish its row reduces all rows in
+    reduce_partials_block's order and solves — against k_lidar_residual + k_lidar_solve: every byte of the result block (state, P, per-iteration sums and
+    solutions, counters) and the per-point outputs, with and without the block order, update after update on the same scan (tickets re-zeroed by the header)."""
+    sc, vs, cfg, vcfg, lid, vis = c4
+    ctx.upload_map(sc.fmap)
+    out = {}
+    for fused, order in ((1, 1), (0, 1), (1, 0), (0, 0), (1, 1)):
+        ctx.set_option("lidar_fused_iteration", fused); ctx.set_option("lidar_block_order", order)
+        ctx.set_scan(sc.xyz, cfg)
+        n0 = ctx.counter("lidar_fused_launches")
+        rs = []
+        for rep in range(2):
+            for f in range(3):
+                r, pts = ctx.lidar_update(lid[f], lid[f], cfg, want=("match_plane", "dis_to_plane"))
+                rs.append((bytes(r), pts["match_plane"].tobytes(), pts["dis_to_plane"].tobytes()))
+        assert (ctx.counter("lidar_fused_launches") > n0) == bool(fused)
+        out.setdefault((fused, order), []).append(rs)
+    ctx.set_option("lidar_fused_iteration", 0); ctx.set_option("lidar_block_order", 1)
+    ref = out[(0, 0)][0]
+    assert all(rs == ref for v in out.values() for rs in v)
+
+
+def _meaningful(r):
+    """the result block without the per-iteration slots the update did not reach (they keep whatever an earlier update left there)"""
+    return (bytes(r.state), r.n_iters, r.converged, bytes(r.position_last), [bytes(r.iter_sums[i]) for i in range(r.n_iters)], [bytes(r.iter_solution[i]) for i in range(r.n_iters)])
+
+
+def test_fused_iteration_small_scans_and_fixed_iteration_loops(ctx, livo2):
+    """the same equality where the grid is a single round of blocks (8 ... 64 chunks: ticket chunks - 2 and chunks - 1 may be drawn by blocks that started together),
+    for an empty scan, and for the benchmark loop of more iterations than the header has ticket slots (livo2_lidar_iterations_async, mode 2)."""
+    cfgs = importlib.import_module("fast-livo2_amd.configs")
+    for n in (0, 1, 300, 2047, 2048, 16000):
+        sc = synth.lidar_scenario(seed=31 + n % 7, n_points=max(n, 64), downsample=0.1)
+        xyz = sc.xyz[:n]
+        cfg = cfgs.lidar_cfg(sc)
+        st = livo2.State.from_pose(sc.R_prior, sc.t_prior, sc.P)
+        ctx.upload_map(sc.fmap)
+        res = {}
+        for fused in (1, 0):
+            ctx.set_option("lidar_fused_iteration", fused)
+            ctx.set_scan(xyz, cfg)
+            a = [_meaningful(ctx.lidar_update(st, st, cfg)[0]) for _ in range(3)]
+            ctx.lidar_iterations_async(st, st, cfg, 37); ctx.synchronize()
+            b = bytes(ctx.lidar_update_fetch().state)
+            res[fused] = (a, b)
+        ctx.set_option("lidar_fused_iteration", 0)
+        assert res[1] == res[0], n
+        assert res[1][0][0] == res[1][0][1] == res[1][0][2]

@@ -1,9 +1,9 @@
 #!/bin/bash
 # !! the TCP_UTCL1_* / TCP_* / TA_* sets below made rocprofv3 abort in hipStreamCreate on this image (signal 6) and each run then sat out its timeout: 10 GPU-minutes
 #    for nothing.  Only the first two sets are known good; try the others one at a time with `timeout 30`.
-# counter passes over tools/lidar_ab.py (torch-free C4 frame updates): one rocprofv3 --pmc run per set, summary per kernel -> gpurun_out/r04u/pmc_sets.txt
+# counter passes over tools/lidar_ab.py (torch-free C4 frame updates): one rocprofv3 --pmc run per set, summary per kernel -> gpurun_out/pmc_sets/pmc_sets.txt
 set -u
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04u; mkdir -p "$OUT"; : > "$OUT/pmc_sets.txt"
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_sets; mkdir -p "$OUT"; : > "$OUT/pmc_sets.txt"
 db() { find "$1" -name '*results.db' | head -1; }
 k=0
 while read -r set; do
