@@ -379,8 +379,8 @@ def compact_line(full):
     """The ONE stdout line of the driver contract: the headline fields + roofline + cpu_baseline, < 4 KB, strict JSON.  Everything else (`extra`, the verbose
     notes) goes to the full report (gpurun_out/bench_full.json + one stderr line) — BENCH_r03.json could not be parsed because the single line had grown to 22 KB."""
     rf, cpu = full["roofline"], full.get("cpu_baseline")
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_src", "kernel_us", "bytes_per_launch", "launches_executed",
-            "copy_kernel_GBps", "frac_of_copy_kernel")
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_src", "kernel_us", "per_rank_kernel_us", "per_rank_frame_update_us", "bytes_per_launch",
+            "launches_executed", "copy_kernel_GBps", "frac_of_copy_kernel")
     roof = {k: rf.get(k) for k in keep}
     if rf.get("visual"):
         roof["visual"] = {k: rf["visual"].get(k) for k in ("kernel", "achieved", "frac", "kernel_us", "bytes_per_launch", "launches_executed")}
@@ -624,13 +624,17 @@ def main():
     sol_us, vsol_us = 1e3 * bins[2][0] / n_lid, 1e3 * bins[3][0] / n_vis
     achieved = LIDAR_BYTES_PER_EVAL * w.N / (res_us * 1e-6) / 1e9
     vachieved = VISUAL_BYTES_PER_PATCH * w.M / (vres_us * 1e-6) / 1e9
+    # every rank's own kernel times, gathered: a straggler GPU of an 8-GPU node shows up in the one line
+    per_rank_us = frames.gather_results(np.array([[res_us, sol_us, vres_us, 1e6 * elapsed_local / (w.F * args.steps)]]), world, dist, device=device)
     copy_gbs = measure_copy_gbs(torch)
     from tools import traffic as traffic_mod
     traffic, traffic_note = traffic_mod.load("c4", points=w.N, kernel="k_lidar_residual")
     frames_ev = w.F * ev_steps
     roofline = {"bound": "hbm", "kernel": "k_lidar_residual", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note, "traffic_src": traffic_note.split(":")[0] if traffic else None,
-                "kernel_us": res_us, "bytes_per_launch": LIDAR_BYTES_PER_EVAL * w.N, "launches_executed": n_lid, "launches_timed": int(bins[0][1]),
+                "kernel_us": res_us, "per_rank_kernel_us": [round(float(x), 3) for x in per_rank_us[:, 0]], "per_rank_lidar_solve_us": [round(float(x), 3) for x in per_rank_us[:, 1]],
+                "per_rank_visual_step_us": [round(float(x), 3) for x in per_rank_us[:, 2]], "per_rank_frame_update_us": [round(float(x), 2) for x in per_rank_us[:, 3]],
+                "bytes_per_launch": LIDAR_BYTES_PER_EVAL * w.N, "launches_executed": n_lid, "launches_timed": int(bins[0][1]),
                 "copy_kernel_GBps": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs,
                 "timing": "second pass over the same launch sequence with a HIP event pair per launch on the launching stream; kernel_us = total event time of ALL "
                           "launches (the early-exit launches of converged frames included) / EXECUTED launches, so it is an upper bound of the rocprofv3 kernel-only average in profiles/",

@@ -82,12 +82,13 @@ inline hipError_t fence_alloc(void **p, size_t bytes, int line, int m) {
   void *va = nullptr;
   if ((e = hipMemAddressReserve(&va, reserved, gran, nullptr, 0)) != hipSuccess) return e;
   hipMemGenericAllocationHandle_t h;
-  if ((e = hipMemCreate(&h, mapped, &prop, 0)) != hipSuccess) return e;
+  // (every early return gives back what it has taken so far: advisor, round 4)
+  if ((e = hipMemCreate(&h, mapped, &prop, 0)) != hipSuccess) { hipError_t e2 = hipMemAddressFree(va, reserved); (void)e2; return e; }
   char *map_at = (char *)va + gran;                         // one unmapped granule on either side of the mapping
-  if ((e = hipMemMap(map_at, mapped, 0, h, 0)) != hipSuccess) return e;
+  if ((e = hipMemMap(map_at, mapped, 0, h, 0)) != hipSuccess) { hipError_t e2 = hipMemRelease(h); e2 = hipMemAddressFree(va, reserved); (void)e2; return e; }
   hipMemAccessDesc acc = {};
   acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-  if ((e = hipMemSetAccess(map_at, mapped, &acc, 1)) != hipSuccess) return e;
+  if ((e = hipMemSetAccess(map_at, mapped, &acc, 1)) != hipSuccess) { hipError_t e2 = hipMemUnmap(map_at, mapped); e2 = hipMemRelease(h); e2 = hipMemAddressFree(va, reserved); (void)e2; return e; }
   char *user = (m == 2) ? map_at + ((mapped - bytes) & ~(size_t)15) : map_at;
   *p = user;
   std::lock_guard<std::mutex> lk(mtx());

@@ -892,7 +892,8 @@ __device__ __forceinline__ void lidar_solve_body(DevCtl *__restrict__ ctl, const
   // atomics and 16 loads per lane share the CU's LDS and its memory pipeline with the wave whose latency chain is the critical path of the iteration.  On its own CU
   // it costs the solve nothing and ends well inside the solve's shadow.
   if (order_block) {
-    if (threadIdx.x < LIVO2_WAVE && lpt.order && !(mode == 1 && ctl->hdr.stop)) {
+    // (no test of ctl->hdr.stop here: block 0 of this launch may be writing it — advisor, round 4; an order computed for a loop that has just ended is simply not used)
+    if (threadIdx.x < LIVO2_WAVE && lpt.order) {
       uint32_t lpt_cc[LPT_MAX_CHUNKS / LIVO2_WAVE];
       lidar_block_order_load(lpt, threadIdx.x, lpt_cc);
       lidar_block_order_wave(lpt, lpt_hist, lpt_fill, threadIdx.x, lpt_cc);

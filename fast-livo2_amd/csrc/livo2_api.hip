@@ -2092,6 +2092,7 @@ int livo2_visual_map_upload(livo2_ctx *ctx, int32_t n, const double *pos, const 
 static int select_reserve(livo2_ctx *ctx, const livo2_select_cfg *cfg, int32_t n_pg, size_t *cap_out) {
   if (!ctx->has_vmap) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_map_upload has not been called");
   const int length = cfg->grid_n_width * cfg->grid_n_height;
+  if (cfg->raycast_en != 0 && cfg->raycast_en != 1) return fail(ctx, LIVO2_ERR_INVALID, "raycast_en must be 0 or 1 (the field was padding before livo2_hip 0.2: zero-initialise livo2_select_cfg)");
   if (cfg->grid_size < 1 || cfg->grid_n_width < 1 || cfg->grid_n_height < 1 || length > (1 << 20) || cfg->cam.width < 1 || cfg->cam.height < 1 || cfg->patch_size_half < 0 ||
       cfg->border < cfg->patch_size_half) return fail(ctx, LIVO2_ERR_INVALID, "bad grid / border (the 9x9 depth window must stay inside the image: border >= patch_size_half)");
   const size_t px = (size_t)cfg->cam.width * cfg->cam.height;

@@ -69,8 +69,10 @@ int livo2_ctx_synchronize(livo2_ctx *ctx);
 int livo2_host_alloc_pinned(size_t bytes, void **out);
 void livo2_host_free_pinned(void *p);
 const char *livo2_version(void);
-/* sizeof() of a struct of this header as the library was compiled ("livo2_state", "livo2_lidar_cfg", ...), 0 for an unknown name: lets a
- * foreign-language binding check its mirror of the layouts at load time. */
+/* sizeof() of a struct of this header as the library was compiled ("livo2_state", "livo2_lidar_cfg", ...), 0 for an unknown name.  MANDATORY for a binding:
+ * compare every struct it mirrors at load time and refuse to run on a mismatch — structs grow at their end between versions (0.2: livo2_lidar_points.pinned) and
+ * former padding becomes meaningful (0.2: livo2_select_cfg.raycast_en, validated to be 0 or 1), so a caller built against an older header must zero-initialise
+ * every struct it passes and must not pass a shorter one.  livo2_version() names the version ("livo2_hip 0.2 (gfx950)"). */
 int32_t livo2_abi_sizeof(const char *struct_name);
 
 /* Per-kernel timing with HIP events on the ctx stream (off by default; adds an event pair per launch).
@@ -84,17 +86,27 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *                        the previous launch (longest first; recorded by every launch, sorted on the device by the solve of the previous iteration, reset by
  *                        livo2_lidar_set_scan); 0: scan order.
  *                        Admission counts the resident grids of THIS process only; if another process or a long foreign kernel keeps a block of the grid off the
- *                        device, every block gives up after 2 s, nothing is committed, and livo2_visual_update_fetch re-runs the update as the per-step sequence
- *                        (counter "visual_persistent_timeouts"; "visual_persistent_debug_timeout" = 1 provokes exactly that in 2 ms, for the tests).
- * Counters: "visual_persistent_launches", "visual_persistent_fallbacks", "visual_persistent_timeouts", "map_tree_grow_events". */
+ *                        device, every block gives up after the watchdog time, nothing is committed, and livo2_visual_update_fetch re-runs the update as the
+ *                        per-step sequence (counter "visual_persistent_timeouts"; "visual_persistent_debug_timeout" = 1 provokes exactly that in 2 ms, for the tests).
+ *                        After a time-out the ctx stays on the per-step sequence for the next 8 updates (16, 32, ... up to 1024 while time-outs repeat; counter
+ *                        "visual_persistent_backoff_skips") before it tries a resident grid again.
+ *   "visual_persistent_timeout_us" (default 20000; environment LIVO2_VP_TIMEOUT_US): that watchdog, in microseconds, [100, 10000000].  A C4-sized update takes
+ *                        0.25 ms; the default keeps a 10 Hz pipeline inside its frame budget when a grid loses a compute unit (2 s until round 4).
+ *   "lidar_fused_iteration" (default 0; environment LIVO2_LIDAR_FUSED): one launch per ESIKF iteration (k_lidar_iteration: the last block of the residual grid to
+ *                        publish its partial row reduces and solves) instead of k_lidar_residual + k_lidar_solve.  Bit-identical results; measured slower at C4
+ *                        (profiles/r05_lidar_fused_iteration_ab.txt), kept for grids whose solve launch is the larger share.
+ * Counters: "visual_persistent_launches", "visual_persistent_fallbacks", "visual_persistent_timeouts", "visual_persistent_backoff_skips", "map_tree_grow_events",
+ *           "lidar_fused_launches". */
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value);
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value);
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
 /* Debug allocator (no reference counterpart; fast-livo2_amd/csrc/dev_alloc.hpp).  The environment variable LIVO2_REDZONE, read at the first device allocation
  * of the process, puts every device allocation of the library behind a checker: 1 = poisoned guard regions in front of and behind each allocation, scanned by
  * livo2_ctx_synchronize, every *_fetch and this call (a damaged guard => LIVO2_ERR_HIP, livo2_last_error names the allocation's source line, size, side and
- * offset); 2 / 3 = each allocation is its own virtual-memory mapping that ends (2) or starts (3) at unmapped address space, so that an out-of-bounds READ
- * faults deterministically.  *mode receives the active mode, *damaged_words the number of overwritten guard words (mode 1). */
+ * offset); 2 / 3 = EXPERIMENTAL: each allocation is its own virtual-memory mapping that ends (2) or starts (3) at unmapped address space, so that an
+ * out-of-bounds READ would fault deterministically — on ROCm 7.2 / gfx950 purely in-bounds traffic inside hipMemMap'ed ranges already miscomputes
+ * (tools/fence_selftest.hip, profiles/r04_memory_fault_hunt.txt), so these two modes are left out of the test suite and must not be used to judge the library.
+ * *mode receives the active mode, *damaged_words the number of overwritten guard words (mode 1). */
 int livo2_debug_redzone_check(livo2_ctx *ctx, int32_t *mode, int64_t *damaged_words);
 /* Self-test of the checker: one 4-byte device store `byte_offset` bytes behind the END of the ctx's control block (negative: in front of its start).
  * Refused (LIVO2_ERR_INVALID) unless LIVO2_REDZONE is set. */
