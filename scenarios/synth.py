@@ -122,9 +122,20 @@ def sample_dirs(rng, n, fov_h_deg=70.4, fov_v_deg=77.2, full_sphere=False):
     return np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
 
 
-def lidar_scan(rng, scene, R_wi, t_wi, extR, extT, n_rays, dept_err, beam_err_deg, blind=0.8, full_sphere=False, max_range=80.0):
+def boresight_towards(axis_l):
+    """rotation B (LiDAR frame) with B e_x = axis_l: turns the +x-forward field of view of sample_dirs towards `axis_l` (a spinning LiDAR sees all around; the
+    synthetic scan covers the part of it a camera mounted along `axis_l` looks at)"""
+    a = np.asarray(axis_l, np.float64); a = a / np.linalg.norm(a)
+    h = np.array([0.0, 0.0, 1.0]) if abs(a[2]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    b = np.cross(h, a); b /= np.linalg.norm(b)
+    return np.stack([a, b, np.cross(a, b)], 1)
+
+
+def lidar_scan(rng, scene, R_wi, t_wi, extR, extT, n_rays, dept_err, beam_err_deg, blind=0.8, full_sphere=False, max_range=80.0, boresight=None):
     """Noisy scan in the LiDAR body frame (float32 xyz), rays cast from the true pose."""
     d_l = sample_dirs(rng, n_rays, full_sphere=full_sphere)
+    if boresight is not None:
+        d_l = d_l @ np.asarray(boresight, np.float64).T
     o_w = R_wi @ extT + t_wi
     d_w = d_l @ (R_wi @ extR).T
     r = cast(scene, o_w, d_w)
@@ -669,18 +680,20 @@ def feat_map_key_np(pos):
     return loc.astype(np.int64)
 
 
-def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scene=None, R0=None, t0=None, raycast=False):
+def select_scenario(seed=71, n_pg=10000, n_vis=6000, L=4, grid_n_height=17, scene=None, R0=None, t0=None, raycast=False, cam=None, extrinsics=None):
     """scene / R0 / t0: take the visual points and the scan from THIS room at THIS sensor pose (scenarios/live_inputs.py: the one-scene live chain) instead of a
-    room of the scenario's own."""
+    room of the scenario's own.  cam / extrinsics = (extR, extT, Rcl, Pcl): another shipped configuration's camera intrinsics + image size and sensor mounting
+    (scenarios/shipped_configs.py); default: config/avia.yaml."""
     rng = np.random.default_rng(seed)
-    cam = dict(AVIA["cam"])
-    extR, extT, Rcl, Pcl = AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy(), AVIA["Rcl"].copy(), AVIA["Pcl"].copy()
+    cam = dict(AVIA["cam"]) if cam is None else dict(cam)
+    extR, extT, Rcl, Pcl = (AVIA["extrinsic_R"].copy(), AVIA["extrinsic_T"].copy(), AVIA["Rcl"].copy(), AVIA["Pcl"].copy()) if extrinsics is None else [np.array(x, np.float64) for x in extrinsics]
     c = dict(AVIA["lio"])
     if scene is None:
         scene = make_room(rng, (20.0, 20.0, 6.0), 8)
         R0 = scene.R_ws @ rot_from_rpy(0.01, -0.015, 0.4)
         t0 = scene.R_ws @ np.array([0.3, -0.2, 1.0 if raycast else 1.4]) + scene.t_ws          # (raycast: low enough for the 2.9-m rays to reach the floor's planes)
-    xyz = lidar_scan(rng, scene, R0, t0, extR, extT, n_pg + 3 * n_vis, c["dept_err"], c["beam_err"], AVIA["blind"], False).astype(np.float64)
+    bore = None if extrinsics is None else boresight_towards(Rcl[2])             # the camera's optical axis in the LiDAR frame (third row of Rcl)
+    xyz = lidar_scan(rng, scene, R0, t0, extR, extT, n_pg + 3 * n_vis, c["dept_err"], c["beam_err"], AVIA["blind"], False, boresight=bore).astype(np.float64)
     pw = (xyz @ extR.T + extT) @ R0.T + t0
     pg = pw[:n_pg].astype(np.float32).astype(np.float64)            # point_w comes from a float32 cloud
     pos = pw[n_pg:][rng.permutation(len(pw) - n_pg)[:n_vis]] + rng.normal(0, 0.01, (n_vis, 3))
@@ -747,12 +760,12 @@ class RetrieveChainScenario:
 
 
 def retrieve_chain_scenario(seed=81, n_pg=10000, n_vis=20000, L=4, grid_n_height=17, normal_en=True, ncc_en=False, ncc_thre=0.5, outlier_threshold=1000.0,
-                            max_obs=6, scene=None, R0=None, t0=None, raycast=False):
+                            max_obs=6, scene=None, R0=None, t0=None, raycast=False, cam=None, extrinsics=None):
     """Visual points of select_scenario, each observed by 1..max_obs features made in a handful of earlier frames: frames 0-3 stand close to the
     current pose and show the current texture (their patches warp almost identically and pass the gates), frame 4 is a close-up with another
     texture, frame 5 looks at the scene from the side (more than 60 degrees off: getCloseViewObs rejects it).  A share of points carries two
     observations of ONE frame (same id_), only same-id observations, a preset ref_patch, or an uninitialised normal."""
-    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height, scene=scene, R0=R0, t0=t0, raycast=raycast)
+    base = select_scenario(seed=seed, n_pg=n_pg, n_vis=n_vis, L=L, grid_n_height=grid_n_height, scene=scene, R0=R0, t0=t0, raycast=raycast, cam=cam, extrinsics=extrinsics)
     rng = np.random.default_rng(seed + 1000)
     cam = base.cam
     W, H = cam["width"], cam["height"]
