@@ -419,6 +419,47 @@ class Context:
                       int(refs.shape[2]), 0)
         self._chk(self.lib.livo2_visual_obs_upload(self.h, C.byref(o)))
 
+    def visual_map_counts(self):
+        c = np.zeros(4, np.int32)
+        self._chk(self.lib.livo2_visual_map_counts(self.h, abi.as_ptr(c, C.c_int32)))
+        return dict(points=int(c[0]), obs=int(c[1]), ref_imgs=int(c[2]), stride=int(c[3]))
+
+    def visual_map_apply(self, new_pos=None, new_keys=None, new_active=None, obs=None, touched=None, img=None, img_slot=0):
+        """livo2_visual_map_apply: one frame's changes of the resident visual map.  obs: dict(id, img_idx, px, f, R, t, level, inv_expo, patch) of the NEW
+        observations; touched: dict(point [q], lists = list of q index lists (global observation indices, obs_ order), normal [q,3], normal_initialized [q],
+        ref_patch [q], active [q] optional); img: one new reference image [H,W] u8 for slot img_slot."""
+        keep = []
+
+        def arr(a, dt, ct):
+            a = np.ascontiguousarray(a, dt); keep.append(a)
+            return abi.as_ptr(a, ct)
+        d = abi.VisualMapDelta()
+        d.img_slot = int(img_slot)
+        if new_pos is not None and len(new_pos):
+            d.n_new_points = len(new_pos)
+            d.new_pos = arr(np.asarray(new_pos, np.float64).reshape(-1, 3), np.float64, C.c_double); d.new_voxel_key = arr(np.asarray(new_keys).reshape(-1, 3), np.int64, C.c_int64)
+            if new_active is not None:
+                d.new_active = arr(new_active, np.uint8, C.c_uint8)
+        if obs is not None and len(obs["id"]):
+            d.n_new_obs = len(obs["id"])
+            d.obs_id = arr(obs["id"], np.int32, C.c_int32); d.obs_img_idx = arr(obs["img_idx"], np.int32, C.c_int32); d.obs_level = arr(obs["level"], np.int32, C.c_int32)
+            d.obs_px = arr(obs["px"], np.float64, C.c_double); d.obs_f = arr(obs["f"], np.float64, C.c_double); d.obs_R = arr(obs["R"], np.float64, C.c_double)
+            d.obs_t = arr(obs["t"], np.float64, C.c_double); d.obs_inv_expo = arr(obs["inv_expo"], np.float64, C.c_double); d.obs_patch = arr(obs["patch"], np.float32, C.c_float)
+        if touched is not None and len(touched["point"]):
+            q = len(touched["point"])
+            d.n_touched = q
+            off = np.zeros(q + 1, np.int32); off[1:] = np.cumsum([len(l) for l in touched["lists"]])
+            flat = np.concatenate([np.asarray(l, np.int32) for l in touched["lists"]]) if off[-1] else np.zeros(1, np.int32)
+            d.touched_point = arr(touched["point"], np.int32, C.c_int32); d.touched_offset = arr(off, np.int32, C.c_int32); d.touched_obs = arr(flat, np.int32, C.c_int32)
+            d.touched_normal = arr(np.asarray(touched["normal"], np.float64).reshape(-1, 3), np.float64, C.c_double)
+            d.touched_normal_initialized = arr(touched["normal_initialized"], np.uint8, C.c_uint8); d.touched_ref_patch = arr(touched["ref_patch"], np.int32, C.c_int32)
+            if touched.get("active") is not None:
+                d.touched_active = arr(touched["active"], np.uint8, C.c_uint8)
+        if img is not None:
+            d.img = arr(img, np.uint8, C.c_uint8)
+        self._chk(self.lib.livo2_visual_map_apply(self.h, C.byref(d)))
+        self.n_vm += int(d.n_new_points)
+
     def visual_retrieve_from_map(self, cs, want_patches=True, raycast=False):
         """The whole retrieveFromVisualSparseMap as one chain (selection -> reference-patch choice -> tail) over a RetrieveChainScenario-like object
         whose points / observations were uploaded with visual_map_upload + visual_obs_upload.  Returns the stage outputs (same names as

@@ -138,6 +138,17 @@ class VisualObs(C.Structure):
                 ("pad", C.c_int32)]
 
 
+class VisualMapDelta(C.Structure):
+    """livo2_visual_map_delta: one frame's changes of the visual map (generateVisualMapPoints / updateVisualMapPoints / updateReferencePatch of the reference)"""
+    _fields_ = [("n_new_points", C.c_int32), ("n_new_obs", C.c_int32), ("n_touched", C.c_int32), ("img_slot", C.c_int32),
+                ("new_pos", C.POINTER(C.c_double)), ("new_voxel_key", C.POINTER(C.c_int64)), ("new_active", C.POINTER(C.c_uint8)),
+                ("obs_id", C.POINTER(C.c_int32)), ("obs_img_idx", C.POINTER(C.c_int32)), ("obs_px", C.POINTER(C.c_double)), ("obs_f", C.POINTER(C.c_double)),
+                ("obs_R", C.POINTER(C.c_double)), ("obs_t", C.POINTER(C.c_double)), ("obs_level", C.POINTER(C.c_int32)), ("obs_inv_expo", C.POINTER(C.c_double)),
+                ("obs_patch", C.POINTER(C.c_float)), ("touched_point", C.POINTER(C.c_int32)), ("touched_offset", C.POINTER(C.c_int32)), ("touched_obs", C.POINTER(C.c_int32)),
+                ("touched_normal", C.POINTER(C.c_double)), ("touched_normal_initialized", C.POINTER(C.c_uint8)), ("touched_active", C.POINTER(C.c_uint8)),
+                ("touched_ref_patch", C.POINTER(C.c_int32)), ("img", C.POINTER(C.c_uint8))]
+
+
 class RetrieveChainOut(C.Structure):
     _fields_ = [("cell_point", C.POINTER(C.c_int32)), ("cell_dist", C.POINTER(C.c_float)), ("cell_discontinuous", C.POINTER(C.c_uint8)), ("cell_obs", C.POINTER(C.c_int32)),
                 ("ref_patch", C.POINTER(C.c_int32)), ("cand_cell", C.POINTER(C.c_int32)), ("tail", RetrieveOut), ("sub_point", C.POINTER(C.c_int32)),
@@ -234,6 +245,8 @@ SIGNATURES = {
                                              _P(RetrieveOut), _P(C.c_int32)]),
     "livo2_visual_retrieve_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_visual_obs_upload": (C.c_int, [_CTX, _P(VisualObs)]),
+    "livo2_visual_map_apply": (C.c_int, [_CTX, _P(VisualMapDelta)]),
+    "livo2_visual_map_counts": (C.c_int, [_CTX, _P(C.c_int32)]),
     "livo2_visual_retrieve_from_map": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), C.c_int32, _P(SelectCfg), _P(RetrieveCfg),
                                                  _P(RetrieveChainOut), _P(C.c_int32), _P(C.c_int32)]),
     "livo2_visual_retrieve_from_map_last_kernel_us": (C.c_double, [_CTX]),

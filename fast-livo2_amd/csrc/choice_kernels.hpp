@@ -12,7 +12,8 @@
 //   k_gather_candidates chosen (cell -> observation) -> dense candidate arrays in cell order (slots from k_warp_scan)
 //   k_leader_insert / k_leader_lookup   warp_map of the !normal_en branch (vio.cpp:716-734): the cache key ref_ftr->id_ is the id of the
 //                       FRAME a feature was made in, so all candidates whose ref_ftr share a frame reuse the warp of the first of them.
-// The visual map's observations live on the device as a CSR table over the points (livo2_visual_obs_upload).
+// The visual map's observations live on the device as global arrays (append-only) + one fixed-stride index list per point in obs_ list order: a full upload
+// (livo2_visual_obs_upload, a CSR table) and the per-frame deltas of the map maintenance (livo2_visual_map_apply) maintain the same structure.
 #pragma once
 #include "livo2_device.hpp"
 
@@ -25,7 +26,10 @@ struct ChoiceArgs {
   const int32_t *cell_point;                 // [length] from k_sel_cells
   const uint8_t *cell_discont;               // [length]
   const double *pos;                         // [n_pts][3]
-  const int32_t *obs_offset;                 // [n_pts + 1]
+  const int32_t *obs_list;                   // [n_pts][obs_stride]: VisualPoint::obs_ in list order, as GLOBAL observation indices (livo2_visual_obs_upload fills it from
+                                             // the CSR table; livo2_visual_map_apply rewrites the lists of the points a frame touched: addFrameRef pushes to the FRONT)
+  const int32_t *obs_count;                  // [n_pts] obs_.size()
+  int32_t obs_stride, pad_;
   const int32_t *obs_id;
   const double *obs_R, *obs_t;
   const float *obs_patch;                    // [n_obs][64]
@@ -42,23 +46,26 @@ __global__ void __launch_bounds__(CHOICE_WAVES *LIVO2_WAVE) k_choose_ref(ChoiceA
   int chosen = -1;                                                   // wave-uniform
   const int p = a.cell_point[c];
   if (p >= 0 && !a.cell_discont[c] && a.normal_init[p]) {
-    const int b = a.obs_offset[p], n = a.obs_offset[p + 1] - b;
+    const int32_t *ol = a.obs_list + (size_t)p * a.obs_stride;          // the point's observations, list order
+    const int n = a.obs_count[p];
     if (a.normal_en) {
       const int preset = a.ref_patch[p];
       if (n == 1) {
-        chosen = b;
-        if (lane == 0) a.ref_patch[p] = b;
+        chosen = ol[0];
+        if (lane == 0) a.ref_patch[p] = chosen;
       } else if (n > 1 && preset < 0) {
         float best = 3.402823466e+38f;                               // FLT_MAX (phtometric_errors_min): a score must be below it to win
         int best_a = -1;
         for (int it = lane; it < n; it += 64) {
-          const float *pa = a.obs_patch + (size_t)(b + it) * 64;
-          const int id_a = a.obs_id[b + it];
+          const int oa = ol[it];
+          const float *pa = a.obs_patch + (size_t)oa * 64;
+          const int id_a = a.obs_id[oa];
           float err = 0.0f;
           int count = 0;
           for (int itm = 0; itm < n; itm++) {
-            if (a.obs_id[b + itm] == id_a) continue;
-            const float *pb = a.obs_patch + (size_t)(b + itm) * 64;
+            const int ob = ol[itm];
+            if (a.obs_id[ob] == id_a) continue;
+            const float *pb = a.obs_patch + (size_t)ob * 64;
             for (int ind = 0; ind < 64; ind++) { const float d = pa[ind] - pb[ind]; err = err + d * d; }
             count++;
           }
@@ -72,7 +79,7 @@ __global__ void __launch_bounds__(CHOICE_WAVES *LIVO2_WAVE) k_choose_ref(ChoiceA
           if (e2 < best || (e2 == best && (unsigned)a2 < (unsigned)best_a)) { best = e2; best_a = a2; }
         }
         if (best_a >= 0) {
-          chosen = b + best_a;
+          chosen = ol[best_a];
           if (lane == 0) a.ref_patch[p] = chosen;
         }
       } else if (n > 1) chosen = preset;
@@ -84,7 +91,7 @@ __global__ void __launch_bounds__(CHOICE_WAVES *LIVO2_WAVE) k_choose_ref(ChoiceA
       double best = 0.0;                                             // min_cos_angle starts at 0: only a positive cosine replaces the first observation
       int best_a = -1;
       for (int it = lane; it < n; it += 64) {
-        const double *R = a.obs_R + (size_t)(b + it) * 9, *t = a.obs_t + (size_t)(b + it) * 3;
+        const double *R = a.obs_R + (size_t)ol[it] * 9, *t = a.obs_t + (size_t)ol[it] * 3;
         double d[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) d[r] = ((R[r] * t[0] + R[3 + r] * t[1]) + R[6 + r] * t[2]) * (-1.0);     // Feature::pos()
@@ -100,7 +107,7 @@ __global__ void __launch_bounds__(CHOICE_WAVES *LIVO2_WAVE) k_choose_ref(ChoiceA
         const int a2 = __shfl_xor(best_a, off, 64);
         if (e2 > best || (e2 == best && (unsigned)a2 < (unsigned)best_a)) { best = e2; best_a = a2; }
       }
-      if (best_a >= 0 && !(best < 0.5)) chosen = b + best_a;          // min_cos_angle < 0.5: more than 60 degrees off
+      if (best_a >= 0 && !(best < 0.5)) chosen = ol[best_a];          // min_cos_angle < 0.5: more than 60 degrees off
     }
   }
   if (lane == 0) { a.cell_obs[c] = chosen; a.cell_flag[c] = chosen >= 0 ? 1 : 0; }
@@ -176,4 +183,66 @@ __global__ void __launch_bounds__(256) k_leader_lookup(const int32_t *__restrict
   uint32_t h = leader_hash(key) & mask;
   while (keys[h] != key) h = (h + 1) & mask;
   leader[i] = vals[h];
+}
+
+// ---- the per-point observation lists ---------------------------------------------------------------------------------------------------------------
+// CSR table of a full upload -> fixed-stride lists (identity ranges)
+__global__ void __launch_bounds__(256) k_ob_lists_from_csr(const int32_t *__restrict__ off, int n, int stride, int32_t *__restrict__ list, int32_t *__restrict__ count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, p = t / stride, k = t % stride;
+  if (p >= n) return;
+  const int b = off[p], m = off[p + 1] - b;
+  if (k == 0) count[p] = m;
+  list[(size_t)p * stride + k] = k < m ? b + k : -1;
+}
+
+// One frame's changes of the visual map (livo2_visual_map_apply), from ONE staging blob that travelled in one copy:
+//   new points  [n_new_points] : pos, packed voxel key, active                                      -> rows n_points .. of the point arrays
+//   new observations [n_new_obs]: id, image slot, level, px, f, R, t, inv_expo, patch               -> rows n_obs .. of the observation arrays
+//   touched points [n_touched] : whole obs_ list (global indices, list order), normal_, is_normal_initialized_, active, ref_patch
+struct VmDeltaArgs {
+  int32_t n_points, n_obs, n_new_points, n_new_obs, n_touched, stride, pad0, pad1;
+  // staged sections (device addresses inside the blob)
+  const double *s_pos; const unsigned long long *s_pkey; const uint8_t *s_active;
+  const int32_t *s_oid, *s_oimg, *s_olvl; const double *s_opx, *s_of, *s_oR, *s_ot, *s_oie; const float *s_opatch;
+  const int32_t *s_tpoint, *s_toff, *s_tobs, *s_trefp; const double *s_tnormal; const uint8_t *s_tninit, *s_tactive;
+  // the resident arrays
+  double *pos; unsigned long long *pkey; uint8_t *active, *fov;
+  int32_t *oid, *oimg, *olvl; double *opx, *of, *oR, *ot, *oie; float *opatch;
+  int32_t *list, *count, *refp; double *normal; uint8_t *ninit;
+};
+__global__ void __launch_bounds__(256) k_vm_apply(VmDeltaArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // section 1: new points, one thread each
+  if (t < a.n_new_points) {
+    const size_t p = (size_t)a.n_points + t;
+    a.pos[p * 3] = a.s_pos[(size_t)t * 3]; a.pos[p * 3 + 1] = a.s_pos[(size_t)t * 3 + 1]; a.pos[p * 3 + 2] = a.s_pos[(size_t)t * 3 + 2];
+    a.pkey[p] = a.s_pkey[t]; a.active[p] = a.s_active[t]; a.fov[p] = 0;
+    a.count[p] = 0; a.refp[p] = -1; a.ninit[p] = 0; a.normal[p * 3] = 0.0; a.normal[p * 3 + 1] = 0.0; a.normal[p * 3 + 2] = 0.0;      // until its `touched` row lands (below, same launch: other threads)
+  }
+  // section 2: new observations, 32 threads each (the patch is 64 floats = 32 x 8 bytes)
+  {
+    const int o = t >> 5, k = t & 31;
+    if (o < a.n_new_obs) {
+      const size_t g = (size_t)a.n_obs + o;
+      reinterpret_cast<double *>(a.opatch + g * 64)[k] = reinterpret_cast<const double *>(a.s_opatch + (size_t)o * 64)[k];
+      if (k < 9) a.oR[g * 9 + k] = a.s_oR[(size_t)o * 9 + k];
+      else if (k < 12) a.ot[g * 3 + (k - 9)] = a.s_ot[(size_t)o * 3 + (k - 9)];
+      else if (k < 15) a.of[g * 3 + (k - 12)] = a.s_of[(size_t)o * 3 + (k - 12)];
+      else if (k < 17) a.opx[g * 2 + (k - 15)] = a.s_opx[(size_t)o * 2 + (k - 15)];
+      else if (k == 17) a.oie[g] = a.s_oie[o];
+      else if (k == 18) a.oid[g] = a.s_oid[o];
+      else if (k == 19) a.oimg[g] = a.s_oimg[o];
+      else if (k == 20) a.olvl[g] = a.s_olvl[o];
+    }
+  }
+}
+// touched points in their own launch (a new point's defaults of k_vm_apply must be in place first): `stride` threads per touched point
+__global__ void __launch_bounds__(256) k_vm_apply_touched(VmDeltaArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t / a.stride, k = t % a.stride;
+  if (q >= a.n_touched) return;
+  const size_t p = (size_t)a.s_tpoint[q];
+  const int b = a.s_toff[q], m = a.s_toff[q + 1] - b;
+  a.list[p * a.stride + k] = k < m ? a.s_tobs[b + k] : -1;
+  if (k == 0) { a.count[p] = m; a.refp[p] = a.s_trefp[q]; a.ninit[p] = a.s_tninit[q]; a.active[p] = a.s_tactive[q]; }
+  if (k < 3) a.normal[p * 3 + k] = a.s_tnormal[(size_t)q * 3 + k];
 }

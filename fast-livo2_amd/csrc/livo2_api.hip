@@ -84,12 +84,16 @@ struct livo2_ctx {
   int32_t *d_ray_action = nullptr, *d_ray_hit_cell = nullptr, *d_ray_counters = nullptr; size_t ray_action_cap = 0, ray_hit_cell_cap = 0;
   double *d_ray_add = nullptr; size_t ray_add_cap = 0; int ray_add_n = -1;
   // observation table of the visual map, reference-patch choice, chained retrieval (N2)
-  bool has_obs = false; int n_obs = 0, ob_n_ref = 0, ob_w = 0, ob_h = 0, ob_stride = 0;
+  bool has_obs = false; int n_obs = 0, ob_n_ref = 0, ob_w = 0, ob_h = 0, ob_img_stride = 0;
   int32_t *d_ob_off = nullptr, *d_ob_id = nullptr, *d_ob_img = nullptr, *d_ob_lvl = nullptr, *d_vm_refpatch = nullptr;
   size_t ob_off_cap = 0, ob_id_cap = 0, ob_img_cap = 0, ob_lvl_cap = 0, vm_refpatch_cap = 0;
   double *d_ob_px = nullptr, *d_ob_f = nullptr, *d_ob_R = nullptr, *d_ob_t = nullptr, *d_ob_ie = nullptr, *d_vm_normal = nullptr;
   size_t ob_px_cap = 0, ob_f_cap = 0, ob_R_cap = 0, ob_t_cap = 0, ob_ie_cap = 0, vm_normal_cap = 0;
   float *d_ob_patch = nullptr; size_t ob_patch_cap = 0; uint8_t *d_vm_ninit = nullptr, *d_ob_imgs = nullptr; size_t vm_ninit_cap = 0, ob_imgs_cap = 0;
+  // per-point observation lists (fixed stride, global observation indices in obs_ list order) + staging of livo2_visual_map_apply
+  int32_t *d_ob_list = nullptr, *d_ob_cnt = nullptr; size_t ob_list_cap = 0, ob_cnt_cap = 0; int ob_stride = 0;
+  void *h_delta = nullptr; size_t h_delta_cap = 0; void *d_delta = nullptr; size_t d_delta_cap = 0; hipEvent_t delta_ev = nullptr; bool delta_ev_used = false;
+  int vm_delta_calls = 0, vm_delta_grows = 0;
   int32_t *d_ch_obs = nullptr, *d_ch_flag = nullptr, *d_ch_slot = nullptr, *d_cand_cell = nullptr, *d_cand_point = nullptr, *d_cand_obs = nullptr, *d_sub_point = nullptr,
           *d_sub_obs = nullptr, *d_ch_count = nullptr;
   size_t ch_obs_cap = 0, ch_flag_cap = 0, ch_slot_cap = 0, cand_cell_cap = 0, cand_point_cap = 0, cand_obs_cap = 0, sub_point_cap = 0, sub_obs_cap = 0;
@@ -231,6 +235,25 @@ template <typename T> int grow_array_at(int line, livo2_ctx *ctx, T *&p, size_t 
   return LIVO2_OK;
 }
 #define grow_array(...) grow_array_at(__LINE__, __VA_ARGS__)
+
+// capacity for `need` elements, CONTENT KEPT (the first `used` elements): geometric growth, so a map that grows by a few points per frame re-allocates O(log) times
+template <typename T> int keep_grow_at(int line, livo2_ctx *ctx, T *&p, size_t &cap, size_t used, size_t need) {
+  if (need <= cap && p) return LIVO2_OK;
+  const size_t newcap = std::max(need, 2 * cap + 64);
+  T *q = nullptr;
+  HIPCHK(DMALLOC_AT(line, (void **)&q, newcap * sizeof(T)));
+  if (p && used) HIPCHK(devalloc::memcpy_async(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (p) HIPCHK(DFREE(p));
+  p = q; cap = newcap;
+  ctx->vm_delta_grows++;
+  return LIVO2_OK;
+}
+#define keep_grow(...) keep_grow_at(__LINE__, __VA_ARGS__)
+struct Blob {                                           // sections of the staging block, 16-byte aligned
+  size_t size = 0;
+  size_t add(size_t bytes) { const size_t at = size; size += (bytes + 15) & ~(size_t)15; return at; }
+};
 
 struct Timed {                 // RAII-free helper: brackets one launch with an event pair when timing is on
   livo2_ctx *ctx; int bin; EvPair ev{}; bool on = false;
@@ -642,7 +665,7 @@ int32_t livo2_abi_sizeof(const char *name) {
   LIVO2_SZ(livo2_state) LIVO2_SZ(livo2_map_view) LIVO2_SZ(livo2_lidar_cfg) LIVO2_SZ(livo2_lidar_sums) LIVO2_SZ(livo2_lidar_points) LIVO2_SZ(livo2_lidar_result)
   LIVO2_SZ(livo2_cam) LIVO2_SZ(livo2_visual_cfg) LIVO2_SZ(livo2_visual_sums) LIVO2_SZ(livo2_visual_step) LIVO2_SZ(livo2_visual_result)
   LIVO2_SZ(livo2_plane_fit) LIVO2_SZ(livo2_imu_step) LIVO2_SZ(livo2_imu_cfg) LIVO2_SZ(livo2_imu_pose) LIVO2_SZ(livo2_select_cfg)
-  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out)
+  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out) LIVO2_SZ(livo2_visual_map_delta)
 #undef LIVO2_SZ
   return 0;
 }
@@ -690,12 +713,14 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->d_sub_point, ctx->d_sub_obs, ctx->d_ch_count, ctx->d_c_id, ctx->d_c_leader, ctx->d_ld_keys, ctx->d_ld_vals,
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
-                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
+                 ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_ob_list, ctx->d_ob_cnt, ctx->d_delta, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
                  ctx->d_ray_counters, ctx->d_ray_add};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
   if (ctx->h_pts) e = hipHostFree(ctx->h_pts);
+  if (ctx->h_delta) e = hipHostFree(ctx->h_delta);
+  if (ctx->delta_ev) e = hipEventDestroy(ctx->delta_ev);
   for (int k = 0; k < 2; k++) { if (ctx->scan_stage[k]) e = hipHostFree(ctx->scan_stage[k]); if (ctx->scan_stage_ev[k]) e = hipEventDestroy(ctx->scan_stage_ev[k]); }
   if (ctx->bh_in) e = hipHostFree(ctx->bh_in);
   if (ctx->bh_results) e = hipHostFree(ctx->bh_results);
@@ -770,6 +795,8 @@ int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
   if (std::strcmp(name, "visual_persistent_backoff_skips") == 0) { *value = ctx->vp_backoff_skips; return LIVO2_OK; }
   if (std::strcmp(name, "map_tree_grow_events") == 0) { *value = ctx->mt_grow_events; return LIVO2_OK; }
   if (std::strcmp(name, "lidar_fused_launches") == 0) { *value = ctx->lidar_fused_launches; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_map_delta_calls") == 0) { *value = ctx->vm_delta_calls; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_map_delta_grows") == 0) { *value = ctx->vm_delta_grows; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
 }
 
@@ -2393,9 +2420,174 @@ int livo2_visual_obs_upload(livo2_ctx *ctx, const livo2_visual_obs *o) {
     HIPCHK(devalloc::memcpy_async(ctx->d_ob_patch, o->patch, (size_t)m * 256, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(devalloc::memcpy_async(ctx->d_ob_imgs, o->ref_imgs, img_bytes * (size_t)o->n_ref, hipMemcpyHostToDevice, ctx->stream));
   }
+  {                                                     // obs_ lists: fixed stride, identity ranges of the CSR table
+    int longest = 0;
+    for (int i = 0; i < n; i++) longest = std::max(longest, o->point_offset[i + 1] - o->point_offset[i]);
+    int stride = 32; while (stride < longest) stride <<= 1;
+    ctx->ob_stride = stride;
+    if ((rc = ensure(ctx, ctx->d_ob_list, ctx->ob_list_cap, n1 * (size_t)stride))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ob_cnt, ctx->ob_cnt_cap, n1))) return rc;
+    if (n > 0) hipLaunchKernelGGL(k_ob_lists_from_csr, dim3((unsigned)(((size_t)n * stride + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ob_off, n, stride, ctx->d_ob_list, ctx->d_ob_cnt);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->n_obs = m; ctx->ob_n_ref = o->n_ref; ctx->ob_w = o->width; ctx->ob_h = o->height; ctx->ob_stride = o->stride;
+  ctx->n_obs = m; ctx->ob_n_ref = o->n_ref; ctx->ob_w = o->width; ctx->ob_h = o->height; ctx->ob_img_stride = o->stride;
   ctx->has_obs = true;
+  return LIVO2_OK;
+}
+
+// ---- one frame's changes of the visual map: O(changes) ---------------------------------------------------------------------------------------------
+
+int livo2_visual_map_counts(livo2_ctx *ctx, int32_t *c) {
+  if (!ctx || !c) return LIVO2_ERR_INVALID;
+  c[0] = ctx->has_vmap ? ctx->n_vm : 0; c[1] = ctx->has_obs ? ctx->n_obs : 0; c[2] = ctx->has_obs ? ctx->ob_n_ref : 0; c[3] = ctx->has_obs ? ctx->ob_stride : 0;
+  return LIVO2_OK;
+}
+
+int livo2_visual_map_apply(livo2_ctx *ctx, const livo2_visual_map_delta *d) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!d) return fail(ctx, LIVO2_ERR_INVALID, "delta is NULL");
+  if (!ctx->has_vmap || !ctx->has_obs) return fail(ctx, LIVO2_ERR_NO_MAP, "livo2_visual_map_upload + livo2_visual_obs_upload must have installed a map (an empty one will do)");
+  const int np = d->n_new_points, no = d->n_new_obs, nt = d->n_touched;
+  if (np < 0 || no < 0 || nt < 0) return fail(ctx, LIVO2_ERR_INVALID, "negative count");
+  if ((np > 0 && (!d->new_pos || !d->new_voxel_key)) || (no > 0 && (!d->obs_id || !d->obs_img_idx || !d->obs_px || !d->obs_f || !d->obs_R || !d->obs_t || !d->obs_level || !d->obs_inv_expo || !d->obs_patch)) ||
+      (nt > 0 && (!d->touched_point || !d->touched_offset || !d->touched_normal || !d->touched_normal_initialized || !d->touched_ref_patch)))
+    return fail(ctx, LIVO2_ERR_INVALID, "a delta array is NULL");
+  const int n0 = ctx->n_vm, m0 = ctx->n_obs, stride = ctx->ob_stride;
+  const long long n1l = (long long)n0 + np, m1l = (long long)m0 + no;
+  if (n1l > 0x7fffffffll / std::max(stride, 1) || m1l > 0x7fffffffll / 64) return fail(ctx, LIVO2_ERR_RANGE, "the visual map outgrows int32 indexing");
+  const int n1 = (int)n1l, m1 = (int)m1l;
+  int n_ref = ctx->ob_n_ref;
+  if (d->img) {
+    if (ctx->ob_w < 1 || ctx->ob_h < 1) return fail(ctx, LIVO2_ERR_INVALID, "no image geometry: the full upload must name width / height / stride (n_ref may be 0)");
+    if (d->img_slot < 0 || d->img_slot > n_ref) return fail(ctx, LIVO2_ERR_INVALID, "img_slot must be an existing slot or the next free one");
+    if (d->img_slot == n_ref) n_ref++;
+  }
+  const long long B = 1ll << 20;
+  for (int i = 0; i < np; i++) {
+    const int64_t *k = d->new_voxel_key + 3 * (size_t)i;
+    if (k[0] < -B || k[0] >= B || k[1] < -B || k[1] >= B || k[2] < -B || k[2] >= B) return fail(ctx, LIVO2_ERR_RANGE, "visual voxel key outside 21 bits per axis");
+  }
+  for (int k = 0; k < no; k++) {
+    if (d->obs_img_idx[k] < 0 || d->obs_img_idx[k] >= n_ref) return fail(ctx, LIVO2_ERR_INVALID, "img_idx out of range");
+    if (d->obs_level[k] < 0 || d->obs_level[k] > 8) return fail(ctx, LIVO2_ERR_RANGE, "level out of [0,8]");
+    if (d->obs_id[k] == LEADER_EMPTY) return fail(ctx, LIVO2_ERR_RANGE, "id must differ from INT32_MAX");
+  }
+  int n_tobs = 0;
+  if (nt > 0) {
+    if (d->touched_offset[0] != 0) return fail(ctx, LIVO2_ERR_INVALID, "touched_offset must start at 0");
+    n_tobs = d->touched_offset[nt];
+    if (n_tobs < 0 || (n_tobs > 0 && !d->touched_obs)) return fail(ctx, LIVO2_ERR_INVALID, "bad touched_obs");
+    for (int q = 0; q < nt; q++) {
+      const int p = d->touched_point[q], b = d->touched_offset[q], e = d->touched_offset[q + 1];
+      if (p < 0 || p >= n1) return fail(ctx, LIVO2_ERR_INVALID, "touched_point out of range");
+      if (e < b || e > n_tobs) return fail(ctx, LIVO2_ERR_INVALID, "touched_offset must not decrease");
+      if (e - b > stride) return fail(ctx, LIVO2_ERR_RANGE, "an obs_ list is longer than the stride of the resident lists: re-upload the map (livo2_visual_obs_upload sizes the stride)");
+      bool ref_ok = d->touched_ref_patch[q] == -1;
+      for (int k = b; k < e; k++) {
+        if (d->touched_obs[k] < 0 || d->touched_obs[k] >= m1) return fail(ctx, LIVO2_ERR_INVALID, "touched_obs out of range");
+        ref_ok = ref_ok || d->touched_obs[k] == d->touched_ref_patch[q];
+      }
+      if (!ref_ok) return fail(ctx, LIVO2_ERR_INVALID, "ref_patch is not an observation of its point");
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->vm_delta_calls++;
+  if (np == 0 && no == 0 && nt == 0 && !d->img) return LIVO2_OK;
+  int rc;
+  // ---- capacity (content kept)
+  const size_t N0 = (size_t)n0, N1 = (size_t)std::max(n1, 1), M0 = (size_t)m0, M1 = (size_t)std::max(m1, 1), S = (size_t)stride;
+  if ((rc = keep_grow(ctx, ctx->d_vm_pos, ctx->vm_pos_cap, N0 * 3, N1 * 3))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_vm_pkey, ctx->vm_pkey_cap, N0, N1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_vm_active, ctx->vm_active_cap, N0, N1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_vm_fov, ctx->vm_fov_cap, N0, N1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_vm_normal, ctx->vm_normal_cap, N0 * 3, N1 * 3))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_vm_ninit, ctx->vm_ninit_cap, N0, N1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_vm_refpatch, ctx->vm_refpatch_cap, N0, N1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_list, ctx->ob_list_cap, N0 * S, N1 * S))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_cnt, ctx->ob_cnt_cap, N0, N1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_id, ctx->ob_id_cap, M0, M1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_img, ctx->ob_img_cap, M0, M1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_lvl, ctx->ob_lvl_cap, M0, M1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_px, ctx->ob_px_cap, M0 * 2, M1 * 2))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_f, ctx->ob_f_cap, M0 * 3, M1 * 3))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_R, ctx->ob_R_cap, M0 * 9, M1 * 9))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_t, ctx->ob_t_cap, M0 * 3, M1 * 3))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_ie, ctx->ob_ie_cap, M0, M1))) return rc;
+  if ((rc = keep_grow(ctx, ctx->d_ob_patch, ctx->ob_patch_cap, M0 * 64, M1 * 64))) return rc;
+  const size_t img_bytes = (size_t)ctx->ob_img_stride * ctx->ob_h;
+  if (d->img && (rc = keep_grow(ctx, ctx->d_ob_imgs, ctx->ob_imgs_cap, img_bytes * (size_t)ctx->ob_n_ref, img_bytes * (size_t)n_ref))) return rc;
+  // ---- one staging block
+  Blob bl;
+  const size_t o_pos = bl.add((size_t)np * 24), o_pkey = bl.add((size_t)np * 8), o_act = bl.add((size_t)np);
+  const size_t o_oid = bl.add((size_t)no * 4), o_oimg = bl.add((size_t)no * 4), o_olvl = bl.add((size_t)no * 4), o_opx = bl.add((size_t)no * 16), o_of = bl.add((size_t)no * 24),
+               o_oR = bl.add((size_t)no * 72), o_ot = bl.add((size_t)no * 24), o_oie = bl.add((size_t)no * 8), o_opatch = bl.add((size_t)no * 256);
+  const size_t o_tp = bl.add((size_t)nt * 4), o_toff = bl.add(((size_t)nt + 1) * 4), o_tobs = bl.add((size_t)n_tobs * 4), o_tref = bl.add((size_t)nt * 4), o_tn = bl.add((size_t)nt * 24),
+               o_tni = bl.add((size_t)nt), o_ta = bl.add((size_t)nt);
+  const size_t o_img = bl.add(d->img ? img_bytes : 0);
+  if (ctx->delta_ev_used) HIPCHK(hipEventSynchronize(ctx->delta_ev));          // the previous delta's copy has left the staging block
+  if (bl.size > ctx->h_delta_cap) {
+    if (ctx->h_delta) { hipError_t e = hipHostFree(ctx->h_delta); (void)e; ctx->h_delta = nullptr; }
+    const size_t cap = std::max(bl.size, 2 * ctx->h_delta_cap + 4096);
+    HIPCHK(hipHostMalloc(&ctx->h_delta, cap, hipHostMallocDefault));
+    ctx->h_delta_cap = cap;
+  }
+  {
+    size_t dcap = ctx->d_delta_cap; char *dp = (char *)ctx->d_delta;
+    if ((rc = keep_grow(ctx, dp, dcap, 0, bl.size - (d->img ? ((img_bytes + 15) & ~(size_t)15) : 0) + 16))) return rc;
+    ctx->d_delta = dp; ctx->d_delta_cap = dcap;
+  }
+  if (!ctx->delta_ev) HIPCHK(hipEventCreateWithFlags(&ctx->delta_ev, hipEventDisableTiming));
+  char *h = (char *)ctx->h_delta;
+  if (np) {
+    std::memcpy(h + o_pos, d->new_pos, (size_t)np * 24);
+    unsigned long long *pk = (unsigned long long *)(h + o_pkey);
+    for (int i = 0; i < np; i++) { const int64_t *k = d->new_voxel_key + 3 * (size_t)i; pk[i] = ((unsigned long long)(k[0] + B) << 42) | ((unsigned long long)(k[1] + B) << 21) | (unsigned long long)(k[2] + B); }
+    if (d->new_active) std::memcpy(h + o_act, d->new_active, (size_t)np); else std::memset(h + o_act, 1, (size_t)np);
+  }
+  if (no) {
+    std::memcpy(h + o_oid, d->obs_id, (size_t)no * 4); std::memcpy(h + o_oimg, d->obs_img_idx, (size_t)no * 4); std::memcpy(h + o_olvl, d->obs_level, (size_t)no * 4);
+    std::memcpy(h + o_opx, d->obs_px, (size_t)no * 16); std::memcpy(h + o_of, d->obs_f, (size_t)no * 24); std::memcpy(h + o_oR, d->obs_R, (size_t)no * 72);
+    std::memcpy(h + o_ot, d->obs_t, (size_t)no * 24); std::memcpy(h + o_oie, d->obs_inv_expo, (size_t)no * 8); std::memcpy(h + o_opatch, d->obs_patch, (size_t)no * 256);
+  }
+  if (nt) {
+    std::memcpy(h + o_tp, d->touched_point, (size_t)nt * 4); std::memcpy(h + o_toff, d->touched_offset, ((size_t)nt + 1) * 4);
+    if (n_tobs) std::memcpy(h + o_tobs, d->touched_obs, (size_t)n_tobs * 4);
+    std::memcpy(h + o_tref, d->touched_ref_patch, (size_t)nt * 4); std::memcpy(h + o_tn, d->touched_normal, (size_t)nt * 24);
+    std::memcpy(h + o_tni, d->touched_normal_initialized, (size_t)nt);
+    if (d->touched_active) std::memcpy(h + o_ta, d->touched_active, (size_t)nt); else std::memset(h + o_ta, 1, (size_t)nt);
+  }
+  if (d->img) std::memcpy(h + o_img, d->img, img_bytes);
+  if (o_img > 0) HIPCHK(devalloc::memcpy_async(ctx->d_delta, h, o_img, hipMemcpyHostToDevice, ctx->stream));
+  if (d->img) HIPCHK(devalloc::memcpy_async(ctx->d_ob_imgs + img_bytes * (size_t)d->img_slot, h + o_img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->delta_ev, ctx->stream)); ctx->delta_ev_used = true;
+  const char *g = (const char *)ctx->d_delta;
+  VmDeltaArgs a{};
+  a.n_points = n0; a.n_obs = m0; a.n_new_points = np; a.n_new_obs = no; a.n_touched = nt; a.stride = stride;
+  a.s_pos = (const double *)(g + o_pos); a.s_pkey = (const unsigned long long *)(g + o_pkey); a.s_active = (const uint8_t *)(g + o_act);
+  a.s_oid = (const int32_t *)(g + o_oid); a.s_oimg = (const int32_t *)(g + o_oimg); a.s_olvl = (const int32_t *)(g + o_olvl); a.s_opx = (const double *)(g + o_opx);
+  a.s_of = (const double *)(g + o_of); a.s_oR = (const double *)(g + o_oR); a.s_ot = (const double *)(g + o_ot); a.s_oie = (const double *)(g + o_oie); a.s_opatch = (const float *)(g + o_opatch);
+  a.s_tpoint = (const int32_t *)(g + o_tp); a.s_toff = (const int32_t *)(g + o_toff); a.s_tobs = (const int32_t *)(g + o_tobs); a.s_trefp = (const int32_t *)(g + o_tref);
+  a.s_tnormal = (const double *)(g + o_tn); a.s_tninit = (const uint8_t *)(g + o_tni); a.s_tactive = (const uint8_t *)(g + o_ta);
+  a.pos = ctx->d_vm_pos; a.pkey = ctx->d_vm_pkey; a.active = ctx->d_vm_active; a.fov = ctx->d_vm_fov;
+  a.oid = ctx->d_ob_id; a.oimg = ctx->d_ob_img; a.olvl = ctx->d_ob_lvl; a.opx = ctx->d_ob_px; a.of = ctx->d_ob_f; a.oR = ctx->d_ob_R; a.ot = ctx->d_ob_t; a.oie = ctx->d_ob_ie; a.opatch = ctx->d_ob_patch;
+  a.list = ctx->d_ob_list; a.count = ctx->d_ob_cnt; a.refp = ctx->d_vm_refpatch; a.normal = ctx->d_vm_normal; a.ninit = ctx->d_vm_ninit;
+  const size_t work = std::max((size_t)np, (size_t)no * 32);
+  if (work) hipLaunchKernelGGL(k_vm_apply, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, ctx->stream, a);
+  if (nt) hipLaunchKernelGGL(k_vm_apply_touched, dim3((unsigned)(((size_t)nt * stride + 255) / 256)), dim3(256), 0, ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  // the voxel set of the RayCasting module follows the points (rebuilt larger when it would pass half full)
+  if (np > 0 && ctx->d_vm_set) {
+    if (2 * (size_t)n1 > ctx->vm_set_cap) {
+      size_t cap = ctx->vm_set_cap; while (cap < 4 * (size_t)n1) cap <<= 1;
+      if ((rc = ensure(ctx, ctx->d_vm_set, ctx->vm_set_cap, cap))) return rc;
+      ctx->vm_set_cap = cap; ctx->vm_set_mask = (uint32_t)(cap - 1);
+      HIPCHK(hipMemsetAsync(ctx->d_vm_set, 0xFF, cap * 8, ctx->stream));
+      hipLaunchKernelGGL(k_vm_voxel_set, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_vm_pkey, n1, ctx->d_vm_set, ctx->vm_set_mask);
+    } else hipLaunchKernelGGL(k_vm_voxel_set, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_vm_pkey + n0, np, ctx->d_vm_set, ctx->vm_set_mask);
+    HIPCHK(hipGetLastError());
+  }
+  ctx->n_vm = n1; ctx->n_obs = m1; ctx->ob_n_ref = n_ref;
   return LIVO2_OK;
 }
 
@@ -2413,7 +2605,7 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   const int L = cfg->patch_pyrimid_level;
   if (L < 1 || L > LIVO2_MAX_LEVELS) return fail(ctx, LIVO2_ERR_INVALID, "bad patch_pyrimid_level");
   if (cfg->cam.width != width || cfg->cam.height != height || sel->cam.width != width || sel->cam.height != height) return fail(ctx, LIVO2_ERR_INVALID, "camera size differs from the image");
-  if (ctx->n_obs > 0 && (ctx->ob_w != width || ctx->ob_h != height || ctx->ob_stride != stride)) return fail(ctx, LIVO2_ERR_INVALID, "reference images differ in size from the image");
+  if (ctx->n_obs > 0 && (ctx->ob_w != width || ctx->ob_h != height || ctx->ob_img_stride != stride)) return fail(ctx, LIVO2_ERR_INVALID, "reference images differ in size from the image");
   if (sel->border < 4) return fail(ctx, LIVO2_ERR_INVALID, "border must keep the 8x8 patch of a selected point inside the image (>= 4)");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2441,7 +2633,7 @@ int livo2_visual_retrieve_from_map(livo2_ctx *ctx, const uint8_t *img, int32_t w
   ChoiceArgs ca{};
   ca.normal_en = cfg->normal_en; ca.length = length;
   frame_pos(sel->R_cur, sel->t_cur, ca.cam_pos);
-  ca.cell_point = ctx->d_sel_point; ca.cell_discont = ctx->d_sel_disc; ca.pos = ctx->d_vm_pos; ca.obs_offset = ctx->d_ob_off; ca.obs_id = ctx->d_ob_id;
+  ca.cell_point = ctx->d_sel_point; ca.cell_discont = ctx->d_sel_disc; ca.pos = ctx->d_vm_pos; ca.obs_list = ctx->d_ob_list; ca.obs_count = ctx->d_ob_cnt; ca.obs_stride = ctx->ob_stride; ca.obs_id = ctx->d_ob_id;
   ca.obs_R = ctx->d_ob_R; ca.obs_t = ctx->d_ob_t; ca.obs_patch = ctx->d_ob_patch; ca.normal_init = ctx->d_vm_ninit; ca.ref_patch = ctx->d_vm_refpatch;
   ca.cell_obs = ctx->d_ch_obs; ca.cell_flag = ctx->d_ch_flag;
   hipLaunchKernelGGL(k_choose_ref, dim3((length + CHOICE_WAVES - 1) / CHOICE_WAVES), dim3(CHOICE_WAVES * LIVO2_WAVE), 0, ctx->stream, ca);

@@ -489,6 +489,40 @@ typedef struct livo2_visual_obs {
   int32_t width, height, stride, pad;
 } livo2_visual_obs;
 int livo2_visual_obs_upload(livo2_ctx *ctx, const livo2_visual_obs *obs);
+
+/* ---- incremental maintenance of that mirror (round 5) ----------------------------------------------------------------------------------
+ * The reference changes its visual map by a few points per frame: generateVisualMapPoints appends new VisualPoints with one Feature each
+ * (src/vio.cpp:804-895, insertPointIntoVoxelMap 227-246), updateVisualMapPoints pushes one new Feature to the FRONT of obs_ of sub-map points and drops one where
+ * a list has reached 30 (vio.cpp:908-967, visual_point.cpp:35-55), updateReferencePatch rewrites normal_ / ref_patch / has_ref_patch_ (vio.cpp:969-1100) — and every
+ * new Feature points at the image of the frame it was made in.  Re-flattening and re-uploading the whole map (and all reference images) for that costs tens of
+ * milliseconds per frame; this call applies ONE frame's changes in O(changes): one pinned staging copy + two small launches, asynchronous on the ctx stream.
+ *   new points       appended behind the resident ones: their indices are n_points_before + k (pos, voxel_key as in livo2_visual_map_upload, active); a new point
+ *                    gets its obs_ list, normal_ ... through a `touched` row like any other point
+ *   new observations appended behind the resident ones: global indices n_obs_before + k, members as in livo2_visual_obs; img_idx = slot of the reference image
+ *   touched points   every point whose obs_ list, normal_, is_normal_initialized_, active flag or ref_patch changed: its WHOLE new state — obs_ as global
+ *                    observation indices in list order (at most the stride the last livo2_visual_obs_upload chose: max(32, longest list rounded up to a power of
+ *                    two); LIVO2_ERR_RANGE beyond it: re-upload), ref_patch = global index of an observation OF THAT LIST or -1.  An observation that is in no
+ *                    list any more (deleteFeatureRef) simply stays unreferenced; a point that left the map is touched with active = 0 and an empty list.
+ *   new image        at most one per call: stored in slot img_slot — == the current number of reference images: appended; smaller: replaces an image no
+ *                    observation refers to any more (the caller's bookkeeping).  Copied through the ctx's staging: the caller's buffer is free on return.
+ * ref_patch of points that are NOT touched keeps the value the device remembered (livo2_visual_retrieve_from_map writes it, and reports it in out->ref_patch).
+ * Results are identical to a full livo2_visual_map_upload + livo2_visual_obs_upload of the same map (tests/test_visual_map_delta_gpu.py). */
+typedef struct livo2_visual_map_delta {
+  int32_t n_new_points, n_new_obs, n_touched, img_slot;
+  const double *new_pos; const int64_t *new_voxel_key; const uint8_t *new_active;                                  /* [n_new_points] */
+  const int32_t *obs_id, *obs_img_idx; const double *obs_px, *obs_f, *obs_R, *obs_t; const int32_t *obs_level;     /* [n_new_obs] */
+  const double *obs_inv_expo; const float *obs_patch;
+  const int32_t *touched_point;       /* [n_touched] point index, resident or new; each point at most once */
+  const int32_t *touched_offset;      /* [n_touched + 1] CSR into touched_obs */
+  const int32_t *touched_obs;         /* global observation indices, obs_ list order */
+  const double *touched_normal;       /* [n_touched][3] */
+  const uint8_t *touched_normal_initialized, *touched_active;
+  const int32_t *touched_ref_patch;   /* [n_touched] */
+  const uint8_t *img;                 /* NULL: no new reference image; else width x height x stride as in the last livo2_visual_obs_upload */
+} livo2_visual_map_delta;
+int livo2_visual_map_apply(livo2_ctx *ctx, const livo2_visual_map_delta *delta);
+/* (n_points, n_obs, n_ref, obs stride) of the resident mirror */
+int livo2_visual_map_counts(livo2_ctx *ctx, int32_t *counts4);
 /* Outputs, each may be NULL.  length = grid_n_width * grid_n_height.  Per cell [length]: cell_point / cell_dist / cell_discontinuous as
  * livo2_visual_select, cell_obs = global index of the chosen ref_ftr or -1 (no candidate from this cell).  ref_patch [n_points]: pt->ref_patch
  * after the call (the device copy is updated too, so the next call sees it).  Per candidate, in grid-cell order, arrays of CAPACITY length:

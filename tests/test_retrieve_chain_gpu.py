@@ -20,9 +20,9 @@ def _run(ctx, cs):
     return ctx.visual_retrieve_from_map(cs)
 
 
-def _compare(ctx, orc, cs):
+def _compare(ctx, orc, cs, run=None):
     ref = orc.visual_retrieve(cs)
-    out = _run(ctx, cs)
+    out = (run or _run)(ctx, cs)
     sel = ref["sel"]
     assert np.array_equal(out["cell_point"], sel["cell_point"])
     assert np.array_equal(out["cell_dist"], sel["cell_dist"])
