@@ -9,6 +9,8 @@
 // surfaces of the same room, seen from frame k's true pose).  The visual map of frame k is installed in feat_map before the frame starts (its maintenance —
 // generateVisualMapPoints / updateVisualMapPoints / updateReferencePatch — is out of scope) and mirrored on the device by syncFeatMap: that cost is
 // reported on its own, outside the four stages.
+// Growing-map mode (the directory holds grow_cfg.bin, scenarios/live_inputs.py make_live(grow=n)): ONE visual map installed before frame 0 and changed after every frame
+// by a scripted stand-in for the maintenance; syncFeatMap then applies O(changes) deltas and is timed INSIDE the frame (stage 5 of live_out.bin).
 // Usage: live_chain <dir> [lean]   "lean": host_point_lists_ = false (no pv_list_ / ptpl_list_ on the host) and `pg` read where the map update left it on the GPU.
 // Output: live_out.bin [F][5] ms (StateEstimation, UpdateVoxelMapFromPosterior, retrieveFromVisualSparseMap, computeJacobianAndUpdateEKF, syncFeatMap),
 //         live_states.bin [F][2] livo2_state (LIO posterior, VIO posterior), live_counts.bin [F][2] int32 (effct_feat_num_, total_points),
@@ -70,6 +72,62 @@ static bool load_visual_map(const std::string &dir, int k, size_t img_bytes, Vis
     if (m.refp[i] >= 0) { m.vp[i].ref_patch = &m.ft[m.refp[i]]; m.vp[i].has_ref_patch_ = true; }
   }
   return true;
+}
+
+// ---- growing-map mode: ONE visual map, changed after every frame by a scripted stand-in for generateVisualMapPoints / updateVisualMapPoints / updateReferencePatch
+// (scenarios/visual_map_growth.py; the maintenance logic is out of scope, its effect on the containers is what the mirror has to follow).  The script is replayed
+// on the shim's objects through the three hooks a maintainer adds to those functions — insertPointIntoVoxelMap, markPointDirty, erasePointFromVoxelMap — and the
+// next syncFeatMap brings the device mirror up to date in O(changes) (livo2_visual_map_apply).
+struct GrowScript {
+  std::vector<double> new_pos, new_normal, opx, of, oR, ot, oie;
+  std::vector<int32_t> oid, oimg, olvl, t_point, t_pop, t_push, t_ref, t_flip, t_toggle, t_remove;
+  std::vector<float> opatch;
+  std::vector<uint8_t> ref_img;
+  std::vector<Feature> ft;                  // storage of the new Features / points of this script (stable: reserved before use)
+  std::vector<VisualPoint> vp;
+};
+static bool load_grow_script(const std::string &dir, int k, GrowScript &g) {
+  const std::string p = "grow" + std::to_string(k) + "_";
+  g.new_pos = rd<double>(dir, p + "new_pos"); g.new_normal = rd<double>(dir, p + "new_normal"); g.ref_img = rd<uint8_t>(dir, p + "ref_img");
+  g.oid = rd<int32_t>(dir, p + "obs_id"); g.oimg = rd<int32_t>(dir, p + "obs_img_idx"); g.olvl = rd<int32_t>(dir, p + "obs_level"); g.opx = rd<double>(dir, p + "obs_px");
+  g.of = rd<double>(dir, p + "obs_f"); g.oR = rd<double>(dir, p + "obs_R"); g.ot = rd<double>(dir, p + "obs_t"); g.oie = rd<double>(dir, p + "obs_inv_expo"); g.opatch = rd<float>(dir, p + "obs_patch");
+  g.t_point = rd<int32_t>(dir, p + "t_point"); g.t_pop = rd<int32_t>(dir, p + "t_pop"); g.t_push = rd<int32_t>(dir, p + "t_push"); g.t_ref = rd<int32_t>(dir, p + "t_ref");
+  g.t_flip = rd<int32_t>(dir, p + "t_flip"); g.t_toggle = rd<int32_t>(dir, p + "t_toggle"); g.t_remove = rd<int32_t>(dir, p + "t_remove");
+  return !g.ref_img.empty() && g.oid.size() * 64 == g.opatch.size() && g.t_point.size() == g.t_ref.size();
+}
+// replays one script: `points` / `feats` = file index -> object (the scripts count points and observations the way scenarios/visual_map_growth.py does)
+static void replay_grow_script(VIOManager &vio, GrowScript &g, std::vector<VisualPoint *> &points, std::vector<Feature *> &feats) {
+  const size_t no = g.oid.size(), nn = g.new_pos.size() / 3;
+  g.ft.assign(no, Feature()); g.vp.assign(nn, VisualPoint());
+  for (size_t i = 0; i < no; i++) {
+    Feature &f = g.ft[i];
+    f.id_ = g.oid[i]; f.patch_ = g.opatch.data() + 64 * i; f.img_ = g.ref_img.data(); f.px_ = {g.opx[i * 2], g.opx[i * 2 + 1]}; f.level_ = g.olvl[i]; f.inv_expo_time_ = g.oie[i];
+    for (int j = 0; j < 3; j++) { f.f_[j] = g.of[i * 3 + j]; f.t_f_w[j] = g.ot[i * 3 + j]; }
+    for (int j = 0; j < 9; j++) f.R_f_w[j] = g.oR[i * 9 + j];
+    feats.push_back(&f);
+  }
+  const size_t m0 = feats.size() - no;
+  for (size_t k = 0; k < nn; k++) {                                                  // generateVisualMapPoints: a new point with its one Feature (global index m0 + k)
+    VisualPoint &v = g.vp[k];
+    for (int j = 0; j < 3; j++) { v.pos_[j] = g.new_pos[k * 3 + j]; v.normal_[j] = g.new_normal[k * 3 + j]; }
+    v.is_normal_initialized_ = true; v.obs_.push_back(feats[m0 + k]);
+    vio.insertPointIntoVoxelMap(&v);
+    points.push_back(&v);
+  }
+  for (size_t q = 0; q < g.t_point.size(); q++) {                                    // updateVisualMapPoints / updateReferencePatch on resident points
+    VisualPoint *pt = points[g.t_point[q]];
+    if (g.t_remove[q]) { vio.erasePointFromVoxelMap(pt); pt->obs_.clear(); pt->ref_patch = nullptr; pt->has_ref_patch_ = false; continue; }
+    if (g.t_pop[q]) {                                                                // deleteFeatureRef (visual_point.cpp:40-55)
+      Feature *victim = pt->obs_.back(); pt->obs_.pop_back();
+      if (pt->ref_patch == victim) { pt->ref_patch = nullptr; pt->has_ref_patch_ = false; }
+    }
+    if (g.t_push[q] >= 0) pt->obs_.insert(pt->obs_.begin(), feats[g.t_push[q]]);    // addFrameRef: push_front
+    if (g.t_ref[q] == -1) { pt->ref_patch = nullptr; pt->has_ref_patch_ = false; }
+    else if (g.t_ref[q] >= 0) { pt->ref_patch = feats[g.t_ref[q]]; pt->has_ref_patch_ = true; }
+    if (g.t_flip[q]) for (int j = 0; j < 3; j++) pt->normal_[j] = -pt->normal_[j];
+    if (g.t_toggle[q]) pt->is_normal_initialized_ = !pt->is_normal_initialized_;
+    vio.markPointDirty(pt);
+  }
 }
 
 static void install_visual_map(VIOManager &vio, VisualMapFrame &m) {
@@ -139,10 +197,20 @@ int main(int argc, char **argv) {
     double total = 0.0; size_t timed = 0, sub_pts = 0, eff = 0;
     VisualMapFrame vmap;
     const size_t warm = F >= 4 ? 2 : (F >= 2 ? 1 : 0);
+    // growing-map mode (grow_cfg present): chain0_* is installed once, grow<k>_* scripts change it after frame k, grow<k>_img is the image of frame k >= 1
+    const auto grow_cfg = rd<int32_t>(dir, "grow_cfg");
+    const bool grow = !grow_cfg.empty();
+    std::vector<GrowScript> scripts(grow ? (size_t)grow_cfg[0] : 0);
+    std::vector<VisualPoint *> g_points; std::vector<Feature *> g_feats;
+    std::vector<uint8_t> cur_img;
     for (size_t f = 0; f < F; f++) {
-      if (!load_visual_map(dir, (int)f, img_bytes, vmap)) { std::fprintf(stderr, "live_chain: chain%zu_* inputs missing\n", f); return 2; }
-      install_visual_map(vio, vmap);
-      GrayImage img{vmap.img.data(), vio.width, vio.height, vio.width};
+      if (!grow || f == 0) {
+        if (!load_visual_map(dir, (int)f, img_bytes, vmap)) { std::fprintf(stderr, "live_chain: chain%zu_* inputs missing\n", f); return 2; }
+        install_visual_map(vio, vmap);
+        if (grow) { for (auto &v : vmap.vp) g_points.push_back(&v); for (auto &x : vmap.ft) g_feats.push_back(&x); }
+      }
+      if (grow && f > 0) { cur_img = rd<uint8_t>(dir, "grow" + std::to_string(f) + "_img"); if (cur_img.size() != img_bytes) { std::fprintf(stderr, "live_chain: grow%zu_img missing\n", f); return 2; } }
+      GrayImage img{(grow && f > 0) ? cur_img.data() : vmap.img.data(), vio.width, vio.height, vio.width};
       const auto tm = std::chrono::steady_clock::now();
       vio.syncFeatMap(img);
       dev.check(livo2_ctx_synchronize(dev.ctx()));                                   // (the mirror's uploads are asynchronous: their tail must not be billed to StateEstimation)
@@ -181,9 +249,13 @@ int main(int argc, char **argv) {
       std::memcpy(&states[(f * 2) * sizeof(livo2_state) / 8], &s_lio, sizeof(livo2_state));
       std::memcpy(&states[(f * 2 + 1) * sizeof(livo2_state) / 8], &s_vio, sizeof(livo2_state));
       counts[f * 2] = vm.effct_feat_num_; counts[f * 2 + 1] = vio.total_points;
+      if (grow && f < scripts.size()) {                                              // the map maintenance that closes processFrame (scripted): the NEXT frame's sync carries it to the device
+        if (!load_grow_script(dir, (int)f, scripts[f])) { std::fprintf(stderr, "live_chain: grow%zu_* inputs missing\n", f); return 2; }
+        replay_grow_script(vio, scripts[f], g_points, g_feats);
+      }
       for (VisualPoint *pt : sm.voxel_points) for (int k = 0; k < 3; k++) sub_pos.push_back(pt->pos_[k]);
       stage[f * 5] = a; stage[f * 5 + 1] = b - a; stage[f * 5 + 2] = c - b; stage[f * 5 + 3] = d - c;
-      if (f >= warm) { total += d; timed++; sub_pts += (size_t)vio.total_points; eff += (size_t)vm.effct_feat_num_; }   // the first frames are warm-up: allocations, pinned buffers,
+      if (f >= warm) { total += d + (grow ? stage[f * 5 + 4] : 0.0); timed++; sub_pts += (size_t)vio.total_points; eff += (size_t)vm.effct_feat_num_; }   // the first frames are warm-up: allocations, pinned buffers,
                                                                                                                         // and the first update of a freshly built tree (every root voxel is new to it)
     }
     auto wr = [&](const char *name, const void *p, size_t bytes) { std::ofstream o(dir + "/" + name, std::ios::binary); o.write((const char *)p, bytes); };
@@ -201,6 +273,12 @@ int main(int argc, char **argv) {
       s[k] = v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]);
     }
     const double T = timed ? (double)timed : 1.0;
+    if (grow)
+      std::printf("live_chain%s grow: %zu frames timed, %.3f ms per frame (syncFeatMap %.3f [incremental: %d delta syncs, %d full], StateEstimation %.3f, UpdateVoxelMapFromPosterior %.3f, "
+                  "retrieveFromVisualSparseMap %.3f, computeJacobianAndUpdateEKF %.3f); visual map %zu points / %zu observations at the end; mean scan %.0f points, sub-map %.0f patches; medians over the timed frames\n",
+                  lean ? " (lean)" : "", timed, s[0] + s[1] + s[2] + s[3] + s[4], s[4], vio.delta_syncs_, vio.full_syncs_, s[0], s[1], s[2], s[3], vio.mirroredPoints(), vio.mirroredObservations(),
+                  (double)off / (double)F, (double)sub_pts / T);
+    else
     std::printf("live_chain%s: %zu frames timed, %.3f ms per frame (StateEstimation %.3f, UpdateVoxelMapFromPosterior %.3f, retrieveFromVisualSparseMap %.3f, computeJacobianAndUpdateEKF %.3f); "
                 "mean scan %.0f points, effct_feat_num_ %.0f, sub-map %.0f patches; syncFeatMap %.3f ms per frame (outside the stages); medians over the timed frames, mean frame %.3f ms\n",
                 lean ? " (lean)" : "", timed, s[0] + s[1] + s[2] + s[3], s[0], s[1], s[2], s[3], (double)off / (double)F, (double)eff / T, (double)sub_pts / T, s[4], total / T);

@@ -508,6 +508,9 @@ void VIOManager::mirrorFeatMap(bool with_obs, const GrayImage *img) {
     }
   dev_.check(livo2_visual_map_upload(dev_.ctx(), (int32_t)mirror_.size(), pos.data(), key.data(), act.data()));
   feat_map_dirty_ = false; obs_resident_ = false;
+  for (size_t i = 0; i < mirror_.size(); i++) if (mirror_[i]) { mirror_[i]->mirror_index_ = (int32_t)i; mirror_[i]->mirror_dirty_ = false; }
+  pending_new_.clear(); pending_new_keys_.clear(); pending_dirty_.clear(); pending_removed_.clear();      // the full upload carries whatever they stood for
+  full_syncs_++;
   if (!with_obs) return;
   const size_t n = mirror_.size();
   std::vector<int32_t> off(n + 1, 0), id, iidx, lvl, refp(n, -1);
@@ -525,6 +528,7 @@ void VIOManager::mirrorFeatMap(bool with_obs, const GrayImage *img) {
         if (pt->has_ref_patch_ && ft == pt->ref_patch) refp[i] = (int32_t)obs_mirror_.size();
         size_t k = 0; while (k < imgs.size() && imgs[k] != ft->img_) k++;
         if (k == imgs.size()) imgs.push_back(ft->img_);
+        ft->mirror_index_ = (int32_t)obs_mirror_.size();
         obs_mirror_.push_back(ft);
         id.push_back(ft->id_); iidx.push_back((int32_t)k); lvl.push_back(ft->level_); ie.push_back(ft->inv_expo_time_);
         px.insert(px.end(), ft->px_.begin(), ft->px_.end()); f.insert(f.end(), ft->f_.begin(), ft->f_.end());
@@ -545,6 +549,114 @@ void VIOManager::mirrorFeatMap(bool with_obs, const GrayImage *img) {
   o.width = img->cols; o.height = img->rows; o.stride = img->step;
   dev_.check(livo2_visual_obs_upload(dev_.ctx(), &o));
   obs_resident_ = true;
+  img_slots_ = imgs;
+}
+
+// ---- incremental mirror -------------------------------------------------------------------------------------------------------------------------------
+void VIOManager::insertPointIntoVoxelMap(VisualPoint *pt_new) {                   // reference src/vio.cpp:227-246
+  float loc_xyz[3];
+  for (int j = 0; j < 3; j++) {
+    loc_xyz[j] = (float)(pt_new->pos_[j] / 0.5);
+    if (loc_xyz[j] < 0) loc_xyz[j] -= 1.0f;
+  }
+  const VOXEL_LOCATION position((int64_t)loc_xyz[0], (int64_t)loc_xyz[1], (int64_t)loc_xyz[2]);
+  auto it = feat_map.find(position);
+  if (it != feat_map.end()) { it->second->voxel_points.push_back(pt_new); it->second->count++; }
+  else { VOXEL_POINTS *ot = new VOXEL_POINTS; ot->voxel_points.push_back(pt_new); feat_map[position] = ot; }
+  pt_new->mirror_index_ = -1;
+  pending_new_.push_back(pt_new); pending_new_keys_.push_back(position);
+}
+
+void VIOManager::markPointDirty(VisualPoint *pt) {
+  if (!pt || pt->mirror_dirty_ || pt->mirror_index_ < 0) return;                  // (a point that is not mirrored yet travels whole with the delta that creates it)
+  pt->mirror_dirty_ = true;
+  pending_dirty_.push_back(pt);
+}
+
+void VIOManager::erasePointFromVoxelMap(VisualPoint *pt) {
+  if (!pt) return;
+  for (auto &kv : feat_map) {                                                       // (the voxel is known to a caller of the reference; the demo's removals are rare)
+    auto &v = kv.second->voxel_points;
+    auto it = std::find(v.begin(), v.end(), pt);
+    if (it != v.end()) { v.erase(it); kv.second->count--; break; }
+  }
+  if (pt->mirror_index_ >= 0) { mirror_[pt->mirror_index_] = nullptr; pending_removed_.push_back(pt->mirror_index_); }
+  for (size_t i = 0; i < pending_new_.size(); i++) if (pending_new_[i] == pt) { pending_new_.erase(pending_new_.begin() + i); pending_new_keys_.erase(pending_new_keys_.begin() + i); break; }
+  for (size_t i = 0; i < pending_dirty_.size(); i++) if (pending_dirty_[i] == pt) { pending_dirty_.erase(pending_dirty_.begin() + i); break; }
+  pt->mirror_index_ = -1; pt->mirror_dirty_ = false;
+}
+
+void VIOManager::syncFeatMap(const GrayImage &img) {
+  if (feat_map_dirty_ || !obs_resident_) { mirrorFeatMap(true, &img); return; }
+  if (!pending_new_.empty() || !pending_dirty_.empty() || !pending_removed_.empty()) applyPendingDelta(img);
+}
+
+void VIOManager::applyPendingDelta(const GrayImage &img) {
+  const size_t n_new = pending_new_.size();
+  std::vector<double> npos(n_new * 3), tnormal;
+  std::vector<int64_t> nkey(n_new * 3);
+  std::vector<uint8_t> nact(n_new, 1), tninit, tactive;
+  std::vector<int32_t> oid, oimg, olvl, tpoint, toff(1, 0), tobs, tref;
+  std::vector<double> opx, of, oR, ot, oie;
+  std::vector<float> opatch;
+  std::vector<const uint8_t *> new_imgs;
+  for (size_t k = 0; k < n_new; k++) {                                              // new points take the indices behind the resident ones, in queue order
+    VisualPoint *pt = pending_new_[k];
+    pt->mirror_index_ = (int32_t)mirror_.size(); mirror_.push_back(pt);
+    std::memcpy(&npos[k * 3], pt->pos_.data(), 24);
+    nkey[k * 3] = pending_new_keys_[k].x; nkey[k * 3 + 1] = pending_new_keys_[k].y; nkey[k * 3 + 2] = pending_new_keys_[k].z;
+    pt->mirror_dirty_ = true;
+  }
+  std::vector<VisualPoint *> touched(pending_new_);                                 // a new point's list / normal / flags travel as a touched row like any other
+  touched.insert(touched.end(), pending_dirty_.begin(), pending_dirty_.end());
+  auto image_slot = [&](const uint8_t *p) -> int32_t {
+    for (size_t k = img_slots_.size(); k-- > 0;) if (img_slots_[k] == p) return (int32_t)k;      // new images sit at the back
+    img_slots_.push_back(p); new_imgs.push_back(p);
+    return (int32_t)img_slots_.size() - 1;
+  };
+  for (VisualPoint *pt : touched) {
+    tpoint.push_back(pt->mirror_index_);
+    int32_t ref = -1;
+    for (Feature *ft : pt->obs_) {
+      if (ft->mirror_index_ < 0) {                                                  // a Feature the device has not seen: appended behind the resident observations
+        if (!ft->patch_) throw std::runtime_error("syncFeatMap: Feature without patch_");
+        ft->mirror_index_ = (int32_t)obs_mirror_.size(); obs_mirror_.push_back(ft);
+        oid.push_back(ft->id_); oimg.push_back(image_slot(ft->img_)); olvl.push_back(ft->level_); oie.push_back(ft->inv_expo_time_);
+        opx.insert(opx.end(), ft->px_.begin(), ft->px_.end()); of.insert(of.end(), ft->f_.begin(), ft->f_.end());
+        oR.insert(oR.end(), ft->R_f_w.begin(), ft->R_f_w.end()); ot.insert(ot.end(), ft->t_f_w.begin(), ft->t_f_w.end());
+        opatch.insert(opatch.end(), ft->patch_, ft->patch_ + 64);
+      }
+      tobs.push_back(ft->mirror_index_);
+      if (pt->has_ref_patch_ && ft == pt->ref_patch) ref = ft->mirror_index_;
+    }
+    toff.push_back((int32_t)tobs.size());
+    tref.push_back(ref);
+    tnormal.insert(tnormal.end(), pt->normal_.begin(), pt->normal_.end());
+    tninit.push_back(pt->is_normal_initialized_ ? 1 : 0); tactive.push_back(pt->obs_.empty() ? 0 : 1);
+    pt->mirror_dirty_ = false;
+  }
+  for (int32_t idx : pending_removed_) {                                            // gone from feat_map: the slot stays, inactive, with an empty list
+    tpoint.push_back(idx); toff.push_back((int32_t)tobs.size()); tref.push_back(-1);
+    tnormal.insert(tnormal.end(), {0.0, 0.0, 0.0}); tninit.push_back(0); tactive.push_back(0);
+  }
+  const int32_t slot0 = (int32_t)(img_slots_.size() - new_imgs.size());
+  for (size_t k = 0; k + 1 < new_imgs.size(); k++) {                                // the API takes one image per call: all but the last travel on their own
+    livo2_visual_map_delta di{};
+    di.img = new_imgs[k]; di.img_slot = slot0 + (int32_t)k;
+    dev_.check(livo2_visual_map_apply(dev_.ctx(), &di));
+  }
+  livo2_visual_map_delta d{};
+  d.n_new_points = (int32_t)n_new; d.n_new_obs = (int32_t)oid.size(); d.n_touched = (int32_t)tpoint.size();
+  d.new_pos = npos.data(); d.new_voxel_key = nkey.data(); d.new_active = nact.data();
+  d.obs_id = oid.data(); d.obs_img_idx = oimg.data(); d.obs_px = opx.data(); d.obs_f = of.data(); d.obs_R = oR.data(); d.obs_t = ot.data(); d.obs_level = olvl.data();
+  d.obs_inv_expo = oie.data(); d.obs_patch = opatch.data();
+  d.touched_point = tpoint.data(); d.touched_offset = toff.data(); d.touched_obs = tobs.data(); d.touched_normal = tnormal.data();
+  d.touched_normal_initialized = tninit.data(); d.touched_active = tactive.data(); d.touched_ref_patch = tref.data();
+  if (!new_imgs.empty()) { d.img = new_imgs.back(); d.img_slot = (int32_t)img_slots_.size() - 1; }
+  (void)img;
+  dev_.check(livo2_visual_map_apply(dev_.ctx(), &d));
+  pending_new_.clear(); pending_new_keys_.clear(); pending_dirty_.clear(); pending_removed_.clear();
+  delta_syncs_++;
 }
 
 void VIOManager::gridSetup() {                                                    // reference src/vio.cpp:67-78
@@ -597,7 +709,7 @@ void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::ve
   if (feat_map.empty()) return;                                                   // reference src/vio.cpp:354
   SubSparseMap &sm = *visual_submap;                                              // visual_submap->reset(), vio.cpp:359
   sm.voxel_points.clear(); sm.search_levels.clear(); sm.errors.clear(); sm.inv_expo_list.clear(); sm.warp_patch.clear();
-  mirrorFeatMap(true, &img);
+  syncFeatMap(img);
   gridSetup();
   const int length = grid_n_width * grid_n_height, L = patch_pyrimid_level;
   std::vector<double> pgw(pg.size() * 3);

@@ -230,12 +230,15 @@ struct Feature {                            // reference include/feature.h:19-54
   V3D pos{};                                // pos(): camera centre of the reference frame
   int level_ = 0;
   double inv_expo_time_ = 1.0;
+  int32_t mirror_index_ = -1;               // shim: global observation index on the device, -1 = not mirrored yet
 };
 struct VisualPoint {                        // reference include/visual_point.h:23-46
   V3D pos_{}, normal_{};
   Feature *ref_patch = nullptr;
-  std::vector<Feature *> obs_;              // (std::list in the reference; the order is what matters)
+  std::vector<Feature *> obs_;              // (std::list in the reference; the order is what matters: addFrameRef pushes to the FRONT, visual_point.cpp:35-38)
   bool is_normal_initialized_ = true, has_ref_patch_ = false;
+  int32_t mirror_index_ = -1;               // shim: index of the point in the device mirror, -1 = not mirrored yet
+  bool mirror_dirty_ = false;               // shim: waiting in the next delta (VIOManager::markPointDirty)
 };
 
 struct VOXEL_POINTS {                       // reference include/vio.h:59-69
@@ -313,7 +316,16 @@ public:
   bool pg_from_map_update_ = false;
   // mirror feat_map (+ observations, reference images) on the device now instead of inside the next retrieveFromVisualSparseMap (the cost of a visual-map change,
   // which the reference's map maintenance — out of scope — causes once per frame)
-  void syncFeatMap(const GrayImage &img) { mirrorFeatMap(true, &img); }
+  void syncFeatMap(const GrayImage &img);
+  // ---- incremental mirror (round 5).  The reference changes feat_map by a few points per frame (generateVisualMapPoints vio.cpp:804-895, updateVisualMapPoints
+  // 908-967, updateReferencePatch 969-1100 — the maintenance itself is out of scope); three hooks in those functions keep the device mirror in step in O(changes)
+  // (livo2_visual_map_apply) instead of the re-flatten + re-upload that feat_map_dirty_ = true asks for:
+  void insertPointIntoVoxelMap(VisualPoint *pt_new);     // reference src/vio.cpp:227-246: files the point under its voxel in feat_map AND queues it for the next sync
+  void markPointDirty(VisualPoint *pt);                  // after addFrameRef / deleteFeatureRef / a change of normal_, is_normal_initialized_, ref_patch, has_ref_patch_
+  void erasePointFromVoxelMap(VisualPoint *pt);          // the point leaves feat_map (and the mirror: its slot stays, inactive); the caller may delete it afterwards
+  size_t mirroredPoints() const { return mirror_.size(); }
+  size_t mirroredObservations() const { return obs_mirror_.size(); }
+  int delta_syncs_ = 0, full_syncs_ = 0;                 // how the mirror was brought up to date so far
 
 private:
   Device &dev_;
@@ -321,6 +333,11 @@ private:
   std::vector<VisualPoint *> mirror_;       // device index -> VisualPoint*
   std::vector<Feature *> obs_mirror_;       // device observation index -> Feature*
   bool obs_resident_ = false;
+  std::vector<VisualPoint *> pending_new_, pending_dirty_;       // queued by the hooks above, consumed by applyPendingDelta
+  std::vector<VOXEL_LOCATION> pending_new_keys_;
+  std::vector<int32_t> pending_removed_;
+  std::vector<const uint8_t *> img_slots_;                        // device image slot -> Feature::img_
+  void applyPendingDelta(const GrayImage &img);
   void mirrorFeatMap(bool with_obs, const GrayImage *img);
   void gridSetup();
   livo2_select_cfg selectCfg() const;

@@ -42,6 +42,11 @@ def run(live, lib=None, num_threads=1, timing=False):
     cfg = orc.lidar_cfg(c, extR, extT, num_threads=num_threads)
     post = orc.state_arrays(orc.make_state(live["R0"], live["t0"], live["P0"]))
     out = []
+    grow = live.get("grow")
+    gm = None
+    if grow:                                                              # ONE visual map that the scripted maintenance changes after every frame
+        from scenarios.visual_map_growth import GrowingMap
+        gm = GrowingMap(live["cs"][0])
     for k, xyz in enumerate(live["scans"]):
         mo = live["motion"][k]
         prop = orc.make_state(post["R"] @ mo[:9].reshape(3, 3), post["t"] + mo[9:], post["P"] + np.diag(live["q"]), inv_expo=post["inv_expo"], vel=post["vel"],
@@ -53,7 +58,11 @@ def run(live, lib=None, num_threads=1, timing=False):
         pw, var = posterior_points(xyz, r["body_cov"], r["cross_mat"], lio["R"], lio["t"], lio["P"], extR, extT)
         om.update(pw, var.reshape(-1, 9))
         tb = time.perf_counter()
-        ck = live["cs"][k]
+        if gm is not None:
+            ck, g2c = gm.flat()                                           # the whole map as it stands when frame k arrives (CSR: what a full upload would carry)
+            ck.img = grow["imgs"][k]
+        else:
+            ck = live["cs"][k]
         ck.sel.pg = pw
         ck.sel.R_cur, ck.sel.t_cur = frame_pose(lio["R"], lio["t"], vs)
         ck.inv_expo_cur = lio["inv_expo"]                                 # retrieve reads state->inv_expo_time (vio.cpp:745-752)
@@ -75,7 +84,15 @@ def run(live, lib=None, num_threads=1, timing=False):
             vio = lio
         td = time.perf_counter()
         n_it = r["n_iters"]
-        rec = dict(lio=lio, vio=vio, n_iters=n_it, n_eff=int(r["trace"][n_it - 1].n_eff) if n_it else 0, n_sub=int(keep.sum()), steps=steps, sub_point=ret["sub_point"])
+        rec = dict(lio=lio, vio=vio, n_iters=n_it, n_eff=int(r["trace"][n_it - 1].n_eff) if n_it else 0, n_sub=int(keep.sum()), steps=steps, sub_point=ret["sub_point"],
+                   sub_pos=ck.sel.pos[ret["sub_point"]])
+        if gm is not None:
+            # pt->ref_patch as the retrieval left it (vio.cpp:660-661, 689-690), then the maintenance that closes processFrame
+            c2g = gm.c2g(g2c)
+            gm.set_ref_patch(np.where(ret["ref_patch"] >= 0, c2g[np.maximum(ret["ref_patch"], 0)], -1))
+            if k < len(grow["scripts"]):
+                gm.apply(grow["scripts"][k])
+            rec["map_points"], rec["map_obs"] = gm.n_points, gm.n_obs
         if timing:
             rec["stage_s"] = (ta - t0, tb - ta, tc - tb, td - tc)
         out.append(rec)

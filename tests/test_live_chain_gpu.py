@@ -63,3 +63,45 @@ def test_full_and_lean_give_the_same_states(chain):
         assert r.returncode == 0, r.stderr
         outs.append(np.fromfile(os.path.join(d, "live_states.bin")))
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.fixture(scope="module")
+def grow_chain(tmp_path_factory):
+    from oracle import live_chain as OC
+    live = LI.make_live(**LI.SIZES["test_grow"])
+    d = str(tmp_path_factory.mktemp("live_grow"))
+    LI.write_live_dir(d, live)
+    recs, _ = OC.run(live)
+    return d, live, recs, OC.pack(recs)
+
+
+@pytest.mark.parametrize("mode", ["full", "lean"])
+def test_growing_visual_map_through_the_incremental_mirror(grow_chain, mode):
+    """ONE visual map that the (scripted) map maintenance changes after every frame — new points, new observations pushed to the front of obs_, deletions, ref_patch /
+    normal changes, a new reference image (scenarios/visual_map_growth.py) — replayed on the shim's objects through insertPointIntoVoxelMap / markPointDirty /
+    erasePointFromVoxelMap; syncFeatMap brings the device mirror up to date with ONE full upload before frame 0 and O(changes) deltas afterwards
+    (livo2_visual_map_apply).  Against the oracle that gets the WHOLE map re-flattened per frame: same sub-maps (members, order), same states."""
+    d, live, recs, want = grow_chain
+    r = subprocess.run([EXE, d] + (["lean"] if mode == "lean" else []), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    F = len(recs)
+    got = np.fromfile(os.path.join(d, "live_states.bin")).reshape(F, 2, K)
+    counts = np.fromfile(os.path.join(d, "live_counts.bin"), np.int32).reshape(F, 2)
+    sub_pos = np.fromfile(os.path.join(d, "live_sub_pos.bin")).reshape(-1, 3)
+    at = 0
+    for f, rec in enumerate(recs):
+        assert counts[f, 0] == rec["n_eff"] and counts[f, 1] == rec["n_sub"] > 100, (f, counts[f], rec["n_eff"], rec["n_sub"])
+        assert np.array_equal(sub_pos[at:at + rec["n_sub"]], rec["sub_pos"]), f                      # the same visual points, in the same (grid) order
+        at += rec["n_sub"]
+        for which in (0, 1):
+            g, w = got[f, which], want[f, which]
+            assert np.abs(g[:25] - w[:25]).max() < 1e-7, (mode, f, which, np.abs(g[:25] - w[:25]).max())
+            assert np.linalg.norm(g[25:] - w[25:]) < 1e-6 * np.linalg.norm(w[25:]), (mode, f, which)
+        assert np.linalg.norm(rec["vio"]["t"] - live["t_true"][f]) < 0.03
+    assert at == len(sub_pos)
+    assert ("%d delta syncs, 1 full" % (F - 1)) in r.stdout, r.stdout
+    assert ("visual map %d points / %d observations" % (recs[-1]["map_points"], recs[-1]["map_obs"])) in r.stdout, r.stdout
+    # new points of later frames do get selected: the sub-map of the last frame holds points that did not exist when frame 0 arrived
+    n_base = len(live["cs"][0].sel.pos)
+    assert (recs[-1]["sub_point"] >= n_base).sum() > 0
+    print(r.stdout)
