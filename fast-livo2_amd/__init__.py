@@ -529,6 +529,35 @@ class Context:
         self._chk(self.lib.livo2_visual_update(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg), C.byref(res), abi.as_ptr(errors, C.c_float)))
         return res, errors
 
+    # ---- one LIO + VIO frame per call ------------------------------------------------------------------------------
+    def _frame_in(self, xyz, prior, cfg, vs_img, pos, warp_patch, search_levels, inv_expo_list, vcfg):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        img = np.ascontiguousarray(vs_img, np.uint8)
+        pos = _f64(pos).reshape(-1, 3)
+        warp = np.ascontiguousarray(warp_patch, np.float32)
+        sl, ie = np.ascontiguousarray(search_levels, np.int32), _f64(inv_expo_list)
+        M = len(pos)
+        L = int(warp.shape[1]) if warp.ndim == 3 else int(vcfg.patch_pyrimid_level)
+        f = abi.FrameIn(abi.as_ptr(xyz, C.c_float), len(xyz), M, L, img.shape[1], img.shape[0], img.shape[1], C.addressof(prior), C.addressof(cfg), C.addressof(vcfg),
+                        abi.as_ptr(img, C.c_uint8), abi.as_ptr(pos, C.c_double), abi.as_ptr(warp, C.c_float), abi.as_ptr(sl, C.c_int32), abi.as_ptr(ie, C.c_double))
+        return f, (xyz, img, pos, warp, sl, ie, prior, cfg, vcfg), M, L
+
+    def frame_update_async(self, xyz, prior, cfg, img, pos, warp_patch, search_levels, inv_expo_list, vcfg):
+        """livo2_frame_update_async: scan + StateEstimation from `prior` + image / sub-map + computeJacobianAndUpdateEKF from the LiDAR posterior, enqueued in one
+        call (up to two frames in flight; the arrays are staged inside the call)."""
+        f, keep, M, L = self._frame_in(xyz, prior, cfg, img, pos, warp_patch, search_levels, inv_expo_list, vcfg)
+        self._chk(self.lib.livo2_frame_update_async(self.h, C.byref(f)))
+        self.n, self.M, self.L = len(keep[0]), M, L
+
+    def frame_update_fetch(self):
+        lres, vres = LidarResult(), VisualResult()
+        self._chk(self.lib.livo2_frame_update_fetch(self.h, C.byref(lres), C.byref(vres)))
+        return lres, vres
+
+    def frame_update(self, *a):
+        self.frame_update_async(*a)
+        return self.frame_update_fetch()
+
     def visual_update_async(self, state_in, prop, cfg):
         self._chk(self.lib.livo2_visual_update_async(self.h, C.byref(state_in), C.byref(prop), C.byref(cfg)))
 

@@ -149,6 +149,13 @@ class VisualMapDelta(C.Structure):
                 ("touched_ref_patch", C.POINTER(C.c_int32)), ("img", C.POINTER(C.c_uint8))]
 
 
+class FrameIn(C.Structure):
+    """livo2_frame_in: one LIO + VIO frame (scan, prior, image + visual sub-map, both configurations)"""
+    _fields_ = [("xyz", C.POINTER(C.c_float)), ("n_points", C.c_int32), ("M", C.c_int32), ("L", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+                ("prior", C.c_void_p), ("lidar_cfg", C.c_void_p), ("visual_cfg", C.c_void_p), ("img", C.POINTER(C.c_uint8)), ("pos", C.POINTER(C.c_double)),
+                ("warp_patch", C.POINTER(C.c_float)), ("search_levels", C.POINTER(C.c_int32)), ("inv_expo_list", C.POINTER(C.c_double))]
+
+
 class RetrieveChainOut(C.Structure):
     _fields_ = [("cell_point", C.POINTER(C.c_int32)), ("cell_dist", C.POINTER(C.c_float)), ("cell_discontinuous", C.POINTER(C.c_uint8)), ("cell_obs", C.POINTER(C.c_int32)),
                 ("ref_patch", C.POINTER(C.c_int32)), ("cand_cell", C.POINTER(C.c_int32)), ("tail", RetrieveOut), ("sub_point", C.POINTER(C.c_int32)),
@@ -245,6 +252,9 @@ SIGNATURES = {
                                              _P(RetrieveOut), _P(C.c_int32)]),
     "livo2_visual_retrieve_last_kernel_us": (C.c_double, [_CTX]),
     "livo2_visual_obs_upload": (C.c_int, [_CTX, _P(VisualObs)]),
+    "livo2_frame_update_async": (C.c_int, [_CTX, _P(FrameIn)]),
+    "livo2_frame_update_fetch": (C.c_int, [_CTX, _P(LidarResult), _P(VisualResult)]),
+    "livo2_frame_update": (C.c_int, [_CTX, _P(FrameIn), _P(LidarResult), _P(VisualResult)]),
     "livo2_visual_map_apply": (C.c_int, [_CTX, _P(VisualMapDelta)]),
     "livo2_visual_map_counts": (C.c_int, [_CTX, _P(C.c_int32)]),
     "livo2_visual_retrieve_from_map": (C.c_int, [_CTX, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), C.c_int32, _P(SelectCfg), _P(RetrieveCfg),

@@ -94,6 +94,11 @@ struct livo2_ctx {
   int32_t *d_ob_list = nullptr, *d_ob_cnt = nullptr; size_t ob_list_cap = 0, ob_cnt_cap = 0; int ob_stride = 0;
   void *h_delta = nullptr; size_t h_delta_cap = 0; void *d_delta = nullptr; size_t d_delta_cap = 0; hipEvent_t delta_ev = nullptr; bool delta_ev_used = false;
   int vm_delta_calls = 0, vm_delta_grows = 0;
+  // whole frames (livo2_frame_update_*): pinned staging of the image + sub-map (two blocks, like the scan's), pinned ring of two result slots
+  void *frame_stage[2] = {nullptr, nullptr}; size_t frame_stage_cap[2] = {0, 0}; hipEvent_t frame_stage_ev[2] = {nullptr, nullptr}; bool frame_stage_used[2] = {false, false}; int frame_stage_next = 0;
+  void *h_frame_res = nullptr; hipEvent_t frame_res_ev[2] = {nullptr, nullptr}; int frame_head = 0, frame_inflight = 0;
+  livo2_visual_cfg frame_vcfg[2] = {}; int frame_M[2] = {0, 0}; bool frame_persistent[2] = {false, false};
+  bool vp_last_chained = false;
   int32_t *d_ch_obs = nullptr, *d_ch_flag = nullptr, *d_ch_slot = nullptr, *d_cand_cell = nullptr, *d_cand_point = nullptr, *d_cand_obs = nullptr, *d_sub_point = nullptr,
           *d_sub_obs = nullptr, *d_ch_count = nullptr;
   size_t ch_obs_cap = 0, ch_flag_cap = 0, ch_slot_cap = 0, cand_cell_cap = 0, cand_point_cap = 0, cand_obs_cap = 0, sub_point_cap = 0, sub_obs_cap = 0;
@@ -665,7 +670,7 @@ int32_t livo2_abi_sizeof(const char *name) {
   LIVO2_SZ(livo2_state) LIVO2_SZ(livo2_map_view) LIVO2_SZ(livo2_lidar_cfg) LIVO2_SZ(livo2_lidar_sums) LIVO2_SZ(livo2_lidar_points) LIVO2_SZ(livo2_lidar_result)
   LIVO2_SZ(livo2_cam) LIVO2_SZ(livo2_visual_cfg) LIVO2_SZ(livo2_visual_sums) LIVO2_SZ(livo2_visual_step) LIVO2_SZ(livo2_visual_result)
   LIVO2_SZ(livo2_plane_fit) LIVO2_SZ(livo2_imu_step) LIVO2_SZ(livo2_imu_cfg) LIVO2_SZ(livo2_imu_pose) LIVO2_SZ(livo2_select_cfg)
-  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out) LIVO2_SZ(livo2_visual_map_delta)
+  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out) LIVO2_SZ(livo2_visual_map_delta) LIVO2_SZ(livo2_frame_in)
 #undef LIVO2_SZ
   return 0;
 }
@@ -720,6 +725,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
   if (ctx->h_pts) e = hipHostFree(ctx->h_pts);
   if (ctx->h_delta) e = hipHostFree(ctx->h_delta);
+  if (ctx->h_frame_res) e = hipHostFree(ctx->h_frame_res);
+  for (int k = 0; k < 2; k++) { if (ctx->frame_stage[k]) e = hipHostFree(ctx->frame_stage[k]); if (ctx->frame_stage_ev[k]) e = hipEventDestroy(ctx->frame_stage_ev[k]); if (ctx->frame_res_ev[k]) e = hipEventDestroy(ctx->frame_res_ev[k]); }
   if (ctx->delta_ev) e = hipEventDestroy(ctx->delta_ev);
   for (int k = 0; k < 2; k++) { if (ctx->scan_stage[k]) e = hipHostFree(ctx->scan_stage[k]); if (ctx->scan_stage_ev[k]) e = hipEventDestroy(ctx->scan_stage_ev[k]); }
   if (ctx->bh_in) e = hipHostFree(ctx->bh_in);
@@ -1094,7 +1101,9 @@ int scan_reserve(livo2_ctx *ctx, int n) {
   if (n > ctx->n_cap) {
     hipError_t e;
     if (ctx->d_x) { e = DFREE(ctx->d_xyz_aos); e = DFREE(ctx->d_x); e = DFREE(ctx->d_y); e = DFREE(ctx->d_z); e = DFREE(ctx->d_cb); e = DFREE(ctx->d_keys); e = DFREE(ctx->d_keys2); e = DFREE(ctx->d_idx); e = DFREE(ctx->d_perm); (void)e; }
-    int cap = std::max(n, 1024);
+    // headroom: live scans differ in size from frame to frame (the voxel-grid filter's output), and a re-allocation is nine hipFree / hipMalloc pairs that stall every
+    // stream of the device — with an exact fit the C1-shaped frames of three contexts ran at 2 200 frames/s instead of 5 100 (profiles/r05_frame_api_probe.txt)
+    int cap = std::max(n + n / 2, 4096);
     HIPCHK(DMALLOC((void **)&ctx->d_xyz_aos, (size_t)cap * 12)); HIPCHK(DMALLOC((void **)&ctx->d_x, (size_t)cap * 4));
     HIPCHK(DMALLOC((void **)&ctx->d_y, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_z, (size_t)cap * 4));
     HIPCHK(DMALLOC((void **)&ctx->d_cb, (size_t)cap * 48));
@@ -1592,8 +1601,8 @@ int livo2_lidar_set_scan(livo2_ctx *ctx, const float *xyz, int32_t n, const livo
     if (bytes > ctx->scan_stage_cap[k]) {
       if (ctx->scan_stage[k]) HIPCHK(hipHostFree(ctx->scan_stage[k]));
       ctx->scan_stage[k] = nullptr; ctx->scan_stage_cap[k] = 0;
-      HIPCHK(hipHostMalloc(&ctx->scan_stage[k], bytes + bytes / 4));
-      ctx->scan_stage_cap[k] = bytes + bytes / 4;
+      HIPCHK(hipHostMalloc(&ctx->scan_stage[k], 2 * bytes));                        // (hipHostMalloc / hipHostFree synchronise the device: grow rarely)
+      ctx->scan_stage_cap[k] = 2 * bytes;
     }
     if (!ctx->scan_stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->scan_stage_ev[k], hipEventDisableTiming));
     std::memcpy(ctx->scan_stage[k], xyz, bytes);
@@ -2743,9 +2752,22 @@ int livo2_visual_iterate(livo2_ctx *ctx, int32_t level, const livo2_state *cur, 
   return LIVO2_OK;
 }
 
+// the iterate and the prior of a visual update := the LiDAR posterior that the update before it left in the result block (LIVMapper.cpp:135-136, 256, 371: `state`
+// is shared and processImu re-assigns state_propagat from it), header cleared as upload_states clears it — the hand-over of livo2_frame_update, all on the device
+__global__ void __launch_bounds__(256) k_ctl_chain_visual(DevCtl *__restrict__ ctl) {
+  const int t = threadIdx.x;
+  const double *src = reinterpret_cast<const double *>(&ctl->lidar.state);
+  double *c = reinterpret_cast<double *>(&ctl->cur), *p = reinterpret_cast<double *>(&ctl->prop);
+  for (int k = t; k < (int)(sizeof(livo2_state) / 8); k += 256) { const double v = src[k]; c[k] = v; p[k] = v; }
+  if (t == 0) { ctl->hdr.stop = 0; ctl->hdr.rematch_num = 0; ctl->hdr.reserved = 0; ctl->hdr.last_error = FLT_MAX; ctl->hdr.n_steps = 0; ctl->hdr.pad[0] = ctl->hdr.pad[1] = ctl->hdr.pad[2] = 0; }
+  if (t < 9) ctl->hdr.RE[t] = 0.0;
+}
+
 static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg, int level_hi, int level_lo,
                           int iters, int mode) {
-  int rc = upload_states(ctx, state_in, prop); if (rc) return rc;
+  int rc;
+  if (state_in) { rc = upload_states(ctx, state_in, prop); if (rc) return rc; }
+  else { hipLaunchKernelGGL(k_ctl_chain_visual, dim3(1), dim3(256), 0, ctx->stream, ctx->d_ctl); HIPCHK(hipGetLastError()); }      // chained: states from the LiDAR result block
   const int grid = cfg->inverse_composition_en ? visual_grid_inverse(std::max(ctx->M, 1)) : visual_grid(std::max(ctx->M, 1));
   VisualKernelArgs a{};
   ctx->vp_last_valid = false;
@@ -2775,7 +2797,9 @@ static int visual_enqueue(livo2_ctx *ctx, const livo2_state *state_in, const liv
       if (ctx->vp_prof) p.prof = ctx->d_vp_prof;
       p.timeout = ctx->vp_debug_timeout ? 200000ull : (unsigned long long)ctx->vp_timeout_us * 100ull;      // 100 MHz ticks; debug: 2 ms
       p.debug_drop_block = (ctx->vp_debug_timeout && G > 1) ? G - 1 : -1;
-      ctx->vp_last_in = *state_in; ctx->vp_last_prop = *prop; ctx->vp_last_cfg = *cfg; ctx->vp_last_valid = true;    // what a timed-out grid is re-run from
+      ctx->vp_last_chained = state_in == nullptr;                                                                      // what a timed-out grid is re-run from
+      if (state_in) { ctx->vp_last_in = *state_in; ctx->vp_last_prop = *prop; }
+      ctx->vp_last_cfg = *cfg; ctx->vp_last_valid = true;
       { Timed t(ctx, 1); hipLaunchKernelGGL(k_visual_update_persistent, dim3(G), dim3(VP_BLOCK), 0, ctx->stream, p, ctx->d_ctl); t.done(); }
       const hipError_t le = hipGetLastError();
       persist_register(ctx, le == hipSuccess ? G : 0);            // a failed launch gives its reservation back
@@ -2840,7 +2864,7 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
     HIPCHK(hipMemsetAsync(&ctx->d_ctl->hdr.pad[0], 0, 4, ctx->stream));
     const livo2_state in = ctx->vp_last_in, pr = ctx->vp_last_prop; const livo2_visual_cfg vc = ctx->vp_last_cfg;
     ctx->vp_rerun = true;
-    const int rc = visual_enqueue(ctx, &in, &pr, &vc, vc.patch_pyrimid_level - 1, 0, vc.max_iterations, 1);
+    const int rc = visual_enqueue(ctx, ctx->vp_last_chained ? nullptr : &in, ctx->vp_last_chained ? nullptr : &pr, &vc, vc.patch_pyrimid_level - 1, 0, vc.max_iterations, 1);
     ctx->vp_rerun = false;
     if (rc) return rc;
     HIPCHK(devalloc::memcpy_async(ctx->h_out, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
@@ -2856,6 +2880,128 @@ int livo2_visual_update(livo2_ctx *ctx, const livo2_state *state_in, const livo2
                         float *errors) {
   int rc = livo2_visual_update_async(ctx, state_in, prop, cfg); if (rc) return rc;
   return livo2_visual_update_fetch(ctx, result, errors);
+}
+
+// ---- one LIO + VIO frame per call -------------------------------------------------------------------------------------------------------------------
+namespace {
+struct FrameRes { livo2_lidar_result lidar; livo2_visual_result visual; int32_t timed_out, pad; };
+}
+int livo2_frame_update_async(livo2_ctx *ctx, const livo2_frame_in *f) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!f || !f->prior || !f->lidar_cfg || !f->visual_cfg) return fail(ctx, LIVO2_ERR_INVALID, "frame / prior / cfg is NULL");
+  if (ctx->frame_inflight >= 2) return fail(ctx, LIVO2_ERR_INVALID, "two frames are in flight: livo2_frame_update_fetch first");
+  int rc = check_visual_cfg(ctx, f->visual_cfg); if (rc) return rc;
+  const int M = f->M, L = f->L;
+  if (!f->img || f->width <= 0 || f->height <= 0 || f->stride < f->width) return fail(ctx, LIVO2_ERR_INVALID, "bad image");
+  if (M < 0 || L < 1 || L > LIVO2_MAX_LEVELS || (M > 0 && (!f->pos || !f->warp_patch || !f->search_levels || !f->inv_expo_list))) return fail(ctx, LIVO2_ERR_INVALID, "bad sub-map arrays");
+  if (L != f->visual_cfg->patch_pyrimid_level) return fail(ctx, LIVO2_ERR_INVALID, "warp_patch holds L levels per patch: L must equal visual_cfg->patch_pyrimid_level");
+  for (int i = 0; i < M; i++) if (f->search_levels[i] < 0 || f->search_levels[i] > 8) return fail(ctx, LIVO2_ERR_RANGE, "search_level out of [0,8]");
+  // ---- LIO: scan up, StateEstimation from the prior (both asynchronous)
+  rc = livo2_lidar_set_scan(ctx, f->xyz, f->n_points, f->lidar_cfg); if (rc) return rc;
+  rc = lidar_ready(ctx, f->prior, f->prior, f->lidar_cfg); if (rc) return rc;
+  rc = ensure_lidar_outputs(ctx, nullptr); if (rc) return rc;
+  rc = lidar_enqueue(ctx, f->prior, f->prior, f->lidar_cfg, f->lidar_cfg->max_iterations, 1); if (rc) return rc;
+  // ---- the frame: image + sub-map through a pinned staging block (the caller's arrays are free on return; device buffers grow only between frames in flight)
+  const size_t img_bytes = (size_t)f->stride * f->height;
+  const size_t o_pos = (img_bytes + 15) & ~(size_t)15, o_warp = o_pos + (((size_t)M * 24 + 15) & ~(size_t)15), o_sl = o_warp + (((size_t)M * L * 256 + 15) & ~(size_t)15),
+               o_ie = o_sl + (((size_t)M * 4 + 15) & ~(size_t)15), total = o_ie + (size_t)M * 8;
+  const bool grow = img_bytes > ctx->img_cap || M > ctx->M_cap || (size_t)M * L * 64 > ctx->warp_cap;
+  if (grow) HIPCHK(hipStreamSynchronize(ctx->stream));                              // buffers of a frame still in flight are about to be re-allocated
+  rc = ensure(ctx, ctx->d_img, ctx->img_cap, img_bytes); if (rc) return rc;
+  if (M > ctx->M_cap) {
+    hipError_t e;
+    if (ctx->d_pos) { e = DFREE(ctx->d_pos); e = DFREE(ctx->d_invexpo); e = DFREE(ctx->d_search); e = DFREE(ctx->d_errors); (void)e; }
+    const int cap = std::max(M, 512);
+    HIPCHK(DMALLOC((void **)&ctx->d_pos, (size_t)cap * 24)); HIPCHK(DMALLOC((void **)&ctx->d_invexpo, (size_t)cap * 8));
+    HIPCHK(DMALLOC((void **)&ctx->d_search, (size_t)cap * 4)); HIPCHK(DMALLOC((void **)&ctx->d_errors, (size_t)cap * 4));
+    ctx->M_cap = cap;
+  }
+  rc = ensure(ctx, ctx->d_warp, ctx->warp_cap, std::max((size_t)M * L * 64, (size_t)64)); if (rc) return rc;
+  {
+    const int vgrid = visual_grid_inverse(std::max(M, 1));
+    const size_t need = std::max(std::max((size_t)vgrid * VIS_PSTRIDE, (size_t)64), (size_t)lidar_grid(std::max(ctx->n, 1), ctx->lidar_block) * 32);      // d_partials serves both updates of the frame
+    if (need > ctx->partials_cap) { HIPCHK(hipStreamSynchronize(ctx->stream)); rc = ensure(ctx, ctx->d_partials, ctx->partials_cap, need); if (rc) return rc; }
+  }
+  const int k = ctx->frame_stage_next; ctx->frame_stage_next ^= 1;
+  if (ctx->frame_stage_used[k]) HIPCHK(hipEventSynchronize(ctx->frame_stage_ev[k]));
+  if (total > ctx->frame_stage_cap[k]) {
+    if (ctx->frame_stage[k]) HIPCHK(hipHostFree(ctx->frame_stage[k]));
+    ctx->frame_stage[k] = nullptr; ctx->frame_stage_cap[k] = 0;
+    HIPCHK(hipHostMalloc(&ctx->frame_stage[k], 2 * total));
+    ctx->frame_stage_cap[k] = 2 * total;
+  }
+  if (!ctx->frame_stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->frame_stage_ev[k], hipEventDisableTiming));
+  char *h = (char *)ctx->frame_stage[k];
+  std::memcpy(h, f->img, img_bytes);
+  if (M > 0) {
+    std::memcpy(h + o_pos, f->pos, (size_t)M * 24); std::memcpy(h + o_warp, f->warp_patch, (size_t)M * L * 256);
+    std::memcpy(h + o_sl, f->search_levels, (size_t)M * 4); std::memcpy(h + o_ie, f->inv_expo_list, (size_t)M * 8);
+  }
+  HIPCHK(devalloc::memcpy_async(ctx->d_img, h, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (M > 0) {
+    HIPCHK(devalloc::memcpy_async(ctx->d_pos, h + o_pos, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_warp, h + o_warp, (size_t)M * L * 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_search, h + o_sl, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(devalloc::memcpy_async(ctx->d_invexpo, h + o_ie, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipEventRecord(ctx->frame_stage_ev[k], ctx->stream)); ctx->frame_stage_used[k] = true;
+  ctx->width = f->width; ctx->height = f->height; ctx->stride = f->stride; ctx->M = M; ctx->L = L;
+  ctx->has_frame = true; ctx->has_ref = false;
+  // ---- VIO on the shared state: iterate = prior = the LiDAR posterior, handed over on the device
+  if (M == 0) {                 // total_points == 0: computeJacobianAndUpdateEKF returns immediately (vio.cpp:786)
+    hipLaunchKernelGGL(k_ctl_chain_visual, dim3(1), dim3(256), 0, ctx->stream, ctx->d_ctl);
+    VisualKernelArgs a = make_visual_args(ctx, f->visual_cfg, 0);
+    hipLaunchKernelGGL(k_visual_finish, dim3(1), dim3(LIVO2_WAVE), 0, ctx->stream, ctx->d_ctl, a, 0);
+    HIPCHK(hipGetLastError());
+  } else {
+    rc = visual_enqueue(ctx, nullptr, nullptr, f->visual_cfg, f->visual_cfg->patch_pyrimid_level - 1, 0, f->visual_cfg->max_iterations, 1); if (rc) return rc;
+  }
+  // ---- both result blocks + the watchdog flag into this frame's pinned slot
+  if (!ctx->h_frame_res) HIPCHK(hipHostMalloc(&ctx->h_frame_res, 2 * sizeof(FrameRes)));
+  const int slot = (ctx->frame_head + ctx->frame_inflight) & 1;
+  FrameRes *r = (FrameRes *)ctx->h_frame_res + slot;
+  if (!ctx->frame_res_ev[slot]) HIPCHK(hipEventCreateWithFlags(&ctx->frame_res_ev[slot], hipEventDisableTiming));
+  HIPCHK(devalloc::memcpy_async(&r->lidar, &ctx->d_ctl->lidar, sizeof(livo2_lidar_result), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&r->visual, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(devalloc::memcpy_async(&r->timed_out, &ctx->d_ctl->hdr.pad[0], 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->frame_res_ev[slot], ctx->stream));
+  ctx->frame_inflight++;
+  return LIVO2_OK;
+}
+
+int livo2_frame_update_fetch(livo2_ctx *ctx, livo2_lidar_result *lidar, livo2_visual_result *visual) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (!lidar || !visual) return fail(ctx, LIVO2_ERR_INVALID, "result is NULL");
+  if (ctx->frame_inflight < 1) return fail(ctx, LIVO2_ERR_INVALID, "no frame in flight");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int slot = ctx->frame_head;
+  FrameRes *r = (FrameRes *)ctx->h_frame_res + slot;
+  HIPCHK(hipEventSynchronize(ctx->frame_res_ev[slot]));
+  ctx->frame_head ^= 1; ctx->frame_inflight--;
+  if (r->timed_out) {
+    // the resident visual grid of this frame gave up and committed nothing.  With a second frame already in flight its inputs on the device are gone: the caller
+    // gets an error for THIS frame (the next one is unaffected); alone in flight, the update is re-run per step from the LiDAR posterior still in the result block
+    ctx->vp_timeouts++;
+    ctx->vp_backoff_len = ctx->vp_backoff_len ? std::min(2 * ctx->vp_backoff_len, 1024) : 8;
+    ctx->vp_backoff_left = ctx->vp_debug_timeout ? 0 : ctx->vp_backoff_len;
+    if (ctx->frame_inflight > 0) return fail(ctx, LIVO2_ERR_HIP, "the resident visual grid of this frame timed out while the next frame was already enqueued: re-submit the frame");
+    HIPCHK(hipMemsetAsync(&ctx->d_ctl->hdr.pad[0], 0, 4, ctx->stream));
+    const livo2_visual_cfg vc = ctx->vp_last_cfg;
+    ctx->vp_rerun = true;
+    const int rc = visual_enqueue(ctx, nullptr, nullptr, &vc, vc.patch_pyrimid_level - 1, 0, vc.max_iterations, 1);
+    ctx->vp_rerun = false;
+    if (rc) return rc;
+    HIPCHK(devalloc::memcpy_async(&r->visual, &ctx->d_ctl->visual, sizeof(livo2_visual_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else if (ctx->vp_backoff_left == 0) ctx->vp_backoff_len = 0;
+  std::memcpy(lidar, &r->lidar, sizeof(livo2_lidar_result));
+  std::memcpy(visual, &r->visual, sizeof(livo2_visual_result));
+  return rz_gate(ctx);
+}
+
+int livo2_frame_update(livo2_ctx *ctx, const livo2_frame_in *frame, livo2_lidar_result *lidar, livo2_visual_result *visual) {
+  int rc = livo2_frame_update_async(ctx, frame); if (rc) return rc;
+  return livo2_frame_update_fetch(ctx, lidar, visual);
 }
 
 int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg,

@@ -72,14 +72,105 @@ def run_frame(ctx, State, frame, cfg, vcfg):
     return pack_result(lres, vres), int(lres.n_iters) * len(frame["xyz"]) + int(vres.n_steps) * 64 * len(vs.pos)
 
 
-def run_frames_sharded(ctx, State, frames, cfg, vcfg, rank, world):
+def prepare_frames(ctx, State, frames, cfg, vcfg, indices=None):
+    """the livo2_frame_in structs of the frames (pointers into the caller's arrays) + result blocks, built ahead of a timed loop: in the reference's C++ this is
+    a handful of pointer assignments per frame; in Python it is numpy / ctypes bookkeeping that has nothing to do with the library"""
+    import ctypes as C
+    from . import LidarResult, VisualResult
+    idx = list(range(len(frames))) if indices is None else list(indices)
+    prep = []
+    for f in idx:
+        fr = frames[f]; vs = fr["vs"]
+        prior = State.from_pose(fr["R_prior"], fr["t_prior"], fr["P"], inv_expo=getattr(vs, "tau_prior", 1.0))
+        fin, keep, M, L = ctx._frame_in(fr["xyz"], prior, cfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg)
+        prep.append((f, fin, keep, LidarResult(), VisualResult()))
+    return prep
+
+
+def run_prepared(ctx, frames, prep):
+    """two frames in flight on one context over prepared frames; returns (records, evaluations) like run_frames_pipelined"""
+    import ctypes as C
+    lib, h = ctx.lib, ctx.h
+    pending = []
+    for k, (f, fin, keep, lres, vres) in enumerate(prep):
+        ctx._chk(lib.livo2_frame_update_async(h, C.byref(fin)))
+        pending.append(k)
+        if len(pending) == 2:
+            j = pending.pop(0)
+            ctx._chk(lib.livo2_frame_update_fetch(h, C.byref(prep[j][3]), C.byref(prep[j][4])))
+    for j in pending:
+        ctx._chk(lib.livo2_frame_update_fetch(h, C.byref(prep[j][3]), C.byref(prep[j][4])))
+    recs = np.zeros((len(prep), RESULT_DOUBLES))
+    evals = 0
+    for k, (f, fin, keep, lres, vres) in enumerate(prep):
+        recs[k] = pack_result(lres, vres)
+        evals += int(lres.n_iters) * len(frames[f]["xyz"]) + int(vres.n_steps) * 64 * len(frames[f]["vs"].pos)
+    return recs, evals
+
+
+def run_frames_pipelined(ctx, State, frames, cfg, vcfg, indices=None):
+    """The same frames through livo2_frame_update_async / _fetch on ONE context, two frames in flight: frame k + 1 is enqueued (scan and image staged, every launch of
+    both updates queued behind frame k's on the stream) before frame k's results are fetched, so the host's work for one frame hides behind the GPU's work for the
+    other; the visual update takes the LiDAR posterior on the device.  Records identical to run_frame's (tests/test_c5_gpu.py)."""
+    idx = list(range(len(frames))) if indices is None else list(indices)
+    recs = np.zeros((len(idx), RESULT_DOUBLES))
+    evals, pending = 0, []
+
+    def enqueue(f):
+        fr = frames[f]; vs = fr["vs"]
+        prior = State.from_pose(fr["R_prior"], fr["t_prior"], fr["P"], inv_expo=getattr(vs, "tau_prior", 1.0))
+        ctx.frame_update_async(fr["xyz"], prior, cfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg)
+        return prior                                                   # (kept alive until the fetch)
+
+    def fetch(k, f):
+        nonlocal evals
+        lres, vres = ctx.frame_update_fetch()
+        recs[k] = pack_result(lres, vres)
+        evals += int(lres.n_iters) * len(frames[f]["xyz"]) + int(vres.n_steps) * 64 * len(frames[f]["vs"].pos)
+    for k, f in enumerate(idx):
+        pending.append((k, f, enqueue(f)))
+        if len(pending) == 2:
+            kk, ff, _ = pending.pop(0)
+            fetch(kk, ff)
+    for kk, ff, _ in pending:
+        fetch(kk, ff)
+    return recs, evals
+
+
+def run_prepared_sharded(ctxs, frames, preps):
+    """preps[j] = prepare_frames(ctxs[j], ..., share j of the rank's frames): every context pipelines its share from its own host thread.  Returns per context (records, evaluations)."""
+    import threading
+    out, errors = [None] * len(ctxs), []
+
+    def work(j):
+        try:
+            out[j] = run_prepared(ctxs[j], frames, preps[j])
+        except BaseException as exc:
+            errors.append(exc)
+    if len(ctxs) == 1:
+        work(0)
+    else:
+        th = [threading.Thread(target=work, args=(j,)) for j in range(len(ctxs))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def run_frames_sharded(ctx, State, frames, cfg, vcfg, rank, world, frame_api=False):
     """rank's share (frames rank, rank + world, ...) in order; returns (records [n_local, RESULT_DOUBLES], residual evaluations done).
     `ctx` may be a list of K contexts of the rank's GPU (each with the map resident): frame k of the share then runs on context k % K from its own host thread, so
     that the H2D of one frame, the updates of another and the D2H of a third overlap on the contexts' streams (the C ABI calls release the GIL).  The records do
-    not depend on K: a context's results depend on its inputs only."""
+    not depend on K: a context's results depend on its inputs only.  frame_api: every frame is ONE library call (livo2_frame_update_async / _fetch, two frames in
+    flight per context) instead of the four calls of run_frame — same records."""
     mine = frames_for_rank(len(frames), rank, world)
     recs = np.zeros((len(mine), RESULT_DOUBLES))
     ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+    if frame_api and (len(ctxs) == 1 or len(mine) < 2):
+        return run_frames_pipelined(ctxs[0], State, frames, cfg, vcfg, mine)
     if len(ctxs) == 1 or len(mine) < 2:
         evals = 0
         for k, f in enumerate(mine):
@@ -92,6 +183,11 @@ def run_frames_sharded(ctx, State, frames, cfg, vcfg, rank, world):
 
     def work(j):
         try:
+            if frame_api:                                                  # each context pipelines its own share, two frames in flight
+                ks = list(range(j, len(mine), K))
+                r, evals[j] = run_frames_pipelined(ctxs[j], State, frames, cfg, vcfg, [mine[k] for k in ks])
+                recs[ks] = r
+                return
             for k in range(j, len(mine), K):
                 recs[k], e = run_frame(ctxs[j], State, frames[mine[k]], cfg, vcfg)
                 evals[j] += e

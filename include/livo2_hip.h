@@ -583,6 +583,32 @@ int livo2_visual_update_fetch(livo2_ctx *ctx, livo2_visual_result *result, float
 int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_state *state_in, const livo2_state *prop,
                                   const livo2_visual_cfg *cfg, int32_t iters);
 
+/* ---- one LIO + VIO frame as ONE call (round 5) ------------------------------------------------------------------------------------------------------
+ * LIVMapper::handleLIO + handleVIO for a frame whose visual sub-map is known (reference src/LIVMapper.cpp:336-482, 281-334): scan upload + per-scan precompute
+ * (livo2_lidar_set_scan), StateEstimation from `prior` (state_ = state_propagat = prior, LIVMapper.cpp:256-257, 370), image + sub-map upload
+ * (livo2_visual_set_frame), computeJacobianAndUpdateEKF on the SHARED state — `state` and `state_propagat` are the LiDAR posterior (LIVMapper.cpp:135-136, 256,
+ * 371), handed over ON THE DEVICE — and both result blocks back in one copy.  Same kernels, same bits as the four separate calls (tests/test_c5_gpu.py); what it
+ * saves is host work: one library call, one stream synchronisation and no host round trip of the state per frame instead of six calls, four synchronisations and a
+ * D2H + H2D of the posterior — a 10 k-point frame is ~0.3 ms of kernels and was bound by exactly that (missing 5).
+ * _async only enqueues (the caller's arrays are free on return: everything is staged through pinned blocks of the ctx); up to two frames may be in flight per ctx:
+ * _fetch returns them in order.  A third _async without a _fetch fails with LIVO2_ERR_INVALID.  The map must be resident (livo2_map_upload / livo2_map_tree_*). */
+typedef struct livo2_frame_in {
+  const float *xyz;             /* [n_points][3] down-sampled body-frame scan */
+  int32_t n_points, M, L, width, height, stride;
+  const livo2_state *prior;
+  const livo2_lidar_cfg *lidar_cfg;
+  const livo2_visual_cfg *visual_cfg;
+  const uint8_t *img;           /* [height][stride] */
+  const double *pos;            /* the visual sub-map, as livo2_visual_set_frame takes it */
+  const float *warp_patch;
+  const int32_t *search_levels;
+  const double *inv_expo_list;
+} livo2_frame_in;
+int livo2_frame_update_async(livo2_ctx *ctx, const livo2_frame_in *frame);
+int livo2_frame_update_fetch(livo2_ctx *ctx, livo2_lidar_result *lidar, livo2_visual_result *visual);
+int livo2_frame_update(livo2_ctx *ctx, const livo2_frame_in *frame, livo2_lidar_result *lidar, livo2_visual_result *visual);
+
+
 /* ---- batch of frames, visual (offline / replay: BASELINE config "batched frames") ------------------------------------------------------
  * n_frames independent VIOManager::computeJacobianAndUpdateEKF problems (src/vio.cpp:784-802; call site vio.cpp:1810) — each with its own gray image,
  * visual sub-map (SubSparseMap arrays as in livo2_visual_set_frame), *state and *state_propagat — advanced in lockstep: every (level, iteration) is ONE residual

@@ -84,6 +84,9 @@ def test_c5_frames_one_and_three_contexts_match_the_oracle(livo2, orc, shape):
         r0, _ = frames_mod.run_frames_sharded(ctxs[:2], livo2.State, seq, cfg, vcfg, 0, 2)
         r1, _ = frames_mod.run_frames_sharded(ctxs[2], livo2.State, seq, cfg, vcfg, 1, 2)
         assert sum(c.counter("visual_persistent_launches") for c in ctxs) > 0          # the resident-grid form ran next to the other contexts' kernels
+        # the whole frame as ONE call (livo2_frame_update_async / _fetch), two frames in flight on one context, the LiDAR posterior handed to the visual update on the device
+        piped, evp = frames_mod.run_frames_pipelined(ctxs[1], livo2.State, seq, cfg, vcfg)
+        twice, _ = frames_mod.run_frames_pipelined(ctxs[1], livo2.State, seq + seq, cfg, vcfg)
     finally:
         for c in ctxs:
             c.close()
@@ -92,3 +95,38 @@ def test_c5_frames_one_and_three_contexts_match_the_oracle(livo2, orc, shape):
     assert np.array_equal(one, three) and ev1 == ev3                                  # a context's results depend on its inputs only
     sharded = np.zeros_like(one); sharded[0::2] = r0; sharded[1::2] = r1
     assert np.array_equal(sharded, one)
+    assert np.array_equal(piped, one) and evp == ev1                                   # same kernels, same bits: only host work was removed
+    assert np.array_equal(twice[: len(seq)], one) and np.array_equal(twice[len(seq):], one)
+
+
+def test_frame_update_argument_errors_and_empty_submap(livo2, orc):
+    frames_mod = importlib.import_module("fast-livo2_amd.frames")
+    cfgs = importlib.import_module("fast-livo2_amd.configs")
+    fmap, lio_cfg, extR, extT, seq = synth.frame_sequence(2)
+    cfg = cfgs.lidar_cfg(_Sc(lio_cfg, extR, extT)); vcfg = cfgs.visual_cfg(seq[0]["vs"], mp_proc_num=4)
+    c = livo2.Context(0)
+    try:
+        fr = seq[0]; vs = fr["vs"]
+        prior = livo2.State.from_pose(fr["R_prior"], fr["t_prior"], fr["P"], inv_expo=vs.tau_prior)
+        args = (fr["xyz"], prior, cfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg)
+        with pytest.raises(livo2.Livo2Error) as e:
+            c.frame_update(*args)                                                   # no map
+        assert e.value.code == livo2.abi.ERR_NO_MAP
+        c.upload_map(fmap)
+        with pytest.raises(livo2.Livo2Error) as e:
+            c.frame_update_fetch()                                                  # nothing in flight
+        assert e.value.code == livo2.abi.ERR_INVALID
+        c.frame_update_async(*args); c.frame_update_async(*args)
+        with pytest.raises(livo2.Livo2Error) as e:
+            c.frame_update_async(*args)                                             # a third frame without a fetch
+        assert e.value.code == livo2.abi.ERR_INVALID
+        a, b = c.frame_update_fetch(), c.frame_update_fetch()
+        assert bytes(a[0].state) == bytes(b[0].state) and bytes(a[1].state) == bytes(b[1].state)
+        # the four separate calls give the same bits
+        rec, _ = frames_mod.run_frame(c, livo2.State, fr, cfg, vcfg)
+        assert np.array_equal(rec, frames_mod.pack_result(*a))
+        # an empty sub-map: computeJacobianAndUpdateEKF returns at once (vio.cpp:786), the visual result is the LiDAR posterior
+        l0, v0 = c.frame_update(fr["xyz"], prior, cfg, vs.img, vs.pos[:0], vs.warp_patch[:0], vs.search_levels[:0], vs.inv_expo_list[:0], vcfg)
+        assert v0.n_steps == 0 and bytes(v0.state) == bytes(l0.state) and bytes(l0.state) == bytes(a[0].state)
+    finally:
+        c.close()

@@ -68,7 +68,7 @@ def headline_legs(ctx, livo2, synth, H, w, args, torch, copy_gbs):
     if "chains" in legs:
         _chains_leg(ctx, livo2, w, extra)
     if "chain" in legs or "live" in legs:                   # (the C4-sized chain: 6 frames of 200 000 points + 120 000 visual points to generate on the host first — only with --full / --legs live_c4)
-        _live_chain_leg(extra, ("avia", "c4") if (getattr(args, "full", False) or "live_c4" in legs) else ("avia",))
+        _live_chain_leg(extra, ("avia", "avia_grow", "c4") if (getattr(args, "full", False) or "live_c4" in legs) else ("avia", "avia_grow"))
     if "live" in legs:
         _live_leg(ctx, w, extra)
     if legs & {"c2", "c3", "batched", "ooc"}:
@@ -194,6 +194,13 @@ def _live_chain_leg(extra, sizes=("avia", "c4")):
                 r = subprocess.run([exe, d] + (["lean"] if mode == "lean" else []), capture_output=True, text=True, timeout=600)
                 m = re.search(r"live_chain[^:]*: (\d+) frames timed, ([\d.]+) ms per frame \(StateEstimation ([\d.]+), UpdateVoxelMapFromPosterior ([\d.]+), retrieveFromVisualSparseMap ([\d.]+), "
                               r"computeJacobianAndUpdateEKF ([\d.]+)\); mean scan ([\d.]+) points, effct_feat_num_ ([\d.]+), sub-map ([\d.]+) patches; syncFeatMap ([\d.]+) ms", r.stdout)
+                g = re.search(r"live_chain[^:]*grow: (\d+) frames timed, ([\d.]+) ms per frame \(syncFeatMap ([\d.]+) \[incremental: (\d+) delta syncs, (\d+) full\], StateEstimation ([\d.]+), "
+                              r"UpdateVoxelMapFromPosterior ([\d.]+), retrieveFromVisualSparseMap ([\d.]+), computeJacobianAndUpdateEKF ([\d.]+)\); visual map (\d+) points / (\d+) observations", r.stdout)
+                if r.returncode == 0 and g:                              # growing-map mode: the mirror's sync is a stage of the frame
+                    res[mode] = {"frames_timed": int(g.group(1)), "ms_per_frame": float(g.group(2)), "syncFeatMap_ms": float(g.group(3)), "delta_syncs": int(g.group(4)), "full_syncs": int(g.group(5)),
+                                 "StateEstimation_ms": float(g.group(6)), "UpdateVoxelMapFromPosterior_ms": float(g.group(7)), "retrieveFromVisualSparseMap_ms": float(g.group(8)),
+                                 "computeJacobianAndUpdateEKF_ms": float(g.group(9)), "visual_map_points": int(g.group(10)), "visual_map_observations": int(g.group(11))}
+                    continue
                 if r.returncode != 0 or not m:
                     res[mode] = {"error": (r.stderr or r.stdout)[-300:]}
                     continue
@@ -208,7 +215,10 @@ def _live_chain_leg(extra, sizes=("avia", "c4")):
                   "ctx's pinned buffer); 'full': StateEstimation also fills pv_list_ / ptpl_list_ / body_cov_list_ / cross_mat_list_ on the host (168 B per point D2H + ~900 B per point of "
                   "reference structs) as the reference does; 'lean' (VoxelMapManager::host_point_lists_ = false): those lists stay on the device, where their consumers run in "
                   "device_map_ mode; the first two frames (allocations, pinned buffers, the first update of the freshly built tree) not timed, per-stage medians over the others (a frame in which a pool of the device tree grows is an outlier); "
-                  "cpu_baseline.live_chain has the oracle's time for the same sequence")
+                  "cpu_baseline.live_chain has the oracle's time for the same sequence.  'avia_grow': ONE visual map of 30 000 points that a scripted stand-in for the reference's map "
+                  "maintenance changes after every frame (<= 100 new points, ~100 obs_ lists get a new front observation, deletions, ref_patch / normal changes, one new reference image: "
+                  "scenarios/visual_map_growth.py); syncFeatMap applies O(changes) deltas (livo2_visual_map_apply) and is a stage of the frame (syncFeatMap_ms), against "
+                  "syncFeatMap_ms_outside_the_stages of the re-flatten + re-upload that 'avia' pays per frame")
     extra["live_chain"] = out
 
 
