@@ -549,10 +549,17 @@ class Context:
         self._chk(self.lib.livo2_frame_update_async(self.h, C.byref(f)))
         self.n, self.M, self.L = len(keep[0]), M, L
 
-    def frame_update_fetch(self):
-        lres, vres = LidarResult(), VisualResult()
+    def frame_enqueue(self, fin):
+        """livo2_frame_update_async on a prepared livo2_frame_in (_frame_in): what a timed loop calls"""
+        self._chk(self.lib.livo2_frame_update_async(self.h, C.byref(fin)))
+
+    def frame_update_fetch(self, into=None):
+        lres, vres = into if into is not None else (LidarResult(), VisualResult())
         self._chk(self.lib.livo2_frame_update_fetch(self.h, C.byref(lres), C.byref(vres)))
         return lres, vres
+
+    def new_frame_results(self):
+        return LidarResult(), VisualResult()
 
     def frame_update(self, *a):
         self.frame_update_async(*a)

@@ -27,6 +27,11 @@ constexpr uint32_t RZ_WORD = 0xCBCBCBCBu;
 
 struct Rec { void *base; size_t bytes; size_t mapped; int line; int mode; hipMemGenericAllocationHandle_t handle; size_t reserved; };
 
+inline const char *src_part(int tagged_line) {                   // LIVO2_HERE = part * 100000 + line
+  static const char *names[] = {"livo2_api.hip", "api_map.inc", "api_imu.inc", "api_map_tree.inc", "api_lidar.inc", "api_retrieve.inc", "api_visual.inc"};
+  const int k = tagged_line / 100000;
+  return (k >= 0 && k < 7) ? names[k] : "?";
+}
 inline int mode() {
   static const int m = [] { const char *e = std::getenv("LIVO2_REDZONE"); return e ? std::atoi(e) : 0; }();
   return m;
@@ -38,7 +43,7 @@ inline std::vector<Freed> &graveyard() { static std::vector<Freed> g; return g; 
 
 inline void dump_table(FILE *f) {
   // (called from the abort handler too: no locking, plain stdio — a debugging aid, not a service)
-  fprintf(f, "livo2 device allocations (LIVO2_REDZONE=%d): user pointer .. end, bytes, source line of livo2_api.hip\n", mode());
+  fprintf(f, "livo2 device allocations (LIVO2_REDZONE=%d): user pointer .. end, bytes, source line (part * 100000 + line; parts: 0 livo2_api.hip, 1 api_map.inc, 2 api_imu.inc, 3 api_map_tree.inc, 4 api_lidar.inc, 5 api_retrieve.inc, 6 api_visual.inc)\n", mode());
   for (auto &kv : table())
     fprintf(f, "  %p .. %p  %zu B  line %d\n", kv.first, (void *)((char *)kv.first + kv.second.bytes), kv.second.bytes, kv.second.line);
   fprintf(f, "freed allocations (oldest first; an address inside one of them is a use after free):\n");
@@ -203,12 +208,12 @@ inline long long check(char *msg, size_t msg_len) {
   const long long bad = (long long)out.bad_words + tail_bad;
   if (bad && msg && msg_len) {
     if (tail_id >= 0)
-      snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B BEHIND its end", recs[tail_id].bytes, recs[tail_id].line, tail_off);
+      snprintf(msg, msg_len, "redzone: allocation of %zu B made at %s:%d was written %lld B BEHIND its end", recs[tail_id].bytes, src_part(recs[tail_id].line), recs[tail_id].line % 100000, tail_off);
     else if (out.first_id >= 0) {
       const Rec &r = recs[out.first_id];
-      if (out.first_side == 0) snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld B IN FRONT of its start (%llu damaged words in all)",
-                                        r.bytes, r.line, (long long)RZ_GUARD - out.first_byte, out.bad_words);
-      else snprintf(msg, msg_len, "redzone: allocation of %zu B made at livo2_api.hip:%d was written %lld .. %lld B BEHIND its end (%llu damaged words in all; first words %08x %08x %08x %08x %08x %08x)", r.bytes, r.line,
+      if (out.first_side == 0) snprintf(msg, msg_len, "redzone: allocation of %zu B made at %s:%d was written %lld B IN FRONT of its start (%llu damaged words in all)",
+                                        r.bytes, src_part(r.line), r.line % 100000, (long long)RZ_GUARD - out.first_byte, out.bad_words);
+      else snprintf(msg, msg_len, "redzone: allocation of %zu B made at %s:%d was written %lld .. %lld B BEHIND its end (%llu damaged words in all; first words %08x %08x %08x %08x %08x %08x)", r.bytes, src_part(r.line), r.line % 100000,
                     (long long)(r.mapped - 2 * RZ_GUARD - r.bytes) + out.first_byte, (long long)(r.mapped - 2 * RZ_GUARD - r.bytes) + out.last_byte, out.bad_words,
                     out.sample[0], out.sample[1], out.sample[2], out.sample[3], out.sample[4], out.sample[5]);
     }
@@ -228,6 +233,11 @@ inline hipError_t memcpy_async(void *dst, const void *src, size_t bytes, hipMemc
 
 }  // namespace devalloc
 
-#define DMALLOC(pp, bytes) devalloc::dev_malloc((void **)(pp), (bytes), __LINE__)
+// The library is ONE translation unit in several files (livo2_api.hip + api_*.inc): an allocation is named by part * 100000 + line.  Every part sets LIVO2_SRC_ID.
+#ifndef LIVO2_SRC_ID
+#define LIVO2_SRC_ID 0
+#endif
+#define LIVO2_HERE (LIVO2_SRC_ID * 100000 + __LINE__)
+#define DMALLOC(pp, bytes) devalloc::dev_malloc((void **)(pp), (bytes), LIVO2_HERE)
 #define DMALLOC_AT(line, pp, bytes) devalloc::dev_malloc((void **)(pp), (bytes), (line))
 #define DFREE(p) devalloc::dev_free((void *)(p))

@@ -75,31 +75,27 @@ def run_frame(ctx, State, frame, cfg, vcfg):
 def prepare_frames(ctx, State, frames, cfg, vcfg, indices=None):
     """the livo2_frame_in structs of the frames (pointers into the caller's arrays) + result blocks, built ahead of a timed loop: in the reference's C++ this is
     a handful of pointer assignments per frame; in Python it is numpy / ctypes bookkeeping that has nothing to do with the library"""
-    import ctypes as C
-    from . import LidarResult, VisualResult
     idx = list(range(len(frames))) if indices is None else list(indices)
     prep = []
     for f in idx:
         fr = frames[f]; vs = fr["vs"]
         prior = State.from_pose(fr["R_prior"], fr["t_prior"], fr["P"], inv_expo=getattr(vs, "tau_prior", 1.0))
         fin, keep, M, L = ctx._frame_in(fr["xyz"], prior, cfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg)
-        prep.append((f, fin, keep, LidarResult(), VisualResult()))
+        prep.append([f, fin, keep] + list(ctx.new_frame_results()))
     return prep
 
 
 def run_prepared(ctx, frames, prep):
     """two frames in flight on one context over prepared frames; returns (records, evaluations) like run_frames_pipelined"""
-    import ctypes as C
-    lib, h = ctx.lib, ctx.h
     pending = []
     for k, (f, fin, keep, lres, vres) in enumerate(prep):
-        ctx._chk(lib.livo2_frame_update_async(h, C.byref(fin)))
+        ctx.frame_enqueue(fin)
         pending.append(k)
         if len(pending) == 2:
             j = pending.pop(0)
-            ctx._chk(lib.livo2_frame_update_fetch(h, C.byref(prep[j][3]), C.byref(prep[j][4])))
+            prep[j][3], prep[j][4] = ctx.frame_update_fetch(into=(prep[j][3], prep[j][4]))
     for j in pending:
-        ctx._chk(lib.livo2_frame_update_fetch(h, C.byref(prep[j][3]), C.byref(prep[j][4])))
+        prep[j][3], prep[j][4] = ctx.frame_update_fetch(into=(prep[j][3], prep[j][4]))
     recs = np.zeros((len(prep), RESULT_DOUBLES))
     evals = 0
     for k, (f, fin, keep, lres, vres) in enumerate(prep):

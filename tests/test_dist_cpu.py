@@ -95,6 +95,29 @@ class _FakeCtx:
     def set_frame(self, img, pos, warp, sl, ie):
         self.m = len(pos)
 
+    # the whole-frame API (livo2_frame_update_async / _fetch): two frames in flight, the visual update chained to the LiDAR posterior
+    def _frame_in(self, xyz, prior, cfg, img, pos, warp, sl, ie, vcfg):
+        return (np.asarray(xyz), prior, len(pos)), None, len(pos), 1
+
+    def new_frame_results(self):
+        return None, None
+
+    def frame_enqueue(self, fin):
+        if not hasattr(self, "_q"):
+            self._q = []
+        assert len(self._q) < 2
+        self._q.append(fin)
+
+    def frame_update_async(self, xyz, prior, cfg, img, pos, warp, sl, ie, vcfg):
+        self.frame_enqueue(self._frame_in(xyz, prior, cfg, img, pos, warp, sl, ie, vcfg)[0])
+
+    def frame_update_fetch(self, into=None):
+        xyz, prior, m = self._q.pop(0)
+        self.xyz, self.m = xyz, m
+        lres, _ = self.lidar_update(prior, prior, None)
+        vres, _ = self.visual_update(lres.state, lres.state, None)
+        return lres, vres
+
     def visual_update(self, prior, prop, cfg):
         v = _Obj(); v.n_steps = 2; v.state = self._state(prior, 1e-3 * self.m)
         v.steps = [_Obj(), _Obj()]; v.steps[0].error = 5.0; v.steps[1].error = 4.0 + self.m
@@ -134,6 +157,9 @@ def test_c5_frames_sharded_and_gathered_world2():
     assert single.shape == (n_frames, frames.RESULT_DOUBLES)
     piped, evk = frames.run_frames_sharded([_FakeCtx() for _ in range(4)], _FakeState, _fake_frames(n_frames), None, None, 0, 1)      # contexts in threads: same records
     assert np.array_equal(piped, single) and evk == ev1
+    for cs in (_FakeCtx(), [_FakeCtx() for _ in range(3)]):                                                                           # one library call per frame, two in flight
+        api, eva = frames.run_frames_sharded(cs, _FakeState, _fake_frames(n_frames), None, None, 0, 1, frame_api=True)
+        assert np.array_equal(api, single) and eva == ev1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -201,5 +227,7 @@ def test_bench_c5_leg_world2(tmp_path):
     assert o["frames"] == 8 and o["frames_per_rank"] == 4 and o["distinct_frames"] == 3
     assert len(o["frames_per_s_per_rank"]) == 2 and len(o["frames_per_s_per_rank_one_context"]) == 2
     assert o["all_gather_ms"] >= 0 and o["frames_per_s"] > 0 and o["frames_per_s_one_context"] > 0
-    assert o["gathered_copy_check"] == {"frames_recomputed_on_rank0": 2, "mismatches": 0, "pipelined_records_equal_one_context_records": True}
+    assert o["gathered_copy_check"] == {"frames_recomputed_on_rank0": 2, "mismatches": 0, "pipelined_records_equal_one_context_records": True,
+                                        "frame_api_records_equal_one_context_records": True}
+    assert o["frames_per_s_frame_api"] > 0 and o["frames_per_s_frame_api_one_context"] > 0 and len(o["frames_per_s_per_rank_frame_api"]) == 2
     assert outs[1]["gathered_copy_check"] is None

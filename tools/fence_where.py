@@ -20,4 +20,4 @@ for mm in re.finditer(r"(freed )?(0x[0-9a-f]+) \.\. (0x[0-9a-f]+)\s+(\d+) B\s+li
 rows.sort()
 print("fault address", hex(addr), "(page-granular);", len(rows), "live + freed allocations")
 for d, side, a, b, n, l in rows[:5]:
-    print(f"  {d:>12} B {side:22} of {hex(a)}..{hex(b)} ({n} B) allocated at livo2_api.hip:{l}")
+    print(f"  {d:>12} B {side:22} of {hex(a)}..{hex(b)} ({n} B) allocated at source part {l // 100000} line {l % 100000} (parts: dev_alloc.hpp src_part)")

@@ -20,7 +20,7 @@ LIB = os.path.join(ROOT, "fast-livo2_amd", "lib", "liblivo2_hip.so")
 
 def csrc_sha():
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "fast-livo2_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "include", "livo2_hip.h")]
+    files = sorted(glob.glob(os.path.join(ROOT, "fast-livo2_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "fast-livo2_amd", "csrc", "*.inc"))) + [os.path.join(ROOT, "include", "livo2_hip.h")]
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
