@@ -19,6 +19,9 @@
 #ifndef LIDAR_BLOCK
 #define LIDAR_BLOCK 256          // threads (= points) per block of a single-scan launch (overridable: tools/block_probe.py)
 #endif
+#ifndef LIDAR_WPE
+#define LIDAR_WPE 2             // waves per SIMD the single-scan kernel is compiled for (experiments: 3 = 168 VGPRs)
+#endif
 #define LIDAR_BLOCK_BATCH 64    // ... of a batched launch: single-wave blocks (17 KB LDS each) keep eight of them in flight per CU and make every barrier of
                                 // the cooperative visit wave-local: 126 us (256) -> 109 us (128) -> 102 us (64) per 16 frames of 91k points
 #define LIDAR_NSUM 29       // 21 (sym HtH) + 6 (Htz) + n_eff + sum|r|
@@ -749,7 +752,7 @@ __device__ __forceinline__ const double *lidar_kernarg_ext() {
 }
 __device__ __forceinline__ const LidarKernelArgs &lidar_kernarg_args() { return *(const LidarKernelArgs *)__builtin_amdgcn_kernarg_segment_ptr(); }
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LIDAR_WPE))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
                                                                 int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost) {
   // One block per chunk, and NO loop around the body: inside a loop every launch-invariant value of the body (kernel arguments, addresses into the control block, the
   // "is this output wanted" conditions) is hoisted in front of it and stays live across the whole body — 145 spilled SGPRs, i.e. ~140 v_writelane at the start of every

@@ -704,8 +704,15 @@ __device__ __forceinline__ void vis_log_lds(SolveLds &s) {           // Log(cur^
 }
 
 typedef unsigned long long vp_word;
+#define VP_ERR_PITCH(M) (((size_t)(M) + 1) & ~(size_t)1)      // words between the two error buffers: even, so that the word pairs of the collect are 16-byte aligned
 __device__ __forceinline__ vp_word vp_ld(const vp_word *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void vp_st(vp_word *p, vp_word v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Both words of a published double in ONE cache-bypassing request (they are adjacent and 16-byte aligned; each 8-byte half is validated by its own tag, so a torn pair is
+// simply re-loaded).  A relaxed agent-scope atomic load lowers to an sc1 load only up to 8 bytes, hence the asm; vp_ld2_land ties the destination registers to the wait.
+typedef unsigned long long vp_word2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void vp_ld2_issue(vp_word2 &v, const vp_word *p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void vp_ld2_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void vp_ld2_land(vp_word2 &v) { asm volatile("" : "+v"(v)); }
 
 // The phases of a step are separate NON-inlined functions: inlined into one loop body the compiler hoists each phase's invariants (addresses, lane predicates,
 // libm constants) above the step loop, where they are live across every other phase — 256 VGPRs + 112 spilled + 194 spilled SGPRs, reloaded in every phase.  A call
@@ -735,7 +742,7 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   const int buf = step_global & 1;
   const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
   vp_word *rows = p.rows + (size_t)buf * R * VIS_PSTRIDE * 2;
-  vp_word *errs = p.errs + (size_t)buf * M;
+  vp_word *errs = p.errs + (size_t)buf * VP_ERR_PITCH(M);
   VPP(0);
   double out_val = 0.0;
   // row r = blockIdx.x * halves + (wave / VIS_WAVES) sums the patch groups r, r + R, ... (a group = VIS_PPB = 16 patches = the row unit of k_visual_residual):
@@ -779,40 +786,93 @@ __device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
   const int buf = step_global & 1;
   const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
   const vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
-  const vp_word *errs = p.errs + (size_t)buf * M;
+  const vp_word *errs = p.errs + (size_t)buf * VP_ERR_PITCH(M);
   const int kidx = tid_c % VIS_PSTRIDE, slice = tid_c / VIS_PSTRIDE;
   const int n_stage = min(VIS_ERR_STAGE, M);
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   double acc = 0.0;
+#ifndef VP_NO_LD2
+  // the per-patch errors in pairs (words 2t, 2t + 1 of every 1 024): half the requests
+  vp_word2 ev2[VIS_ERR_STAGE / 1024];
+  uint32_t eneed = 0, ehave = 0;
+#pragma unroll
+  for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) if (2 * tid_c + 1024 * u < n_stage) eneed |= 1u << u;
+#else
   vp_word ev[VIS_ERR_STAGE / 512];
   uint32_t eneed = 0, ehave = 0;
 #pragma unroll
   for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (tid_c + 512 * u < n_stage) eneed |= 1u << u;
+#endif
   for (int base = 0; base < G; base += 12 * VP_RPT) {          // (same order of additions as k_visual_solve: rows slice, slice + 12, ... per thread)
+#ifndef VP_NO_LD2
+    vp_word2 w2[VP_RPT];
+#define VP_LO(u) w2[u].x
+#define VP_HI(u) w2[u].y
+#else
     vp_word lo[VP_RPT], hi[VP_RPT];
+#define VP_LO(u) lo[u]
+#define VP_HI(u) hi[u]
+#endif
     uint32_t need = 0, have = 0;
 #pragma unroll
     for (int u = 0; u < VP_RPT; u++) if (tid_c < VIS_SOLVE_THREADS && kidx < VIS_NSUM && base + slice + 12 * u < G) need |= 1u << u;      // (entries >= VIS_NSUM of a row are padding: never published, never read)
     while (have != need || ehave != eneed) {
       const uint32_t todo = need & ~have, etodo = eneed & ~ehave;
+#ifndef VP_NO_LD2
+      // unconditional loads (an asm statement cannot be predicated: a branch around each of the 21 costs an exec-mask pair apiece, 44 more spilled SGPRs): an entry this
+      // thread does not need reads the buffer's first word pair, an entry it already has reads the same — unchanged — words again (the buffer of step k is not rewritten
+      // before every block has left step k + 1)
+#pragma unroll
+      for (int u = 0; u < VP_RPT; u++) {
+        const size_t row = (need >> u & 1u) ? (size_t)(base + slice + 12 * u) : 0;
+        vp_ld2_issue(w2[u], rows + (row * VIS_PSTRIDE + ((need >> u & 1u) ? kidx : 0)) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) vp_ld2_issue(ev2[u], errs + ((eneed >> u & 1u) ? 2 * tid_c + 1024 * u : 0));
+      vp_ld2_wait();
+#pragma unroll
+      for (int u = 0; u < VP_RPT; u++)
+        vp_ld2_land(w2[u]);
+#pragma unroll
+      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) vp_ld2_land(ev2[u]);
+#else
 #pragma unroll
       for (int u = 0; u < VP_RPT; u++)
         if (todo >> u & 1u) { const vp_word *src = rows + ((size_t)(base + slice + 12 * u) * VIS_PSTRIDE + kidx) * 2; lo[u] = vp_ld(src); hi[u] = vp_ld(src + 1); }
 #pragma unroll
       for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (etodo >> u & 1u) ev[u] = vp_ld(errs + tid_c + 512 * u);
+#endif
 #pragma unroll
-      for (int u = 0; u < VP_RPT; u++) if ((todo >> u & 1u) && (uint32_t)(lo[u] >> 32) == tag && (uint32_t)(hi[u] >> 32) == tag) have |= 1u << u;
+      for (int u = 0; u < VP_RPT; u++) if ((todo >> u & 1u) && (uint32_t)(VP_LO(u) >> 32) == tag && (uint32_t)(VP_HI(u) >> 32) == tag) have |= 1u << u;
+#ifndef VP_NO_LD2
+#pragma unroll
+      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++)          // (an odd n_stage: the pair's second word is beyond the errors of this step and carries whatever tag)
+        if ((etodo >> u & 1u) && (uint32_t)(ev2[u].x >> 32) == tag && ((uint32_t)(ev2[u].y >> 32) == tag || 2 * tid_c + 1024 * u + 1 >= n_stage)) ehave |= 1u << u;
+#else
 #pragma unroll
       for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if ((etodo >> u & 1u) && (uint32_t)(ev[u] >> 32) == tag) ehave |= 1u << u;
+#endif
       if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } }
     }
 #pragma unroll
-    for (int u = 0; u < VP_RPT; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((lo[u] & 0xffffffffull) | (hi[u] << 32)));
+    for (int u = 0; u < VP_RPT; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((VP_LO(u) & 0xffffffffull) | (VP_HI(u) << 32)));
+#undef VP_LO
+#undef VP_HI
   }
   __syncthreads();                                       // every wave is done with the tiles of phase 1 (they alias the staging below)
   if (tid_c < VIS_SOLVE_THREADS) SL.u.s.scratch[slice * 41 + kidx] = acc;
+#ifndef VP_NO_LD2
+#pragma unroll
+  for (int u = 0; u < VIS_ERR_STAGE / 1024; u++)
+    if (eneed >> u & 1u) {
+      const int i = 2 * tid_c + 1024 * u;
+      SL.u.s.errs[i] = __uint_as_float((uint32_t)ev2[u].x);
+      if (i + 1 < n_stage) SL.u.s.errs[i + 1] = __uint_as_float((uint32_t)ev2[u].y);
+    }
+#else
 #pragma unroll
   for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (eneed >> u & 1u) SL.u.s.errs[tid_c + 512 * u] = __uint_as_float((uint32_t)ev[u]);
+#endif
   __syncthreads();
   VPP(3);
 }
@@ -829,7 +889,7 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
   const int M = p.a.M;
   const int n_stage = min(VIS_ERR_STAGE, M);
   const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
-  const vp_word *errs = p.errs + (size_t)(step_global & 1) * M;
+  const vp_word *errs = p.errs + (size_t)(step_global & 1) * VP_ERR_PITCH(M);
   if (tid < VIS_PSTRIDE) {
     double rr = SL.u.s.scratch[tid];
 #pragma unroll
@@ -943,7 +1003,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
   const VisualKernelArgs &a = p.a;
   // ---- every block: errors[] of the LAST evaluated step for its own patches (visual_submap->errors, vio.cpp:1632)
   {
-    const vp_word *errs = p.errs + (size_t)last_buf * M;
+    const vp_word *errs = p.errs + (size_t)last_buf * VP_ERR_PITCH(M);
     for (int g = blockIdx.x; g < ngroups; g += G) {
       const int patch = g * VIS_PPB + tid;
       if (tid < VIS_PPB && patch < M) a.errors[patch] = __uint_as_float((uint32_t)vp_ld(errs + patch));
