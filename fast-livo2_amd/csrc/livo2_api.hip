@@ -150,7 +150,8 @@ struct livo2_ctx {
   // persistent visual update (k_visual_update_persistent): one launch per computeJacobianAndUpdateEKF.  LIVO2_VISUAL_PERSISTENT=0 (or livo2_ctx_set_option) selects
   // the launch-per-step sequence instead.
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
-  unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0; uint32_t vp_seq = 0;
+  unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0;
+  bool vp_xchg_dirty = true; size_t vp_err_pitch = 0; int vp_hw_rows = 0, vp_hw_m = 0;      // exchange buffers of k_visual_update_persistent: host-side view (api_visual.inc)
   // block order of k_lidar_residual (lidar_kernels.hpp, LptArgs): lifetimes per chunk written by every launch, order written by every solve; valid once a solve of this scan has run
   int32_t *d_lidar_tickets = nullptr;
   int32_t *d_lpt_order = nullptr; uint32_t *d_lpt_cost = nullptr; size_t lpt_order_cap = 0, lpt_cost_cap = 0; int lpt_chunks = 0; bool lpt_valid = false;

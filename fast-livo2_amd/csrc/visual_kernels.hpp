@@ -149,10 +149,10 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
 // Four patches per wave (the body shared by the single-frame and the batched kernel).  patch0 = first patch of this wave.  Returns lane q's value q (q < 37) of the
 // SUM of the wave's patch vectors (slot order).
 // The iterate enters as three pointers (rot_end, pos_end, inv_expo_time): HBM (ctl->cur) in the per-step kernels, LDS in the persistent kernel.
-// errors_out: float[M] (plain / write-through stores), or — TAGGED — uint64[M] words {tag << 32 | float bits} written with one 8-byte write-through store each.
-template <bool DEBUG_ROWS, bool XB = false, bool TAGGED = false>
+// errors_out: float[M] (plain stores, or write-through stores with XB: the resident grid of k_visual_update_persistent reads them from other blocks).
+template <bool DEBUG_ROWS, bool XB = false>
 __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const int level, const double *Rwi, const double *Pwi, const double *tau_p, float *errors_out,
-                                                   VisWaveLds &L, int patch0, int lane, uint32_t tag = 0) {
+                                                   VisWaveLds &L, int patch0, int lane) {
   const int slot = lane / VIS_LPP, j = lane % VIS_LPP;
   const VisRC rc = vis_rc(lane);
   const int patch_raw = patch0 + slot;
@@ -302,10 +302,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   VIS_CHAIN(40, 64)
 #undef VIS_CHAIN
   if (!ok) pe = 0.0f;
-  if (j == 0 && valid) {
-    if (TAGGED) xb_store<true>(reinterpret_cast<unsigned long long *>(errors_out) + patch, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(pe));
-    else xb_store<XB>(&errors_out[patch], pe);
-  }
+  if (j == 0 && valid) xb_store<XB>(&errors_out[patch], pe);
   return out_val;
 }
 template <bool DEBUG_ROWS, bool XB = false>
@@ -642,12 +639,17 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict
 //   2. EVERY block collects all G rows and the M errors and runs the reduction, the float error chain, the accept / revert decision and the 19-dim solve
 //      REDUNDANTLY — same instructions on same data, so all blocks hold the same new iterate bit for bit and no second hand-off (solve -> publish ->
 //      everyone reloads) exists.  Block 0 alone writes the step trace and, at the end, the result.
-// Hand-off without a barrier: every published 8-byte word carries its own validity — {tag << 32 | 32 payload bits}, tag = launch sequence << 8 | step + 1 —
-// and is written with ONE write-through store (an aligned 8-byte store is single-copy atomic); a double travels as two such words.  A reader loads with
-// cache-bypassing loads and simply re-loads the words whose tag is not yet the step's: no arrival counter, no store-drain wait, no fence — the data is its own
-// flag, and a stale value (previous step: other buffer parity; previous launch: other sequence number) can never be mistaken for a fresh one.
-// Buffers alternate with the step parity: a block can be at most one step ahead of the slowest reader (it cannot finish step k+1 without everyone's row of
-// step k+1, and whoever wrote that has finished reading step k).
+// Hand-off without a barrier: the exchange buffers hold plain doubles / floats, and a slot that has not been written yet holds an all-ones pattern (VP_EMPTY: a
+// NaN with a payload no arithmetic produces).  A publisher writes each value with ONE write-through store (aligned 8- and 4-byte stores are single-copy atomic); a
+// reader loads with cache-bypassing 16-byte loads (two doubles / four floats per request) and simply re-loads what is still empty: no arrival counter, no store-drain
+// wait, no fence — the data is its own flag.  (Rounds 3-4 carried a 32-bit tag next to every 32 payload bits instead: twice the bytes and twice the requests of the
+// collect, which is bound by exactly those.)  FOUR buffers rotate with the step number; during the collect of step k every block empties ITS OWN slots of buffer
+// k + 2: its last readers finished step k - 2 before they published step k - 1, which this block has seen, and the emptying stores are acknowledged (s_waitcnt
+// vmcnt(0) at the end of the phase) before this block publishes step k + 1 — so whoever looks into buffer k + 2 has seen that publication and cannot meet a value
+// of step k - 2.  The step numbers run on from launch to launch (`*base`, advanced by block 0 when it leaves): a launch that ends with step L leaves buffers L + 1
+// (emptied during step L - 1, or never written) and L + 2 (emptied during step L) empty — exactly what the first two steps of the next launch need, so the host
+// clears nothing between updates.  Because the sub-map (M, G) changes from frame to frame, a launch empties its share of everything ANY launch since the last host
+// clear may have written (clean_rows >= G rows, clean_m >= M errors: the host's high-water marks); after a timeout the host clears all four buffers.
 // The loops end on the device: a level that stops after two iterations costs two steps, not five launch pairs.
 // Bit-compatibility: the residual body, the order in which rows are added, the error chain and the solve are the code of the per-step kernels; with one
 // patch group per block the partial rows are the same too, so the result equals the launch-per-step path bit for bit (tests/test_visual_gpu.py).
@@ -665,11 +667,15 @@ __global__ void __launch_bounds__(LIVO2_WAVE) k_visual_finish(DevCtl *__restrict
 #define VP_BLOCK 512             // the collect / solve phases use 480 threads; the residual phase runs on waves 0..VIS_WAVES-1 (one per SIMD), the others wait at the barrier
 struct VisPersistArgs {
   VisualKernelArgs a;
-  unsigned long long *rows;     // [2][G][VIS_PSTRIDE][2]: every double as two words {tag << 32 | low half}, {tag << 32 | high half}
-  unsigned long long *errs;     // [2][M]: {tag << 32 | float bits}
+  unsigned long long *rows;     // [VP_NBUF][VP_MAX_ROWS][VIS_PSTRIDE] doubles (their bits); VP_EMPTY64 = not published yet
+  uint32_t *errs;               // [VP_NBUF][err_pitch] floats (their bits); VP_EMPTY32 = not published yet
   int32_t levels, max_iterations, error_threads;
   int32_t n_rows, halves;       // rows published per step (= min(patch groups, 256)); rows per block: 1 (grid = n_rows, residual on 4 waves) or 2 (grid = n_rows / 2, all 8 waves)
-  uint32_t tag_base;            // launch sequence number << 8
+  int32_t err_pitch;            // floats per error buffer (a multiple of 4: the collect loads four per request)
+  int32_t clean_rows, clean_m;  // what the emptying covers: the largest n_rows / M of any launch since the host last cleared the buffers (>= n_rows, >= M)
+  uint32_t *base;               // [0] step number of this launch's first step (mod 2^32; the buffer index is step % VP_NBUF), left behind by the launch before;
+                                // [1] != 0: a grid gave up half-way and the buffers hold words of unfinished steps — every later launch gives up at once (and is re-run
+                                //     per step by the fetch) until the host has cleared the buffers
   double img_point_cov;
   unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 256][step < 32][16] stamps of the 100 MHz clock, else null
   unsigned long long timeout;   // 100 MHz ticks a block waits for a word before it gives the update up (VP_TIMEOUT; option "visual_persistent_debug_timeout" shortens it)
@@ -688,6 +694,7 @@ struct __attribute__((aligned(16))) VisPersistLds {
   double Gfull[DS * DS];        // G as the reference keeps it: written on accepted steps only (vio.cpp:1655-1665), zero-padded 19 x 19
   float last_error, err_total;
   int stop, n_steps, timed_out, stop_if_accepted;
+  uint32_t base;                // *p.base as the launch found it
 };
 
 __device__ __forceinline__ void vis_log_lds(SolveLds &s) {           // Log(cur^T prop) from the LDS copies (esikf_log_lane reads HBM)
@@ -704,13 +711,18 @@ __device__ __forceinline__ void vis_log_lds(SolveLds &s) {           // Log(cur^
 }
 
 typedef unsigned long long vp_word;
-#define VP_ERR_PITCH(M) (((size_t)(M) + 1) & ~(size_t)1)      // words between the two error buffers: even, so that the word pairs of the collect are 16-byte aligned
-__device__ __forceinline__ vp_word vp_ld(const vp_word *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define VP_NBUF 4
+#define VP_ROW_PITCH ((size_t)VP_MAX_ROWS * VIS_PSTRIDE)          // doubles per row buffer
+#define VP_ERR_PITCH(M) (((size_t)(M) + 3) & ~(size_t)3)          // floats per error buffer
+#define VP_EMPTY64 0xffffffffffffffffull
+#define VP_EMPTY32 0xffffffffu
 __device__ __forceinline__ void vp_st(vp_word *p, vp_word v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Both words of a published double in ONE cache-bypassing request (they are adjacent and 16-byte aligned; each 8-byte half is validated by its own tag, so a torn pair is
-// simply re-loaded).  A relaxed agent-scope atomic load lowers to an sc1 load only up to 8 bytes, hence the asm; vp_ld2_land ties the destination registers to the wait.
+__device__ __forceinline__ void vp_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t vp_ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes in ONE cache-bypassing request (every 8- / 4-byte part is validated on its own, so a pair that is half there is simply loaded again).  A relaxed
+// agent-scope atomic load lowers to an sc1 load only up to 8 bytes, hence the asm; vp_ld2_land ties the destination registers to the wait.
 typedef unsigned long long vp_word2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void vp_ld2_issue(vp_word2 &v, const vp_word *p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void vp_ld2_issue(vp_word2 &v, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void vp_ld2_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void vp_ld2_land(vp_word2 &v) { asm volatile("" : "+v"(v)); }
 
@@ -727,7 +739,7 @@ __device__ __forceinline__ const VisPersistArgs &vp_args() {
 }
 #define VP_TIMEOUT 200000000ull          // 100 MHz ticks: 2 s
 
-// ---- 1. residual of this block's patch groups; the row and the errors are published as tagged words
+// ---- 1. residual of this block's patch groups; the row and the errors are published into buffer step % VP_NBUF
 __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step_v) {
   VisPersistLds &SL = *(VisPersistLds *)slp;
   const VisPersistArgs &p = vp_args();
@@ -739,10 +751,9 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = p.a.M, R = p.n_rows, halves = p.halves;
   const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
-  const int buf = step_global & 1;
-  const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
-  vp_word *rows = p.rows + (size_t)buf * R * VIS_PSTRIDE * 2;
-  vp_word *errs = p.errs + (size_t)buf * VP_ERR_PITCH(M);
+  const int buf = (int)((SL.base + (uint32_t)step_global) & (VP_NBUF - 1));
+  vp_word *rows = p.rows + (size_t)buf * VP_ROW_PITCH;
+  float *errs = reinterpret_cast<float *>(p.errs + (size_t)buf * p.err_pitch);
   VPP(0);
   double out_val = 0.0;
   // row r = blockIdx.x * halves + (wave / VIS_WAVES) sums the patch groups r, r + R, ... (a group = VIS_PPB = 16 patches = the row unit of k_visual_residual):
@@ -751,7 +762,7 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   if (wave < VIS_WAVES * halves && my_row < R) {
     for (int g = my_row; g < ngroups; g += R) {
       const int patch0 = (g * VIS_WAVES + wv) * VIS_PPW;
-      if (patch0 < M) out_val += visual_wave_body<false, true, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, reinterpret_cast<float *>(errs), SL.u.r.lds[wave], patch0, lane, tag);
+      if (patch0 < M) out_val += visual_wave_body<false, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wave], patch0, lane);
       if (g + R < ngroups) wave_sync();
     }
     if (lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
@@ -760,20 +771,18 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   __syncthreads();
   if (tid < VIS_PSTRIDE * halves) {
     const int h = tid / VIS_PSTRIDE, k = tid % VIS_PSTRIDE, r = (int)blockIdx.x * halves + h;
-    if (r < R && k < VIS_NSUM) {
+    if (r < R) {                                               // all VIS_PSTRIDE entries (the padding beyond VIS_NSUM is 0.0): the collect reads whole pairs
       double v = SL.u.r.red[h * VIS_WAVES][k];
 #pragma unroll
       for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[h * VIS_WAVES + w][k];
-      const vp_word bits = (vp_word)__double_as_longlong(v), hi = (vp_word)tag << 32;
-      vp_word *dst = rows + ((size_t)r * VIS_PSTRIDE + k) * 2;
-      vp_st(dst, hi | (bits & 0xffffffffull)); vp_st(dst + 1, hi | (bits >> 32));
+      vp_st(rows + (size_t)r * VIS_PSTRIDE + k, (vp_word)__double_as_longlong(v));
     }
   }
   if (tid == LIVO2_WAVE) vis_log_lds(SL.s);                    // rotation part of vec = prior [-] iterate, while the words travel
   VPP(2);
 }
 
-// ---- 2. collect: all G rows and the M errors; words of blocks that are not there yet are simply loaded again
+// ---- 2. collect: all G rows (waves 0-3: one column pair per thread) and the M errors (waves 4-7: four per request); what is still empty is simply loaded again
 __device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
   VisPersistLds &SL = *(VisPersistLds *)slp;
   const VisPersistArgs &p = vp_args();
@@ -783,96 +792,88 @@ __device__ VP_PHASE_ATTR void vp_phase_collect(VpLds slp, int step_v) {
   const int tid_c = tid_o;
   const int tid = tid_c;                                     // (VPP)
   const int G = p.n_rows, M = p.a.M;                      // G rows (not blocks) from here on
-  const int buf = step_global & 1;
-  const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
-  const vp_word *rows = p.rows + (size_t)buf * G * VIS_PSTRIDE * 2;
-  const vp_word *errs = p.errs + (size_t)buf * VP_ERR_PITCH(M);
-  const int kidx = tid_c % VIS_PSTRIDE, slice = tid_c / VIS_PSTRIDE;
+  const int buf = (int)((SL.base + (uint32_t)step_global) & (VP_NBUF - 1)), cbuf = (buf + 2) & (VP_NBUF - 1);
+  const vp_word *rows = p.rows + (size_t)buf * VP_ROW_PITCH;
+  const uint32_t *errs = p.errs + (size_t)buf * p.err_pitch;
   const int n_stage = min(VIS_ERR_STAGE, M);
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  double acc = 0.0;
-#ifndef VP_NO_LD2
-  // the per-patch errors in pairs (words 2t, 2t + 1 of every 1 024): half the requests
-  vp_word2 ev2[VIS_ERR_STAGE / 1024];
-  uint32_t eneed = 0, ehave = 0;
+  // this block's own slots of the buffer two steps ahead: empty again (see the head of this section for why nobody can still be reading them, and why nobody can
+  // look at them before these stores have landed)
+  {
+    const int halves = p.halves, cm = p.clean_m, cgroups = (cm + VIS_PPB - 1) / VIS_PPB, crows_n = p.clean_rows;
+    vp_word *crows = p.rows + (size_t)cbuf * VP_ROW_PITCH;
+    uint32_t *cerrs = p.errs + (size_t)cbuf * p.err_pitch;
+    if (tid_c < VIS_PSTRIDE * halves) {                      // (rows / patch groups r, r + G, ...: this block's own, then its share of what older launches left)
+      const int r = (int)blockIdx.x * halves + tid_c / VIS_PSTRIDE;
+      if (r < G) for (int rr = r; rr < crows_n; rr += G) vp_st(crows + (size_t)rr * VIS_PSTRIDE + tid_c % VIS_PSTRIDE, VP_EMPTY64);
+    } else if (tid_c >= 2 * LIVO2_WAVE && tid_c < 2 * LIVO2_WAVE + VIS_PPB * halves) {
+      const int q = tid_c - 2 * LIVO2_WAVE, r = (int)blockIdx.x * halves + q / VIS_PPB;
+      if (r < G) for (int g = r; g < cgroups; g += G) { const int patch = g * VIS_PPB + q % VIS_PPB; if (patch < cm) vp_st32(cerrs + patch, VP_EMPTY32); }
+    }
+  }
+  double acc0 = 0.0, acc1 = 0.0;
+  const int pair = tid_c % (VIS_PSTRIDE / 2), slice = tid_c / (VIS_PSTRIDE / 2);       // rows: threads 0..239 = 12 slices x 20 column pairs
+  vp_word2 ev4[VIS_ERR_STAGE / 1024];                                                      // errors: threads 256..511, four floats per request
+  const int et = tid_c - 4 * LIVO2_WAVE;
+  if (tid_c < VIS_SOLVE_THREADS / 2) {
+    for (int base = 0; base < G; base += 12 * VP_RPT) {          // (same order of additions as k_visual_solve: rows slice, slice + 12, ... per thread and column)
+      vp_word2 w2[VP_RPT];
+      uint32_t need = 0, have = 0;
 #pragma unroll
-  for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) if (2 * tid_c + 1024 * u < n_stage) eneed |= 1u << u;
-#else
-  vp_word ev[VIS_ERR_STAGE / 512];
-  uint32_t eneed = 0, ehave = 0;
+      for (int u = 0; u < VP_RPT; u++) if (base + slice + 12 * u < G) need |= 1u << u;
+      while (have != need) {
+        // unconditional loads (an asm statement cannot be predicated: a branch around each of the 21 costs an exec-mask pair apiece): an entry beyond the last row
+        // reads row 0, an entry this thread already has reads the same — unchanged — values again (a buffer is not emptied before every block has left the next step)
 #pragma unroll
-  for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (tid_c + 512 * u < n_stage) eneed |= 1u << u;
-#endif
-  for (int base = 0; base < G; base += 12 * VP_RPT) {          // (same order of additions as k_visual_solve: rows slice, slice + 12, ... per thread)
-#ifndef VP_NO_LD2
-    vp_word2 w2[VP_RPT];
-#define VP_LO(u) w2[u].x
-#define VP_HI(u) w2[u].y
-#else
-    vp_word lo[VP_RPT], hi[VP_RPT];
-#define VP_LO(u) lo[u]
-#define VP_HI(u) hi[u]
-#endif
-    uint32_t need = 0, have = 0;
+        for (int u = 0; u < VP_RPT; u++) {
+          const size_t row = (need >> u & 1u) ? (size_t)(base + slice + 12 * u) : 0;
+          vp_ld2_issue(w2[u], rows + row * VIS_PSTRIDE + 2 * pair);
+        }
+        vp_ld2_wait();
 #pragma unroll
-    for (int u = 0; u < VP_RPT; u++) if (tid_c < VIS_SOLVE_THREADS && kidx < VIS_NSUM && base + slice + 12 * u < G) need |= 1u << u;      // (entries >= VIS_NSUM of a row are padding: never published, never read)
-    while (have != need || ehave != eneed) {
-      const uint32_t todo = need & ~have, etodo = eneed & ~ehave;
-#ifndef VP_NO_LD2
-      // unconditional loads (an asm statement cannot be predicated: a branch around each of the 21 costs an exec-mask pair apiece, 44 more spilled SGPRs): an entry this
-      // thread does not need reads the buffer's first word pair, an entry it already has reads the same — unchanged — words again (the buffer of step k is not rewritten
-      // before every block has left step k + 1)
+        for (int u = 0; u < VP_RPT; u++) vp_ld2_land(w2[u]);
 #pragma unroll
-      for (int u = 0; u < VP_RPT; u++) {
-        const size_t row = (need >> u & 1u) ? (size_t)(base + slice + 12 * u) : 0;
-        vp_ld2_issue(w2[u], rows + (row * VIS_PSTRIDE + ((need >> u & 1u) ? kidx : 0)) * 2);
+        for (int u = 0; u < VP_RPT; u++) if ((need >> u & 1u) && w2[u].x != VP_EMPTY64 && w2[u].y != VP_EMPTY64) have |= 1u << u;
+        if (have != need) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } }
       }
 #pragma unroll
-      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) vp_ld2_issue(ev2[u], errs + ((eneed >> u & 1u) ? 2 * tid_c + 1024 * u : 0));
+      for (int u = 0; u < VP_RPT; u++) if (need >> u & 1u) { acc0 += __longlong_as_double((long long)w2[u].x); acc1 += __longlong_as_double((long long)w2[u].y); }
+    }
+  } else if (et >= 0) {
+    uint32_t eneed = 0, ehave = 0;
+#pragma unroll
+    for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) if (4 * (et + 256 * u) < n_stage) eneed |= 1u << u;
+    while (ehave != eneed) {
+#pragma unroll
+      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) vp_ld2_issue(ev4[u], errs + ((eneed >> u & 1u) ? 4 * (et + 256 * u) : 0));
       vp_ld2_wait();
 #pragma unroll
-      for (int u = 0; u < VP_RPT; u++)
-        vp_ld2_land(w2[u]);
+      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) vp_ld2_land(ev4[u]);
 #pragma unroll
-      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) vp_ld2_land(ev2[u]);
-#else
-#pragma unroll
-      for (int u = 0; u < VP_RPT; u++)
-        if (todo >> u & 1u) { const vp_word *src = rows + ((size_t)(base + slice + 12 * u) * VIS_PSTRIDE + kidx) * 2; lo[u] = vp_ld(src); hi[u] = vp_ld(src + 1); }
-#pragma unroll
-      for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (etodo >> u & 1u) ev[u] = vp_ld(errs + tid_c + 512 * u);
-#endif
-#pragma unroll
-      for (int u = 0; u < VP_RPT; u++) if ((todo >> u & 1u) && (uint32_t)(VP_LO(u) >> 32) == tag && (uint32_t)(VP_HI(u) >> 32) == tag) have |= 1u << u;
-#ifndef VP_NO_LD2
-#pragma unroll
-      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++)          // (an odd n_stage: the pair's second word is beyond the errors of this step and carries whatever tag)
-        if ((etodo >> u & 1u) && (uint32_t)(ev2[u].x >> 32) == tag && ((uint32_t)(ev2[u].y >> 32) == tag || 2 * tid_c + 1024 * u + 1 >= n_stage)) ehave |= 1u << u;
-#else
-#pragma unroll
-      for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if ((etodo >> u & 1u) && (uint32_t)(ev[u] >> 32) == tag) ehave |= 1u << u;
-#endif
-      if (have != need || ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } }
+      for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) {           // (floats beyond the last patch of the step are not part of it: whatever they hold)
+        const int i = 4 * (et + 256 * u);
+        const bool ok = (uint32_t)ev4[u].x != VP_EMPTY32 && (i + 1 >= n_stage || (uint32_t)(ev4[u].x >> 32) != VP_EMPTY32) &&
+                        (i + 2 >= n_stage || (uint32_t)ev4[u].y != VP_EMPTY32) && (i + 3 >= n_stage || (uint32_t)(ev4[u].y >> 32) != VP_EMPTY32);
+        if ((eneed >> u & 1u) && ok) ehave |= 1u << u;
+      }
+      if (ehave != eneed) { __builtin_amdgcn_s_sleep(1); if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } }
     }
-#pragma unroll
-    for (int u = 0; u < VP_RPT; u++) if (need >> u & 1u) acc += __longlong_as_double((long long)((VP_LO(u) & 0xffffffffull) | (VP_HI(u) << 32)));
-#undef VP_LO
-#undef VP_HI
   }
+  vp_ld2_wait();                                         // the emptying stores above have landed (threads that had nothing to load included)
   __syncthreads();                                       // every wave is done with the tiles of phase 1 (they alias the staging below)
-  if (tid_c < VIS_SOLVE_THREADS) SL.u.s.scratch[slice * 41 + kidx] = acc;
-#ifndef VP_NO_LD2
+  if (tid_c < VIS_SOLVE_THREADS / 2) { SL.u.s.scratch[slice * 41 + 2 * pair] = acc0; SL.u.s.scratch[slice * 41 + 2 * pair + 1] = acc1; }
+  else if (et >= 0) {
 #pragma unroll
-  for (int u = 0; u < VIS_ERR_STAGE / 1024; u++)
-    if (eneed >> u & 1u) {
-      const int i = 2 * tid_c + 1024 * u;
-      SL.u.s.errs[i] = __uint_as_float((uint32_t)ev2[u].x);
-      if (i + 1 < n_stage) SL.u.s.errs[i + 1] = __uint_as_float((uint32_t)ev2[u].y);
+    for (int u = 0; u < VIS_ERR_STAGE / 1024; u++) {
+      const int i = 4 * (et + 256 * u);
+      if (i < n_stage) {
+        SL.u.s.errs[i] = __uint_as_float((uint32_t)ev4[u].x);
+        if (i + 1 < n_stage) SL.u.s.errs[i + 1] = __uint_as_float((uint32_t)(ev4[u].x >> 32));
+        if (i + 2 < n_stage) SL.u.s.errs[i + 2] = __uint_as_float((uint32_t)ev4[u].y);
+        if (i + 3 < n_stage) SL.u.s.errs[i + 3] = __uint_as_float((uint32_t)(ev4[u].y >> 32));
+      }
     }
-#else
-#pragma unroll
-  for (int u = 0; u < VIS_ERR_STAGE / 512; u++) if (eneed >> u & 1u) SL.u.s.errs[tid_c + 512 * u] = __uint_as_float((uint32_t)ev[u]);
-#endif
+  }
   __syncthreads();
   VPP(3);
 }
@@ -888,8 +889,7 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
   const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = p.a.M;
   const int n_stage = min(VIS_ERR_STAGE, M);
-  const uint32_t tag = p.tag_base | (uint32_t)(step_global + 1);
-  const vp_word *errs = p.errs + (size_t)(step_global & 1) * VP_ERR_PITCH(M);
+  const uint32_t *errs = p.errs + (size_t)((SL.base + (uint32_t)step_global) & (VP_NBUF - 1)) * p.err_pitch;
   if (tid < VIS_PSTRIDE) {
     double rr = SL.u.s.scratch[tid];
 #pragma unroll
@@ -922,9 +922,9 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
       priv = float_chain(SL.u.s.errs, my_begin, min(my_end, n_stage), priv);
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       for (int i = max(my_begin, n_stage); i < my_end; i++) {                 // sub-maps beyond the staging area: straight from the published words
-        vp_word w = vp_ld(errs + i);
-        while ((uint32_t)(w >> 32) != tag) { if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } w = vp_ld(errs + i); }
-        priv += __uint_as_float((uint32_t)w);
+        uint32_t w = vp_ld32(errs + i);
+        while (w == VP_EMPTY32) { if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } w = vp_ld32(errs + i); }
+        priv += __uint_as_float(w);
       }
       SL.u.s.err_chunk[lane] = priv;
     }
@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
     double craw[6];
     if (wave == 0) esikf_prefetch_wave(ctl, s, p.img_point_cov, lane, craw);
     for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.Gfull[e] = ctl->G[e];
-    if (tid == 0) { SL.last_error = FLT_MAX; SL.stop = 0; SL.n_steps = 0; SL.timed_out = 0; }
+    if (tid == 0) { SL.last_error = FLT_MAX; SL.stop = 0; SL.n_steps = 0; SL.base = p.base[0]; SL.timed_out = p.base[1] != 0 ? 1 : 0; }      // (base[1]: the launch before gave up half-way)
   }
   __syncthreads();
   if (tid < 25) SL.old[tid] = s.cur[tid];
@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
   for (int level = p.levels - 1; level >= 0 && !SL.timed_out; level--) {
     for (int it = 0; it < p.max_iterations; it++) {
       vp_phase_residual(slp, level, step_global);
-      last_buf = step_global & 1;
+      last_buf = (int)((SL.base + (uint32_t)step_global) & (VP_NBUF - 1));
       vp_phase_collect(slp, step_global);
       if (SL.timed_out) break;
       vp_phase_solve(slp, ctl, level, it, step_global);
@@ -1003,16 +1003,18 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
   const VisualKernelArgs &a = p.a;
   // ---- every block: errors[] of the LAST evaluated step for its own patches (visual_submap->errors, vio.cpp:1632)
   {
-    const vp_word *errs = p.errs + (size_t)last_buf * VP_ERR_PITCH(M);
+    const uint32_t *errs = p.errs + (size_t)last_buf * p.err_pitch;
     for (int g = blockIdx.x; g < ngroups; g += G) {
       const int patch = g * VIS_PPB + tid;
-      if (tid < VIS_PPB && patch < M) a.errors[patch] = __uint_as_float((uint32_t)vp_ld(errs + patch));
+      if (tid < VIS_PPB && patch < M) a.errors[patch] = __uint_as_float(vp_ld32(errs + patch));
     }
   }
+  if (SL.timed_out && tid == 0) p.base[1] = 1u;
   if (blockIdx.x != 0) return;
   // A grid that lost a block (not co-resident: admission is per process, advisor round 3) commits NOTHING: ctl->cur, cov and G stay what the launch found, only the
   // flag goes up, and livo2_visual_update_fetch re-runs the update as the launch-per-step sequence from the inputs it kept.
   if (SL.timed_out) { if (tid == 0) ctl->hdr.pad[0] = 1; return; }
+  if (tid == 0) p.base[0] = SL.base + (uint32_t)step_global;     // (every other block read it before it published its first row, and this block has seen all of those)
   // ---- block 0: the result.  state->cov -= G * state->cov (vio.cpp:800), updateFrameState (vio.cpp:1690-1697)
   for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
   __syncthreads();

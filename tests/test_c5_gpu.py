@@ -130,3 +130,40 @@ def test_frame_update_argument_errors_and_empty_submap(livo2, orc):
         assert v0.n_steps == 0 and bytes(v0.state) == bytes(l0.state) and bytes(l0.state) == bytes(a[0].state)
     finally:
         c.close()
+
+
+def test_a_frame_behind_a_resident_grid_that_gave_up_is_rerun_per_step(livo2, orc):
+    """round 5: the exchange buffers of the resident visual grid carry no launch tags any more; a grid that gives up half-way leaves a mark on the device, and a launch
+    that is ALREADY enqueued behind it gives up at once instead of reading words of unfinished steps.  Two frames in flight, the first one loses a block (test hook):
+    its fetch reports the error (its inputs are gone), the second frame is re-run per step by its fetch and equals the undisturbed result; afterwards the resident
+    grid is back."""
+    frames_mod = importlib.import_module("fast-livo2_amd.frames")
+    cfgs = importlib.import_module("fast-livo2_amd.configs")
+    fmap, lio_cfg, extR, extT, seq = synth.frame_sequence(2)
+    cfg = cfgs.lidar_cfg(_Sc(lio_cfg, extR, extT)); vcfg = cfgs.visual_cfg(seq[0]["vs"], mp_proc_num=4)
+    c = livo2.Context(0)
+    try:
+        c.upload_map(fmap)
+        args = []
+        for fr in seq:
+            vs = fr["vs"]
+            prior = livo2.State.from_pose(fr["R_prior"], fr["t_prior"], fr["P"], inv_expo=vs.tau_prior)
+            args.append((fr["xyz"], prior, cfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg))
+        want = [c.frame_update(*a) for a in args]
+        t0, l0 = c.counter("visual_persistent_timeouts"), c.counter("visual_persistent_launches")
+        c.set_option("visual_persistent_debug_timeout", 1)
+        c.frame_update_async(*args[0])
+        c.set_option("visual_persistent_debug_timeout", 0)
+        c.frame_update_async(*args[1])
+        with pytest.raises(livo2.Livo2Error):
+            c.frame_update_fetch()
+        got = c.frame_update_fetch()
+        assert bytes(got[0].state) == bytes(want[1][0].state) and bytes(got[1].state) == bytes(want[1][1].state) and got[1].n_steps == want[1][1].n_steps
+        assert c.counter("visual_persistent_timeouts") == t0 + 2 and c.counter("visual_persistent_launches") == l0 + 2
+        for _ in range(20):                                                          # (the back-off after two time-outs: 8 + 16 updates on the per-step path)
+            again = c.frame_update(*args[0])
+            assert bytes(again[1].state) == bytes(want[0][1].state)
+        again = [c.frame_update(*a) for a in args for _ in range(6)]
+        assert c.counter("visual_persistent_launches") > l0 + 2 and c.counter("visual_persistent_timeouts") == t0 + 2
+    finally:
+        c.close()

@@ -199,6 +199,36 @@ def test_persistent_update_gives_the_same_bits_as_the_per_step_launches(livo2, c
     assert ctx.counter("visual_persistent_launches") == n0 + 10 and ctx.counter("visual_persistent_fallbacks") == 0
 
 
+def test_persistent_updates_of_changing_shape_share_the_exchange_buffers(livo2):
+    """round 5: the exchange buffers of the resident grid hold plain values, 'empty' is an all-ones word, four buffers rotate with a step number that runs on from
+    launch to launch and every launch empties two steps ahead — also the slots that an OLDER, larger sub-map wrote.  Updates of very different size and length
+    (one level x one iteration = a single step; many steps) alternate on one fresh context: every one equals the launch-per-step sequence bit for bit."""
+    c = livo2.Context(0)
+    try:
+        cases = []
+        for k, (M, L, kw) in enumerate([(4000, 4, {}), (40, 4, {}), (1700, 4, dict(max_iterations=1)), (4000, 4, {}), (300, 1, dict(max_iterations=1)), (3100, 3, {}),
+                                        (17, 4, {}), (2500, 2, dict(max_iterations=2)), (4000, 1, dict(max_iterations=1)), (4000, 4, {})]):
+            vs = synth.visual_scenario(seed=300 + k, n_patches=M, L=L)
+            cfg = H.visual_cfg_product(vs, mp_proc_num=4, **kw)
+            cur, prop = H.states(vs, livo2.State)
+            cases.append((vs, cfg, cur, prop))
+        refs = []
+        c.set_option("visual_persistent", 0)
+        for vs, cfg, cur, prop in cases:
+            c.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+            refs.append(c.visual_update(cur, prop, cfg))
+        c.set_option("visual_persistent", 1)
+        for rep in range(3):
+            for (vs, cfg, cur, prop), (ref, ref_err) in zip(cases, refs):
+                c.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+                res, err = c.visual_update(cur, prop, cfg)
+                assert res.n_steps == ref.n_steps and bytes(res.state) == bytes(ref.state) and bytes(res.G) == bytes(ref.G) and np.array_equal(err, ref_err)
+                assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
+        assert c.counter("visual_persistent_launches") == 3 * len(cases) and c.counter("visual_persistent_timeouts") == 0
+    finally:
+        c.close()
+
+
 def test_persistent_update_matches_oracle_with_reverts(livo2, ctx, orc):
     """the persistent path against the oracle on scenes where levels end by a rejected step (state restored from old_state, vio.cpp:1677-1681)"""
     seen = False
