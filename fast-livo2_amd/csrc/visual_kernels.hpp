@@ -72,7 +72,7 @@ __device__ unsigned long long g_vis_prof[VIS_PROF_WAVES][8];
   do {                                                                                                                       \
     __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0);                     \
     const unsigned gw = blockIdx.x * VIS_WAVES + (threadIdx.x >> 6);                                                         \
-    if ((threadIdx.x & 63) == 0 && gw < VIS_PROF_WAVES)                                                                      \
+    if ((threadIdx.x & 63) == 0 && gw < VIS_PROF_WAVES && (threadIdx.x >> 6) < VIS_WAVES)                                    \
       g_vis_prof[gw][k] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();          \
     __builtin_amdgcn_sched_barrier(0);                                                                                       \
   } while (0)
@@ -150,7 +150,12 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
 // SUM of the wave's patch vectors (slot order).
 // The iterate enters as three pointers (rot_end, pos_end, inv_expo_time): HBM (ctl->cur) in the per-step kernels, LDS in the persistent kernel.
 // errors_out: float[M] (plain stores, or write-through stores with XB: the resident grid of k_visual_update_persistent reads them from other blocks).
-template <bool DEBUG_ROWS, bool XB = false>
+// ROLE 0: one wave does everything.  ROLE 1 / 2 (k_visual_update_persistent with one row per block, round 5): TWO waves of the block share the four patches — the
+// critical path of a patch is projection -> window -> B grid -> pixel loop -> moment sums -> expansion; the 2x6 M (needed only by the expansion) and the 64-step float
+// chain of patch_error (needed only for errors[]) hang off it.  ROLE 1 (main) walks the critical path, ROLE 2 (partner, same SIMD, same VisWaveLds) repeats the
+// projection, forms M while the main wave waits for its window, and runs the chain from the main wave's Rr while that one reduces and expands.  One block barrier in
+// the middle (Rr and Mx complete), so ALL waves of the block must call the body the same number of times.  Same expressions in the same order: same bits.
+template <bool DEBUG_ROWS, bool XB = false, int ROLE = 0>
 __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const int level, const double *Rwi, const double *Pwi, const double *tau_p, float *errors_out,
                                                    VisWaveLds &L, int patch0, int lane) {
   const int slot = lane / VIS_LPP, j = lane % VIS_LPP;
@@ -161,11 +166,14 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   // loads that do not depend on the state go first, so they travel together with the scalar loads of the state
   const double p0 = a.pos[(size_t)patch * 3], p1 = a.pos[(size_t)patch * 3 + 1], p2 = a.pos[(size_t)patch * 3 + 2];
   const int search_level = a.search_levels[patch];
-  const double inv_ref_expo = a.inv_expo[patch];
-  float Pref[4];
+  double inv_ref_expo = 0.0, tau = 0.0;
+  float Pref[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ROLE != 2) {
+    inv_ref_expo = a.inv_expo[patch];
 #pragma unroll
-  for (int k = 0; k < 4; k++) Pref[k] = a.warp[((size_t)patch * a.L + level) * 64 + j + VIS_LPP * k];
-  const double tau = *tau_p;
+    for (int k = 0; k < 4; k++) Pref[k] = a.warp[((size_t)patch * a.L + level) * 64 + j + VIS_LPP * k];
+    tau = *tau_p;
+  }
   VPHASE(1);
   double Rcw[9], Pcw[3];
   mat3_mul_Bt(a.Rci, Rwi, Rcw);                            // Rcw = Rci * Rwi^T
@@ -185,8 +193,8 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   const bool inside = (u_ref_i - 5 * scale >= 0) && (u_ref_i + 5 * scale < a.width) && (v_ref_i - 5 * scale >= 0) && (v_ref_i + 5 * scale < a.height);
   const bool ok = valid && inside;
   // the 11x11 strided window of the lane's patch: 8 byte loads per lane, all issued before the projection Jacobian below
-  uint8_t px[8];
-  {
+  uint8_t px[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ROLE != 2) {
     const size_t base = ok ? (size_t)(v_ref_i - 5 * scale) * a.stride + (size_t)(u_ref_i - 5 * scale) : 0;
     const int sc = ok ? scale : 0;
 #pragma unroll
@@ -204,13 +212,13 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   const float w_bl = (float)((1.0 - (double)subpix_u) * (double)subpix_v);
   const float w_br = subpix_u * subpix_v;
   // computeProjectionJacobian (vio.cpp:189-201) and the patch-constant 2x6 M
-  double Jpi[6];
-  {
+  double Jpi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (ROLE != 1 || DEBUG_ROWS) {
     const double z_inv = 1. / pf[2], z_inv_2 = z_inv * z_inv;
     Jpi[0] = a.fx * z_inv; Jpi[1] = 0.0; Jpi[2] = -a.fx * pf[0] * z_inv_2;
     Jpi[3] = 0.0; Jpi[4] = a.fy * z_inv; Jpi[5] = -a.fy * pf[1] * z_inv_2;
   }
-  {
+  if (ROLE != 1) {
     double M0[6], M1[6];
     jac_row(1.0, 0.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M0);
     jac_row(0.0, 1.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M1);
@@ -219,6 +227,10 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
       for (int k = 0; k < 6; k++) { L.Mx[slot][k] = M0[k]; L.Mx[slot][6 + k] = M1[k]; }
     }
   }
+  double acc[9];
+#pragma unroll
+  for (int v = 0; v < 9; v++) acc[v] = 0.0;
+  if (ROLE != 2) {
 #pragma unroll
   for (int k = 0; k < 8; k++) { const int e = j + VIS_LPP * k; if (e < 121) L.st.Wf[slot][e] = (float)px[k]; }
   wave_sync();
@@ -233,9 +245,6 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   }
   wave_sync();
   VPHASE(3);
-  double acc[9];
-#pragma unroll
-  for (int v = 0; v < 9; v++) acc[v] = 0.0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int p = j + VIS_LPP * k, x = p >> 3, y = p & 7;
@@ -263,7 +272,9 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
     L.Rr[slot][p] = res * res;
   }
   wave_sync();                                              // the staging buffers alias the tile written next; Rr is complete
+  }
   VPHASE(4);
+  if (ROLE != 0) __syncthreads();                           // main: Rr is written; partner: Mx is written
   // patch error: the reference's accumulator is a FLOAT updated in pixel order, `patch_error += res * res` = float(double(patch_error) + res*res)
   // (vio.cpp:1563,1624); the 16 lanes of a slot run that 64-step chain from broadcast LDS reads, so errors[] equals the CPU loop bit for bit.  The chain is
   // 192 dependent operations (~1.2 us) that nothing else in the wave needs: it is cut into three pieces placed inside the three synchronisation regions
@@ -275,9 +286,15 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
 #else
 #define VIS_CHAIN(lo, hi)
 #endif
+  if (ROLE == 2) {
+    VIS_CHAIN(0, 64)
+    if (!ok) pe = 0.0f;
+    if (j == 0 && valid) xb_store<XB>(&errors_out[patch], pe);
+    return 0.0;
+  }
 #pragma unroll
   for (int v = 0; v < 9; v++) L.T[v * VIS_TPITCH + lane] = ok ? acc[v] : 0.0;
-  VIS_CHAIN(0, 16)
+  if (ROLE == 0) { VIS_CHAIN(0, 16) }
   wave_sync();
   {
     // lane 4v+q adds columns [16q, 16q+16) of row v = the 16 lanes of patch slot q (16 independent LDS reads)
@@ -290,7 +307,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
       L.S[q][v] = (s0 + s1) + (s2 + s3);
     }
   }
-  VIS_CHAIN(16, 40)
+  if (ROLE == 0) { VIS_CHAIN(16, 40) }
   if (j == 0) L.nm[slot] = ok ? 64.0f : 0.0f;
   wave_sync();
   VPHASE(5);
@@ -299,10 +316,12 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
 #pragma unroll
     for (int sl = 0; sl < VIS_PPW; sl++) out_val += vis_expand(lane, rc, L.S[sl], L.Mx[sl], L.nm[sl]);
   }
-  VIS_CHAIN(40, 64)
+  if (ROLE == 0) {
+    VIS_CHAIN(40, 64)
+    if (!ok) pe = 0.0f;
+    if (j == 0 && valid) xb_store<XB>(&errors_out[patch], pe);
+  }
 #undef VIS_CHAIN
-  if (!ok) pe = 0.0f;
-  if (j == 0 && valid) xb_store<XB>(&errors_out[patch], pe);
   return out_val;
 }
 template <bool DEBUG_ROWS, bool XB = false>
@@ -758,8 +777,23 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   double out_val = 0.0;
   // row r = blockIdx.x * halves + (wave / VIS_WAVES) sums the patch groups r, r + R, ... (a group = VIS_PPB = 16 patches = the row unit of k_visual_residual):
   // the rows — and with them every sum — do not depend on the block shape the host chose
-  const int my_row = (int)blockIdx.x * halves + wave / VIS_WAVES, wv = wave % VIS_WAVES;
-  if (wave < VIS_WAVES * halves && my_row < R) {
+  const int my_row = (int)blockIdx.x * halves + (halves == 1 ? 0 : wave / VIS_WAVES), wv = wave % VIS_WAVES;
+  if (halves == 1) {
+    // one row per block: waves 0-3 walk the critical path of their four patches, waves 4-7 (same SIMD, same VisWaveLds) form M and run the patch_error chains
+    // (visual_wave_body, ROLE 1 / 2).  Every wave makes every call (the body holds a block barrier); a wave whose patches lie beyond M computes on the last patch
+    // and contributes zeros, as invalid slots of a partly filled wave always did.
+    if (my_row < R) {
+      VPHASE(0);                                             // (profiling build: the stamps of the LAST step stay, tools/vis_phase.py --persistent)
+      for (int g = my_row; g < ngroups; g += R) {
+        const int patch0 = (g * VIS_WAVES + wv) * VIS_PPW;
+        if (wave < VIS_WAVES) out_val += visual_wave_body<false, true, 1>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane);
+        else visual_wave_body<false, true, 2>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane);
+        VPHASE(6);
+        if (g + R < ngroups) __syncthreads();                // the partner is done with Rr, the main wave with Mx
+      }
+      if (wave < VIS_WAVES && lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
+    }
+  } else if (wave < VIS_WAVES * halves && my_row < R) {
     for (int g = my_row; g < ngroups; g += R) {
       const int patch0 = (g * VIS_WAVES + wv) * VIS_PPW;
       if (patch0 < M) out_val += visual_wave_body<false, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wave], patch0, lane);
