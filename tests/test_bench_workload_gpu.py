@@ -73,12 +73,13 @@ def test_headline_frames_match_oracle(ctx, c4, oracle_results):
     sc, vs, cfg, vcfg, lid, vis = c4
     ctx.upload_map(sc.fmap); ctx.set_scan(sc.xyz, cfg)
     ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    n0, t0 = ctx.counter("visual_persistent_launches"), ctx.counter("visual_persistent_timeouts")
     for f in range(F):
         res, pts = ctx.lidar_update(lid[f], lid[f], cfg, want=("match_plane", "dis_to_plane"))
         _check_lidar(res, pts, oracle_results[f][0], sc, lid[f])
         vres, errors = ctx.visual_update(vis[f], vis[f], vcfg)
         _check_visual(vres, errors, oracle_results[f][1])
-    assert ctx.counter("visual_persistent_launches") > 0
+    assert ctx.counter("visual_persistent_launches") == n0 + F and ctx.counter("visual_persistent_timeouts") == t0      # the resident grid ran AND finished (a grid that gives up is re-run per step)
 
 
 def test_lockstep_batch_equals_single_updates_and_oracle(ctx, c4, oracle_results):

@@ -84,6 +84,7 @@ def test_c5_frames_one_and_three_contexts_match_the_oracle(livo2, orc, shape):
         r0, _ = frames_mod.run_frames_sharded(ctxs[:2], livo2.State, seq, cfg, vcfg, 0, 2)
         r1, _ = frames_mod.run_frames_sharded(ctxs[2], livo2.State, seq, cfg, vcfg, 1, 2)
         assert sum(c.counter("visual_persistent_launches") for c in ctxs) > 0          # the resident-grid form ran next to the other contexts' kernels
+        assert sum(c.counter("visual_persistent_timeouts") for c in ctxs) == 0          # ... and none of those grids gave up (it would be re-run per step, with the same result)
         # the whole frame as ONE call (livo2_frame_update_async / _fetch), two frames in flight on one context, the LiDAR posterior handed to the visual update on the device
         piped, evp = frames_mod.run_frames_pipelined(ctxs[1], livo2.State, seq, cfg, vcfg)
         twice, _ = frames_mod.run_frames_pipelined(ctxs[1], livo2.State, seq + seq, cfg, vcfg)

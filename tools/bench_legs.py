@@ -502,8 +502,9 @@ def widened_rows(ctx, livo2, synth, H, sc, cfg):
     for _ in range(5):
         ctx.imu_propagate(ist, isteps, icfg); us.append(ctx.imu_last_kernel_us())
     extra["imu_propagate"] = {"samples": 20, "kernel_us": float(np.median(us)), "us_per_sample": float(np.median(us)) / 20,
-                              "note": "k_imu_propagate: one block, sequential over the samples (19x19 F P F^T + Q per sample); latency-bound, on par with a host core "
-                                      "(cpu_baseline.imu_propagate_us_20_samples) — built so that state_propagat / IMUpose can be produced next to their consumers"}
+                              "note": "k_imu_propagate (round 5): one block; the per-sample exponentials in parallel, a single-lane state recursion, F P F^T + Q with the <= 8 "
+                                      "non-zeros per row of F_x; latency-bound (cpu_baseline.imu_propagate_us_20_samples is one host core) — built so that state_propagat / "
+                                      "IMUpose are produced next to their consumers"}
     # raw scan -> UndistortPcl -> pcl::VoxelGrid -> resident scan
     raw = synth.raw_scan_scenario(seed=51, n_raw=240000)
     ctx.preprocess_scan(raw.xyz, raw.curvature, raw.poses, raw.rot_end, raw.pos_end, raw.leaf, cfg, want=False)
