@@ -89,17 +89,20 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
   v &= 0x3ffu; v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
   return v;
 }
-__global__ void __launch_bounds__(256) k_morton_keys(const float *__restrict__ aos, int n, float inv_cell, uint32_t *__restrict__ keys, int32_t *__restrict__ idx) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ uint32_t morton_key_of(const float *__restrict__ p, float inv_cell) {
   uint32_t c[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    float f = floorf(aos[(size_t)i * 3 + j] * inv_cell) + 512.f;
+    float f = floorf(p[j] * inv_cell) + 512.f;
     f = fminf(fmaxf(f, 0.f), 1023.f);                          // NaN -> 0
     c[j] = (uint32_t)f;
   }
-  keys[i] = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+  return spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+}
+__global__ void __launch_bounds__(256) k_morton_keys(const float *__restrict__ aos, int n, float inv_cell, uint32_t *__restrict__ keys, int32_t *__restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = morton_key_of(aos + (size_t)i * 3, inv_cell);
   idx[i] = i;
 }
 __global__ void __launch_bounds__(256) k_gather_xyz(const float *__restrict__ aos, const int32_t *__restrict__ perm, int n, float *__restrict__ x,
@@ -111,11 +114,9 @@ __global__ void __launch_bounds__(256) k_gather_xyz(const float *__restrict__ ao
 }
 
 // ---- once per scan: calcBodyCov -------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_body_cov(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, int n,
-                                                  float range_inc, float degree_inc, double deg2rad, double *__restrict__ cb) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double p0 = x[i], p1 = y[i], p2 = z[i];
+// body covariance of one sensor-frame point, symmetric part {00, 01, 02, 11, 12, 22} (shared by k_body_cov and the single-launch scan preparation of frame_kernels.hpp)
+__device__ __forceinline__ void body_cov_point(float fx, float fy, float fz, float range_inc, float degree_inc, double deg2rad, double (&out)[6]) {
+  double p0 = fx, p1 = fy, p2 = fz;
   if (p2 == 0) p2 = 0.001;                                  // voxel_map.cpp:352 (calcBodyCov's own 0.0001 patch can then never fire)
   float range = (float)sqrt((p0 * p0 + p1 * p1) + p2 * p2); // float range (voxel_map.cpp:18)
   float range_var = range_inc * range_inc;
@@ -146,8 +147,17 @@ __global__ void __launch_bounds__(256) k_body_cov(const float *__restrict__ x, c
     int a = idx[e][0], b = idx[e][1];
     double t1 = (dd[a] * rv) * dd[b];
     double t2 = (A[a * 2] * dv) * A[b * 2] + (A[a * 2 + 1] * dv) * A[b * 2 + 1];
-    cb[(size_t)e * n + i] = t1 + t2;
+    out[e] = t1 + t2;
   }
+}
+__global__ void __launch_bounds__(256) k_body_cov(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, int n,
+                                                  float range_inc, float degree_inc, double deg2rad, double *__restrict__ cb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double c6[6];
+  body_cov_point(x[i], y[i], z[i], range_inc, degree_inc, deg2rad, c6);
+#pragma unroll
+  for (int e = 0; e < 6; e++) cb[(size_t)e * n + i] = c6[e];
 }
 
 // ---- plane record in registers ------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "raycast_kernels.hpp"
 #include "choice_kernels.hpp"
 #include "imu_kernels.hpp"
+#include "frame_kernels.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -97,6 +98,15 @@ struct livo2_ctx {
   // whole frames (livo2_frame_update_*): pinned staging of the image + sub-map (two blocks, like the scan's), pinned ring of two result slots
   void *frame_stage[2] = {nullptr, nullptr}; size_t frame_stage_cap[2] = {0, 0}; hipEvent_t frame_stage_ev[2] = {nullptr, nullptr}; bool frame_stage_used[2] = {false, false}; int frame_stage_next = 0;
   void *h_frame_res = nullptr; hipEvent_t frame_res_ev[2] = {nullptr, nullptr}; int frame_head = 0, frame_inflight = 0;
+  // head and tail of a frame as single launches (frame_kernels.hpp).  scan_small_fused: a scan of <= 16 384 points is prepared by ONE block (keys, LDS radix sort, gather,
+  // body covariance) instead of ~10 launches; frame_ingest: 0 = one copy command per input array (round 4), 1 = one H2D into an arena + one scatter launch,
+  // 2 = the launch reads the pinned staging block itself (payloads up to FRAME_ZERO_COPY_MAX bytes, larger ones go through the arena); frame_publish: the two result
+  // blocks + the watchdog flag leave through one launch instead of three D2H copies.  Options of the same names / LIVO2_SCAN_SMALL_FUSED, LIVO2_FRAME_INGEST, LIVO2_FRAME_PUBLISH.
+  int scan_small_fused = [] { const char *e = std::getenv("LIVO2_SCAN_SMALL_FUSED"); return e ? (std::atoi(e) != 0 ? 1 : 0) : 1; }();
+  int frame_ingest = [] { const char *e = std::getenv("LIVO2_FRAME_INGEST"); const int v = e ? std::atoi(e) : 2; return (v >= 0 && v <= 2) ? v : 2; }();
+  int frame_publish = [] { const char *e = std::getenv("LIVO2_FRAME_PUBLISH"); return e ? (std::atoi(e) != 0 ? 1 : 0) : 1; }();
+  unsigned char *d_frame_arena = nullptr; size_t frame_arena_cap = 0;
+  int scan_small_launches = 0, frame_ingest_launches = 0, frame_zero_copy_launches = 0, frame_publish_launches = 0;
   livo2_visual_cfg frame_vcfg[2] = {}; int frame_M[2] = {0, 0}; bool frame_persistent[2] = {false, false};
   bool vp_last_chained = false;
   int32_t *d_ch_obs = nullptr, *d_ch_flag = nullptr, *d_ch_slot = nullptr, *d_cand_cell = nullptr, *d_cand_point = nullptr, *d_cand_obs = nullptr, *d_sub_point = nullptr,
@@ -720,7 +730,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
                  ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_ob_list, ctx->d_ob_cnt, ctx->d_delta, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
-                 ctx->d_ray_counters, ctx->d_ray_add};
+                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -792,6 +802,12 @@ int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
     if (value < 100 || value > 10000000) return fail(ctx, LIVO2_ERR_INVALID, "visual_persistent_timeout_us out of [100, 10000000]");
     ctx->vp_timeout_us = value; return LIVO2_OK;
   }
+  if (std::strcmp(name, "scan_small_fused") == 0) { ctx->scan_small_fused = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "frame_ingest") == 0) {
+    if (value < 0 || value > 2) return fail(ctx, LIVO2_ERR_INVALID, "frame_ingest must be 0 (a copy per array), 1 (arena + scatter launch) or 2 (launch reads the pinned block)");
+    ctx->frame_ingest = value; return LIVO2_OK;
+  }
+  if (std::strcmp(name, "frame_publish") == 0) { ctx->frame_publish = value != 0; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_debug_timeout") == 0) { ctx->vp_debug_timeout = value != 0; return LIVO2_OK; }     // test hook: the last block of the grid leaves at once, the others give up after 2 ms
   return fail(ctx, LIVO2_ERR_INVALID, "unknown option");
 }
@@ -804,6 +820,10 @@ int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
   if (std::strcmp(name, "map_tree_grow_events") == 0) { *value = ctx->mt_grow_events; return LIVO2_OK; }
   if (std::strcmp(name, "lidar_fused_launches") == 0) { *value = ctx->lidar_fused_launches; return LIVO2_OK; }
   if (std::strcmp(name, "visual_map_delta_calls") == 0) { *value = ctx->vm_delta_calls; return LIVO2_OK; }
+  if (std::strcmp(name, "scan_small_launches") == 0) { *value = ctx->scan_small_launches; return LIVO2_OK; }
+  if (std::strcmp(name, "frame_ingest_launches") == 0) { *value = ctx->frame_ingest_launches; return LIVO2_OK; }
+  if (std::strcmp(name, "frame_zero_copy_launches") == 0) { *value = ctx->frame_zero_copy_launches; return LIVO2_OK; }
+  if (std::strcmp(name, "frame_publish_launches") == 0) { *value = ctx->frame_publish_launches; return LIVO2_OK; }
   if (std::strcmp(name, "visual_map_delta_grows") == 0) { *value = ctx->vm_delta_grows; return LIVO2_OK; }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
 }

@@ -95,8 +95,18 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *   "lidar_fused_iteration" (default 0; environment LIVO2_LIDAR_FUSED): one launch per ESIKF iteration (k_lidar_iteration: the last block of the residual grid to
  *                        publish its partial row reduces and solves) instead of k_lidar_residual + k_lidar_solve.  Bit-identical results; measured slower at C4
  *                        (profiles/r05_lidar_fused_iteration_ab.txt), kept for grids whose solve launch is the larger share.
+ *   "scan_small_fused" (default 1; environment LIVO2_SCAN_SMALL_FUSED): a scan of up to 16 384 points (the reference's operating point: ~10 k points after the
+ *                        0.1-m filter, preprocess.cpp:185) is prepared by ONE block of ONE launch — Morton keys, a stable radix sort in LDS, the SoA gather and
+ *                        calcBodyCov (voxel_map.cpp:15-34, 349-360) — instead of k_morton_keys + the library's device-wide sort (5-8 launches) + k_gather_xyz +
+ *                        k_body_cov.  Same permutation, same bits downstream (tests/test_frame_ingest_gpu.py).  0: the launch sequence.
+ *   "frame_ingest" (default 2; LIVO2_FRAME_INGEST): how the inputs of livo2_frame_update_* (and the scan of livo2_lidar_set_scan) reach the device.  0: one copy
+ *                        command per array (prior, scan, image, four sub-map arrays).  1: one H2D copy of the pinned staging block into a device arena + one
+ *                        launch that scatters it (and prepares the scan).  2: that launch reads the pinned block itself over the link — no copy command — for
+ *                        payloads up to 1 MiB; larger frames take form 1.
+ *   "frame_publish" (default 1; LIVO2_FRAME_PUBLISH): the two result blocks and the watchdog flag of a frame are written into the pinned result slot by one
+ *                        launch instead of three D2H copies.
  * Counters: "visual_persistent_launches", "visual_persistent_fallbacks", "visual_persistent_timeouts", "visual_persistent_backoff_skips", "map_tree_grow_events",
- *           "lidar_fused_launches". */
+ *           "lidar_fused_launches", "scan_small_launches", "frame_ingest_launches", "frame_zero_copy_launches", "frame_publish_launches". */
 int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value);
 int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value);
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
