@@ -98,8 +98,8 @@ struct livo2_ctx {
   // whole frames (livo2_frame_update_*): pinned staging of the image + sub-map (two blocks, like the scan's), pinned ring of two result slots
   void *frame_stage[2] = {nullptr, nullptr}; size_t frame_stage_cap[2] = {0, 0}; hipEvent_t frame_stage_ev[2] = {nullptr, nullptr}; bool frame_stage_used[2] = {false, false}; int frame_stage_next = 0;
   void *h_frame_res = nullptr; hipEvent_t frame_res_ev[2] = {nullptr, nullptr}; int frame_head = 0, frame_inflight = 0;
-  // head and tail of a frame as single launches (frame_kernels.hpp).  scan_small_fused: a scan of <= 16 384 points is prepared by ONE block (keys, LDS radix sort, gather,
-  // body covariance) instead of ~10 launches; frame_ingest: 0 = one copy command per input array (round 4), 1 = one H2D into an arena + one scatter launch,
+  // head and tail of a frame as single launches (frame_kernels.hpp).  scan_small_fused: a scan of <= 16 384 points is prepared by two launches (keys with the frame's
+  // input scatter; order by counting + gather + body covariance) instead of ~10; frame_ingest: 0 = one copy command per input array (round 4), 1 = one H2D into an arena + one scatter launch,
   // 2 = the launch reads the pinned staging block itself (payloads up to FRAME_ZERO_COPY_MAX bytes, larger ones go through the arena); frame_publish: the two result
   // blocks + the watchdog flag leave through one launch instead of three D2H copies.  Options of the same names / LIVO2_SCAN_SMALL_FUSED, LIVO2_FRAME_INGEST, LIVO2_FRAME_PUBLISH.
   int scan_small_fused = [] { const char *e = std::getenv("LIVO2_SCAN_SMALL_FUSED"); return e ? (std::atoi(e) != 0 ? 1 : 0) : 1; }();

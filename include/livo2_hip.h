@@ -96,9 +96,10 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *                        publish its partial row reduces and solves) instead of k_lidar_residual + k_lidar_solve.  Bit-identical results; measured slower at C4
  *                        (profiles/r05_lidar_fused_iteration_ab.txt), kept for grids whose solve launch is the larger share.
  *   "scan_small_fused" (default 1; environment LIVO2_SCAN_SMALL_FUSED): a scan of up to 16 384 points (the reference's operating point: ~10 k points after the
- *                        0.1-m filter, preprocess.cpp:185) is prepared by ONE block of ONE launch — Morton keys, a stable radix sort in LDS, the SoA gather and
- *                        calcBodyCov (voxel_map.cpp:15-34, 349-360) — instead of k_morton_keys + the library's device-wide sort (5-8 launches) + k_gather_xyz +
- *                        k_body_cov.  Same permutation, same bits downstream (tests/test_frame_ingest_gpu.py).  0: the launch sequence.
+ *                        0.1-m filter, preprocess.cpp:185) is prepared by two launches — Morton keys (in the launch that scatters the frame's inputs), then the
+ *                        position of every point in the stable key order COUNTED instead of sorted, with the SoA gather and calcBodyCov (voxel_map.cpp:15-34,
+ *                        349-360) at the final positions — instead of k_morton_keys + the library's device-wide sort (5-8 launches) + k_gather_xyz + k_body_cov.
+ *                        Same permutation, same bits downstream (tests/test_frame_ingest_gpu.py).  0: the launch sequence.
  *   "frame_ingest" (default 2; LIVO2_FRAME_INGEST): how the inputs of livo2_frame_update_* (and the scan of livo2_lidar_set_scan) reach the device.  0: one copy
  *                        command per array (prior, scan, image, four sub-map arrays).  1: one H2D copy of the pinned staging block into a device arena + one
  *                        launch that scatters it (and prepares the scan).  2: that launch reads the pinned block itself over the link — no copy command — for

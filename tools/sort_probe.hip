@@ -1,5 +1,5 @@
-// Timing probe for the one-block scan preparation of frame_kernels.hpp (round 5): which block-wide sort is the fastest for ~10 k (key, index) pairs, and how the
-// gather + calcBodyCov part compares on one block against a grid.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ifast-livo2_amd/csrc -Iinclude tools/sort_probe.hip -o /tmp/sort_probe
+// Timing probe for the small-scan preparation of frame_kernels.hpp (round 5): block-wide radix sorts of ~10 k (key, index) pairs on ONE compute unit (what was tried
+// first) against the order counted directly on the whole chip (k_frame_ingest keys + k_scan_rank: what is shipped), and the gather + calcBodyCov part on a grid.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ifast-livo2_amd/csrc -Iinclude tools/sort_probe.hip -o /tmp/sort_probe
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstring>
@@ -7,6 +7,7 @@
 #include <vector>
 #include <random>
 #include <algorithm>
+#include <rocprim/block/block_radix_sort.hpp>
 #include "frame_kernels.hpp"
 
 template <int IPT, int BITS, rocprim::block_radix_rank_algorithm ALG>
@@ -25,6 +26,7 @@ __global__ void __launch_bounds__(1024) k_sort_only(const float *__restrict__ xy
   for (int i = 0; i < IPT; i++) { const int pos = i * 1024 + t; if (pos < n) perm[pos] = idx[i]; }
 }
 
+struct ScanSmallOut { const float *xyz; float *x, *y, *z; int32_t *perm; double *cb; double deg2rad; float range_inc, degree_inc; int32_t n; };
 __global__ void __launch_bounds__(256) k_gather_cov(ScanSmallOut s) {
   const int pos = blockIdx.x * 256 + threadIdx.x;
   if (pos >= s.n) return;
@@ -53,20 +55,27 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&xyz, n * 12)); CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&y, n * 4)); CK(hipMalloc(&z, n * 4)); CK(hipMalloc(&perm, n * 4)); CK(hipMalloc(&perm2, n * 4)); CK(hipMalloc(&cb, n * 48));
   CK(hipMalloc(&z0, 4096)); CK(hipMalloc(&z1, 4096));
   CK(hipMemcpy(xyz, h.data(), n * 12, hipMemcpyHostToDevice));
-  FrameIngestArgs a{}; a.n = n; a.xyz = xyz; a.x = x; a.y = y; a.z = z; a.perm = perm; a.cb = cb; a.inv_cell = 2.f; a.range_inc = 0.02f; a.degree_inc = 0.05f; a.deg2rad = 0.017453293;
-  a.zero0 = z0; a.zero0_words = 64; a.zero1 = z1; a.zero1_words = 18;
+  uint32_t *keys; CK(hipMalloc(&keys, (n + 16) * 4));
+  FrameIngestArgs a{}; a.n_seg = 0; a.n_keys = n; a.xyz = xyz; a.keys = keys; a.inv_cell = 2.f; a.zero0 = z0; a.zero0_words = 64; a.zero1 = z1; a.zero1_words = 18;
+  ScanRankArgs r{}; r.keys = keys; r.xyz = xyz; r.x = x; r.y = y; r.z = z; r.perm = perm; r.cb = cb; r.deg2rad = 0.017453293; r.range_inc = 0.02f; r.degree_inc = 0.05f; r.n = n;
   const float inv = 2.f;
+  const int kb = (((n + 15) & ~15) + FRAME_THREADS - 1) / FRAME_THREADS;
   printf("n = %d\n", n);
-  if (n <= 16384) printf("k_frame_ingest<16> (sort + gather + cov, one block): %.1f us\n", time_us([&] { hipLaunchKernelGGL(k_frame_ingest<16>, dim3(1), dim3(1024), 0, 0, a); }));
+  printf("k_frame_ingest (keys only, %d blocks): %.1f us\n", kb, time_us([&] { hipLaunchKernelGGL(k_frame_ingest, dim3(kb), dim3(FRAME_THREADS), 0, 0, a); }));
+  printf("k_scan_rank (order by counting + gather + cov, %d blocks of %d): %.1f us\n", (n + 63) / 64, RANK_THREADS, time_us([&] { hipLaunchKernelGGL(k_scan_rank, dim3((n + 63) / 64), dim3(RANK_THREADS), 0, 0, r); }));
+  printf("both, back to back: %.1f us\n", time_us([&] { hipLaunchKernelGGL(k_frame_ingest, dim3(kb), dim3(FRAME_THREADS), 0, 0, a); hipLaunchKernelGGL(k_scan_rank, dim3((n + 63) / 64), dim3(RANK_THREADS), 0, 0, r); }));
   using A = rocprim::block_radix_rank_algorithm;
 #define SORT(IPT, BITS, ALG, NAME) if (n <= IPT * 1024) printf("sort only IPT=%d bits=%d %s: %.1f us\n", IPT, BITS, NAME, time_us([&] { hipLaunchKernelGGL((k_sort_only<IPT, BITS, ALG>), dim3(1), dim3(1024), 0, 0, xyz, n, inv, perm2); }))
   SORT(16, 8, A::match, "match"); SORT(16, 4, A::basic_memoize, "basic_memoize"); SORT(16, 4, A::match, "match"); SORT(16, 6, A::match, "match"); SORT(16, 5, A::basic_memoize, "basic_memoize"); SORT(16, 6, A::basic_memoize, "basic_memoize");
   SORT(12, 8, A::match, "match"); SORT(12, 4, A::basic_memoize, "basic_memoize"); SORT(12, 6, A::basic_memoize, "basic_memoize"); SORT(11, 6, A::basic_memoize, "basic_memoize");
   SORT(8, 8, A::match, "match"); SORT(8, 4, A::basic_memoize, "basic_memoize"); SORT(4, 8, A::match, "match"); SORT(4, 4, A::basic_memoize, "basic_memoize");
-  const ScanSmallOut so = {xyz, x, y, z, perm, cb, a.deg2rad, a.range_inc, a.degree_inc, n};
+  const ScanSmallOut so = {xyz, x, y, z, perm, cb, r.deg2rad, r.range_inc, r.degree_inc, n};
   printf("gather + cov, %d blocks of 256: %.1f us\n", (n + 255) / 256, time_us([&] { hipLaunchKernelGGL(k_gather_cov, dim3((n + 255) / 256), dim3(256), 0, 0, so); }));
-  // same permutation from every variant?
+  // the counted order against a stable sort on the host, and against the last block-sort variant that fits
   std::vector<int32_t> p1(n), p2(n); CK(hipMemcpy(p1.data(), perm, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(p2.data(), perm2, n * 4, hipMemcpyDeviceToHost));
-  printf("perm of the last variant == perm of k_frame_ingest<16>: %s\n", (n <= 4096 && p1 == p2) ? "yes" : (n <= 4096 ? "NO" : "(n > 4096: last variant not run)"));
+  std::vector<uint32_t> hk(n); CK(hipMemcpy(hk.data(), keys, n * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> ref(n); for (int i = 0; i < n; i++) ref[i] = i;
+  std::stable_sort(ref.begin(), ref.end(), [&](int32_t u, int32_t v) { return hk[u] < hk[v]; });
+  printf("perm of k_scan_rank == std::stable_sort by key: %s ; == last block-sort variant: %s\n", p1 == ref ? "yes" : "NO", p1 == p2 ? "yes" : "NO");
   return 0;
 }
