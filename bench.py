@@ -315,7 +315,7 @@ def c5_leg(ctx, livo2, frames_mod, cfgs, dist, device, rank, world, n_distinct, 
             "frames_per_s_per_rank_frame_api": out["frame_api"][4], "frames_per_s_frame_api_untimed_ramp_passes": ramps.get("frame_api"),
             "frames_per_s_frame_api_one_context_untimed_ramp_passes": ramps.get("frame_api_one_context"),
             "frame_api": "livo2_frame_update_async / _fetch: the whole LIO + VIO frame as ONE library call, two frames in flight per context, the LiDAR posterior handed to the visual update on "
-                         "the device (round 5); same records bit for bit (gathered_copy_check); livo2_frame_in structs built ahead of the timed pass, which follows up to five untimed passes over the same "
+                         "the device (round 5), the frame's inputs scattered by ONE launch that reads the pinned staging block, a small scan ordered by counting instead of a sort, the results published by one launch (fast-livo2_amd/csrc/frame_kernels.hpp); same records bit for bit (gathered_copy_check); livo2_frame_in structs built ahead of the timed pass, which follows up to five untimed passes over the same "
                          "frames (clock ramp: their rates are listed); frames_per_s (below) stays the round-4 methodology: four calls per frame, three contexts, ONE warm-up frame",
             "frames_per_s": len(frames) / dtk, "contexts_per_gpu": C5_CONTEXTS, "ms_per_frame_per_gpu": 1e3 * dtk / per_rank, "evals_per_s": evk / dtk,
             "frames_per_s_per_rank": fpsk, "all_gather_ms": 1e3 * gk,

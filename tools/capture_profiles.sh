@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r04}
 ROOT=$(pwd); export TMPDIR=/tmp
-cp .c4cache/livo2_c4_*.pkl /tmp/ 2>/dev/null          # the headline frame, if a generated copy travelled with the tree (bench.c4_frame caches it under $TMPDIR; ~40 s of numpy otherwise)
+cp .c4cache/livo2_c4_*.pkl .c4cache/livo2_c5_*.pkl /tmp/ 2>/dev/null          # the headline frame, if a generated copy travelled with the tree (bench.c4_frame caches it under $TMPDIR; ~40 s of numpy otherwise)
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p "$OUT"
 python tools/traffic.py sha > "$OUT/build_sha.txt"
 HEAD="python bench.py --no-cpu --no-extra --steps 10 --warmup 2"
@@ -44,5 +44,10 @@ cp gpurun_out/${TAG}_traffic_*.json profiles/ 2>/dev/null
 # 5. the bench line (default command + --full: every informational leg in the full report; the stdout line is the default command's), LAST (its roofline.traffic now cites the records above), then the probes
 timeout 1200 python bench.py --full > "$OUT/bench.json" 2> "$OUT/bench.err"; cp gpurun_out/bench_full.json "$OUT/bench_full.json"
 [ -n "${SKIP_VIS_PROBE:-}" ] || timeout 300 python tools/vis_persist_probe.py > "$OUT/vis_persist_probe.txt" 2> "$OUT/vis_persist_probe.err"
+# 6. the C1-shaped frame through the whole-frame API (the reference's operating point): rates, and the kernel trace of its launch chain
+timeout 200 python tools/frame_probe.py c1 32 3 > "$OUT/frame_api_probe.txt" 2> "$OUT/frame_api_probe.err"
+rm -rf /tmp/ktf; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/ktf -o kt -- python tools/frame_probe.py c1 32 1 > /dev/null 2>> "$OUT/kt.err"
+python tools/kt_summary.py "$(db /tmp/ktf)" "rocprofv3 --kernel-trace --stats -- python tools/frame_probe.py c1 32 1 (C1-shaped frames, livo2_frame_update_async / _fetch)" --split-us 3 > "$OUT/kernel_trace_stats_c1_frame.txt"
+[ -n "${SKIP_SUITE:-}" ] || timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu.txt" 2>&1
 timeout 900 python tests/sweeps/parity_sweep.py ${SWEEP_ARGS:-12 8} > "$OUT/parity_sweep.txt" 2> "$OUT/parity_sweep.err"
 ls -la "$OUT"
