@@ -50,3 +50,40 @@ def test_counted_positions_are_the_stable_order(n, key_bits):
     want = np.empty(n, np.int64); want[order] = np.arange(n)
     assert np.array_equal(pos, want)
     assert np.array_equal(np.sort(pos), np.arange(n))                        # a permutation: every output slot written exactly once
+
+
+FRAME_COPY_BLOCKS, FRAME_THREADS = 64, 256
+
+
+def model_copy_counts(nbytes):
+    """how often every byte of a segment is written by the copy blocks of k_frame_ingest (frame_kernels.hpp): 16-byte units, four per thread and trip while four strides
+    fit, then one per trip, then the < 16 tail bytes by the first threads of block 0"""
+    units, tail = nbytes >> 4, nbytes & 15
+    stride = FRAME_COPY_BLOCKS * FRAME_THREADS
+    hits = np.zeros(nbytes, np.int64)
+    u0 = np.arange(stride)                                                  # one entry per (block, thread)
+    u = u0.copy()
+    while True:
+        go = u + 3 * stride < units
+        if not go.any():
+            break
+        for q in range(4):
+            for x in (u[go] + q * stride):
+                hits[x * 16:(x + 1) * 16] += 1
+        u = np.where(go, u + 4 * stride, u)
+    while True:
+        go = u < units
+        if not go.any():
+            break
+        for x in u[go]:
+            hits[x * 16:(x + 1) * 16] += 1
+        u = np.where(go, u + stride, u)
+    for t in range(tail):
+        hits[(units << 4) + t] += 1
+    return hits
+
+
+@pytest.mark.parametrize("nbytes", [0, 1, 15, 16, 17, 6280, 4096 * 16, 4096 * 16 + 4, 64 * 256 * 16 - 16, 64 * 256 * 16, 64 * 256 * 16 * 4 + 12, 64 * 256 * 16 * 5 + 16 * 77 + 3, 358400, 327680])
+def test_every_byte_of_a_segment_is_copied_exactly_once(nbytes):
+    hits = model_copy_counts(nbytes)
+    assert hits.shape == (nbytes,) and (hits == 1).all()
