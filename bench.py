@@ -138,6 +138,9 @@ def emit_selftest(args):
     full["pre_warm_s"] = args.pre_warm_s
     full["extra"] = dict(full.get("extra") or {}, big_note="x" * 65536, nan=float("nan"), inf=float("inf"), np_scalar=np.float32(1.5), np_int=np.int64(3), arr=np.arange(3))
     full["roofline"]["evals_per_s_in_event_pass"] = float("nan")
+    from tools import traffic as traffic_mod              # the cross-reference of the real run: the committed kernel trace of this build, if any
+    t_us, t_n, t_src = traffic_mod.committed_trace_us("k_lidar_residual<")
+    full["roofline"].update({"kernel_us_rocprofv3": t_us, "frac_rocprofv3": (LIDAR_BYTES_PER_EVAL * 200000 / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if t_us else None, "rocprofv3_src": t_src})
     emit(full)
 
 
@@ -411,7 +414,7 @@ def compact_line(full):
     notes) goes to the full report (gpurun_out/bench_full.json + one stderr line) — BENCH_r03.json could not be parsed because the single line had grown to 22 KB."""
     rf, cpu = full["roofline"], full.get("cpu_baseline")
     keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_src", "kernel_us", "per_rank_kernel_us", "per_rank_frame_update_us", "bytes_per_launch",
-            "launches_executed", "copy_kernel_GBps", "frac_of_copy_kernel")
+            "launches_executed", "copy_kernel_GBps", "frac_of_copy_kernel", "kernel_us_rocprofv3", "frac_rocprofv3", "rocprofv3_src")
     roof = {k: rf.get(k) for k in keep}
     if rf.get("visual"):
         roof["visual"] = {k: rf["visual"].get(k) for k in ("kernel", "achieved", "frac", "kernel_us", "bytes_per_launch", "launches_executed")}
@@ -661,7 +664,11 @@ def main():
     from tools import traffic as traffic_mod
     traffic, traffic_note = traffic_mod.load("c4", points=w.N, kernel="k_lidar_residual")
     frames_ev = w.F * ev_steps
+    # the committed rocprofv3 kernel trace of THIS build (another run, possibly another box): the kernel's own average duration beside the live event bracket around its launch
+    trace_us, trace_launches, trace_src = traffic_mod.committed_trace_us("k_lidar_residual<")
     roofline = {"bound": "hbm", "kernel": "k_lidar_residual", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "kernel_us_rocprofv3": trace_us, "frac_rocprofv3": (LIDAR_BYTES_PER_EVAL * w.N / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if trace_us else None,
+                "rocprofv3_src": trace_src, "rocprofv3_launches": trace_launches,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note, "traffic_src": traffic_note.split(":")[0] if traffic else None,
                 "kernel_us": res_us, "per_rank_kernel_us": [round(float(x), 3) for x in per_rank_us[:, 0]], "per_rank_lidar_solve_us": [round(float(x), 3) for x in per_rank_us[:, 1]],
                 "per_rank_visual_step_us": [round(float(x), 3) for x in per_rank_us[:, 2]], "per_rank_frame_update_us": [round(float(x), 2) for x in per_rank_us[:, 3]],

@@ -49,3 +49,24 @@ def test_traffic_records_are_tied_to_the_build():
         assert (val is not None) == bool(matching), (wl, note)
         if val is None:
             assert "no PMC capture of this build" in note
+
+
+def test_committed_kernel_trace_is_quoted_only_for_the_build_it_was_taken_from():
+    """bench.py puts the rocprofv3 kernel-only duration of k_lidar_residual from the committed trace BESIDE its live event timing (roofline.kernel_us_rocprofv3 /
+    frac_rocprofv3) — under the same rule as the traffic records: only a capture of THIS device code (tools/traffic.py::committed_trace_us)"""
+    sys.path.insert(0, ROOT)
+    from tools import traffic
+    import glob
+    want = traffic.csrc_sha()
+    us, launches, src = traffic.committed_trace_us("k_lidar_residual<")
+    tags = [os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_trace_stats_c4.txt"))]
+    matching = [t for t in tags if os.path.exists(os.path.join(ROOT, "profiles", t + "_build_sha.txt")) and open(os.path.join(ROOT, "profiles", t + "_build_sha.txt")).read().split()[0] == want]
+    assert (us is not None) == bool(matching), src
+    if us is not None:
+        assert 5.0 < us < 100.0 and launches > 100 and src.startswith("profiles/")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emit-selftest"], capture_output=True, text=True, timeout=300)
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+        assert out["roofline"]["kernel_us_rocprofv3"] == us and out["roofline"]["rocprofv3_src"] == src
+        assert abs(out["roofline"]["frac_rocprofv3"] - 276.0 * 200000 / (us * 1e-6) / 8e12) < 1e-9
+    else:
+        assert "no committed kernel trace of this build" in src

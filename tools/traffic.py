@@ -11,6 +11,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import sqlite3
 import sys
 
@@ -52,6 +53,28 @@ def load(workload, **match):
         if all(rec.get(k) == v for k, v in match.items()):
             return (rec["fetch_size_kb_reported"] * rec["fetch_correction"] + rec["write_size_kb"]) * 1024.0, f"{name}: {rec['source']}"
     return None, ("no PMC capture of this build (csrc_sha %s)%s" % (want, "; captures of other builds not quoted: " + ", ".join(stale) if stale else ""))
+
+
+def committed_trace_us(kernel_prefix, which="c4"):
+    """(average kernel duration in us, launches, source) of `kernel_prefix` in the newest committed `rocprofv3 --kernel-trace --stats` summary
+    profiles/r*_rocprofv3_kernel_trace_stats_<which>.txt whose capture (profiles/r*_build_sha.txt of the same tag) ran THIS device code; (None, None, note) otherwise.
+    bench.py quotes it BESIDE its own live event timing (another run, possibly another box): the kernel's own duration against the event bracket around its launch."""
+    want = csrc_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_rocprofv3_kernel_trace_stats_{which}.txt")), reverse=True):
+        tag = os.path.basename(path).split("_")[0]
+        try:
+            built = open(os.path.join(ROOT, "profiles", f"{tag}_build_sha.txt")).read().split()[0]
+        except (OSError, IndexError):
+            continue
+        if built != want:
+            continue
+        for ln in open(path):
+            if ln.startswith("#"):
+                continue
+            m = re.match(r"^(.*), (\d+), ([0-9.]+), ([0-9.]+), ([0-9.]+) \[", ln)          # name (may contain commas), calls, avg_us, min_us, max_us [...]
+            if m and kernel_prefix in m.group(1):
+                return float(m.group(3)), int(m.group(2)), "profiles/" + os.path.basename(path)
+    return None, None, "no committed kernel trace of this build (csrc_sha %s)" % want
 
 
 def _counter(db, kernel, counter, use_max):
