@@ -481,37 +481,12 @@ def cpu_baseline(sc, vs, budget_s=20.0):
             runs += 1
         out[threads] = dict(value=(le + ve) / (ls + vsec), lidar=le / ls, visual=ve / vsec, runs=runs, lidar_ms=1e3 * ls / runs, visual_ms=1e3 * vsec / runs)
     o4 = out[4]
-    ref_build = reference_sources_timing(orc, sc, vs, cur, prop, vcur, vprop, o4)
-    return {"reference_sources": ref_build, "value": o4["value"], "unit": "evals/s", "cores": 4, "kind": "port",
+    return {"value": o4["value"], "unit": "evals/s", "cores": 4, "kind": "port",
             "sample": f"{o4['runs']} frame updates of the same C4 frame ({len(sc.xyz)} points + {len(vs.pos)} patches): StateEstimation window (LIVMapper.cpp:368-374) + "
                       f"computeJacobianAndUpdateEKF window (vio.cpp:1808-1812), OpenMP 4 threads (reference MP_PROC_NUM cap), {flags}",
             "lidar_evals_per_s": o4["lidar"], "visual_evals_per_s": o4["visual"], "lidar_update_ms": o4["lidar_ms"], "visual_update_ms": o4["visual_ms"],
             "value_1thread": out[1]["value"], "lidar_evals_per_s_1thread": out[1]["lidar"], "visual_evals_per_s_1thread": out[1]["visual"],
             "value_all_cores": out[ncores]["value"], "host_cores": ncores}, (orc, lib, orc_chain)
-
-
-def reference_sources_timing(orc, sc, vs, cur, prop, vcur, vprop, o4):
-    """The reference's OWN translation units (oracle/_ref/libref_mp4.so: voxel_map.cpp / vio.cpp compiled unmodified with -DMP_EN -DMP_PROC_NUM=4 against the
-    stand-in headers of oracle/ref_build/stubs, -O2 -ffp-contract=off) on the same C4 frame, same two windows.  A datum beside the port, not the baseline: the
-    stand-in Eigen evaluates eagerly without Eigen's vectorised kernels, and the library is the portable -O2 build that travelled with the snapshot."""
-    path = os.path.join(ROOT, "oracle", "_ref", "libref_mp4.so")
-    if not os.path.exists(path):
-        return None
-    try:
-        rlib = orc.load(path)
-        rom = orc.OracleMap.from_flat(sc.fmap, rlib)
-        cfg = orc.lidar_cfg(sc.cfg, sc.extR, sc.extT, num_threads=4)
-        vcfg = orc.visual_cfg(vs, num_threads=4)
-        ls, vsec, runs = [], [], 0
-        while runs < 3:
-            r = orc.lidar_state_estimation(rom, cfg, sc.xyz, cur, prop, want_points=False)
-            v = orc.visual_update(vcfg, vs, vcur, vprop, rlib)
-            ls.append(r["seconds"]); vsec.append(v["seconds"]); runs += 1
-        return {"lidar_update_ms": 1e3 * min(ls), "visual_update_ms": 1e3 * min(vsec), "runs": runs, "threads": 4,
-                "build": "oracle/ref_build/Makefile: g++ -O2 -ffp-contract=off -fopenmp -DMP_EN -DMP_PROC_NUM=4, reference sources unmodified, stand-in Eigen/PCL/OpenCV/vikit headers",
-                "port_lidar_update_ms": o4["lidar_ms"], "port_visual_update_ms": o4["visual_ms"]}
-    except Exception as exc:                                                              # the checker must never take the bench line down
-        return {"error": repr(exc)}
 
 
 def cpu_widened_rows(orc, lib, orc_chain):

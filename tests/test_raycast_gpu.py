@@ -1,5 +1,5 @@
 """vio/raycast_en = true on the device (fast-livo2_amd/csrc/raycast_kernels.hpp) against the oracle's restatement of the RayCasting module (reference
-src/vio.cpp:487-591 with the rays of initializeVIO, vio.cpp:80-118; the oracle is pinned to the reference's own loop by tests/test_ref_pin_cpu.py).  The LiDAR
+src/vio.cpp:487-591 with the rays of initializeVIO, vio.cpp:80-118).  The LiDAR
 VoxelMap the rays look into (plane_map) is the device-resident tree of the same context, built from the same points as the oracle's map.
 Compared: which cells end TYPE_MAP, the point and float distance every cell keeps, in_fov, add_from_voxel_map (center_ exactly; normal_ up to the sign the eigen-solver
 gives), and the whole retrieval (sub-map members, float errors, warped patches) downstream of that selection."""

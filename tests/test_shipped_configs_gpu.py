@@ -5,8 +5,7 @@ img_point_cov 1000, 2448 x 2048 camera at scale 0.25) — scenarios/shipped_conf
   * BuildVoxelMap on the device (livo2_map_tree_*) == the oracle's octree; the LIO update (StateEstimation) reading that device tree == the oracle on the exported
     map, decisions bit for bit; UpdateVoxelMap from the posterior keeps the trees equal;
   * the VIO update (computeJacobianAndUpdateEKF) with the configuration's camera model, pyramid depth, img_point_cov and extrinsics == the oracle;
-  * retrieveFromVisualSparseMap with the configuration's camera / grid / outlier_threshold == the oracle;
-  * at small size the LIO and VIO updates against the reference's OWN translation units (oracle/_ref/libref.so), without the oracle in between."""
+  * retrieveFromVisualSparseMap with the configuration's camera / grid / outlier_threshold == the oracle."""
 import os
 
 import numpy as np
@@ -113,48 +112,3 @@ def test_retrieve_from_visual_sparse_map(ctx, orc, profile):
     cs.sel.cam = SC.cam_dict(profile)                                                    # the configuration's distortion model in world2cam / cam2world
     ref, out = _compare_chain(ctx, orc, cs)
     assert len(ref["cand_cell"]) > 150 and len(ref["sub_point"]) > 40
-
-
-@pytest.fixture(scope="module")
-def refbuild(orc):
-    path = os.path.join(ROOT, "oracle", "_ref", "libref.so")
-    if not os.path.exists(path):
-        pytest.skip("oracle/_ref/libref.so was not built (it is built by __graft_entry__.build() where /root/reference exists)")
-    return orc.load(path)
-
-
-@pytest.mark.parametrize("profile", NAMES)
-def test_against_the_reference_build_at_small_size(ctx, livo2, orc, refbuild, profile):
-    """HIP vs voxel_map.cpp / vio.cpp compiled unmodified (no oracle in between): LIO update on the exported device tree, VIO update with the profile's camera."""
-    s = SC.lio_scene(profile, seed=500 + NAMES.index(profile), n_map=30000, n_scan=5000)
-    c = s["cfg"]
-    ctx.map_tree_create(c, max_roots=40000)
-    ctx.map_tree_update(s["pw0"], s["var0"], build=True)
-    fm = _flat(ctx.map_tree_export(), c)
-    sc = _lidar_scenario(s, fm)
-    pcfg = H.lidar_cfg_product(sc)
-    pcur, pprop = H.states(sc, livo2.State)
-    ctx.set_scan(sc.xyz, pcfg)
-    res, pts = ctx.lidar_update(pcur, pprop, pcfg, want=("match_plane", "dis_to_plane", "point_w"))
-    cur, prop = H.states(sc, orc.StatePOD)
-    r = orc.lidar_state_estimation(orc.OracleMap.from_flat(fm, refbuild), orc.lidar_cfg(c, s["extR"], s["extT"]), sc.xyz, cur, prop)
-    assert res.n_iters == r["n_iters"] and [res.iter_sums[i].n_eff for i in range(res.n_iters)] == [t.n_eff for t in r["trace"]]
-    assert np.array_equal(pts["match_plane"], r["match_plane"]) and np.array_equal(pts["dis_to_plane"], r["dis"]) and np.array_equal(pts["point_w"], r["pw"])
-    d = H.state_diff(res.state, r["state"])
-    assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-8, d
-    ctx.upload_map(fm)
-    vs = SC.visual_scene(profile, seed=600 + NAMES.index(profile), n_patches=300)
-    kw = SC.cam_kw(profile)
-    cur, prop = H.states(vs, orc.StatePOD)
-    rv = orc.visual_update(orc.visual_cfg(vs, num_threads=1, **kw), vs, cur, prop, lib=refbuild)
-    pcur, pprop = H.states(vs, livo2.State)
-    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
-    resv, errors = ctx.visual_update(pcur, pprop, H.visual_cfg_product(vs, mp_proc_num=1, **kw))
-    # (unmodified reference code exposes no per-step trace: the per-patch float errors of the last evaluated step, the final state / covariance and G pin the run)
-    if "distortion" in kw:
-        assert np.array_equal(errors, rv["errors"])
-    else:
-        assert np.allclose(errors, rv["errors"], rtol=1e-4)
-    d = H.state_diff(resv.state, rv["state"])
-    assert d["R"] < 1e-8 and d["t"] < 1e-8 and d["P"] < 1e-7 and d["inv_expo"] < 1e-8, d
-    assert H.relerr(np.array(resv.G).reshape(19, 19), rv["G"]) < 1e-6
