@@ -413,7 +413,9 @@ def compact_line(full):
     """The ONE stdout line of the driver contract: the headline fields + roofline + cpu_baseline, < 4 KB, strict JSON.  Everything else (`extra`, the verbose
     notes) goes to the full report (gpurun_out/bench_full.json + one stderr line) — BENCH_r03.json could not be parsed because the single line had grown to 22 KB."""
     rf, cpu = full["roofline"], full.get("cpu_baseline")
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_src", "kernel_us", "per_rank_kernel_us", "per_rank_frame_update_us", "bytes_per_launch",
+    # live measurements first; the figures read back from a committed rocprofv3 capture of the same build (another run, possibly another box) last and labelled as such
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_src", "kernel_us", "kernel_us_device", "frac_device", "device_clock_launches",
+            "per_rank_kernel_us", "per_rank_kernel_us_device", "per_rank_lidar_solve_us", "per_rank_frame_update_us", "box_kind", "bytes_per_launch",
             "launches_executed", "copy_kernel_GBps", "frac_of_copy_kernel", "kernel_us_rocprofv3", "frac_rocprofv3", "rocprofv3_src")
     roof = {k: rf.get(k) for k in keep}
     if rf.get("visual"):
@@ -622,10 +624,15 @@ def main():
         ctx.kernel_timing_read(b)
     ev_steps = max(1, min(args.steps, 8))
     vp0 = ctx.counter("visual_persistent_launches")
+    dev0 = (ctx.counter("lidar_residual_device_ticks"), ctx.counter("lidar_residual_device_launches"))
     t1 = time.perf_counter()
     w.run(ev_steps); ctx.synchronize()
     ev_elapsed = time.perf_counter() - t1
     bins = [ctx.kernel_timing_read(b) for b in range(4)]       # (total ms, launches) of LiDAR residual, visual residual (or the persistent visual update), LiDAR solve, visual solve
+    # k_lidar_residual's OWN duration in this pass, from the device: first block's start to last block's end on the chip-wide 100-MHz clock (s_memrealtime stamps of every
+    # block, folded by k_lidar_span_acc behind each solve; executed launches only) — no profiler, no launch-boundary cost of an event pair
+    dev_ticks, dev_launches = ctx.counter("lidar_residual_device_ticks") - dev0[0], ctx.counter("lidar_residual_device_launches") - dev0[1]
+    res_dev_us = 0.01 * dev_ticks / dev_launches if dev_launches > 0 else float("nan")
     vp_launches = ctx.counter("visual_persistent_launches") - vp0
     ctx.kernel_timing(False)
     n_lid, n_vis = sum(w.iters) * ev_steps, sum(w.vsteps) * ev_steps            # executed launches (the rest exit at their first instruction)
@@ -634,7 +641,7 @@ def main():
     achieved = LIDAR_BYTES_PER_EVAL * w.N / (res_us * 1e-6) / 1e9
     vachieved = VISUAL_BYTES_PER_PATCH * w.M / (vres_us * 1e-6) / 1e9
     # every rank's own kernel times, gathered: a straggler GPU of an 8-GPU node shows up in the one line
-    per_rank_us = frames.gather_results(np.array([[res_us, sol_us, vres_us, 1e6 * elapsed_local / (w.F * args.steps)]]), world, dist, device=device)
+    per_rank_us = frames.gather_results(np.array([[res_us, sol_us, vres_us, 1e6 * elapsed_local / (w.F * args.steps), res_dev_us]]), world, dist, device=device)
     copy_gbs = measure_copy_gbs(torch)
     from tools import traffic as traffic_mod
     traffic, traffic_note = traffic_mod.load("c4", points=w.N, kernel="k_lidar_residual")
@@ -645,7 +652,13 @@ def main():
                 "kernel_us_rocprofv3": trace_us, "frac_rocprofv3": (LIDAR_BYTES_PER_EVAL * w.N / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if trace_us else None,
                 "rocprofv3_src": trace_src, "rocprofv3_launches": trace_launches,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note, "traffic_src": traffic_note.split(":")[0] if traffic else None,
-                "kernel_us": res_us, "per_rank_kernel_us": [round(float(x), 3) for x in per_rank_us[:, 0]], "per_rank_lidar_solve_us": [round(float(x), 3) for x in per_rank_us[:, 1]],
+                "kernel_us": res_us, "kernel_us_device": res_dev_us, "frac_device": LIDAR_BYTES_PER_EVAL * w.N / (res_dev_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "device_clock_launches": int(dev_launches),
+                "device_clock": "kernel_us_device = (last block's end - first block's start) of k_lidar_residual on the device's 100-MHz clock (10-ns ticks), averaged over the executed "
+                                "launches of this event pass; kernel_us = the HIP event pair around the same launches (includes the launch boundary)",
+                "per_rank_kernel_us_device": [round(float(x), 3) for x in per_rank_us[:, 4]],
+                # the pool has two kinds of box (same binary: 1.13e10 - 1.28e10 evals/s); the single-block solve shows it first (profiles/r05_solve_by_position.txt)
+                "box_kind": "slow" if sol_us > 12.0 else "fast",
+                "per_rank_kernel_us": [round(float(x), 3) for x in per_rank_us[:, 0]], "per_rank_lidar_solve_us": [round(float(x), 3) for x in per_rank_us[:, 1]],
                 "per_rank_visual_step_us": [round(float(x), 3) for x in per_rank_us[:, 2]], "per_rank_frame_update_us": [round(float(x), 2) for x in per_rank_us[:, 3]],
                 "bytes_per_launch": LIDAR_BYTES_PER_EVAL * w.N, "launches_executed": n_lid, "launches_timed": int(bins[0][1]),
                 "copy_kernel_GBps": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs,

@@ -41,6 +41,9 @@ struct LidarKernelArgs {
   double ER[9], Et[3];
   // optional per-point outputs (device pointers or null)
   int32_t *match_plane; float *dis; float *pw; int32_t *normal_plane; double *var; double *r_inv; double *h_row;
+  // round 6 — fewer issued instructions per point (the pass is bound by them, profiles/r04_l2_retention_probe.txt):
+  double inv_voxel_size;           // 1 / voxel_size when that is exact (voxel_size a power of two: every shipped LiDAR config but HILTI22's 0.4), else 0: the key needs a true division
+  double sn2_lo, sn2_hi;           // sigma_num^2 (1 -+ 1e-14): the 3-sigma gate without its square root outside a 2e-14 band (sigma_gate_and_row)
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *prof;        // [waves][8] s_memtime stamps (profiling build only)
 #endif
@@ -243,7 +246,7 @@ struct StateRefs {               // ONE base pointer: every operand is a scalar 
   __device__ __forceinline__ const double *tp() const { return ctl->prop.pos; }
 };
 __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double *c, const double *See, const double *pv, double pk, const GateOut &g, int32_t pidx,
-                                                   double sigma_num, const double *pc, const double *pi, const double *Cb, const StateRefs &st, Best &best) {
+                                                   double sigma_num, double sn2_lo, double sn2_hi, const double *pc, const double *pi, const double *Cb, const StateRefs &st, Best &best) {
   // sigma_l = J_nq plane_var J_nq^T + n^T Sigma_w n ,  J_nq = [p_w - c, -n]
   const double aw[3] = {-g.e[0], -g.e[1], -g.e[2]};
   double sigma_l = quad_plane(See, pv, pk, aw);
@@ -256,13 +259,18 @@ __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double
     for (int e = 0; e < 6; e++) { sPrr[e] = st.sP[e]; sPtt[e] = st.sP[6 + e]; }
     sigma_l += (quad3_sym(Cb, m) + quad3_sym(sPrr, qx)) + quad3_sym(sPtt, n);
   }
-  const double sq = sqrt(sigma_l);
-  if ((double)g.dis_to_plane < sigma_num * sq) {
-    const double dis2 = (double)g.dis_to_plane * (double)g.dis_to_plane;
+  // 3-sigma gate  dis < sigma_num * sqrt(sigma_l)  (voxel_map.cpp:737).  The square root (a 16-cycle v_rsq_f64 + ~10 dependent f64 operations) only decides
+  // when dis^2 lies within 1e-14 (relative) of sigma_num^2 sigma_l: both roundings of the reference's right-hand side are 2^-53 each and the three of the squared
+  // form another 3 x 2^-53, so outside the band the two forms agree by construction; inside it (and for NaN / negative sigma_l, which fail both fast tests) the
+  // reference's expression is evaluated as written.
+  const double dd = (double)g.dis_to_plane, dis2 = dd * dd;
+  bool pass = dis2 < sn2_lo * sigma_l;
+  if (!pass && !(dis2 > sn2_hi * sigma_l)) pass = dd < sigma_num * sqrt(sigma_l);
+  if (pass) {
     bool take = true;
     if (best.success) {
       if (!best.prob_valid) { best.prob = 1.0 / sqrt(best.sigma) * exp(-0.5 * best.dis2 / best.sigma); best.prob_valid = true; }
-      const double this_prob = 1.0 / sq * exp(-0.5 * dis2 / sigma_l);
+      const double this_prob = 1.0 / sqrt(sigma_l) * exp(-0.5 * dis2 / sigma_l);
       take = this_prob > best.prob;
       if (take) best.prob = this_prob;
     }
@@ -270,13 +278,17 @@ __device__ __forceinline__ void sigma_gate_and_row(const double *n, const double
     if (take) {
       best.plane = pidx; best.r = (float)g.sd; best.dis2 = dis2; best.sigma = sigma_l;
       // H / R^-1 row (voxel_map.cpp:414-458): sigma_l' at the PRIOR-pose point, var with the PRIOR rotation, A with the CURRENT one
-      double q[3];                                          // PRIOR-pose world point R^ p_i + t^, un-rounded (voxel_map.cpp:425)
+      // (R^-1 depends on the prior pose only; keeping it per point from one iteration to the next — 12 B per point read in T1, written on change — was built and
+      //  measured: +1.0 us per iteration, profiles/r06_lidar_instruction_ab.txt.  Recomputed.)
+      {
+        double q[3];                                          // PRIOR-pose world point R^ p_i + t^, un-rounded (voxel_map.cpp:425)
 #pragma unroll
-      for (int j = 0; j < 3; j++) q[j] = ((st.Rp()[j * 3] * pi[0] + st.Rp()[j * 3 + 1] * pi[1]) + st.Rp()[j * 3 + 2] * pi[2]) + st.tp()[j];
-      const double aq[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
-      const double sig_q = quad_plane(See, pv, pk, aq);
-      double mp[3]; mat3t_vec_fma(st.RE(), n, mp);            // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
-      best.w = 1.0 / (0.001 + sig_q + quad3_sym(Cb, mp));
+        for (int j = 0; j < 3; j++) q[j] = ((st.Rp()[j * 3] * pi[0] + st.Rp()[j * 3 + 1] * pi[1]) + st.Rp()[j * 3 + 2] * pi[2]) + st.tp()[j];
+        const double aq[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+        const double sig_q = quad_plane(See, pv, pk, aq);
+        double mp[3]; mat3t_vec_fma(st.RE(), n, mp);            // (R^ extR)^T n ; n^T var n = mp^T Cb mp   (voxel_map.cpp:445,449)
+        best.w = 1.0 / (0.001 + sig_q + quad3_sym(Cb, mp));
+      }
       best.h[0] = pi[1] * m[2] - pi[2] * m[1];             // A = [p_i]x R^T n = p_i x (R^T n)   (voxel_map.cpp:453)
       best.h[1] = pi[2] * m[0] - pi[0] * m[2];
       best.h[2] = pi[0] * m[1] - pi[1] * m[0];
@@ -315,13 +327,21 @@ __device__ __forceinline__ bool head_match(const SlotHead &s, const int32_t key[
 //    (coop_plan / coop_run below), in depth-first order so that ties keep the first.
 struct RootRef { int32_t val, cand_begin, cand_count; };   // what a visit needs from a RootSlot
 
-__device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx, double sigma_num, const PointCtx &pt, const double *ER, const double *Et,
+struct LidarKernelArgs;
+struct GateConsts {                // the gate's three launch constants, read where they are used (scalar loads from the argument block: no SGPRs held across the body)
+  const double *p;                 // -> {sigma_num, ..., sn2_lo, sn2_hi} inside LidarKernelArgs
+  int off_lo, off_hi;
+  __device__ __forceinline__ double sigma_num() const { return p[0]; }
+  __device__ __forceinline__ double sn2_lo() const { return p[off_lo]; }
+  __device__ __forceinline__ double sn2_hi() const { return p[off_hi]; }
+};
+__device__ __forceinline__ void visit_plane_root(const PlaneRec &p, int32_t pidx, const GateConsts &gc, const PointCtx &pt, const double *ER, const double *Et,
                                                  const StateRefs &st, Best &best) {
   GateOut g;
   const double pw[3] = {(double)pt.pwf[0], (double)pt.pwf[1], (double)pt.pwf[2]};
   if (radius_gate(p.n, p.c, p.d, p.radius, pw, g)) {
     double pc[3]; point_pc(pt, ER, Et, pc);
-    sigma_gate_and_row(p.n, p.c, p.See, p.v, p.k, g, pidx, sigma_num, pc, pt.pi, pt.Cb, st, best);
+    sigma_gate_and_row(p.n, p.c, p.See, p.v, p.k, g, pidx, gc.sigma_num(), gc.sn2_lo(), gc.sn2_hi(), pc, pt.pi, pt.Cb, st, best);
   }
 }
 
@@ -402,7 +422,7 @@ template <int BLOCK> __device__ __forceinline__ void coop_unpark_ctx(const CoopL
 // the winner — LDS max over the probability bit patterns (accepted probabilities are non-negative, so the patterns order like the
 // values), then LDS min over the slots holding that maximum (ascending slot = list order -> the first one) — and the owner copies
 // one row (walking its accepted rows cost a dependent LDS round trip per accepted plane, ~1.8 us in cluttered blocks).
-template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int base, int max_layer, double sigma_num,
+template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int base, int max_layer, const GateConsts &gc,
                                                               const StateRefs &st, Best &best COOP_PROF_PARAM) {
   const int tid = threadIdx.x;
   const int cnt = pl.cnt, cand_begin = pl.cand_begin, excl = pl.excl, W = pl.W;
@@ -483,7 +503,7 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
     Best tb; tb.success = false; tb.prob_valid = false; tb.prob = 0.0; tb.dis2 = 0.0; tb.sigma = 1.0; tb.w = 0.0; tb.plane = -1; tb.r = 0.f;
 #pragma unroll
     for (int u = 0; u < 6; u++) tb.h[u] = 0.0;
-    sigma_gate_and_row(n[q], c[q], See, pv, pk, g[q], meta[q] & CAND_PLANE_MASK, sigma_num, ppc, ppi, pCb, st, tb);
+    sigma_gate_and_row(n[q], c[q], See, pv, pk, g[q], meta[q] & CAND_PLANE_MASK, gc.sigma_num(), gc.sn2_lo(), gc.sn2_hi(), ppc, ppi, pCb, st, tb);
     if (tb.success) {
       const double prob = 1.0 / sqrt(tb.sigma) * exp(-0.5 * tb.dis2 / tb.sigma);
       int row = tid;
@@ -527,7 +547,7 @@ template <int PAIRS, int BLOCK> __device__ __forceinline__ bool coop_round(CoopL
 }
 
 // Evaluation half: every thread of the block calls it with its plan (W is block-uniform).
-template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int max_layer, double sigma_num,
+template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L, const DevMap &map, const CoopPlan &pl, int max_layer, const GateConsts &gc,
                                          const StateRefs &st, Best &best COOP_PROF_PARAM) {
 #ifdef LIVO2_PHASE_PROF
 #define COOP_PROF_FWD , cprof
@@ -535,8 +555,8 @@ template <int BLOCK> __device__ __forceinline__ void coop_run(CoopLds<BLOCK> &L,
 #define COOP_PROF_FWD
 #endif
   for (int base = 0; base < pl.W;) {
-    if (pl.W - base > BLOCK && coop_round<2, BLOCK>(L, map, pl, base, max_layer, sigma_num, st, best COOP_PROF_FWD)) { base += 2 * BLOCK; continue; }
-    coop_round<1, BLOCK>(L, map, pl, base, max_layer, sigma_num, st, best COOP_PROF_FWD);
+    if (pl.W - base > BLOCK && coop_round<2, BLOCK>(L, map, pl, base, max_layer, gc, st, best COOP_PROF_FWD)) { base += 2 * BLOCK; continue; }
+    coop_round<1, BLOCK>(L, map, pl, base, max_layer, gc, st, best COOP_PROF_FWD);
     base += BLOCK;
   }
 }
@@ -573,6 +593,7 @@ template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar
   pt.plx = a.x[ic]; pt.ply = a.y[ic]; pt.zpatch = (plz == 0);
 #pragma unroll
   for (int e = 0; e < 6; e++) Cb[e] = a.cb[(size_t)e * a.n + ic];
+  const GateConsts gc = {&a.sigma_num, (int)((offsetof(LidarKernelArgs, sn2_lo) - offsetof(LidarKernelArgs, sigma_num)) / 8), (int)((offsetof(LidarKernelArgs, sn2_hi) - offsetof(LidarKernelArgs, sigma_num)) / 8)};
   // p_i = extR * p_l + extT  (un-patched, voxel_map.cpp:522 / 418)
 #pragma unroll
   for (int j = 0; j < 3; j++) pi[j] = ((a.ER[j * 3] * plx + a.ER[j * 3 + 1] * ply) + a.ER[j * 3 + 2] * plz) + a.Et[j];
@@ -582,8 +603,14 @@ template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar
   // voxel key (voxel_map.cpp:665-671): double divide, narrow to float, -1 for negatives, truncate
   float loc[3]; int32_t key[3]; bool in_range = valid;
 #pragma unroll
+  for (int j = 0; j < 3; j++) loc[j] = (float)((double)pwf[j] * a.inv_voxel_size);       // power-of-two voxel_size: the product IS the quotient
+  if (__builtin_expect(a.inv_voxel_size == 0.0, 0)) {                                     // any other voxel_size (HILTI22's 0.4): the true division, ~12 f64 operations per axis
+#pragma unroll
+    for (int j = 0; j < 3; j++) loc[j] = (float)((double)pwf[j] / a.voxel_size);
+  }
+#pragma unroll
   for (int j = 0; j < 3; j++) {
-    float l = (float)((double)pwf[j] / a.voxel_size);
+    float l = loc[j];
     if (l < 0) l = (float)((double)l - 1.0);
     loc[j] = l;
     in_range = in_range && (l > -2147483000.f) && (l < 2147483000.f);
@@ -593,8 +620,7 @@ template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar
   // T2: both cuckoo slots at once
   RootSlot s1, s2;
   {
-    const uint32_t h1 = voxel_hash(key[0], key[1], key[2], a.map.seed1) & a.map.mask;
-    const uint32_t h2 = voxel_hash(key[0], key[1], key[2], a.map.seed2) & a.map.mask;
+    LIVO2_HASH_PAIR(key[0], key[1], key[2], a.map.seed1, a.map.seed2, a.map.mask, h1, h2);
     s1 = load_slot(a.map.slots, h1); s2 = load_slot(a.map.slots, h2);
   }
   // symmetric parts of P[0:3,0:3] and P[3:6,3:6] (a quadratic form only sees the symmetric part): block-uniform, kept in LDS behind the prefetch dump
@@ -646,8 +672,7 @@ template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar
     SlotHead n1, n2;                                             // only the words a later visit needs: key, val, cand_begin, cand_count
     n1.val = -1; n2.val = -1;
     if (nbr) {
-      const uint32_t g1 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed1) & a.map.mask;
-      const uint32_t g2 = voxel_hash(nk[0], nk[1], nk[2], a.map.seed2) & a.map.mask;
+      LIVO2_HASH_PAIR(nk[0], nk[1], nk[2], a.map.seed1, a.map.seed2, a.map.mask, g1, g2);
       n1 = load_slot_head(a.map.slots, g1); n2 = load_slot_head(a.map.slots, g2);
     }
     if (s.val >= 0) load_plane(a.map, s.val, p0);         // issued right behind the neighbour slots: same round trip
@@ -661,11 +686,11 @@ template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar
     // A plane-root neighbour is visited only if the first visit fails, one dependent trip later: start pulling its two cache
     // lines towards this CU now (a discarded dword per line), so that trip is an L2 hit instead of an HBM miss.
     if (nb.val >= 0) { touch_line<BLOCK>(a.map.planes + (size_t)nb.val * PLANE_HOT_DOUBLES); touch_line<BLOCK>(a.map.plane_aux + nb.val); }
-    if (s.val >= 0) visit_plane_root(p0, s.val, a.sigma_num, pt, ext, ext + 9, st, best);
+    if (s.val >= 0) visit_plane_root(p0, s.val, gc, pt, ext, ext + 9, st, best);
     plan1W = plan1.W;
     if (plan1.W > 0) {              // block-uniform
       coop_park_ctx(coop, pt, ext, ext + 9);      // (the first barrier inside coop_run orders these rows before the evaluators' reads)
-      coop_run(coop, a.map, plan1, a.max_layer, a.sigma_num, st, best COOP_PROF_ARG1);
+      coop_run(coop, a.map, plan1, a.max_layer, gc, st, best COOP_PROF_ARG1);
       coop_unpark_ctx(coop, pt);
     }
 #ifdef LIVO2_PHASE_PROF
@@ -678,11 +703,11 @@ template <int BLOCK, bool PUBLISH = false> __device__ __forceinline__ void lidar
     const CoopPlan plan2 = coop_plan(coop, 1, (retry && nb.val == -2) ? nb.cand_count : 0, nb.cand_begin);
     if (retry && nb.val >= 0) {
       PlaneRec p1; load_plane(a.map, nb.val, p1);
-      visit_plane_root(p1, nb.val, a.sigma_num, pt, ext, ext + 9, st, best);
+      visit_plane_root(p1, nb.val, gc, pt, ext, ext + 9, st, best);
     }
     if (plan2.W > 0) {
       if (plan1W == 0) coop_park_ctx(coop, pt, ext, ext + 9);
-      coop_run(coop, a.map, plan2, a.max_layer, a.sigma_num, st, best COOP_PROF_ARG2);
+      coop_run(coop, a.map, plan2, a.max_layer, gc, st, best COOP_PROF_ARG2);
     }
   }
   PHASE(4);
@@ -761,21 +786,57 @@ __device__ __forceinline__ const double *lidar_kernarg_ext() {
   return (const double *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LidarKernelArgs, ER));      // (constant address space -> generic)
 }
 __device__ __forceinline__ const LidarKernelArgs &lidar_kernarg_args() { return *(const LidarKernelArgs *)__builtin_amdgcn_kernarg_segment_ptr(); }
+// `stamps` (nullable, read by address like the other arguments): [chunks][2] start / end of the block that worked on the chunk on the chip-wide 100-MHz clock — the
+// kernel's OWN duration (first block's start to last block's end) without a profiler and without the launch-boundary cost an event pair includes; k_lidar_span_acc
+// folds them into per-context totals behind every solve of a timed pass (bench.py: roofline.kernel_us_device).
+struct LidarResidualKernargs { LidarKernelArgs a; const DevCtl *ctl; double *partials; int32_t check_stop, chunks; const int32_t *order; uint32_t *cost; unsigned long long *stamps; };   // mirror of the parameter list
+__device__ __forceinline__ unsigned long long *lidar_kernarg_stamps() {
+  return *(unsigned long long *const *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LidarResidualKernargs, stamps));
+}
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LIDAR_WPE))) k_lidar_residual(LidarKernelArgs a, const DevCtl *__restrict__ ctl, double *__restrict__ partials,
-                                                                int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost) {
+                                                                int check_stop, int chunks, const int32_t *__restrict__ order, uint32_t *__restrict__ cost, unsigned long long *stamps_by_address) {
   // One block per chunk, and NO loop around the body: inside a loop every launch-invariant value of the body (kernel arguments, addresses into the control block, the
   // "is this output wanted" conditions) is hoisted in front of it and stays live across the whole body — 145 spilled SGPRs, i.e. ~140 v_writelane at the start of every
   // wave and ~180 v_readlane along its way, a quarter of the VALU instructions a wave issues (the body is bound by instruction issue, profiles/r04_l2_retention_probe.txt).
+  static_assert(offsetof(LidarResidualKernargs, stamps) == sizeof(LidarKernelArgs) + 40, "kernel-argument layout");
   if (check_stop && ctl->hdr.stop) return;
   const int pb = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const unsigned long long t0 = cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   // The body reads the launch arguments BY ADDRESS from the kernel-argument segment (scalar loads where a value is used): as by-value parameters LLVM loads all ~70
   // SGPRs of them in the prologue and keeps them live across the whole body — 70 spilled SGPRs, i.e. v_writelane / v_readlane traffic in a body that is bound by
   // instruction issue.  By address: 30 spills (exec masks of the nested branches), k_lidar_residual 21.1 -> 20.35 us by events, 28.45 -> 27.2 us per iteration
   // (profiles/r05_lidar_args_by_address_ab.txt).
   lidar_residual_body<BLOCK>(lidar_kernarg_args(), lidar_kernarg_ext(), ctl, partials, 0, pb, chunks);
-  if (cost && threadIdx.x == 0) cost[pb] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t0);
+  if (threadIdx.x == 0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (cost) cost[pb] = (uint32_t)(t1 - t0);
+    unsigned long long *st = lidar_kernarg_stamps();
+    if (st) { st[2 * pb] = t0; st[2 * pb + 1] = t1; }
+  }
+}
+// acc[0] += last end - first start of the launch whose stamps are in `stamps` (nothing if it exited at its first instruction), acc[1] += 1, acc[2] = longest, acc[3] = shortest span;
+// the stamps are emptied again.  One block.
+__global__ void __launch_bounds__(256) k_lidar_span_acc(unsigned long long *__restrict__ stamps, int chunks, unsigned long long *__restrict__ acc) {
+  __shared__ unsigned long long smin[256], smax[256];
+  unsigned long long lo = ~0ull, hi = 0ull;
+  for (int c = threadIdx.x; c < chunks; c += 256) {
+    const unsigned long long s0 = stamps[2 * c], s1 = stamps[2 * c + 1];
+    if (s0 != ~0ull && s1 != ~0ull) { lo = s0 < lo ? s0 : lo; hi = s1 > hi ? s1 : hi; }
+    stamps[2 * c] = ~0ull; stamps[2 * c + 1] = ~0ull;
+  }
+  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) { if (smin[threadIdx.x + d] < smin[threadIdx.x]) smin[threadIdx.x] = smin[threadIdx.x + d]; if (smax[threadIdx.x + d] > smax[threadIdx.x]) smax[threadIdx.x] = smax[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && smin[0] != ~0ull && smax[0] >= smin[0]) {
+    const unsigned long long span = smax[0] - smin[0];
+    acc[0] += span; acc[1] += 1;
+    if (span > acc[2]) acc[2] = span;
+    if (acc[3] == 0 || span < acc[3]) acc[3] = span;
+  }
 }
 // The resident-grid variant (LIVO2_LIDAR_RESIDENT=<blocks>, tools/lidar_resident_probe.py): block b works through chunks b, b + gridDim, ...
 template <int BLOCK>

@@ -122,6 +122,7 @@ struct livo2_ctx {
   int n = 0, n_cap = 0, lidar_block = 256;
   float *d_xyz_aos = nullptr, *d_x = nullptr, *d_y = nullptr, *d_z = nullptr; double *d_cb = nullptr;
   uint32_t *d_keys = nullptr, *d_keys2 = nullptr; int32_t *d_idx = nullptr, *d_perm = nullptr; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  unsigned long long *d_lidar_stamps = nullptr, *d_lidar_span_acc = nullptr; size_t lidar_stamps_cap = 0;      // device-clock duration of k_lidar_residual in a timed pass (k_lidar_span_acc)
   double *d_partials = nullptr; size_t partials_cap = 0;
   double *d_bcov_rows = nullptr; size_t bcov_rows_cap = 0;      // body_cov_list_ as 3x3 rows in caller order (fetch_lidar_points)
   int32_t *d_match = nullptr, *d_normal_plane = nullptr; float *d_dis = nullptr, *d_pw = nullptr; double *d_var = nullptr, *d_rinv = nullptr, *d_hrow = nullptr;
@@ -405,11 +406,12 @@ void launch_lidar_residual(livo2_ctx *ctx, const LidarKernelArgs &a, int check_s
   const bool lpt = lidar_lpt_on(ctx, chunks) && resident == 0;
   const int32_t *order = (lpt && ctx->lpt_valid) ? ctx->d_lpt_order : nullptr;
   uint32_t *cost = lpt ? ctx->d_lpt_cost : nullptr;
+  unsigned long long *stamps = (ctx->timing && ctx->d_lidar_stamps && ctx->lidar_stamps_cap >= 2 * (size_t)chunks) ? ctx->d_lidar_stamps : nullptr;
   if (resident > 0) {
     if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual_resident<128>, dim3(grid), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
     else hipLaunchKernelGGL(k_lidar_residual_resident<256>, dim3(grid), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
-  } else if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(chunks), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
-  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(chunks), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost);
+  } else if (ctx->lidar_block == 128) hipLaunchKernelGGL(k_lidar_residual<128>, dim3(chunks), dim3(128), LIDAR_LDS_BYTES_OF(128) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost, stamps);
+  else hipLaunchKernelGGL(k_lidar_residual<256>, dim3(chunks), dim3(256), LIDAR_LDS_BYTES_OF(256) + LIDAR_LDS_DUMP, ctx->stream, a, ctx->d_ctl, ctx->d_partials, check_stop, chunks, order, cost, stamps);
 }
 
 // One ESIKF iteration as ONE launch (lidar_kernels.hpp, k_lidar_iteration).  False: this configuration runs the two-launch sequence (128-point blocks, the resident-grid
@@ -481,10 +483,19 @@ int ensure_lidar_outputs(livo2_ctx *ctx, const livo2_lidar_points *want) {
   return LIVO2_OK;
 }
 
+// launch constants derived from voxel_size / sigma_num (lidar_kernels.hpp, LidarKernelArgs)
+void lidar_args_consts(LidarKernelArgs &a) {
+  int ex = 0;
+  const double inv = 1.0 / a.voxel_size;
+  a.inv_voxel_size = (std::frexp(a.voxel_size, &ex) == 0.5 && std::isfinite(inv) && inv >= 0x1p-500 && inv <= 0x1p500) ? inv : 0.0;      // a power of two: x * inv == x / voxel_size bit for bit
+  const double sn2 = a.sigma_num * a.sigma_num;
+  a.sn2_lo = sn2 * (1.0 - 1e-14); a.sn2_hi = sn2 * (1.0 + 1e-14);
+}
 LidarKernelArgs make_lidar_args(livo2_ctx *ctx, const livo2_lidar_cfg *cfg) {
   LidarKernelArgs a{};
   a.x = ctx->d_x; a.y = ctx->d_y; a.z = ctx->d_z; a.cb = ctx->d_cb; a.perm = ctx->d_perm; a.n = ctx->n; a.max_layer = cfg->max_layer; a.map = ctx->map;
   a.voxel_size = cfg->voxel_size; a.sigma_num = cfg->sigma_num;
+  lidar_args_consts(a);
   std::memcpy(a.ER, cfg->extR, 72); std::memcpy(a.Et, cfg->extT, 24);
 #ifdef LIVO2_PHASE_PROF
   {
@@ -730,7 +741,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
                  ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_ob_list, ctx->d_ob_cnt, ctx->d_delta, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
-                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena};
+                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena, ctx->d_lidar_stamps, ctx->d_lidar_span_acc};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
@@ -825,10 +836,35 @@ int livo2_ctx_get_counter(livo2_ctx *ctx, const char *name, int64_t *value) {
   if (std::strcmp(name, "frame_zero_copy_launches") == 0) { *value = ctx->frame_zero_copy_launches; return LIVO2_OK; }
   if (std::strcmp(name, "frame_publish_launches") == 0) { *value = ctx->frame_publish_launches; return LIVO2_OK; }
   if (std::strcmp(name, "visual_map_delta_grows") == 0) { *value = ctx->vm_delta_grows; return LIVO2_OK; }
+  {   // k_lidar_residual's own duration on the device clock, summed over the executed launches of the timed passes so far (10-ns ticks / launches / longest / shortest)
+    static const char *const names[4] = {"lidar_residual_device_ticks", "lidar_residual_device_launches", "lidar_residual_device_ticks_max", "lidar_residual_device_ticks_min"};
+    for (int k = 0; k < 4; k++) if (std::strcmp(name, names[k]) == 0) {
+      *value = 0;
+      if (!ctx->d_lidar_span_acc) return LIVO2_OK;
+      unsigned long long h[4];
+      HIPCHK(hipSetDevice(ctx->device));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(h, ctx->d_lidar_span_acc, 32, hipMemcpyDeviceToHost));
+      *value = (int64_t)h[k];
+      return LIVO2_OK;
+    }
+  }
   return fail(ctx, LIVO2_ERR_INVALID, "unknown counter");
 }
 
-int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable) { if (!ctx) return LIVO2_ERR_INVALID; ctx->timing = enable != 0; return LIVO2_OK; }
+int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable) {
+  if (!ctx) return LIVO2_ERR_INVALID;
+  if (enable) {      // the stamps of k_lidar_residual (its own duration on the device clock): room for the current scan, emptied
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t need = 2 * (size_t)std::max(lidar_grid(std::max(ctx->n, 1), ctx->lidar_block), 64);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int rc = ensure(ctx, ctx->d_lidar_stamps, ctx->lidar_stamps_cap, need); if (rc) return rc;
+    if (!ctx->d_lidar_span_acc) { HIPCHK(DMALLOC((void **)&ctx->d_lidar_span_acc, 32)); HIPCHK(hipMemsetAsync(ctx->d_lidar_span_acc, 0, 32, ctx->stream)); }
+    HIPCHK(hipMemsetAsync(ctx->d_lidar_stamps, 0xFF, ctx->lidar_stamps_cap * 8, ctx->stream));
+  }
+  ctx->timing = enable != 0;
+  return LIVO2_OK;
+}
 int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset) {
   if (!ctx || which < 0 || which > 3) return LIVO2_ERR_INVALID;
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -70,13 +70,23 @@ struct DevMap {
   int32_t n_planes;
 };
 
-__host__ __device__ inline uint32_t voxel_hash(int32_t x, int32_t y, int32_t z, uint32_t seed) {
-  uint32_t h = seed;
-  h ^= (uint32_t)x * 0x9e3779b1u; h = (h << 13) | (h >> 19); h *= 0x85ebca6bu;
-  h ^= (uint32_t)y * 0xc2b2ae35u; h = (h << 15) | (h >> 17); h *= 0x27d4eb2fu;
-  h ^= (uint32_t)z * 0x165667b1u; h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+// Table hash of a voxel key.  Both probes of a lookup (seed1 / seed2) share the key-dependent part: three multiplies for the pair instead of fourteen — a point makes two
+// lookups (its voxel, the neighbour voxel) per iteration, and an integer multiply costs what an f64 FMA costs on this chip (tools/valu_rate_probe.hip:
+// v_mul_lo_u32 4 cycles per wave, v_xor / shifts 2.4; profiles/r06_valu_rate_probe.txt).  Only key EQUALITY has to agree with VOXEL_LOCATION::operator==
+// (voxel_map.h:103); the hash itself is free.  Add and xor alternate in the base so that it is linear over neither; the finaliser is lowbias32.
+#define LIVO2_HASH_PAIR(x, y, z, s1, s2, m, o1, o2) const uint32_t hb_##o1 = voxel_hash_base(x, y, z); const uint32_t o1 = voxel_hash_fin(hb_##o1, s1) & (m), o2 = voxel_hash_fin(hb_##o1, s2) & (m)
+__host__ __device__ inline uint32_t voxel_hash_base(int32_t x, int32_t y, int32_t z) {
+  uint32_t h = (uint32_t)x * 0x9e3779b1u;
+  h = ((h << 13) | (h >> 19)) + (uint32_t)y * 0x85ebca6bu;
+  h = ((h << 11) | (h >> 21)) ^ ((uint32_t)z * 0xc2b2ae35u);
   return h;
 }
+__host__ __device__ inline uint32_t voxel_hash_fin(uint32_t base, uint32_t seed) {
+  uint32_t h = base ^ seed;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline uint32_t voxel_hash(int32_t x, int32_t y, int32_t z, uint32_t seed) { return voxel_hash_fin(voxel_hash_base(x, y, z), seed); }
 
 // ---- control block (one per ctx, in HBM) ----------------------------------------------------------------------------
 struct DevHeader {             // written by the host at the start of every update (one H2D copy together with cur/prop)

@@ -34,7 +34,18 @@ def main():
         c.synchronize()                                   # mode 1: scans all guards
     m, bad = ctxs[0].redzone_check()
     assert m == mode and bad == 0, (m, bad)
-    print("REDZONE mode %d: smoke + 6 frames on 1 and 3 contexts clean" % mode, flush=True)
+    # small scans whose size sits at the end of the scan buffers' capacity (advisor, round 5): the small-scan path pads the key array to a multiple of 16 words and
+    # reads it with 16-byte loads — a first scan of 10 801 points used to give a capacity of 16 201, and scans of 16 193..16 201 points then touched up to 7 words past it
+    c = livo2.Context(0)
+    c.upload_map(fmap)
+    rng = __import__("numpy").random.default_rng(3)
+    for n in (10801, 16193, 16199, 16201, 16208):
+        xyz = (rng.uniform(-8, 8, (n, 3))).astype("float32")
+        c.set_scan(xyz, cfg)
+        c.synchronize()
+        assert c.redzone_check()[1] == 0, n
+    c.close()
+    print("REDZONE mode %d: smoke + 6 frames on 1 and 3 contexts + scans at the capacity edge clean" % mode, flush=True)
     if mode == 1:
         c = ctxs[0]
         for off, words in ((0, "BEHIND its end"), (300, "BEHIND its end"), (-4, "IN FRONT of its start")):

@@ -26,6 +26,11 @@ def test_headline_is_one_small_strict_json_line():
     assert "workload" in out["config"] and "model" not in out["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us"):
         assert k in out["roofline"], k
+    # the live device-clock figures (round 6) come before anything read back from a committed capture, and the box hint is in the line
+    keys = list(out["roofline"])
+    for k in ("kernel_us_device", "frac_device", "per_rank_lidar_solve_us", "box_kind"):
+        assert k in keys, k
+    assert keys.index("kernel_us_device") < keys.index("kernel_us_rocprofv3") and keys.index("frac_device") < keys.index("frac_rocprofv3")
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in out["cpu_baseline"], k
     assert "extra" not in out

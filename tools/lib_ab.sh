@@ -4,7 +4,7 @@
 set -u
 ROOT=$(pwd); TAG=$1; VARIANTS=${2:-order=1}; shift 2
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
-export TMPDIR=$ROOT/.c4cache
+export TMPDIR=$ROOT/.c4cache; mkdir -p "$TMPDIR"
 L=fast-livo2_amd/lib/liblivo2_hip.so
 ALTS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do ALTS+=("$1"); shift; done
 [ $# -gt 0 ] && shift

@@ -19,6 +19,13 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (torch is imported inside bench.main only)
 
 
+def device_clock(ctx):
+    try:
+        return ctx.counter("lidar_residual_device_ticks"), ctx.counter("lidar_residual_device_launches")
+    except Exception:
+        return 0, 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=3)
@@ -47,9 +54,12 @@ def main():
             ctx.kernel_timing(True)
             for b in range(4):
                 ctx.kernel_timing_read(b)
+            dev0 = device_clock(ctx)
             w.run(args.steps); ctx.synchronize()
             bins = [ctx.kernel_timing_read(b) for b in range(4)]
+            dev1 = device_clock(ctx)
             ctx.kernel_timing(False)
+            dev_us = 0.01 * (dev1[0] - dev0[0]) / max(dev1[1] - dev0[1], 1)        # the kernel's own span on the 100-MHz device clock (round 6; 0 with a library that has no stamps)
             res_us, sol_us = 1e3 * bins[0][0] / (n_lid * args.steps), 1e3 * bins[2][0] / (n_lid * args.steps)
             vis_us = 1e3 * bins[1][0] / (len(w.vsteps) * args.steps)
             # LiDAR updates only, no events, no profiler: wall time per executed iteration (residual + solve + launch gaps) — an event record or a profiler's
@@ -63,13 +73,13 @@ def main():
                     ctx.lidar_update_async(w.lid[f], w.lid[f], w.cfg)
             ctx.synchronize()
             it_us = 1e6 * (time.perf_counter() - t2) / (n_lid * args.steps * 4)
-            rows[v].append((res_us, sol_us, vis_us, 1e3 * wall, it_us))
-            print(f"round {rnd} {v:16s} k_lidar_residual {res_us:6.2f} us  k_lidar_solve {sol_us:6.2f} us  visual update {vis_us:7.1f} us  8 frames {1e3 * wall:6.3f} ms  "
+            rows[v].append((res_us, sol_us, vis_us, 1e3 * wall, it_us, dev_us))
+            print(f"round {rnd} {v:16s} k_lidar_residual {res_us:6.2f} us (device clock {dev_us:6.2f})  k_lidar_solve {sol_us:6.2f} us  visual update {vis_us:7.1f} us  8 frames {1e3 * wall:6.3f} ms  "
                   f"lidar-only wall per iteration {it_us:6.2f} us", flush=True)
     print("# medians")
     for v in args.variants:
         m = np.median(np.array(rows[v]), axis=0)
-        print(f"{v:16s} k_lidar_residual {m[0]:6.2f} us  k_lidar_solve {m[1]:6.2f} us  visual update {m[2]:7.1f} us  8 frames {m[3]:6.3f} ms  lidar-only wall per iteration {m[4]:6.2f} us")
+        print(f"{v:16s} k_lidar_residual {m[0]:6.2f} us (device clock {m[5]:6.2f})  k_lidar_solve {m[1]:6.2f} us  visual update {m[2]:7.1f} us  8 frames {m[3]:6.3f} ms  lidar-only wall per iteration {m[4]:6.2f} us")
 
 
 if __name__ == "__main__":
