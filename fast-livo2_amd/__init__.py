@@ -146,6 +146,13 @@ class Context:
     def map_tree_update_from_scan(self, state, cfg, build=False):
         self._chk(self.lib.livo2_map_tree_update_from_scan(self.h, C.byref(state), C.byref(cfg), 1 if build else 0))
 
+    def map_tree_update_from_scan_async(self, state, cfg):
+        """UpdateVoxelMap on the context's second stream (state None: the posterior of the last LiDAR update, taken on the device); map_tree_update_join() collects it"""
+        self._chk(self.lib.livo2_map_tree_update_from_scan_async(self.h, C.byref(state) if state is not None else None, C.byref(cfg)))
+
+    def map_tree_update_join(self):
+        self._chk(self.lib.livo2_map_tree_update_join(self.h))
+
     def map_tree_stats(self):
         c = np.zeros(8, np.int32)
         self._chk(self.lib.livo2_map_tree_stats(self.h, abi.as_ptr(c, C.c_int32)))

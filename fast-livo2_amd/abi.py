@@ -268,6 +268,8 @@ SIGNATURES = {
     "livo2_map_tree_create": (C.c_int, [_CTX, _P(MapTreeCfg)]),
     "livo2_map_tree_update": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), C.c_int32, C.c_int32]),
     "livo2_map_tree_update_from_scan": (C.c_int, [_CTX, _P(State), _P(LidarCfg), C.c_int32]),
+    "livo2_map_tree_update_from_scan_async": (C.c_int, [_CTX, _P(State), _P(LidarCfg)]),
+    "livo2_map_tree_update_join": (C.c_int, [_CTX]),
     "livo2_map_tree_read_pv": (C.c_int, [_CTX, _P(C.c_double), _P(C.c_double), C.c_int32, _P(C.c_int32)]),
     "livo2_map_tree_stats": (C.c_int, [_CTX, _P(C.c_int32)]),
     "livo2_map_tree_slide": (C.c_int, [_CTX, _P(C.c_double), C.c_double, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),

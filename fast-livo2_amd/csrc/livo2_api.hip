@@ -23,7 +23,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -114,6 +117,8 @@ struct livo2_ctx {
   size_t ch_obs_cap = 0, ch_flag_cap = 0, ch_slot_cap = 0, cand_cell_cap = 0, cand_point_cap = 0, cand_obs_cap = 0, sub_point_cap = 0, sub_obs_cap = 0;
   int32_t *d_c_id = nullptr, *d_c_leader = nullptr, *d_ld_keys = nullptr, *d_ld_vals = nullptr; size_t c_id_cap = 0, c_leader_cap = 0, ld_keys_cap = 0, ld_vals_cap = 0;
   double chain_kernel_us = 0.0;
+  int32_t *d_ret_blob = nullptr; size_t ret_blob_cap = 0; void *h_ret = nullptr; size_t h_ret_cap = 0;      // packed results of livo2_visual_retrieve_from_map (k_ret_pack), pinned landing block
+  void *h_img = nullptr; size_t h_img_cap = 0;                                                              // pinned staging of that call's image
   // IMU propagation (N4)
   double *d_imu_steps = nullptr, *d_imu_poses = nullptr; size_t imu_steps_cap = 0, imu_poses_cap = 0; livo2_state *d_imu_state = nullptr;   // [2]: in, out
   double imu_kernel_us = 0.0;
@@ -195,6 +200,14 @@ struct livo2_ctx {
   int mt_pv_n = -1;                         // points of the pv_list in mt_in_pw / mt_in_var (last map-tree update), -1: none since the last set_scan
   int32_t *mt_rp_rows = nullptr; size_t mt_rp_rows_cap = 0; double *mt_rp_out = nullptr; size_t mt_rp_out_cap = 0;   // livo2_map_tree_read_planes staging
   double mt_kernel_us = 0.0;
+  // livo2_map_tree_update_from_scan_async: the octree update on a second stream of the context, concurrently with the visual half of the frame (api_map_tree.inc)
+  hipStream_t stream_mt = nullptr; hipEvent_t mt_fork = nullptr, mt_ev0 = nullptr, mt_ev1 = nullptr; bool mt_async = false;
+  void *mt_sort_tmp = nullptr; size_t mt_sort_tmp_bytes = 0;
+  int32_t *h_mt_cnt = nullptr;               // pinned: the pool counters of an update on the second stream, copied behind its last kernel (the join reads them without a round trip)
+  // the ~25 launches of such an update are enqueued by a helper thread of the context: on the caller's thread they stood (0.13 ms) between the LiDAR update and the
+  // retrieval they are meant to run beside
+  std::thread mt_worker; std::mutex mt_mu; std::condition_variable mt_cv; std::function<int()> mt_job; bool mt_job_pending = false, mt_job_done = true, mt_quit = false; int mt_job_rc = 0;
+  std::string mt_job_err;
   int mt_grow_events = 0;                   // pool growths / candidate re-packs so far (livo2_ctx_get_counter "map_tree_grow_events")
 #ifdef LIVO2_PHASE_PROF
   unsigned long long *d_prof = nullptr; size_t prof_waves = 0;
@@ -208,16 +221,19 @@ struct livo2_ctx {
 
 namespace {
 
+// where an error text goes: ctx->err, except on the context's helper thread (api_map_tree.inc), which keeps its own until the join hands it over
+thread_local std::string *tl_err_sink = nullptr;
+inline std::string &err_of(livo2_ctx *ctx) { return tl_err_sink ? *tl_err_sink : ctx->err; }
 #define HIPCHK(call)                                                                                        \
   do {                                                                                                      \
     hipError_t e_ = (call);                                                                                 \
     if (e_ != hipSuccess) {                                                                                 \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                         \
+      err_of(ctx) = std::string(#call) + ": " + hipGetErrorString(e_);                                      \
       return LIVO2_ERR_HIP;                                                                                 \
     }                                                                                                       \
   } while (0)
 
-int fail(livo2_ctx *ctx, int code, const char *msg) { if (ctx) ctx->err = msg; return code; }
+int fail(livo2_ctx *ctx, int code, const char *msg) { if (ctx) err_of(ctx) = msg; return code; }
 
 // LIVO2_REDZONE=1 (dev_alloc.hpp): every synchronising entry point ends by scanning the guards of all device allocations of the process
 int rz_gate(livo2_ctx *ctx) {
@@ -741,11 +757,13 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
                  ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_ob_list, ctx->d_ob_cnt, ctx->d_delta, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
-                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena, ctx->d_lidar_stamps, ctx->d_lidar_span_acc};
+                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena, ctx->d_lidar_stamps, ctx->d_lidar_span_acc, ctx->mt_sort_tmp, ctx->d_ret_blob};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);
   if (ctx->h_pts) e = hipHostFree(ctx->h_pts);
+  if (ctx->h_ret) e = hipHostFree(ctx->h_ret);
+  if (ctx->h_img) e = hipHostFree(ctx->h_img);
   if (ctx->h_delta) e = hipHostFree(ctx->h_delta);
   if (ctx->h_frame_res) e = hipHostFree(ctx->h_frame_res);
   for (int k = 0; k < 2; k++) { if (ctx->frame_stage[k]) e = hipHostFree(ctx->frame_stage[k]); if (ctx->frame_stage_ev[k]) e = hipEventDestroy(ctx->frame_stage_ev[k]); if (ctx->frame_res_ev[k]) e = hipEventDestroy(ctx->frame_res_ev[k]); }
@@ -760,6 +778,9 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   for (auto &ev : ctx->ev_pool) { e = hipEventDestroy(ev.a); e = hipEventDestroy(ev.b); }
   for (int k = 0; k < IN_RING; k++) if (ctx->in_ev[k]) e = hipEventDestroy(ctx->in_ev[k]);
   if (ctx->vp_done) { persist_forget(ctx); e = hipEventDestroy(ctx->vp_done); }
+  if (ctx->mt_worker.joinable()) { { std::lock_guard<std::mutex> lk(ctx->mt_mu); ctx->mt_quit = true; } ctx->mt_cv.notify_all(); ctx->mt_worker.join(); }
+  if (ctx->h_mt_cnt) e = hipHostFree(ctx->h_mt_cnt);
+  if (ctx->stream_mt) { e = hipStreamSynchronize(ctx->stream_mt); e = hipStreamDestroy(ctx->stream_mt); e = hipEventDestroy(ctx->mt_fork); e = hipEventDestroy(ctx->mt_ev0); e = hipEventDestroy(ctx->mt_ev1); }
   if (ctx->span0) e = hipEventDestroy(ctx->span0);
   if (ctx->span1) e = hipEventDestroy(ctx->span1);
   if (ctx->own_stream && ctx->stream) e = hipStreamDestroy(ctx->stream);
@@ -877,6 +898,7 @@ int livo2_ctx_kernel_timing_read(livo2_ctx *ctx, int which, double *total_ms, in
   return LIVO2_OK;
 }
 
+static int mt_join(livo2_ctx *ctx);      // api_map_tree.inc: wait for a map update that runs on the second stream (no-op when none is pending)
 // ---- the entry points, by subsystem (order matters: later parts call helpers of earlier ones) ----------------------------------------------------------------
 #include "api_map.inc"
 #include "api_imu.inc"

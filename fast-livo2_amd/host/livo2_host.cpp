@@ -276,6 +276,7 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
   cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
   std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
   livo2_state s; state_.to_abi(s);
+  if (async_map_update_ && !host_point_lists_) { dev_.check(livo2_map_tree_update_from_scan_async(dev_.ctx(), &s, &cfg)); return; }
   dev_.check(livo2_map_tree_update_from_scan(dev_.ctx(), &s, &cfg, 0));
   last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
   if (host_point_lists_ && !pv_list_.empty()) {        // the reference leaves the posterior point_w / var in pv_list_ (LIVMapper.cpp:417-424; `_pv_list` of :426 feeds handleVIO)
@@ -293,6 +294,12 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (int32_t i = 0; i < got; i++) { std::memcpy(pv_list_[i].point_w.data(), &pw[(size_t)i * 3], 24); std::memcpy(pv_list_[i].var.data(), &var[(size_t)i * 9], 72); }
   }
+}
+
+void VoxelMapManager::JoinMapUpdate() {
+  if (!device_map_) return;
+  dev_.check(livo2_map_tree_update_join(dev_.ctx()));
+  last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
 }
 
 int VoxelMapManager::mapSliding() {

@@ -238,6 +238,14 @@ int livo2_map_tree_update(livo2_ctx *ctx, const double *point_w, const double *v
  * StateEstimation and UpdateVoxelMap (src/LIVMapper.cpp:413-423): point_w = float32(R (extR p + extT) + t), var = (R extR) body_cov (R extR)^T +
  * [p_i]x P_rr [p_i]x^T + P_tt.  Nothing crosses PCIe but the state. */
 int livo2_map_tree_update_from_scan(livo2_ctx *ctx, const livo2_state *state, const livo2_lidar_cfg *cfg, int32_t build);
+/* The same (UpdateVoxelMap, build = 0) OFF the critical path of the frame: the reference runs UpdateVoxelMap (src/LIVMapper.cpp:413-424) before handleVIO
+ * (:281-334), but the visual half of a frame does not read the LiDAR voxel map (unless vio/raycast_en).  pv_list_ is formed on the context's stream — the retrieval
+ * may read it there (LIVO2_PG_FROM_MAP_UPDATE) — and the octree update itself runs on a second stream of the context, concurrently with whatever is enqueued next
+ * (livo2_visual_retrieve_from_map, livo2_visual_update).  state == NULL: the posterior the last livo2_lidar_update of this context left on the device.  Returns at
+ * once.  livo2_map_tree_update_join waits for the update, reads its pool counters, grows the pools and reports its errors exactly as the synchronous call does
+ * (livo2_map_tree_last_kernel_us is valid after it); every entry point that touches the tree, the scan or the LiDAR update joins a pending update first. */
+int livo2_map_tree_update_from_scan_async(livo2_ctx *ctx, const livo2_state *state, const livo2_lidar_cfg *cfg);
+int livo2_map_tree_update_join(livo2_ctx *ctx);
 /* pv_list_[i].point_w ([n][3]) / .var ([n][9]) as the last livo2_map_tree_update[_from_scan] consumed them (the reference keeps them: `_pv_list =
  * voxelmap_manager->pv_list_`, LIVMapper.cpp:426, read by handleVIO :306 and the publishers); either pointer may be NULL.  *n receives the point count. */
 int livo2_map_tree_read_pv(livo2_ctx *ctx, double *point_w, double *var, int32_t capacity, int32_t *n);

@@ -189,6 +189,53 @@ def test_lidar_update_reads_the_device_tree(ctx, livo2, orc):
     ctx.upload_map(fm)                                        # leave a snapshot resident for whatever test comes next on this ctx
 
 
+def test_map_update_on_the_second_stream_equals_the_synchronous_one(livo2, orc):
+    """livo2_map_tree_update_from_scan_async (UpdateVoxelMap beside handleVIO, LIVMapper.cpp:413-424 / 281-334): over three chained frames the tree it leaves equals
+    the synchronous call's (same voxels, same plane decisions, same counters), with a visual update enqueued between the fork and the join; state == NULL takes the posterior on the device; an entry point that
+    needs the tree (the next LiDAR update, an export) joins by itself; the kernel time is reported after the join."""
+    cs, cloud, R0, t0, P0, extR, extT = _scene(47)
+    _, (pw0, var0) = cloud(50000, R0, t0)
+    vs = synth.visual_scenario(seed=48, n_patches=600)
+    vcur, vprop = H.states(vs, livo2.State)
+    vcfg = H.visual_cfg_product(vs)
+    poses = [(R0 @ synth.rot_from_rpy(0.0, 0.0, 0.05 * f), t0 + np.array([0.15 * f, 0.05 * f, 0.0])) for f in range(3)]
+    scans = [cloud(8000, Rf, tf)[0] for Rf, tf in poses]                          # (the scene's generator is stateful: one set of scans for all three modes)
+    exports = {}
+    for mode in ("sync", "async", "async_device_state_implicit_join"):
+        c = livo2.Context(0)
+        c.map_tree_create(cs, max_roots=60000)
+        c.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+        c.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+        rng = np.random.default_rng(5)
+        out = []
+        for f in range(3):
+            (Rf, tf), xyz = poses[f], scans[f]
+            sc = synth.LidarScenario(None, np.ascontiguousarray(xyz, np.float32), Rf, tf, Rf @ synth.so3_exp(rng.normal(0, 0.003, 3)), tf + rng.normal(0, 0.01, 3),
+                                     synth.prior_cov(np.random.default_rng(1)), extR, extT, cs)
+            pcfg = H.lidar_cfg_product(sc)
+            pcur, pprop = H.states(sc, livo2.State)
+            c.set_scan(sc.xyz, pcfg)
+            res, _ = c.lidar_update(pcur, pprop, pcfg)
+            if mode == "sync":
+                c.map_tree_update_from_scan(res.state, pcfg)
+                vres, _ = c.visual_update(vcur, vprop, vcfg)
+            else:
+                c.map_tree_update_from_scan_async(None if mode.startswith("async_device") else res.state, pcfg)
+                vres, _ = c.visual_update(vcur, vprop, vcfg)                      # runs on the context's stream while the octree update runs on the second one
+                if mode == "async":
+                    c.map_tree_update_join()
+                    assert c.map_tree_last_kernel_us() > 10.0
+            out.append((bytes(res.state), bytes(vres.state), res.n_iters))
+        exports[mode] = (out, c.map_tree_export(), c.map_tree_stats())            # (export / stats join a pending update themselves)
+        c.close()
+    ref_out, ref_tree, ref_stats = exports["sync"]
+    for mode in ("async", "async_device_state_implicit_join"):
+        o, t, st = exports[mode]
+        assert o == ref_out and st == ref_stats, mode
+        assert _compare(_flat(t, cs), _flat(ref_tree, cs)) > 500                 # (node / plane rows are handed out by atomics: compared by structure, values to 1e-13)
+    assert ref_stats["planes"] > 500 and ref_stats["error"] == 0
+
+
 def test_soak_random_walk_with_sliding_grows_recycles_and_matches_oracle(ctx, orc):
     """200 frames of a random walk through a long corridor with mapSliding on (a +-6 m box follows the sensor), pools deliberately small at creation: they must grow on
     demand instead of killing the tree (LIVO2_ERR_RANGE), what sliding and freezing release must be reused (pool high-water marks stay bounded once the box is full),
