@@ -537,7 +537,7 @@ class Context:
         return res, errors
 
     # ---- one LIO + VIO frame per call ------------------------------------------------------------------------------
-    def _frame_in(self, xyz, prior, cfg, vs_img, pos, warp_patch, search_levels, inv_expo_list, vcfg):
+    def _frame_in(self, xyz, prior, cfg, vs_img, pos, warp_patch, search_levels, inv_expo_list, vcfg, reference=None):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         img = np.ascontiguousarray(vs_img, np.uint8)
         pos = _f64(pos).reshape(-1, 3)
@@ -546,13 +546,23 @@ class Context:
         M = len(pos)
         L = int(warp.shape[1]) if warp.ndim == 3 else int(vcfg.patch_pyrimid_level)
         f = abi.FrameIn(abi.as_ptr(xyz, C.c_float), len(xyz), M, L, img.shape[1], img.shape[0], img.shape[1], C.addressof(prior), C.addressof(cfg), C.addressof(vcfg),
-                        abi.as_ptr(img, C.c_uint8), abi.as_ptr(pos, C.c_double), abi.as_ptr(warp, C.c_float), abi.as_ptr(sl, C.c_int32), abi.as_ptr(ie, C.c_double))
-        return f, (xyz, img, pos, warp, sl, ie, prior, cfg, vcfg), M, L
+                        abi.as_ptr(img, C.c_uint8), abi.as_ptr(pos, C.c_double), abi.as_ptr(warp, C.c_float), abi.as_ptr(sl, C.c_int32), abi.as_ptr(ie, C.c_double), None)
+        keep_ref = None
+        if reference is not None:          # (ref_imgs, ref_img_idx, ref_px, ref_f, ref_R, ref_pos) as set_reference takes them
+            ri = np.ascontiguousarray(reference[0], np.uint8)
+            ri = ri[None] if ri.ndim == 2 else ri
+            idx = np.ascontiguousarray(reference[1], np.int32)
+            px, ff, RR, pp = _f64(reference[2]).reshape(-1, 2), _f64(reference[3]).reshape(-1, 3), _f64(reference[4]).reshape(-1, 9), _f64(reference[5]).reshape(-1, 3)
+            ref = abi.VisualReference(abi.as_ptr(ri, C.c_uint8), len(ri), 0, abi.as_ptr(idx, C.c_int32), abi.as_ptr(px, C.c_double), abi.as_ptr(ff, C.c_double),
+                                      abi.as_ptr(RR, C.c_double), abi.as_ptr(pp, C.c_double))
+            f.reference = C.addressof(ref)
+            keep_ref = (ref, ri, idx, px, ff, RR, pp)
+        return f, (xyz, img, pos, warp, sl, ie, prior, cfg, vcfg, keep_ref), M, L
 
-    def frame_update_async(self, xyz, prior, cfg, img, pos, warp_patch, search_levels, inv_expo_list, vcfg):
+    def frame_update_async(self, xyz, prior, cfg, img, pos, warp_patch, search_levels, inv_expo_list, vcfg, reference=None):
         """livo2_frame_update_async: scan + StateEstimation from `prior` + image / sub-map + computeJacobianAndUpdateEKF from the LiDAR posterior, enqueued in one
         call (up to two frames in flight; the arrays are staged inside the call)."""
-        f, keep, M, L = self._frame_in(xyz, prior, cfg, img, pos, warp_patch, search_levels, inv_expo_list, vcfg)
+        f, keep, M, L = self._frame_in(xyz, prior, cfg, img, pos, warp_patch, search_levels, inv_expo_list, vcfg, reference)
         self._chk(self.lib.livo2_frame_update_async(self.h, C.byref(f)))
         self.n, self.M, self.L = len(keep[0]), M, L
 
@@ -568,8 +578,8 @@ class Context:
     def new_frame_results(self):
         return LidarResult(), VisualResult()
 
-    def frame_update(self, *a):
-        self.frame_update_async(*a)
+    def frame_update(self, *a, **kw):
+        self.frame_update_async(*a, **kw)
         return self.frame_update_fetch()
 
     def visual_update_async(self, state_in, prop, cfg):

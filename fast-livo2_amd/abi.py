@@ -149,11 +149,17 @@ class VisualMapDelta(C.Structure):
                 ("touched_ref_patch", C.POINTER(C.c_int32)), ("img", C.POINTER(C.c_uint8))]
 
 
+class VisualReference(C.Structure):
+    """livo2_visual_reference: reference patches of a frame's sub-map (inverse-compositional update)"""
+    _fields_ = [("ref_imgs", C.POINTER(C.c_uint8)), ("n_ref", C.c_int32), ("pad", C.c_int32), ("ref_img_idx", C.POINTER(C.c_int32)), ("ref_px", C.POINTER(C.c_double)),
+                ("ref_f", C.POINTER(C.c_double)), ("ref_R", C.POINTER(C.c_double)), ("ref_pos", C.POINTER(C.c_double))]
+
+
 class FrameIn(C.Structure):
     """livo2_frame_in: one LIO + VIO frame (scan, prior, image + visual sub-map, both configurations)"""
     _fields_ = [("xyz", C.POINTER(C.c_float)), ("n_points", C.c_int32), ("M", C.c_int32), ("L", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
                 ("prior", C.c_void_p), ("lidar_cfg", C.c_void_p), ("visual_cfg", C.c_void_p), ("img", C.POINTER(C.c_uint8)), ("pos", C.POINTER(C.c_double)),
-                ("warp_patch", C.POINTER(C.c_float)), ("search_levels", C.POINTER(C.c_int32)), ("inv_expo_list", C.POINTER(C.c_double))]
+                ("warp_patch", C.POINTER(C.c_float)), ("search_levels", C.POINTER(C.c_int32)), ("inv_expo_list", C.POINTER(C.c_double)), ("reference", C.c_void_p)]
 
 
 class RetrieveChainOut(C.Structure):

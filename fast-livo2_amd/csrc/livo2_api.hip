@@ -708,7 +708,7 @@ int32_t livo2_abi_sizeof(const char *name) {
   LIVO2_SZ(livo2_state) LIVO2_SZ(livo2_map_view) LIVO2_SZ(livo2_lidar_cfg) LIVO2_SZ(livo2_lidar_sums) LIVO2_SZ(livo2_lidar_points) LIVO2_SZ(livo2_lidar_result)
   LIVO2_SZ(livo2_cam) LIVO2_SZ(livo2_visual_cfg) LIVO2_SZ(livo2_visual_sums) LIVO2_SZ(livo2_visual_step) LIVO2_SZ(livo2_visual_result)
   LIVO2_SZ(livo2_plane_fit) LIVO2_SZ(livo2_imu_step) LIVO2_SZ(livo2_imu_cfg) LIVO2_SZ(livo2_imu_pose) LIVO2_SZ(livo2_select_cfg)
-  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out) LIVO2_SZ(livo2_visual_map_delta) LIVO2_SZ(livo2_frame_in)
+  LIVO2_SZ(livo2_map_tree_cfg) LIVO2_SZ(livo2_retrieve_cfg) LIVO2_SZ(livo2_retrieve_candidates) LIVO2_SZ(livo2_retrieve_out) LIVO2_SZ(livo2_visual_obs) LIVO2_SZ(livo2_retrieve_chain_out) LIVO2_SZ(livo2_visual_map_delta) LIVO2_SZ(livo2_frame_in) LIVO2_SZ(livo2_visual_reference)
 #undef LIVO2_SZ
   return 0;
 }

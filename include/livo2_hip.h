@@ -611,6 +611,12 @@ int livo2_visual_iterations_async(livo2_ctx *ctx, int32_t level, const livo2_sta
  * D2H + H2D of the posterior — a 10 k-point frame is ~0.3 ms of kernels and was bound by exactly that (missing 5).
  * _async only enqueues (the caller's arrays are free on return: everything is staged through pinned blocks of the ctx); up to two frames may be in flight per ctx:
  * _fetch returns them in order.  A third _async without a _fetch fails with LIVO2_ERR_INVALID.  The map must be resident (livo2_map_upload / livo2_map_tree_*). */
+typedef struct livo2_visual_reference {   /* the arguments of livo2_visual_set_reference, for the M points of the frame's sub-map */
+  const uint8_t *ref_imgs;      /* [n_ref][height][stride] */
+  int32_t n_ref, pad;
+  const int32_t *ref_img_idx;   /* [M] */
+  const double *ref_px, *ref_f, *ref_R, *ref_pos;   /* [M][2], [M][3], [M][9], [M][3] */
+} livo2_visual_reference;
 typedef struct livo2_frame_in {
   const float *xyz;             /* [n_points][3] down-sampled body-frame scan */
   int32_t n_points, M, L, width, height, stride;
@@ -622,6 +628,9 @@ typedef struct livo2_frame_in {
   const float *warp_patch;
   const int32_t *search_levels;
   const double *inv_expo_list;
+  /* round 6: vio/inverse_composition_en in the frame call too (updateStateInverse, src/vio.cpp:1327-1518) — required iff visual_cfg->inverse_composition_en, else
+   * NULL.  The reference patches are copied before the call returns (this form waits for the previous frame of the context: one frame in flight). */
+  const livo2_visual_reference *reference;
 } livo2_frame_in;
 int livo2_frame_update_async(livo2_ctx *ctx, const livo2_frame_in *frame);
 int livo2_frame_update_fetch(livo2_ctx *ctx, livo2_lidar_result *lidar, livo2_visual_result *visual);

@@ -40,7 +40,7 @@ def test_ctypes_mirrors_have_the_compiled_sizes(livo2):
                    livo2_lidar_result=a.LidarResult, livo2_cam=a.Cam, livo2_visual_cfg=a.VisualCfg, livo2_visual_sums=a.VisualSums, livo2_visual_step=a.VisualStep,
                    livo2_visual_result=a.VisualResult, livo2_plane_fit=a.PlaneFit, livo2_imu_cfg=a.ImuCfg, livo2_select_cfg=a.SelectCfg, livo2_retrieve_cfg=a.RetrieveCfg,
                    livo2_retrieve_candidates=a.RetrieveCandidates, livo2_retrieve_out=a.RetrieveOut, livo2_visual_obs=a.VisualObs,
-                   livo2_retrieve_chain_out=a.RetrieveChainOut)
+                   livo2_retrieve_chain_out=a.RetrieveChainOut, livo2_frame_in=a.FrameIn, livo2_visual_reference=a.VisualReference)
     for name, cls in mirrors.items():
         assert lib.livo2_abi_sizeof(name.encode()) == C.sizeof(cls), name
     assert lib.livo2_abi_sizeof(b"livo2_imu_step") == 64 and lib.livo2_abi_sizeof(b"livo2_imu_pose") == 176

@@ -106,3 +106,35 @@ def test_inverse_update_with_equidistant_camera(ctx, livo2, orc, vs_inv):
     assert [(res.steps[j].level, res.steps[j].accepted) for j in range(res.n_steps)] == [(t.level, t.accepted) for t in full["trace"]]
     d = H.state_diff(res.state, full["state"])
     assert d["R"] < 1e-7 and d["t"] < 1e-7, d
+
+
+def test_inverse_in_the_frame_call_equals_the_separate_calls(ctx, livo2, orc, vs_inv):
+    """livo2_frame_in.reference (round 6): a whole LIO + VIO frame with vio/inverse_composition_en — scan, StateEstimation, image + sub-map + reference patches,
+    updateStateInverse from the LiDAR posterior — in one call gives the bits of the separate calls, and a forward-compositional frame afterwards does not see the
+    reference patches of this one."""
+    vs = vs_inv
+    sc = synth.lidar_scenario(seed=61, n_points=4000, downsample=0.1)
+    pcfg = H.lidar_cfg_product(sc)
+    vcfg = H.visual_cfg_product(vs, inverse=True)
+    prior = orc.make_state(sc.R_prior, sc.t_prior, sc.P, cls=livo2.State)
+    ctx.upload_map(sc.fmap)
+    # separate calls: LIO, then VIO on the shared state (iterate = prior = the LiDAR posterior)
+    ctx.set_scan(sc.xyz, pcfg)
+    lres, _ = ctx.lidar_update(prior, prior, pcfg)
+    _upload(ctx, vs)
+    vres, _ = ctx.visual_update(lres.state, lres.state, vcfg)
+    ref = (vs.ref_imgs, vs.ref_img_idx, vs.ref_px, vs.ref_f, vs.ref_R, vs.ref_pos)
+    fl, fv = ctx.frame_update(sc.xyz, prior, pcfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg, reference=ref)
+    assert bytes(fl.state) == bytes(lres.state) and fl.n_iters == lres.n_iters
+    assert fv.n_steps == vres.n_steps >= 4 and bytes(fv.state) == bytes(vres.state)
+    assert np.linalg.norm(np.array(fv.state.pos) - np.array(lres.state.pos)) > 0          # the visual update moved the state
+    with pytest.raises(livo2.Livo2Error):                                                  # the inverse form without reference patches is refused
+        ctx.frame_update(sc.xyz, prior, pcfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, vcfg)
+    # a forward-compositional frame on the same context: same as its own separate calls
+    fcfg = H.visual_cfg_product(vs)
+    ctx.set_scan(sc.xyz, pcfg)
+    lres2, _ = ctx.lidar_update(prior, prior, pcfg)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    vres2, _ = ctx.visual_update(lres2.state, lres2.state, fcfg)
+    fl2, fv2 = ctx.frame_update(sc.xyz, prior, pcfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, fcfg)
+    assert bytes(fv2.state) == bytes(vres2.state) and bytes(fv2.state) != bytes(fv.state)

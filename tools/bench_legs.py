@@ -426,6 +426,35 @@ def _load_traffic(workload, **match):
     return traffic.load(workload, **match)
 
 
+def _visual_inverse_leg(ctx, livo2, synth, H, n_patches=2000):
+    """V6 (vio/inverse_composition_en, src/vio.cpp:1327-1518) measured, not only tested: the whole updateStateInverse-based computeJacobianAndUpdateEKF on a
+    sub-map of n_patches (precomputeReferencePatches per level + residual / solve per step, launch-per-step: this form has no resident grid), next to the forward-compositional
+    update of the same sub-map, by wall time of asynchronous updates back to back and by the kernels' events."""
+    vs = synth.visual_inverse_scenario(seed=7, n_patches=n_patches)
+    cur, prop = make_states(livo2, vs)
+    out = {"patches": int(len(vs.pos))}
+    for name, inverse in (("inverse_compositional", True), ("forward_compositional", False)):
+        vcfg = H.visual_cfg(vs, inverse=inverse) if inverse else H.visual_cfg(vs)
+        ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+        if inverse:
+            ctx.set_reference(vs.ref_imgs, vs.ref_img_idx, vs.ref_px, vs.ref_f, vs.ref_R, vs.ref_pos)
+        res, _ = ctx.visual_update(cur, prop, vcfg)
+        steps = int(res.n_steps)
+        for _ in range(3):
+            ctx.visual_update_async(cur, prop, vcfg)
+        ctx.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.visual_update_async(cur, prop, vcfg)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"steps": steps, "us_per_update": 1e6 * dt, "us_per_step": 1e6 * dt / max(steps, 1), "evals_per_s": 64.0 * len(vs.pos) * steps / dt}
+    out["note"] = ("inverse: gradients from the reference images once per level (k_visual_ref_precompute), per step only residuals + N^T (sum g g^T) N (k_visual_inverse_residual) and the "
+                   "shared solve — a launch per step; forward: the resident grid.  Same synthetic sub-map (search levels 0, reference frames at the true pose)")
+    return out
+
+
 def widened_rows(ctx, livo2, synth, H, sc, cfg):
     """N1-N4 legs; leaves the map and scan of `sc` resident again on return."""
     extra = {}
@@ -454,6 +483,10 @@ def widened_rows(ctx, livo2, synth, H, sc, cfg):
         if rep:
             for name, a, b in (("preprocess_scan", 0, 1), ("lidar_update", 2, 3), ("plane_fit_800_voxels", 3, 4), ("retrieve_warp_400", 4, 5), ("visual_update", 5, 6)):
                 stage.setdefault(name, []).append((t[b] - t[a]) * 1e3)
+    try:
+        extra["visual_inverse"] = _visual_inverse_leg(ctx, livo2, synth, H)
+    except Exception as exc:
+        extra["visual_inverse"] = {"error": repr(exc)}
     extra["avia_frame_stages_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
     extra["avia_frame_stages_ms"]["sum"] = float(sum(np.median(v) for v in stage.values()))
     extra["avia_frame_stages_ms"]["note"] = "host-synchronous calls through the Python wrappers incl. H2D/D2H: 24 000 raw points -> %d, 10 000-point LiDAR update, 800 voxel re-fits, 400 retrieval candidates, visual update on the survivors" % nd1
