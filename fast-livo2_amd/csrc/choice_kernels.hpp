@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(256) k_vm_apply(VmDeltaArgs a) {
     const size_t p = (size_t)a.n_points + t;
     a.pos[p * 3] = a.s_pos[(size_t)t * 3]; a.pos[p * 3 + 1] = a.s_pos[(size_t)t * 3 + 1]; a.pos[p * 3 + 2] = a.s_pos[(size_t)t * 3 + 2];
     a.pkey[p] = a.s_pkey[t]; a.active[p] = a.s_active[t]; a.fov[p] = 0;
-    a.count[p] = 0; a.refp[p] = -1; a.ninit[p] = 0; a.normal[p * 3] = 0.0; a.normal[p * 3 + 1] = 0.0; a.normal[p * 3 + 2] = 0.0;      // until its `touched` row lands (below, same launch: other threads)
+    a.count[p] = 0; a.refp[p] = -1; a.ninit[p] = 0; a.normal[p * 3] = 0.0; a.normal[p * 3 + 1] = 0.0; a.normal[p * 3 + 2] = 0.0;      // until its `touched` row lands (k_vm_apply_touched)
+    for (int k = 0; k < a.stride; k++) a.list[p * a.stride + k] = -1;              // as k_ob_lists_from_csr leaves the unused entries of a full upload (a new point without a touched row: advisor, round 5)
   }
   // section 2: new observations, 32 threads each (the patch is 64 floats = 32 x 8 bytes)
   {

@@ -289,6 +289,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   if (ROLE == 2) {
     VIS_CHAIN(0, 64)
     if (!ok) pe = 0.0f;
+    if (XB && pe != pe) pe = __uint_as_float(0x7fc00000u);      // the exchange's "not published yet" word is the all-ones NaN: a NaN that came in with that payload (garbage patches) must not look like it (advisor, round 5)
     if (j == 0 && valid) xb_store<XB>(&errors_out[patch], pe);
     return 0.0;
   }
@@ -319,6 +320,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   if (ROLE == 0) {
     VIS_CHAIN(40, 64)
     if (!ok) pe = 0.0f;
+    if (XB && pe != pe) pe = __uint_as_float(0x7fc00000u);
     if (j == 0 && valid) xb_store<XB>(&errors_out[patch], pe);
   }
 #undef VIS_CHAIN
@@ -809,6 +811,7 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
       double v = SL.u.r.red[h * VIS_WAVES][k];
 #pragma unroll
       for (int w = 1; w < VIS_WAVES; w++) v = v + SL.u.r.red[h * VIS_WAVES + w][k];
+      if (v != v) v = __longlong_as_double(0x7ff8000000000000ll);                // (a NaN sum is published as the canonical NaN, never as the all-ones "empty" word)
       vp_st(rows + (size_t)r * VIS_PSTRIDE + k, (vp_word)__double_as_longlong(v));
     }
   }

@@ -599,6 +599,15 @@ void VIOManager::syncFeatMap(const GrayImage &img) {
 }
 
 void VIOManager::applyPendingDelta(const GrayImage &img) {
+  // A delta the device refuses (e.g. LIVO2_ERR_RANGE: an obs_ list longer than the resident stride) leaves the host mirror ahead of the device — the indices assigned
+  // below are not undone.  The answer the header prescribes is a full upload: it re-assigns every index, so the failure is turned into one (advisor, round 5).
+  auto apply = [&](const livo2_visual_map_delta *dd) {
+    if (livo2_visual_map_apply(dev_.ctx(), dd) == LIVO2_OK) return true;
+    pending_new_.clear(); pending_new_keys_.clear(); pending_dirty_.clear(); pending_removed_.clear();
+    feat_map_dirty_ = true;
+    mirrorFeatMap(true, &img);                                                      // throws if even that fails
+    return false;
+  };
   const size_t n_new = pending_new_.size();
   std::vector<double> npos(n_new * 3), tnormal;
   std::vector<int64_t> nkey(n_new * 3);
@@ -650,7 +659,7 @@ void VIOManager::applyPendingDelta(const GrayImage &img) {
   for (size_t k = 0; k + 1 < new_imgs.size(); k++) {                                // the API takes one image per call: all but the last travel on their own
     livo2_visual_map_delta di{};
     di.img = new_imgs[k]; di.img_slot = slot0 + (int32_t)k;
-    dev_.check(livo2_visual_map_apply(dev_.ctx(), &di));
+    if (!apply(&di)) return;
   }
   livo2_visual_map_delta d{};
   d.n_new_points = (int32_t)n_new; d.n_new_obs = (int32_t)oid.size(); d.n_touched = (int32_t)tpoint.size();
@@ -660,8 +669,7 @@ void VIOManager::applyPendingDelta(const GrayImage &img) {
   d.touched_point = tpoint.data(); d.touched_offset = toff.data(); d.touched_obs = tobs.data(); d.touched_normal = tnormal.data();
   d.touched_normal_initialized = tninit.data(); d.touched_active = tactive.data(); d.touched_ref_patch = tref.data();
   if (!new_imgs.empty()) { d.img = new_imgs.back(); d.img_slot = (int32_t)img_slots_.size() - 1; }
-  (void)img;
-  dev_.check(livo2_visual_map_apply(dev_.ctx(), &d));
+  if (!apply(&d)) return;
   pending_new_.clear(); pending_new_keys_.clear(); pending_dirty_.clear(); pending_removed_.clear();
   delta_syncs_++;
 }

@@ -341,7 +341,10 @@ private:
   std::vector<VisualPoint *> pending_new_, pending_dirty_;       // queued by the hooks above, consumed by applyPendingDelta
   std::vector<VOXEL_LOCATION> pending_new_keys_;
   std::vector<int32_t> pending_removed_;
-  std::vector<const uint8_t *> img_slots_;                        // device image slot -> Feature::img_
+  // device image slot -> Feature::img_.  LIFETIME (advisor, round 5): a slot is identified by the POINTER, and slots are only ever appended — an image buffer must stay
+  // alive and keep its address for as long as a Feature that names it is in the map (the reference keeps every reference frame's cv::Mat alive through its Features'
+  // shared pixels, feature.h:19-54); a caller that frees one and gets a new frame at the same address must mark the map dirty (feat_map_dirty_ = true: full upload).
+  std::vector<const uint8_t *> img_slots_;
   void applyPendingDelta(const GrayImage &img);
   void mirrorFeatMap(bool with_obs, const GrayImage *img);
   void gridSetup();

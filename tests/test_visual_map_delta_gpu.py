@@ -112,6 +112,9 @@ def test_delta_argument_errors(livo2):
         with pytest.raises(livo2.Livo2Error) as e:
             c.visual_map_apply(touched=dict(base, point=np.array([n]), lists=[[0]], ref_patch=np.array([-1])))      # a point that does not exist
         assert e.value.code == livo2.abi.ERR_INVALID
+        with pytest.raises(livo2.Livo2Error) as e:                                                                  # one point named by two rows (they would race on the device)
+            c.visual_map_apply(touched=dict(point=np.array([0, 0]), normal=np.zeros((2, 3)), normal_initialized=np.ones(2, np.uint8), lists=[[0], [1]], ref_patch=np.array([-1, -1])))
+        assert e.value.code == livo2.abi.ERR_INVALID
         with pytest.raises(livo2.Livo2Error) as e:
             c.visual_map_apply(img=cs.img, img_slot=len(cs.ref_imgs) + 1)                                           # a hole in the image pool
         assert e.value.code == livo2.abi.ERR_INVALID
