@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(256) k_undistort(UndistortArgs a) {
 }
 
 // ---- pcl::VoxelGrid ----------------------------------------------------------------------------------------------------------------
-// bounds[0..2] = min, [3..5] = max of the cloud as order-preserving uint32 codes of the floats (atomicMin / atomicMax across blocks;
-// min / max are exact, so the result does not depend on the order).  The host presets min codes to 0xFFFFFFFF and max codes to 0.
+// bounds[0..2] = min, [3..5] = max of the cloud as order-preserving uint32 codes of the floats (atomicMax across blocks; min / max are exact, so the result does
+// not depend on the order).  The minima are kept as the COMPLEMENT of their code, so that ONE fill with zeros presets all six words (round 6: one launch less).
 __device__ __forceinline__ uint32_t f32_code(float f) { const uint32_t b = __builtin_bit_cast(uint32_t, f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float f32_decode(uint32_t c) { return __builtin_bit_cast(float, (c & 0x80000000u) ? (c & 0x7fffffffu) : ~c); }
 __global__ void __launch_bounds__(1024) k_vg_minmax(const float *__restrict__ xyz, int n, uint32_t *__restrict__ bounds) {
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(1024) k_vg_minmax(const float *__restrict__ xy
   if (tid < 3) {                                                  // one pair of atomics per block and axis
     float a = s_mn[0][tid], b = s_mx[0][tid];
     for (int w = 1; w < 16; w++) { a = fminf(a, s_mn[w][tid]); b = fmaxf(b, s_mx[w][tid]); }
-    atomicMin(&bounds[tid], f32_code(a)); atomicMax(&bounds[3 + tid], f32_code(b));
+    atomicMax(&bounds[tid], ~f32_code(a)); atomicMax(&bounds[3 + tid], f32_code(b));
   }
 }
 
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_vg_keys(const float *__restrict__ xyz, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   long long min_b[3], div_b[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) { min_b[k] = (long long)floorf(f32_decode(bounds[k]) * inv_leaf); div_b[k] = (long long)floorf(f32_decode(bounds[3 + k]) * inv_leaf) - min_b[k] + 1; }
+  for (int k = 0; k < 3; k++) { min_b[k] = (long long)floorf(f32_decode(~bounds[k]) * inv_leaf); div_b[k] = (long long)floorf(f32_decode(bounds[3 + k]) * inv_leaf) - min_b[k] + 1; }
   if (div_b[0] * div_b[1] * div_b[2] > 2147483647ll) { if (i == 0) flag[0] = 1; return; }
   if (i >= n) return;
   const int mul[3] = {1, (int)div_b[0], (int)(div_b[0] * div_b[1])};
@@ -121,24 +121,58 @@ __global__ void __launch_bounds__(256) k_vg_keys(const float *__restrict__ xyz, 
   keys[i] = (uint32_t)key; idx[i] = i;
 }
 
-__global__ void __launch_bounds__(256) k_vg_heads(const uint32_t *__restrict__ keys_sorted, int n, int32_t *__restrict__ head) {
+// leaves per 256-point block of the sorted keys (a leaf belongs to the block of its first point): what k_vg_centroid needs to number the leaves without a device-wide scan
+__global__ void __launch_bounds__(256) k_vg_heads(const uint32_t *__restrict__ keys_sorted, int n, int32_t *__restrict__ blk_count) {
+  __shared__ int s_cnt[4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) head[i] = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1 : 0;
+  const bool head = i < n && (i == 0 || keys_sorted[i] != keys_sorted[i - 1]);
+  const unsigned long long m = __ballot(head);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_count[blockIdx.x] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
 }
 
-// one thread per leaf head: float centroid of the leaf's points in sorted (= input) order ; slot = exclusive scan of the head flags
+// one thread per leaf head: float centroid of the leaf's points in sorted (= input) order.  The leaf's number (its row in `out`: leaves in ascending key order, as
+// pcl::VoxelGrid emits them) = leaves in the blocks before this one (k_vg_heads' counts, summed by the block: <= 4 per thread for a million points) + heads before
+// it in the block — the library's device-wide exclusive scan (three launches) is gone (round 6).
 __global__ void __launch_bounds__(256) k_vg_centroid(const float *__restrict__ xyz, const uint32_t *__restrict__ keys_sorted, const int32_t *__restrict__ perm,
-                                                     const int32_t *__restrict__ head, const int32_t *__restrict__ slot, int n, float *__restrict__ out,
-                                                     int32_t *__restrict__ count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) count[0] = slot[i] + head[i];
-  if (!head[i]) return;
-  const int s = slot[i];
-  const uint32_t key = keys_sorted[i];
+                                                     const int32_t *__restrict__ blk_count, int n, float *__restrict__ out, int32_t *__restrict__ count) {
+  __shared__ int s_part[256], s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * blockDim.x + tid;
+  const uint32_t key = i < n ? keys_sorted[i] : 0u;
+  const bool head = i < n && (i == 0 || key != keys_sorted[i - 1]);
+  int before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += 256) before += blk_count[b];
+  s_part[tid] = before;
+  const unsigned long long m = __ballot(head);
+  if (lane == 0) s_wave[wave] = __popcll(m);
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if (tid < d) s_part[tid] += s_part[tid + d]; __syncthreads(); }
+  int s = s_part[0] + __popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; w++) s += s_wave[w];
+  if (i == n - 1) count[0] = s + (head ? 1 : 0);
+  if (!head) return;
+  // The sums are float and in sorted (= input) order, as pcl::VoxelGrid accumulates them, so the ADDS are a chain; the loads need not be.  One point per turn made every
+  // turn two dependent round trips (perm[j], then the point): the busiest leaf of a 240 k-point scan set the kernel's 61 us.  Sixteen points per turn now: their keys and
+  // permutation entries in one batch, their coordinates in a second, then the adds in order, stopping at the first key that differs (round 6: 61 -> 22 us).
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   int j = i;
-  for (; j < n && keys_sorted[j] == key; j++) { const int p = perm[j]; c0 += xyz[(size_t)p * 3]; c1 += xyz[(size_t)p * 3 + 1]; c2 += xyz[(size_t)p * 3 + 2]; }
+  bool more = true;
+  while (more) {
+    uint32_t kk[16]; int pp[16]; float q[16][3];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int jj = min(j + u, n - 1); kk[u] = keys_sorted[jj]; pp[u] = perm[jj]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { q[u][0] = xyz[(size_t)pp[u] * 3]; q[u][1] = xyz[(size_t)pp[u] * 3 + 1]; q[u][2] = xyz[(size_t)pp[u] * 3 + 2]; }
+    int taken = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      if (more && j + u < n && kk[u] == key) { c0 += q[u][0]; c1 += q[u][1]; c2 += q[u][2]; taken++; }
+      else more = false;
+    }
+    j += taken;
+  }
   const float cnt = (float)(j - i);
   out[(size_t)s * 3] = c0 / cnt; out[(size_t)s * 3 + 1] = c1 / cnt; out[(size_t)s * 3 + 2] = c2 / cnt;
 }
