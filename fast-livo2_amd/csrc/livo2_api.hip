@@ -119,6 +119,8 @@ struct livo2_ctx {
   double chain_kernel_us = 0.0;
   int32_t *d_ret_blob = nullptr; size_t ret_blob_cap = 0; void *h_ret = nullptr; size_t h_ret_cap = 0;      // packed results of livo2_visual_retrieve_from_map (k_ret_pack), pinned landing block
   void *h_img = nullptr; size_t h_img_cap = 0;                                                              // pinned staging of that call's image
+  hipStream_t stream_img = nullptr; hipEvent_t img_ready = nullptr;                                          // that image's DMA runs beside the selection kernels
+  void *h_err = nullptr; size_t h_err_cap = 0;                                                              // pinned landing block of livo2_visual_update_fetch's errors[]
   // IMU propagation (N4)
   double *d_imu_steps = nullptr, *d_imu_poses = nullptr; size_t imu_steps_cap = 0, imu_poses_cap = 0; livo2_state *d_imu_state = nullptr;   // [2]: in, out
   double imu_kernel_us = 0.0;
@@ -197,6 +199,7 @@ struct livo2_ctx {
   int32_t *mt_idx = nullptr, *mt_order = nullptr, *mt_head = nullptr, *mt_slot = nullptr, *mt_seg_begin = nullptr, *mt_seg_root = nullptr, *mt_nseg = nullptr;
   size_t mt_idx_cap = 0, mt_order_cap = 0, mt_head_cap = 0, mt_slot_cap = 0, mt_seg_begin_cap = 0, mt_seg_root_cap = 0;
   livo2_state *mt_state = nullptr;
+  int mt_last_touched = 0;                  // root voxels the last update touched (sizes the next one's lanes per root)
   int mt_pv_n = -1;                         // points of the pv_list in mt_in_pw / mt_in_var (last map-tree update), -1: none since the last set_scan
   int32_t *mt_rp_rows = nullptr; size_t mt_rp_rows_cap = 0; double *mt_rp_out = nullptr; size_t mt_rp_out_cap = 0;   // livo2_map_tree_read_planes staging
   double mt_kernel_us = 0.0;
@@ -764,6 +767,9 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (ctx->h_pts) e = hipHostFree(ctx->h_pts);
   if (ctx->h_ret) e = hipHostFree(ctx->h_ret);
   if (ctx->h_img) e = hipHostFree(ctx->h_img);
+  if (ctx->h_err) e = hipHostFree(ctx->h_err);
+  if (ctx->img_ready) e = hipEventDestroy(ctx->img_ready);
+  if (ctx->stream_img) e = hipStreamDestroy(ctx->stream_img);
   if (ctx->h_delta) e = hipHostFree(ctx->h_delta);
   if (ctx->h_frame_res) e = hipHostFree(ctx->h_frame_res);
   for (int k = 0; k < 2; k++) { if (ctx->frame_stage[k]) e = hipHostFree(ctx->frame_stage[k]); if (ctx->frame_stage_ev[k]) e = hipEventDestroy(ctx->frame_stage_ev[k]); if (ctx->frame_res_ev[k]) e = hipEventDestroy(ctx->frame_res_ev[k]); }

@@ -60,6 +60,7 @@ struct MapTreeArgs {
   int32_t n, build;
   int32_t slab;                                      // points per default temp_points_ region (see MT_SLAB_MIN)
   int32_t may_pop;                                   // host-side note: bit 0 / 1 / 2 = the free stack of node ids / plane rows / 52-point regions is non-empty
+  int32_t spread;                                    // k_mt_update / k_mt_emit: lanes per root = MT_LPG * spread, the first MT_LPG work (set per launch)
 };
 
 // The free stacks live behind the counters in the SAME allocation — [MTC_TOTAL counters][node ids: cap_nodes][plane rows: cap_planes][regions: cap_points /
@@ -254,6 +255,10 @@ __global__ void __launch_bounds__(64) k_mt_overflow(MapTreeArgs a) {
 template <bool RECYCLE> struct MtGroup {
   const MapTreeArgs &a; int lane;
   __device__ MtGroup(const MapTreeArgs &a_, int l) : a(a_), lane(l) {}
+  // (round 6: the previous point's path kept per depth in LDS — a root's consecutive points mostly end in the same leaf, and every node on the way is a dependent 128-B
+  //  load — changed nothing measurable once a wave ran one root only: 328 / 351 / 316 us without, 335 / 345 / 362 us with, whole chain at 15 k points.  Not kept.)
+  __device__ DevNode get_node(int, int id) { return a.nodes[id]; }
+  __device__ void put_node(int, int id, const DevNode &n) { if (lane == 0) a.nodes[id] = n; }
 
   __device__ int thr(int layer) const { return a.layer_init_num[layer <= LIVO2_MAX_LAYER ? layer : LIVO2_MAX_LAYER]; }
   // temp_points_.push_back(pv)
@@ -413,13 +418,12 @@ template <bool RECYCLE> struct MtGroup {
   __device__ void update(int root, const double *pw, const double *var) {
     int id = root;
     for (int depth = 0; depth <= LIVO2_MAX_LAYER + 1; depth++) {
-      DevNode n = a.nodes[id];
+      DevNode n = get_node(depth, id);
       if (!n.init_octo) {
         n.new_points++;
-        if (!push(n, pw, var)) { if (lane == 0) a.nodes[id] = n; return; }
+        if (!push(n, pw, var)) { put_node(depth, id, n); return; }
         if (n.n_temp > thr(n.layer)) init_octo_tree(id, n);
-        else if (lane == 0) a.nodes[id] = n;
-        if (lane == 0) a.nodes[id] = n;
+        put_node(depth, id, n);
         return;
       }
       if (n.is_plane) {
@@ -428,7 +432,7 @@ template <bool RECYCLE> struct MtGroup {
           push(n, pw, var);
           if (n.new_points > a.update_size_threshold) { fit(n); n.new_points = 0; }
           if (n.n_temp >= a.max_points_num) { freeze(n); n.new_points = 0; }
-          if (lane == 0) a.nodes[id] = n;
+          put_node(depth, id, n);
         }
         return;
       }
@@ -442,7 +446,7 @@ template <bool RECYCLE> struct MtGroup {
           if (cid < 0) return;
 #pragma unroll
           for (int q = 0; q < 8; q++) if (q == leafnum) n.child[q] = cid;
-          if (lane == 0) a.nodes[id] = n;
+          put_node(depth, id, n);
           wave_sync();
         }
         id = cid;
@@ -453,7 +457,7 @@ template <bool RECYCLE> struct MtGroup {
         push(n, pw, var);
         if (n.new_points > a.update_size_threshold) { fit(n); n.new_points = 0; }
         if (n.n_temp > a.max_points_num) { freeze(n); n.new_points = 0; }
-        if (lane == 0) a.nodes[id] = n;
+        put_node(depth, id, n);
       }
       return;
     }
@@ -461,7 +465,13 @@ template <bool RECYCLE> struct MtGroup {
 };
 
 template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / MT_LPG, lane = threadIdx.x & (MT_LPG - 1);
+  // a.spread (1, 2, 4 or 8) groups' worth of lanes per root, of which the first MT_LPG work.  The eight state machines of a wave DIVERGE (one descends, one fits a plane,
+  // one cuts a node ...) and a wave runs them one after the other: with spread 8 a wave runs ONE root's machine.  Round 6, whole update chain at 15 k points (1 900
+  // touched roots): 503-579 -> 320-367 us; at 94 k points (12 000 roots) eight times the waves no longer fit the device and the chain gets slower (517 -> 926 us), so the
+  // host picks the spread from the number of roots the previous update touched (map_tree_run).
+  const int width = MT_LPG * max(a.spread, 1);
+  if ((int)(threadIdx.x & (width - 1)) >= MT_LPG) return;
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / width, lane = threadIdx.x & (MT_LPG - 1);
   if (g >= *n_seg_p) return;
   const int root = a.seg_root[g];
   if (root < 0) return;
@@ -575,7 +585,9 @@ __global__ void __launch_bounds__(256) k_mt_all_roots_dirty(MapTreeArgs a) {
 // ---- what k_lidar_residual reads: the root's slot and, for a non-plane root, the depth-first list of its descendant planes (record copies) -----------
 // build_single_residual (voxel_map.cpp:713-786) evaluates a node's plane if is_plane_, otherwise recurses into all eight leaves while layer < max_layer.
 __global__ void __launch_bounds__(256) k_mt_emit(MapTreeArgs a) {
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / MT_LPG, lane = threadIdx.x & (MT_LPG - 1);
+  const int width = MT_LPG * max(a.spread, 1);                // (lanes per root as in k_mt_update: the subtree walks of a wave's roots diverge too)
+  if ((int)(threadIdx.x & (width - 1)) >= MT_LPG) return;
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / width, lane = threadIdx.x & (MT_LPG - 1);
   if (g >= a.counters[MTC_DIRTY]) return;
   const int rid = a.dirty_list[g];
   DevNode r = a.nodes[rid];

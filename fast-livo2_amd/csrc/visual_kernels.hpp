@@ -644,7 +644,7 @@ __device__ __forceinline__ void visual_finish_body(DevCtl *__restrict__ ctl, con
     mat3_mul_Bt(a.Rci, sc, Rcw);
     for (int j = 0; j < 9; j++) ctl->visual.Rcw[j] = Rcw[j];
     for (int j = 0; j < 3; j++) ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * sc[9] + Rcw[j * 3 + 1] * sc[10]) + Rcw[j * 3 + 2] * sc[11]);
-    ctl->visual.n_steps = n_steps;
+    ctl->visual.n_steps = n_steps; ctl->visual.pad = 0;
   }
 }
 
@@ -1050,7 +1050,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
   if (blockIdx.x != 0) return;
   // A grid that lost a block (not co-resident: admission is per process, advisor round 3) commits NOTHING: ctl->cur, cov and G stay what the launch found, only the
   // flag goes up, and livo2_visual_update_fetch re-runs the update as the launch-per-step sequence from the inputs it kept.
-  if (SL.timed_out) { if (tid == 0) ctl->hdr.pad[0] = 1; return; }
+  if (SL.timed_out) { if (tid == 0) { ctl->hdr.pad[0] = 1; ctl->visual.pad = 1; } return; }      // (visual.pad: the flag travels with the result block — one copy command less per fetch)
   if (tid == 0) p.base[0] = SL.base + (uint32_t)step_global;     // (every other block read it before it published its first row, and this block has seen all of those)
   // ---- block 0: the result.  state->cov -= G * state->cov (vio.cpp:800), updateFrameState (vio.cpp:1690-1697)
   for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
@@ -1071,6 +1071,6 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
     for (int j = 0; j < 9; j++) ctl->visual.Rcw[j] = Rcw[j];
     for (int j = 0; j < 3; j++) ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * s.cur[9] + Rcw[j * 3 + 1] * s.cur[10]) + Rcw[j * 3 + 2] * s.cur[11]);
     ctl->visual.n_steps = SL.n_steps; ctl->hdr.n_steps = SL.n_steps; ctl->hdr.last_error = SL.last_error; ctl->hdr.stop = SL.stop;
-    ctl->hdr.pad[0] = 0;
+    ctl->hdr.pad[0] = 0; ctl->visual.pad = 0;
   }
 }

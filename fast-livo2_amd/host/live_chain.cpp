@@ -11,7 +11,8 @@
 // reported on its own, outside the four stages.
 // Growing-map mode (the directory holds grow_cfg.bin, scenarios/live_inputs.py make_live(grow=n)): ONE visual map installed before frame 0 and changed after every frame
 // by a scripted stand-in for the maintenance; syncFeatMap then applies O(changes) deltas and is timed INSIDE the frame (stage 5 of live_out.bin).
-// Usage: live_chain <dir> [lean]   "lean": host_point_lists_ = false (no pv_list_ / ptpl_list_ on the host) and `pg` read where the map update left it on the GPU.
+// Usage: live_chain <dir> [lean]   "lean": host_point_lists_ = false (no pv_list_ / ptpl_list_ on the host), `pg` read where the map update left it on the GPU, the map
+//        update on the context's second stream (LIVO2_LIVE_SYNC_MAP=1: synchronous) and retrieval + visual update through VIOManager::retrieveAndUpdate (LIVO2_LIVE_SPLIT_VIO=1: two calls).
 // Output: live_out.bin [F][5] ms (StateEstimation, UpdateVoxelMapFromPosterior, retrieveFromVisualSparseMap, computeJacobianAndUpdateEKF, syncFeatMap),
 //         live_states.bin [F][2] livo2_state (LIO posterior, VIO posterior), live_counts.bin [F][2] int32 (effct_feat_num_, total_points),
 //         live_sub_pos.bin: pos_ of visual_submap->voxel_points, frame after frame.
@@ -184,6 +185,7 @@ int main(int argc, char **argv) {
     vio.normal_en = ccfg[1] != 0; vio.ncc_en = ccfg[2] != 0; vio.ncc_thre = ccfg[3]; vio.outlier_threshold = ccfg[4]; vio.patch_pyrimid_level = (int)ccfg[5];
     vio.border = (int)ccfg[6]; vio.grid_n_height = (int)ccfg[7]; vio.grid_size = 5; vio.grid_n_width = 0;
     vio.pg_from_map_update_ = lean;
+    const bool pair_call = lean && std::getenv("LIVO2_LIVE_SPLIT_VIO") == nullptr;   // lean: VIOManager::retrieveAndUpdate (round 6); the env restores the two separate calls
     const size_t img_bytes = (size_t)vio.width * vio.height;
 
     // ---- the frames
@@ -242,9 +244,15 @@ int main(int argc, char **argv) {
       livo2_state s_lio; state.to_abi(s_lio);
       state_propagat = state;                                                        // processImu before the VIO step (LIVMapper.cpp:256)
       vio.updateFrameState(state);                                                   // vio.cpp:1799-1800
-      vio.retrieveFromVisualSparseMap(img, vm.pv_list_);                             // vio.cpp:1808 (lean: pg stays on the device)
-      const double c = ms_since(t0);
-      vio.computeJacobianAndUpdateEKF(img);                                          // vio.cpp:1810, updates *state = _state
+      double c;
+      if (pair_call) {                                                               // vio.cpp:1808 + 1810 as one member: the update runs on the GPU while the host builds visual_submap's lists
+        vio.retrieveAndUpdate(img, vm.pv_list_);
+        c = vio.total_points > 0 ? std::chrono::duration<double, std::milli>(vio.update_enqueued_at_ - t0).count() : ms_since(t0);      // the stages are split where the update was enqueued
+      } else {
+        vio.retrieveFromVisualSparseMap(img, vm.pv_list_);                           // vio.cpp:1808 (lean: pg stays on the device)
+        c = ms_since(t0);
+        vio.computeJacobianAndUpdateEKF(img);                                        // vio.cpp:1810, updates *state = _state
+      }
       const double d0 = ms_since(t0);
       vm.JoinMapUpdate();                                                            // (async_map_update_: the frame is over when BOTH halves are; billed to the map-update stage)
       const double d = ms_since(t0);

@@ -276,7 +276,12 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
   cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
   std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
   livo2_state s; state_.to_abi(s);
-  if (async_map_update_ && !host_point_lists_) { dev_.check(livo2_map_tree_update_from_scan_async(dev_.ctx(), &s, &cfg)); return; }
+  if (async_map_update_ && !host_point_lists_) {
+    // state_ untouched since StateEstimation wrote it (LIVMapper.cpp:371-413 only reads it): the posterior is still on the device, no upload
+    const bool resident = posterior_valid_ && std::memcmp(&s, &posterior_, sizeof(s)) == 0;
+    dev_.check(livo2_map_tree_update_from_scan_async(dev_.ctx(), resident ? nullptr : &s, &cfg));
+    return;
+  }
   dev_.check(livo2_map_tree_update_from_scan(dev_.ctx(), &s, &cfg, 0));
   last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
   if (host_point_lists_ && !pv_list_.empty()) {        // the reference leaves the posterior point_w / var in pv_list_ (LIVMapper.cpp:417-424; `_pv_list` of :426 feeds handleVIO)
@@ -395,6 +400,7 @@ void VoxelMapManager::StateEstimation(StatesGroup &state_propagat) {
   dev_.check(livo2_lidar_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, host_point_lists_ ? &pts : nullptr));
   const double t_update = since();
   state_.from_abi(res.state);
+  state_.to_abi(posterior_); posterior_valid_ = true;                              // (what UpdateVoxelMapFromPosterior compares state_ with)
   std::memcpy(position_last_.data(), res.position_last, 24);
   {   // euler_cur = RotMtoEuler(state_.rot_end) (so3_math.h:68-87); geoQuat_ = tf::createQuaternionMsgFromRollPitchYaw(euler_cur) (voxel_map.cpp:493)
     const double *R = res.state.rot;
@@ -720,46 +726,87 @@ void VIOManager::updateFrameState(const StatesGroup &s) {                       
   R_f_w_new = Rcw; t_f_w_new = Pcw;
 }
 
-void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg) {
-  if (feat_map.empty()) return;                                                   // reference src/vio.cpp:354
+// retrieveFromVisualSparseMap in three stages (the members r_* carry the chain's outputs between them), so that retrieveAndUpdate below can put the update on the
+// GPU before the host lists are built:
+//   retrieveChain  — everything up to the device chain's results (total_points known, the survivors resident as the frame of the next update)
+//   retrieveLists  — visual_submap's lists and the ref_patch write-backs from those results (host only: ~50 ns per candidate of pointer chasing)
+//   retrieveRaycast — add_from_voxel_map (raycast_en; synchronises the stream)
+bool VIOManager::retrieveChain(const GrayImage &img, const std::vector<pointWithVar> &pg) {
+  if (feat_map.empty()) return false;                                             // reference src/vio.cpp:354
   SubSparseMap &sm = *visual_submap;                                              // visual_submap->reset(), vio.cpp:359
   sm.voxel_points.clear(); sm.search_levels.clear(); sm.errors.clear(); sm.inv_expo_list.clear(); sm.warp_patch.clear();
+  static const bool shim_prof = std::getenv("LIVO2_SHIM_PROF") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); };
   syncFeatMap(img);
   gridSetup();
   const int length = grid_n_width * grid_n_height, L = patch_pyrimid_level;
-  std::vector<double> pgw(pg.size() * 3);
-  for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24);
+  std::vector<double> pgw;
+  if (!pg_from_map_update_) { pgw.resize(pg.size() * 3); for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24); }
   const livo2_select_cfg sc = selectCfg();
   livo2_retrieve_cfg rc{};
   rc.cam = sc.cam;
   std::memcpy(rc.R_cur, R_f_w_new.data(), 72); std::memcpy(rc.t_cur, t_f_w_new.data(), 24);
   rc.inv_expo_cur = state->inv_expo_time; rc.patch_pyrimid_level = L; rc.normal_en = normal_en; rc.ncc_en = ncc_en; rc.ncc_thre = ncc_thre; rc.outlier_threshold = outlier_threshold;
-  std::vector<int32_t> cell(length), cobs(length), acc(length), sl(length), cand_cell(length);
-  std::vector<float> err(length);
+  r_cell_.resize(length); r_cobs_.resize(length); r_acc_.resize(length); r_sl_.resize(length); r_cand_cell_.resize(length); r_err_.resize(length);
   map_dist.assign(length, 10000.0f);
   livo2_retrieve_chain_out out{};
-  out.cell_point = cell.data(); out.cell_dist = map_dist.data(); out.cell_obs = cobs.data(); out.cand_cell = cand_cell.data();
-  out.tail.accepted = acc.data(); out.tail.search_level = sl.data(); out.tail.error = err.data();
-  int32_t n_cand = 0, n_acc = 0;
-  if (pg_from_map_update_) dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, nullptr, LIVO2_PG_FROM_MAP_UPDATE, &sc, &rc, &out, &n_cand, &n_acc));
-  else dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, pgw.data(), (int32_t)pg.size(), &sc, &rc, &out, &n_cand, &n_acc));
-  for (int i = 0; i < n_cand; i++) {
-    const int c = cand_cell[i];
-    VisualPoint *pt = mirror_[cell[c]]; Feature *ref_ftr = obs_mirror_[cobs[c]];
-    if (normal_en) { pt->ref_patch = ref_ftr; pt->has_ref_patch_ = true; }        // vio.cpp:660-661, 689-690
-    if (!acc[i]) continue;
-    sm.voxel_points.push_back(pt); sm.search_levels.push_back(sl[i]); sm.errors.push_back(err[i]); sm.inv_expo_list.push_back(ref_ftr->inv_expo_time_);   // vio.cpp:762-767
-  }
+  out.cell_point = r_cell_.data(); out.cell_dist = map_dist.data(); out.cell_obs = r_cobs_.data(); out.cand_cell = r_cand_cell_.data();
+  out.tail.accepted = r_acc_.data(); out.tail.search_level = r_sl_.data(); out.tail.error = r_err_.data();
+  int32_t n_acc = 0;
+  r_n_cand_ = 0;
+  const double t_before = since();
+  if (pg_from_map_update_) dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, nullptr, LIVO2_PG_FROM_MAP_UPDATE, &sc, &rc, &out, &r_n_cand_, &n_acc));
+  else dev_.check(livo2_visual_retrieve_from_map(dev_.ctx(), img.data, img.cols, img.rows, img.step, pgw.data(), (int32_t)pg.size(), &sc, &rc, &out, &r_n_cand_, &n_acc));
   total_points = n_acc;
   frame_resident_ = true;
-  sm.add_from_voxel_map.clear();
-  if (raycast_en) {
-    std::vector<double> add((size_t)length * 6);
-    int32_t n_add = 0;
-    dev_.check(livo2_visual_raycast_fetch(dev_.ctx(), add.data(), length, &n_add));
-    sm.add_from_voxel_map.resize(n_add);
-    for (int k = 0; k < n_add; k++) { std::memcpy(sm.add_from_voxel_map[k].point_w.data(), &add[(size_t)k * 6], 24); std::memcpy(sm.add_from_voxel_map[k].normal.data(), &add[(size_t)k * 6 + 3], 24); }
+  if (shim_prof) std::fprintf(stderr, "retrieveFromVisualSparseMap: before the call %.3f ms, call %.3f ms (chain kernels %.1f us), %d candidates\n", t_before, since() - t_before,
+                              livo2_visual_retrieve_from_map_last_kernel_us(dev_.ctx()), r_n_cand_);
+  return true;
+}
+
+void VIOManager::retrieveLists() {
+  SubSparseMap &sm = *visual_submap;
+  const size_t na = (size_t)std::max(total_points, 0);
+  sm.voxel_points.reserve(na); sm.search_levels.reserve(na); sm.errors.reserve(na); sm.inv_expo_list.reserve(na);
+  for (int i = 0; i < r_n_cand_; i++) {
+    const int c = r_cand_cell_[i];
+    VisualPoint *pt = mirror_[r_cell_[c]]; Feature *ref_ftr = obs_mirror_[r_cobs_[c]];
+    if (normal_en) { pt->ref_patch = ref_ftr; pt->has_ref_patch_ = true; }        // vio.cpp:660-661, 689-690
+    if (!r_acc_[i]) continue;
+    sm.voxel_points.push_back(pt); sm.search_levels.push_back(r_sl_[i]); sm.errors.push_back(r_err_[i]); sm.inv_expo_list.push_back(ref_ftr->inv_expo_time_);   // vio.cpp:762-767
   }
+}
+
+void VIOManager::retrieveRaycast() {
+  SubSparseMap &sm = *visual_submap;
+  sm.add_from_voxel_map.clear();
+  if (!raycast_en) return;
+  const int length = grid_n_width * grid_n_height;
+  std::vector<double> add((size_t)length * 6);
+  int32_t n_add = 0;
+  dev_.check(livo2_visual_raycast_fetch(dev_.ctx(), add.data(), length, &n_add));
+  sm.add_from_voxel_map.resize(n_add);
+  for (int k = 0; k < n_add; k++) { std::memcpy(sm.add_from_voxel_map[k].point_w.data(), &add[(size_t)k * 6], 24); std::memcpy(sm.add_from_voxel_map[k].normal.data(), &add[(size_t)k * 6 + 3], 24); }
+}
+
+void VIOManager::retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg) {
+  if (!retrieveChain(img, pg)) return;
+  retrieveLists();
+  retrieveRaycast();
+}
+
+// The two calls processFrame makes back to back (reference src/vio.cpp:1808, 1810), with the same results in the same members, in the order that suits a GPU: the
+// update is ENQUEUED as soon as the chain has told the host how many patches survived, the host lists are built while it runs, then its result is fetched.
+// (computeJacobianAndUpdateEKF reads nothing retrieveLists writes: positions, patches, levels and exposure times of the survivors are resident since the chain.)
+void VIOManager::retrieveAndUpdate(const GrayImage &img, const std::vector<pointWithVar> &pg) {
+  if (kernel_times_en || inverse_composition_en) { retrieveFromVisualSparseMap(img, pg); computeJacobianAndUpdateEKF(img); return; }   // (both read visual_submap's lists / toggle options around the call)
+  if (!retrieveChain(img, pg)) { computeJacobianAndUpdateEKF(img); return; }                          // (an empty feat_map leaves total_points alone, vio.cpp:354, 786)
+  retrieveRaycast();
+  const bool run = total_points > 0;                                               // vio.cpp:786
+  if (run) updateEnqueue(img);
+  retrieveLists();
+  if (run) updateFetch();
 }
 
 void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<Candidate> &cands) {
@@ -799,16 +846,24 @@ void VIOManager::warpAndGateCandidates(const GrayImage &img, const std::vector<C
 
 void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
   if (total_points == 0) return;            // reference src/vio.cpp:786
+  updateEnqueue(img);
+  updateFetch();
+}
+
+// computeJacobianAndUpdateEKF up to the enqueue of the update (livo2_visual_update_async) ...
+void VIOManager::updateEnqueue(const GrayImage &img) {
   const int M = total_points, L = patch_pyrimid_level;
-  std::vector<double> pos((size_t)M * 3);
-  std::vector<float> warp((size_t)M * L * 64);
-  for (int i = 0; i < M && !frame_resident_; i++) {
-    std::memcpy(&pos[(size_t)i * 3], visual_submap->voxel_points[i]->pos_.data(), 24);
-    std::memcpy(&warp[(size_t)i * L * 64], visual_submap->warp_patch[i].data(), (size_t)L * 64 * sizeof(float));   // ragged vector<vector<float>> -> [M][L][64]
-  }
-  if (!frame_resident_)
+  u_t0_ = std::chrono::steady_clock::now();
+  if (!frame_resident_) {                   // (a sub-map the retrieval left on the device needs none of this: the 1 MB of warp_patch alone was ~0.05 ms of zero-fill per frame)
+    std::vector<double> pos((size_t)M * 3);
+    std::vector<float> warp((size_t)M * L * 64);
+    for (int i = 0; i < M; i++) {
+      std::memcpy(&pos[(size_t)i * 3], visual_submap->voxel_points[i]->pos_.data(), 24);
+      std::memcpy(&warp[(size_t)i * L * 64], visual_submap->warp_patch[i].data(), (size_t)L * 64 * sizeof(float));   // ragged vector<vector<float>> -> [M][L][64]
+    }
     dev_.check(livo2_visual_set_frame(dev_.ctx(), img.data, img.cols, img.rows, img.step, pos.data(), warp.data(), visual_submap->search_levels.data(),
                                       visual_submap->inv_expo_list.data(), M, L));
+  }
   frame_resident_ = false;
   if (inverse_composition_en) {             // gather the reference patches (distinct reference images are uploaded once each)
     std::vector<const uint8_t *> imgs; std::vector<int32_t> idx(M);
@@ -837,9 +892,19 @@ void VIOManager::computeJacobianAndUpdateEKF(const GrayImage &img) {
   if (kernel_times_en) { dev_.check(livo2_ctx_set_option(dev_.ctx(), "visual_persistent", 0)); dev_.check(livo2_ctx_kernel_timing(dev_.ctx(), 1)); livo2_ctx_kernel_timing_read(dev_.ctx(), 1, nullptr, nullptr, 1); livo2_ctx_kernel_timing_read(dev_.ctx(), 3, nullptr, nullptr, 1); }
   livo2_state s_in, s_prop;
   state->to_abi(s_in); state_propagat->to_abi(s_prop);
+  dev_.check(livo2_visual_update_async(dev_.ctx(), &s_in, &s_prop, &cfg));
+  update_enqueued_at_ = std::chrono::steady_clock::now();
+}
+
+// ... and from its fetch on
+void VIOManager::updateFetch() {
+  static const bool shim_prof = std::getenv("LIVO2_SHIM_PROF") != nullptr;
+  const int M = total_points;
   static livo2_visual_result res;
   visual_submap->errors.resize(M);
-  dev_.check(livo2_visual_update(dev_.ctx(), &s_in, &s_prop, &cfg, &res, visual_submap->errors.data()));
+  dev_.check(livo2_visual_update_fetch(dev_.ctx(), &res, visual_submap->errors.data()));
+  if (shim_prof) std::fprintf(stderr, "computeJacobianAndUpdateEKF: %.3f ms from the enqueue to the fetched result (%d steps)\n",
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u_t0_).count(), res.n_steps);
   if (kernel_times_en) {
     double ms = 0; int64_t nl = 0;
     dev_.check(livo2_ctx_kernel_timing_read(dev_.ctx(), 1, &ms, &nl, 1)); compute_jacobian_time = ms * 1e-3;

@@ -9,6 +9,7 @@
 // ABI takes, moves data across, and scatters the results back into the members the rest of LIVMapper reads.
 #pragma once
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -205,6 +206,7 @@ private:
   std::vector<const VoxelPlane *> plane_by_index_;
   std::vector<int> plane_layer_;
   void *pin_ = nullptr; size_t pin_bytes_ = 0;       // page-locked receive buffer of the per-point outputs
+  livo2_state posterior_{}; bool posterior_valid_ = false;      // state_ as StateEstimation left it (= what is still on the device)
 };
 
 // ---- IMU ------------------------------------------------------------------------------------------------------------------
@@ -316,6 +318,11 @@ public:
   // Fills visual_submap (voxel_points, search_levels, errors, inv_expo_list), map_dist and total_points; the survivors stay resident as the frame
   // of the next computeJacobianAndUpdateEKF.  feat_map_dirty_ must be set whenever feat_map, an obs_ list, a normal or a ref_patch changed on the host.
   void retrieveFromVisualSparseMap(const GrayImage &img, const std::vector<pointWithVar> &pg);
+  // retrieveFromVisualSparseMap(img, pg); computeJacobianAndUpdateEKF(img); — the two calls VIOManager::processFrame makes back to back (reference src/vio.cpp:1808,
+  // 1810) — as ONE member with the same results in the same members (tests/test_live_chain_gpu.py): the update is enqueued as soon as the retrieval chain has returned
+  // its counts, visual_submap's host lists are built while it runs on the GPU (round 6: ~0.06 ms of pointer chasing per avia frame leaves the critical path).
+  void retrieveAndUpdate(const GrayImage &img, const std::vector<pointWithVar> &pg);
+  std::chrono::steady_clock::time_point update_enqueued_at_{};      // when the last update went onto the stream (a caller that times the two stages splits retrieveAndUpdate here)
   // pg_from_map_update_: `pg` is ignored and the scan's posterior world points are read where VoxelMapManager::UpdateVoxelMap[FromPosterior] (same Device) left
   // them on the GPU (LIVMapper.cpp:413-426 `_pv_list`, :306) — the lean form: pv_list_ never exists on the host.
   bool pg_from_map_update_ = false;
@@ -345,6 +352,16 @@ private:
   // alive and keep its address for as long as a Feature that names it is in the map (the reference keeps every reference frame's cv::Mat alive through its Features'
   // shared pixels, feature.h:19-54); a caller that frees one and gets a new frame at the same address must mark the map dirty (feat_map_dirty_ = true: full upload).
   std::vector<const uint8_t *> img_slots_;
+  // stages of retrieveFromVisualSparseMap / computeJacobianAndUpdateEKF (livo2_host.cpp) and the chain's outputs they hand on
+  bool retrieveChain(const GrayImage &img, const std::vector<pointWithVar> &pg);
+  void retrieveLists();
+  void retrieveRaycast();
+  void updateEnqueue(const GrayImage &img);
+  void updateFetch();
+  std::vector<int32_t> r_cell_, r_cobs_, r_acc_, r_sl_, r_cand_cell_;
+  std::vector<float> r_err_;
+  int32_t r_n_cand_ = 0;
+  std::chrono::steady_clock::time_point u_t0_{};
   void applyPendingDelta(const GrayImage &img);
   void mirrorFeatMap(bool with_obs, const GrayImage *img);
   void gridSetup();

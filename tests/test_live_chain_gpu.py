@@ -65,6 +65,20 @@ def test_full_and_lean_give_the_same_states(chain):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_retrieve_and_update_as_one_member_equals_the_two_calls(chain):
+    """lean runs vio.cpp:1808 + 1810 through VIOManager::retrieveAndUpdate (the update is enqueued before visual_submap's host lists are built); with
+    LIVO2_LIVE_SPLIT_VIO=1 the same program makes the two separate calls.  Same states, same sub-maps (members, order), same counts, bit for bit."""
+    d, live, recs, want = chain
+    outs = []
+    for env_add in ({}, {"LIVO2_LIVE_SPLIT_VIO": "1"}, {"LIVO2_LIVE_SPLIT_VIO": "1", "LIVO2_LIVE_SYNC_MAP": "1"}):
+        r = subprocess.run([EXE, d, "lean"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_add))
+        assert r.returncode == 0, r.stderr
+        outs.append([np.fromfile(os.path.join(d, n)) for n in ("live_states.bin", "live_sub_pos.bin")] + [np.fromfile(os.path.join(d, "live_counts.bin"), np.int32)])
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
 @pytest.fixture(scope="module")
 def grow_chain(tmp_path_factory):
     from oracle import live_chain as OC
