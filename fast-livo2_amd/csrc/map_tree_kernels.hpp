@@ -73,6 +73,7 @@ __device__ __forceinline__ int32_t *mt_free_slabs(const MapTreeArgs &a) { return
 // point regions come in whole multiples of `slab` points, so that a freed region of any size goes back as `slab`-sized pieces
 __device__ __forceinline__ int mt_round_slab(const MapTreeArgs &a, int points) { return ((points + a.slab - 1) / a.slab) * a.slab; }
 __device__ __forceinline__ int grp_first(int v) { return __shfl(v, (threadIdx.x & 63) & ~(MT_LPG - 1), 64); }
+template <int LPG> __device__ __forceinline__ int grp_first_n(int v) { return __shfl(v, (threadIdx.x & 63) & ~(LPG - 1), 64); }
 __device__ __forceinline__ void mt_error(const MapTreeArgs &a, int bit) { atomicOr(&a.counters[MTC_ERROR], bit); }
 
 // packed 3 x 21-bit voxel key (offset 2^20) <-> VOXEL_LOCATION
@@ -251,8 +252,8 @@ __global__ void __launch_bounds__(64) k_mt_overflow(MapTreeArgs a) {
   a.counters[MTC_OVERFLOW] = 0;
 }
 
-// ---- the octree state machine, one group of MT_LPG lanes per touched root --------------------------------------------------------------
-template <bool RECYCLE> struct MtGroup {
+// ---- the octree state machine, one group of LPG (MT_LPG, or a whole wave) lanes per touched root --------------------------------------------------------------
+template <bool RECYCLE, int LPG = MT_LPG> struct MtGroup {
   const MapTreeArgs &a; int lane;
   __device__ MtGroup(const MapTreeArgs &a_, int l) : a(a_), lane(l) {}
   // (round 6: the previous point's path kept per depth in LDS — a root's consecutive points mostly end in the same leaf, and every node on the way is a dependent 128-B
@@ -265,7 +266,7 @@ template <bool RECYCLE> struct MtGroup {
   __device__ bool push(DevNode &n, const double *pw, const double *var) {
     if (n.n_temp >= n.pts_cap) { mt_error(a, MTE_REGION); return false; }
     const size_t at = (size_t)n.pts_off + n.n_temp;
-    for (int q = lane; q < 12; q += MT_LPG) { if (q < 3) a.pool_pw[at * 3 + q] = pw[q]; else a.pool_var[at * 9 + q - 3] = var[q - 3]; }
+    for (int q = lane; q < 12; q += LPG) { if (q < 3) a.pool_pw[at * 3 + q] = pw[q]; else a.pool_var[at * 9 + q - 3] = var[q - 3]; }
     n.n_temp++;
     return true;
   }
@@ -277,15 +278,15 @@ template <bool RECYCLE> struct MtGroup {
   __device__ void fit(DevNode &n) {
     wave_sync();                                              // the pushes of this group are visible to its 8 lanes
     FitRes R;
-    plane_fit_core<MT_LPG, true>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);      // upper triangle of plane_var_ only
+    plane_fit_core<LPG, true>(a.pool_pw, a.pool_var, n.pts_off, n.pts_off + n.n_temp, lane, a.planer_threshold, R);      // upper triangle of plane_var_ only
     n.is_plane = R.is_plane ? 1 : 0;
     if (!R.is_plane) return;
-    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc_plane<RECYCLE>(a); n.plane = grp_first(row); if (n.plane < 0) { n.is_plane = 0; return; } }
+    if (n.plane < 0) { int row = 0; if (lane == 0) row = mt_alloc_plane<RECYCLE>(a); n.plane = grp_first_n<LPG>(row); if (n.plane < 0) { n.is_plane = 0; return; } }
     double *rec = a.planes + (size_t)n.plane * PLANE_REC_DOUBLES;
     const double nrm[3] = {R.vmin[0], R.vmin[1], R.vmin[2]};
     const float radius = (float)sqrt(R.ev_max);
     const float dd = (float)(-((nrm[0] * R.c[0] + nrm[1] * R.c[1]) + nrm[2] * R.c[2]));
-    auto put = [&](int k, double v) { if (lane == k % MT_LPG) rec[k] = v; };
+    auto put = [&](int k, double v) { if (lane == k % LPG) rec[k] = v; };
 #pragma unroll
     for (int k = 0; k < 3; k++) { put(k, nrm[k]); put(3 + k, R.c[k]); }
     double S[21];
@@ -300,7 +301,7 @@ template <bool RECYCLE> struct MtGroup {
     double hot[PLANE_HOT_DOUBLES];
     plane_hot_words(nrm, R.c, S, hot);
 #pragma unroll
-    for (int k = 0; k < PLANE_HOT_DOUBLES; k++) if (lane == k % MT_LPG) a.planes_hot[(size_t)n.plane * PLANE_HOT_DOUBLES + k] = hot[k];
+    for (int k = 0; k < PLANE_HOT_DOUBLES; k++) if (lane == k % LPG) a.planes_hot[(size_t)n.plane * PLANE_HOT_DOUBLES + k] = hot[k];
     if (lane == 0) { PlaneAux x; x.d = dd; x.radius = radius; x.meta = n.plane | (n.layer << CAND_LAYER_SHIFT); x.pad = 0; a.plane_aux[n.plane] = x; }
     put(28, __builtin_bit_cast(double, make_int2(n.layer, 0)));       // PointToPlane::layer_ of a match (livo2_map_tree_read_planes)
 #pragma unroll
@@ -311,7 +312,7 @@ template <bool RECYCLE> struct MtGroup {
   __device__ int new_leaf(const DevNode &n, int leafnum, int cap) {
     int id = -1, off = -1;
     if (lane == 0) { id = mt_alloc_node<RECYCLE>(a); off = mt_alloc_region<RECYCLE>(a, cap); }
-    id = grp_first(id); off = grp_first(off);
+    id = grp_first_n<LPG>(id); off = grp_first_n<LPG>(off);
     if (id < 0 || off < 0) return -1;
     DevNode l;
     const int xyz[3] = {(leafnum >> 2) & 1, (leafnum >> 1) & 1, leafnum & 1};
@@ -377,7 +378,7 @@ template <bool RECYCLE> struct MtGroup {
           const DevNode &cn = a.nodes[cid];
           if (at >= cn.pts_cap) { mt_error(a, MTE_REGION); continue; }
           const size_t dst = (size_t)cn.pts_off + at;
-          for (int q = lane; q < 12; q += MT_LPG) { if (q < 3) a.pool_pw[dst * 3 + q] = a.pool_pw[src * 3 + q]; else a.pool_var[dst * 9 + q - 3] = a.pool_var[src * 9 + q - 3]; }
+          for (int q = lane; q < 12; q += LPG) { if (q < 3) a.pool_pw[dst * 3 + q] = a.pool_pw[src * 3 + q]; else a.pool_var[dst * 9 + q - 3] = a.pool_var[src * 9 + q - 3]; }
         }
         if (lane == 0) {
 #pragma unroll
@@ -426,17 +427,7 @@ template <bool RECYCLE> struct MtGroup {
         put_node(depth, id, n);
         return;
       }
-      if (n.is_plane) {
-        if (n.update_enable) {
-          n.new_points++;
-          push(n, pw, var);
-          if (n.new_points > a.update_size_threshold) { fit(n); n.new_points = 0; }
-          if (n.n_temp >= a.max_points_num) { freeze(n); n.new_points = 0; }
-          put_node(depth, id, n);
-        }
-        return;
-      }
-      if (n.layer < a.max_layer) {
+      if (!n.is_plane && n.layer < a.max_layer) {
         const int leafnum = octant(n, pw);
         int cid = -1;
 #pragma unroll
@@ -452,11 +443,14 @@ template <bool RECYCLE> struct MtGroup {
         id = cid;
         continue;
       }
-      if (n.update_enable) {                                  // a non-plane node at max_layer_ keeps collecting
+      // a plane (voxel_map.cpp:233-251), or a non-plane node at max_layer_ that keeps collecting (:268-286): the same statements but for the freeze test (>= / >).  ONE
+      // copy of them, so that the groups of a wave that re-fit in this iteration do it together whichever of the two they are (the fit is the long part)
+      if (n.update_enable) {
+        const int limit = n.is_plane ? a.max_points_num : a.max_points_num + 1;
         n.new_points++;
         push(n, pw, var);
         if (n.new_points > a.update_size_threshold) { fit(n); n.new_points = 0; }
-        if (n.n_temp > a.max_points_num) { freeze(n); n.new_points = 0; }
+        if (n.n_temp >= limit) { freeze(n); n.new_points = 0; }
         put_node(depth, id, n);
       }
       return;
@@ -464,19 +458,24 @@ template <bool RECYCLE> struct MtGroup {
   }
 };
 
-template <bool RECYCLE> __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
-  // a.spread (1, 2, 4 or 8) groups' worth of lanes per root, of which the first MT_LPG work.  The eight state machines of a wave DIVERGE (one descends, one fits a plane,
-  // one cuts a node ...) and a wave runs them one after the other: with spread 8 a wave runs ONE root's machine.  Round 6, whole update chain at 15 k points (1 900
-  // touched roots): 503-579 -> 320-367 us; at 94 k points (12 000 roots) eight times the waves no longer fit the device and the chain gets slower (517 -> 926 us), so the
-  // host picks the spread from the number of roots the previous update touched (map_tree_run).
-  const int width = MT_LPG * max(a.spread, 1);
-  if ((int)(threadIdx.x & (width - 1)) >= MT_LPG) return;
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / width, lane = threadIdx.x & (MT_LPG - 1);
+template <bool RECYCLE, int LPG> __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
+  // Lanes per root.  LPG = MT_LPG (8): a.spread (1, 2 or 4) groups' worth of lanes per root, of which the first 8 work.  The eight state machines of a wave DIVERGE
+  // (one descends, one re-fits a plane, one cuts a node ...) and a wave runs them one after the other — every root stops at every re-fit of its seven neighbours.
+  // LPG = 64: ONE root per wave, and the re-fit (init_plane: one Jacobi eigen-decomposition + a 6x3 Jacobian product per point, the long part) spread over all 64
+  // lanes.  Round 6, whole update chain at 15 k points (1 900 touched roots): 503-579 us with eight roots to a wave, 320-367 us with one (8 of 64 lanes working); at
+  // 94 k points (12 000 roots) eight times the waves no longer fit the device and the chain gets slower (517 -> 926 us), so the host picks the form from the number of
+  // roots the previous update touched (map_tree_run; profiles/r06_map_update_spread.txt).
+  // (Also tried: a wave each only for the roots with >= 12 / 24 / 48 points of the frame, the others eight to a wave — two lists from one more small kernel.  At 94 k
+  //  points 537-585 us against 511-533 us; at 15 k only the 12-point threshold, i.e. nearly every root alone, reached the one-root-per-wave time: it is not the ONE
+  //  busiest root that the neighbours' re-fits hold up, it is every root.)
+  const int width = LPG * (LPG == MT_LPG ? max(a.spread, 1) : 1);
+  if ((int)(threadIdx.x & (width - 1)) >= LPG) return;
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / width, lane = threadIdx.x & (LPG - 1);
   if (g >= *n_seg_p) return;
   const int root = a.seg_root[g];
   if (root < 0) return;
   const int b = a.seg_begin[g], e = a.seg_begin[g + 1];
-  MtGroup<RECYCLE> G(a, lane);
+  MtGroup<RECYCLE, LPG> G(a, lane);
   if (a.build) {                                              // BuildVoxelMap: every point of the voxel first, then init_octo_tree (voxel_map.cpp:568-590)
     DevNode n = a.nodes[root];
     for (int k = b; k < e; k++) {
