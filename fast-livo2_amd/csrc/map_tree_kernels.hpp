@@ -458,7 +458,13 @@ template <bool RECYCLE, int LPG = MT_LPG> struct MtGroup {
   }
 };
 
-template <bool RECYCLE, int LPG> __global__ void __launch_bounds__(256) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
+// Two waves per SIMD: the state machine with the plane fit inlined wants every register there is (256 VGPRs + as many accumulation registers as spill space, 2.8 KB of
+// scratch per lane on top: ONE wave per SIMD); held to 256 it runs two, and the chain at 94 k points takes 446-487 us instead of 511-541 (15 k: unchanged).  Three
+// or four (128 VGPRs) do not compile with this toolchain ("Subtarget requires even aligned vector registers" on a scratch reload).  round 6
+#ifndef MT_UPDATE_WPE
+#define MT_UPDATE_WPE 2
+#endif
+template <bool RECYCLE, int LPG> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT_UPDATE_WPE))) k_mt_update(MapTreeArgs a, const int32_t *__restrict__ n_seg_p) {
   // Lanes per root.  LPG = MT_LPG (8): a.spread (1, 2 or 4) groups' worth of lanes per root, of which the first 8 work.  The eight state machines of a wave DIVERGE
   // (one descends, one re-fits a plane, one cuts a node ...) and a wave runs them one after the other — every root stops at every re-fit of its seven neighbours.
   // LPG = 64: ONE root per wave, and the re-fit (init_plane: one Jacobi eigen-decomposition + a 6x3 Jacobian product per point, the long part) spread over all 64
