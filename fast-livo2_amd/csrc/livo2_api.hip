@@ -168,6 +168,7 @@ struct livo2_ctx {
   // persistent visual update (k_visual_update_persistent): one launch per computeJacobianAndUpdateEKF.  LIVO2_VISUAL_PERSISTENT=0 (or livo2_ctx_set_option) selects
   // the launch-per-step sequence instead.
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
+  bool visual_persistent_inverse = true;      // the inverse-compositional form on the resident grid too (option "visual_persistent_inverse")
   unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0;
   bool vp_xchg_dirty = true; size_t vp_err_pitch = 0; int vp_hw_rows = 0, vp_hw_m = 0;      // exchange buffers of k_visual_update_persistent: host-side view (api_visual.inc)
   // block order of k_lidar_residual (lidar_kernels.hpp, LptArgs): lifetimes per chunk written by every launch, order written by every solve; valid once a solve of this scan has run
@@ -610,7 +611,10 @@ int persist_capacity(int device) {
   if (cap[device] == 0) {
     hipDeviceProp_t prop; int per_cu = 0;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_visual_update_persistent, VP_BLOCK, 0) != hipSuccess || per_cu < 1) return 0;
+    int per_cu_inv = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_visual_update_persistent<false>, VP_BLOCK, 0) != hipSuccess || per_cu < 1) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_inv, k_visual_update_persistent<true>, VP_BLOCK, 0) != hipSuccess || per_cu_inv < 1) return 0;
+    per_cu = std::min(per_cu, per_cu_inv);
     cap[device] = prop.multiProcessorCount * std::min(per_cu, 2);        // a C4 frame takes 250 blocks (one per CU); a second grid of another context may share the CUs
   }
   return cap[device];
@@ -836,6 +840,7 @@ int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (std::strcmp(name, "lidar_block_order") == 0) { ctx->lidar_block_order = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "lidar_fused_iteration") == 0) { ctx->lidar_fused = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_persistent_inverse") == 0) { ctx->visual_persistent_inverse = value != 0; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_timeout_us") == 0) {
     if (value < 100 || value > 10000000) return fail(ctx, LIVO2_ERR_INVALID, "visual_persistent_timeout_us out of [100, 10000000]");
     ctx->vp_timeout_us = value; return LIVO2_OK;

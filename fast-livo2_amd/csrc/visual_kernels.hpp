@@ -146,6 +146,80 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
   return v;
 }
 
+// ---- inverse-compositional form (vio/inverse_composition_en; reference src/vio.cpp:1327-1518): what precomputeReferencePatches leaves per level (visual_inverse_kernels.hpp)
+struct VisualRefArgs {
+  const uint8_t *ref_imgs;           // [n_ref][height][stride]
+  const int32_t *ref_idx;            // [M] reference image of each point (ref_patch->img_)
+  const double *ref_px;              // [M][2] ref_patch->px_
+  const double *ref_f;               // [M][3] ref_patch->f_
+  const double *ref_R;               // [M][9] ref_patch->T_f_w_.rotation_matrix()
+  const double *ref_pos;             // [M][3] ref_patch->pos()
+  double *gref;                      // [M][64][2]
+  double *mref;                      // [M][16]: M_ref (12), sum g0g0, g0g1, g1g1, valid
+  int32_t n_ref, pad;
+};
+
+// bilinear weights and integer anchor of the reference (vio.cpp:1359-1368 / 1449-1458), float/double mix reproduced
+struct Anchor { int ui, vi; float w_tl, w_tr, w_bl, w_br; };
+__device__ __forceinline__ Anchor make_anchor(double pcx, double pcy, int scale) {
+  Anchor A;
+  const float u_ref = (float)pcx, v_ref = (float)pcy;
+  A.ui = (int)(floorf((float)(pcx / scale)) * (float)scale);
+  A.vi = (int)(floorf((float)(pcy / scale)) * (float)scale);
+  const float su = (u_ref - (float)A.ui) / (float)scale, sv = (v_ref - (float)A.vi) / (float)scale;
+  A.w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv));
+  A.w_tr = (float)((double)su * (1.0 - (double)sv));
+  A.w_bl = (float)((1.0 - (double)su) * (double)sv);
+  A.w_br = su * sv;
+  return A;
+}
+
+// precomputeReferencePatches for ONE patch by one wave (lane = pixel 8x + y); Wf / Bf: 11 x 11 and 10 x 10 floats of the calling wave's LDS
+__device__ __forceinline__ void ref_precompute_patch(const VisualKernelArgs &a, const VisualRefArgs &r, const int level, const int patch, const int lane, float *Wf, float *Bf) {
+  const int scale = 1 << level;                              // no search level here (vio.cpp:1341)
+  const double p[3] = {a.pos[(size_t)patch * 3], a.pos[(size_t)patch * 3 + 1], a.pos[(size_t)patch * 3 + 2]};
+  const double *rp = r.ref_pos + (size_t)patch * 3, *rf = r.ref_f + (size_t)patch * 3, *RR = r.ref_R + (size_t)patch * 9;
+  const double dx = p[0] - rp[0], dy = p[1] - rp[1], dz = p[2] - rp[2];
+  const double depth = sqrt((dx * dx + dy * dy) + dz * dz);   // (pt->pos_ - ref_patch->pos()).norm()
+  const double pf[3] = {rf[0] * depth, rf[1] * depth, rf[2] * depth};
+  double Jpi[6];
+  {
+    const double z_inv = 1. / pf[2], z_inv_2 = z_inv * z_inv;
+    Jpi[0] = a.fx * z_inv; Jpi[1] = 0.0; Jpi[2] = -a.fx * pf[0] * z_inv_2;
+    Jpi[3] = 0.0; Jpi[4] = a.fy * z_inv; Jpi[5] = -a.fy * pf[1] * z_inv_2;
+  }
+  const Anchor A = make_anchor(r.ref_px[(size_t)patch * 2], r.ref_px[(size_t)patch * 2 + 1], scale);
+  const int ridx = r.ref_idx[patch];
+  const bool inside = (ridx >= 0) && (ridx < r.n_ref) && (A.ui - 5 * scale >= 0) && (A.ui + 5 * scale < a.width) && (A.vi - 5 * scale >= 0) && (A.vi + 5 * scale < a.height);
+  double g0 = 0.0, g1 = 0.0;
+  if (inside) {
+    const uint8_t *img = r.ref_imgs + (size_t)ridx * a.height * a.stride;
+    for (int e = lane; e < 121; e += LIVO2_WAVE) { const int wr = e / 11, wc = e - wr * 11; Wf[e] = (float)img[(size_t)(A.vi + (wr - 5) * scale) * a.stride + (A.ui + (wc - 5) * scale)]; }
+    vis_wave_sync();
+    for (int e = lane; e < 100; e += LIVO2_WAVE) { const int br = e / 10, bc = e - br * 10; const float *w = &Wf[br * 11 + bc]; Bf[e] = ((A.w_tl * w[0] + A.w_tr * w[1]) + A.w_bl * w[11]) + A.w_br * w[12]; }
+    vis_wave_sync();
+    const int x = lane >> 3, y = lane & 7;
+    const float *b = &Bf[(x + 1) * 10 + (y + 1)];
+    const float du = 0.5f * (b[1] - b[-1]), dv = 0.5f * (b[10] - b[-10]);
+    const double isc = 1.0 / scale;                           // Jimg = Jimg * (1.0 / scale)  (vio.cpp:1385)
+    g0 = (double)du * isc; g1 = (double)dv * isc;
+  }
+  r.gref[((size_t)patch * 64 + lane) * 2] = g0;
+  r.gref[((size_t)patch * 64 + lane) * 2 + 1] = g1;
+  if (lane < 2) {                                             // M_ref row `lane`: JdR = ((g Jpi) R_ref_w) [p]x ; Jdt = ((-g) Jpi) R_ref_w   (vio.cpp:1387-1388)
+    const double e0 = lane == 0 ? 1.0 : 0.0, e1 = lane == 1 ? 1.0 : 0.0;
+    const double a3[3] = {e0 * Jpi[0] + e1 * Jpi[3], e0 * Jpi[1] + e1 * Jpi[4], e0 * Jpi[2] + e1 * Jpi[5]};
+    double aR[3], naR[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { aR[j] = (a3[0] * RR[j] + a3[1] * RR[3 + j]) + a3[2] * RR[6 + j]; naR[j] = ((-a3[0]) * RR[j] + (-a3[1]) * RR[3 + j]) + (-a3[2]) * RR[6 + j]; }
+    const double ph[9] = {0.0, -p[2], p[1], p[2], 0.0, -p[0], -p[1], p[0], 0.0};
+    double *m = r.mref + (size_t)patch * 16 + lane * 6;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { m[j] = (aR[0] * ph[j] + aR[1] * ph[3 + j]) + aR[2] * ph[6 + j]; m[3 + j] = naR[j]; }
+  }
+  if (lane == 2) { double *m = r.mref + (size_t)patch * 16; m[12] = 0.0; m[13] = 0.0; m[14] = 0.0; m[15] = inside ? 1.0 : 0.0; }
+}
+
 // Four patches per wave (the body shared by the single-frame and the batched kernel).  patch0 = first patch of this wave.  Returns lane q's value q (q < 37) of the
 // SUM of the wave's patch vectors (slot order).
 // The iterate enters as three pointers (rot_end, pos_end, inv_expo_time): HBM (ctl->cur) in the per-step kernels, LDS in the persistent kernel.
@@ -155,9 +229,13 @@ __device__ __forceinline__ double vis_expand(int q, VisRC rc, const double *S, c
 // chain of patch_error (needed only for errors[]) hang off it.  ROLE 1 (main) walks the critical path, ROLE 2 (partner, same SIMD, same VisWaveLds) repeats the
 // projection, forms M while the main wave waits for its window, and runs the chain from the main wave's Rr while that one reduces and expands.  One block barrier in
 // the middle (Rr and Mx complete), so ALL waves of the block must call the body the same number of times.  Same expressions in the same order: same bits.
-template <bool DEBUG_ROWS, bool XB = false, int ROLE = 0>
+// INV (round 6): the same body evaluates updateStateInverse (vio.cpp:1418-1477) — the residual is the current image's bilinear sample minus the reference patch (one
+// float expression, no exposure factors), the per-pixel gradient is the REFERENCE image's (rp->gref, precomputed per level), the patch-constant 2x6 matrix is
+// N = M_ref T(state) (vio.cpp:1470-1474) and the exposure column is zero; window 9 x 9 at scale 2^level (no search level).  Moment sums, expansion, error chain,
+// roles and barriers are the forward form's, so the resident grid and the per-step kernel share one code for either form.
+template <bool DEBUG_ROWS, bool XB = false, int ROLE = 0, bool INV = false>
 __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, const int level, const double *Rwi, const double *Pwi, const double *tau_p, float *errors_out,
-                                                   VisWaveLds &L, int patch0, int lane) {
+                                                   VisWaveLds &L, int patch0, int lane, const VisualRefArgs *rp = nullptr) {
   const int slot = lane / VIS_LPP, j = lane % VIS_LPP;
   const VisRC rc = vis_rc(lane);
   const int patch_raw = patch0 + slot;
@@ -165,14 +243,28 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   const int patch = valid ? patch_raw : a.M - 1;            // clamped: invalid slots compute on the last patch and contribute nothing
   // loads that do not depend on the state go first, so they travel together with the scalar loads of the state
   const double p0 = a.pos[(size_t)patch * 3], p1 = a.pos[(size_t)patch * 3 + 1], p2 = a.pos[(size_t)patch * 3 + 2];
-  const int search_level = a.search_levels[patch];
+  const int search_level = INV ? 0 : a.search_levels[patch];
   double inv_ref_expo = 0.0, tau = 0.0;
   float Pref[4] = {0.f, 0.f, 0.f, 0.f};
+  double gr0[4] = {0.0, 0.0, 0.0, 0.0}, gr1[4] = {0.0, 0.0, 0.0, 0.0}, mr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool ref_ok = true;
+  if (INV) {
+    const double *m = rp->mref + (size_t)patch * 16;
+    ref_ok = m[15] != 0.0;
+    if (ROLE != 1) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) mr[k] = m[k];
+    }
+  }
   if (ROLE != 2) {
-    inv_ref_expo = a.inv_expo[patch];
+    if (!INV) inv_ref_expo = a.inv_expo[patch];
 #pragma unroll
     for (int k = 0; k < 4; k++) Pref[k] = a.warp[((size_t)patch * a.L + level) * 64 + j + VIS_LPP * k];
-    tau = *tau_p;
+    if (!INV) tau = *tau_p;
+    if (INV) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const double2 g = *reinterpret_cast<const double2 *>(rp->gref + ((size_t)patch * 64 + j + VIS_LPP * k) * 2); gr0[k] = g.x; gr1[k] = g.y; }
+    }
   }
   VPHASE(1);
   double Rcw[9], Pcw[3];
@@ -190,17 +282,18 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   const int u_ref_i = (int)(floorf((float)(pcx / scale)) * (float)scale);
   const int v_ref_i = (int)(floorf((float)(pcy / scale)) * (float)scale);
   // the reference reads this window unchecked (vio.cpp:1595-1609); a window leaving the image is skipped here
-  const bool inside = (u_ref_i - 5 * scale >= 0) && (u_ref_i + 5 * scale < a.width) && (v_ref_i - 5 * scale >= 0) && (v_ref_i + 5 * scale < a.height);
-  const bool ok = valid && inside;
+  constexpr int HW = INV ? 4 : 5, WN = 2 * HW + 1;          // half-width and side of the strided window (INV: vio.cpp:1463-1468 reads rows / columns -4..+4 unchecked)
+  const bool inside = (u_ref_i - HW * scale >= 0) && (u_ref_i + HW * scale < a.width) && (v_ref_i - HW * scale >= 0) && (v_ref_i + HW * scale < a.height);
+  const bool ok = valid && inside && ref_ok;
   // the 11x11 strided window of the lane's patch: 8 byte loads per lane, all issued before the projection Jacobian below
   uint8_t px[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (ROLE != 2) {
-    const size_t base = ok ? (size_t)(v_ref_i - 5 * scale) * a.stride + (size_t)(u_ref_i - 5 * scale) : 0;
+    const size_t base = ok ? (size_t)(v_ref_i - HW * scale) * a.stride + (size_t)(u_ref_i - HW * scale) : 0;
     const int sc = ok ? scale : 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const int e = j + VIS_LPP * k < 121 ? j + VIS_LPP * k : 120;
-      const int wr = e / 11, wc = e - wr * 11;
+      const int e = j + VIS_LPP * k < WN * WN ? j + VIS_LPP * k : WN * WN - 1;
+      const int wr = e / WN, wc = e - wr * WN;
       px[k] = a.img[base + (size_t)(wr * sc) * a.stride + (size_t)(wc * sc)];
     }
   }
@@ -218,10 +311,30 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
     Jpi[0] = a.fx * z_inv; Jpi[1] = 0.0; Jpi[2] = -a.fx * pf[0] * z_inv_2;
     Jpi[3] = 0.0; Jpi[4] = a.fy * z_inv; Jpi[5] = -a.fy * pf[1] * z_inv_2;
   }
+  double M0[6] = {0, 0, 0, 0, 0, 0}, M1[6] = {0, 0, 0, 0, 0, 0};
   if (ROLE != 1) {
-    double M0[6], M1[6];
-    jac_row(1.0, 0.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M0);
-    jac_row(0.0, 1.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M1);
+    if (!INV) {
+      jac_row(1.0, 0.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M0);
+      jac_row(0.0, 1.0, Jpi, pf, a.Rci, a.Jdp_dR, Rcw, M1);
+    } else {
+      // N = M_ref * T :  JdR = J_dR Rwi + (J_dt [Pwi]x) Rwi ; Jdt = J_dt Rwi    (vio.cpp:1472-1473)
+      const double Ph[9] = {0.0, -Pwi[2], Pwi[1], Pwi[2], 0.0, -Pwi[0], -Pwi[1], Pwi[0], 0.0};
+#pragma unroll
+      for (int row = 0; row < 2; row++) {
+        const double *m = mr + row * 6;
+        double tP[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) tP[q] = (m[3] * Ph[q] + m[4] * Ph[3 + q]) + m[5] * Ph[6 + q];
+        double *N = row == 0 ? M0 : M1;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const double t1 = (m[0] * Rwi[q] + m[1] * Rwi[3 + q]) + m[2] * Rwi[6 + q];
+          const double t2 = (tP[0] * Rwi[q] + tP[1] * Rwi[3 + q]) + tP[2] * Rwi[6 + q];
+          N[q] = t1 + t2;
+          N[3 + q] = (m[3] * Rwi[q] + m[4] * Rwi[3 + q]) + m[5] * Rwi[6 + q];
+        }
+      }
+    }
     if (j == 0) {
 #pragma unroll
       for (int k = 0; k < 6; k++) { L.Mx[slot][k] = M0[k]; L.Mx[slot][6 + k] = M1[k]; }
@@ -232,8 +345,30 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
   for (int v = 0; v < 9; v++) acc[v] = 0.0;
   if (ROLE != 2) {
 #pragma unroll
-  for (int k = 0; k < 8; k++) { const int e = j + VIS_LPP * k; if (e < 121) L.st.Wf[slot][e] = (float)px[k]; }
+  for (int k = 0; k < 8; k++) { const int e = j + VIS_LPP * k; if (e < WN * WN) L.st.Wf[slot][e] = (float)px[k]; }
   wave_sync();
+  if (INV) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = j + VIS_LPP * k, x = p >> 3, y = p & 7;
+      const float *w = &L.st.Wf[slot][x * 9 + y];
+      const double res = (double)((((w_tl * w[0] + w_tr * w[1]) + w_bl * w[9]) + w_br * w[10]) - Pref[k]);   // all-float expression (vio.cpp:1466-1467)
+      const double g0 = gr0[k], g1 = gr1[k];
+      if (DEBUG_ROWS && ok) {
+        if (a.z) a.z[(size_t)patch * 64 + p] = res;
+        if (a.H_sub) {
+          double *h = a.H_sub + ((size_t)patch * 64 + p) * 7;
+#pragma unroll
+          for (int c = 0; c < 6; c++) h[c] = g0 * M0[c] + g1 * M1[c];
+          h[6] = 0.0;
+        }
+      }
+      acc[0] += g0 * g0; acc[1] += g0 * g1; acc[2] += g1 * g1;
+      acc[6] += g0 * res; acc[7] += g1 * res;
+      L.Rr[slot][p] = res * res;
+    }
+    wave_sync();
+  } else {
 #pragma unroll
   for (int k = 0; k < 7; k++) {
     const int e = j + VIS_LPP * k;
@@ -272,6 +407,7 @@ __device__ __forceinline__ double visual_wave_body(const VisualKernelArgs &a, co
     L.Rr[slot][p] = res * res;
   }
   wave_sync();                                              // the staging buffers alias the tile written next; Rr is complete
+  }
   }
   VPHASE(4);
   if (ROLE != 0) __syncthreads();                           // main: Rr is written; partner: Mx is written
@@ -701,7 +837,8 @@ struct VisPersistArgs {
   unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 256][step < 32][16] stamps of the 100 MHz clock, else null
   unsigned long long timeout;   // 100 MHz ticks a block waits for a word before it gives the update up (VP_TIMEOUT; option "visual_persistent_debug_timeout" shortens it)
   int32_t debug_drop_block;     // -1; else this block leaves at once (a grid that is not co-resident, simulated: tests/test_visual_gpu.py)
-  int32_t pad_;
+  int32_t inverse;              // 1: updateStateInverse — precomputeReferencePatches at the head of every level, then the INV form of the wave body (round 6)
+  VisualRefArgs r;              // (inverse)
 };
 #define VPP(k) do { if (p.prof && tid == 0 && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define VPP_W(k, w) do { if (p.prof && tid == (w) * LIVO2_WAVE && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) p.prof[((size_t)blockIdx.x * 32 + step_global) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -761,7 +898,7 @@ __device__ __forceinline__ const VisPersistArgs &vp_args() {
 #define VP_TIMEOUT 200000000ull          // 100 MHz ticks: 2 s
 
 // ---- 1. residual of this block's patch groups; the row and the errors are published into buffer step % VP_NBUF
-__device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step_v) {
+template <bool INV> __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step_v) {      // INV: a compile-time copy of the kernel per form (a run-time branch here cost the forward form 0.4 us per step)
   VisPersistLds &SL = *(VisPersistLds *)slp;
   const VisPersistArgs &p = vp_args();
   const int level = __builtin_amdgcn_readfirstlane(level_v), step_global = __builtin_amdgcn_readfirstlane(step_v);
@@ -788,7 +925,11 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
       VPHASE(0);                                             // (profiling build: the stamps of the LAST step stay, tools/vis_phase.py --persistent)
       for (int g = my_row; g < ngroups; g += R) {
         const int patch0 = (g * VIS_WAVES + wv) * VIS_PPW;
-        if (wave < VIS_WAVES) out_val += visual_wave_body<false, true, 1>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane);
+        if (INV) {
+          if (wave < VIS_WAVES) out_val += visual_wave_body<false, true, 1, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane, &p.r);
+          else visual_wave_body<false, true, 2, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane, &p.r);
+        }
+        else if (wave < VIS_WAVES) out_val += visual_wave_body<false, true, 1>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane);
         else visual_wave_body<false, true, 2>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wv], patch0, lane);
         VPHASE(6);
         if (g + R < ngroups) __syncthreads();                // the partner is done with Rr, the main wave with Mx
@@ -798,7 +939,8 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   } else if (wave < VIS_WAVES * halves && my_row < R) {
     for (int g = my_row; g < ngroups; g += R) {
       const int patch0 = (g * VIS_WAVES + wv) * VIS_PPW;
-      if (patch0 < M) out_val += visual_wave_body<false, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wave], patch0, lane);
+      if (patch0 < M) out_val += INV ? visual_wave_body<false, true, 0, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wave], patch0, lane, &p.r)
+                                           : visual_wave_body<false, true>(p.a, level, SL.s.cur, SL.s.cur + 9, SL.s.cur + 12, errs, SL.u.r.lds[wave], patch0, lane);
       if (g + R < ngroups) wave_sync();
     }
     if (lane < VIS_PSTRIDE) SL.u.r.red[wave][lane] = out_val;
@@ -817,6 +959,32 @@ __device__ VP_PHASE_ATTR void vp_phase_residual(VpLds slp, int level_v, int step
   }
   if (tid == LIVO2_WAVE) vis_log_lds(SL.s);                    // rotation part of vec = prior [-] iterate, while the words travel
   VPP(2);
+}
+
+// ---- 0. (inverse form) precomputeReferencePatches at the head of a level (has_ref_patch_cache = false at every level, vio.cpp:794-795) for the patch groups whose rows
+// this block publishes: one patch per wave and turn, all 8 waves.  Written and read by this block only; the barrier at the end orders the two.
+__device__ VP_PHASE_ATTR void vp_phase_precompute(VpLds slp, int level_v) {
+  VisPersistLds &SL = *(VisPersistLds *)slp;
+  const VisPersistArgs &p = vp_args();
+  const int level = __builtin_amdgcn_readfirstlane(level_v);
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));
+  const int tid = tid_o, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = p.a.M, R = p.n_rows, halves = p.halves;
+  const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
+  VisWaveLds &L = SL.u.r.lds[wave];
+  for (int h = 0; h < halves; h++) {
+    const int my_row = (int)blockIdx.x * halves + h;
+    if (my_row >= R) break;
+    for (int g = my_row; g < ngroups; g += R)
+      for (int q = wave; q < VIS_PPB; q += VP_BLOCK / LIVO2_WAVE) {
+        const int patch = g * VIS_PPB + q;
+        if (patch < M) ref_precompute_patch(p.a, p.r, level, patch, lane, &L.st.Wf[0][0], &L.st.Bf[0][0]);
+        wave_sync();                                             // (the next patch reuses the staging floats)
+      }
+  }
+  __threadfence_block();
+  __syncthreads();
 }
 
 // ---- 2. collect: all G rows (waves 0-3: one column pair per thread) and the M errors (waves 4-7: four per request); what is still empty is simply loaded again
@@ -1005,7 +1173,7 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
   VPP(6);
 }
 
-__global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersistArgs p, DevCtl *__restrict__ ctl) {
+template <bool INV> __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersistArgs p, DevCtl *__restrict__ ctl) {
   __shared__ VisPersistLds SL;
   SolveLds &s = SL.s;
   const VpLds slp = (VpLds)&SL;
@@ -1025,8 +1193,9 @@ __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_persistent(VisPersis
   __syncthreads();
   int step_global = 0, last_buf = 0;
   for (int level = p.levels - 1; level >= 0 && !SL.timed_out; level--) {
+    if (INV) vp_phase_precompute(slp, level);
     for (int it = 0; it < p.max_iterations; it++) {
-      vp_phase_residual(slp, level, step_global);
+      vp_phase_residual<INV>(slp, level, step_global);
       last_buf = (int)((SL.base + (uint32_t)step_global) & (VP_NBUF - 1));
       vp_phase_collect(slp, step_global);
       if (SL.timed_out) break;

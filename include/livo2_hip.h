@@ -90,6 +90,8 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *                        per-step sequence (counter "visual_persistent_timeouts"; "visual_persistent_debug_timeout" = 1 provokes exactly that in 2 ms, for the tests).
  *                        After a time-out the ctx stays on the per-step sequence for the next 8 updates (16, 32, ... up to 1024 while time-outs repeat; counter
  *                        "visual_persistent_backoff_skips") before it tries a resident grid again.
+ *   "visual_persistent_inverse" (default 1, round 6): with cfg->inverse_composition_en the resident grid also runs precomputeReferencePatches + updateStateInverse
+ *                        (vio.cpp:1327-1518; 0: that form stays on the launch-per-step sequence — same bits, tests/test_visual_inverse_gpu.py).
  *   "visual_persistent_timeout_us" (default 20000; environment LIVO2_VP_TIMEOUT_US): that watchdog, in microseconds, [100, 10000000].  A C4-sized update takes
  *                        0.25 ms; the default keeps a 10 Hz pipeline inside its frame budget when a grid loses a compute unit (2 s until round 4).
  *   "lidar_fused_iteration" (default 0; environment LIVO2_LIDAR_FUSED): one launch per ESIKF iteration (k_lidar_iteration: the last block of the residual grid to

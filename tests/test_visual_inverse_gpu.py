@@ -138,3 +138,30 @@ def test_inverse_in_the_frame_call_equals_the_separate_calls(ctx, livo2, orc, vs
     vres2, _ = ctx.visual_update(lres2.state, lres2.state, fcfg)
     fl2, fv2 = ctx.frame_update(sc.xyz, prior, pcfg, vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list, fcfg)
     assert bytes(fv2.state) == bytes(vres2.state) and bytes(fv2.state) != bytes(fv.state)
+
+
+@pytest.mark.parametrize("M,seed", [(300, 5), (1000, 6), (37, 7), (4000, 8)])
+def test_inverse_on_the_resident_grid_gives_the_bits_of_the_per_step_launches(ctx, livo2, M, seed):
+    """round 6: updateStateInverse + precomputeReferencePatches run on the resident grid too (k_visual_update_persistent<true>: the reference patches of a block's own
+    patch groups at the head of every level, then the INV form of the shared wave body).  Same body, same rows, same order of additions as the launch-per-step
+    sequence (option visual_persistent_inverse = 0) => the same bits: state, covariance, G, every recorded step, errors[].  Counters: the resident grid is what ran."""
+    vs = synth.visual_inverse_scenario(seed=seed, n_patches=M)
+    cfg = H.visual_cfg_product(vs, inverse=True)
+    cur, prop = H.states(vs, livo2.State)
+    _upload(ctx, vs)
+    ctx.set_option("visual_persistent_inverse", 0)
+    try:
+        n_before = ctx.counter("visual_persistent_launches")
+        ref, ref_err = ctx.visual_update(cur, prop, cfg)
+        assert ctx.counter("visual_persistent_launches") == n_before
+    finally:
+        ctx.set_option("visual_persistent_inverse", 1)
+    n0, t0, f0 = ctx.counter("visual_persistent_launches"), ctx.counter("visual_persistent_timeouts"), ctx.counter("visual_persistent_fallbacks")
+    for _ in range(5):
+        _upload(ctx, vs)
+        res, err = ctx.visual_update(cur, prop, cfg)
+        assert res.n_steps == ref.n_steps > 0
+        assert np.array_equal(err, ref_err)
+        assert bytes(res.state) == bytes(ref.state) and bytes(res.G) == bytes(ref.G) and bytes(res.Rcw) == bytes(ref.Rcw) and bytes(res.Pcw) == bytes(ref.Pcw)
+        assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
+    assert ctx.counter("visual_persistent_launches") == n0 + 5 and ctx.counter("visual_persistent_fallbacks") == f0 and ctx.counter("visual_persistent_timeouts") == t0

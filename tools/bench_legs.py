@@ -428,13 +428,14 @@ def _load_traffic(workload, **match):
 
 def _visual_inverse_leg(ctx, livo2, synth, H, n_patches=2000):
     """V6 (vio/inverse_composition_en, src/vio.cpp:1327-1518) measured, not only tested: the whole updateStateInverse-based computeJacobianAndUpdateEKF on a
-    sub-map of n_patches (precomputeReferencePatches per level + residual / solve per step, launch-per-step: this form has no resident grid), next to the forward-compositional
+    sub-map of n_patches (precomputeReferencePatches per level + residual / solve per step; resident grid since round 6, and as launches per step), next to the forward-compositional
     update of the same sub-map, by wall time of asynchronous updates back to back and by the kernels' events."""
     vs = synth.visual_inverse_scenario(seed=7, n_patches=n_patches)
     cur, prop = make_states(livo2, vs)
     out = {"patches": int(len(vs.pos))}
-    for name, inverse in (("inverse_compositional", True), ("forward_compositional", False)):
+    for name, inverse, resident in (("inverse_compositional", True, 1), ("inverse_compositional_launch_per_step", True, 0), ("forward_compositional", False, 1)):
         vcfg = H.visual_cfg(vs, inverse=inverse) if inverse else H.visual_cfg(vs)
+        ctx.set_option("visual_persistent_inverse", resident)
         ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
         if inverse:
             ctx.set_reference(vs.ref_imgs, vs.ref_img_idx, vs.ref_px, vs.ref_f, vs.ref_R, vs.ref_pos)
@@ -450,8 +451,10 @@ def _visual_inverse_leg(ctx, livo2, synth, H, n_patches=2000):
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / reps
         out[name] = {"steps": steps, "us_per_update": 1e6 * dt, "us_per_step": 1e6 * dt / max(steps, 1), "evals_per_s": 64.0 * len(vs.pos) * steps / dt}
-    out["note"] = ("inverse: gradients from the reference images once per level (k_visual_ref_precompute), per step only residuals + N^T (sum g g^T) N (k_visual_inverse_residual) and the "
-                   "shared solve — a launch per step; forward: the resident grid.  Same synthetic sub-map (search levels 0, reference frames at the true pose)")
+    ctx.set_option("visual_persistent_inverse", 1)
+    out["note"] = ("inverse: gradients from the reference images once per level, per step only residuals + N^T (sum g g^T) N and the shared solve; since round 6 on the resident grid "
+                   "like the forward form (k_visual_update_persistent<true>), '_launch_per_step': the round-5 form (option visual_persistent_inverse = 0).  Same synthetic sub-map "
+                   "(search levels 0, reference frames at the true pose)")
     return out
 
 
