@@ -200,6 +200,7 @@ struct livo2_ctx {
   int32_t *mt_idx = nullptr, *mt_order = nullptr, *mt_head = nullptr, *mt_slot = nullptr, *mt_seg_begin = nullptr, *mt_seg_root = nullptr, *mt_nseg = nullptr;
   size_t mt_idx_cap = 0, mt_order_cap = 0, mt_head_cap = 0, mt_slot_cap = 0, mt_seg_begin_cap = 0, mt_seg_root_cap = 0;
   livo2_state *mt_state = nullptr;
+  int mt_spread_opt = 0, mt_wide_fit_opt = 1;    // options "map_update_spread" (0: by the previous update's touched roots; 1 / 2 / 4 / 8) and "map_update_wide_fit"
   int mt_last_touched = 0;                  // root voxels the last update touched (sizes the next one's lanes per root)
   int mt_pv_n = -1;                         // points of the pv_list in mt_in_pw / mt_in_var (last map-tree update), -1: none since the last set_scan
   int32_t *mt_rp_rows = nullptr; size_t mt_rp_rows_cap = 0; double *mt_rp_out = nullptr; size_t mt_rp_out_cap = 0;   // livo2_map_tree_read_planes staging
@@ -841,6 +842,11 @@ int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (std::strcmp(name, "lidar_fused_iteration") == 0) { ctx->lidar_fused = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_inverse") == 0) { ctx->visual_persistent_inverse = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "map_update_spread") == 0) {
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, LIVO2_ERR_INVALID, "map_update_spread: 0 (automatic), 1, 2, 4 or 8");
+    ctx->mt_spread_opt = (int)value; return LIVO2_OK;
+  }
+  if (std::strcmp(name, "map_update_wide_fit") == 0) { ctx->mt_wide_fit_opt = value != 0; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_timeout_us") == 0) {
     if (value < 100 || value > 10000000) return fail(ctx, LIVO2_ERR_INVALID, "visual_persistent_timeout_us out of [100, 10000000]");
     ctx->vp_timeout_us = value; return LIVO2_OK;

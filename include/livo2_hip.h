@@ -92,6 +92,9 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *                        "visual_persistent_backoff_skips") before it tries a resident grid again.
  *   "visual_persistent_inverse" (default 1, round 6): with cfg->inverse_composition_en the resident grid also runs precomputeReferencePatches + updateStateInverse
  *                        (vio.cpp:1327-1518; 0: that form stays on the launch-per-step sequence — same bits, tests/test_visual_inverse_gpu.py).
+ *   "map_update_spread" (default 0, round 6): lanes per touched root voxel in the octree update = 8 x this (1, 2, 4, 8; of which 8 work, or all 64 in the plane re-fit when
+ *                        this is 8 and "map_update_wide_fit" = 1, the default); 0: chosen per update from the number of roots the previous one touched.  Every choice gives the
+ *                        same tree (plane parameters to the rounding of the re-fit's summation order: tests/test_map_tree_gpu.py).
  *   "visual_persistent_timeout_us" (default 20000; environment LIVO2_VP_TIMEOUT_US): that watchdog, in microseconds, [100, 10000000].  A C4-sized update takes
  *                        0.25 ms; the default keeps a 10 Hz pipeline inside its frame budget when a grid loses a compute unit (2 s until round 4).
  *   "lidar_fused_iteration" (default 0; environment LIVO2_LIDAR_FUSED): one launch per ESIKF iteration (k_lidar_iteration: the last block of the residual grid to

@@ -30,7 +30,18 @@ def _scene(seed):
     return c, cloud, R0, t0, P0, extR, extT
 
 
-def test_build_and_update_sequence_match_oracle(ctx, orc):
+@pytest.mark.parametrize("spread,wide", [(0, 1), (1, 1), (2, 1), (4, 1), (8, 0), (8, 1)])
+def test_build_and_update_sequence_match_oracle(ctx, orc, spread, wide):
+    """spread / wide: the lane layouts of k_mt_update (round 6) — eight, four, two or one root voxel per wave, the plane re-fit on 8 or on all 64 lanes; 0 = the choice
+    the library makes itself from the previous update's touched roots.  Every one of them must take every counter-driven decision where the oracle takes it."""
+    ctx.set_option("map_update_spread", spread); ctx.set_option("map_update_wide_fit", wide)
+    try:
+        _build_and_update_sequence(ctx, orc)
+    finally:
+        ctx.set_option("map_update_spread", 0); ctx.set_option("map_update_wide_fit", 1)
+
+
+def _build_and_update_sequence(ctx, orc):
     c, cloud, R0, t0, P0, extR, extT = _scene(81)
     _, (pw0, var0) = cloud(40000, R0, t0)
     ctx.map_tree_create(c, max_roots=60000)
