@@ -319,3 +319,61 @@ def test_a_frame_that_exhausts_a_pool_is_dropped_and_the_pools_grow_for_the_next
         print("dropped frames:", dropped, st)
     finally:
         ctx.close()
+
+
+def test_three_contexts_update_their_maps_on_second_streams_from_three_host_threads(livo2, orc):
+    """Each context owns a second stream and a helper thread for livo2_map_tree_update_from_scan_async; three of them driven from three host threads at once (the ctypes
+    calls release the interpreter lock) run the same five chained frames.  Every context must end with the tree, the counters and the posteriors of a context that ran
+    the sequence alone with the synchronous call — nothing of the asynchronous path may be shared between contexts (the resident visual grid's admission is, under a lock)."""
+    import threading
+    cs, cloud, R0, t0, P0, extR, extT = _scene(53)
+    _, (pw0, var0) = cloud(40000, R0, t0)
+    vs = synth.visual_scenario(seed=54, n_patches=500)
+    vcur, vprop = H.states(vs, livo2.State)
+    vcfg = H.visual_cfg_product(vs)
+    F = 5
+    poses = [(R0 @ synth.rot_from_rpy(0.0, 0.0, 0.04 * f), t0 + np.array([0.12 * f, 0.04 * f, 0.0])) for f in range(F)]
+    scans = [cloud(9000, Rf, tf)[0] for Rf, tf in poses]
+    rng = np.random.default_rng(6)
+    frames = []
+    for f in range(F):
+        (Rf, tf), xyz = poses[f], scans[f]
+        sc = synth.LidarScenario(None, np.ascontiguousarray(xyz, np.float32), Rf, tf, Rf @ synth.so3_exp(rng.normal(0, 0.003, 3)), tf + rng.normal(0, 0.01, 3),
+                                 synth.prior_cov(np.random.default_rng(1)), extR, extT, cs)
+        frames.append((sc, H.lidar_cfg_product(sc), H.states(sc, livo2.State)))
+
+    def run(mode, out, k):
+        try:
+            c = livo2.Context(0)
+            c.map_tree_create(cs, max_roots=60000)
+            c.map_tree_update(pw0, var0.reshape(-1, 9), build=True)
+            c.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+            states = []
+            for sc, pcfg, (pcur, pprop) in frames:
+                c.set_scan(sc.xyz, pcfg)
+                res, _ = c.lidar_update(pcur, pprop, pcfg)
+                if mode == "sync":
+                    c.map_tree_update_from_scan(res.state, pcfg)
+                    vres, _ = c.visual_update(vcur, vprop, vcfg)
+                else:
+                    c.map_tree_update_from_scan_async(None, pcfg)
+                    vres, _ = c.visual_update(vcur, vprop, vcfg)
+                states.append((bytes(res.state), bytes(vres.state)))
+            out[k] = (states, c.map_tree_stats(), c.map_tree_export())
+            c.close()
+        except Exception as exc:                                                    # (a thread's exception would otherwise vanish)
+            out[k] = exc
+
+    out = {}
+    run("sync", out, "ref")
+    assert not isinstance(out["ref"], Exception), out["ref"]
+    threads = [threading.Thread(target=run, args=("async", out, k)) for k in range(3)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    ref_states, ref_stats, ref_tree = out["ref"]
+    for k in range(3):
+        assert not isinstance(out[k], Exception), out[k]
+        states, stats, tree = out[k]
+        assert states == ref_states, k
+        assert stats == ref_stats, (k, stats, ref_stats)
+        assert _compare(_flat(tree, cs), _flat(ref_tree, cs), loose=True) > 500
