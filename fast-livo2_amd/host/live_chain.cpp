@@ -157,7 +157,7 @@ int main(int argc, char **argv) {
     VoxelMapManager vm(dev);
     vm.device_map_ = true;
     vm.host_point_lists_ = !lean;
-    vm.async_map_update_ = lean && std::getenv("LIVO2_LIVE_SYNC_MAP") == nullptr;       // lean: the map update runs beside handleVIO on the context's second stream (round 6)
+    vm.async_map_update_ = std::getenv("LIVO2_LIVE_SYNC_MAP") == nullptr;       // lean: the map update runs beside handleVIO on the context's second stream (round 6)
     vm.config_setting_.max_voxel_size_ = mc[0]; vm.config_setting_.max_layer_ = (int)mc[1]; vm.config_setting_.max_points_num_ = (int)mc[2]; vm.config_setting_.planner_threshold_ = mc[3];
     vm.config_setting_.layer_init_num_.assign(5, 5);
     for (int k = 0; k < 5; k++) vm.config_setting_.layer_init_num_[k] = (int)mc[4 + k];
@@ -185,7 +185,7 @@ int main(int argc, char **argv) {
     vio.normal_en = ccfg[1] != 0; vio.ncc_en = ccfg[2] != 0; vio.ncc_thre = ccfg[3]; vio.outlier_threshold = ccfg[4]; vio.patch_pyrimid_level = (int)ccfg[5];
     vio.border = (int)ccfg[6]; vio.grid_n_height = (int)ccfg[7]; vio.grid_size = 5; vio.grid_n_width = 0;
     vio.pg_from_map_update_ = lean;
-    const bool pair_call = lean && std::getenv("LIVO2_LIVE_SPLIT_VIO") == nullptr;   // lean: VIOManager::retrieveAndUpdate (round 6); the env restores the two separate calls
+    const bool pair_call = std::getenv("LIVO2_LIVE_SPLIT_VIO") == nullptr;   // lean: VIOManager::retrieveAndUpdate (round 6); the env restores the two separate calls
     const size_t img_bytes = (size_t)vio.width * vio.height;
 
     // ---- the frames

@@ -276,14 +276,16 @@ void VoxelMapManager::UpdateVoxelMapFromPosterior() {
   cfg.dept_err = config_setting_.dept_err_; cfg.beam_err = config_setting_.beam_err_; cfg.voxel_size = config_setting_.max_voxel_size_; cfg.deg2rad = 0.0;
   std::memcpy(cfg.extR, extR_.data(), 72); std::memcpy(cfg.extT, extT_.data(), 24);
   livo2_state s; state_.to_abi(s);
-  if (async_map_update_ && !host_point_lists_) {
+  if (async_map_update_) {
     // state_ untouched since StateEstimation wrote it (LIVMapper.cpp:371-413 only reads it): the posterior is still on the device, no upload
     const bool resident = posterior_valid_ && std::memcmp(&s, &posterior_, sizeof(s)) == 0;
     dev_.check(livo2_map_tree_update_from_scan_async(dev_.ctx(), resident ? nullptr : &s, &cfg));
-    return;
+    if (!host_point_lists_) return;
+    // (host lists wanted: pv_list_ at the posterior is on the context's stream already — it is read back below while the octree update runs on the second stream)
+  } else {
+    dev_.check(livo2_map_tree_update_from_scan(dev_.ctx(), &s, &cfg, 0));
+    last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
   }
-  dev_.check(livo2_map_tree_update_from_scan(dev_.ctx(), &s, &cfg, 0));
-  last_map_kernel_us_ = livo2_map_tree_last_kernel_us(dev_.ctx());
   if (host_point_lists_ && !pv_list_.empty()) {        // the reference leaves the posterior point_w / var in pv_list_ (LIVMapper.cpp:417-424; `_pv_list` of :426 feeds handleVIO)
     const int32_t n = (int32_t)pv_list_.size();
     const size_t bytes = (size_t)n * 96 + 64;

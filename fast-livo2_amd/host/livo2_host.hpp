@@ -186,7 +186,8 @@ public:
   int fill_threads_ = 16;                   // host threads that write the per-point lists (one per 2048 points, at most this many)
   int device_map_max_roots_ = 300000;
   void UpdateVoxelMapFromPosterior();
-  // async_map_update_ (lean mode only: nobody reads pv_list_ on the host): UpdateVoxelMapFromPosterior() only ENQUEUES — pv_list_ at the posterior on the context's
+  // async_map_update_: UpdateVoxelMapFromPosterior() only ENQUEUES the octree update (with host_point_lists_ it still reads pv_list_ at the posterior back, from the
+  // context's stream, while the octree update runs) — pv_list_ at the posterior on the context's
   // stream, the octree update on its second stream (livo2_map_tree_update_from_scan_async) — so that handleVIO's retrieval and update (which do not read the LiDAR
   // voxel map unless raycast_en) run beside it.  JoinMapUpdate() collects it (pool counters, growth, errors); the next StateEstimation does so implicitly.
   bool async_map_update_ = false;
