@@ -120,6 +120,7 @@ struct livo2_ctx {
   int32_t *d_ret_blob = nullptr; size_t ret_blob_cap = 0; void *h_ret = nullptr; size_t h_ret_cap = 0;      // packed results of livo2_visual_retrieve_from_map (k_ret_pack), pinned landing block
   void *h_img = nullptr; size_t h_img_cap = 0;                                                              // pinned staging of that call's image
   hipStream_t stream_img = nullptr; hipEvent_t img_ready = nullptr;                                          // that image's DMA runs beside the selection kernels
+  void *h_rp = nullptr; size_t h_rp_cap = 0;                                                                // pinned block of livo2_map_tree_read_planes (rows up, records down)
   void *h_err = nullptr; size_t h_err_cap = 0;                                                              // pinned landing block of livo2_visual_update_fetch's errors[]
   // IMU propagation (N4)
   double *d_imu_steps = nullptr, *d_imu_poses = nullptr; size_t imu_steps_cap = 0, imu_poses_cap = 0; livo2_state *d_imu_state = nullptr;   // [2]: in, out
@@ -773,6 +774,7 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
   if (ctx->h_ret) e = hipHostFree(ctx->h_ret);
   if (ctx->h_img) e = hipHostFree(ctx->h_img);
   if (ctx->h_err) e = hipHostFree(ctx->h_err);
+  if (ctx->h_rp) e = hipHostFree(ctx->h_rp);
   if (ctx->img_ready) e = hipEventDestroy(ctx->img_ready);
   if (ctx->stream_img) e = hipStreamDestroy(ctx->stream_img);
   if (ctx->h_delta) e = hipHostFree(ctx->h_delta);

@@ -744,7 +744,13 @@ bool VIOManager::retrieveChain(const GrayImage &img, const std::vector<pointWith
   gridSetup();
   const int length = grid_n_width * grid_n_height, L = patch_pyrimid_level;
   std::vector<double> pgw;
-  if (!pg_from_map_update_) { pgw.resize(pg.size() * 3); for (size_t i = 0; i < pg.size(); i++) std::memcpy(&pgw[i * 3], pg[i].point_w.data(), 24); }
+  if (!pg_from_map_update_) {            // (one 24-B field out of every ~900-B pointWithVar: a cache miss per point — spread over a few threads when the scan is large)
+    pgw.resize(pg.size() * 3);
+    const long long np = (long long)pg.size();
+    const int threads = (int)std::max<long long>(1, std::min<long long>(8, np / 4096 + 1));
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (long long i = 0; i < np; i++) std::memcpy(&pgw[(size_t)i * 3], pg[(size_t)i].point_w.data(), 24);
+  }
   const livo2_select_cfg sc = selectCfg();
   livo2_retrieve_cfg rc{};
   rc.cam = sc.cam;
