@@ -165,3 +165,26 @@ def test_inverse_on_the_resident_grid_gives_the_bits_of_the_per_step_launches(ct
         assert bytes(res.state) == bytes(ref.state) and bytes(res.G) == bytes(ref.G) and bytes(res.Rcw) == bytes(ref.Rcw) and bytes(res.Pcw) == bytes(ref.Pcw)
         assert all(bytes(res.steps[j]) == bytes(ref.steps[j]) for j in range(ref.n_steps))
     assert ctx.counter("visual_persistent_launches") == n0 + 5 and ctx.counter("visual_persistent_fallbacks") == f0 and ctx.counter("visual_persistent_timeouts") == t0
+
+
+@pytest.mark.parametrize("M,seed", [(37, 11), (1500, 12)])
+def test_inverse_full_update_matches_oracle_at_other_sizes(ctx, livo2, orc, M, seed):
+    """the resident-grid form (default) against the oracle for a sub-map that does not fill a wave's four patch slots / one that spans ~94 blocks"""
+    vs = synth.visual_inverse_scenario(seed=seed, n_patches=M)
+    ocfg = orc.visual_cfg(vs, inverse=True)
+    pcfg = H.visual_cfg_product(vs, inverse=True)
+    ocur, oprop = H.states(vs, orc.StatePOD)
+    pcur, pprop = H.states(vs, livo2.State)
+    ref = orc.visual_update(ocfg, vs, ocur, oprop)
+    _upload(ctx, vs)
+    n0 = ctx.counter("visual_persistent_launches")
+    res, errors = ctx.visual_update(pcur, pprop, pcfg)
+    assert ctx.counter("visual_persistent_launches") == n0 + 1
+    assert res.n_steps == len(ref["trace"])
+    for k in range(res.n_steps):
+        a, b = res.steps[k], ref["trace"][k]
+        assert (a.level, a.iteration, a.accepted, a.n_meas) == (b.level, b.iteration, b.accepted, b.n_meas), k
+        assert abs(a.error - b.error) <= 4e-6 * abs(b.error)
+    d = H.state_diff(res.state, ref["state"])
+    assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-8, d
+    assert np.allclose(errors, ref["errors"], rtol=1e-5)
