@@ -605,6 +605,18 @@ class Context:
                                                          abi.as_ptr(sl, C.c_int32), abi.as_ptr(ie, C.c_double), abi.as_ptr(counts, C.c_int32), L))
         self.vbatch_n = len(frames)
 
+    def visual_batch_set_references(self, refs):
+        """refs: per frame (ref_imgs [n_ref][h][w] u8, ref_img_idx [M], ref_px [M][2], ref_f [M][3], ref_R [M][3][3], ref_pos [M][3]) — the arguments of set_reference"""
+        n_ref = np.array([len(r[0]) for r in refs], np.int32)
+        imgs = np.ascontiguousarray(np.concatenate([np.asarray(r[0], np.uint8) for r in refs]))
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(r[1], np.int32).reshape(-1) for r in refs]), np.int32)
+        px = _f64(np.concatenate([np.asarray(r[2], np.float64).reshape(-1, 2) for r in refs]))
+        f = _f64(np.concatenate([np.asarray(r[3], np.float64).reshape(-1, 3) for r in refs]))
+        R = _f64(np.concatenate([np.asarray(r[4], np.float64).reshape(-1, 9) for r in refs]))
+        pos = _f64(np.concatenate([np.asarray(r[5], np.float64).reshape(-1, 3) for r in refs]))
+        self._chk(self.lib.livo2_visual_batch_set_references(self.h, len(refs), abi.as_ptr(imgs, C.c_uint8), abi.as_ptr(n_ref, C.c_int32), abi.as_ptr(idx, C.c_int32),
+                                                             abi.as_ptr(px, C.c_double), abi.as_ptr(f, C.c_double), abi.as_ptr(R, C.c_double), abi.as_ptr(pos, C.c_double)))
+
     def visual_batch_update(self, states_in, props, cfg):
         res = (VisualResult * self.vbatch_n)()
         self._chk(self.lib.livo2_visual_batch_update(self.h, self.vbatch_n, self._state_array(states_in), self._state_array(props), C.byref(cfg), res))

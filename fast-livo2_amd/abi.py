@@ -283,6 +283,7 @@ SIGNATURES = {
                                         _P(C.c_double), _P(C.c_float), _P(C.c_float), _P(C.c_int32)]),
     "livo2_map_tree_read_planes": (C.c_int, [_CTX, _P(C.c_int32), C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_float), _P(C.c_float), _P(C.c_int32)]),
     "livo2_map_tree_last_kernel_us": (C.c_double, [_CTX]),
+    "livo2_visual_batch_set_references": (C.c_int, [_CTX, C.c_int32, _P(C.c_uint8), _P(C.c_int32), _P(C.c_int32), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "livo2_visual_batch_set_frames": (C.c_int, [_CTX, C.c_int32, _P(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_float), _P(C.c_int32), _P(C.c_double),
                                                 _P(C.c_int32), C.c_int32]),
     "livo2_visual_batch_update": (C.c_int, [_CTX, C.c_int32, _P(State), _P(State), _P(VisualCfg), _P(VisualResult)]),

@@ -157,7 +157,10 @@ struct livo2_ctx {
   DevCtl *bd_ctl = nullptr; LidarBatchEntry *bd_entries = nullptr; HostIn *bd_in = nullptr; livo2_lidar_result *bd_results = nullptr;   // [LIVO2_MAX_BATCH]
   HostIn *bh_in = nullptr; livo2_lidar_result *bh_results = nullptr; LidarBatchEntry *bh_entries = nullptr;                              // pinned
   // batch of frames, visual (own images / sub-maps / states, lockstep (level, iteration) grids); shares bd_ctl / bd_in / bh_in with the LiDAR batch
-  bool has_vbatch = false;
+  bool has_vbatch = false, has_vb_ref = false;
+  uint8_t *vbd_ref_imgs = nullptr; int32_t *vbd_ref_idx = nullptr; double *vbd_ref_px = nullptr, *vbd_ref_f = nullptr, *vbd_ref_R = nullptr, *vbd_ref_pos = nullptr, *vbd_gref = nullptr, *vbd_mref = nullptr;
+  size_t vb_ref_imgs_cap = 0, vb_ref_idx_cap = 0, vb_ref_px_cap = 0, vb_ref_f_cap = 0, vb_ref_R_cap = 0, vb_ref_pos_cap = 0, vb_gref_cap = 0, vb_mref_cap = 0;
+  std::vector<int> vb_ref_cnt, vb_ref_off;      // reference images per frame of the batch / index of a frame's first one
   int vbn = 0, vb_total = 0, vb_blocks = 0, vb_L = 0, vb_w = 0, vb_h = 0, vb_stride = 0;
   std::vector<int32_t> vb_count, vb_off, vb_grid, vb_block_begin;
   uint8_t *vbd_img = nullptr; size_t vb_img_cap = 0;
@@ -766,7 +769,8 @@ void livo2_ctx_destroy(livo2_ctx *ctx) {
                  ctx->vbd_img, ctx->vbd_pos, ctx->vbd_invexpo, ctx->vbd_partials, ctx->vbd_warp, ctx->vbd_errors, ctx->vbd_search, ctx->vbd_block_frame, ctx->vbd_entries, ctx->vbd_results,
                  ctx->mt_in_pw, ctx->mt_in_var, ctx->mt_keys, ctx->mt_keys2, ctx->mt_idx, ctx->mt_order, ctx->mt_head, ctx->mt_slot, ctx->mt_seg_begin, ctx->mt_seg_root, ctx->mt_nseg, ctx->mt_state,
                  ctx->mt.nodes, ctx->mt.pool_pw, ctx->mt.pool_var, ctx->mt.counters, ctx->mt.dirty_list, ctx->mt.overflow_list, ctx->d_vp_rows, ctx->d_vp_errs, ctx->d_vp_prof, ctx->mt_rp_rows, ctx->mt_rp_out, ctx->d_lpt_order, ctx->d_lpt_cost, ctx->d_lidar_tickets, ctx->d_ob_list, ctx->d_ob_cnt, ctx->d_delta, ctx->d_bcov_rows, ctx->d_vm_set, ctx->d_ray_set, ctx->d_ray_key, ctx->d_ray_hit_key, ctx->d_ray_hit_best, ctx->d_ray_action, ctx->d_ray_hit_cell,
-                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena, ctx->d_lidar_stamps, ctx->d_lidar_span_acc, ctx->mt_sort_tmp, ctx->d_ret_blob};
+                 ctx->d_ray_counters, ctx->d_ray_add, ctx->d_frame_arena, ctx->d_lidar_stamps, ctx->d_lidar_span_acc, ctx->mt_sort_tmp, ctx->d_ret_blob,
+                 ctx->vbd_ref_imgs, ctx->vbd_ref_idx, ctx->vbd_ref_px, ctx->vbd_ref_f, ctx->vbd_ref_R, ctx->vbd_ref_pos, ctx->vbd_gref, ctx->vbd_mref};
   for (void *p : dev) if (p) e = DFREE(p);
   if (ctx->h_in) e = hipHostFree(ctx->h_in);
   if (ctx->h_out) e = hipHostFree(ctx->h_out);

@@ -499,7 +499,8 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual(VisualKernelArgs 
 
 // Batched launch: several independent computeJacobianAndUpdateEKF problems (own image, own sub-map, own state) in ONE grid per (level, iteration) —
 // the visual counterpart of k_lidar_residual_batch.  A frame whose level has ended (hdr.stop) drops out at its blocks' first instruction.
-struct VisualBatchEntry { VisualKernelArgs a; DevCtl *ctl; double *partials; int32_t block_begin, nblocks; };
+struct VisualBatchEntry { VisualKernelArgs a; DevCtl *ctl; double *partials; int32_t block_begin, nblocks; VisualRefArgs r; };      // r: the inverse-compositional form (livo2_visual_batch_set_references)
+template <bool INV = false>
 __global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual_batch(const VisualBatchEntry *__restrict__ entries, const int32_t *__restrict__ block_frame, int level, int check_stop) {
   const int f = block_frame[blockIdx.x];
   const VisualBatchEntry &e = entries[f];
@@ -512,8 +513,24 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_residual_batch(const Visua
   const int pblock = (int)blockIdx.x - e.block_begin;
   const int patch0 = (pblock * VIS_WAVES + wave) * VIS_PPW;
   double out_val = 0.0;
-  if (patch0 < a.M) out_val = visual_wave_body<false>(a, e.ctl, lds[wave], patch0, lane);
+  if (patch0 < a.M) out_val = INV ? visual_wave_body<false, false, 0, true>(a, a.level, e.ctl->cur.rot, e.ctl->cur.pos, &e.ctl->cur.inv_expo, a.errors, lds[wave], patch0, lane, &e.r)
+                                  : visual_wave_body<false>(a, e.ctl, lds[wave], patch0, lane);
   vis_block_store(red, out_val, e.partials + (size_t)pblock * VIS_PSTRIDE);
+}
+// precomputeReferencePatches of every frame of a batch at one level (the grid of k_visual_residual_batch: a block = VIS_PPB patches of one frame, a wave takes four in turn)
+__global__ void __launch_bounds__(VIS_BLOCK) k_visual_ref_precompute_batch(const VisualBatchEntry *__restrict__ entries, const int32_t *__restrict__ block_frame, int level, int check_stop) {
+  const int f = block_frame[blockIdx.x];
+  const VisualBatchEntry &e = entries[f];
+  if (e.a.M == 0 || (check_stop && e.ctl->hdr.stop)) return;
+  __shared__ float Wf[VIS_WAVES][11 * 11 + 3];
+  __shared__ float Bf[VIS_WAVES][10 * 10 + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pblock = (int)blockIdx.x - e.block_begin;
+  for (int q = 0; q < VIS_PPW; q++) {
+    const int patch = (pblock * VIS_WAVES + wave) * VIS_PPW + q;
+    if (patch < e.a.M) ref_precompute_patch(e.a, e.r, level, patch, lane, Wf[wave], Bf[wave]);
+    vis_wave_sync();
+  }
 }
 
 // ---- reduction + accept / revert + solve --------------------------------------------------------------------------------------------

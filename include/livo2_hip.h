@@ -648,9 +648,15 @@ int livo2_frame_update(livo2_ctx *ctx, const livo2_frame_in *frame, livo2_lidar_
  * grid over the patches of all frames plus one solve block per frame; a frame whose level has ended (EKF_end, vio.cpp:1675-1681) drops out of the level's later
  * grids.  Every frame makes the same decisions and produces the same bits as its own livo2_visual_update call (same kernels, same per-frame reduction order).
  * imgs: n_frames images of width x height with row stride `stride`, back to back; pos / warp_patch / search_levels / inv_expo_list: the frames' arrays
- * concatenated; counts[f] = total_points of frame f (0 allowed).  The forward-compositional form only (inverse_composition_en must be 0). */
+ * concatenated; counts[f] = total_points of frame f (0 allowed).
+ * cfg->inverse_composition_en (round 6): precomputeReferencePatches + updateStateInverse per frame (src/vio.cpp:1327-1518) in the same lockstep; the frames' reference
+ * patches come from livo2_visual_batch_set_references (after _set_frames, which forgets them): the arguments of livo2_visual_set_reference concatenated like the sub-map
+ * arrays; ref_imgs = the frames' reference images back to back (n_ref[f] of them for frame f, size and stride of the batch's images), ref_img_idx[i] indexes the
+ * images of point i's own frame. */
 int livo2_visual_batch_set_frames(livo2_ctx *ctx, int32_t n_frames, const uint8_t *imgs, int32_t width, int32_t height, int32_t stride, const double *pos,
                                   const float *warp_patch, const int32_t *search_levels, const double *inv_expo_list, const int32_t *counts, int32_t L);
+int livo2_visual_batch_set_references(livo2_ctx *ctx, int32_t n_frames, const uint8_t *ref_imgs, const int32_t *n_ref, const int32_t *ref_img_idx, const double *ref_px,
+                                      const double *ref_f, const double *ref_R, const double *ref_pos);
 int livo2_visual_batch_update(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg,
                               livo2_visual_result *results);
 int livo2_visual_batch_update_async(livo2_ctx *ctx, int32_t n_frames, const livo2_state *state_in, const livo2_state *prop, const livo2_visual_cfg *cfg);

@@ -188,3 +188,37 @@ def test_inverse_full_update_matches_oracle_at_other_sizes(ctx, livo2, orc, M, s
     d = H.state_diff(res.state, ref["state"])
     assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-8, d
     assert np.allclose(errors, ref["errors"], rtol=1e-5)
+
+
+def test_batched_inverse_frames_equal_single_updates(ctx, livo2, orc):
+    """livo2_visual_batch_* with inverse_composition_en (round 6; livo2_visual_batch_set_references): B independent updateStateInverse-based updates in lockstep grids
+    produce the bits of B separate livo2_visual_update calls (ragged sizes, different numbers of reference images); one of them also against the oracle."""
+    sizes = [400, 37, 900, 5]
+    frames = [synth.visual_inverse_scenario(seed=70 + k, n_patches=m) for k, m in enumerate(sizes)]
+    cfg = H.visual_cfg_product(frames[0], inverse=True)
+    st = [H.states(vs, livo2.State)[0] for vs in frames]
+    singles = []
+    for vs, s in zip(frames, st):
+        _upload(ctx, vs)
+        singles.append(ctx.visual_update(s, s, cfg))
+    ctx.visual_batch_set_frames([(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list) for vs in frames])
+    with pytest.raises(livo2.Livo2Error):
+        ctx.visual_batch_update(st, st, cfg)                       # no references yet
+    ctx.visual_batch_set_references([(vs.ref_imgs, vs.ref_img_idx, vs.ref_px, vs.ref_f, vs.ref_R, vs.ref_pos) for vs in frames])
+    for _ in range(2):
+        res = ctx.visual_batch_update(st, st, cfg)
+        for k, (r, (single, _)) in enumerate(zip(res, singles)):
+            assert r.n_steps == single.n_steps > 0, k
+            assert bytes(r.state) == bytes(single.state) and bytes(r.Rcw) == bytes(single.Rcw) and bytes(r.Pcw) == bytes(single.Pcw) and bytes(r.G) == bytes(single.G), k
+            for j in range(r.n_steps):
+                assert bytes(r.steps[j]) == bytes(single.steps[j]), (k, j)
+    k = 2
+    ocur, oprop = H.states(frames[k], orc.StatePOD)
+    ref = orc.visual_update(orc.visual_cfg(frames[k], inverse=True), frames[k], ocur, oprop)
+    assert [(res[k].steps[j].level, res[k].steps[j].accepted) for j in range(res[k].n_steps)] == [(t.level, t.accepted) for t in ref["trace"]]
+    d = H.state_diff(res[k].state, ref["state"])
+    assert d["R"] < 1e-9 and d["t"] < 1e-9 and d["P"] < 1e-8, d
+    # the forward form on the same batch still works (the references are simply not read)
+    fcfg = H.visual_cfg_product(frames[0])
+    fres = ctx.visual_batch_update(st, st, fcfg)
+    assert all(r.n_steps > 0 for r in fres)
