@@ -70,8 +70,9 @@ def test_retrieve_and_update_as_one_member_equals_the_two_calls(chain):
     LIVO2_LIVE_SPLIT_VIO=1 the same program makes the two separate calls.  Same states, same sub-maps (members, order), same counts, bit for bit."""
     d, live, recs, want = chain
     outs = []
-    for env_add in ({}, {"LIVO2_LIVE_SPLIT_VIO": "1"}, {"LIVO2_LIVE_SPLIT_VIO": "1", "LIVO2_LIVE_SYNC_MAP": "1"}):
-        r = subprocess.run([EXE, d, "lean"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_add))
+    for mode_args, env_add in ((["lean"], {}), (["lean"], {"LIVO2_LIVE_SPLIT_VIO": "1"}), (["lean"], {"LIVO2_LIVE_SPLIT_VIO": "1", "LIVO2_LIVE_SYNC_MAP": "1"}),
+                               ([], {}), ([], {"LIVO2_LIVE_SPLIT_VIO": "1", "LIVO2_LIVE_SYNC_MAP": "1"})):      # (the form with the host point lists uses both as well)
+        r = subprocess.run([EXE, d] + mode_args, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_add))
         assert r.returncode == 0, r.stderr
         outs.append([np.fromfile(os.path.join(d, n)) for n in ("live_states.bin", "live_sub_pos.bin")] + [np.fromfile(os.path.join(d, "live_counts.bin"), np.int32)])
     for o in outs[1:]:
