@@ -636,6 +636,14 @@ class Context:
     def visual_iterations_async(self, level, state_in, prop, cfg, iters):
         self._chk(self.lib.livo2_visual_iterations_async(self.h, int(level), C.byref(state_in), C.byref(prop), C.byref(cfg), int(iters)))
 
+    def debug_float_chain(self, errors, threads, lanes_per_chain=32):
+        """Per-thread partial sums of the frame error (vio.cpp:1554, 1634): (by float_chain_wave, by the one-lane chain)."""
+        e = np.ascontiguousarray(errors, np.float32)
+        a, b = np.zeros(threads, np.float32), np.zeros(threads, np.float32)
+        self._chk(self.lib.livo2_debug_float_chain(self.h, abi.as_ptr(e, C.c_float), len(e), int(threads), int(lanes_per_chain), abi.as_ptr(a, C.c_float),
+                                                   abi.as_ptr(b, C.c_float)))
+        return a, b
+
     # ---- solve ---------------------------------------------------------------------------------------------
     def esikf_solve(self, HtH, Htz, k, meas_cov_scale, sign, cur, prop):
         HtH, Htz = _f64(HtH).reshape(k, k), _f64(Htz).reshape(k)

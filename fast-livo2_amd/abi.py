@@ -225,6 +225,7 @@ SIGNATURES = {
     "livo2_host_free_pinned": (None, [C.c_void_p]),
     "livo2_debug_redzone_check": (C.c_int, [_CTX, _P(C.c_int32), _P(C.c_int64)]),
     "livo2_debug_redzone_poke": (C.c_int, [_CTX, C.c_int64]),
+    "livo2_debug_float_chain": (C.c_int, [_CTX, _P(C.c_float), C.c_int32, C.c_int32, C.c_int32, _P(C.c_float), _P(C.c_float)]),
     "livo2_ctx_kernel_timing_read": (C.c_int, [_CTX, C.c_int, _P(C.c_double), _P(C.c_int64), C.c_int]),
     "livo2_map_upload": (C.c_int, [_CTX, _P(MapView)]),
     "livo2_map_update_planes": (C.c_int, [_CTX, _P(C.c_int32), C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_float), _P(C.c_float)]),

@@ -173,6 +173,7 @@ struct livo2_ctx {
   // the launch-per-step sequence instead.
   bool visual_persistent = [] { const char *e = std::getenv("LIVO2_VISUAL_PERSISTENT"); return e ? std::atoi(e) != 0 : true; }();
   bool visual_persistent_inverse = true;      // the inverse-compositional form on the resident grid too (option "visual_persistent_inverse")
+  bool visual_error_waves = true;             // the frame error's float chains on groups of lanes (float_chain.hpp) when the threads' blocks are long enough (option "visual_error_waves")
   unsigned long long *d_vp_rows = nullptr; size_t vp_rows_cap = 0; unsigned long long *d_vp_errs = nullptr; size_t vp_errs_cap = 0;
   bool vp_xchg_dirty = true; size_t vp_err_pitch = 0; int vp_hw_rows = 0, vp_hw_m = 0;      // exchange buffers of k_visual_update_persistent: host-side view (api_visual.inc)
   // block order of k_lidar_residual (lidar_kernels.hpp, LptArgs): lifetimes per chunk written by every launch, order written by every solve; valid once a solve of this scan has run
@@ -707,7 +708,10 @@ VisualRefArgs make_ref_args(livo2_ctx *ctx) {
 int visual_grid(int M) { return std::max(1, (M + VIS_PPB - 1) / VIS_PPB); }          // forward-compositional kernels: VIS_PPB patches per block
 int visual_grid_inverse(int M) { return std::max(1, (M + VIS_WAVES - 1) / VIS_WAVES); }   // inverse-compositional kernels: one patch per wave
 // updateStateInverse has no OpenMP loop (vio.cpp:1422-1477): its frame error is always the serial sum
-VisualSolveArgs visual_solve_args(livo2_ctx *ctx, const livo2_visual_cfg *cfg) { return VisualSolveArgs{ctx->d_errors, ctx->M, cfg->inverse_composition_en ? 1 : cfg->mp_proc_num}; }
+VisualSolveArgs visual_solve_args(livo2_ctx *ctx, const livo2_visual_cfg *cfg) {
+  const int T = std::max(1, cfg->inverse_composition_en ? 1 : cfg->mp_proc_num);            // (updateStateInverse has no OpenMP loop: one serial chain, vio.cpp:1418-1477)
+  return VisualSolveArgs{ctx->d_errors, ctx->M, ctx->visual_error_waves ? T : -T};
+}
 
 } // namespace
 
@@ -848,6 +852,7 @@ int livo2_ctx_set_option(livo2_ctx *ctx, const char *name, int32_t value) {
   if (std::strcmp(name, "lidar_fused_iteration") == 0) { ctx->lidar_fused = value != 0; ctx->lpt_valid = false; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent") == 0) { ctx->visual_persistent = value != 0; return LIVO2_OK; }
   if (std::strcmp(name, "visual_persistent_inverse") == 0) { ctx->visual_persistent_inverse = value != 0; return LIVO2_OK; }
+  if (std::strcmp(name, "visual_error_waves") == 0) { ctx->visual_error_waves = value != 0; return LIVO2_OK; }
   if (std::strcmp(name, "map_update_spread") == 0) {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, LIVO2_ERR_INVALID, "map_update_spread: 0 (automatic), 1, 2, 4 or 8");
     ctx->mt_spread_opt = (int)value; return LIVO2_OK;

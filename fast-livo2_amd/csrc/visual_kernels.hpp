@@ -542,9 +542,10 @@ __global__ void __launch_bounds__(VIS_BLOCK) k_visual_ref_precompute_batch(const
 //   wave 2    : the frame error with the reference's float accumulation order — lane t adds the per-patch errors of OpenMP thread t's static block in
 //               index order (vio.cpp:1554, 1634), the T partial sums are joined in thread order (error_threads = MP_PROC_NUM of the reference build)
 //   then      : one barrier; wave 0 compares `error <= last_error` (vio.cpp:1648) and commits either the update or the revert.
+#include "float_chain.hpp"
 #define VIS_SOLVE_THREADS 480         // 12 slices x 40 values
 #define VIS_ERR_STAGE 8192            // per-patch errors staged per pass (floats)
-struct VisualSolveArgs { const float *errors; int32_t M, error_threads; };
+struct VisualSolveArgs { const float *errors; int32_t M, error_threads; };      // error_threads: MP_PROC_NUM of the reference build; NEGATIVE: that many threads, and the frame error on one lane per thread only (option "visual_error_waves" = 0)
 
 // acc + e[lo] + e[lo+1] + ... in this order, one float rounding per add (the serial CPU loop).  The adds are a dependent chain; the LDS reads are not, but
 // the compiler sinks them next to their first use (measured: 14.5 cycles per element, one exposed LDS round trip per 16 adds).  The reads are therefore issued
@@ -590,6 +591,27 @@ __device__ __forceinline__ float float_chain(const float *e, int lo, int hi, flo
   return acc;
 }
 
+// ---- the frame error on whole waves (float_chain.hpp): a chain per group of FC_W lanes instead of a chain per lane, same bits ----------------------------------
+// Used when every OpenMP thread's block of patches is long enough to pay for the rounds (C4: 1 000 per thread, 4.1-5.4 us as one dependent chain of adds — longer than the
+// 19-dim solve beside it, 3.2-4.2 us — against ~2 us here) and the chains fit the waves set aside for them; otherwise lane t of one wave adds thread t's block serially.
+#define VS_FC_WAVES 5            // chain waves of k_visual_solve and of the resident grid's solve phase
+#define FC_W 32
+#define FC_LMAX 35
+#define FC_CPW (LIVO2_WAVE / FC_W)
+// chain waves of an 8-wave block whose wave 0 runs the solve: SIMDs 2, 3 first, never the solve's own SIMD (waves 0 and 4)
+__device__ __forceinline__ int fc_wave_index(int wave, int nwaves) {
+  const int idx = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : wave == 5 ? 4 : -1;
+  return idx < nwaves ? idx : -1;
+}
+__device__ __forceinline__ int fc_threads(int error_threads) { const int t = error_threads < 0 ? -error_threads : error_threads; return t < 1 ? 1 : (t > LIVO2_WAVE ? LIVO2_WAVE : t); }
+__device__ __forceinline__ bool fc_use_waves(int M, int T, int nwaves) { return T <= nwaves * FC_CPW && M / T >= FC_MIN_N; }
+// OpenMP static partition of M patches over T threads (libgomp: the first M % T threads get one patch more)
+__device__ __forceinline__ void fc_partition(int M, int T, int c, int &b, int &e) {
+  const int q = M / T, r = M % T;
+  b = c < r ? c * (q + 1) : c * q + r; e = b + (c < r ? q + 1 : q);
+  if (c >= T) { b = 0; e = 0; }
+}
+
 struct __attribute__((aligned(16))) VisSolveLds {
   float errs[VIS_ERR_STAGE];
   SolveLds s;
@@ -605,7 +627,6 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
   SolveLds &s = SL.s;
   double *sums = SL.sums, *scratch = SL.scratch;
   float *errs = SL.errs, *err_chunk = SL.err_chunk;
-  float &err_total = SL.err_total;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   VSPHASE(0);
   // every global read of this kernel is issued here, in one batch: loop-control words, covariance + states, the partial rows
@@ -652,6 +673,8 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
   }
   __syncthreads();
   VSPHASE(3);
+  const int T = fc_threads(va.error_threads);
+  const bool fcw = va.error_threads >= 0 && fc_use_waves(va.M, T, VS_FC_WAVES);         // block-uniform
   if (wave == 0) {                                           // the 19-dim algebra, speculative: LDS only
     if (lane < 49) {
       int rr = lane / 7, c = lane % 7;
@@ -662,21 +685,27 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
     if (lane < 7) s.htz[lane] = sums[28 + lane];
     wave_sync();
     if (mode != 0) esikf_solve_wave<7>(s, -1, lane);
-  } else if (wave == 2) {                                    // frame error, part 2: lane c owns OpenMP thread c's static block of patches (libgomp: the first
-    const int T = va.error_threads < 1 ? 1 : (va.error_threads > LIVO2_WAVE ? LIVO2_WAVE : va.error_threads);   // M % T threads get one patch more)
-    const int q = va.M / T, r = va.M % T;
-    const int my_begin = lane < r ? lane * (q + 1) : lane * q + r, my_end = my_begin + (lane < r ? q + 1 : q);
-    float priv = 0.0f;
-    if (lane < T) {
-      const int mid = min(my_end, n_stage);
-      priv = float_chain(errs, my_begin, mid, priv);
-      for (int i = max(my_begin, n_stage); i < my_end; i++) priv += xb_load<XB>(&va.errors[i]);
-      err_chunk[lane] = priv;
+  } else if (fcw ? (fc_wave_index(wave, VS_FC_WAVES) >= 0) : (wave == 2)) {      // frame error, part 2: OpenMP thread c's static block of patches, added in index order
+    if (fcw) {                                                 // a chain per FC_W lanes (float_chain.hpp)
+      const int c = fc_wave_index(wave, VS_FC_WAVES) * FC_CPW + lane / FC_W;
+      int my_begin, my_end; fc_partition(va.M, T, c, my_begin, my_end);
+      float priv = float_chain_wave<FC_W, FC_LMAX>(errs, min(my_begin, n_stage), min(my_end, n_stage), 0.0f, lane);
+      if ((lane & (FC_W - 1)) == 0 && c < T) {
+        for (int i = max(my_begin, n_stage); i < my_end; i++) priv += xb_load<XB>(&va.errors[i]);
+        err_chunk[c] = priv;
+      }
+    } else {                                                   // a chain per lane
+      int my_begin, my_end; fc_partition(va.M, T, lane, my_begin, my_end);
+      float priv = 0.0f;
+      if (lane < T) {
+        const int mid = min(my_end, n_stage);
+        priv = float_chain(errs, min(my_begin, mid), mid, priv);
+        for (int i = max(my_begin, n_stage); i < my_end; i++) priv += xb_load<XB>(&va.errors[i]);
+        err_chunk[lane] = priv;
+      }
     }
-    wave_sync();
-    if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += err_chunk[c]; err_total = e; }
   }
-  else if (wave == 3) {                                      // diagnostic double-precision sum of the patch errors (livo2_visual_sums.err_sum): a tree, off the chain
+  else if (wave == 1) {                                      // diagnostic double-precision sum of the patch errors (livo2_visual_sums.err_sum): a tree, off the chain
     double e = 0.0;
     for (int i = lane; i < n_stage; i += LIVO2_WAVE) e += (double)errs[i];
     for (int i = n_stage + lane; i < va.M; i += LIVO2_WAVE) e += (double)xb_load<XB>(&va.errors[i]);
@@ -689,7 +718,8 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
   if (wave != 0) return;                                     // the rest is one wave; only wave-local synchronisation below
   const double err_sum = SL.err_sum_d;                       // (the partial rows do not carry the error: both sums are formed from errors[])
   const int n_meas = (int)sums[36];
-  float error = err_total;
+  float error = 0.0f;
+  for (int c = 0; c < T; c++) error += err_chunk[c];         // the threads' partial sums joined in thread order
   error = error / n_meas;                                   // float / int (vio.cpp:1636); NaN when n_meas == 0
   if (mode == 0) {
     if (lane < 49) ctl->sums_v.HtH[lane] = s.hth[lane];
@@ -1120,6 +1150,8 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
   }
   __syncthreads();
   VPP(4);
+  const int T = fc_threads(p.error_threads);
+  const bool fcw = p.error_threads >= 0 && fc_use_waves(M, T, VS_FC_WAVES);         // block-uniform
   if (wave == 0) {
     if (lane < 49) {
       const int rr = lane / 7, c = lane % 7, u = rr < c ? rr : c, v = rr < c ? c : rr;
@@ -1135,30 +1167,38 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
       SL.stop_if_accepted = ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) ? 1 : 0;
     }
     VPP(9);
-  } else if (wave == 2) {                                 // the frame error in the reference's float accumulation order (k_visual_solve, wave 2)
-    const int T = p.error_threads < 1 ? 1 : (p.error_threads > LIVO2_WAVE ? LIVO2_WAVE : p.error_threads);
-    const int q = M / T, r = M % T;
-    const int my_begin = lane < r ? lane * (q + 1) : lane * q + r, my_end = my_begin + (lane < r ? q + 1 : q);
+  } else if (fcw ? (fc_wave_index(wave, VS_FC_WAVES) >= 0) : (wave == 2)) {      // the frame error in the reference's float accumulation order (as in k_visual_solve)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int c, my_begin, my_end;
     float priv = 0.0f;
-    if (lane < T) {
-      priv = float_chain(SL.u.s.errs, my_begin, min(my_end, n_stage), priv);
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool owner;
+    if (fcw) {                                            // a chain per FC_W lanes (float_chain.hpp)
+      c = fc_wave_index(wave, VS_FC_WAVES) * FC_CPW + lane / FC_W;
+      fc_partition(M, T, c, my_begin, my_end);
+      priv = float_chain_wave<FC_W, FC_LMAX>(SL.u.s.errs, min(my_begin, n_stage), min(my_end, n_stage), 0.0f, lane);
+      owner = (lane & (FC_W - 1)) == 0 && c < T;
+    } else {                                              // a chain per lane
+      c = lane;
+      fc_partition(M, T, c, my_begin, my_end);
+      owner = lane < T;
+      if (owner) priv = float_chain(SL.u.s.errs, min(my_begin, n_stage), min(my_end, n_stage), priv);
+    }
+    if (owner) {
       for (int i = max(my_begin, n_stage); i < my_end; i++) {                 // sub-maps beyond the staging area: straight from the published words
         uint32_t w = vp_ld32(errs + i);
         while (w == VP_EMPTY32) { if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout) { SL.timed_out = 1; break; } w = vp_ld32(errs + i); }
         priv += __uint_as_float(w);
       }
-      SL.u.s.err_chunk[lane] = priv;
+      SL.u.s.err_chunk[c] = priv;
     }
-    wave_sync();
-    if (lane == 0) { float e = 0.0f; for (int c = 0; c < T; c++) e += SL.u.s.err_chunk[c]; SL.err_total = e; }
     VPP_W(7, 2);
   }
   __syncthreads();
   VPP(5);
   if (wave == 0) {                                        // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
     const int n_meas = (int)SL.u.s.sums[36];
-    float error = SL.err_total;
+    float error = 0.0f;
+    for (int c = 0; c < T; c++) error += SL.u.s.err_chunk[c];       // the threads' partial sums joined in thread order
     error = error / n_meas;
     const float last_error = (it == 0) ? FLT_MAX : SL.last_error;
     const bool accepted = error <= last_error;
@@ -1258,5 +1298,24 @@ template <bool INV> __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_
     for (int j = 0; j < 3; j++) ctl->visual.Pcw[j] = a.Pci[j] - ((Rcw[j * 3] * s.cur[9] + Rcw[j * 3 + 1] * s.cur[10]) + Rcw[j * 3 + 2] * s.cur[11]);
     ctl->visual.n_steps = SL.n_steps; ctl->hdr.n_steps = SL.n_steps; ctl->hdr.last_error = SL.last_error; ctl->hdr.stop = SL.stop;
     ctl->hdr.pad[0] = 0; ctl->visual.pad = 0;
+  }
+}
+
+// ---- livo2_debug_float_chain: the frame error's partial sums both ways, for the tests (tests/test_float_chain_gpu.py) ------------------------------------------------
+// errors[n] are staged in LDS as the solve kernels stage them; out[0][c]: a chain per group of W lanes (waves 1..7), out[1][c]: a chain per lane (wave 0).
+template <int W, int LMAX>
+__global__ void __launch_bounds__(512) k_debug_float_chain(const float *__restrict__ errors, int n, int T, float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float errs[VIS_ERR_STAGE + 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < VIS_ERR_STAGE + 64; i += 512) errs[i] = i < n ? errors[i] : 0.0f;
+  __syncthreads();
+  if (wave == 0) {
+    int b, e; fc_partition(n, T, lane, b, e);
+    if (lane < T) out[64 + lane] = float_chain(errs, b, e, 0.0f);
+  } else {
+    const int c = (wave - 1) * (LIVO2_WAVE / W) + lane / W;
+    int b, e; fc_partition(n, T, c, b, e);
+    const float v = float_chain_wave<W, LMAX>(errs, b, e, 0.0f, lane);
+    if ((lane & (W - 1)) == 0 && c < T) out[c] = v;
   }
 }

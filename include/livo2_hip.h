@@ -92,6 +92,10 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *                        "visual_persistent_backoff_skips") before it tries a resident grid again.
  *   "visual_persistent_inverse" (default 1, round 6): with cfg->inverse_composition_en the resident grid also runs precomputeReferencePatches + updateStateInverse
  *                        (vio.cpp:1327-1518; 0: that form stays on the launch-per-step sequence — same bits, tests/test_visual_inverse_gpu.py).
+ *   "visual_error_waves" (default 1, round 6): the frame error — each OpenMP thread's serial float sum over its block of patch errors (vio.cpp:1554, 1634), whose exact
+ *                        bits decide accept / revert — is formed by a group of 32 lanes per thread (fast-livo2_amd/csrc/float_chain.hpp) when the blocks hold >= 768
+ *                        patches and the threads fit five waves; 0: always one lane per thread (a dependent chain of adds).  Same bits either way
+ *                        (tests/test_float_chain_gpu.py, tests/test_visual_gpu.py).
  *   "map_update_spread" (default 0, round 6): lanes per touched root voxel in the octree update = 8 x this (1, 2, 4, 8; of which 8 work, or all 64 in the plane re-fit when
  *                        this is 8 and "map_update_wide_fit" = 1, the default); 0: chosen per update from the number of roots the previous one touched.  Every choice gives the
  *                        same tree (plane parameters to the rounding of the re-fit's summation order: tests/test_map_tree_gpu.py).
@@ -127,6 +131,11 @@ int livo2_debug_redzone_check(livo2_ctx *ctx, int32_t *mode, int64_t *damaged_wo
 /* Self-test of the checker: one 4-byte device store `byte_offset` bytes behind the END of the ctx's control block (negative: in front of its start).
  * Refused (LIVO2_ERR_INVALID) unless LIVO2_REDZONE is set. */
 int livo2_debug_redzone_poke(livo2_ctx *ctx, int64_t byte_offset);
+/* Self-test of the frame error's accumulation (reference src/vio.cpp:1554, 1634, 1636: each OpenMP thread adds the patch errors of its static block into a float,
+ * in index order).  errors[n] (n <= 8192) are split over `threads` blocks as libgomp splits them; sums_wave[c] is thread c's partial sum as the visual solve forms it
+ * for long blocks (a group of `lanes_per_chain` = 16 / 32 / 64 lanes per chain, fast-livo2_amd/csrc/float_chain.hpp; threads <= 7 * 64 / lanes_per_chain),
+ * sums_serial[c] as one lane adds it.  Both equal the serial float loop bit for bit (tests/test_float_chain_gpu.py). */
+int livo2_debug_float_chain(livo2_ctx *ctx, const float *errors, int32_t n, int32_t threads, int32_t lanes_per_chain, float *sums_wave, float *sums_serial);
 
 /* ---- VoxelMap snapshot ("flat map") -------------------------------------------------------------------------- */
 /* Index-based mirror of `std::unordered_map<VOXEL_LOCATION, VoxelOctoTree*> voxel_map_` (reference include/voxel_map.h:194)

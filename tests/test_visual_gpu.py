@@ -297,3 +297,27 @@ def test_a_resident_grid_that_loses_a_block_is_rerun_per_step_with_the_same_resu
     assert ctx.counter("visual_persistent_timeouts") == t0 + 3 and ctx.counter("visual_persistent_launches") == f0 + 3
     res, err = ctx.visual_update(cur, prop, cfg)                    # and the resident grid works again afterwards
     assert bytes(res.state) == bytes(ref.state) and ctx.counter("visual_persistent_timeouts") == t0 + 3
+
+
+@pytest.mark.parametrize("M,threads", [(4000, 4), (2000, 1), (9000, 4), (6001, 7), (8000, 10)])
+def test_frame_error_on_groups_of_lanes_gives_the_bits_of_the_one_lane_chains(livo2, ctx, M, threads):
+    """round 6: the frame error's float chains (vio.cpp:1554, 1634) run on groups of 32 lanes (float_chain.hpp) when every OpenMP thread's block holds >= 768 patch
+    errors (>= 768 since the break-even was measured); option "visual_error_waves" = 0 keeps one lane per thread.  Same records, same errors[], on the resident grid and on the launch-per-step sequence
+    (M = 9000: the blocks reach beyond the staging area; 7 threads: four chain waves; 10 threads: five)."""
+    vs = synth.visual_scenario(seed=400 + threads, n_patches=M)
+    cfg = H.visual_cfg_product(vs, mp_proc_num=threads)
+    cur, prop = H.states(vs, livo2.State)
+    ctx.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
+    out = {}
+    try:
+        for persistent in (0, 1):
+            for waves in (0, 1):
+                ctx.set_option("visual_persistent", persistent); ctx.set_option("visual_error_waves", waves)
+                out[persistent, waves] = ctx.visual_update(cur, prop, cfg)
+    finally:
+        ctx.set_option("visual_persistent", 1); ctx.set_option("visual_error_waves", 1)
+    for persistent in (0, 1):
+        (a, ea), (b, eb) = out[persistent, 0], out[persistent, 1]
+        assert a.n_steps == b.n_steps and np.array_equal(ea, eb)
+        assert bytes(a.state) == bytes(b.state) and bytes(a.G) == bytes(b.G)
+        assert all(bytes(a.steps[j]) == bytes(b.steps[j]) for j in range(a.n_steps)), persistent

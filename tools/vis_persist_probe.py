@@ -27,6 +27,9 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ctx = livo2.Context(0)
+    ew = os.environ.get("LIVO2_PROBE_ERROR_WAVES")                 # "0": the frame error on one lane per thread (option "visual_error_waves")
+    if ew is not None:
+        ctx.set_option("visual_error_waves", int(ew))
     for seed in (4, 5):
         vs = synth.visual_scenario(seed=seed, n_patches=M)
         cfg = cfg_of(vs)
@@ -57,6 +60,8 @@ def main():
     os.environ["LIVO2_VP_PROF"] = "1"
     c2 = livo2.Context(0)
     del os.environ["LIVO2_VP_PROF"]
+    if ew is not None:
+        c2.set_option("visual_error_waves", int(ew))
     c2.set_frame(vs.img, vs.pos, vs.warp_patch, vs.search_levels, vs.inv_expo_list)
     for _ in range(3):
         res, _ = c2.visual_update(prior, prior, cfg)
