@@ -898,6 +898,7 @@ struct __attribute__((aligned(16))) VisPersistLds {
   double old[25];               // old_state (vio.cpp:1523, 1650, 1679), scalars only (cov never differs)
   double Gfull[DS * DS];        // G as the reference keeps it: written on accepted steps only (vio.cpp:1655-1665), zero-padded 19 x 19
   float last_error, err_total;
+  float last_error2[2];         // last_error as step k reads it ([k & 1]) and leaves it ([(k + 1) & 1]): the waves that decide in parallel never read a word another one writes
   int stop, n_steps, timed_out, stop_if_accepted;
   uint32_t base;                // *p.base as the launch found it
 };
@@ -1195,36 +1196,40 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
   }
   __syncthreads();
   VPP(5);
-  if (wave == 0) {                                        // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
+  if (wave < 3) {                                         // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
+    // Three waves take the same decision from the same words (the float error, n_meas, last_error of the step's parity slot) and share what follows it: wave 0 the
+    // iterate and the loop flags — the only part the next residual waits for —, wave 1 the copy of G, wave 2 (block 0) the step record.  (One wave did all of it: 1.0 us
+    // per accepted step against 0.64 for a reverted one.)
     const int n_meas = (int)SL.u.s.sums[36];
     float error = 0.0f;
     for (int c = 0; c < T; c++) error += SL.u.s.err_chunk[c];       // the threads' partial sums joined in thread order
     error = error / n_meas;
-    const float last_error = (it == 0) ? FLT_MAX : SL.last_error;
+    const float last_error = (it == 0) ? FLT_MAX : SL.last_error2[step_global & 1];
     const bool accepted = error <= last_error;
-    const int step = SL.n_steps;
-    livo2_visual_step *st = (blockIdx.x == 0 && step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) ? &ctl->visual.steps[step] : nullptr;
-    int stop = 0;
-    if (st) {
+    const int step = step_global;                          // (= the number of steps taken so far: SL.n_steps)
+    if (wave == 0) {
+      int stop = 0;
+      if (accepted) {
+        stop = SL.stop_if_accepted;
+        double nv = 0.0;
+        if (lane < 9) nv = s.newR[lane]; else if (lane < 25) nv = s.cur[lane] + s.sol[lane - 6];
+        if (lane < 25) { SL.old[lane] = s.cur[lane]; s.cur[lane] = nv; }                              // old_state = *state ; *state += solution
+      } else {
+        if (it > 0 && lane < 25) s.cur[lane] = SL.old[lane];                                           // *state = old_state ; EKF_end
+        stop = 1;
+      }
+      if (lane == 0) { SL.last_error2[(step_global + 1) & 1] = accepted ? error : last_error; if (accepted) SL.last_error = error; SL.stop = stop; SL.n_steps = step + 1; }
+    } else if (wave == 1) {
+      if (accepted) {
+        for (int e = lane; e < DS * KMAX; e += LIVO2_WAVE) SL.Gfull[(e / KMAX) * DS + e % KMAX] = s.G[e];
+      }
+    } else if (blockIdx.x == 0 && step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) {
+      livo2_visual_step *st = &ctl->visual.steps[step];
       if (lane < 49) st->HtH[lane] = s.hth[lane];
       if (lane < 7) st->Htz[lane] = s.htz[lane];
       if (lane < DS) st->solution[lane] = accepted ? s.sol[lane] : 0.0;
       if (lane == 0) { st->level = level; st->iteration = it; st->accepted = accepted ? 1 : 0; st->n_meas = n_meas; st->error = error; st->pad = 0; }
     }
-    if (accepted) {
-      stop = SL.stop_if_accepted;
-      double nv = 0.0;
-      if (lane < 9) nv = s.newR[lane]; else if (lane < 25) nv = s.cur[lane] + s.sol[lane - 6];
-      if (lane < 25) { SL.old[lane] = s.cur[lane]; s.cur[lane] = nv; }                              // old_state = *state ; *state += solution
-      if (lane < DS) {
-#pragma unroll
-        for (int c = 0; c < KMAX; c++) SL.Gfull[lane * DS + c] = s.G[lane * KMAX + c];
-      }
-    } else {
-      if (it > 0 && lane < 25) s.cur[lane] = SL.old[lane];                                           // *state = old_state ; EKF_end
-      stop = 1;
-    }
-    if (lane == 0) { if (accepted) SL.last_error = error; SL.stop = stop; SL.n_steps = step + 1; }
   }
   __syncthreads();
   VPP(6);
