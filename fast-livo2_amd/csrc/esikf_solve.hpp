@@ -35,16 +35,19 @@ struct SolveLds {
 // Part 1 (independent of the measurement sums, so it overlaps the partial-sum loads): P' = cov / scale and the 25 pose / bias scalars
 // of both states into LDS.  Every later step of the solve reads LDS only: a global load issued late costs a full ~1.5-us round trip
 // on the single wave that is the critical path of the whole iteration.  Call from wave 0 only; no barrier inside.
-__device__ inline void esikf_prefetch_wave(const DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int lane, double *c /*[6] raw covariance words of this lane*/) {
+// (cur_state / prop_state: the iterate and the prior where they are — ctl->cur / ctl->prop, or the LiDAR posterior for an update chained to it on the device)
+__device__ inline void esikf_prefetch_wave(const livo2_state *cur_state, const livo2_state *prop_state, SolveLds &s, const double meas_cov_scale, const int lane, double *c /*[6] raw covariance words of this lane*/) {
 #pragma unroll
-  for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; c[q] = (e < DS * DS) ? ctl->cur.cov[e] : 0.0; }
-  const double *cs = reinterpret_cast<const double *>(&ctl->cur), *ps = reinterpret_cast<const double *>(&ctl->prop);
+  for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; c[q] = (e < DS * DS) ? cur_state->cov[e] : 0.0; }
+  const double *cs = reinterpret_cast<const double *>(cur_state), *ps = reinterpret_cast<const double *>(prop_state);
   double sv = 0.0;
   if (lane < 25) sv = cs[lane]; else if (lane < 50) sv = ps[lane - 25];
 #pragma unroll
   for (int q = 0; q < 6; q++) { const int e = lane + q * LIVO2_WAVE; if (e < DS * DS) s.P[e] = c[q] / meas_cov_scale; }
   if (lane < 25) s.cur[lane] = sv; else if (lane < 50) s.prop[lane - 25] = sv;
 }
+
+__device__ inline void esikf_prefetch_wave(const DevCtl *ctl, SolveLds &s, const double meas_cov_scale, const int lane, double *c) { esikf_prefetch_wave(&ctl->cur, &ctl->prop, s, meas_cov_scale, lane, c); }
 
 // rotation part of vec = state_propagat [-] state: Log(cur^T prop) (common_lib.h:196-197) -> s.vec[0..2].  ~1.5 us of dependent f64
 // transcendental code on one lane, so the solve kernels run it on a second wave while the partial rows are in flight.

@@ -125,6 +125,9 @@ __global__ void __launch_bounds__(256) k_frame_publish(const DevCtl *__restrict_
   constexpr int NL = (int)(sizeof(livo2_lidar_result) / 8), NV = (int)(sizeof(livo2_visual_result) / 8);
   const double *l = reinterpret_cast<const double *>(&ctl->lidar), *v = reinterpret_cast<const double *>(&ctl->visual);
   for (int k = threadIdx.x; k < NL; k += 256) out[k] = l[k];
-  for (int k = threadIdx.x; k < NV; k += 256) out[NL + k] = v[k];
+  // the step records are written up to n_steps only (a slot holds LIVO2_MAX_LEVELS x LIVO2_MAX_ITERS = 128 of them, 83 KB across the link, of which a frame fills ~15)
+  constexpr int NVH = (int)(offsetof(livo2_visual_result, steps) / 8), NVS = (int)(sizeof(livo2_visual_step) / 8);
+  const int ns = min(max(ctl->visual.n_steps, 0), LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS);
+  for (int k = threadIdx.x; k < NVH + ns * NVS && k < NV; k += 256) out[NL + k] = v[k];
   if (threadIdx.x == 0) { const int2 f = make_int2(ctl->hdr.pad[0], 0); out[NL + NV] = __builtin_bit_cast(double, f); }
 }

@@ -884,6 +884,7 @@ struct VisPersistArgs {
   unsigned long long *prof;     // debug (LIVO2_VP_PROF=1): [block < 256][step < 32][16] stamps of the 100 MHz clock, else null
   unsigned long long timeout;   // 100 MHz ticks a block waits for a word before it gives the update up (VP_TIMEOUT; option "visual_persistent_debug_timeout" shortens it)
   int32_t debug_drop_block;     // -1; else this block leaves at once (a grid that is not co-resident, simulated: tests/test_visual_gpu.py)
+  int32_t chained;              // 1: iterate = prior = the LiDAR posterior in ctl->lidar.state (what k_ctl_chain_visual would have copied into ctl->cur / ctl->prop: one launch less per frame)
   int32_t inverse;              // 1: updateStateInverse — precomputeReferencePatches at the head of every level, then the INV form of the wave body (round 6)
   VisualRefArgs r;              // (inverse)
 };
@@ -1244,9 +1245,10 @@ template <bool INV> __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_
   const int ngroups = (M + VIS_PPB - 1) / VIS_PPB;
   if ((int)blockIdx.x == p.debug_drop_block) return;
   // ---- entry: the iterate, the prior, P' = cov / img_point_cov, the G the reference would still hold (all blocks read the same words)
+  const livo2_state *src_state = p.chained ? &ctl->lidar.state : &ctl->cur;        // (LIVMapper.cpp:135-136, 256, 371: `state` is shared; nobody writes either before block 0's last lines)
   {
     double craw[6];
-    if (wave == 0) esikf_prefetch_wave(ctl, s, p.img_point_cov, lane, craw);
+    if (wave == 0) esikf_prefetch_wave(src_state, p.chained ? src_state : &ctl->prop, s, p.img_point_cov, lane, craw);
     for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.Gfull[e] = ctl->G[e];
     if (tid == 0) { SL.last_error = FLT_MAX; SL.stop = 0; SL.n_steps = 0; SL.base = p.base[0]; SL.timed_out = p.base[1] != 0 ? 1 : 0; }      // (base[1]: the launch before gave up half-way)
   }
@@ -1284,8 +1286,14 @@ template <bool INV> __global__ void __launch_bounds__(VP_BLOCK) k_visual_update_
   if (SL.timed_out) { if (tid == 0) { ctl->hdr.pad[0] = 1; ctl->visual.pad = 1; } return; }      // (visual.pad: the flag travels with the result block — one copy command less per fetch)
   if (tid == 0) p.base[0] = SL.base + (uint32_t)step_global;     // (every other block read it before it published its first row, and this block has seen all of those)
   // ---- block 0: the result.  state->cov -= G * state->cov (vio.cpp:800), updateFrameState (vio.cpp:1690-1697)
-  for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.u.s.cov[e] = ctl->cur.cov[e];
+  for (int e = tid; e < DS * DS; e += VP_BLOCK) SL.u.s.cov[e] = src_state->cov[e];
   __syncthreads();
+  if (p.chained) {                                               // what k_ctl_chain_visual leaves behind: prop = the LiDAR posterior, header cleared (hdr.stop / n_steps / last_error follow below)
+    const double *ls = reinterpret_cast<const double *>(&ctl->lidar.state); double *pp = reinterpret_cast<double *>(&ctl->prop);
+    for (int k = tid; k < (int)(sizeof(livo2_state) / 8); k += VP_BLOCK) pp[k] = ls[k];
+    if (tid == 0) { ctl->hdr.rematch_num = 0; ctl->hdr.reserved = 0; ctl->hdr.pad[1] = ctl->hdr.pad[2] = 0; }
+    if (tid < 9) ctl->hdr.RE[tid] = 0.0;
+  }
   double *dst = reinterpret_cast<double *>(&ctl->visual.state);
   for (int e = tid; e < DS * DS; e += VP_BLOCK) {
     const int r = e / DS, c = e % DS;

@@ -647,6 +647,8 @@ typedef struct livo2_frame_in {
   const livo2_visual_reference *reference;
 } livo2_frame_in;
 int livo2_frame_update_async(livo2_ctx *ctx, const livo2_frame_in *frame);
+/* (visual->steps: entries [0, n_steps) are written; the 128 - n_steps entries behind them are left as the caller's struct holds them — a frame fills ~15 of them,
+ * and the slot crosses the link once per frame) */
 int livo2_frame_update_fetch(livo2_ctx *ctx, livo2_lidar_result *lidar, livo2_visual_result *visual);
 int livo2_frame_update(livo2_ctx *ctx, const livo2_frame_in *frame, livo2_lidar_result *lidar, livo2_visual_result *visual);
 
