@@ -71,7 +71,7 @@ template <int SRC> __device__ __forceinline__ double esikf_bcast(double v) {
 }
 
 // elimination step C of the column-per-lane scheme (see esikf_solve_wave): lane C holds column C of A, finds the pivot row and forms the multipliers
-template <int C, int k> __device__ __forceinline__ void esikf_eliminate(double (&col)[k]) {
+template <int C, int k> __device__ __forceinline__ void esikf_eliminate(double (&col)[k], double (&pinv)[k]) {
   if constexpr (C < k) {
     int piv = C; double best = fabs(col[C]);
 #pragma unroll
@@ -81,24 +81,25 @@ template <int C, int k> __device__ __forceinline__ void esikf_eliminate(double (
     for (int i = C + 1; i < k; i++)
       if (piv == i) { const double t = col[C]; col[C] = col[i]; col[i] = t; }     // wave-uniform row swap
     const double inv = 1.0 / col[C];
+    pinv[C] = inv;                                            // (lane C's copy is the reciprocal of the pivot U[C][C]: the back substitution multiplies by it)
 #pragma unroll
     for (int i = C + 1; i < k; i++) {
       const double li = esikf_bcast<C>(col[i] * inv);         // l = A[i][C] * inv, formed in lane C
       col[i] = fma(-li, col[C], col[i]);
     }
-    esikf_eliminate<C + 1, k>(col);
+    esikf_eliminate<C + 1, k>(col, pinv);
   }
 }
 // t -= U[I][J] x[J] for J = I+1 .. k-1 (ascending), U[I][J] = entry I of lane J's column
 template <int I, int J, int k> __device__ __forceinline__ void esikf_back_row(const double (&col)[k], const double (&x)[k], double &t) {
   if constexpr (J < k) { t = fma(-esikf_bcast<J>(col[I]), x[J], t); esikf_back_row<I, J + 1, k>(col, x, t); }
 }
-template <int I, int k> __device__ __forceinline__ void esikf_back(const double (&col)[k], double (&x)[k]) {
+template <int I, int k> __device__ __forceinline__ void esikf_back(const double (&col)[k], const double (&pinv)[k], double (&x)[k]) {
   if constexpr (I >= 0) {
     double t = col[I];
     esikf_back_row<I, I + 1, k>(col, x, t);
-    x[I] = t / esikf_bcast<I>(col[I]);
-    esikf_back<I - 1, k>(col, x);
+    x[I] = t * esikf_bcast<I>(pinv[I]);                       // (round 6: the reciprocal the elimination formed, instead of a second f64 division per row: 7 dependent divisions less per solve)
+    esikf_back<I - 1, k>(col, pinv, x);
   }
 }
 
@@ -125,9 +126,10 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
   double col[k];
 #pragma unroll
   for (int i = 0; i < k; i++) col[i] = (lane < k) ? s.aug[lane * k + i] : s.P[r * DS + i];   // column `lane` of A = S^T is row `lane` of S
-  esikf_eliminate<0, k>(col);                                // forward elimination, one pivot column at a time
+  double pinv[k];
+  esikf_eliminate<0, k>(col, pinv);                          // forward elimination, one pivot column at a time
   double x[k];                                               // back substitution: x = K_1[r, 0:k] in the lanes that own a right-hand side
-  esikf_back<k - 1, k>(col, x);
+  esikf_back<k - 1, k>(col, pinv, x);
   double kz = 0.0, gv = 0.0;                                 // G[r, 0:k] = K_1[r, 0:k] H_k
   double g[KMAX];
 #pragma unroll
