@@ -2,17 +2,19 @@
 // (reference src/vio.cpp:1554, 1634: `error += patch_error` inside an OpenMP static block) evaluated by W lanes instead of one dependent chain of adds,
 // with the SAME bits.  Test infrastructure: g++ -O2 -ffp-contract=off tools/float_chain_model.cpp && ./a.out [cases]  (tests/test_float_chain_cpu.py runs it).
 //
-// Why it can be done: while the accumulator stays inside one binade (ulp u) and no add lands exactly half-way between two floats, fl(acc + e) = acc + D(e) u
-// with D(e) = e rounded to a multiple of u — independent of acc.  A segment of the chain that neither leaves the binade nor meets a tie therefore adds a
-// CONSTANT, which a lane can measure from a guessed start; only the segments that cross a binade or meet a tie need their true start.
-//   1. lane l owns L consecutive elements; its start is guessed from an f64 prefix sum.
-//   2. every lane runs its L adds twice, from its start `a` and from `a` with the last mantissa bit flipped.  Without a tie both runs make the same rounding
-//      decisions and keep their distance of one ulp; a tie changes the distance to 0 or 2 ulps for good (round-to-even looks at the parity) — so
-//      "same increment in both runs, start and ends in one binade" certifies the segment as linear.
-//   3. the true starts follow from an exact f64 prefix sum over the increments, beginning at the last lane whose start is known exactly (`jx`, initially lane 0);
-//      they are accepted up to the first lane whose segment is not certified for its true start.  That lane's start is exact now: the next round runs it
-//      for real.  Every round advances jx; after MAXR rounds the rest is added serially.
-// Exactness of the f64 sums: every term is a multiple of 2^(klow-23) and every accepted partial sum is below 2^(klow+30), klow = exponent of the exact base.
+// The method (lane by lane as the device code does it; every number below is produced by real float adds, nothing is inferred):
+//   0. lane l of a group of W lanes owns L consecutive elements.
+//   1. guesses: the f64 prefix over the float sums of the segments (four partial sums per lane).
+//   2. one PLAIN round: every lane adds its segment to its guessed start; the increments it measures are increments in the right binade (a segment's float sum from 0
+//      is off by a few ulps of the accumulator's binade, which step 3 could not absorb), their f64 prefix behind the exact end of lane 0 gives the second guesses.
+//   3. a TABLE round: every lane adds its segment to the EIGHT consecutive floats around its guess, bit patterns b .. b + 7 with b = bits(guess) - 3 — a table of the
+//      lane's true start -> end function on that window.  What the next lane needs of it is an INDEX map: g_l[i] = where the end e_l[i] lies in the window of lane
+//      l + 1 (bits(e_l[i]) - b_{l+1}, INVALID = 0xff outside 0..7): eight bytes.  Index maps compose by byte permutation (one v_perm_b32 per four entries on the
+//      device, 0xff selecting 0xff), so a log-step scan gives every lane the map "index of the chain's start in lane 0's window -> index of my true start in MY
+//      window", and with it the exact end of the lane — or INVALID from the first lane on whose true start fell outside its window.  Then the starts of all lanes up
+//      to that one are exact, the guesses behind it are shifted by what that lane's guess was off, and step 3 is repeated (rare).  After MAXT table rounds the rest is
+//      added serially.
+// Any element that is negative, infinite or NaN sends the whole call to the serial loop (a table entry could then equal the INVALID pattern).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,8 +25,6 @@
 
 static inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float fromb(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
-static inline int fexp(float f) { return (int)((fbits(f) >> 23) & 0xffu); }
-static inline bool is_float(double s) { return (double)(float)s == s; }
 
 static long g_ties = 0;
 static float chain_seq(const float *e, int n, float acc) {
@@ -37,82 +37,82 @@ static float chain_seq(const float *e, int n, float acc) {
   return acc;
 }
 
-struct Stats { long rounds = 0, superblocks = 0, bails = 0, serial = 0; int max_rounds = 0; };
-
-static const int MAXR = 24;
+struct Stats { long table_rounds = 0, superblocks = 0, bails = 0, serial = 0; int max_rounds = 0; };
+static const int MAXT = 6;
+static const uint32_t INVALID = 0xffffffffu;
 static int lmax_of(int W) { return W == 16 ? 63 : W == 32 ? 35 : 19; }      // the instantiations of float_chain_wave
+
+static const int WIN = 8, WOFF = 3;
+struct Map { uint8_t g[WIN]; };                             // index map of a run of lanes: index in the first lane's window -> index in the window of the lane behind the run
+// own = the later lanes, partner = the lanes before them: partner first, then own (R[i] = own[partner[i]], 0xff stays 0xff)
+static inline Map compose(const Map &own, const Map &partner) { Map r; for (int i = 0; i < WIN; i++) r.g[i] = partner.g[i] < WIN ? own.g[partner.g[i]] : 0xff; return r; }
 
 static float chain_par(const float *e, int n, float acc, int W, Stats &st) {
   if (fbits(acc) >= 0x7f800000u) { st.serial++; return chain_seq(e, n, acc); }
   for (int i = 0; i < n; i++) if (fbits(e[i]) >= 0x7f800000u) { st.serial++; return chain_seq(e, n, acc); }      // negative, -0, inf, NaN: the serial loop
   int pos = 0;
-  std::vector<float> a(W), r0(W), r1(W);
-  std::vector<double> T(W), S(W + 1), C(W);
-  std::vector<char> reg(W);
+  std::vector<float> a(W);
+  std::vector<double> T(W);
   while (pos < n) {
     const int nsb = std::min(n - pos, W * lmax_of(W));
     const int L = ((nsb + W - 1) / W) | 1;
+    const int SLOTS = (lmax_of(W) + 3) & ~3;
     const float *x = e + pos;
-    auto elem = [&](int l, int m) -> float { const int i = l * L + m; return i < nsb ? x[i] : 0.0f; };
-    // guesses: f64 prefix over the float sums of the segments (four partial sums per lane, as the device forms them)
+    auto elem = [&](int l, int m) -> float { const int i = l * L + m; return (m < L && i < nsb) ? x[i] : 0.0f; };
+    auto run = [&](int l, float start) -> float { float v = start; for (int m = 0; m < SLOTS; m++) { volatile float t = v + elem(l, m); v = t; } return v; };
+    st.superblocks++;
+    // 1. guesses
     {
-      double run = 0.0;
-      const int SLOTS = (lmax_of(W) + 3) & ~3;
+      double s = 0.0;
       for (int l = 0; l < W; l++) {
-        a[l] = (float)run;
+        a[l] = (float)s;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int m = 0; m < SLOTS; m++) { volatile float t = g[m & 3] + (m < L ? elem(l, m) : 0.0f); g[m & 3] = t; }
+        for (int m = 0; m < SLOTS; m++) { volatile float t = g[m & 3] + elem(l, m); g[m & 3] = t; }
         volatile float g01 = g[0] + g[1], g23 = g[2] + g[3]; volatile float gs = g01 + g23;
-        run += (double)gs + (l == 0 ? (double)acc : 0.0);
+        s += (double)gs + (l == 0 ? (double)acc : 0.0);
       }
       a[0] = acc;
     }
-    int jx = 0;
-    st.superblocks++;
-    int round = 0;
-    float result = 0.f; bool done = false;
-    for (; !done; round++) {
-      if (round >= MAXR) {
-        float v = a[jx];
-        for (int i = jx * L; i < nsb; i++) { volatile float t = v + x[i]; v = t; }
-        result = v; st.bails++; break;
-      }
-      for (int l = 0; l < W; l++) {
-        const float a1 = fromb(fbits(a[l]) ^ 1u);
-        float v0 = a[l], v1 = a1;
-        for (int m = 0; m < L; m++) { volatile float t0 = v0 + elem(l, m); v0 = t0; volatile float t1 = v1 + elem(l, m); v1 = t1; }
-        r0[l] = v0; r1[l] = v1;
-        C[l] = (double)v0 - (double)a[l];
-        const double C1 = (double)v1 - (double)a1;
-        const int k = fexp(a[l]);
-        reg[l] = (C1 == C[l]) && fexp(v0) == k && fexp(v1) == k && k >= 2;
-      }
-      // base: the end of lane jx is exact
-      const int klow = fexp(r0[jx]);
-      for (int l = 0; l < W; l++) T[l] = l < jx ? 0.0 : (l == jx ? (double)r0[jx] : C[l]);
-      S[0] = 0.0;
-      for (int l = 0; l < W; l++) S[l + 1] = S[l] + T[l];              // S[l] = exclusive sum; exact where it is accepted
-      int first_bad = W;
-      for (int l = jx + 1; l < W; l++) {
-        const double s = S[l], en = S[l] + C[l];
-        const float sf = (float)s, ef = (float)en;
-        const int k = fexp(a[l]);
-        bool ok = is_float(s) && is_float(en) && k >= klow && fexp(ef) - klow <= 28 && fexp(sf) >= klow;
-        if (ok) {
-          const bool same = fbits(sf) == fbits(a[l]);                  // the guess WAS the true start: its run is the true run
-          const bool lin = reg[l] && fexp(sf) == k && fexp(ef) == k;
-          ok = (same && fbits(ef) == fbits(r0[l])) || lin;
-        }
-        if (!ok) { first_bad = l; break; }
-      }
-      if (klow == 0) first_bad = jx + 1;       // zero or subnormal base: one lane per round (its start is the base itself)
-      if (first_bad >= W) { result = (jx == W - 1) ? r0[jx] : (float)(S[W - 1] + C[W - 1]); done = true; }
-      else {
-        for (int l = jx + 1; l < W; l++) a[l] = (float)S[l];
-        jx = first_bad;
-      }
+    // 2. the plain round
+    {
+      for (int l = 0; l < W; l++) { const float v = run(l, a[l]); T[l] = l == 0 ? (double)v : (double)v - (double)a[l]; }
+      double s = 0.0;
+      for (int l = 0; l < W; l++) { if (l > 0) a[l] = (float)s; s += T[l]; }
     }
-    st.rounds += round; if (round > st.max_rounds) st.max_rounds = round;
+    // 3. table rounds
+    std::vector<uint32_t> b(W), val(W); std::vector<std::vector<uint32_t>> en(W, std::vector<uint32_t>(WIN));
+    std::vector<Map> H(W), Hn(W);
+    float result = 0.f; bool done = false; int t = 0;
+    for (; !done; t++) {
+      for (int l = 0; l < W; l++) {
+        const uint32_t ba = fbits(a[l]);
+        b[l] = ba - std::min<uint32_t>(ba, WOFF);
+        for (int i = 0; i < WIN; i++) en[l][i] = fbits(run(l, fromb(b[l] + i)));
+      }
+      for (int l = 0; l < W; l++)
+        for (int i = 0; i < WIN; i++) { const uint32_t idx = l + 1 < W ? en[l][i] - b[l + 1] : 0u; H[l].g[i] = idx < (uint32_t)WIN ? (uint8_t)idx : 0xff; }
+      // the scan as the device runs it: row_shr 1, 2, 4, 8 inside rows of 16 lanes, then row_bcast15 (rows 1, 3 <- lane 15 of the row before), row_bcast31 (rows 2, 3 <- lane 31)
+      for (int d = 1; d < 16 && d < W; d <<= 1) { for (int l = 0; l < W; l++) Hn[l] = (l % 16) >= d ? compose(H[l], H[l - d]) : H[l]; H = Hn; }
+      if (W >= 32) { for (int l = 0; l < W; l++) Hn[l] = ((l / 16) & 1) ? compose(H[l], H[(l / 16) * 16 - 1]) : H[l]; H = Hn; }
+      if (W >= 64) { for (int l = 0; l < W; l++) Hn[l] = (l >= 32) ? compose(H[l], H[31]) : H[l]; H = Hn; }
+      const uint32_t i0 = fbits(acc) - b[0];               // (< WIN by construction: lane 0's guess IS the chain's start)
+      int lf = W;
+      for (int l = 0; l < W; l++) {
+        const uint32_t idx = l == 0 ? i0 : H[l - 1].g[i0];
+        val[l] = idx < (uint32_t)WIN ? en[l][idx] : INVALID;
+        if (val[l] == INVALID && lf == W) lf = l;
+      }
+      if (lf == W) { result = fromb(val[W - 1]); done = true; break; }
+      if (lf == 0 || t + 1 >= MAXT) {                      // (lane 0 cannot fail) the rest serially, from the exact start of lane lf
+        float v = lf == 0 ? acc : fromb(val[lf - 1]);
+        for (int i = lf * L; i < nsb; i++) { volatile float tt = v + x[i]; v = tt; }
+        result = v; st.bails++; done = true; t++; break;
+      }
+      const float xf = fromb(val[lf - 1]);                 // the exact start of lane lf
+      const double delta = (double)xf - (double)a[lf];
+      for (int l = 1; l < W; l++) a[l] = l <= lf ? fromb(val[l - 1]) : (float)((double)a[l] + delta);
+    }
+    st.table_rounds += t + (done && t == 0 ? 1 : 0); if (t + 1 > st.max_rounds) st.max_rounds = t + 1;
     acc = result;
     pos += nsb;
   }
@@ -140,9 +140,9 @@ int main(int argc, char **argv) {
           case 2: v = scale * std::exp((U(rng) - 0.5) * 20.0); break;                      // wide range
           case 3: v = (rng() % 4 == 0) ? 0.0 : scale * U(rng); break;                      // zeros in between
           case 4: v = (i < (int)(rng() % 200)) ? 0.0 : scale * U(rng); break;              // leading zeros
-          case 5: v = std::ldexp((double)(1 + rng() % 7), -3 + (int)(rng() % 3)); break;   // few mantissa bits: many ties
+          case 5: v = std::ldexp((double)(1 + rng() % 7), -3 + (int)(rng() % 3)); break;   // few mantissa bits
           case 6: v = scale * 1e-38 * U(rng); break;                                       // subnormal neighbourhood
-          case 7: v = std::exp((U(rng) - 0.5) * 150.0); break;                             // extreme range (inexact f64 prefix)
+          case 7: v = std::exp((U(rng) - 0.5) * 150.0); break;                             // extreme range
           case 8: v = (double)(float)scale; break;                                         // constant
           case 10: { const float f = (float)(scale * (0.2 + U(rng))); const int keep = 12 + (int)(rng() % 5); v = (double)fromb(fbits(f) & ~((1u << (24 - keep)) - 1u)); break; }   // short mantissas: ties on most adds of some binades
           default: v = scale * U(rng); break;
@@ -160,8 +160,8 @@ int main(int argc, char **argv) {
         fails++;
       }
     }
-    std::printf("W %2d: %d cases, super-blocks %ld, rounds %ld (%.2f per super-block, max %d), bails %ld, serial %ld\n", W, cases, st.superblocks, st.rounds,
-                (double)st.rounds / (double)st.superblocks, st.max_rounds, st.bails, st.serial);
+    std::printf("W %2d: %d cases, super-blocks %ld, table rounds %ld (%.2f per super-block, max %d), bails %ld, serial %ld\n", W, cases, st.superblocks, st.table_rounds,
+                (double)st.table_rounds / (double)st.superblocks, st.max_rounds, st.bails, st.serial);
   }
   // the C4 shape: 1 000 similar errors per chain, acc0 = 0
   for (int W : {16, 32, 64}) {
@@ -172,7 +172,7 @@ int main(int argc, char **argv) {
       const float want = chain_seq(e.data(), 1000, 0.f), got = chain_par(e.data(), 1000, 0.f, W, st);
       if (fbits(want) != fbits(got)) fails++;
     }
-    std::printf("C4 shape W %2d: rounds per chain %.2f (max %d), bails %ld\n", W, (double)st.rounds / 2000.0, st.max_rounds, st.bails);
+    std::printf("C4 shape W %2d: table rounds per chain %.2f (max %d), bails %ld\n", W, (double)st.table_rounds / 2000.0, st.max_rounds, st.bails);
   }
   std::printf("ties met by the serial loops: %ld\n", g_ties);
   std::printf("%s (%ld mismatches)\n", fails ? "FAIL" : "PASS", fails);
