@@ -111,8 +111,10 @@ template <int I, int k> __device__ __forceinline__ void esikf_back(const double 
 //   the full system — the form this replaces held the whole k x k matrix redundantly in every lane: ~250 VGPRs, which no kernel that inlines the solve next to
 //   other work could afford (k_visual_update_persistent) — and the results are bit-identical to it.  G[r, :], the Kalman solution entry and the new rotation follow
 //   without further LDS round trips.
+// (stamps: null, or five slots of the 100-MHz clock written by lane 0 — S built, eliminated, back-substituted, G / solution stored, Exp done: tools/vis_persist_probe.py)
+#define ESIKF_STAMP(i) do { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 template <int k, bool MATH_CALLS = false>
-__device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane) {
+__device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane, unsigned long long *stamps = nullptr) {
   if (lane < k * k) {                                        // S = I + H_k P'_kk, row-major stride k
     const int i = lane / k, j = lane % k;
     double v = (i == j) ? 1.0 : 0.0;
@@ -122,14 +124,17 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
   }
   if (lane >= 9 && lane < 25) s.vec[lane - 6] = s.prop[lane] - s.cur[lane];     // pos, inv_expo, vel, bg, ba, grav parts of vec
   wave_sync();
+  ESIKF_STAMP(0);
   const int r = (lane < k) ? 0 : (lane - k < DS ? lane - k : DS - 1);             // right-hand side owned by this lane (lanes < k own a matrix column)
   double col[k];
 #pragma unroll
   for (int i = 0; i < k; i++) col[i] = (lane < k) ? s.aug[lane * k + i] : s.P[r * DS + i];   // column `lane` of A = S^T is row `lane` of S
   double pinv[k];
   esikf_eliminate<0, k>(col, pinv);                          // forward elimination, one pivot column at a time
+  ESIKF_STAMP(1);
   double x[k];                                               // back substitution: x = K_1[r, 0:k] in the lanes that own a right-hand side
   esikf_back<k - 1, k>(col, pinv, x);
+  ESIKF_STAMP(2);
   double kz = 0.0, gv = 0.0;                                 // G[r, 0:k] = K_1[r, 0:k] H_k
   double g[KMAX];
 #pragma unroll
@@ -147,6 +152,7 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
   }
   wave_sync();
+  ESIKF_STAMP(3);
   if (lane == 0) {                                           // state.rot_end * Exp(delta theta)  (common_lib.h:184), ~1 us of sin / cos / sqrt on one lane
     double E[9], Rn[9];
     if (MATH_CALLS) { const So3Mat m = so3_exp_call(s.sol[0], s.sol[1], s.sol[2]); for (int i = 0; i < 9; i++) E[i] = m.v[i]; }
@@ -155,6 +161,7 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     for (int i = 0; i < 9; i++) s.newR[i] = Rn[i];
   }
   wave_sync();
+  ESIKF_STAMP(4);
 }
 
 // Part 3: publish G (zero-padded 19x19 in ctl->G) and apply  state += solution  (common_lib.h:182-192) to ctl->cur, from the LDS copies.

@@ -1162,7 +1162,7 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
     if (lane < 7) s.htz[lane] = SL.u.s.sums[28 + lane];
     wave_sync();
     VPP(8);
-    esikf_solve_wave<7, true>(s, -1, lane);               // speculative: LDS only (s.sol, s.G, s.newR)
+    esikf_solve_wave<7, true>(s, -1, lane, (p.prof && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) ? p.prof + ((size_t)blockIdx.x * 32 + step_global) * 16 + 10 : nullptr);               // speculative: LDS only (s.sol, s.G, s.newR)
     if (lane == 0) {                                      // the convergence test of an accepted step (vio.cpp:1675), formed while the error chain still runs
       const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
       const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);

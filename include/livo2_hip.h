@@ -93,7 +93,7 @@ int livo2_ctx_kernel_timing(livo2_ctx *ctx, int enable);
  *   "visual_persistent_inverse" (default 1, round 6): with cfg->inverse_composition_en the resident grid also runs precomputeReferencePatches + updateStateInverse
  *                        (vio.cpp:1327-1518; 0: that form stays on the launch-per-step sequence — same bits, tests/test_visual_inverse_gpu.py).
  *   "visual_error_waves" (default 1, round 6): the frame error — each OpenMP thread's serial float sum over its block of patch errors (vio.cpp:1554, 1634), whose exact
- *                        bits decide accept / revert — is formed by a group of 32 lanes per thread (fast-livo2_amd/csrc/float_chain.hpp) when the blocks hold >= 768
+ *                        bits decide accept / revert — is formed by a group of 32 lanes per thread (fast-livo2_amd/csrc/float_chain.hpp: start -> end tables on consecutive floats, composed in a scan) when the blocks hold >= 768
  *                        patches and the threads fit five waves; 0: always one lane per thread (a dependent chain of adds).  Same bits either way
  *                        (tests/test_float_chain_gpu.py, tests/test_visual_gpu.py).
  *   "map_update_spread" (default 0, round 6): lanes per touched root voxel in the octree update = 8 x this (1, 2, 4, 8; of which 8 work, or all 64 in the plane re-fit when
