@@ -23,6 +23,7 @@ struct SolveLds {
   double G[DS * KMAX];         // G[:, 0:k],   row stride KMAX
   double hth[49];              // H_k, row stride k
   double htz[8];
+  double hv[8];                 // H_k vec[0:k]: with it the solution row needs 2k FMAs behind the back substitution instead of k x k + 2k (G = K_1 H_k can wait, see DEFER_G)
   double vec[DS + 1];
   double sol[DS + 1];
   double cur[25], prop[25];     // the 25 non-covariance scalars of state_ / state_propagat (rot 9, pos 3, inv_expo, vel, bg, ba, grav)
@@ -111,10 +112,10 @@ template <int I, int k> __device__ __forceinline__ void esikf_back(const double 
 //   the full system — the form this replaces held the whole k x k matrix redundantly in every lane: ~250 VGPRs, which no kernel that inlines the solve next to
 //   other work could afford (k_visual_update_persistent) — and the results are bit-identical to it.  G[r, :], the Kalman solution entry and the new rotation follow
 //   without further LDS round trips.
-// (stamps: null, or five slots of the 100-MHz clock written by lane 0 — S built, eliminated, back-substituted, G / solution stored, Exp done: tools/vis_persist_probe.py)
-#define ESIKF_STAMP(i) do { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-template <int k, bool MATH_CALLS = false>
-__device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane, unsigned long long *stamps = nullptr) {
+// DEFER_G: K_1[:, 0:k] is left in s.Kc and s.G is NOT formed — the caller forms G = K_1 H_k (same FMA order: bit-identical) when and where it needs it (the resident
+// visual grid: a second wave, on accepted steps only).
+template <int k, bool MATH_CALLS = false, bool DEFER_G = false>
+__device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane) {
   if (lane < k * k) {                                        // S = I + H_k P'_kk, row-major stride k
     const int i = lane / k, j = lane % k;
     double v = (i == j) ? 1.0 : 0.0;
@@ -123,36 +124,46 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     s.aug[lane] = v;
   }
   if (lane >= 9 && lane < 25) s.vec[lane - 6] = s.prop[lane] - s.cur[lane];     // pos, inv_expo, vel, bg, ba, grav parts of vec
+  if (lane >= 56 && lane < 56 + k) {                         // hv = H_k vec[0:k] on lanes that idle here (vec[c >= 3] re-formed from the same operands: the same values)
+    const int m = lane - 56;
+    double h = 0.0;
+#pragma unroll
+    for (int c = 0; c < k; c++) h = fma(s.hth[m * k + c], (c < 3) ? s.vec[c] : (s.prop[c + 6] - s.cur[c + 6]), h);
+    s.hv[m] = h;
+  }
   wave_sync();
-  ESIKF_STAMP(0);
   const int r = (lane < k) ? 0 : (lane - k < DS ? lane - k : DS - 1);             // right-hand side owned by this lane (lanes < k own a matrix column)
   double col[k];
 #pragma unroll
   for (int i = 0; i < k; i++) col[i] = (lane < k) ? s.aug[lane * k + i] : s.P[r * DS + i];   // column `lane` of A = S^T is row `lane` of S
   double pinv[k];
   esikf_eliminate<0, k>(col, pinv);                          // forward elimination, one pivot column at a time
-  ESIKF_STAMP(1);
   double x[k];                                               // back substitution: x = K_1[r, 0:k] in the lanes that own a right-hand side
   esikf_back<k - 1, k>(col, pinv, x);
-  ESIKF_STAMP(2);
-  double kz = 0.0, gv = 0.0;                                 // G[r, 0:k] = K_1[r, 0:k] H_k
-  double g[KMAX];
+  double kz = 0.0, gv = 0.0;                                 // solution[r] = +-K_1[r, 0:k] H^T z + vec[r] - G[r, 0:k] vec[0:k], with G vec = K_1 (H_k vec)
 #pragma unroll
-  for (int c = 0; c < k; c++) {
-    double t = 0.0;
+  for (int c = 0; c < k; c++) { kz = fma(x[c], s.htz[c], kz); gv = fma(x[c], s.hv[c], gv); }
+  if (lane >= k && lane < k + DS) s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
+  if (DEFER_G) {
+    if (lane >= k && lane < k + DS) {
 #pragma unroll
-    for (int m = 0; m < k; m++) t = fma(x[m], s.hth[m * k + c], t);
-    g[c] = t;
-    kz = fma(x[c], s.htz[c], kz);
-    gv = fma(t, s.vec[c], gv);
-  }
-  if (lane >= k && lane < k + DS) {
+      for (int c = 0; c < KMAX; c++) s.Kc[r * KMAX + c] = (c < k) ? x[c] : 0.0;
+    }
+  } else {                                                   // G[r, 0:k] = K_1[r, 0:k] H_k
+    double g[KMAX];
 #pragma unroll
-    for (int c = 0; c < KMAX; c++) s.G[r * KMAX + c] = (c < k) ? g[c] : 0.0;
-    s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
+    for (int c = 0; c < k; c++) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < k; m++) t = fma(x[m], s.hth[m * k + c], t);
+      g[c] = t;
+    }
+    if (lane >= k && lane < k + DS) {
+#pragma unroll
+      for (int c = 0; c < KMAX; c++) s.G[r * KMAX + c] = (c < k) ? g[c] : 0.0;
+    }
   }
   wave_sync();
-  ESIKF_STAMP(3);
   if (lane == 0) {                                           // state.rot_end * Exp(delta theta)  (common_lib.h:184), ~1 us of sin / cos / sqrt on one lane
     double E[9], Rn[9];
     if (MATH_CALLS) { const So3Mat m = so3_exp_call(s.sol[0], s.sol[1], s.sol[2]); for (int i = 0; i < 9; i++) E[i] = m.v[i]; }
@@ -161,7 +172,16 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     for (int i = 0; i < 9; i++) s.newR[i] = Rn[i];
   }
   wave_sync();
-  ESIKF_STAMP(4);
+}
+
+// fl(fl(sqrt(q)) * scale) < bound — the reference's convergence tests (voxel_map.cpp:475-478, vio.cpp:1675) — decided from q itself outside a band of 1e-9 around the
+// threshold (the predicate is monotone in q and its flip lies within a few ulps of (bound / scale)^2); inside the band, the expression as the reference writes it.  Two
+// f64 square roots (~0.3 us on one lane) leave the tail of every solve.
+__device__ __forceinline__ bool esikf_norm_below(double q, double scale, double bound) {
+  const double t = bound / scale, t2 = t * t;
+  if (q < t2 * (1.0 - 1e-9)) return true;
+  if (q > t2 * (1.0 + 1e-9)) return false;
+  return sqrt(q) * scale < bound;
 }
 
 // Part 3: publish G (zero-padded 19x19 in ctl->G) and apply  state += solution  (common_lib.h:182-192) to ctl->cur, from the LDS copies.

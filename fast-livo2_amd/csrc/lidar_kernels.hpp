@@ -1011,9 +1011,8 @@ __device__ __forceinline__ void lidar_solve_algebra(DevCtl *__restrict__ ctl, So
   if (lane < DS) ctl->lidar.iter_solution[iter][lane] = s.sol[lane];
 
   // convergence / rematch / covariance update (voxel_map.cpp:475-499)
-  const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
-  const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
-  const bool conv = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+  const double rq = (s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2], tq = (s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5];
+  const bool conv = esikf_norm_below(rq, 57.3, 0.01) && esikf_norm_below(tq, 100.0, 0.015);
   int rematch = hdr_rematch;
   if (conv || ((rematch == 0) && (iter == (max_iter - 2)))) rematch++;
   const bool stop_now = (rematch >= 2 || (iter == max_iter - 1));

@@ -743,9 +743,8 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
       for (int qq = 0; qq < 6; qq++) { const int e = lane + qq * LIVO2_WAVE; if (e < DS * DS) dst[25 + e] = craw[qq]; }
     }
     esikf_commit_wave(ctl, s, lane);
-    const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
-    const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
-    if ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) stop = 1;   // vio.cpp:1675
+    const double rq = (s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2], tq = (s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5];
+    if (esikf_norm_below(rq, (double)57.3f, (double)0.001f) && esikf_norm_below(tq, (double)100.0f, (double)0.001f)) stop = 1;   // vio.cpp:1675
     if (st) {
       if (lane < 49) st->HtH[lane] = s.hth[lane];
       if (lane < 7) st->Htz[lane] = s.htz[lane];
@@ -1162,11 +1161,10 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
     if (lane < 7) s.htz[lane] = SL.u.s.sums[28 + lane];
     wave_sync();
     VPP(8);
-    esikf_solve_wave<7, true>(s, -1, lane, (p.prof && blockIdx.x < VP_MAX_BLOCKS && step_global < 32) ? p.prof + ((size_t)blockIdx.x * 32 + step_global) * 16 + 10 : nullptr);               // speculative: LDS only (s.sol, s.G, s.newR)
+    esikf_solve_wave<7, true, true>(s, -1, lane);         // speculative: LDS only (s.sol, s.Kc, s.newR; G = K_1 H_k is formed in the accept / revert phase, by other waves)
     if (lane == 0) {                                      // the convergence test of an accepted step (vio.cpp:1675), formed while the error chain still runs
-      const double rn = sqrt((s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2]);
-      const double tn = sqrt((s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5]);
-      SL.stop_if_accepted = ((rn * (double)57.3f < (double)0.001f) && (tn * (double)100.0f < (double)0.001f)) ? 1 : 0;
+      const double rq = (s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1]) + s.sol[2] * s.sol[2], tq = (s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4]) + s.sol[5] * s.sol[5];
+      SL.stop_if_accepted = (esikf_norm_below(rq, (double)57.3f, (double)0.001f) && esikf_norm_below(tq, (double)100.0f, (double)0.001f)) ? 1 : 0;
     }
     VPP(9);
   } else if (fcw ? (fc_wave_index(wave, VS_FC_WAVES) >= 0) : (wave == 2)) {      // the frame error in the reference's float accumulation order (as in k_visual_solve)
@@ -1197,9 +1195,9 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
   }
   __syncthreads();
   VPP(5);
-  if (wave < 3) {                                         // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
-    // Three waves take the same decision from the same words (the float error, n_meas, last_error of the step's parity slot) and share what follows it: wave 0 the
-    // iterate and the loop flags — the only part the next residual waits for —, wave 1 the copy of G, wave 2 (block 0) the step record.  (One wave did all of it: 1.0 us
+  if (wave < 5) {                                         // accept / revert (vio.cpp:1636, 1648-1681), on the LDS iterate
+    // Five waves take the same decision from the same words (the float error, n_meas, last_error of the step's parity slot) and share what follows it: wave 0 the
+    // iterate and the loop flags — the only part the next residual waits for —, waves 1, 3, 4 G = K_1 H_k (which the solve left undone), wave 2 (block 0) the step record.  (One wave did all of it: 1.0 us
     // per accepted step against 0.64 for a reverted one.)
     const int n_meas = (int)SL.u.s.sums[36];
     float error = 0.0f;
@@ -1220,9 +1218,15 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
         stop = 1;
       }
       if (lane == 0) { SL.last_error2[(step_global + 1) & 1] = accepted ? error : last_error; if (accepted) SL.last_error = error; SL.stop = stop; SL.n_steps = step + 1; }
-    } else if (wave == 1) {
+    } else if (wave != 2) {                               // waves 1, 3, 4: one element of G each
       if (accepted) {
-        for (int e = lane; e < DS * KMAX; e += LIVO2_WAVE) SL.Gfull[(e / KMAX) * DS + e % KMAX] = s.G[e];
+        for (int e = (wave == 1 ? 0 : wave - 2) * LIVO2_WAVE + lane; e < DS * KMAX; e += 3 * LIVO2_WAVE) {                  // G = K_1 H_k, left undone by the solve (DEFER_G): the FMA order of esikf_solve_wave
+          const int r = e / KMAX, c = e % KMAX;
+          double g = 0.0;
+#pragma unroll
+          for (int m = 0; m < KMAX; m++) g = fma(s.Kc[r * KMAX + m], s.hth[m * KMAX + c], g);
+          SL.Gfull[r * DS + c] = g;
+        }
       }
     } else if (blockIdx.x == 0 && step < LIVO2_MAX_LEVELS * LIVO2_MAX_ITERS) {
       livo2_visual_step *st = &ctl->visual.steps[step];

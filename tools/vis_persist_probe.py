@@ -74,8 +74,7 @@ def main():
         for st in range(res.n_steps):
             t = buf[b, st].astype(np.int64)
             d = [(int(t[k + 1]) - int(t[k])) / 100.0 for k in range(6)]
-            sv = [(int(t[10 + k]) - int(t[8])) / 100.0 for k in range(5)]          # inside esikf_solve_wave, from the assembled H^T H: S built, eliminated, back-substituted, G / solution stored, Exp done
-            print(f"  {b} {st:2d} : {(int(t[0]) - t00) / 100.0:7.2f}  " + "  ".join(f"{x:6.2f}" for x in d) + f"   from sums: chain_end {(int(t[7]) - int(t[4])) / 100.0:5.2f} hth {(int(t[8]) - int(t[4])) / 100.0:5.2f} solve_end {(int(t[9]) - int(t[4])) / 100.0:5.2f}  solve: " + " ".join(f"{x:4.2f}" for x in sv))
+            print(f"  {b} {st:2d} : {(int(t[0]) - t00) / 100.0:7.2f}  " + "  ".join(f"{x:6.2f}" for x in d) + f"   from sums: chain_end {(int(t[7]) - int(t[4])) / 100.0:5.2f} hth {(int(t[8]) - int(t[4])) / 100.0:5.2f} solve_end {(int(t[9]) - int(t[4])) / 100.0:5.2f}")
     # all blocks: when does a block finish its residual / see every word, relative to block 0's step start (which blocks make the others wait?)
     G = int((buf[:, 0, 0] != 0).sum())
     print(f"# {G} blocks; per step: residual-end offsets (us, vs block 0's step start) min / median / p90 / max ; all-words-arrived min / max ; slowest 6 blocks (by residual end)")
