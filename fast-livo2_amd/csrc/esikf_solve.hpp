@@ -114,8 +114,11 @@ template <int I, int k> __device__ __forceinline__ void esikf_back(const double 
 //   without further LDS round trips.
 // DEFER_G: K_1[:, 0:k] is left in s.Kc and s.G is NOT formed — the caller forms G = K_1 H_k (same FMA order: bit-identical) when and where it needs it (the resident
 // visual grid: a second wave, on accepted steps only).
-template <int k, bool MATH_CALLS = false, bool DEFER_G = false>
+// HV: the solution row from hv = H_k vec[0:k] (2k FMAs behind the back substitution) instead of from G — the visual update's forms (its solve is on the step's critical
+// path and the resident grid defers G); the LiDAR solve forms G anyway and keeps the fused loop (with hv it measured 9.10 instead of 8.51 us per launch).
+template <int k, bool MATH_CALLS = false, bool DEFER_G = false, bool HV = DEFER_G>
 __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int lane) {
+  static_assert(HV || !DEFER_G, "a deferred G needs the hv form of the solution");
   if (lane < k * k) {                                        // S = I + H_k P'_kk, row-major stride k
     const int i = lane / k, j = lane % k;
     double v = (i == j) ? 1.0 : 0.0;
@@ -124,7 +127,7 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     s.aug[lane] = v;
   }
   if (lane >= 9 && lane < 25) s.vec[lane - 6] = s.prop[lane] - s.cur[lane];     // pos, inv_expo, vel, bg, ba, grav parts of vec
-  if (lane >= 56 && lane < 56 + k) {                         // hv = H_k vec[0:k] on lanes that idle here (vec[c >= 3] re-formed from the same operands: the same values)
+  if (HV && lane >= 56 && lane < 56 + k) {                   // hv = H_k vec[0:k] on lanes that idle here (vec[c >= 3] re-formed from the same operands: the same values)
     const int m = lane - 56;
     double h = 0.0;
 #pragma unroll
@@ -140,16 +143,19 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
   esikf_eliminate<0, k>(col, pinv);                          // forward elimination, one pivot column at a time
   double x[k];                                               // back substitution: x = K_1[r, 0:k] in the lanes that own a right-hand side
   esikf_back<k - 1, k>(col, pinv, x);
-  double kz = 0.0, gv = 0.0;                                 // solution[r] = +-K_1[r, 0:k] H^T z + vec[r] - G[r, 0:k] vec[0:k], with G vec = K_1 (H_k vec)
+  if (HV) {
+    double kz = 0.0, gv = 0.0;                               // solution[r] = +-K_1[r, 0:k] H^T z + vec[r] - G[r, 0:k] vec[0:k], with G vec = K_1 (H_k vec)
 #pragma unroll
-  for (int c = 0; c < k; c++) { kz = fma(x[c], s.htz[c], kz); gv = fma(x[c], s.hv[c], gv); }
-  if (lane >= k && lane < k + DS) s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
+    for (int c = 0; c < k; c++) { kz = fma(x[c], s.htz[c], kz); gv = fma(x[c], s.hv[c], gv); }
+    if (lane >= k && lane < k + DS) s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
+  }
   if (DEFER_G) {
     if (lane >= k && lane < k + DS) {
 #pragma unroll
       for (int c = 0; c < KMAX; c++) s.Kc[r * KMAX + c] = (c < k) ? x[c] : 0.0;
     }
   } else {                                                   // G[r, 0:k] = K_1[r, 0:k] H_k
+    double kz = 0.0, gv = 0.0;
     double g[KMAX];
 #pragma unroll
     for (int c = 0; c < k; c++) {
@@ -157,10 +163,13 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
 #pragma unroll
       for (int m = 0; m < k; m++) t = fma(x[m], s.hth[m * k + c], t);
       g[c] = t;
+      kz = fma(x[c], s.htz[c], kz);
+      gv = fma(t, s.vec[c], gv);
     }
     if (lane >= k && lane < k + DS) {
 #pragma unroll
       for (int c = 0; c < KMAX; c++) s.G[r * KMAX + c] = (c < k) ? g[c] : 0.0;
+      if (!HV) s.sol[r] = ((sign > 0) ? kz : -kz) + s.vec[r] - gv;
     }
   }
   wave_sync();

@@ -684,7 +684,7 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
     }
     if (lane < 7) s.htz[lane] = sums[28 + lane];
     wave_sync();
-    if (mode != 0) esikf_solve_wave<7>(s, -1, lane);
+    if (mode != 0) esikf_solve_wave<7, false, false, true>(s, -1, lane);      // (the solution in the hv form, as the resident grid forms it: same bits)
   } else if (fcw ? (fc_wave_index(wave, VS_FC_WAVES) >= 0) : (wave == 2)) {      // frame error, part 2: OpenMP thread c's static block of patches, added in index order
     if (fcw) {                                                 // a chain per FC_W lanes (float_chain.hpp)
       const int c = fc_wave_index(wave, VS_FC_WAVES) * FC_CPW + lane / FC_W;
