@@ -173,12 +173,16 @@ __device__ inline void esikf_solve_wave(SolveLds &s, const int sign, const int l
     }
   }
   wave_sync();
-  if (lane == 0) {                                           // state.rot_end * Exp(delta theta)  (common_lib.h:184), ~1 us of sin / cos / sqrt on one lane
-    double E[9], Rn[9];
-    if (MATH_CALLS) { const So3Mat m = so3_exp_call(s.sol[0], s.sol[1], s.sol[2]); for (int i = 0; i < 9; i++) E[i] = m.v[i]; }
-    else so3_exp(s.sol[0], s.sol[1], s.sol[2], E);
-    mat3_mul(s.cur, E, Rn);
-    for (int i = 0; i < 9; i++) s.newR[i] = Rn[i];
+  {                                                          // state.rot_end * Exp(delta theta)  (common_lib.h:184): lane e < 9 forms element (e / 3, e % 3) of the product —
+    // the operations of so3_exp and mat3_mul for that element, in their order (same bits as one lane forming K, K K, R and the product: 0.7-1.1 us there)
+    const int e9 = lane < 9 ? lane : 0, i = e9 / 3, j = e9 - 3 * i;
+    const double v1 = s.sol[0], v2 = s.sol[1], v3 = s.sol[2];
+    const double c0 = s.cur[i * 3], c1 = s.cur[i * 3 + 1], c2 = s.cur[i * 3 + 2];
+    double E[3];
+    if (MATH_CALLS) { const So3Vec m = so3_exp_col_call(v1, v2, v3, j); E[0] = m.v[0]; E[1] = m.v[1]; E[2] = m.v[2]; }
+    else so3_exp_col(v1, v2, v3, j, E);
+    const double rn = (c0 * E[0] + c1 * E[1]) + c2 * E[2];
+    if (lane < 9) s.newR[lane] = rn;
   }
   wave_sync();
 }

@@ -216,6 +216,25 @@ __device__ inline void so3_exp(double v1, double v2, double v3, double *R) {
     for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
   }
 }
+// column j of so3_exp(v1, v2, v3): the operations of so3_exp for the three elements of that column, in their order (the same bits) — for callers that spread the
+// nine elements of a product with Exp over nine lanes instead of forming K, K^2 and R on one
+__device__ inline void so3_exp_col(double v1, double v2, double v3, int j, double *E) {
+  const double nrm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+  if (nrm > 0.00001) {
+    const double r0 = v1 / nrm, r1 = v2 / nrm, r2 = v3 / nrm;
+    // K = {0, -r2, r1, r2, 0, -r0, -r1, r0, 0}: its column j, and (K K)[k][j] = (K[k][0] K[0][j] + K[k][1] K[1][j]) + K[k][2] K[2][j] as mat3_mul forms it
+    const double k0 = j == 0 ? 0.0 : (j == 1 ? -r2 : r1), k1 = j == 0 ? r2 : (j == 1 ? 0.0 : -r0), k2 = j == 0 ? -r1 : (j == 1 ? r0 : 0.0);
+    const double kk0 = (0.0 * k0 + (-r2) * k1) + r1 * k2, kk1 = (r2 * k0 + 0.0 * k1) + (-r0) * k2, kk2 = ((-r1) * k0 + r0 * k1) + 0.0 * k2;
+    double s, c;
+    sincos(nrm, &s, &c);
+    const double c1 = 1.0 - c;
+    E[0] = ((j == 0) ? 1.0 : 0.0) + s * k0 + c1 * kk0;
+    E[1] = ((j == 1) ? 1.0 : 0.0) + s * k1 + c1 * kk1;
+    E[2] = ((j == 2) ? 1.0 : 0.0) + s * k2 + c1 * kk2;
+  } else {
+    E[0] = (j == 0) ? 1.0 : 0.0; E[1] = (j == 1) ? 1.0 : 0.0; E[2] = (j == 2) ? 1.0 : 0.0;
+  }
+}
 __device__ inline void so3_log(const double *R, double *o) {
   double tr = (R[0] + R[4]) + R[8];
   double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
@@ -229,6 +248,7 @@ __device__ inline void so3_log(const double *R, double *o) {
 struct So3Mat { double v[9]; };
 struct So3Vec { double v[3]; };
 __device__ __attribute__((noinline)) So3Mat so3_exp_call(double v1, double v2, double v3) { So3Mat m; so3_exp(v1, v2, v3, m.v); return m; }
+__device__ __attribute__((noinline)) So3Vec so3_exp_col_call(double v1, double v2, double v3, int j) { So3Vec o; so3_exp_col(v1, v2, v3, j, o.v); return o; }
 __device__ __attribute__((noinline)) So3Vec so3_log_call(So3Mat R) { So3Vec o; so3_log(R.v, o.v); return o; }
 
 // LDS hand-off inside ONE wave: orders this wave's LDS writes before its later LDS reads without a workgroup barrier (s_barrier counts every wave of the
