@@ -428,6 +428,7 @@ def compact_line(full):
     line["roofline"] = roof
     line["cpu_baseline"] = None if cpu is None else {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample", "host_cores", "lidar_update_ms", "visual_update_ms")}
     line["pre_warm_s"] = full.get("pre_warm_s")
+    line["timed_regions_discarded"] = full.get("timed_regions_discarded", 0)     # regions in which a resident visual grid met its watchdog are timed again (0 normally)
     line["full_report"] = full.get("full_report")
     out = json.dumps(strict_json(line), allow_nan=False, separators=(",", ":"))
     if len(out) >= HEADLINE_MAX_BYTES:                       # never let a long note take the line down: drop the optional parts first
@@ -607,14 +608,31 @@ def main():
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.pre_warm_s:
         w.run(4); ctx.synchronize()
-    w.run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    w.run(args.steps)
-    ctx.synchronize(); torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed_local = time.perf_counter() - t0
+    # A resident visual grid that meets its watchdog (a block kept off the device for 20 ms) gives up, and every later launch of the context gives up at its first
+    # instruction until a fetch has re-run the update per step: a timed region that contains such a launch measures launches of nothing.  The region is therefore
+    # bracketed by the library's counters, and a region in which a grid timed out (or fell back, or was skipped by the back-off) is discarded and timed again.
+    retimed = 0
+    while True:
+        w.run(args.warmup)
+        barrier()
+        guard0 = [ctx.counter(k) for k in ("visual_persistent_timeouts", "visual_persistent_fallbacks", "visual_persistent_backoff_skips", "visual_persistent_launches")]
+        t0 = time.perf_counter()
+        w.run(args.steps)
+        ctx.synchronize(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed_local = time.perf_counter() - t0
+        ctx.visual_update_fetch()                              # (the last update's result block carries the watchdog flag: a timed-out grid is counted — and re-run — here)
+        guard1 = [ctx.counter(k) for k in ("visual_persistent_timeouts", "visual_persistent_fallbacks", "visual_persistent_backoff_skips", "visual_persistent_launches")]
+        clean = guard1[:3] == guard0[:3] and guard1[3] - guard0[3] == w.F * args.steps
+        if clean or retimed >= 3:
+            break
+        retimed += 1
+        print(f"bench.py: the timed region met a resident-grid time-out / fallback (counters {guard0} -> {guard1}): discarded, timing again ({retimed})", file=sys.stderr, flush=True)
+        for f in range(48):                                    # past the back-off (8 updates on the per-step sequence after a time-out, doubling while they repeat)
+            ctx.visual_update(w.vis[f % w.F], w.vis[f % w.F], w.vcfg)
+    if not clean:
+        raise RuntimeError("bench.py: every timed region met a resident-grid time-out: no valid measurement")
     elapsed, evals_all, frames_all, per_rank = reduce_line(frames, dist, device, elapsed_local, w.evals_per_step * args.steps, w.F * args.steps)
     value = evals_all / elapsed
 
@@ -719,7 +737,7 @@ def main():
                                    f"{w.N} post-filter LiDAR points + {w.M} patches (8x8); 1 step = {w.F} frame updates from distinct priors",
                        "points_per_frame": w.N, "patches_per_frame": w.M, "frames_per_step": w.F, "plane_records": int(sc.fmap.n_planes), "voxels": int(len(sc.fmap.root_node)),
                        "evals_per_step": w.evals_per_step, "parallelism": f"frames x{world} (one process per GPU, no collective on the data path)"},
-            "roofline": roofline, "cpu_baseline": cpu, "pre_warm_s": args.pre_warm_s, "extra": extra,
+            "roofline": roofline, "cpu_baseline": cpu, "pre_warm_s": args.pre_warm_s, "timed_regions_discarded": retimed, "extra": extra,
         }
         emit(line)
     ctx.close()
