@@ -625,6 +625,8 @@ def main():
         ctx.visual_update_fetch()                              # (the last update's result block carries the watchdog flag: a timed-out grid is counted — and re-run — here)
         guard1 = [ctx.counter(k) for k in ("visual_persistent_timeouts", "visual_persistent_fallbacks", "visual_persistent_backoff_skips", "visual_persistent_launches")]
         clean = guard1[:3] == guard0[:3] and guard1[3] - guard0[3] == w.F * args.steps
+        if dist is not None:                                   # every rank times the same number of regions
+            flag = torch.tensor([1 if clean else 0], dtype=torch.int32, device=device); dist.all_reduce(flag, op=dist.ReduceOp.MIN); clean = bool(int(flag.item()))
         if clean or retimed >= 3:
             break
         retimed += 1
