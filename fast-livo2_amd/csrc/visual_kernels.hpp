@@ -604,6 +604,8 @@ __device__ __forceinline__ int fc_wave_index(int wave, int nwaves) {
   return idx < nwaves ? idx : -1;
 }
 __device__ __forceinline__ int fc_threads(int error_threads) { const int t = error_threads < 0 ? -error_threads : error_threads; return t < 1 ? 1 : (t > LIVO2_WAVE ? LIVO2_WAVE : t); }
+// a single OpenMP thread (updateStateInverse has no parallel loop; MP_PROC_NUM = 1): its one chain gets all 64 lanes of the first chain wave and twice the elements per pass
+template <typename E> __device__ __forceinline__ float fc_one_chain(const E *errs, int n, int lane) { return float_chain_wave<64, FC_LMAX>(errs, 0, n, 0.0f, lane); }
 __device__ __forceinline__ bool fc_use_waves(int M, int T, int nwaves) { return T <= nwaves * FC_CPW && M / T >= FC_MIN_N; }
 // OpenMP static partition of M patches over T threads (libgomp: the first M % T threads get one patch more)
 __device__ __forceinline__ void fc_partition(int M, int T, int c, int &b, int &e) {
@@ -689,7 +691,7 @@ __device__ __forceinline__ void visual_solve_body(VisSolveLds &SL, DevCtl *__res
     if (fcw) {                                                 // a chain per FC_W lanes (float_chain.hpp)
       const int c = fc_wave_index(wave, VS_FC_WAVES) * FC_CPW + lane / FC_W;
       int my_begin, my_end; fc_partition(va.M, T, c, my_begin, my_end);
-      float priv = float_chain_wave<FC_W, FC_LMAX>(errs, min(my_begin, n_stage), min(my_end, n_stage), 0.0f, lane);
+      float priv = T == 1 ? (fc_wave_index(wave, VS_FC_WAVES) == 0 ? fc_one_chain(errs, n_stage, lane) : 0.0f) : float_chain_wave<FC_W, FC_LMAX>(errs, min(my_begin, n_stage), min(my_end, n_stage), 0.0f, lane);
       if ((lane & (FC_W - 1)) == 0 && c < T) {
         for (int i = max(my_begin, n_stage); i < my_end; i++) priv += xb_load<XB>(&va.errors[i]);
         err_chunk[c] = priv;
@@ -1175,7 +1177,7 @@ __device__ VP_PHASE_ATTR void vp_phase_solve(VpLds slp, DevCtl *ctl, int level_v
     if (fcw) {                                            // a chain per FC_W lanes (float_chain.hpp)
       c = fc_wave_index(wave, VS_FC_WAVES) * FC_CPW + lane / FC_W;
       fc_partition(M, T, c, my_begin, my_end);
-      priv = float_chain_wave<FC_W, FC_LMAX>(SL.u.s.errs, min(my_begin, n_stage), min(my_end, n_stage), 0.0f, lane);
+      priv = T == 1 ? (fc_wave_index(wave, VS_FC_WAVES) == 0 ? fc_one_chain(SL.u.s.errs, n_stage, lane) : 0.0f) : float_chain_wave<FC_W, FC_LMAX>(SL.u.s.errs, min(my_begin, n_stage), min(my_end, n_stage), 0.0f, lane);
       owner = (lane & (FC_W - 1)) == 0 && c < T;
     } else {                                              // a chain per lane
       c = lane;
