@@ -299,11 +299,11 @@ def test_a_resident_grid_that_loses_a_block_is_rerun_per_step_with_the_same_resu
     assert bytes(res.state) == bytes(ref.state) and ctx.counter("visual_persistent_timeouts") == t0 + 3
 
 
-@pytest.mark.parametrize("M,threads", [(4000, 4), (2000, 1), (9000, 4), (6001, 6), (8000, 10)])
+@pytest.mark.parametrize("M,threads", [(4000, 4), (2000, 1), (9000, 4), (9000, 1), (6001, 6), (8000, 10)])
 def test_frame_error_on_groups_of_lanes_gives_the_bits_of_the_one_lane_chains(livo2, ctx, M, threads):
     """round 6: the frame error's float chains (vio.cpp:1554, 1634) run on groups of 32 lanes (float_chain.hpp) when every OpenMP thread's block holds >= 768 patch
     errors (>= 768 since the break-even was measured); option "visual_error_waves" = 0 keeps one lane per thread.  Same records, same errors[], on the resident grid and on the launch-per-step sequence
-    (M = 9000: the blocks reach beyond the staging area; 7 threads: four chain waves; 10 threads: five)."""
+    (M = 9000: the blocks reach beyond the staging area; one thread: its chain on all 64 lanes of one wave, several passes; 6 threads: three chain waves; 10 threads: five)."""
     vs = synth.visual_scenario(seed=400 + threads, n_patches=M)
     cfg = H.visual_cfg_product(vs, mp_proc_num=threads)
     cur, prop = H.states(vs, livo2.State)
